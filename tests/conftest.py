@@ -1,0 +1,30 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+LIST_CASES = ["survey", "clustered_s2_b16_d64", "clustered_s4_b8_d48",
+              "clustered_s2_b32_d128", "clustered_s2_b40_d72"]
+
+
+@pytest.fixture(params=LIST_CASES)
+def list_case(request):
+    g = load_golden(request.param)
+    g["name"] = request.param
+    return g
