@@ -1,0 +1,133 @@
+/*
+ * otgan.h -- C ABI of the MI355X-native OT-GAN hot path (libotgan_hip.so).
+ *
+ * The reference (openai/ot-gan) has no FFI: its "operator API" is Python call sites on stock
+ * TensorFlow ops.  Each entry point below replaces one group of those call sites; the
+ * reference file:line it stands in for is cited per function.  The Python host layer
+ * (ot-gan_amd/) mirrors the reference's own names (utils/matching.py, utils/nn.py,
+ * models/, train.py) on top of this ABI.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - every function returns 0 on success or a negative OTGAN_ERR_* code; the text of the
+ *     last error on the calling thread is available from otgan_last_error().
+ *   - all buffers are caller-owned DEVICE pointers (fp32 unless stated), row-major,
+ *     with explicit leading dimensions in elements.
+ *   - `stream` is a hipStream_t passed as void*; all work is asynchronous on it.
+ *   - no internal allocation: scratch comes from a caller-provided workspace sized by the
+ *     matching *_workspace_bytes() query.  Distinct workspaces/streams may be used from
+ *     distinct threads concurrently.
+ *   - scalar results (entropy, distance) are written to DEVICE memory so that the caller
+ *     decides when to synchronise.
+ */
+#ifndef OTGAN_H
+#define OTGAN_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OTGAN_ABI_VERSION 1
+
+/* error codes */
+#define OTGAN_OK 0
+#define OTGAN_ERR_INVALID (-1)
+#define OTGAN_ERR_WORKSPACE (-2)
+#define OTGAN_ERR_LAUNCH (-3)
+#define OTGAN_ERR_UNSUPPORTED (-4)
+
+int otgan_version(void);
+const char* otgan_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Per-kernel-class HIP-event timing (measurement support for bench.py's roofline leg).
+ * Classes: 0 conv_fwd, 1 conv_dgrad, 2 conv_wgrad, 3 cost_gemm, 4 sinkhorn, 5 plan_apply,
+ * 6 pointwise.  While enabled every launch of a class is bracketed by hipEvents on its
+ * launch stream; otgan_prof_collect() synchronises and returns the totals since the last
+ * reset: out[0]=launches, out[1]=sum of milliseconds, out[2]=sum of algorithmic FLOP,
+ * out[3]=sum of algorithmic bytes.
+ * ------------------------------------------------------------------------------------- */
+int otgan_prof_enable(int on);
+int otgan_prof_reset(void);
+int otgan_prof_collect(int cls, double* out4);
+
+/* ---------------------------------------------------------------------------------------
+ * Matching operator (mini-batch Sinkhorn energy distance).
+ * Replaces reference utils/matching.py:11-85 (two-batch), :88-136 (single-batch) and the
+ * toy variant toy_example/matching_cpu.py:4-95.
+ * ------------------------------------------------------------------------------------- */
+#define OTGAN_COST_COSINE 0        /* C = 1 - x.y            (utils/matching.py:31)              */
+#define OTGAN_COST_SQEUCLID_MEAN 1 /* C = |x-y|^2 / (2 D)    (toy_example/matching_cpu.py:17-21) */
+
+#define OTGAN_MATCH_TWO_BATCH 0
+#define OTGAN_MATCH_SINGLE_BATCH 1
+
+/* Scratch bytes needed by otgan_matching_*_f32 for a problem of `rows` rows per side
+ * (two-batch: rows = N = half the samples of each kind; single-batch: rows = all samples). */
+size_t otgan_matching_workspace_bytes(int mode, int rows, int D);
+
+/*
+ * Two-batch matching.  fa, fb: [2N, D] (rows [0,N) = mini-batch 1, [N,2N) = mini-batch 2;
+ * `a` = generated, `b` = data), leading dimension ldf.  Outputs f_aa, f_bb, f_ab, f_ba:
+ * [2N, D] with leading dimension ldo.  entropy: 1 float (mean of the six mean row
+ * entropies, matching.py:57,61).  dist: 1 double = calc_distance (matching.py:139-153; for
+ * OTGAN_COST_SQEUCLID_MEAN the toy normalisation matching_cpu.py:155-164), evaluated with
+ * fp64 accumulation.  stats (nullable): [6][4] doubles per problem in the reference order
+ * (a1a2, b2b1, a1b1, a1b2, a2b1, a2b2): {sum of row entropies, <M,C>, sum(M), 0}.
+ * Exactly `iters` row->column sweeps are run, then a row softmax (no early exit).
+ */
+int otgan_matching_two_batch_f32(const float* fa, const float* fb, int N, int D, long ldf,
+                                 float sinkhorn_lambda, int iters, int cost_kind,
+                                 float* f_aa, float* f_bb, float* f_ab, float* f_ba, long ldo,
+                                 float* entropy, double* dist, double* stats,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Single-batch matching (matching.py:88-136): fa, fb [n, D]; 999 is added to the a-a and
+ * b-b cost diagonals.  stats: [3][4] doubles (aa, bb, ab).
+ */
+int otgan_matching_single_batch_f32(const float* fa, const float* fb, int n, int D, long ldf,
+                                    float sinkhorn_lambda, int iters,
+                                    float* f_aa, float* f_bb, float* f_ab, float* f_ba, long ldo,
+                                    float* entropy, double* dist, double* stats,
+                                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Staged entry points (same kernels, exposed for parity tests and custom pipelines). */
+
+/* K[n,m] = -lambda * (cost(X[n,D], Y[m,D]) + diag_add * I)     (matching.py:31,50,109) */
+size_t otgan_cost_matrix_workspace_bytes(int n, int m, int D);
+int otgan_cost_matrix_f32(const float* X, const float* Y, int n, int m, int D, long ldf,
+                          float sinkhorn_lambda, int cost_kind, float diag_add, float* K,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* P log-kernels K[P][n][m] -> plans M[P][n][m], transposed plans MT[P][m][n] and stats[P][4]
+ * (matching.py:52-57).  lambda is only used to report <M,C> with C = -K/lambda. */
+size_t otgan_sinkhorn_workspace_bytes(int P, int n, int m);
+int otgan_sinkhorn_plan_f32(const float* K, int P, int n, int m, int iters,
+                            float sinkhorn_lambda, float* plan, float* planT, double* stats,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[rows, D] = alpha * plan[rows, kdim] . feat[kdim, D]       (matching.py:64-75) */
+int otgan_plan_apply_f32(const float* plan, long ldp, int rows, int kdim, const float* feat,
+                         long ldf, int D, float alpha, float* out, long ldo, void* stream);
+
+/* dist = (sum(b*bb) + sum(a*aa) - 2 sum(a*ab)) / denom over contiguous [rows, D] arrays,
+ * fp64 accumulation (matching.py:147-152).  scratch3: 3 doubles of device scratch. */
+int otgan_calc_distance_f32(const float* a, const float* b, const float* aa, const float* bb,
+                            const float* ab, long rows, int D, double denom, double* dist,
+                            double* scratch3, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Layer kernels (generator / critic blocks).  Activations NHWC, weights HWIO.
+ * Replace reference utils/nn.py:103-183 (weight norm), :190-206 (pre-activation),
+ * :234-241 (conv), :208-209 (dense), models/dcgan.py:16-19,35-36 (feature head, GLU).
+ * Declared in otgan_layers.h (included below) to keep this header readable.
+ * ------------------------------------------------------------------------------------- */
+#include "otgan_layers.h"
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OTGAN_H */

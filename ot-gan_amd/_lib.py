@@ -1,0 +1,113 @@
+"""ctypes binding of csrc/libotgan_hip.so (the C ABI declared in include/otgan.h)."""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libotgan_hip.so")
+_lock = threading.Lock()
+_lib = None
+
+c_fp = ctypes.c_void_p   # device pointers travel as integers (tensor.data_ptr())
+c_int, c_long, c_float, c_double, c_size_t = (ctypes.c_int, ctypes.c_long, ctypes.c_float,
+                                               ctypes.c_double, ctypes.c_size_t)
+
+# name -> (restype, argtypes); every symbol include/otgan.h declares
+SIGNATURES = {
+    "otgan_version": (c_int, []),
+    "otgan_last_error": (ctypes.c_char_p, []),
+    "otgan_prof_enable": (c_int, [c_int]),
+    "otgan_prof_reset": (c_int, []),
+    "otgan_prof_collect": (c_int, [c_int, ctypes.POINTER(c_double)]),
+    "otgan_matching_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "otgan_matching_two_batch_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_long, c_float, c_int, c_int,
+                                             c_fp, c_fp, c_fp, c_fp, c_long, c_fp, c_fp, c_fp,
+                                             c_fp, c_size_t, c_fp]),
+    "otgan_matching_single_batch_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_long, c_float, c_int,
+                                                c_fp, c_fp, c_fp, c_fp, c_long, c_fp, c_fp, c_fp,
+                                                c_fp, c_size_t, c_fp]),
+    "otgan_cost_matrix_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "otgan_cost_matrix_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_long, c_float, c_int,
+                                      c_float, c_fp, c_fp, c_size_t, c_fp]),
+    "otgan_sinkhorn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "otgan_sinkhorn_plan_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_float, c_fp, c_fp, c_fp,
+                                        c_fp, c_size_t, c_fp]),
+    "otgan_plan_apply_f32": (c_int, [c_fp, c_long, c_int, c_int, c_fp, c_long, c_int, c_float,
+                                     c_fp, c_long, c_fp]),
+    "otgan_calc_distance_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_long, c_int, c_double,
+                                        c_fp, c_fp, c_fp]),
+}
+
+
+def _register_layers(sig):
+    try:
+        from ._lib_layers import SIGNATURES as L
+        sig.update(L)
+    except ImportError:
+        pass
+
+
+_register_layers(SIGNATURES)
+
+
+class OtganError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library once.  Fails loudly -- there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise OtganError(
+                    f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                    f"g.build()'` (or `make -C ot-gan_amd/csrc`). There is no CPU fallback.")
+            import torch  # noqa: F401  -- load torch's HIP runtime first so both share one libamdhip64
+            L = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(L, name)  # AttributeError here == ABI/header drift: fail loudly
+                fn.restype = res
+                fn.argtypes = args
+            _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().otgan_last_error().decode("utf-8", "replace")
+        raise OtganError(f"{what} failed with code {rc}: {msg}")
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+# ---- profiler helpers -------------------------------------------------------------------
+PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "cost_gemm", "sinkhorn", "plan_apply",
+                "pointwise")
+
+
+def prof_enable(on=True):
+    check(lib().otgan_prof_enable(1 if on else 0), "otgan_prof_enable")
+
+
+def prof_reset():
+    check(lib().otgan_prof_reset(), "otgan_prof_reset")
+
+
+def prof_collect():
+    out = {}
+    buf = (c_double * 4)()
+    for i, name in enumerate(PROF_CLASSES):
+        check(lib().otgan_prof_collect(i, buf), "otgan_prof_collect")
+        out[name] = {"launches": int(buf[0]), "ms": buf[1], "flop": buf[2], "bytes": buf[3]}
+    return out

@@ -1,0 +1,88 @@
+// common.h -- shared device/host helpers for the OT-GAN gfx950 kernels.
+// gfx950 (MI355X / CDNA4) only: wave = 64 lanes, fp32-input MFMA, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define OTGAN_OK 0
+#define OTGAN_ERR_INVALID (-1)
+#define OTGAN_ERR_WORKSPACE (-2)
+#define OTGAN_ERR_LAUNCH (-3)
+#define OTGAN_ERR_UNSUPPORTED (-4)
+
+// Thread-local last-error text (returned by otgan_last_error()).
+void otgan_set_error(const char* fmt, ...);
+
+#define OTGAN_CHECK_ARG(cond, ...)            \
+  do {                                        \
+    if (!(cond)) {                            \
+      otgan_set_error(__VA_ARGS__);           \
+      return OTGAN_ERR_INVALID;               \
+    }                                         \
+  } while (0)
+
+#define OTGAN_CHECK_LAUNCH(what)                                              \
+  do {                                                                        \
+    hipError_t e__ = hipGetLastError();                                       \
+    if (e__ != hipSuccess) {                                                  \
+      otgan_set_error("%s: launch failed: %s", what, hipGetErrorString(e__)); \
+      return OTGAN_ERR_LAUNCH;                                                \
+    }                                                                         \
+  } while (0)
+
+// ---- optional per-kernel-class HIP-event timing (used by bench.py's roofline leg) -----------
+// Classes are small integers; each timed launch records a start/stop event pair on the
+// launch stream.  Disabled (zero overhead beyond one branch) unless otgan_prof_enable(1).
+enum OtganProfClass {
+  OTGAN_PROF_CONV_FWD = 0,
+  OTGAN_PROF_CONV_DGRAD = 1,
+  OTGAN_PROF_CONV_WGRAD = 2,
+  OTGAN_PROF_COST_GEMM = 3,
+  OTGAN_PROF_SINKHORN = 4,
+  OTGAN_PROF_PLAN_APPLY = 5,
+  OTGAN_PROF_POINTWISE = 6,
+  OTGAN_PROF_NCLASS = 7
+};
+void otgan_prof_begin(int cls, double flops, double bytes, hipStream_t s);
+void otgan_prof_end(int cls, hipStream_t s);
+
+struct ProfScope {
+  int cls;
+  hipStream_t s;
+  ProfScope(int c, double flops, double bytes, hipStream_t st) : cls(c), s(st) {
+    otgan_prof_begin(c, flops, bytes, st);
+  }
+  ~ProfScope() { otgan_prof_end(cls, s); }
+};
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline long ceil_div_l(long a, long b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+#ifdef __HIPCC__
+// ---- wave (64 lanes) reductions ---------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// exp(x) for x <= 0 (max-shifted) through the native 2^x unit.
+__device__ __forceinline__ float exp_neg(float x) {
+  return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+}
+#endif

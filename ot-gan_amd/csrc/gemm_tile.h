@@ -1,0 +1,240 @@
+// gemm_tile.h -- the fp32 MFMA block-GEMM engine shared by every contraction on the
+// OT-GAN hot path (cost Gram blocks, plan application, implicit-GEMM conv fwd/dgrad/wgrad).
+//
+// Design (gfx950 / CDNA4, wave64):
+//   * v_mfma_f32_32x32x2_f32: exact-fp32 matrix FMA (k-ordered fmaf chain), 64 FLOP/clk/SIMD,
+//     157.3 TFLOP/s chip peak.  One instruction = 64 cycles on a SIMD, so a wave needs only
+//     ONE dword of A and ONE dword of B per MFMA per lane; with a MTxNT register tile the LDS
+//     read rate is (MT+NT)/(MT*NT) dwords per MFMA -- far below the LDS limit.  The engine is
+//     therefore built for simplicity of the operand path, not for LDS bandwidth:
+//       - operand tiles live in LDS as [BK][rows + pad] (row index contiguous),
+//       - fragments are read with conflict-free ds_read_b32 (lane = row),
+//       - global->LDS staging goes through registers so loaders can apply on-the-fly
+//         transforms (CReLU / sign / zero padding / gathers) before the data reaches LDS,
+//       - double-buffered LDS, one barrier per BK step; the loads for step k+1 are issued
+//         before the MFMAs of step k and written to LDS after them (latency hidden under
+//         BK/2 * MT*NT * 64 cycles of matrix work).
+//   * MFMA fragment maps (32x32x2 f32):  A: lane l holds A[i=l&31][k=l>>5];
+//     B: lane l holds B[k=l>>5][j=l&31];  D reg r of lane l is
+//     D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31].
+//
+// A "loader" is a struct with:  static constexpr int LD, FLOATS;  void load(int kt);
+// void store(float* lds_tile) const;   load() pulls tile kt into registers, store() writes
+// it to an LDS tile laid out [BK][LD].
+#pragma once
+#include "common.h"
+
+template <int WM_, int WN_, int MT_, int NT_, int BK_>
+struct GemmCfg {
+  static constexpr int WM = WM_, WN = WN_, MT = MT_, NT = NT_, BK = BK_;
+  static constexpr int THREADS = 64 * WM * WN;
+  static constexpr int BM = WM * MT * 32;
+  static constexpr int BN = WN * NT * 32;
+};
+
+// LDS row padding: chosen so that the scattered ds_write_b32 of a k-contiguous loader
+// (lanes = {k-chunk, row}) hit distinct banks.  BK=32: 8 chunks -> pad 1; BK=16: 4 chunks -> pad 2.
+template <int BK>
+struct KPad {
+  static constexpr int value = (BK == 32) ? 1 : 2;
+};
+
+template <class Cfg, class LA, class LB>
+__device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int nkt, float* smem,
+                                              f32x16 (&acc)[Cfg::MT][Cfg::NT]) {
+  constexpr int BK = Cfg::BK, MT = Cfg::MT, NT = Cfg::NT;
+  float* sA = smem;
+  float* sB = smem + 2 * LA::FLOATS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int a_off = lh * LA::LD + wm * MT * 32 + li;
+  const int b_off = lh * LB::LD + wn * NT * 32 + li;
+  if (nkt <= 0) return;
+  la.load(0);
+  lb.load(0);
+  la.store(sA);
+  lb.store(sB);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    const bool more = (kt + 1 < nkt);
+    if (more) {
+      la.load(kt + 1);
+      lb.load(kt + 1);
+    }
+    const float* pa = sA + cur * LA::FLOATS + a_off;
+    const float* pb = sB + cur * LB::FLOATS + b_off;
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      float a[MT], b[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = pa[(2 * ks) * LA::LD + mt * 32];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = pb[(2 * ks) * LB::LD + nt * 32];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+    }
+    if (more) {
+      la.store(sA + (cur ^ 1) * LA::FLOATS);
+      lb.store(sB + (cur ^ 1) * LB::FLOATS);
+    }
+    __syncthreads();
+  }
+}
+
+template <class Cfg>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[Cfg::MT][Cfg::NT]) {
+#pragma unroll
+  for (int mt = 0; mt < Cfg::MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < Cfg::NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+}
+
+// Visit every accumulator element: f(row_in_block, col_in_block, mt, nt, r, value).
+// For a fixed (mt, nt, r) the 32 lanes of a half-wave cover 32 consecutive columns of one
+// row, so a store of `value` to out[row*ld + col] is a coalesced 128-byte segment.
+template <class Cfg, class F>
+__device__ __forceinline__ void foreach_acc(const f32x16 (&acc)[Cfg::MT][Cfg::NT], F&& f) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < Cfg::MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < Cfg::NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * Cfg::MT * 32 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int col = wn * Cfg::NT * 32 + nt * 32 + li;
+        f(row, col, mt, nt, r, acc[mt][nt][r]);
+      }
+}
+
+// ---------------------------------------------------------------------------------------
+// Plain-matrix loaders.
+// ---------------------------------------------------------------------------------------
+
+// Operand whose rows are K-contiguous in memory: element (r, k) at base[r*ld + k].
+// Each thread fetches float4s along k (coalesced 16*BK/4 bytes per row) and scatters them
+// into the [BK][LD] LDS tile.  VEC=false is the scalar fallback for unaligned / ragged K.
+template <class Cfg, int BR, bool VEC>
+struct MatLoaderK {
+  static constexpr int BK = Cfg::BK;
+  static constexpr int LD = BR + KPad<BK>::value;
+  static constexpr int FLOATS = BK * LD;
+  static constexpr int CPR = BK / 4;                // float4 chunks per row
+  static constexpr int RPP = Cfg::THREADS / CPR;    // rows per pass
+  static constexpr int PASSES = (BR + RPP - 1) / RPP;
+  const float* base;  // already offset to (row0, k0)
+  long ld;
+  int rows;  // valid rows (relative to row0)
+  int kdim;  // valid k (relative to k0)
+  float scale;
+  float4 reg[PASSES];
+
+  __device__ __forceinline__ void init(const float* b, long ld_, int rows_, int kdim_, float s = 1.f) {
+    base = b; ld = ld_; rows = rows_; kdim = kdim_; scale = s;
+  }
+  __device__ __forceinline__ void load(int kt) {
+    const int c = threadIdx.x % CPR, r0 = threadIdx.x / CPR;
+    const int k = kt * BK + 4 * c;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int r = r0 + p * RPP;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < BR && r < rows) {
+        const float* src = base + (long)r * ld + k;
+        if (VEC) {
+          if (k + 3 < kdim) v = *reinterpret_cast<const float4*>(src);
+          else {
+            if (k + 0 < kdim) v.x = src[0];
+            if (k + 1 < kdim) v.y = src[1];
+            if (k + 2 < kdim) v.z = src[2];
+          }
+        } else {
+          if (k + 0 < kdim) v.x = src[0];
+          if (k + 1 < kdim) v.y = src[1];
+          if (k + 2 < kdim) v.z = src[2];
+          if (k + 3 < kdim) v.w = src[3];
+        }
+      }
+      reg[p] = v;
+    }
+  }
+  __device__ __forceinline__ void store(float* t) const {
+    const int c = threadIdx.x % CPR, r0 = threadIdx.x / CPR;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int r = r0 + p * RPP;
+      if (r < BR) {
+        float* d = t + (4 * c) * LD + r;
+        d[0] = reg[p].x * scale;
+        d[LD] = reg[p].y * scale;
+        d[2 * LD] = reg[p].z * scale;
+        d[3 * LD] = reg[p].w * scale;
+      }
+    }
+  }
+};
+
+// Operand whose ROW index is contiguous in memory: element (r, k) at base[k*ld + r].
+// float4 along r; written to LDS with one ds_write_b128 per chunk.
+template <class Cfg, int BR, bool VEC>
+struct MatLoaderR {
+  static constexpr int BK = Cfg::BK;
+  static constexpr int LD = BR + 4;
+  static constexpr int FLOATS = BK * LD;
+  static constexpr int CPK = BR / 4;                 // float4 chunks per k
+  static constexpr int KPP = (Cfg::THREADS / CPK) > 0 ? (Cfg::THREADS / CPK) : 1;  // k per pass
+  static constexpr int PASSES = (BK + KPP - 1) / KPP;
+  const float* base;  // offset to (row0, k0)
+  long ld;
+  int rows, kdim;
+  float4 reg[PASSES];
+
+  __device__ __forceinline__ void init(const float* b, long ld_, int rows_, int kdim_) {
+    base = b; ld = ld_; rows = rows_; kdim = kdim_;
+  }
+  __device__ __forceinline__ void load(int kt) {
+    const int c = threadIdx.x % CPK, k0 = threadIdx.x / CPK;
+    const int r = 4 * c;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int kk = k0 + p * KPP;
+      const int k = kt * BK + kk;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kk < BK && k < kdim && threadIdx.x < CPK * KPP) {
+        const float* src = base + (long)k * ld + r;
+        if (VEC) {
+          if (r + 3 < rows) v = *reinterpret_cast<const float4*>(src);
+          else {
+            if (r + 0 < rows) v.x = src[0];
+            if (r + 1 < rows) v.y = src[1];
+            if (r + 2 < rows) v.z = src[2];
+          }
+        } else {
+          if (r + 0 < rows) v.x = src[0];
+          if (r + 1 < rows) v.y = src[1];
+          if (r + 2 < rows) v.z = src[2];
+          if (r + 3 < rows) v.w = src[3];
+        }
+      }
+      reg[p] = v;
+    }
+  }
+  __device__ __forceinline__ void store(float* t) const {
+    const int c = threadIdx.x % CPK, k0 = threadIdx.x / CPK;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int kk = k0 + p * KPP;
+      if (kk < BK && threadIdx.x < CPK * KPP)
+        *reinterpret_cast<float4*>(t + kk * LD + 4 * c) = reg[p];
+    }
+  }
+};

@@ -1,0 +1,783 @@
+// sinkhorn.hip -- the OT-GAN matching block on gfx950:
+//   cost Gram blocks (fp32 MFMA, split-K)  ->  log-domain Sinkhorn (potential form, exact
+//   iteration count)  ->  plan application (fp32 MFMA)  ->  distance (fp64 accumulation).
+// Replaces reference utils/matching.py:11-153 and toy_example/matching_cpu.py:4-164.
+#include "gemm_tile.h"
+#include "../../include/otgan.h"
+
+namespace {
+
+using SCfg = GemmCfg<2, 2, 2, 2, 16>;  // 128x128 block tile, 4 waves (2x2), 64x64 per wave
+constexpr int kMaxProb = 6;
+constexpr float kNegBig = -1.0e30f;  // masked log-kernel entry (exp -> 0, never NaN)
+
+// ======================================================================================
+// 1. cost matrices:  dot = X . Y^T  (split-K partials)  ->  K = -lambda * cost
+// ======================================================================================
+struct CostArgs {
+  const float* X[kMaxProb];
+  const float* Y[kMaxProb];
+  int P, n, m, D;
+  long ldf;
+  int kt_per_split;
+  float* ws;  // [nsplit][P][n][m]
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void cost_partial_kernel(CostArgs a) {
+  using LA = MatLoaderK<SCfg, 128, VEC>;
+  using LB = MatLoaderK<SCfg, 128, VEC>;
+  __shared__ __attribute__((aligned(16))) float smem[2 * LA::FLOATS + 2 * LB::FLOATS];
+  const int tn = (a.m + 127) / 128;
+  const int tmi = blockIdx.x / tn, tni = blockIdx.x % tn;
+  const int split = blockIdx.y, p = blockIdx.z;
+  const int nkt_total = (a.D + SCfg::BK - 1) / SCfg::BK;
+  const int kt0 = split * a.kt_per_split;
+  int nkt = nkt_total - kt0;
+  if (nkt > a.kt_per_split) nkt = a.kt_per_split;
+  const int k0 = kt0 * SCfg::BK;
+  LA la;
+  LB lb;
+  la.init(a.X[p] + (long)tmi * 128 * a.ldf + k0, a.ldf, a.n - tmi * 128, a.D - k0);
+  lb.init(a.Y[p] + (long)tni * 128 * a.ldf + k0, a.ldf, a.m - tni * 128, a.D - k0);
+  f32x16 acc[SCfg::MT][SCfg::NT];
+  zero_acc<SCfg>(acc);
+  gemm_mainloop<SCfg>(la, lb, nkt, smem, acc);
+  float* out = a.ws + ((long)split * a.P + p) * a.n * a.m;
+  const int n = a.n, m = a.m;
+  foreach_acc<SCfg>(acc, [&](int r, int c, int, int, int, float v) {
+    const int row = tmi * 128 + r, col = tni * 128 + c;
+    if (row < n && col < m) out[(long)row * m + col] = v;
+  });
+}
+
+struct FinishArgs {
+  const float* ws;
+  int nsplit, P, n, m;
+  float lambda, inv_d;
+  int cost_kind;
+  const float* xsq[kMaxProb];  // 0.5*mean(x^2) per row (sq-Euclid cost only)
+  const float* ysq[kMaxProb];
+  float diag[kMaxProb];
+  float* K;  // [P][n][m]
+};
+
+__global__ void cost_finish_kernel(FinishArgs a) {
+  const long per = (long)a.n * a.m;
+  const long total = per * a.P;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int p = (int)(idx / per);
+    const long rem = idx - (long)p * per;
+    const int i = (int)(rem / a.m), j = (int)(rem - (long)i * a.m);
+    float dot = 0.f;
+    for (int s = 0; s < a.nsplit; ++s) dot += a.ws[(long)s * total + idx];
+    float c;
+    if (a.cost_kind == OTGAN_COST_COSINE) c = 1.f - dot;
+    else c = a.xsq[p][i] + a.ysq[p][j] - dot * a.inv_d;
+    if (i == j) c += a.diag[p];
+    a.K[idx] = -a.lambda * c;
+  }
+}
+
+// out[r] = 0.5 * mean_k x[r][k]^2   (toy_example/matching_cpu.py:17)
+__global__ void row_halfmeansq_kernel(const float* x, long ld, int rows, int D, float* out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (r >= rows) return;
+  const float* p = x + (long)r * ld;
+  double s = 0.0;
+  for (int k = lane; k < D; k += 64) s += (double)p[k] * (double)p[k];
+  s = wave_sum_d(s);
+  if (lane == 0) out[r] = (float)(0.5 * s / D);
+}
+
+// ======================================================================================
+// 2. Sinkhorn.  Potential form of the reference loop (matching.py:52-54):
+//      log_a == K + f_i + g_j,   rows:  f_i = -LSE_j(K_ij + g_j),   cols: g_j = -LSE_i(K_ij + f_i)
+//    exactly `iters` (rows, cols) sweeps, then the row softmax of matching.py:56.
+//    LSE is max-shifted like tf.reduce_logsumexp.
+// ======================================================================================
+
+// ---- 2a. n, m <= 128: one 512-thread workgroup per problem, K resident in registers ------
+// Thread (idx = t & 127, q = t >> 7) holds row-role values K[idx][32q..32q+31] and
+// column-role values K[32q..32q+31][idx]; potentials live in LDS.  Per half-sweep: each
+// thread reduces its 32 values, the four quarter-partials are combined through LDS.
+__device__ __forceinline__ void small_half_step(const float (&kv)[32], const float* s_in,
+                                                float* s_out, float (*s_pm)[128],
+                                                float (*s_ps)[128], int idx, int q, int limit) {
+  const float4* in4 = reinterpret_cast<const float4*>(s_in + 32 * q);
+  float v[32];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float4 g = in4[c];
+    v[4 * c + 0] = kv[4 * c + 0] + g.x;
+    v[4 * c + 1] = kv[4 * c + 1] + g.y;
+    v[4 * c + 2] = kv[4 * c + 2] + g.z;
+    v[4 * c + 3] = kv[4 * c + 3] + g.w;
+    mx = fmaxf(mx, fmaxf(fmaxf(v[4 * c], v[4 * c + 1]), fmaxf(v[4 * c + 2], v[4 * c + 3])));
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 32; ++e) s += exp_neg(v[e] - mx);
+  s_pm[q][idx] = mx;
+  s_ps[q][idx] = s;
+  __syncthreads();
+  if (q == 0) {
+    const float m0 = s_pm[0][idx], m1 = s_pm[1][idx], m2 = s_pm[2][idx], m3 = s_pm[3][idx];
+    const float M = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    const float S = s_ps[0][idx] * exp_neg(m0 - M) + s_ps[1][idx] * exp_neg(m1 - M) +
+                    s_ps[2][idx] * exp_neg(m2 - M) + s_ps[3][idx] * exp_neg(m3 - M);
+    s_out[idx] = (idx < limit) ? -(M + logf(S)) : 0.f;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(512) void sinkhorn_small_kernel(const float* __restrict__ Kmat,
+                                                             int n, int m, int iters,
+                                                             float inv_lambda,
+                                                             float* __restrict__ plan,
+                                                             float* __restrict__ planT,
+                                                             double* __restrict__ stats) {
+  const int p = blockIdx.x;
+  const float* K = Kmat + (long)p * n * m;
+  const int t = threadIdx.x, idx = t & 127, q = t >> 7;
+  __shared__ __attribute__((aligned(16))) float s_f[128];
+  __shared__ __attribute__((aligned(16))) float s_g[128];
+  __shared__ float s_pm[4][128];
+  __shared__ float s_ps[4][128];
+  __shared__ double s_red[3][8];
+
+  float kr[32], kc[32];
+#pragma unroll
+  for (int e = 0; e < 32; ++e) {
+    const int j = 32 * q + e;
+    kr[e] = (idx < n && j < m) ? K[(long)idx * m + j] : kNegBig;
+  }
+#pragma unroll
+  for (int e = 0; e < 32; ++e) {
+    const int i = 32 * q + e;
+    kc[e] = (i < n && idx < m) ? K[(long)i * m + idx] : kNegBig;
+  }
+  if (t < 128) {
+    s_f[t] = 0.f;
+    s_g[t] = 0.f;
+  }
+  __syncthreads();
+
+  for (int it = 0; it < iters; ++it) {
+    small_half_step(kr, s_g, s_f, s_pm, s_ps, idx, q, n);  // rows:    f from g
+    small_half_step(kc, s_f, s_g, s_pm, s_ps, idx, q, m);  // columns: g from f
+  }
+  small_half_step(kr, s_g, s_f, s_pm, s_ps, idx, q, n);    // final row softmax (matching.py:56)
+
+  // plan M_ij = exp(K_ij + f_i + g_j): column role writes M (coalesced along j), row role
+  // writes M^T (coalesced along i) and the statistics.
+  {
+    const float gj = s_g[idx];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      const int i = 32 * q + e;
+      if (i < n && idx < m) plan[(long)p * n * m + (long)i * m + idx] = expf(kc[e] + s_f[i] + gj);
+    }
+  }
+  float h = 0.f, w = 0.f, sm = 0.f;
+  {
+    const float fi = s_f[idx];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      const int j = 32 * q + e;
+      if (idx < n && j < m) {
+        const float lm = kr[e] + fi + s_g[j];
+        const float mij = expf(lm);
+        planT[(long)p * n * m + (long)j * n + idx] = mij;
+        h -= mij * lm;
+        w -= mij * kr[e];
+        sm += mij;
+      }
+    }
+  }
+  double dh = wave_sum_d((double)h), dw = wave_sum_d((double)w), ds = wave_sum_d((double)sm);
+  const int wave = t >> 6, lane = t & 63;
+  if (lane == 0) {
+    s_red[0][wave] = dh;
+    s_red[1][wave] = dw;
+    s_red[2][wave] = ds;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double a = 0, b = 0, c = 0;
+    for (int k = 0; k < 8; ++k) {
+      a += s_red[0][k];
+      b += s_red[1][k];
+      c += s_red[2][k];
+    }
+    stats[p * 4 + 0] = a;                        // sum_i H(M_i.)
+    stats[p * 4 + 1] = b * (double)inv_lambda;   // <M, C>,  C = -K/lambda
+    stats[p * 4 + 2] = c;                        // sum(M)
+    stats[p * 4 + 3] = 0.0;
+  }
+}
+
+// ---- 2b. general sizes: K stays in HBM/L2, two kernels per sweep -------------------------
+// rows: one wave per row.  out[p][i] = -LSE_j(K[p][i][j] + in[p][j])
+__global__ __launch_bounds__(256) void sinkhorn_row_kernel(const float* __restrict__ Kmat,
+                                                           int n, int m,
+                                                           const float* __restrict__ g,
+                                                           float* __restrict__ f) {
+  const int p = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= n) return;
+  const float* row = Kmat + ((long)p * n + i) * m;
+  const float* gp = g + (long)p * m;
+  float mx = -3.0e38f;
+  for (int j = lane; j < m; j += 64) mx = fmaxf(mx, row[j] + gp[j]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int j = lane; j < m; j += 64) s += exp_neg(row[j] + gp[j] - mx);
+  s = wave_sum(s);
+  if (lane == 0) f[(long)p * n + i] = -(mx + logf(s));
+}
+
+// columns: a 256-thread block owns 64 columns (lane = column); its 4 waves split the rows.
+__global__ __launch_bounds__(256) void sinkhorn_col_kernel(const float* __restrict__ Kmat,
+                                                           int n, int m,
+                                                           const float* __restrict__ f,
+                                                           float* __restrict__ g) {
+  const int p = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 64 + lane;
+  const float* Kp = Kmat + (long)p * n * m;
+  const float* fp = f + (long)p * n;
+  __shared__ float s_m[4][64], s_s[4][64];
+  float mx = -3.0e38f, s = 0.f;
+  if (j < m) {
+    for (int i = wave; i < n; i += 4) mx = fmaxf(mx, Kp[(long)i * m + j] + fp[i]);
+    for (int i = wave; i < n; i += 4) s += exp_neg(Kp[(long)i * m + j] + fp[i] - mx);
+  }
+  s_m[wave][lane] = mx;
+  s_s[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && j < m) {
+    const float M = fmaxf(fmaxf(s_m[0][lane], s_m[1][lane]), fmaxf(s_m[2][lane], s_m[3][lane]));
+    float S = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) S += s_s[w][lane] * exp_neg(s_m[w][lane] - M);
+    g[(long)p * m + j] = -(M + logf(S));
+  }
+}
+
+// final: row softmax, plan, transposed plan, statistics (atomics into zeroed stats).
+__global__ __launch_bounds__(256) void sinkhorn_final_kernel(const float* __restrict__ Kmat,
+                                                             int n, int m,
+                                                             const float* __restrict__ g,
+                                                             float inv_lambda,
+                                                             float* __restrict__ plan,
+                                                             float* __restrict__ planT,
+                                                             double* __restrict__ stats) {
+  const int p = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= n) return;
+  const float* row = Kmat + ((long)p * n + i) * m;
+  const float* gp = g + (long)p * m;
+  float mx = -3.0e38f;
+  for (int j = lane; j < m; j += 64) mx = fmaxf(mx, row[j] + gp[j]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int j = lane; j < m; j += 64) s += exp_neg(row[j] + gp[j] - mx);
+  s = wave_sum(s);
+  const float fi = -(mx + logf(s));
+  float h = 0.f, w = 0.f, sm = 0.f;
+  float* prow = plan + ((long)p * n + i) * m;
+  float* pT = planT + (long)p * n * m;
+  for (int j = lane; j < m; j += 64) {
+    const float kij = row[j];
+    const float lm = kij + fi + gp[j];
+    const float mij = expf(lm);
+    prow[j] = mij;
+    pT[(long)j * n + i] = mij;
+    h -= mij * lm;
+    w -= mij * kij;
+    sm += mij;
+  }
+  const double dh = wave_sum_d((double)h), dw = wave_sum_d((double)w), ds = wave_sum_d((double)sm);
+  if (lane == 0) {
+    atomicAdd(&stats[p * 4 + 0], dh);
+    atomicAdd(&stats[p * 4 + 1], dw * (double)inv_lambda);
+    atomicAdd(&stats[p * 4 + 2], ds);
+  }
+}
+
+// ======================================================================================
+// 3. plan application: out = alpha * sum_t plan_t[rows, kdim_t] . feat_t[kdim_t, D]
+// ======================================================================================
+struct ApplyTerm {
+  const float* plan;
+  const float* feat;
+  long ldp;
+  int kdim;
+};
+struct ApplyBlock {
+  float* out;
+  int rows;
+  int nterms;
+  float alpha;
+  ApplyTerm t[2];
+};
+struct ApplyArgs {
+  ApplyBlock b[8];
+  int D;
+  long ldf, ldo;
+  int tiles_d;
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void plan_apply_kernel(ApplyArgs a) {
+  using LA = MatLoaderK<SCfg, 128, VEC>;
+  using LB = MatLoaderR<SCfg, 128, VEC>;
+  __shared__ __attribute__((aligned(16))) float smem[2 * LA::FLOATS + 2 * LB::FLOATS];
+  const ApplyBlock& blk = a.b[blockIdx.y];
+  const int tmi = blockIdx.x / a.tiles_d, tdi = blockIdx.x % a.tiles_d;
+  const int row0 = tmi * 128, d0 = tdi * 128;
+  if (row0 >= blk.rows) return;
+  f32x16 acc[SCfg::MT][SCfg::NT];
+  zero_acc<SCfg>(acc);
+  for (int t = 0; t < blk.nterms; ++t) {
+    LA la;
+    LB lb;
+    la.init(blk.t[t].plan + (long)row0 * blk.t[t].ldp, blk.t[t].ldp, blk.rows - row0, blk.t[t].kdim);
+    lb.init(blk.t[t].feat + d0, a.ldf, a.D - d0, blk.t[t].kdim);
+    gemm_mainloop<SCfg>(la, lb, (blk.t[t].kdim + SCfg::BK - 1) / SCfg::BK, smem, acc);
+  }
+  float* out = blk.out;
+  const int rows = blk.rows, D = a.D;
+  const long ldo = a.ldo;
+  const float alpha = blk.alpha;
+  foreach_acc<SCfg>(acc, [&](int r, int c, int, int, int, float v) {
+    const int row = row0 + r, col = d0 + c;
+    if (row < rows && col < D) out[(long)row * ldo + col] = alpha * v;
+  });
+}
+
+// ======================================================================================
+// 4. distance (matching.py:139-153) with fp64 accumulation
+// ======================================================================================
+__global__ __launch_bounds__(256) void dot3_kernel(const float* __restrict__ a,
+                                                   const float* __restrict__ b,
+                                                   const float* __restrict__ aa,
+                                                   const float* __restrict__ bb,
+                                                   const float* __restrict__ ab, long total,
+                                                   double* __restrict__ out3) {
+  double s_aa = 0, s_bb = 0, s_ab = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const double av = a[i], bv = b[i];
+    s_aa += av * (double)aa[i];
+    s_bb += bv * (double)bb[i];
+    s_ab += av * (double)ab[i];
+  }
+  s_aa = wave_sum_d(s_aa);
+  s_bb = wave_sum_d(s_bb);
+  s_ab = wave_sum_d(s_ab);
+  __shared__ double red[3][4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+    red[0][wave] = s_aa;
+    red[1][wave] = s_bb;
+    red[2][wave] = s_ab;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&out3[0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(&out3[1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    atomicAdd(&out3[2], red[2][0] + red[2][1] + red[2][2] + red[2][3]);
+  }
+}
+
+__global__ void distance_finalize_kernel(const double* s3, double denom, double* dist) {
+  // (nd_bb + nd_aa - 2 nd_ab) / denom          (matching.py:150,152)
+  dist[0] = (s3[1] + s3[0] - 2.0 * s3[2]) / denom;
+}
+
+__global__ void entropy_finalize_kernel(const double* stats, int P, int n, float* entropy) {
+  double e = 0.0;
+  for (int p = 0; p < P; ++p) e += stats[p * 4 + 0] / (double)n;  // mean row entropy (matching.py:57)
+  entropy[0] = (float)(e / P);                                     // mean over problems (:61)
+}
+
+// ---------------------------------------------------------------------------------------
+// host-side planning helpers
+// ---------------------------------------------------------------------------------------
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+struct CostPlan {
+  int tiles, nsplit, kt_per_split;
+};
+inline CostPlan plan_cost(int P, int n, int m, int D) {
+  CostPlan c;
+  c.tiles = ceil_div(n, 128) * ceil_div(m, 128);
+  const int nkt = ceil_div(D, SCfg::BK);
+  int want = ceil_div(768, c.tiles * P);  // aim for ~3 workgroups per CU
+  if (want < 1) want = 1;
+  if (want > nkt) want = nkt;
+  c.kt_per_split = ceil_div(nkt, want);
+  c.nsplit = ceil_div(nkt, c.kt_per_split);
+  return c;
+}
+
+struct Carver {
+  char* base;
+  size_t off, cap;
+  Carver(void* b, size_t c) : base((char*)b), off(0), cap(c) {}
+  void* take(size_t bytes) {
+    void* p = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  }
+};
+
+int launch_cost(const float* const* X, const float* const* Y, const float* const* xsq,
+                const float* const* ysq, const float* diag, int P, int n, int m, int D, long ldf,
+                float lambda, int cost_kind, float* partial_ws, float* K, hipStream_t s) {
+  const CostPlan cp = plan_cost(P, n, m, D);
+  CostArgs ca;
+  memset(&ca, 0, sizeof(ca));
+  bool vec = (ldf % 4 == 0);
+  for (int p = 0; p < P; ++p) {
+    ca.X[p] = X[p];
+    ca.Y[p] = Y[p];
+    vec = vec && aligned16(X[p]) && aligned16(Y[p]);
+  }
+  ca.P = P; ca.n = n; ca.m = m; ca.D = D; ca.ldf = ldf;
+  ca.kt_per_split = cp.kt_per_split;
+  ca.ws = partial_ws;
+  dim3 grid(cp.tiles, cp.nsplit, P);
+  {
+    ProfScope ps(OTGAN_PROF_COST_GEMM, 2.0 * P * n * (double)m * D,
+                 4.0 * P * ((double)n + m) * D, s);
+    if (vec) hipLaunchKernelGGL(cost_partial_kernel<true>, grid, dim3(256), 0, s, ca);
+    else hipLaunchKernelGGL(cost_partial_kernel<false>, grid, dim3(256), 0, s, ca);
+  }
+  OTGAN_CHECK_LAUNCH("cost_partial_kernel");
+  FinishArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.ws = partial_ws; fa.nsplit = cp.nsplit; fa.P = P; fa.n = n; fa.m = m;
+  fa.lambda = lambda; fa.inv_d = 1.f / (float)D; fa.cost_kind = cost_kind; fa.K = K;
+  for (int p = 0; p < P; ++p) {
+    fa.xsq[p] = xsq ? xsq[p] : nullptr;
+    fa.ysq[p] = ysq ? ysq[p] : nullptr;
+    fa.diag[p] = diag ? diag[p] : 0.f;
+  }
+  const long total = (long)P * n * m;
+  const int blocks = (int)(ceil_div_l(total, 256) < 2048 ? ceil_div_l(total, 256) : 2048);
+  hipLaunchKernelGGL(cost_finish_kernel, dim3(blocks), dim3(256), 0, s, fa);
+  OTGAN_CHECK_LAUNCH("cost_finish_kernel");
+  return OTGAN_OK;
+}
+
+int launch_sinkhorn(const float* K, int P, int n, int m, int iters, float lambda, float* plan,
+                    float* planT, double* stats, float* fg_ws, hipStream_t s) {
+  ProfScope ps(OTGAN_PROF_SINKHORN, 0.0, 0.0, s);
+  if (n <= 128 && m <= 128) {
+    hipLaunchKernelGGL(sinkhorn_small_kernel, dim3(P), dim3(512), 0, s, K, n, m, iters,
+                       1.f / lambda, plan, planT, stats);
+    OTGAN_CHECK_LAUNCH("sinkhorn_small_kernel");
+    return OTGAN_OK;
+  }
+  float* f = fg_ws;
+  float* g = fg_ws + (size_t)P * n;
+  hipMemsetAsync(g, 0, sizeof(float) * (size_t)P * m, s);
+  hipMemsetAsync(stats, 0, sizeof(double) * 4 * P, s);
+  const dim3 grow(ceil_div(n, 4), P), gcol(ceil_div(m, 64), P);
+  for (int it = 0; it < iters; ++it) {
+    hipLaunchKernelGGL(sinkhorn_row_kernel, grow, dim3(256), 0, s, K, n, m, g, f);
+    hipLaunchKernelGGL(sinkhorn_col_kernel, gcol, dim3(256), 0, s, K, n, m, f, g);
+  }
+  hipLaunchKernelGGL(sinkhorn_final_kernel, grow, dim3(256), 0, s, K, n, m, g, 1.f / lambda,
+                     plan, planT, stats);
+  OTGAN_CHECK_LAUNCH("sinkhorn general kernels");
+  return OTGAN_OK;
+}
+
+int launch_apply(const ApplyBlock* blocks, int nblocks, int max_rows, int D, long ldf, long ldo,
+                 hipStream_t s) {
+  ApplyArgs aa;
+  memset(&aa, 0, sizeof(aa));
+  bool vec = (ldf % 4 == 0);
+  double flops = 0;
+  for (int b = 0; b < nblocks; ++b) {
+    aa.b[b] = blocks[b];
+    for (int t = 0; t < blocks[b].nterms; ++t) {
+      vec = vec && aligned16(blocks[b].t[t].plan) && aligned16(blocks[b].t[t].feat) &&
+            (blocks[b].t[t].ldp % 4 == 0);
+      flops += 2.0 * blocks[b].rows * (double)blocks[b].t[t].kdim * D;
+    }
+  }
+  aa.D = D; aa.ldf = ldf; aa.ldo = ldo;
+  aa.tiles_d = ceil_div(D, 128);
+  dim3 grid(aa.tiles_d * ceil_div(max_rows, 128), nblocks);
+  {
+    ProfScope ps(OTGAN_PROF_PLAN_APPLY, flops, 0.0, s);
+    if (vec) hipLaunchKernelGGL(plan_apply_kernel<true>, grid, dim3(256), 0, s, aa);
+    else hipLaunchKernelGGL(plan_apply_kernel<false>, grid, dim3(256), 0, s, aa);
+  }
+  OTGAN_CHECK_LAUNCH("plan_apply_kernel");
+  return OTGAN_OK;
+}
+
+int launch_distance(const float* a, const float* b, const float* aa, const float* bb,
+                    const float* ab, long total, double denom, double* dist, double* scratch3,
+                    hipStream_t s) {
+  hipMemsetAsync(scratch3, 0, 3 * sizeof(double), s);
+  long blocks = ceil_div_l(total, 256 * 8);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(dot3_kernel, dim3((int)blocks), dim3(256), 0, s, a, b, aa, bb, ab, total,
+                     scratch3);
+  hipLaunchKernelGGL(distance_finalize_kernel, dim3(1), dim3(1), 0, s, scratch3, denom, dist);
+  OTGAN_CHECK_LAUNCH("distance kernels");
+  return OTGAN_OK;
+}
+
+// workspace layout shared by the size query (base == nullptr) and the launchers
+struct MatchWs {
+  float* sq_a;     // [rows_a] 0.5*mean(x^2) (toy cost)
+  float* sq_b;
+  float* partial;  // [nsplit][P][n][m]
+  float* K;        // [P][n][m]
+  float* plan;     // [P][n][m]
+  float* planT;    // [P][m][n]
+  float* fg;       // [P][n+m]
+  double* stats;   // [P][4]
+  double* dot3;    // [3]
+  size_t bytes;
+};
+MatchWs carve_match(void* base, size_t cap, int P, int n, int D, int feat_rows) {
+  Carver c(base, cap);
+  MatchWs w;
+  const CostPlan cp = plan_cost(P, n, n, D);
+  const size_t pnm = (size_t)P * n * n;
+  w.sq_a = (float*)c.take(sizeof(float) * feat_rows);
+  w.sq_b = (float*)c.take(sizeof(float) * feat_rows);
+  w.partial = (float*)c.take(sizeof(float) * pnm * cp.nsplit);
+  w.K = (float*)c.take(sizeof(float) * pnm);
+  w.plan = (float*)c.take(sizeof(float) * pnm);
+  w.planT = (float*)c.take(sizeof(float) * pnm);
+  w.fg = (float*)c.take(sizeof(float) * (size_t)P * 2 * n);
+  w.stats = (double*)c.take(sizeof(double) * 4 * P);
+  w.dot3 = (double*)c.take(sizeof(double) * 4);
+  w.bytes = c.off;
+  return w;
+}
+
+}  // namespace
+
+// =======================================================================================
+// C ABI
+// =======================================================================================
+extern "C" {
+
+size_t otgan_matching_workspace_bytes(int mode, int rows, int D) {
+  if (rows <= 0 || D <= 0) return 0;
+  if (mode == OTGAN_MATCH_TWO_BATCH) return carve_match(nullptr, 0, 6, rows, D, 2 * rows).bytes;
+  return carve_match(nullptr, 0, 3, rows, D, rows).bytes;
+}
+
+int otgan_matching_two_batch_f32(const float* fa, const float* fb, int N, int D, long ldf,
+                                 float lambda, int iters, int cost_kind, float* f_aa,
+                                 float* f_bb, float* f_ab, float* f_ba, long ldo,
+                                 float* entropy, double* dist, double* stats, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  OTGAN_CHECK_ARG(fa && fb && f_aa && f_bb && f_ab && f_ba && entropy && dist, "null pointer");
+  OTGAN_CHECK_ARG(N > 0 && D > 0 && ldf >= D && ldo >= D && iters >= 0, "bad sizes N=%d D=%d", N, D);
+  OTGAN_CHECK_ARG(cost_kind == OTGAN_COST_COSINE || cost_kind == OTGAN_COST_SQEUCLID_MEAN,
+                  "unknown cost kind %d", cost_kind);
+  // the distance reduction walks the [2N, D] arrays linearly
+  OTGAN_CHECK_ARG(ldf == D && ldo == D, "feature arrays must be contiguous (ld == D)");
+  hipStream_t s = (hipStream_t)stream;
+  MatchWs w = carve_match(workspace, workspace_bytes, 6, N, D, 2 * N);
+  if (!workspace || workspace_bytes < w.bytes) {
+    otgan_set_error("workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
+    return OTGAN_ERR_WORKSPACE;
+  }
+  const float *fa1 = fa, *fa2 = fa + (long)N * ldf, *fb1 = fb, *fb2 = fb + (long)N * ldf;
+  // problem order of the reference (matching.py:41-43): a1a2, b2b1, a1b1, a1b2, a2b1, a2b2
+  const float* X[6] = {fa1, fb2, fa1, fa1, fa2, fa2};
+  const float* Y[6] = {fa2, fb1, fb1, fb2, fb1, fb2};
+  const float *xsq[6], *ysq[6];
+  if (cost_kind == OTGAN_COST_SQEUCLID_MEAN) {
+    hipLaunchKernelGGL(row_halfmeansq_kernel, dim3(ceil_div(2 * N, 4)), dim3(256), 0, s, fa, ldf,
+                       2 * N, D, w.sq_a);
+    hipLaunchKernelGGL(row_halfmeansq_kernel, dim3(ceil_div(2 * N, 4)), dim3(256), 0, s, fb, ldf,
+                       2 * N, D, w.sq_b);
+    const float *sa1 = w.sq_a, *sa2 = w.sq_a + N, *sb1 = w.sq_b, *sb2 = w.sq_b + N;
+    const float* xs[6] = {sa1, sb2, sa1, sa1, sa2, sa2};
+    const float* ys[6] = {sa2, sb1, sb1, sb2, sb1, sb2};
+    memcpy(xsq, xs, sizeof(xs));
+    memcpy(ysq, ys, sizeof(ys));
+  }
+  int rc = launch_cost(X, Y, cost_kind == OTGAN_COST_SQEUCLID_MEAN ? xsq : nullptr,
+                       cost_kind == OTGAN_COST_SQEUCLID_MEAN ? ysq : nullptr, nullptr, 6, N, N, D,
+                       ldf, lambda, cost_kind, w.partial, w.K, s);
+  if (rc) return rc;
+  rc = launch_sinkhorn(w.K, 6, N, N, iters, lambda, w.plan, w.planT, w.stats, w.fg, s);
+  if (rc) return rc;
+  const size_t nn = (size_t)N * N;
+  const float *M0 = w.plan, *M1 = w.plan + nn, *M2 = w.plan + 2 * nn, *M3 = w.plan + 3 * nn,
+              *M4 = w.plan + 4 * nn, *M5 = w.plan + 5 * nn;
+  const float *T0 = w.planT, *T1 = w.planT + nn, *T2 = w.planT + 2 * nn, *T3 = w.planT + 3 * nn,
+              *T4 = w.planT + 4 * nn, *T5 = w.planT + 5 * nn;
+  // matching.py:64-83.  Eight [N,D] output blocks, each one or two plan.feature products.
+  ApplyBlock blk[8];
+  memset(blk, 0, sizeof(blk));
+  auto set1 = [&](int i, float* out, const float* P0, const float* F0, float alpha) {
+    blk[i].out = out; blk[i].rows = N; blk[i].nterms = 1; blk[i].alpha = alpha;
+    blk[i].t[0] = ApplyTerm{P0, F0, (long)N, N};
+  };
+  auto set2 = [&](int i, float* out, const float* P0, const float* F0, const float* P1,
+                  const float* F1, float alpha) {
+    blk[i].out = out; blk[i].rows = N; blk[i].nterms = 2; blk[i].alpha = alpha;
+    blk[i].t[0] = ApplyTerm{P0, F0, (long)N, N};
+    blk[i].t[1] = ApplyTerm{P1, F1, (long)N, N};
+  };
+  const long half = (long)N * ldo;
+  set1(0, f_aa, M0, fa2, 1.f);                  // a1 <- M_a1a2 . a2          (:64)
+  set1(1, f_aa + half, T0, fa1, 1.f);           // a2 <- M_a1a2^T . a1        (:70)
+  set1(2, f_bb, T1, fb2, 1.f);                  // b1 <- M_b2b1^T . b2        (:65)
+  set1(3, f_bb + half, M1, fb1, 1.f);           // b2 <- M_b2b1 . b1          (:71)
+  set2(4, f_ab, M2, fb1, M3, fb2, 0.5f);        // a1 <- (M_a1b1.b1 + M_a1b2.b2)/2   (:66,67,80)
+  set2(5, f_ab + half, M4, fb1, M5, fb2, 0.5f); // a2 <- (M_a2b1.b1 + M_a2b2.b2)/2   (:68,69,80)
+  set2(6, f_ba, T2, fa1, T4, fa2, 0.5f);        // b1 <- (M_a1b1^T.a1 + M_a2b1^T.a2)/2 (:72,74,82)
+  set2(7, f_ba + half, T3, fa1, T5, fa2, 0.5f); // b2 <- (M_a1b2^T.a1 + M_a2b2^T.a2)/2 (:73,75,82)
+  rc = launch_apply(blk, 8, N, D, ldf, ldo, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(entropy_finalize_kernel, dim3(1), dim3(1), 0, s, w.stats, 6, N, entropy);
+  const double denom = (cost_kind == OTGAN_COST_COSINE) ? 2.0 * (2.0 * N)          // matching.py:152
+                                                        : 2.0 * (2.0 * N) * (double)D;  // matching_cpu.py:158-163
+  rc = launch_distance(fa, fb, f_aa, f_bb, f_ab, (long)2 * N * D, denom, dist, w.dot3, s);
+  if (rc) return rc;
+  if (stats) hipMemcpyAsync(stats, w.stats, sizeof(double) * 24, hipMemcpyDeviceToDevice, s);
+  return OTGAN_OK;
+}
+
+int otgan_matching_single_batch_f32(const float* fa, const float* fb, int n, int D, long ldf,
+                                    float lambda, int iters, float* f_aa, float* f_bb,
+                                    float* f_ab, float* f_ba, long ldo, float* entropy,
+                                    double* dist, double* stats, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  OTGAN_CHECK_ARG(fa && fb && f_aa && f_bb && f_ab && f_ba && entropy && dist, "null pointer");
+  OTGAN_CHECK_ARG(n > 0 && D > 0 && ldf >= D && ldo >= D && iters >= 0, "bad sizes n=%d D=%d", n, D);
+  OTGAN_CHECK_ARG(ldf == D && ldo == D, "feature arrays must be contiguous (ld == D)");
+  hipStream_t s = (hipStream_t)stream;
+  MatchWs w = carve_match(workspace, workspace_bytes, 3, n, D, n);
+  if (!workspace || workspace_bytes < w.bytes) {
+    otgan_set_error("workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
+    return OTGAN_ERR_WORKSPACE;
+  }
+  const float* X[3] = {fa, fb, fa};
+  const float* Y[3] = {fa, fb, fb};
+  const float diag[3] = {999.f, 999.f, 0.f};  // matching.py:109-110
+  int rc = launch_cost(X, Y, nullptr, nullptr, diag, 3, n, n, D, ldf, lambda, OTGAN_COST_COSINE,
+                       w.partial, w.K, s);
+  if (rc) return rc;
+  rc = launch_sinkhorn(w.K, 3, n, n, iters, lambda, w.plan, w.planT, w.stats, w.fg, s);
+  if (rc) return rc;
+  const size_t nn = (size_t)n * n;
+  ApplyBlock blk[4];
+  memset(blk, 0, sizeof(blk));
+  auto set1 = [&](int i, float* out, const float* P0, const float* F0) {
+    blk[i].out = out; blk[i].rows = n; blk[i].nterms = 1; blk[i].alpha = 1.f;
+    blk[i].t[0] = ApplyTerm{P0, F0, (long)n, n};
+  };
+  set1(0, f_aa, w.plan, fa);            // :131
+  set1(1, f_bb, w.plan + nn, fb);       // :132
+  set1(2, f_ab, w.plan + 2 * nn, fb);   // :133
+  set1(3, f_ba, w.planT + 2 * nn, fa);  // :134
+  rc = launch_apply(blk, 4, n, D, ldf, ldo, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(entropy_finalize_kernel, dim3(1), dim3(1), 0, s, w.stats, 3, n, entropy);
+  rc = launch_distance(fa, fb, f_aa, f_bb, f_ab, (long)n * D, 2.0 * n, dist, w.dot3, s);
+  if (rc) return rc;
+  if (stats) hipMemcpyAsync(stats, w.stats, sizeof(double) * 12, hipMemcpyDeviceToDevice, s);
+  return OTGAN_OK;
+}
+
+size_t otgan_cost_matrix_workspace_bytes(int n, int m, int D) {
+  if (n <= 0 || m <= 0 || D <= 0) return 0;
+  const CostPlan cp = plan_cost(1, n, m, D);
+  return align_up(sizeof(float) * (size_t)n * m * cp.nsplit, 256) +
+         align_up(sizeof(float) * n, 256) + align_up(sizeof(float) * m, 256);
+}
+
+int otgan_cost_matrix_f32(const float* X, const float* Y, int n, int m, int D, long ldf,
+                          float lambda, int cost_kind, float diag_add, float* K, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  OTGAN_CHECK_ARG(X && Y && K, "null pointer");
+  OTGAN_CHECK_ARG(n > 0 && m > 0 && D > 0 && ldf >= D, "bad sizes");
+  const size_t need = otgan_cost_matrix_workspace_bytes(n, m, D);
+  if (!workspace || workspace_bytes < need) {
+    otgan_set_error("workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    return OTGAN_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const CostPlan cp = plan_cost(1, n, m, D);
+  Carver c(workspace, workspace_bytes);
+  float* partial = (float*)c.take(sizeof(float) * (size_t)n * m * cp.nsplit);
+  float* xs = (float*)c.take(sizeof(float) * n);
+  float* ys = (float*)c.take(sizeof(float) * m);
+  const float *xp[1] = {xs}, *yp[1] = {ys};
+  if (cost_kind == OTGAN_COST_SQEUCLID_MEAN) {
+    hipLaunchKernelGGL(row_halfmeansq_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, X, ldf, n, D, xs);
+    hipLaunchKernelGGL(row_halfmeansq_kernel, dim3(ceil_div(m, 4)), dim3(256), 0, s, Y, ldf, m, D, ys);
+  }
+  const float* Xp[1] = {X};
+  const float* Yp[1] = {Y};
+  const float dg[1] = {diag_add};
+  return launch_cost(Xp, Yp, cost_kind == OTGAN_COST_SQEUCLID_MEAN ? xp : nullptr,
+                     cost_kind == OTGAN_COST_SQEUCLID_MEAN ? yp : nullptr, dg, 1, n, m, D, ldf,
+                     lambda, cost_kind, partial, K, s);
+}
+
+size_t otgan_sinkhorn_workspace_bytes(int P, int n, int m) {
+  if (P <= 0 || n <= 0 || m <= 0) return 0;
+  return align_up(sizeof(float) * (size_t)P * (n + m), 256);
+}
+
+int otgan_sinkhorn_plan_f32(const float* K, int P, int n, int m, int iters, float lambda,
+                            float* plan, float* planT, double* stats, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  OTGAN_CHECK_ARG(K && plan && planT && stats, "null pointer");
+  OTGAN_CHECK_ARG(P > 0 && n > 0 && m > 0 && iters >= 0 && lambda != 0.f, "bad sizes");
+  const size_t need = otgan_sinkhorn_workspace_bytes(P, n, m);
+  if (!workspace || workspace_bytes < need) {
+    otgan_set_error("workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    return OTGAN_ERR_WORKSPACE;
+  }
+  return launch_sinkhorn(K, P, n, m, iters, lambda, plan, planT, stats, (float*)workspace,
+                         (hipStream_t)stream);
+}
+
+int otgan_plan_apply_f32(const float* plan, long ldp, int rows, int kdim, const float* feat,
+                         long ldf, int D, float alpha, float* out, long ldo, void* stream) {
+  OTGAN_CHECK_ARG(plan && feat && out, "null pointer");
+  OTGAN_CHECK_ARG(rows > 0 && kdim > 0 && D > 0 && ldp >= kdim && ldf >= D && ldo >= D, "bad sizes");
+  ApplyBlock blk;
+  memset(&blk, 0, sizeof(blk));
+  blk.out = out; blk.rows = rows; blk.nterms = 1; blk.alpha = alpha;
+  blk.t[0] = ApplyTerm{plan, feat, ldp, kdim};
+  return launch_apply(&blk, 1, rows, D, ldf, ldo, (hipStream_t)stream);
+}
+
+int otgan_calc_distance_f32(const float* a, const float* b, const float* aa, const float* bb,
+                            const float* ab, long rows, int D, double denom, double* dist,
+                            double* scratch3, void* stream) {
+  OTGAN_CHECK_ARG(a && b && aa && bb && ab && dist && scratch3, "null pointer");
+  OTGAN_CHECK_ARG(rows > 0 && D > 0 && denom != 0.0, "bad sizes");
+  return launch_distance(a, b, aa, bb, ab, rows * (long)D, denom, dist, scratch3,
+                         (hipStream_t)stream);
+}
+
+}  // extern "C"

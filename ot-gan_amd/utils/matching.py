@@ -1,0 +1,187 @@
+"""Mini-batch Sinkhorn energy distance on MI355X -- drop-in for the reference's
+`utils/matching.py` (same function names, argument meaning, return structure).
+
+    get_matched_features(features_a, features_b, sinkhorn_lambda, nr_sinkhorn_iter)
+        reference utils/matching.py:11-85   -> otgan_matching_two_batch_f32
+    get_matched_features_single_batch(...)
+        reference utils/matching.py:88-136  -> otgan_matching_single_batch_f32
+    get_matched_features_random(features_a, features_b)
+        reference utils/matching.py:3-9     (list rotation only; no kernel)
+    calc_distance(features_a, features_b, matched_features)
+        reference utils/matching.py:139-153 -> otgan_calc_distance_f32
+
+`features_a` / `features_b` are lists of S equally-shaped `[B, D]` float32 CUDA tensors
+(`a` = generated, `b` = data; shards [0,S/2) form mini-batch 1, [S/2,S) mini-batch 2).
+The return value is `(features_a_a, features_b_b, features_a_b, features_b_a, entropy)`
+with four lists of S `[B, D]` tensors and a 0-d tensor.  Gradients do not flow through
+the matching (reference train.py:111-128 injects the matched differences as `grad_ys`),
+so everything here is computed under no_grad and returned detached.
+
+All arithmetic runs in the HIP library; there is no fallback.
+"""
+import torch
+
+from .. import _lib
+
+COST_COSINE = 0
+COST_SQEUCLID_MEAN = 1
+_MODE_TWO, _MODE_SINGLE = 0, 1
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _check_lists(features_a, features_b):
+    if len(features_a) != len(features_b) or len(features_a) == 0:
+        raise ValueError("features_a and features_b must be non-empty lists of equal length")
+    ref = features_a[0]
+    for t in list(features_a) + list(features_b):
+        if not t.is_cuda:
+            raise _lib.OtganError("matching needs CUDA (MI355X) tensors; there is no CPU fallback")
+        if t.dtype != torch.float32 or t.dim() != 2 or t.shape != ref.shape:
+            raise ValueError("all shards must be float32 [B, D] tensors of one shape")
+
+
+def _stack(shards):
+    with torch.no_grad():
+        return torch.cat([s.detach() for s in shards], 0).contiguous()
+
+
+class MatchedFeatures(tuple):
+    """The reference's 5-tuple, carrying a few extras as attributes (flat outputs, the
+    device-side fp64 distance and per-problem statistics) so that calc_distance and the
+    training step need not recompute them."""
+    flat = None
+    distance = None
+    stats = None
+
+
+def _run(mode, fa, fb, S, lam, iters, cost_kind):
+    L = _lib.lib()
+    rows_total, D = fa.shape
+    rows = rows_total // 2 if mode == _MODE_TWO else rows_total
+    dev = fa.device
+    outs = [torch.empty_like(fa) for _ in range(4)]
+    entropy = torch.empty((), dtype=torch.float32, device=dev)
+    dist = torch.empty((), dtype=torch.float64, device=dev)
+    nprob = 6 if mode == _MODE_TWO else 3
+    stats = torch.empty((nprob, 4), dtype=torch.float64, device=dev)
+    need = L.otgan_matching_workspace_bytes(mode, rows, D)
+    ws = _workspace(need, dev)
+    s = _lib.stream_ptr()
+    if mode == _MODE_TWO:
+        rc = L.otgan_matching_two_batch_f32(fa.data_ptr(), fb.data_ptr(), rows, D, D, float(lam),
+                                            int(iters), int(cost_kind), outs[0].data_ptr(),
+                                            outs[1].data_ptr(), outs[2].data_ptr(),
+                                            outs[3].data_ptr(), D, entropy.data_ptr(),
+                                            dist.data_ptr(), stats.data_ptr(), ws.data_ptr(),
+                                            ws.numel(), s)
+        _lib.check(rc, "otgan_matching_two_batch_f32")
+    else:
+        rc = L.otgan_matching_single_batch_f32(fa.data_ptr(), fb.data_ptr(), rows, D, D, float(lam),
+                                               int(iters), outs[0].data_ptr(), outs[1].data_ptr(),
+                                               outs[2].data_ptr(), outs[3].data_ptr(), D,
+                                               entropy.data_ptr(), dist.data_ptr(),
+                                               stats.data_ptr(), ws.data_ptr(), ws.numel(), s)
+        _lib.check(rc, "otgan_matching_single_batch_f32")
+    lists = [list(torch.chunk(o, S, 0)) for o in outs]
+    res = MatchedFeatures((*lists, entropy))
+    res.flat = outs
+    res.distance = dist
+    res.stats = stats
+    return res
+
+
+def get_matched_features(features_a, features_b, sinkhorn_lambda, nr_sinkhorn_iter):
+    """Two-batch matching (reference utils/matching.py:11-85)."""
+    _check_lists(features_a, features_b)
+    S = len(features_a)
+    if S % 2 != 0:
+        raise ValueError("the two-batch matching needs an even number of shards (train.py:34)")
+    return _run(_MODE_TWO, _stack(features_a), _stack(features_b), S, sinkhorn_lambda,
+                nr_sinkhorn_iter, COST_COSINE)
+
+
+def get_matched_features_single_batch(features_a, features_b, sinkhorn_lambda, nr_sinkhorn_iter):
+    """Single-batch matching (reference utils/matching.py:88-136)."""
+    _check_lists(features_a, features_b)
+    return _run(_MODE_SINGLE, _stack(features_a), _stack(features_b), len(features_a),
+                sinkhorn_lambda, nr_sinkhorn_iter, COST_COSINE)
+
+
+def get_matched_features_random(features_a, features_b):
+    """Random matching baseline (reference utils/matching.py:3-9)."""
+    features_a, features_b = list(features_a), list(features_b)
+    features_a_a = features_a[1:] + features_a[:1]
+    features_b_b = features_b[1:] + features_b[:1]
+    zero = torch.zeros((), dtype=torch.float32, device=features_a[0].device)
+    return MatchedFeatures((features_a_a, features_b_b, features_b, features_a, zero))
+
+
+def calc_distance(features_a, features_b, matched_features):
+    """(sum_i nd_bb + nd_aa - 2 nd_ab) / (2*B*S), fp64 accumulation (matching.py:139-153).
+    Returns a 0-d float64 CUDA tensor."""
+    S = len(features_a)
+    B = features_a[0].shape[0]
+    f_aa, f_bb, f_ab = matched_features[0], matched_features[1], matched_features[2]
+    a, b = _stack(features_a), _stack(features_b)
+    aa, bb, ab = _stack(f_aa), _stack(f_bb), _stack(f_ab)
+    if not a.is_cuda:
+        raise _lib.OtganError("calc_distance needs CUDA (MI355X) tensors; there is no CPU fallback")
+    rows, D = a.shape
+    dist = torch.empty((), dtype=torch.float64, device=a.device)
+    scratch = torch.empty(4, dtype=torch.float64, device=a.device)
+    rc = _lib.lib().otgan_calc_distance_f32(a.data_ptr(), b.data_ptr(), aa.data_ptr(),
+                                            bb.data_ptr(), ab.data_ptr(), rows, D,
+                                            float(2 * B * S), dist.data_ptr(), scratch.data_ptr(),
+                                            _lib.stream_ptr())
+    _lib.check(rc, "otgan_calc_distance_f32")
+    return dist
+
+
+def closed_form_distance(matched_features):
+    """Cancellation-free two-batch / single-batch distance from the per-problem statistics
+    {sum(M), <M,C>} produced by the Sinkhorn kernel:
+    nd = sum(M) - <M,C> per problem.  0-d float64 tensor, no extra kernel."""
+    st = matched_features.stats
+    T = st[:, 2] - st[:, 1]
+    if st.shape[0] == 6:   # a1a2, b2b1, a1b1, a1b2, a2b1, a2b2
+        rows2 = matched_features.flat[0].shape[0]  # 2N
+        return (2 * T[0] + 2 * T[1] - (T[2] + T[3] + T[4] + T[5])) / (2.0 * rows2)
+    rows = matched_features.flat[0].shape[0]
+    return (T[1] + T[0] - 2 * T[2]) / (2.0 * rows)
+
+
+# ---- toy variant (reference toy_example/matching_cpu.py) ------------------------------------
+def toy_get_matched_features(features_a, features_b, sinkhorn_lambda, nr_sinkhorn_iter):
+    """Plain `[2N, n]` tensors, squared-Euclidean/(2n) cost (matching_cpu.py:4-95)."""
+    fa = features_a.detach().contiguous()
+    fb = features_b.detach().contiguous()
+    res = _run(_MODE_TWO, fa, fb, 1, sinkhorn_lambda, nr_sinkhorn_iter, COST_SQEUCLID_MEAN)
+    out = MatchedFeatures((*res.flat, res[4]))
+    out.flat, out.distance, out.stats = res.flat, res.distance, res.stats
+    return out
+
+
+def toy_calc_distance(features_a, features_b, matched_features):
+    """(mean(b*bb) + mean(a*aa) - 2 mean(a*ab)) / 2 (matching_cpu.py:155-164)."""
+    a = features_a.detach().contiguous()
+    b = features_b.detach().contiguous()
+    aa, bb, ab = [m.contiguous() for m in matched_features[:3]]
+    rows, D = a.shape
+    dist = torch.empty((), dtype=torch.float64, device=a.device)
+    scratch = torch.empty(4, dtype=torch.float64, device=a.device)
+    rc = _lib.lib().otgan_calc_distance_f32(a.data_ptr(), b.data_ptr(), aa.data_ptr(),
+                                            bb.data_ptr(), ab.data_ptr(), rows, D,
+                                            float(2 * rows * D), dist.data_ptr(),
+                                            scratch.data_ptr(), _lib.stream_ptr())
+    _lib.check(rc, "otgan_calc_distance_f32")
+    return dist

@@ -1,0 +1,50 @@
+"""CPU: the C-ABI library loads and exports every symbol the headers declare, and the
+ctypes binding covers all of them (no compute calls here -- no GPU in this tier)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def _declared():
+    names = set()
+    for h in ("otgan.h", "otgan_layers.h"):
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(otgan_[a-z0-9_]+)\s*\(", txt))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    from otgan_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build with __graft_entry__.build()"
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    decl = _declared()
+    assert len(decl) >= 14
+    for n in sorted(decl):
+        assert hasattr(L, n), f"{n} declared in include/ but not exported"
+
+
+def test_binding_covers_header():
+    from otgan_amd import _lib
+    assert set(_lib.SIGNATURES) == _declared()
+
+
+def test_version_and_workspace_queries():
+    from otgan_amd import _lib
+    L = _lib.lib()
+    assert L.otgan_version() == 1
+    assert L.otgan_matching_workspace_bytes(0, 128, 32768) > 6 * 128 * 128 * 4 * 3
+    assert L.otgan_matching_workspace_bytes(1, 256, 7296) > 0
+    assert L.otgan_matching_workspace_bytes(0, 0, 16) == 0
+
+
+def test_no_cpu_fallback():
+    import pytest
+    import torch
+    from otgan_amd import _lib
+    from otgan_amd.utils import matching
+    x = torch.zeros(4, 8)
+    with pytest.raises(_lib.OtganError):
+        matching.get_matched_features([x, x], [x, x], 1.0, 1)

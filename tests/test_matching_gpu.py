@@ -1,0 +1,294 @@
+"""GPU parity tests of the matching block: HIP path (through the C ABI) vs the oracle
+(oracle/matching_np.py, fp64) and the reference-generated golden vectors.
+
+Tolerances (floating point): the HIP path computes in fp32 with fp64
+scalar accumulation; with lambda = 500 a 1e-7 cost error is a 5e-5 perturbation of the
+log-kernel, so matched features are compared in relative L2 norm at 2e-4 and the scalar
+loss at 1e-4 relative (+1e-7 absolute) -- the north-star tolerance."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import matching_np as M
+
+pytestmark = pytest.mark.gpu
+
+REL_FEAT = 2e-4
+REL_LOSS = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from otgan_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def _t(x, dev):
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32), device=dev)
+
+
+def _rel(got, ref):
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    return np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
+
+
+def test_single_hip_runtime_loaded(dev):
+    # the library must share torch's HIP runtime (one libamdhip64 in the process)
+    maps = open("/proc/self/maps").read()
+    libs = {l.split()[-1] for l in maps.splitlines() if "libamdhip64" in l}
+    assert len(libs) == 1, libs
+    assert any("libotgan_hip.so" in l for l in maps.splitlines())
+
+
+# ------------------------------------------------------------------ staged entry points
+@pytest.mark.parametrize("n,m,D", [(128, 128, 256), (40, 72, 100), (130, 257, 1030), (64, 64, 2)])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_cost_matrix(dev, n, m, D, kind):
+    from otgan_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(n + m + D)
+    X = rng.randn(n, D)
+    Y = rng.randn(m, D) + 0.3          # X != Y, n != m: catches operand / output transposes
+    if kind == 0:
+        X /= np.linalg.norm(X, axis=1, keepdims=True)
+        Y /= np.linalg.norm(Y, axis=1, keepdims=True)
+        C = M.cosine_cost(X, Y)
+    else:
+        C = M.sqeuclid_mean_cost(X, Y)
+    lam, diag = 7.5, 3.0
+    ref = -lam * (C + diag * np.eye(n, m))
+    x, y = _t(X, dev), _t(Y, dev)
+    K = torch.empty(n, m, device=dev)
+    need = L.otgan_cost_matrix_workspace_bytes(n, m, D)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    rc = L.otgan_cost_matrix_f32(x.data_ptr(), y.data_ptr(), n, m, D, D, lam, kind, diag,
+                                 K.data_ptr(), ws.data_ptr(), need, _lib.stream_ptr())
+    _lib.check(rc, "cost")
+    got = K.cpu().numpy()
+    # absolute error: fp32 dot of length D with |x|,|y| ~ 1 (cosine) or ~sqrt(D) (toy)
+    scale = lam * (1.0 if kind == 0 else float(np.abs(C).max()))
+    assert np.abs(got - ref).max() < 2e-5 * scale + 1e-5
+
+
+@pytest.mark.parametrize("P,n,m,iters", [(6, 128, 128, 50), (3, 40, 72, 13), (2, 200, 136, 21),
+                                         (1, 1, 1, 3), (2, 128, 96, 0)])
+def test_sinkhorn_plan(dev, P, n, m, iters):
+    from otgan_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(P * 1000 + n + m)
+    lam = 500.0
+    C = rng.rand(P, n, m) * 0.3
+    Kh = (-lam * C).astype(np.float32)
+    K = torch.as_tensor(Kh, device=dev)
+    plan = torch.empty(P, n, m, device=dev)
+    planT = torch.empty(P, m, n, device=dev)
+    stats = torch.empty(P, 4, dtype=torch.float64, device=dev)
+    need = max(L.otgan_sinkhorn_workspace_bytes(P, n, m), 256)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    rc = L.otgan_sinkhorn_plan_f32(K.data_ptr(), P, n, m, iters, lam, plan.data_ptr(),
+                                   planT.data_ptr(), stats.data_ptr(), ws.data_ptr(), need,
+                                   _lib.stream_ptr())
+    _lib.check(rc, "sinkhorn")
+    got, gotT, st = plan.cpu().numpy(), planT.cpu().numpy(), stats.cpu().numpy()
+    for p in range(P):
+        Cp = -Kh[p].astype(np.float64) / lam       # the cost the kernel actually saw
+        Mref, ent, _ = M.sinkhorn_plan(Cp, lam, iters)
+        assert _rel(got[p], Mref) < 1e-4
+        np.testing.assert_array_equal(gotT[p], got[p].T)      # same bits, transposed
+        np.testing.assert_allclose(got[p].sum(1), 1.0, rtol=0, atol=5e-6)
+        assert st[p, 0] / n == pytest.approx(ent, rel=1e-4, abs=1e-6)
+        assert st[p, 1] == pytest.approx(np.sum(Mref * Cp), rel=1e-4)
+        assert st[p, 2] == pytest.approx(n, rel=1e-5)
+
+
+def test_sinkhorn_single_batch_diagonal(dev):
+    # -lambda*999 on the diagonal (matching.py:109): needs the max-shifted LSE
+    from otgan_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(5)
+    n, lam, iters = 96, 500.0, 30
+    C = rng.rand(n, n) * 0.2 + 999.0 * np.eye(n)
+    Kh = (-lam * C).astype(np.float32)
+    K = torch.as_tensor(Kh[None], device=dev)
+    plan = torch.empty(1, n, n, device=dev)
+    planT = torch.empty(1, n, n, device=dev)
+    stats = torch.empty(1, 4, dtype=torch.float64, device=dev)
+    ws = torch.empty(4096, dtype=torch.uint8, device=dev)
+    _lib.check(L.otgan_sinkhorn_plan_f32(K.data_ptr(), 1, n, n, iters, lam, plan.data_ptr(),
+                                         planT.data_ptr(), stats.data_ptr(), ws.data_ptr(), 4096,
+                                         _lib.stream_ptr()), "sinkhorn")
+    Mref, ent, _ = M.sinkhorn_plan(-Kh.astype(np.float64) / lam, lam, iters)
+    got = plan.cpu().numpy()[0]
+    assert np.all(np.diag(got) == 0.0)
+    assert _rel(got, Mref) < 1e-4
+    assert np.isfinite(stats.cpu().numpy()).all()
+
+
+@pytest.mark.parametrize("rows,kdim,D", [(128, 128, 256), (40, 72, 100), (130, 257, 515)])
+def test_plan_apply(dev, rows, kdim, D):
+    from otgan_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(rows + kdim + D)
+    P = rng.rand(rows, kdim)
+    F = rng.randn(kdim, D)
+    p, f = _t(P, dev), _t(F, dev)
+    out = torch.empty(rows, D, device=dev)
+    _lib.check(L.otgan_plan_apply_f32(p.data_ptr(), kdim, rows, kdim, f.data_ptr(), D, D, 0.5,
+                                      out.data_ptr(), D, _lib.stream_ptr()), "apply")
+    ref = 0.5 * (P.astype(np.float32).astype(np.float64) @ F.astype(np.float32).astype(np.float64))
+    assert _rel(out.cpu().numpy(), ref) < 2e-6
+
+
+# ------------------------------------------------------------------ operator API vs golden
+def test_two_batch_vs_golden(dev, list_case):
+    from otgan_amd.utils import matching
+    g = list_case
+    fa = [_t(x, dev) for x in g["fa"]]
+    fb = [_t(x, dev) for x in g["fb"]]
+    out = matching.get_matched_features(fa, fb, float(g["lam"]), int(g["iters"]))
+    for k, got in zip(("aa", "bb", "ab", "ba"), out[:4]):
+        assert len(got) == len(fa)
+        assert _rel(torch.stack(got).cpu().numpy(), g["two_" + k]) < REL_FEAT, k
+    assert float(out[4]) == pytest.approx(float(g["two_entropy"]), rel=2e-4)
+    d = float(matching.calc_distance(fa, fb, out))
+    ref = float(g["two_distance"])
+    assert abs(d - ref) <= REL_LOSS * abs(ref) + 1e-7, (d, ref)
+    d2 = float(out.distance)                      # fused evaluation of the same formula
+    assert abs(d2 - ref) <= REL_LOSS * abs(ref) + 1e-7
+    d3 = float(matching.closed_form_distance(out))  # cancellation-free closed form
+    assert abs(d3 - ref) <= REL_LOSS * abs(ref) + 1e-7
+
+
+def test_single_batch_vs_golden(dev, list_case):
+    from otgan_amd.utils import matching
+    g = list_case
+    fa = [_t(x, dev) for x in g["fa"]]
+    fb = [_t(x, dev) for x in g["fb"]]
+    out = matching.get_matched_features_single_batch(fa, fb, float(g["lam"]), int(g["iters"]))
+    for k, got in zip(("aa", "bb", "ab", "ba"), out[:4]):
+        assert _rel(torch.stack(got).cpu().numpy(), g["single_" + k]) < REL_FEAT, k
+    assert float(out[4]) == pytest.approx(float(g["single_entropy"]), rel=2e-4)
+    d = float(matching.calc_distance(fa, fb, out))
+    ref = float(g["single_distance"])
+    assert abs(d - ref) <= REL_LOSS * abs(ref) + 1e-7
+    d3 = float(matching.closed_form_distance(out))
+    assert abs(d3 - ref) <= REL_LOSS * abs(ref) + 1e-7
+
+
+def test_random_vs_golden(dev, list_case):
+    from otgan_amd.utils import matching
+    g = list_case
+    fa = [_t(x, dev) for x in g["fa"]]
+    fb = [_t(x, dev) for x in g["fb"]]
+    out = matching.get_matched_features_random(fa, fb)
+    assert float(out[4]) == 0.0
+    d = float(matching.calc_distance(fa, fb, out))
+    assert d == pytest.approx(float(g["random_distance"]), rel=1e-5)
+
+
+@pytest.mark.parametrize("name", ["survey", "toy_gauss2d_b64"])
+def test_toy_vs_golden(dev, name):
+    # BASELINE config 1: toy_example/matching_cpu.py, batch 64, 50 iterations
+    from otgan_amd.utils import matching
+    g = load_golden(name)
+    a, b = _t(g["toy_a"], dev), _t(g["toy_b"], dev)
+    out = matching.toy_get_matched_features(a, b, float(g["toy_lam"]), int(g["toy_iters"]))
+    for k, got in zip(("aa", "bb", "ab", "ba"), out[:4]):
+        assert _rel(got.cpu().numpy(), g["toy_" + k]) < REL_FEAT, k
+    assert float(out[4]) == pytest.approx(float(g["toy_entropy"]), rel=2e-4)
+    d = float(matching.toy_calc_distance(a, b, out))
+    ref = float(g["toy_distance"])
+    assert abs(d - ref) <= REL_LOSS * abs(ref) + 1e-7
+    assert float(out.distance) == pytest.approx(ref, rel=REL_LOSS)
+
+
+# ------------------------------------------------------------------ BASELINE sizes
+def _clustered(seed, S, B, D):
+    rng = np.random.RandomState(seed)
+    ca, cb = rng.randn(32, D), rng.randn(32, D)
+    fa = np.stack([M.clustered_features(rng, B, D, ca) for _ in range(S)])
+    fb = np.stack([M.clustered_features(rng, B, D, cb) for _ in range(S)])
+    return fa.astype(np.float32), fb.astype(np.float32)
+
+
+@pytest.mark.parametrize("S,B,D,iters", [(2, 128, 32768, 100),    # cfg2: DCGAN width, N=128
+                                         (2, 256, 7296, 200),     # cfg4 width, N=256 (general path)
+                                         ])
+def test_full_size_vs_oracle(dev, S, B, D, iters):
+    from otgan_amd.utils import matching
+    fa, fb = _clustered(2, S, B, D)
+    lam = 500.0
+    A = [_t(x, dev) for x in fa]
+    Bt = [_t(x, dev) for x in fb]
+    out = matching.get_matched_features(A, Bt, lam, iters)
+    ref = M.get_matched_features(list(fa), list(fb), lam, iters)      # fp64 on the fp32 inputs
+    dref = float(M.calc_distance(list(fa), list(fb), ref))
+    for k, got, want in zip("aa bb ab ba".split(), out[:4], ref[:4]):
+        assert _rel(torch.stack(got).cpu().numpy(), np.stack(want)) < REL_FEAT, k
+    # injected gradient (train.py:111): f_aa - f_ab
+    ga = (torch.stack(out[0]) - torch.stack(out[2])).cpu().numpy()
+    gr = np.stack(ref[0]) - np.stack(ref[2])
+    assert _rel(ga, gr) < 2e-3
+    assert float(out[4]) == pytest.approx(float(ref[4]), rel=2e-4)
+    for d in (float(out.distance), float(matching.calc_distance(A, Bt, out)),
+              float(matching.closed_form_distance(out))):
+        assert abs(d - dref) <= REL_LOSS * abs(dref) + 1e-7, (d, dref)
+    # size-independent properties: plan rows sum to one -> sum(M) == N per problem
+    st = out.stats.cpu().numpy()
+    np.testing.assert_allclose(st[:, 2], (S // 2) * B, rtol=1e-5)
+
+
+def test_exact_iteration_count(dev):
+    # F10b: L and L+1 sweeps must give different (un-converged) results: no early exit
+    from otgan_amd.utils import matching
+    fa, fb = _clustered(3, 2, 64, 512)
+    A = [_t(x, dev) for x in fa]
+    Bt = [_t(x, dev) for x in fb]
+    d = [float(matching.get_matched_features(A, Bt, 500.0, L).distance) for L in (5, 6, 50)]
+    r = [float(M.calc_distance(list(fa), list(fb), M.get_matched_features(list(fa), list(fb), 500.0, L)))
+         for L in (5, 6, 50)]
+    for x, y in zip(d, r):
+        assert abs(x - y) <= REL_LOSS * abs(y) + 1e-7
+    assert d[0] != d[1]
+
+
+def test_permutation_equivariance(dev):
+    from otgan_amd.utils import matching
+    fa, fb = _clustered(4, 2, 48, 256)
+    A = [_t(x, dev) for x in fa]
+    Bt = [_t(x, dev) for x in fb]
+    out = matching.get_matched_features(A, Bt, 300.0, 20)
+    perm = torch.randperm(48, device=dev)
+    out2 = matching.get_matched_features([A[0][perm], A[1]], Bt, 300.0, 20)
+    assert _rel(out2[0][0].cpu().numpy(), out[0][0][perm].cpu().numpy()) < 1e-5
+    assert float(out2[4]) == pytest.approx(float(out[4]), rel=1e-5)
+
+
+# ------------------------------------------------------------------ error behaviour of the ABI
+def test_abi_errors(dev):
+    from otgan_amd import _lib
+    L = _lib.lib()
+    x = torch.zeros(8, 16, device=dev)
+    o = torch.zeros(8, 16, device=dev)
+    e = torch.zeros((), device=dev)
+    d = torch.zeros((), dtype=torch.float64, device=dev)
+    ws = torch.zeros(16, dtype=torch.uint8, device=dev)
+    rc = L.otgan_matching_two_batch_f32(x.data_ptr(), x.data_ptr(), 4, 16, 16, 1.0, 1, 0,
+                                        o.data_ptr(), o.data_ptr(), o.data_ptr(), o.data_ptr(), 16,
+                                        e.data_ptr(), d.data_ptr(), None, ws.data_ptr(), 16, None)
+    assert rc == -2 and b"workspace" in L.otgan_last_error()
+    rc = L.otgan_matching_two_batch_f32(None, x.data_ptr(), 4, 16, 16, 1.0, 1, 0,
+                                        o.data_ptr(), o.data_ptr(), o.data_ptr(), o.data_ptr(), 16,
+                                        e.data_ptr(), d.data_ptr(), None, ws.data_ptr(), 16, None)
+    assert rc == -1
+    from otgan_amd.utils import matching
+    with pytest.raises(ValueError):
+        matching.get_matched_features([x, x, x], [x, x, x], 1.0, 1)   # odd shard count (train.py:34)
+    with pytest.raises(_lib.OtganError):
+        matching.get_matched_features([x.cpu(), x.cpu()], [x.cpu(), x.cpu()], 1.0, 1)  # no CPU fallback
