@@ -1,4 +1,109 @@
-/* otgan_layers.h -- layer kernels of the generator / critic (included from otgan.h). */
+/*
+ * otgan_layers.h -- layer kernels of the OT-GAN generator / critic (included from otgan.h).
+ *
+ * Activations are NHWC fp32, weights HWIO fp32 ([KH][KW][Cin_eff][Cout]), exactly the
+ * layouts of the reference's TensorFlow graph, so parameter tensors are interchangeable.
+ * Spatial sizes must be powers of two (32x32 / 64x64 images and their pyramids).
+ */
 #ifndef OTGAN_LAYERS_H
 #define OTGAN_LAYERS_H
-#endif
+
+/* pre-activations of reference utils/nn.py:190-206 */
+#define OTGAN_ACT_NONE 0
+#define OTGAN_ACT_CRELU 1 /* relu(concat([x0,-x0,x1,-x1,...]))  -- doubles the channels */
+#define OTGAN_ACT_CELU 2  /* elu (concat([x0,-x0,x1,-x1,...]))  -- doubles the channels */
+#define OTGAN_ACT_ELU 3
+#define OTGAN_ACT_RELU 4
+
+/*
+ * Geometry of one conv2d layer (reference utils/nn.py:327-338 + :234-241).
+ * The (list of) input tensor(s) is ONE NHWC buffer with channel stride ldx whose first C
+ * channels are the concatenated list elements; the output is written at channel offset
+ * y_coff of a buffer with channel stride ldy (DenseNet blocks grow in place instead of
+ * re-concatenating, reference models/densenet.py:11-16).
+ * Derived: Cin_eff = C * (2 for CRELU/CELU, else 1); Hin = H << upsample;
+ * OH = ceil(Hin / stride); TF 'SAME': pad_before = max((OH-1)*stride + KH - Hin, 0) / 2.
+ */
+typedef struct otgan_conv_desc {
+  int N;        /* batch */
+  int H, W;     /* stored spatial size of the input buffer */
+  int C;        /* real input channels */
+  int ldx;      /* channel stride of the input buffer (>= C) */
+  int upsample; /* 1: 2x nearest-neighbour resize before the conv (nn.py:235-236) */
+  int KH, KW;
+  int stride;   /* 1 or 2 */
+  int Cout;
+  int ldy;      /* channel stride of the output buffer */
+  int y_coff;   /* channel offset of this layer's output inside the output buffer */
+  int preact;   /* OTGAN_ACT_* */
+} otgan_conv_desc;
+
+/*
+ * Channel maps (device int32 arrays, may be NULL for a single-tensor input):
+ *   cmap[d], d in [0, Cin_eff): source channel (low 31 bits) and sign (bit 31 set = negate)
+ *            of effective channel d -- encodes the reference's per-list-element interleave
+ *            [x0,-x0,x1,-x1,...] (nn.py:198,200).  NULL = [x, -x] / identity.
+ *   inv[c], inv[C + c]: effective index of (+x_c) and (-x_c); used by dgrad.  NULL = c, C+c.
+ */
+
+/* which: 0 fwd, 1 dgrad, 2 wgrad */
+size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which);
+
+/* y = conv2d(preact(upsample(x)), W) + bias.   wT: [Cout][KH*KW*Cin_eff] (transposed copy
+ * of the HWIO weight, produced by otgan_weightnorm_fwd_f32).  nn.py:241,337. */
+int otgan_conv2d_fwd_f32(const otgan_conv_desc* d, const float* x, const int32_t* cmap,
+                         const float* wT, const float* bias, float* y, void* stream);
+
+/* dx (+)= d(loss)/d(x) given dy; w is the HWIO weight.  x (the layer input) is needed for
+ * the activation derivative.  dx: [N,H,W,lddx] (first C channels written).
+ * accumulate != 0 adds into dx (DenseNet gradient buffers). */
+int otgan_conv2d_dgrad_f32(const otgan_conv_desc* d, const float* dy, const float* w,
+                           const float* x, const int32_t* inv, float* dx, int lddx,
+                           int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* dw[KH][KW][Cin_eff][Cout] = sum over pixels of preact(x)^T . dy  (overwrites dw). */
+int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32_t* cmap,
+                           const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
+/* ---- weight normalisation (nn.py:176-181): w = g * V / max(||V||_col, 1e-12) ------------
+ * V, w: [K][Cout] (K = KH*KW*Cin_eff), wT: [Cout][K] (nullable), inv_norm: [Cout].        */
+int otgan_weightnorm_fwd_f32(const float* V, const float* g, int K, int Cout, float* w,
+                             float* wT, float* inv_norm, void* stream);
+/* dV, dg from dw (scratch: Cout floats). */
+int otgan_weightnorm_bwd_f32(const float* V, const float* g, const float* inv_norm,
+                             const float* dw, int K, int Cout, float* dV, float* dg,
+                             float* scratch, void* stream);
+
+/* out[c] = sum_r a[r*lda + c]   (bias gradients; rows = pixels).  scratch: 64*cols floats */
+int otgan_colsum_f32(const float* a, long rows, int cols, long lda, float* out, float* scratch,
+                     void* stream);
+
+/* ---- pointwise blocks ------------------------------------------------------------------ */
+/* GLU (models/dcgan.py:35-36): y[r, c] = x[r, c] * sigmoid(x[r, C + c]), x: [rows, 2C].    */
+int otgan_glu_fwd_f32(const float* x, long rows, int C, float* y, void* stream);
+int otgan_glu_bwd_f32(const float* x, const float* dy, long rows, int C, float* dx, void* stream);
+/* tanh output (models/dcgan.py:50) */
+int otgan_tanh_fwd_f32(const float* x, long n, float* y, void* stream);
+int otgan_tanh_bwd_f32(const float* y, const float* dy, long n, float* dx, void* stream);
+/* Feature head (models/dcgan.py:16-19): f = concat([relu(x), relu(-x)], channel), flatten
+ * (h, w, c), L2-normalise rows (no epsilon).  x: [N, HW, C] -> f: [N, HW*2C].
+ * norm: [N] saved row norms for the backward pass. */
+int otgan_feature_head_fwd_f32(const float* x, int N, int HW, int C, float* f, float* norm,
+                               void* stream);
+int otgan_feature_head_bwd_f32(const float* x, const float* f, const float* norm,
+                               const float* df, int N, int HW, int C, float* dx, void* stream);
+
+/* ---- optimiser / EMA (utils/nn.py:50-73, train.py:63-64) --------------------------------
+ * Adam with the reference's epsilon placement:  p -= lr * vhat / sqrt(mghat + 1e-8),
+ * vhat = v/(1-mom1^t), mghat = mg/(1-mom2^t); mom1 == 0 skips the first moment.          */
+int otgan_adam_step_f32(float* p, const float* grad, float* v, float* mg, long n, float lr,
+                        float mom1, float mom2, float t, void* stream);
+int otgan_adamax_step_f32(float* p, const float* grad, float* v, float* mg, long n, float lr,
+                          float mom1, float mom2, void* stream);
+int otgan_nesterov_step_f32(float* p, const float* grad, float* v, long n, float lr, float mom1,
+                            void* stream);
+/* shadow = decay*shadow + (1-decay)*p */
+int otgan_ema_update_f32(float* shadow, const float* p, long n, float decay, void* stream);
+
+#endif /* OTGAN_LAYERS_H */

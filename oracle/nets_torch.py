@@ -1,0 +1,250 @@
+"""PyTorch restatement of the reference's layers and models (CPU or GPU, any dtype).
+
+TEST INFRASTRUCTURE ONLY -- the "plain PyTorch reference of the same op" the HIP layer
+kernels are compared against (fp64 on CPU, or fp32 on the GPU), and the nets of the
+`cpu_baseline` leg of bench.py.  Never imported by the product path (ot-gan_amd/).
+
+The reference's models cannot be imported here (TensorFlow-1.x graph API: tf.make_template,
+arg_scope, tf.get_variable ...), so this file restates them from:
+    utils/nn.py:103-183   get_params (weight norm, non-init branch)
+    utils/nn.py:190-206   apply_pre_activation (list interleave [x0,-x0,x1,-x1,...])
+    utils/nn.py:234-241   conv (NHWC x HWIO, TF 'SAME', optional 2x NN upsample first)
+    utils/nn.py:314-338   dense / conv2d (+ bias)
+    utils/nn.py:29-87     adam / adamax / nesterov updates
+    models/dcgan.py:7-52, models/densenet.py:7-88
+"Parity unpinned" by the reference (it has no numeric fixtures for the nets): pins are the
+layer semantics above plus shapes (D = 32768 / 7296, output [B,32,32,3] in (-1,1)).
+
+Activations are NHWC like the reference; torch's conv wants NCHW, so tensors are permuted
+around F.conv2d.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def apply_pre_activation(xs, pre, axis=3):
+    """nn.py:190-206"""
+    if not isinstance(xs, (list, tuple)):
+        xs = [xs]
+    if pre is None:
+        return torch.cat(list(xs), axis)
+    if pre == "celu":
+        return F.elu(torch.cat([s for x in xs for s in (x, -x)], axis))
+    if pre == "crelu":
+        return F.relu(torch.cat([s for x in xs for s in (x, -x)], axis))
+    if pre == "elu":
+        return F.elu(torch.cat(list(xs), axis))
+    if pre == "relu":
+        return F.relu(torch.cat(list(xs), axis))
+    raise ValueError("unsupported pre-activation")
+
+
+def weight_norm(V, g):
+    """nn.py:176-181: W = l2_normalize(V, all axes but the last) * g  (epsilon 1e-12 under max)"""
+    axes = tuple(range(V.dim() - 1))
+    ss = (V * V).sum(axes, keepdim=True)
+    return V * torch.rsqrt(torch.clamp(ss, min=1e-12)) * g
+
+
+def tf_same_pads(n, k, s):
+    out = -(-n // s)
+    tot = max((out - 1) * s + k - n, 0)
+    return tot // 2, tot - tot // 2
+
+
+def conv2d_nhwc(x, W, stride):
+    """tf.nn.conv2d(x, W, [1,s,s,1], 'SAME') with NHWC x and HWIO W (nn.py:241)."""
+    kh, kw = W.shape[0], W.shape[1]
+    pt, pb = tf_same_pads(x.shape[1], kh, stride)
+    pl, pr = tf_same_pads(x.shape[2], kw, stride)
+    xn = F.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb))
+    y = F.conv2d(xn, W.permute(3, 2, 0, 1), stride=stride)
+    return y.permute(0, 2, 3, 1)
+
+
+def upsample2(x):
+    """tf.image.resize_nearest_neighbor(x, [2H, 2W]) -- exact 2x replication"""
+    return x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+
+
+def conv2d(xs, p, pre=None, stride=1, upsample=False):
+    """nn.py:327-338 with weight norm.  p = {'V','g','b'}"""
+    if not isinstance(xs, (list, tuple)):
+        xs = [xs]
+    if upsample:
+        xs = [upsample2(torch.cat(list(xs), 3))]
+    x = apply_pre_activation(xs, pre, 3)
+    y = conv2d_nhwc(x, weight_norm(p["V"], p["g"]), stride)
+    return y + p["b"]
+
+
+def dense(x, p, pre=None):
+    """nn.py:314-325"""
+    x = apply_pre_activation(x, pre, 1)
+    return x @ weight_norm(p["V"], p["g"]) + p["b"]
+
+
+def feature_head(x):
+    """models/dcgan.py:16-19"""
+    x = torch.cat([F.relu(x), F.relu(-x)], 3)
+    x = x.reshape(x.shape[0], -1)
+    return x / torch.sqrt((x * x).sum(1, keepdim=True))
+
+
+def glu(x, axis):
+    a, l = torch.chunk(x, 2, axis)
+    return a * torch.sigmoid(l)
+
+
+# ----------------------------------------------------------------------------- parameter shapes
+def _crelu_mult(pre):
+    return 2 if pre in ("crelu", "celu") else 1
+
+
+def dcgan_disc_shapes(nonlinearity="crelu"):
+    m = _crelu_mult(nonlinearity)
+    return [("conv2d_0", (5, 5, 3, 128)), ("conv2d_1", (5, 5, 128 * m, 256)),
+            ("conv2d_2", (5, 5, 256 * m, 512)), ("conv2d_3", (5, 5, 512 * m, 1024))]
+
+
+def dcgan_gen_shapes():
+    return [("dense_0", (100, 2 * 4 * 4 * 1024)), ("conv2d_0", (5, 5, 1024, 1024)),
+            ("conv2d_1", (5, 5, 512, 512)), ("conv2d_2", (5, 5, 256, 256)),
+            ("conv2d_3", (5, 5, 128, 3))]
+
+
+def densenet_disc_shapes(nonlinearity="crelu", L=16, Fg=16):
+    m = _crelu_mult(nonlinearity)
+    shapes = [("conv2d_0", (3, 3, 3, 2 * Fg))]
+    c, k = 2 * Fg, 1
+    for _blk in range(3):
+        for _ in range(L):
+            shapes.append((f"conv2d_{k}", (3, 3, c * m, Fg)))
+            c += Fg
+            k += 1
+        shapes.append((f"conv2d_{k}", (3, 3, c * m, c // 2)))
+        c //= 2
+        k += 1
+    return shapes
+
+
+def densenet_gen_shapes(nonlinearity="crelu", L=16, Fg=16):
+    m = _crelu_mult(nonlinearity)
+    shapes = [("dense_0", (100, 8 * 8 * Fg))]
+    c, k = 2 * Fg, 0
+    for blk in range(3):
+        for _ in range(L):
+            shapes.append((f"conv2d_{k}", (3, 3, c * m, Fg)))
+            c += Fg
+            k += 1
+        if blk < 2:
+            shapes.append((f"conv2d_{k}", (3, 3, c * m, c // 2)))
+            c = c // 2 + Fg
+            k += 1
+    shapes.append((f"conv2d_{k}", (3, 3, c * m, 3)))
+    return shapes
+
+
+def init_params(shapes, scope, gen, dtype=torch.float32, device="cpu"):
+    """Effective init of the reference: V ~ N(0, 0.05), g = 1, b = 0."""
+    params = {}
+    for name, shp in shapes:
+        V = torch.empty(shp, dtype=dtype).normal_(0.0, 0.05, generator=gen)
+        params[f"{scope}/{name}"] = {"V": V.to(device), "g": torch.ones(shp[-1], dtype=dtype, device=device),
+                                     "b": torch.zeros(shp[-1], dtype=dtype, device=device)}
+    return params
+
+
+# ----------------------------------------------------------------------------- DCGAN
+def dcgan_discriminator(x, P, nonlinearity="crelu", scope="discriminator"):
+    """models/dcgan.py:7-22"""
+    x = conv2d(x, P[f"{scope}/conv2d_0"], None)
+    x = conv2d(x, P[f"{scope}/conv2d_1"], nonlinearity, 2)
+    x = conv2d(x, P[f"{scope}/conv2d_2"], nonlinearity, 2)
+    x = conv2d(x, P[f"{scope}/conv2d_3"], nonlinearity, 2)
+    return feature_head(x)
+
+
+def dcgan_generator(u, P, scope="generator"):
+    """models/dcgan.py:28-52; u: [B,100] uniform(-1,1) noise"""
+    B = u.shape[0]
+    x = glu(dense(u, P[f"{scope}/dense_0"], None), 1).reshape(B, 4, 4, 1024)
+    x = glu(conv2d(x, P[f"{scope}/conv2d_0"], None, 1, True), 3)
+    x = glu(conv2d(x, P[f"{scope}/conv2d_1"], None, 1, True), 3)
+    x = glu(conv2d(x, P[f"{scope}/conv2d_2"], None, 1, True), 3)
+    return torch.tanh(conv2d(x, P[f"{scope}/conv2d_3"], None))
+
+
+# ----------------------------------------------------------------------------- DenseNet
+def densenet_discriminator(x, P, nonlinearity="crelu", L=16, scope="discriminator"):
+    """models/densenet.py:7-45"""
+    k = [0]
+
+    def nxt():
+        p = P[f"{scope}/conv2d_{k[0]}"]
+        k[0] += 1
+        return p
+
+    x = conv2d(x, nxt(), None)
+    for _ in range(3):
+        xs = [x]
+        for _r in range(L):
+            xs.append(conv2d(xs, nxt(), nonlinearity))
+        x = conv2d(xs, nxt(), nonlinearity, 2)
+    return feature_head(x)
+
+
+def densenet_generator(us, P, nonlinearity="crelu", L=16, Fg=16, scope="generator"):
+    """models/densenet.py:51-88; us = [u0 [B,100], u1 [B,8,8,F], u2 [B,16,16,F], u3 [B,32,32,F]]"""
+    B = us[0].shape[0]
+    k = [0]
+
+    def nxt():
+        p = P[f"{scope}/conv2d_{k[0]}"]
+        k[0] += 1
+        return p
+
+    x = dense(us[0], P[f"{scope}/dense_0"], None).reshape(B, 8, 8, Fg)
+    xs = [x, us[1]]
+    for blk in range(3):
+        for _r in range(L):
+            xs.append(conv2d(xs, nxt(), nonlinearity))
+        if blk < 2:
+            x = conv2d(xs, nxt(), nonlinearity, 1, True)
+            xs = [x, us[blk + 2]]
+    return torch.tanh(conv2d(xs, nxt(), nonlinearity))
+
+
+# ----------------------------------------------------------------------------- optimisers
+def adam_update(p, g, state, lr, mom1=0.9, mom2=0.999):
+    """nn.py:50-73 (epsilon inside the sqrt; t starts at 1 and is shared per optimiser)"""
+    t = state["t"]
+    if mom1 > 0:
+        state["v"] = mom1 * state["v"] + (1 - mom1) * g
+        v_hat = state["v"] / (1 - mom1 ** t)
+    else:
+        v_hat = g
+    state["mg"] = mom2 * state["mg"] + (1 - mom2) * g * g
+    mg_hat = state["mg"] / (1 - mom2 ** t)
+    return p - lr * v_hat / torch.sqrt(mg_hat + 1e-8)
+
+
+def adamax_update(p, g, state, lr, mom1=0.9, mom2=0.999):
+    """nn.py:29-48"""
+    if mom1 > 0:
+        state["v"] = mom1 * state["v"] + (1 - mom1) * g
+        v_t = state["v"]
+    else:
+        v_t = g
+    state["mg"] = torch.maximum(mom2 * state["mg"] + 1e-8, g.abs())
+    return p - lr * v_t / state["mg"]
+
+
+def nesterov_update(p, g, state, lr, mom1=0.9):
+    """nn.py:75-87"""
+    v_new = mom1 * state["v"] - lr * g
+    p_new = p - mom1 * state["v"] + (1 + mom1) * v_new
+    state["v"] = v_new
+    return p_new

@@ -1,0 +1,37 @@
+"""ctypes signatures of the layer kernels declared in include/otgan_layers.h."""
+import ctypes
+
+c_fp = ctypes.c_void_p
+c_int, c_long, c_float, c_size_t = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of `otgan_conv_desc` (include/otgan_layers.h)."""
+    _fields_ = [("N", c_int), ("H", c_int), ("W", c_int), ("C", c_int), ("ldx", c_int),
+                ("upsample", c_int), ("KH", c_int), ("KW", c_int), ("stride", c_int),
+                ("Cout", c_int), ("ldy", c_int), ("y_coff", c_int), ("preact", c_int)]
+
+
+P_DESC = ctypes.POINTER(ConvDesc)
+
+SIGNATURES = {
+    "otgan_conv2d_workspace_bytes": (c_size_t, [P_DESC, c_int]),
+    "otgan_conv2d_fwd_f32": (c_int, [P_DESC, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "otgan_conv2d_dgrad_f32": (c_int, [P_DESC, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp,
+                                       c_size_t, c_fp]),
+    "otgan_conv2d_wgrad_f32": (c_int, [P_DESC, c_fp, c_fp, c_fp, c_fp, c_fp, c_size_t, c_fp]),
+    "otgan_weightnorm_fwd_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp]),
+    "otgan_weightnorm_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp]),
+    "otgan_colsum_f32": (c_int, [c_fp, c_long, c_int, c_long, c_fp, c_fp, c_fp]),
+    "otgan_glu_fwd_f32": (c_int, [c_fp, c_long, c_int, c_fp, c_fp]),
+    "otgan_glu_bwd_f32": (c_int, [c_fp, c_fp, c_long, c_int, c_fp, c_fp]),
+    "otgan_tanh_fwd_f32": (c_int, [c_fp, c_long, c_fp, c_fp]),
+    "otgan_tanh_bwd_f32": (c_int, [c_fp, c_fp, c_long, c_fp, c_fp]),
+    "otgan_feature_head_fwd_f32": (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp]),
+    "otgan_feature_head_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp]),
+    "otgan_adam_step_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_long, c_float, c_float, c_float,
+                                    c_float, c_fp]),
+    "otgan_adamax_step_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_long, c_float, c_float, c_float, c_fp]),
+    "otgan_nesterov_step_f32": (c_int, [c_fp, c_fp, c_fp, c_long, c_float, c_float, c_fp]),
+    "otgan_ema_update_f32": (c_int, [c_fp, c_fp, c_long, c_float, c_fp]),
+}

@@ -60,8 +60,13 @@ struct ProfScope {
   ~ProfScope() { otgan_prof_end(cls, s); }
 };
 
-static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
-static inline long ceil_div_l(long a, long b) { return (a + b - 1) / b; }
+#ifdef __HIPCC__
+#define OTGAN_HD __host__ __device__
+#else
+#define OTGAN_HD
+#endif
+OTGAN_HD static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+OTGAN_HD static inline long ceil_div_l(long a, long b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 #ifdef __HIPCC__

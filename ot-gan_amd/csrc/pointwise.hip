@@ -1,0 +1,409 @@
+// pointwise.hip -- HBM-bound blocks of the generator / critic and the optimiser:
+// weight normalisation (fwd/bwd), column reductions (bias gradients), GLU, tanh, the
+// CReLU + flatten + L2-normalise feature head (fwd/bwd), Adam / Adamax / Nesterov, EMA.
+// Replaces reference utils/nn.py:29-87,176-181 and models/dcgan.py:16-19,35-36,50.
+// All kernels are float4-vectorised, grid-stride, one pass over each array.
+#include "common.h"
+#include "../../include/otgan.h"
+
+namespace {
+
+constexpr int kChunks = 64;  // row chunks of the two-stage (deterministic) column reductions
+
+inline int grid_for(long n, int per_thread = 4) {
+  long b = ceil_div_l(n, 256L * per_thread);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ---- column reductions: partial[chunk][c] = sum_{r in chunk} op(a[r][c], b[r][c]) ----------
+// OP 0: a, 1: a*a, 2: a*b.   Block = 256 threads: lane = column (64 per block), 4 waves split
+// the chunk's rows; coalesced 256-byte row segments.
+template <int OP>
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ a,
+                                                        const float* __restrict__ b, long rows,
+                                                        int cols, long lda,
+                                                        float* __restrict__ partial) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int chunk = blockIdx.y;
+  const long per = ceil_div_l(rows, (long)gridDim.y);
+  const long r0 = chunk * per;
+  long r1 = r0 + per;
+  if (r1 > rows) r1 = rows;
+  float s = 0.f;
+  if (c < cols) {
+    for (long r = r0 + wave; r < r1; r += 4) {
+      const float av = a[r * lda + c];
+      if (OP == 0) s += av;
+      else if (OP == 1) s += av * av;
+      else s += av * b[r * lda + c];
+    }
+  }
+  __shared__ float red[4][64];
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && c < cols)
+    partial[(long)chunk * cols + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// MODE 0: out = sum; 1: out = rsqrt(max(sum, 1e-12))  (tf.nn.l2_normalize epsilon, nn.py:176)
+template <int MODE>
+__global__ void colreduce_finish_kernel(const float* __restrict__ partial, int nchunk, int cols,
+                                        float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int k = 0; k < nchunk; ++k) s += partial[(long)k * cols + c];
+  out[c] = MODE == 1 ? rsqrtf(fmaxf(s, 1e-12f)) : s;
+}
+
+template <int OP>
+int colreduce(const float* a, const float* b, long rows, int cols, long lda, float* partial,
+              int* nchunk_out, hipStream_t s) {
+  int nchunk = (int)(rows < 64 * kChunks ? ceil_div_l(rows, 64) : kChunks);
+  if (nchunk < 1) nchunk = 1;
+  dim3 grid(ceil_div(cols, 64), nchunk);
+  hipLaunchKernelGGL(colreduce_kernel<OP>, grid, dim3(256), 0, s, a, b, rows, cols, lda, partial);
+  *nchunk_out = nchunk;
+  OTGAN_CHECK_LAUNCH("colreduce");
+  return OTGAN_OK;
+}
+
+// ---- weight norm -----------------------------------------------------------------------------
+// w[k][c] = V[k][c] * g[c] * inv[c]; also the transposed copy wT[c][k] through a 32x32 LDS tile.
+__global__ __launch_bounds__(256) void weightnorm_apply_kernel(const float* __restrict__ V,
+                                                               const float* __restrict__ g,
+                                                               const float* __restrict__ inv,
+                                                               int K, int Cout,
+                                                               float* __restrict__ w,
+                                                               float* __restrict__ wT) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + ty + 8 * i, c = c0 + tx;
+    float v = 0.f;
+    if (k < K && c < Cout) {
+      v = V[(long)k * Cout + c] * (g[c] * inv[c]);
+      w[(long)k * Cout + c] = v;
+    }
+    tile[ty + 8 * i][tx] = v;
+  }
+  if (!wT) return;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, k = k0 + tx;
+    if (k < K && c < Cout) wT[(long)c * K + k] = tile[tx][ty + 8 * i];
+  }
+}
+
+// dV = g*inv*(dw - V*dot*inv^2),  dg = dot*inv,  dot[c] = sum_k dw[k][c] V[k][c]
+__global__ void weightnorm_bwd_kernel(const float* __restrict__ V, const float* __restrict__ g,
+                                      const float* __restrict__ inv, const float* __restrict__ dw,
+                                      const float* __restrict__ dot, long total, int Cout,
+                                      float* __restrict__ dV) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cout);
+    const float iv = inv[c];
+    dV[i] = g[c] * iv * (dw[i] - V[i] * dot[c] * iv * iv);
+  }
+}
+__global__ void weightnorm_dg_kernel(const float* __restrict__ dot, const float* __restrict__ inv,
+                                     int Cout, float* __restrict__ dg) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < Cout) dg[c] = dot[c] * inv[c];
+}
+
+// ---- GLU / tanh --------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void glu_fwd_kernel(const float* __restrict__ x, long rows, int C, float* __restrict__ y) {
+  const long total = rows * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    const float a = x[r * 2 * C + c], l = x[r * 2 * C + C + c];
+    y[i] = a * sigmoidf_(l);
+  }
+}
+__global__ void glu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, long rows,
+                               int C, float* __restrict__ dx) {
+  const long total = rows * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    const float a = x[r * 2 * C + c], l = x[r * 2 * C + C + c];
+    const float s = sigmoidf_(l), d = dy[i];
+    dx[r * 2 * C + c] = d * s;
+    dx[r * 2 * C + C + c] = d * a * s * (1.f - s);
+  }
+}
+__global__ void tanh_fwd_kernel(const float* __restrict__ x, long n, float* __restrict__ y) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = tanhf(x[i]);
+}
+__global__ void tanh_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, long n,
+                                float* __restrict__ dx) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dx[i] = dy[i] * (1.f - y[i] * y[i]);
+}
+
+// ---- feature head ------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+  v = wave_sum_d(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  double s = 0;
+  for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += red[k];
+  return s;
+}
+
+// one block per sample: norm = sqrt(sum x^2) (= ||[relu(x), relu(-x)]||); f = crelu(x)/norm
+__global__ __launch_bounds__(256) void feature_head_fwd_kernel(const float* __restrict__ x, int HW,
+                                                               int C, float* __restrict__ f,
+                                                               float* __restrict__ norm) {
+  __shared__ double red[4];
+  const int n = blockIdx.x;
+  const long per = (long)HW * C;
+  const float* xp = x + n * per;
+  double s = 0;
+  for (long i = threadIdx.x; i < per; i += blockDim.x) s += (double)xp[i] * (double)xp[i];
+  s = block_sum_d(s, red);
+  const float nrm = (float)sqrt(s);
+  if (threadIdx.x == 0) norm[n] = nrm;
+  float* fp = f + n * per * 2;
+  for (long i = threadIdx.x; i < per; i += blockDim.x) {
+    const long p = i / C;
+    const int c = (int)(i - p * C);
+    const float v = xp[i];
+    fp[p * 2 * C + c] = fmaxf(v, 0.f) / nrm;        // models/dcgan.py:16,19 (no epsilon)
+    fp[p * 2 * C + C + c] = fmaxf(-v, 0.f) / nrm;
+  }
+}
+// du = (df - f (f.df)) / norm ;  dx = du[+] * [x>0] - du[-] * [x<0]
+__global__ __launch_bounds__(256) void feature_head_bwd_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ f,
+                                                               const float* __restrict__ norm,
+                                                               const float* __restrict__ df, int HW,
+                                                               int C, float* __restrict__ dx) {
+  __shared__ double red[4];
+  const int n = blockIdx.x;
+  const long per = (long)HW * C;
+  const float* fp = f + n * per * 2;
+  const float* dfp = df + n * per * 2;
+  double s = 0;
+  for (long i = threadIdx.x; i < 2 * per; i += blockDim.x) s += (double)fp[i] * (double)dfp[i];
+  s = block_sum_d(s, red);
+  const float dot = (float)s, inv = 1.f / norm[n];
+  const float* xp = x + n * per;
+  float* dxp = dx + n * per;
+  for (long i = threadIdx.x; i < per; i += blockDim.x) {
+    const long p = i / C;
+    const int c = (int)(i - p * C);
+    const float v = xp[i];
+    const long ip = p * 2 * C + c, in = ip + C;
+    const float dup = (dfp[ip] - fp[ip] * dot) * inv;
+    const float dun = (dfp[in] - fp[in] * dot) * inv;
+    dxp[i] = v > 0.f ? dup : (v < 0.f ? -dun : 0.f);
+  }
+}
+
+// ---- optimisers / EMA ----------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ v,
+                            float* __restrict__ mg, long n, float lr, float mom1, float mom2,
+                            float c1, float c2) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    float vhat;
+    if (mom1 > 0.f) {
+      const float vt = mom1 * v[i] + (1.f - mom1) * gi;   // nn.py:61
+      v[i] = vt;
+      vhat = vt / c1;                                     // nn.py:62
+    } else {
+      vhat = gi;
+    }
+    const float mgt = mom2 * mg[i] + (1.f - mom2) * gi * gi;  // nn.py:66
+    mg[i] = mgt;
+    const float mghat = mgt / c2;                              // nn.py:67
+    p[i] -= lr * (vhat / sqrtf(mghat + 1e-8f));                // nn.py:68-69 (eps inside sqrt)
+  }
+}
+__global__ void adamax_kernel(float* __restrict__ p, const float* __restrict__ g,
+                              float* __restrict__ v, float* __restrict__ mg, long n, float lr,
+                              float mom1, float mom2) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    float vt = gi;
+    if (mom1 > 0.f) {
+      vt = mom1 * v[i] + (1.f - mom1) * gi;  // nn.py:39
+      v[i] = vt;
+    }
+    const float mgt = fmaxf(mom2 * mg[i] + 1e-8f, fabsf(gi));  // nn.py:43
+    mg[i] = mgt;
+    p[i] -= lr * (vt / mgt);                                    // nn.py:44-45
+  }
+}
+__global__ void nesterov_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                float* __restrict__ v, long n, float lr, float mom1) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float vo = v[i];
+    const float vn = mom1 * vo - lr * g[i];            // nn.py:83
+    p[i] = p[i] - mom1 * vo + (1.f + mom1) * vn;       // nn.py:84
+    v[i] = vn;
+  }
+}
+__global__ void ema_kernel(float* __restrict__ sh, const float* __restrict__ p, long n, float decay) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    sh[i] = decay * sh[i] + (1.f - decay) * p[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int otgan_weightnorm_fwd_f32(const float* V, const float* g, int K, int Cout, float* w, float* wT,
+                             float* inv_norm, void* stream) {
+  OTGAN_CHECK_ARG(V && g && w && inv_norm && K > 0 && Cout > 0, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, 4.0 * 3 * (double)K * Cout, s);
+  // the partial sums live in the (not yet written) w buffer: K*Cout >= kChunks*Cout whenever
+  // K >= kChunks; small K uses fewer chunks (nchunk <= ceil(K/64) <= K).
+  float* partial = w;
+  int nchunk = 0;
+  int rc = colreduce<1>(V, nullptr, K, Cout, Cout, partial, &nchunk, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(colreduce_finish_kernel<1>, dim3(ceil_div(Cout, 256)), dim3(256), 0, s, partial,
+                     nchunk, Cout, inv_norm);
+  dim3 grid(ceil_div(Cout, 32), ceil_div(K, 32));
+  hipLaunchKernelGGL(weightnorm_apply_kernel, grid, dim3(256), 0, s, V, g, inv_norm, K, Cout, w, wT);
+  OTGAN_CHECK_LAUNCH("weightnorm fwd");
+  return OTGAN_OK;
+}
+
+int otgan_weightnorm_bwd_f32(const float* V, const float* g, const float* inv_norm, const float* dw,
+                             int K, int Cout, float* dV, float* dg, float* scratch, void* stream) {
+  OTGAN_CHECK_ARG(V && g && inv_norm && dw && dV && dg && scratch && K > 0 && Cout > 0, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, 4.0 * 5 * (double)K * Cout, s);
+  float* partial = dV;  // dV is written only after the dots are final
+  int nchunk = 0;
+  int rc = colreduce<2>(dw, V, K, Cout, Cout, partial, &nchunk, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(colreduce_finish_kernel<0>, dim3(ceil_div(Cout, 256)), dim3(256), 0, s, partial,
+                     nchunk, Cout, scratch);
+  hipLaunchKernelGGL(weightnorm_dg_kernel, dim3(ceil_div(Cout, 256)), dim3(256), 0, s, scratch,
+                     inv_norm, Cout, dg);
+  const long total = (long)K * Cout;
+  hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, V, g, inv_norm, dw,
+                     scratch, total, Cout, dV);
+  OTGAN_CHECK_LAUNCH("weightnorm bwd");
+  return OTGAN_OK;
+}
+
+int otgan_colsum_f32(const float* a, long rows, int cols, long lda, float* out, float* scratch,
+                     void* stream) {
+  OTGAN_CHECK_ARG(a && out && scratch && rows > 0 && cols > 0 && lda >= cols, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, 4.0 * (double)rows * cols, s);
+  int nchunk = 0;
+  int rc = colreduce<0>(a, nullptr, rows, cols, lda, scratch, &nchunk, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(colreduce_finish_kernel<0>, dim3(ceil_div(cols, 256)), dim3(256), 0, s, scratch,
+                     nchunk, cols, out);
+  OTGAN_CHECK_LAUNCH("colsum");
+  return OTGAN_OK;
+}
+
+int otgan_glu_fwd_f32(const float* x, long rows, int C, float* y, void* stream) {
+  OTGAN_CHECK_ARG(x && y && rows > 0 && C > 0, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, 4.0 * 3 * (double)rows * C, s);
+  hipLaunchKernelGGL(glu_fwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, s, x, rows, C, y);
+  OTGAN_CHECK_LAUNCH("glu fwd");
+  return OTGAN_OK;
+}
+int otgan_glu_bwd_f32(const float* x, const float* dy, long rows, int C, float* dx, void* stream) {
+  OTGAN_CHECK_ARG(x && dy && dx && rows > 0 && C > 0, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, 4.0 * 5 * (double)rows * C, s);
+  hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, s, x, dy, rows, C, dx);
+  OTGAN_CHECK_LAUNCH("glu bwd");
+  return OTGAN_OK;
+}
+int otgan_tanh_fwd_f32(const float* x, long n, float* y, void* stream) {
+  OTGAN_CHECK_ARG(x && y && n > 0, "bad arguments");
+  hipLaunchKernelGGL(tanh_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, y);
+  OTGAN_CHECK_LAUNCH("tanh fwd");
+  return OTGAN_OK;
+}
+int otgan_tanh_bwd_f32(const float* y, const float* dy, long n, float* dx, void* stream) {
+  OTGAN_CHECK_ARG(y && dy && dx && n > 0, "bad arguments");
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y, dy, n, dx);
+  OTGAN_CHECK_LAUNCH("tanh bwd");
+  return OTGAN_OK;
+}
+
+int otgan_feature_head_fwd_f32(const float* x, int N, int HW, int C, float* f, float* norm,
+                               void* stream) {
+  OTGAN_CHECK_ARG(x && f && norm && N > 0 && HW > 0 && C > 0, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, 4.0 * 4 * (double)N * HW * C, s);
+  hipLaunchKernelGGL(feature_head_fwd_kernel, dim3(N), dim3(256), 0, s, x, HW, C, f, norm);
+  OTGAN_CHECK_LAUNCH("feature head fwd");
+  return OTGAN_OK;
+}
+int otgan_feature_head_bwd_f32(const float* x, const float* f, const float* norm, const float* df,
+                               int N, int HW, int C, float* dx, void* stream) {
+  OTGAN_CHECK_ARG(x && f && norm && df && dx && N > 0 && HW > 0 && C > 0, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, 4.0 * 10 * (double)N * HW * C, s);
+  hipLaunchKernelGGL(feature_head_bwd_kernel, dim3(N), dim3(256), 0, s, x, f, norm, df, HW, C, dx);
+  OTGAN_CHECK_LAUNCH("feature head bwd");
+  return OTGAN_OK;
+}
+
+int otgan_adam_step_f32(float* p, const float* grad, float* v, float* mg, long n, float lr,
+                        float mom1, float mom2, float t, void* stream) {
+  OTGAN_CHECK_ARG(p && grad && mg && n > 0 && t >= 1.f && (mom1 <= 0.f || v), "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, 4.0 * 7 * (double)n, s);
+  const float c1 = 1.f - powf(mom1, t), c2 = 1.f - powf(mom2, t);  // nn.py:62,67
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, grad, v, mg, n, lr, mom1,
+                     mom2, c1, c2);
+  OTGAN_CHECK_LAUNCH("adam");
+  return OTGAN_OK;
+}
+int otgan_adamax_step_f32(float* p, const float* grad, float* v, float* mg, long n, float lr,
+                          float mom1, float mom2, void* stream) {
+  OTGAN_CHECK_ARG(p && grad && mg && n > 0 && (mom1 <= 0.f || v), "bad arguments");
+  hipLaunchKernelGGL(adamax_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, grad, v,
+                     mg, n, lr, mom1, mom2);
+  OTGAN_CHECK_LAUNCH("adamax");
+  return OTGAN_OK;
+}
+int otgan_nesterov_step_f32(float* p, const float* grad, float* v, long n, float lr, float mom1,
+                            void* stream) {
+  OTGAN_CHECK_ARG(p && grad && v && n > 0, "bad arguments");
+  hipLaunchKernelGGL(nesterov_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, grad,
+                     v, n, lr, mom1);
+  OTGAN_CHECK_LAUNCH("nesterov");
+  return OTGAN_OK;
+}
+int otgan_ema_update_f32(float* shadow, const float* p, long n, float decay, void* stream) {
+  OTGAN_CHECK_ARG(shadow && p && n > 0, "bad arguments");
+  hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, shadow, p, n,
+                     decay);
+  OTGAN_CHECK_LAUNCH("ema");
+  return OTGAN_OK;
+}
+
+}  // extern "C"

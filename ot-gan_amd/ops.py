@@ -1,0 +1,304 @@
+"""torch.autograd plumbing around the HIP layer kernels (include/otgan_layers.h).
+
+Every Function launches hand-written gfx950 kernels through the C ABI on the current
+PyTorch stream; PyTorch only owns the device memory and the backward graph.  There is no
+fallback: CPU tensors raise OtganError.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib_layers import ConvDesc
+
+ACT = {None: 0, "none": 0, "crelu": 1, "celu": 2, "elu": 3, "relu": 4}
+DOUBLED = (1, 2)
+
+_ws = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only per-device scratch buffer (caller-provided workspace of the C ABI)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(max(nbytes, 1 << 20)), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.OtganError("otgan_amd ops need CUDA (MI355X) tensors; there is no CPU fallback")
+
+
+_map_cache = {}
+
+
+def channel_maps(segs, preact, device):
+    """Device tables for a *list* input (reference nn.py:198,200 interleaves per element:
+    [x0,-x0,x1,-x1,...]).  Returns (cmap, inv) int32 tensors, or (None, None) when the default
+    single-tensor ordering applies."""
+    segs = tuple(int(s) for s in segs)
+    if preact not in DOUBLED or len(segs) <= 1:
+        return None, None
+    key = (segs, device)
+    hit = _map_cache.get(key)
+    if hit is not None:
+        return hit
+    if any(s % 4 for s in segs):
+        raise _lib.OtganError("list elements must have a multiple of 4 channels for the "
+                              "vectorised gathers (got %r)" % (segs,))
+    C = sum(segs)
+    cmap, invp, invn = [], [0] * C, [0] * C
+    off = 0
+    for s in segs:
+        base = len(cmap)
+        cmap += [off + i for i in range(s)]
+        cmap += [(off + i) | (1 << 31) for i in range(s)]
+        for i in range(s):
+            invp[off + i] = base + i
+            invn[off + i] = base + s + i
+        off += s
+    # int32 with the sign bit as the "negate" flag
+    cm = torch.tensor([c - (1 << 32) if c >= (1 << 31) else c for c in cmap], dtype=torch.int32,
+                      device=device)
+    inv = torch.tensor(invp + invn, dtype=torch.int32, device=device)
+    _map_cache[key] = (cm, inv)
+    return cm, inv
+
+
+def make_desc(x, C, upsample, kh, kw, stride, cout, ldy, y_coff, preact):
+    N, H, W, ldx = x.shape
+    return ConvDesc(N, H, W, C, ldx, 1 if upsample else 0, kh, kw, stride, cout, ldy, y_coff, preact)
+
+
+def out_hw(H, W, upsample, stride):
+    Hin, Win = (H * 2, W * 2) if upsample else (H, W)
+    return -(-Hin // stride), -(-Win // stride)
+
+
+# ------------------------------------------------------------------------------- raw launchers
+def weightnorm_fwd(V2d, g):
+    """V2d: [K, Cout] view of the HWIO direction tensor.  Returns (w, wT, inv_norm)."""
+    K, Cout = V2d.shape
+    w = torch.empty_like(V2d)
+    wT = torch.empty((Cout, K), dtype=V2d.dtype, device=V2d.device)
+    inv = torch.empty(Cout, dtype=V2d.dtype, device=V2d.device)
+    _lib.check(_lib.lib().otgan_weightnorm_fwd_f32(V2d.data_ptr(), g.data_ptr(), K, Cout,
+                                                   w.data_ptr(), wT.data_ptr(), inv.data_ptr(),
+                                                   _lib.stream_ptr()), "weightnorm_fwd")
+    return w, wT, inv
+
+
+def weightnorm_bwd(V2d, g, inv, dw):
+    K, Cout = V2d.shape
+    dV = torch.empty_like(V2d)
+    dg = torch.empty_like(g)
+    scratch = torch.empty(Cout, dtype=V2d.dtype, device=V2d.device)
+    _lib.check(_lib.lib().otgan_weightnorm_bwd_f32(V2d.data_ptr(), g.data_ptr(), inv.data_ptr(),
+                                                   dw.data_ptr(), K, Cout, dV.data_ptr(),
+                                                   dg.data_ptr(), scratch.data_ptr(),
+                                                   _lib.stream_ptr()), "weightnorm_bwd")
+    return dV, dg
+
+
+def colsum(a2d_ptr, rows, cols, lda, device):
+    out = torch.empty(cols, dtype=torch.float32, device=device)
+    scratch = torch.empty(64 * cols, dtype=torch.float32, device=device)
+    _lib.check(_lib.lib().otgan_colsum_f32(a2d_ptr, rows, cols, lda, out.data_ptr(),
+                                           scratch.data_ptr(), _lib.stream_ptr()), "colsum")
+    return out
+
+
+def conv_fwd_raw(desc, x, cmap, wT, bias, y):
+    _lib.check(_lib.lib().otgan_conv2d_fwd_f32(ctypes.byref(desc), x.data_ptr(), _lib.ptr(cmap),
+                                               wT.data_ptr(), _lib.ptr(bias), y.data_ptr(),
+                                               _lib.stream_ptr()), "conv2d_fwd")
+
+
+def conv_dgrad_raw(desc, dy, w, x, inv, dx, lddx, accumulate):
+    L = _lib.lib()
+    need = L.otgan_conv2d_workspace_bytes(ctypes.byref(desc), 1)
+    ws = workspace(need, dy.device)
+    _lib.check(L.otgan_conv2d_dgrad_f32(ctypes.byref(desc), dy.data_ptr(), w.data_ptr(),
+                                        _lib.ptr(x), _lib.ptr(inv), dx.data_ptr(), lddx,
+                                        1 if accumulate else 0, ws.data_ptr(), ws.numel(),
+                                        _lib.stream_ptr()), "conv2d_dgrad")
+
+
+def conv_wgrad_raw(desc, x, cmap, dy, dw):
+    L = _lib.lib()
+    need = L.otgan_conv2d_workspace_bytes(ctypes.byref(desc), 2)
+    ws = workspace(need, dy.device)
+    _lib.check(L.otgan_conv2d_wgrad_f32(ctypes.byref(desc), x.data_ptr(), _lib.ptr(cmap),
+                                        dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                                        _lib.stream_ptr()), "conv2d_wgrad")
+
+
+# ------------------------------------------------------------------------------- conv2d / dense
+class Conv2dFunction(torch.autograd.Function):
+    """y = conv2d(preact(upsample(x)), g*V/||V||) + b     (reference nn.py:327-338).
+
+    x: [N,H,W,C] NHWC (C may be the concatenation of a list, `segs` gives the element sizes);
+    V: [KH,KW,Cin_eff,Cout]; g, b: [Cout]."""
+
+    @staticmethod
+    def forward(ctx, x, V, g, b, stride, upsample, preact, segs):
+        _need_cuda(x, V, g, b)
+        x = x.contiguous()
+        N, H, W, C = x.shape
+        KH, KW, Cin_eff, Cout = V.shape
+        if Cin_eff != C * (2 if preact in DOUBLED else 1):
+            raise ValueError(f"weight expects {Cin_eff} effective input channels, input gives "
+                             f"{C * (2 if preact in DOUBLED else 1)}")
+        V2d = V.contiguous().view(KH * KW * Cin_eff, Cout)
+        w, wT, inv_norm = weightnorm_fwd(V2d, g)
+        OH, OW = out_hw(H, W, upsample, stride)
+        y = torch.empty((N, OH, OW, Cout), dtype=x.dtype, device=x.device)
+        desc = make_desc(x, C, upsample, KH, KW, stride, Cout, Cout, 0, preact)
+        cmap, inv = channel_maps(segs if segs else (C,), preact, x.device)
+        conv_fwd_raw(desc, x, cmap, wT, b, y)
+        ctx.save_for_backward(x, V2d, g, w, inv_norm)
+        ctx.desc, ctx.cmap, ctx.inv = desc, cmap, inv
+        ctx.vshape = V.shape
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, V2d, g, w, inv_norm = ctx.saved_tensors
+        dy = dy.contiguous()
+        desc = ctx.desc
+        dx = dV = dg = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            conv_dgrad_raw(desc, dy, w, x, ctx.inv, dx, x.shape[3], False)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw = torch.empty_like(w)
+            conv_wgrad_raw(desc, x, ctx.cmap, dy, dw)
+            dV2d, dg = weightnorm_bwd(V2d, g, inv_norm, dw)
+            dV = dV2d.view(ctx.vshape)
+        if ctx.has_b and ctx.needs_input_grad[3]:
+            rows = dy.numel() // dy.shape[-1]
+            db = colsum(dy.data_ptr(), rows, dy.shape[-1], dy.shape[-1], dy.device)
+        return dx, dV, dg, db, None, None, None, None
+
+
+def conv2d_op(x, V, g, b, stride=1, upsample=False, preact=0, segs=None):
+    return Conv2dFunction.apply(x, V, g, b, int(stride), bool(upsample), int(preact),
+                                tuple(segs) if segs else None)
+
+
+def dense_op(x, V, g, b, preact=0, segs=None):
+    """x: [N, Cin]; V: [Cin_eff, Cout]  (reference nn.py:314-325) -- a 1x1 conv on a 1x1 image."""
+    N, C = x.shape
+    y = Conv2dFunction.apply(x.view(N, 1, 1, C), V.view(1, 1, *V.shape), g, b, 1, False,
+                             int(preact), tuple(segs) if segs else None)
+    return y.view(N, -1)
+
+
+# ------------------------------------------------------------------------------- pointwise
+class GluFunction(torch.autograd.Function):
+    """x: [..., 2C] -> x[..., :C] * sigmoid(x[..., C:])   (models/dcgan.py:35-36)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        x = x.contiguous()
+        C2 = x.shape[-1]
+        rows = x.numel() // C2
+        y = torch.empty(x.shape[:-1] + (C2 // 2,), dtype=x.dtype, device=x.device)
+        _lib.check(_lib.lib().otgan_glu_fwd_f32(x.data_ptr(), rows, C2 // 2, y.data_ptr(),
+                                                _lib.stream_ptr()), "glu_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        C2 = x.shape[-1]
+        dx = torch.empty_like(x)
+        _lib.check(_lib.lib().otgan_glu_bwd_f32(x.data_ptr(), dy.data_ptr(), x.numel() // C2,
+                                                C2 // 2, dx.data_ptr(), _lib.stream_ptr()), "glu_bwd")
+        return dx
+
+
+class TanhFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().otgan_tanh_fwd_f32(x.data_ptr(), x.numel(), y.data_ptr(),
+                                                 _lib.stream_ptr()), "tanh_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        _lib.check(_lib.lib().otgan_tanh_bwd_f32(y.data_ptr(), dy.data_ptr(), y.numel(),
+                                                 dx.data_ptr(), _lib.stream_ptr()), "tanh_bwd")
+        return dx
+
+
+class FeatureHeadFunction(torch.autograd.Function):
+    """[N,H,W,C] -> [N, H*W*2C]: concat([relu(x), relu(-x)], channel), flatten, L2-normalise
+    (models/dcgan.py:16-19, models/densenet.py:37-42; no epsilon)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        x = x.contiguous()
+        N, H, W, C = x.shape
+        f = torch.empty((N, H * W * 2 * C), dtype=x.dtype, device=x.device)
+        norm = torch.empty(N, dtype=x.dtype, device=x.device)
+        _lib.check(_lib.lib().otgan_feature_head_fwd_f32(x.data_ptr(), N, H * W, C, f.data_ptr(),
+                                                         norm.data_ptr(), _lib.stream_ptr()), "head_fwd")
+        ctx.save_for_backward(x, f, norm)
+        return f
+
+    @staticmethod
+    def backward(ctx, df):
+        x, f, norm = ctx.saved_tensors
+        df = df.contiguous()
+        N, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        _lib.check(_lib.lib().otgan_feature_head_bwd_f32(x.data_ptr(), f.data_ptr(), norm.data_ptr(),
+                                                         df.data_ptr(), N, H * W, C, dx.data_ptr(),
+                                                         _lib.stream_ptr()), "head_bwd")
+        return dx
+
+
+glu = GluFunction.apply
+tanh = TanhFunction.apply
+feature_head = FeatureHeadFunction.apply
+
+
+# ------------------------------------------------------------------------------- optimiser steps
+def adam_step(p, grad, v, mg, lr, mom1, mom2, t):
+    _lib.check(_lib.lib().otgan_adam_step_f32(p.data_ptr(), grad.data_ptr(), _lib.ptr(v), mg.data_ptr(),
+                                              p.numel(), float(lr), float(mom1), float(mom2),
+                                              float(t), _lib.stream_ptr()), "adam_step")
+
+
+def adamax_step(p, grad, v, mg, lr, mom1, mom2):
+    _lib.check(_lib.lib().otgan_adamax_step_f32(p.data_ptr(), grad.data_ptr(), _lib.ptr(v),
+                                                mg.data_ptr(), p.numel(), float(lr), float(mom1),
+                                                float(mom2), _lib.stream_ptr()), "adamax_step")
+
+
+def nesterov_step(p, grad, v, lr, mom1):
+    _lib.check(_lib.lib().otgan_nesterov_step_f32(p.data_ptr(), grad.data_ptr(), v.data_ptr(),
+                                                  p.numel(), float(lr), float(mom1),
+                                                  _lib.stream_ptr()), "nesterov_step")
+
+
+def ema_update(shadow, p, decay):
+    _lib.check(_lib.lib().otgan_ema_update_f32(shadow.data_ptr(), p.data_ptr(), p.numel(),
+                                               float(decay), _lib.stream_ptr()), "ema_update")

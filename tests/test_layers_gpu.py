@@ -1,0 +1,210 @@
+"""GPU parity tests of the layer kernels: HIP conv2d / dense (fwd, dgrad, wgrad through
+torch.autograd), weight norm, GLU, tanh, feature head and the optimiser steps, against the
+plain-PyTorch restatement of the reference layers (oracle/nets_torch.py) evaluated in fp64
+on the CPU.  Tolerance: relative L2 error <= 2e-5 (fp32 MFMA fmaf chains vs fp64)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets_torch as NT
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from otgan_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+CONV_CASES = [
+    # name, N, H, W, segs, Cout, k, stride, upsample, preact
+    ("s1_plain", 2, 8, 8, (16,), 32, 5, 1, False, None),
+    ("s2_crelu", 3, 16, 16, (16,), 48, 5, 2, False, "crelu"),
+    ("up_plain", 2, 4, 4, (32,), 64, 5, 1, True, None),
+    ("list_crelu_narrow", 2, 8, 8, (8, 4, 4), 16, 3, 1, False, "crelu"),
+    ("list_crelu_s2", 2, 8, 8, (16, 16, 16), 24, 3, 2, False, "crelu"),
+    ("up_crelu", 2, 4, 4, (16, 16), 16, 3, 1, True, "crelu"),
+    ("rgb_in", 2, 16, 16, (3,), 128, 5, 1, False, None),
+    ("rgb_out", 2, 16, 16, (128,), 3, 5, 1, False, None),
+    ("celu", 2, 8, 8, (8, 8), 32, 3, 1, False, "celu"),
+    ("elu", 2, 8, 8, (16,), 32, 3, 1, False, "elu"),
+    ("relu_s2", 2, 8, 8, (16,), 32, 3, 2, False, "relu"),
+    ("big_s2_crelu", 4, 16, 16, (64,), 256, 5, 2, False, "crelu"),
+    ("big_wgrad_split", 8, 32, 32, (32,), 64, 3, 1, False, "crelu"),
+    ("dcgan_like_up", 2, 8, 8, (64,), 128, 5, 1, True, None),
+    ("ragged_cout", 2, 8, 8, (16,), 40, 3, 1, False, "crelu"),
+    ("scalar_cin", 2, 8, 8, (6,), 20, 3, 1, False, "crelu"),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d(dev, case):
+    from otgan_amd import ops
+    name, N, H, W, segs, Cout, k, stride, up, pre = case
+    gen = torch.Generator().manual_seed(sum(map(ord, name)))
+    C = sum(segs)
+    mult = 2 if pre in ("crelu", "celu") else 1
+    xs64 = [torch.randn(N, H, W, s, generator=gen, dtype=torch.float64) for s in segs]
+    V64 = torch.randn(k, k, C * mult, Cout, generator=gen, dtype=torch.float64) * 0.05
+    g64 = torch.rand(Cout, generator=gen, dtype=torch.float64) + 0.5
+    b64 = torch.randn(Cout, generator=gen, dtype=torch.float64) * 0.1
+    # the HIP path sees fp32 roundings of these; evaluate the oracle on the same values
+    xs64 = [x.float().double().requires_grad_(True) for x in xs64]
+    V64, g64, b64 = [t.float().double().requires_grad_(True) for t in (V64, g64, b64)]
+    y_ref = NT.conv2d(xs64, {"V": V64, "g": g64, "b": b64}, pre, stride, up)
+    dy64 = torch.randn(y_ref.shape, generator=gen, dtype=torch.float64).float().double()
+    grads_ref = torch.autograd.grad(y_ref, xs64 + [V64, g64, b64], dy64)
+    dx_ref = torch.cat(grads_ref[:len(segs)], 3)
+
+    x = torch.cat([t.detach().float() for t in xs64], 3).to(dev).requires_grad_(True)
+    V = V64.detach().float().to(dev).requires_grad_(True)
+    g = g64.detach().float().to(dev).requires_grad_(True)
+    b = b64.detach().float().to(dev).requires_grad_(True)
+    y = ops.conv2d_op(x, V, g, b, stride=stride, upsample=up, preact=ops.ACT[pre], segs=segs)
+    assert y.shape == y_ref.shape
+    assert _rel(y, y_ref) < TOL, "forward"
+    dx, dV, dg, db = torch.autograd.grad(y, [x, V, g, b], dy64.float().to(dev))
+    assert _rel(dx, dx_ref) < TOL, "dgrad"
+    assert _rel(dV, grads_ref[len(segs)]) < TOL, "wgrad/dV"
+    assert _rel(dg, grads_ref[len(segs) + 1]) < TOL, "dg"
+    assert _rel(db, grads_ref[len(segs) + 2]) < TOL, "db"
+
+
+def test_conv2d_only_needed_grads(dev):
+    # generator step: dgrad through the critic without touching its weights (train.py:112)
+    from otgan_amd import ops
+    x = torch.randn(2, 8, 8, 16, device=dev, requires_grad=True)
+    V = torch.randn(3, 3, 32, 32, device=dev) * 0.05
+    g = torch.ones(32, device=dev)
+    b = torch.zeros(32, device=dev)
+    y = ops.conv2d_op(x, V, g, b, preact=ops.ACT["crelu"])
+    (dx,) = torch.autograd.grad(y, [x], torch.ones_like(y))
+    assert dx.shape == x.shape and torch.isfinite(dx).all()
+
+
+@pytest.mark.parametrize("pre", [None, "crelu"])
+def test_dense(dev, pre):
+    from otgan_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    N, Cin, Cout = 8, 100, 96
+    mult = 2 if pre == "crelu" else 1
+    x64 = (torch.rand(N, Cin, generator=gen, dtype=torch.float64) * 2 - 1).float().double().requires_grad_(True)
+    V64 = (torch.randn(Cin * mult, Cout, generator=gen, dtype=torch.float64) * 0.05).float().double().requires_grad_(True)
+    g64 = (torch.rand(Cout, generator=gen, dtype=torch.float64) + 0.5).float().double().requires_grad_(True)
+    b64 = (torch.randn(Cout, generator=gen, dtype=torch.float64) * 0.1).float().double().requires_grad_(True)
+    y_ref = NT.dense(x64, {"V": V64, "g": g64, "b": b64}, pre)
+    dy = torch.randn(y_ref.shape, generator=gen, dtype=torch.float64).float().double()
+    gref = torch.autograd.grad(y_ref, [x64, V64, g64, b64], dy)
+    x, V, g, b = [t.detach().float().to(dev).requires_grad_(True) for t in (x64, V64, g64, b64)]
+    y = ops.dense_op(x, V, g, b, preact=ops.ACT[pre])
+    assert _rel(y, y_ref) < TOL
+    got = torch.autograd.grad(y, [x, V, g, b], dy.float().to(dev))
+    for a, r, n in zip(got, gref, "dx dV dg db".split()):
+        assert _rel(a, r) < TOL, n
+
+
+def test_weightnorm_epsilon_and_transpose(dev):
+    from otgan_amd import ops
+    V = torch.randn(75, 20, device=dev) * 0.05
+    V[:, 3] = 0.0                                 # all-zero direction: epsilon under the max (nn.py:176)
+    g = torch.rand(20, device=dev) + 0.5
+    w, wT, inv = ops.weightnorm_fwd(V, g)
+    ref = NT.weight_norm(V.double().cpu(), g.double().cpu())
+    assert _rel(w, ref) < 1e-6
+    assert torch.equal(wT, w.t().contiguous())
+    assert torch.all(w[:, 3] == 0)
+
+
+def test_glu_tanh_head(dev):
+    from otgan_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    x64 = torch.randn(3, 4, 4, 32, generator=gen, dtype=torch.float64).float().double().requires_grad_(True)
+    y_ref = NT.glu(x64, 3)
+    dy = torch.randn(y_ref.shape, generator=gen, dtype=torch.float64).float().double()
+    (dx_ref,) = torch.autograd.grad(y_ref, [x64], dy)
+    x = x64.detach().float().to(dev).requires_grad_(True)
+    y = ops.glu(x)
+    assert _rel(y, y_ref) < 1e-6
+    (dx,) = torch.autograd.grad(y, [x], dy.float().to(dev))
+    assert _rel(dx, dx_ref) < 1e-6
+    # dense-style GLU: split along axis 1 of [B, 2C]
+    x2 = torch.randn(4, 64, device=dev)
+    assert _rel(ops.glu(x2), NT.glu(x2.double().cpu(), 1)) < 1e-6
+    # tanh
+    x64 = torch.randn(1000, generator=gen, dtype=torch.float64).float().double().requires_grad_(True)
+    t_ref = torch.tanh(x64)
+    (dt_ref,) = torch.autograd.grad(t_ref, [x64], torch.ones_like(t_ref))
+    xt = x64.detach().float().to(dev).requires_grad_(True)
+    t = ops.tanh(xt)
+    (dt,) = torch.autograd.grad(t, [xt], torch.ones_like(t))
+    assert _rel(t, t_ref) < 1e-6 and _rel(dt, dt_ref) < 1e-5
+    # feature head
+    x64 = torch.randn(5, 4, 4, 24, generator=gen, dtype=torch.float64).float().double().requires_grad_(True)
+    f_ref = NT.feature_head(x64)
+    df = torch.randn(f_ref.shape, generator=gen, dtype=torch.float64).float().double()
+    (dxh_ref,) = torch.autograd.grad(f_ref, [x64], df)
+    xh = x64.detach().float().to(dev).requires_grad_(True)
+    f = ops.feature_head(xh)
+    assert f.shape == (5, 4 * 4 * 48)
+    assert _rel(f, f_ref) < 1e-6
+    np.testing.assert_allclose(f.norm(dim=1).cpu().numpy(), 1.0, atol=1e-6)
+    (dxh,) = torch.autograd.grad(f, [xh], df.float().to(dev))
+    assert _rel(dxh, dxh_ref) < 1e-5
+
+
+def test_optimiser_steps(dev):
+    from otgan_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    n = 10007
+    p0 = torch.randn(n, generator=gen, dtype=torch.float64)
+    # Adam: three steps, shared t starting at 1 (nn.py:56,72), eps inside sqrt (nn.py:68)
+    p_ref = p0.clone()
+    st = {"t": 1.0, "v": torch.zeros(n, dtype=torch.float64), "mg": torch.zeros(n, dtype=torch.float64)}
+    p = p0.float().to(dev)
+    v = torch.zeros(n, device=dev)
+    mg = torch.zeros(n, device=dev)
+    for t in range(1, 4):
+        gr = torch.randn(n, generator=gen, dtype=torch.float64).float().double()
+        st["t"] = float(t)
+        p_ref = NT.adam_update(p_ref, gr, st, -3e-4, 0.5, 0.999)     # critic: lr = -lr (train.py:143)
+        ops.adam_step(p, gr.float().to(dev), v, mg, -3e-4, 0.5, 0.999, t)
+    assert _rel(p, p_ref) < 1e-6
+    assert _rel(v, st["v"]) < 1e-6 and _rel(mg, st["mg"]) < 1e-6
+    # Adamax
+    p_ref = p0.clone()
+    st = {"v": torch.zeros(n, dtype=torch.float64), "mg": torch.zeros(n, dtype=torch.float64)}
+    p = p0.float().to(dev); v.zero_(); mg.zero_()
+    for _ in range(2):
+        gr = torch.randn(n, generator=gen, dtype=torch.float64).float().double()
+        p_ref = NT.adamax_update(p_ref, gr, st, 3e-4, 0.5, 0.999)
+        ops.adamax_step(p, gr.float().to(dev), v, mg, 3e-4, 0.5, 0.999)
+    assert _rel(p, p_ref) < 1e-6
+    # Nesterov
+    p_ref = p0.clone()
+    st = {"v": torch.zeros(n, dtype=torch.float64)}
+    p = p0.float().to(dev); v.zero_()
+    for _ in range(2):
+        gr = torch.randn(n, generator=gen, dtype=torch.float64).float().double()
+        p_ref = NT.nesterov_update(p_ref, gr, st, 1e-2, 0.5)
+        ops.nesterov_step(p, gr.float().to(dev), v, 1e-2, 0.5)
+    assert _rel(p, p_ref) < 1e-6
+    # EMA (train.py:63)
+    sh = torch.zeros(n, device=dev)
+    ops.ema_update(sh, p, 0.999)
+    assert _rel(sh, 0.001 * p.double().cpu()) < 1e-6
+
+
+def test_no_cpu_fallback_layers():
+    from otgan_amd import _lib, ops
+    with pytest.raises(_lib.OtganError):
+        ops.glu(torch.zeros(2, 4))
