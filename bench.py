@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Headline benchmark: OT-GAN training images/sec (CIFAR-10-shaped synthetic 32x32x3 data,
+256 images per GPU, DCGAN generator + critic, 100 Sinkhorn iterations, 5:1 generator:critic
+step mix) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 30 --warmup 6
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see the field notes in DESIGN.md section "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBPS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--model", type=str, default="dcgan")
+    ap.add_argument("--batch_per_gpu", type=int, default=256)
+    ap.add_argument("--nr_sinkhorn_iter", type=int, default=100)
+    ap.add_argument("--matching_scope", type=str, default="global")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_prof", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    from otgan_amd import _lib, parallel
+    from otgan_amd.trainer import OTGAN, default_args
+
+    rank, world, local = parallel.init_from_env()
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    _lib.lib()
+
+    # 256 images per GPU = 2 logical shards x 128 (the reference needs an even shard count,
+    # train.py:34); weak scaling: nr_gpu = 2 * world logical shards.
+    shards_per_rank = 2
+    args = default_args(model=a.model, batch_size=a.batch_per_gpu // shards_per_rank,
+                        nr_gpu=shards_per_rank * world, nr_sinkhorn_iter=a.nr_sinkhorn_iter,
+                        sinkhorn_lambda=500.0, nr_gen_per_disc=5, matching_scope=a.matching_scope, seed=1)
+    model = OTGAN(args, dev)
+    torch.manual_seed(1 + rank)
+    x = torch.rand(model.nb, 32, 32, 3, device=dev) * 2 - 1     # synthetic CIFAR-shaped batch in [-1,1]
+
+    for _ in range(a.warmup):
+        model.step(x)
+    torch.cuda.synchronize()
+    if not a.no_prof:
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        last = model.step(x)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = None
+    if not a.no_prof:
+        prof = _lib.prof_collect()
+        _lib.prof_enable(False)
+
+    if rank != 0:
+        return
+    images = world * model.nb * a.steps
+    value = images / dt
+    out = {
+        "metric": "OT-GAN train images/sec (CIFAR-10 32x32, bs=256/GPU)",
+        "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[1]: {a.model.upper()} generator+critic train step, synthetic "
+                               f"CIFAR-10-shaped 32x32x3, {a.batch_per_gpu} img/GPU as 2 logical shards x "
+                               f"{a.batch_per_gpu // 2} (Sinkhorn rows N={world * a.batch_per_gpu // 2 if a.matching_scope == 'global' else a.batch_per_gpu // 2}), "
+                               f"{a.nr_sinkhorn_iter} Sinkhorn iters, lambda 500, 5:1 generator:critic steps, Adam",
+                   "global_batch": world * a.batch_per_gpu, "parallelism": f"dp{world}",
+                   "matching_scope": args.matching_scope if world > 1 else "local",
+                   "last_distance": float(last["distance"]), "last_entropy": float(last["entropy"])},
+    }
+    if prof:
+        conv = {k: prof[k] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")}
+        dom = max(conv, key=lambda k: conv[k]["ms"])
+        d = conv[dom]
+        ach = d["flop"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2),
+                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                           "launches": d["launches"], "avg_ms": round(d["ms"] / max(d["launches"], 1), 4)}
+        out["kernel_classes"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                     "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flop"] > 0 else None}
+                                 for k, v in prof.items() if v["launches"]}
+        out["kernel_time_frac_of_wall"] = round(sum(v["ms"] for v in prof.values()) / (dt * 1e3), 4)
+    if world == 1 and not a.no_cpu_baseline:
+        from oracle import train_step_cpu
+        torch.set_num_threads(os.cpu_count() or 1)
+        bps = 8
+        ips, best, nb = train_step_cpu.time_cpu_steps(batch_per_shard=bps, shards=2, iters=a.nr_sinkhorn_iter,
+                                                      model=a.model)
+        out["cpu_baseline"] = {"value": round(ips, 3), "unit": "images/sec", "cores": torch.get_num_threads(),
+                               "kind": "port",
+                               "sample": f"one generator step ({best['gen']:.2f} s) + one critic step "
+                                         f"({best['disc']:.2f} s) of the oracle (PyTorch-CPU fp32 nets + C "
+                                         f"Sinkhorn) at {nb} img/step (2 shards x {bps}), combined 5:1"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

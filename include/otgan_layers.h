@@ -97,13 +97,15 @@ int otgan_feature_head_bwd_f32(const float* x, const float* f, const float* norm
 /* ---- optimiser / EMA (utils/nn.py:50-73, train.py:63-64) --------------------------------
  * Adam with the reference's epsilon placement:  p -= lr * vhat / sqrt(mghat + 1e-8),
  * vhat = v/(1-mom1^t), mghat = mg/(1-mom2^t); mom1 == 0 skips the first moment.          */
-int otgan_adam_step_f32(float* p, const float* grad, float* v, float* mg, long n, float lr,
-                        float mom1, float mom2, float t, void* stream);
-int otgan_adamax_step_f32(float* p, const float* grad, float* v, float* mg, long n, float lr,
-                          float mom1, float mom2, void* stream);
-int otgan_nesterov_step_f32(float* p, const float* grad, float* v, long n, float lr, float mom1,
+/* Hyper-parameters travel as doubles: the reference forms (1 - mom) and (1 - mom^t) in
+ * Python doubles before they become fp32 graph constants.                                  */
+int otgan_adam_step_f32(float* p, const float* grad, float* v, float* mg, long n, double lr,
+                        double mom1, double mom2, double t, void* stream);
+int otgan_adamax_step_f32(float* p, const float* grad, float* v, float* mg, long n, double lr,
+                          double mom1, double mom2, void* stream);
+int otgan_nesterov_step_f32(float* p, const float* grad, float* v, long n, double lr, double mom1,
                             void* stream);
 /* shadow = decay*shadow + (1-decay)*p */
-int otgan_ema_update_f32(float* shadow, const float* p, long n, float decay, void* stream);
+int otgan_ema_update_f32(float* shadow, const float* p, long n, double decay, void* stream);
 
 #endif /* OTGAN_LAYERS_H */

@@ -220,14 +220,18 @@ def densenet_generator(us, P, nonlinearity="crelu", L=16, Fg=16, scope="generato
 # ----------------------------------------------------------------------------- optimisers
 def adam_update(p, g, state, lr, mom1=0.9, mom2=0.999):
     """nn.py:50-73 (epsilon inside the sqrt; t starts at 1 and is shared per optimiser)"""
-    t = state["t"]
+    import numpy as np
+    t = np.float32(state["t"])
+    # `1. - tf.pow(mom, t)` lives in the fp32 graph; `(1. - mom)` is a Python double constant
+    c1 = float(np.float32(1) - np.float32(mom1) ** t)
+    c2 = float(np.float32(1) - np.float32(mom2) ** t)
     if mom1 > 0:
         state["v"] = mom1 * state["v"] + (1 - mom1) * g
-        v_hat = state["v"] / (1 - mom1 ** t)
+        v_hat = state["v"] / c1
     else:
         v_hat = g
     state["mg"] = mom2 * state["mg"] + (1 - mom2) * g * g
-    mg_hat = state["mg"] / (1 - mom2 ** t)
+    mg_hat = state["mg"] / c2
     return p - lr * v_hat / torch.sqrt(mg_hat + 1e-8)
 
 

@@ -3,6 +3,7 @@ import ctypes
 
 c_fp = ctypes.c_void_p
 c_int, c_long, c_float, c_size_t = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
+c_double = ctypes.c_double
 
 
 class ConvDesc(ctypes.Structure):
@@ -29,9 +30,9 @@ SIGNATURES = {
     "otgan_tanh_bwd_f32": (c_int, [c_fp, c_fp, c_long, c_fp, c_fp]),
     "otgan_feature_head_fwd_f32": (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp]),
     "otgan_feature_head_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp]),
-    "otgan_adam_step_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_long, c_float, c_float, c_float,
-                                    c_float, c_fp]),
-    "otgan_adamax_step_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_long, c_float, c_float, c_float, c_fp]),
-    "otgan_nesterov_step_f32": (c_int, [c_fp, c_fp, c_fp, c_long, c_float, c_float, c_fp]),
-    "otgan_ema_update_f32": (c_int, [c_fp, c_fp, c_long, c_float, c_fp]),
+    "otgan_adam_step_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_long, c_double, c_double, c_double,
+                                    c_double, c_fp]),
+    "otgan_adamax_step_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_long, c_double, c_double, c_double, c_fp]),
+    "otgan_nesterov_step_f32": (c_int, [c_fp, c_fp, c_fp, c_long, c_double, c_double, c_fp]),
+    "otgan_ema_update_f32": (c_int, [c_fp, c_fp, c_long, c_double, c_fp]),
 }

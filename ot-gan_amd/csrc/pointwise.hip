@@ -219,19 +219,19 @@ __global__ __launch_bounds__(256) void feature_head_bwd_kernel(const float* __re
 
 // ---- optimisers / EMA ----------------------------------------------------------------------------
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ v,
-                            float* __restrict__ mg, long n, float lr, float mom1, float mom2,
-                            float c1, float c2) {
+                            float* __restrict__ mg, long n, float lr, float mom1, float om1,
+                            float mom2, float om2, float c1, float c2) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float gi = g[i];
     float vhat;
     if (mom1 > 0.f) {
-      const float vt = mom1 * v[i] + (1.f - mom1) * gi;   // nn.py:61
+      const float vt = mom1 * v[i] + om1 * gi;            // nn.py:61
       v[i] = vt;
       vhat = vt / c1;                                     // nn.py:62
     } else {
       vhat = gi;
     }
-    const float mgt = mom2 * mg[i] + (1.f - mom2) * gi * gi;  // nn.py:66
+    const float mgt = mom2 * mg[i] + om2 * gi * gi;           // nn.py:66
     mg[i] = mgt;
     const float mghat = mgt / c2;                              // nn.py:67
     p[i] -= lr * (vhat / sqrtf(mghat + 1e-8f));                // nn.py:68-69 (eps inside sqrt)
@@ -239,12 +239,12 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 }
 __global__ void adamax_kernel(float* __restrict__ p, const float* __restrict__ g,
                               float* __restrict__ v, float* __restrict__ mg, long n, float lr,
-                              float mom1, float mom2) {
+                              float mom1, float om1, float mom2) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float gi = g[i];
     float vt = gi;
     if (mom1 > 0.f) {
-      vt = mom1 * v[i] + (1.f - mom1) * gi;  // nn.py:39
+      vt = mom1 * v[i] + om1 * gi;  // nn.py:39
       v[i] = vt;
     }
     const float mgt = fmaxf(mom2 * mg[i] + 1e-8f, fabsf(gi));  // nn.py:43
@@ -253,17 +253,18 @@ __global__ void adamax_kernel(float* __restrict__ p, const float* __restrict__ g
   }
 }
 __global__ void nesterov_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                float* __restrict__ v, long n, float lr, float mom1) {
+                                float* __restrict__ v, long n, float lr, float mom1, float opm) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float vo = v[i];
     const float vn = mom1 * vo - lr * g[i];            // nn.py:83
-    p[i] = p[i] - mom1 * vo + (1.f + mom1) * vn;       // nn.py:84
+    p[i] = p[i] - mom1 * vo + opm * vn;                // nn.py:84
     v[i] = vn;
   }
 }
-__global__ void ema_kernel(float* __restrict__ sh, const float* __restrict__ p, long n, float decay) {
+__global__ void ema_kernel(float* __restrict__ sh, const float* __restrict__ p, long n, float decay,
+                           float omd) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    sh[i] = decay * sh[i] + (1.f - decay) * p[i];
+    sh[i] = decay * sh[i] + omd * p[i];
 }
 
 }  // namespace
@@ -371,37 +372,39 @@ int otgan_feature_head_bwd_f32(const float* x, const float* f, const float* norm
   return OTGAN_OK;
 }
 
-int otgan_adam_step_f32(float* p, const float* grad, float* v, float* mg, long n, float lr,
-                        float mom1, float mom2, float t, void* stream) {
-  OTGAN_CHECK_ARG(p && grad && mg && n > 0 && t >= 1.f && (mom1 <= 0.f || v), "bad arguments");
+int otgan_adam_step_f32(float* p, const float* grad, float* v, float* mg, long n, double lr,
+                        double mom1, double mom2, double t, void* stream) {
+  OTGAN_CHECK_ARG(p && grad && mg && n > 0 && t >= 1.0 && (mom1 <= 0.0 || v), "bad arguments");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, 4.0 * 7 * (double)n, s);
-  const float c1 = 1.f - powf(mom1, t), c2 = 1.f - powf(mom2, t);  // nn.py:62,67
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, grad, v, mg, n, lr, mom1,
-                     mom2, c1, c2);
+  // nn.py:62,67: `1. - tf.pow(mom, t)` is evaluated IN the fp32 graph (t is a float32 variable),
+  // whereas `(1. - mom)` (nn.py:61,66) is a Python double folded into an fp32 constant.
+  const float c1 = 1.f - powf((float)mom1, (float)t), c2 = 1.f - powf((float)mom2, (float)t);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, grad, v, mg, n, (float)lr,
+                     (float)mom1, (float)(1.0 - mom1), (float)mom2, (float)(1.0 - mom2), c1, c2);
   OTGAN_CHECK_LAUNCH("adam");
   return OTGAN_OK;
 }
-int otgan_adamax_step_f32(float* p, const float* grad, float* v, float* mg, long n, float lr,
-                          float mom1, float mom2, void* stream) {
-  OTGAN_CHECK_ARG(p && grad && mg && n > 0 && (mom1 <= 0.f || v), "bad arguments");
+int otgan_adamax_step_f32(float* p, const float* grad, float* v, float* mg, long n, double lr,
+                          double mom1, double mom2, void* stream) {
+  OTGAN_CHECK_ARG(p && grad && mg && n > 0 && (mom1 <= 0.0 || v), "bad arguments");
   hipLaunchKernelGGL(adamax_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, grad, v,
-                     mg, n, lr, mom1, mom2);
+                     mg, n, (float)lr, (float)mom1, (float)(1.0 - mom1), (float)mom2);
   OTGAN_CHECK_LAUNCH("adamax");
   return OTGAN_OK;
 }
-int otgan_nesterov_step_f32(float* p, const float* grad, float* v, long n, float lr, float mom1,
+int otgan_nesterov_step_f32(float* p, const float* grad, float* v, long n, double lr, double mom1,
                             void* stream) {
   OTGAN_CHECK_ARG(p && grad && v && n > 0, "bad arguments");
   hipLaunchKernelGGL(nesterov_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, grad,
-                     v, n, lr, mom1);
+                     v, n, (float)lr, (float)mom1, (float)(1.0 + mom1));
   OTGAN_CHECK_LAUNCH("nesterov");
   return OTGAN_OK;
 }
-int otgan_ema_update_f32(float* shadow, const float* p, long n, float decay, void* stream) {
+int otgan_ema_update_f32(float* shadow, const float* p, long n, double decay, void* stream) {
   OTGAN_CHECK_ARG(shadow && p && n > 0, "bad arguments");
   hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, shadow, p, n,
-                     decay);
+                     (float)decay, (float)(1.0 - decay));
   OTGAN_CHECK_LAUNCH("ema");
   return OTGAN_OK;
 }

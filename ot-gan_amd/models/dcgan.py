@@ -1,0 +1,49 @@
+"""DCGAN-style critic and generator of OT-GAN on the HIP layer kernels.
+
+Plugin surface of the reference's `models/dcgan.py` (module-level `generator` and
+`discriminator` templates with shared parameters, selected by `--model dcgan`):
+
+    discriminator(x, init=False, nonlinearity='crelu', ema=None, **kw) -> [B, 32768] unit rows
+        reference models/dcgan.py:7-22
+    generator(batch_size, init=False, nonlinearity='crelu', ema=None, **kw) -> [B,32,32,3] in (-1,1)
+        reference models/dcgan.py:28-52
+
+Extra keyword arguments (not in the reference): `noise` supplies the U(-1,1) latent instead
+of drawing it (parity tests), `device` places a freshly drawn latent.
+"""
+import torch
+
+from ..utils import nn
+
+# (filters, stride, pre-activated) per critic convolution; all 5x5  (models/dcgan.py:11-14)
+_CRITIC = ((128, 1, False), (256, 2, True), (512, 2, True), (1024, 2, True))
+# output channels of the three upsampling generator convolutions, before the GLU (:39,43,47)
+_GEN = (2 * 512, 2 * 256, 2 * 128)
+
+
+def disc_spec(x, init=False, nonlinearity='crelu', ema=None, **kwargs):
+    with nn.arg_scope([nn.conv2d, nn.dense], counters={}, init=init, weight_norm=True, ema=ema):
+        for filters, s, act in _CRITIC:
+            x = nn.conv2d(x, filters, filter_size=[5, 5], stride=[s, s],
+                          pre_activation=nonlinearity if act else None)
+        # CReLU, flatten (h, w, c), L2-normalise: the critic's feature vector
+        return nn.feature_head(x)
+
+
+discriminator = nn.make_template('discriminator', disc_spec)
+
+
+def gen_spec(batch_size, init=False, nonlinearity='crelu', ema=None, noise=None, device=None, **kwargs):
+    if noise is None:
+        # models/dcgan.py:30 -- fresh uniform(-1, 1) latent on every call
+        noise = torch.rand((batch_size, 100), device=device or 'cuda') * 2.0 - 1.0
+    with nn.arg_scope([nn.conv2d, nn.dense], counters={}, init=init, weight_norm=True, ema=ema):
+        x = nn.glu(nn.dense(noise, 2 * 4 * 4 * 1024, pre_activation=None))   # split along axis 1
+        x = x.view(noise.shape[0], 4, 4, 1024)
+        for filters in _GEN:
+            # nearest-neighbour x2 (fused into the conv's gather) -> 5x5 conv -> gated linear unit
+            x = nn.glu(nn.conv2d(x, filters, filter_size=[5, 5], pre_activation=None, upsample=True))
+        return nn.tanh(nn.conv2d(x, 3, filter_size=[5, 5], pre_activation=None, init_scale=0.1))
+
+
+generator = nn.make_template('generator', gen_spec)

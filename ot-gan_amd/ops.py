@@ -158,7 +158,9 @@ class Conv2dFunction(torch.autograd.Function):
         OH, OW = out_hw(H, W, upsample, stride)
         y = torch.empty((N, OH, OW, Cout), dtype=x.dtype, device=x.device)
         desc = make_desc(x, C, upsample, KH, KW, stride, Cout, Cout, 0, preact)
-        cmap, inv = channel_maps(segs if segs else (C,), preact, x.device)
+        # with upsample the reference concatenates the list BEFORE the pre-activation
+        # (nn.py:235-237), so the doubled ordering is [x_all, -x_all], not per element
+        cmap, inv = channel_maps(segs if (segs and not upsample) else (C,), preact, x.device)
         conv_fwd_raw(desc, x, cmap, wT, b, y)
         ctx.save_for_backward(x, V2d, g, w, inv_norm)
         ctx.desc, ctx.cmap, ctx.inv = desc, cmap, inv

@@ -1,0 +1,93 @@
+"""One-process-per-GPU data parallelism for the OT-GAN step (RCCL over xGMI via
+torch.distributed backend "nccl"; "gloo" on CPU for tests).
+
+The reference is a single process with in-graph towers (`tf.device('/gpu:%d')`,
+train.py:72-85) whose cross-device traffic is implicit.  Here each rank owns
+`shards_per_rank` of the reference's `nr_gpu` logical shards and the two exchange steps are
+explicit collectives:
+
+  * feature all-gather  (replaces the implicit gather of utils/matching.py:16-19) -- only in
+    the reference-faithful *global* matching scope;
+  * gradient all-reduce(SUM)  (replaces the sum-to-gpu:0 of train.py:134-139; the reference
+    sums, it does not average).
+
+Everything in this file is backend-agnostic tensor plumbing (no HIP kernels), so it is
+covered by world_size-2 gloo tests on CPU.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); returns
+    (rank, world, local_rank).  Single-process runs skip initialisation."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+def all_gather_rows(x):
+    """[n, D] per rank -> [world*n, D] in rank order (one collective)."""
+    w = world_size()
+    if w == 1:
+        return x
+    x = x.contiguous()
+    out = torch.empty((w * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x)
+    return out
+
+
+def gather_feature_shards(f_local, shards_per_rank):
+    """Local features [shards_per_rank*B, D] -> the reference's global shard list of
+    `world*shards_per_rank` tensors [B, D]; shard s lives on rank s // shards_per_rank, so the
+    first half of the ranks forms mini-batch 1 and the second half mini-batch 2
+    (utils/matching.py:16-19)."""
+    allf = all_gather_rows(f_local)
+    S = world_size() * shards_per_rank
+    return list(torch.chunk(allf, S, 0))
+
+
+def local_rows(flat_global, rows_per_rank):
+    """This rank's rows of a globally ordered [world*rows_per_rank, D] tensor."""
+    r = get_rank()
+    return flat_global[r * rows_per_rank:(r + 1) * rows_per_rank]
+
+
+def allreduce_sum_(tensors):
+    """In-place SUM all-reduce of a list of tensors through ONE flat bucket (a single large
+    collective suits xGMI's point-to-point links better than many small ones)."""
+    if world_size() == 1 or not tensors:
+        return tensors
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n
+    return tensors
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()

@@ -1,0 +1,165 @@
+"""Command-line training driver with the reference's flag set (reference train.py:14-33:
+same names, types and defaults), one process per GPU:
+
+    python train.py --model dcgan --nr_gpu 2 --batch_size 128 --data_dir /data ...
+    torchrun --nproc-per-node 8 --master-addr 127.0.0.1 train.py --nr_gpu 16 --batch_size 128
+
+`--nr_gpu` keeps the reference's meaning -- the number of equal feature shards of the
+matching problem (it must be even, train.py:34) -- and is decoupled from the number of
+physical GPUs (= torch.distributed world size): every rank owns nr_gpu / world shards.
+
+Added flags (not in the reference): --synthetic (random CIFAR-shaped data instead of the
+pickled dataset), --matching_scope global|local, --max_steps, --image_size.
+"""
+import argparse
+import os
+import pickle
+import sys
+import time
+
+import numpy as np
+import torch
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    # ---- reference flags (train.py:15-32), same defaults
+    p.add_argument('--seed', type=int, default=1)
+    p.add_argument('--batch_size', type=int, default=625)
+    p.add_argument('--learning_rate_disc', type=float, default=0.0003)
+    p.add_argument('--learning_rate_gen', type=float, default=0.0003)
+    p.add_argument('--data_dir', type=str, default='/home/tim/data')
+    p.add_argument('--save_dir', type=str, default='/local_home/tim/med_gan')
+    p.add_argument('--optimizer', type=str, default='adam')
+    p.add_argument('--nonlinearity', type=str, default='crelu')
+    p.add_argument('--nr_gpu', type=int, default=8, help='How many equal shards (reference: GPUs) to split each step across?')
+    p.add_argument('--nr_gen_per_disc', type=int, default=5, help='How many times to update the generator for each update of the discriminator?')
+    p.add_argument('--sinkhorn_lambda', type=float, default=500.)
+    p.add_argument('--nr_sinkhorn_iter', type=int, default=500)
+    p.add_argument('--single_batch', dest='single_batch', action='store_true', help='Use simplified batching using a single batch instead of 2')
+    p.add_argument('--train_disc_against_ema', dest='train_disc_against_ema', action='store_true', help='Should discriminator be trained against samples of EMA generator?')
+    p.add_argument('--model', type=str, default='dcgan')
+    p.add_argument('--load_params', dest='load_params', action='store_true')
+    p.add_argument('--model_name', type=str, default='med_gan_params-2399')
+    p.add_argument('--no_sinkhorn', dest='no_sinkhorn', action='store_true')
+    # ---- additions
+    p.add_argument('--synthetic', action='store_true', help='uniform random 32x32x3 data instead of CIFAR-10')
+    p.add_argument('--matching_scope', type=str, default='global', choices=['global', 'local'])
+    p.add_argument('--max_steps', type=int, default=0, help='stop after this many steps (0 = run like the reference)')
+    p.add_argument('--image_size', type=int, default=32)
+    return p
+
+
+def load_cifar(data_dir, subset='train'):
+    """Pickled CIFAR-10 python batches under <data_dir>/cifar-10-python/cifar-10-batches-py
+    (the layout the reference's data/cifar10_data.py:40-53 reads; no download here)."""
+    d = os.path.join(data_dir, 'cifar-10-python', 'cifar-10-batches-py')
+    files = ['data_batch_%d' % i for i in range(1, 6)] if subset == 'train' else ['test_batch']
+    xs = []
+    for f in files:
+        with open(os.path.join(d, f), 'rb') as fo:
+            e = pickle.load(fo, encoding='latin1')
+        xs.append(np.asarray(e['data']).reshape(-1, 3, 32, 32))
+    x = np.concatenate(xs, 0)
+    return np.transpose(x, (0, 2, 3, 1)).astype(np.float32) / 127.5 - 1.     # train.py:158
+
+
+def maybe_flip(x):
+    """Random horizontal flip per image (train.py:163-170), on the device."""
+    flip = torch.rand(x.shape[0], device=x.device) < 0.5
+    return torch.where(flip[:, None, None, None], x.flip(2), x)
+
+
+def save_tile_png(x, path, n=100):
+    """10x10 sample sheet (the role of utils/plotting.py:9-13,29-74)."""
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    x = x[:n].clamp(-1, 1).add(1).mul(127.5).byte().cpu().numpy()
+    k = int(np.ceil(np.sqrt(x.shape[0])))
+    H, W = x.shape[1:3]
+    sheet = np.full((k * (H + 1) + 1, k * (W + 1) + 1, 3), 255, np.uint8)
+    for i, im in enumerate(x):
+        r, c = divmod(i, k)
+        sheet[1 + r * (H + 1):1 + r * (H + 1) + H, 1 + c * (W + 1):1 + c * (W + 1) + W] = im
+    Image.fromarray(sheet).save(path)
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    assert args.nr_gpu % 2 == 0                                   # train.py:34
+    from . import parallel
+    from .trainer import OTGAN
+    rank, world, local = parallel.init_from_env()
+    if not torch.cuda.is_available():
+        raise RuntimeError("training needs MI355X GPUs: there is no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if rank == 0:
+        print(args)
+    np.random.seed(args.seed)                                      # train.py:48
+    torch.manual_seed(args.seed + rank)
+    model = OTGAN(args, dev)
+    if rank == 0:
+        print("model has a hidden representation with %d features" % model.num_features)   # train.py:56
+
+    if args.synthetic:
+        trainx = np.random.rand(50000, args.image_size, args.image_size, 3).astype(np.float32) * 2 - 1
+    else:
+        trainx = load_cifar(args.data_dir)
+    per_step = args.nr_gpu * args.batch_size
+    nr_batches = trainx.shape[0] // per_step                        # train.py:159
+    if rank == 0:
+        os.makedirs(args.save_dir, exist_ok=True)
+    current_epoch = 0
+    if args.load_params:                                           # train.py:190-193
+        sd = torch.load(os.path.join(args.save_dir, args.model_name), map_location='cpu')
+        model.load_state_dict(sd)
+        current_epoch = int(args.model_name[args.model_name.rfind('-') + 1:])
+    if rank == 0:
+        print('starting training')
+    mean_dist_gen, mean_dist_disc = [], []
+    start_time = time.time()
+    total = 0
+    for epoch in range(current_epoch, 1000000):
+        begin = time.time()
+        inds = np.random.permutation(trainx.shape[0])              # same seed on every rank
+        dg, dd, ent = [], [], []
+        for t in range(nr_batches):
+            # shard s of this step reads rows (t + s*nr_batches)*B ... (train.py:209-211)
+            rows = []
+            for j in range(model.shards):
+                s = rank * model.shards + j
+                td = t + s * nr_batches
+                rows.append(inds[td * args.batch_size:(td + 1) * args.batch_size])
+            xb = torch.from_numpy(trainx[np.concatenate(rows)]).to(dev, non_blocking=True)
+            r = model.step(maybe_flip(xb))
+            (dd if r["kind"] == "disc" else dg).append(r["distance"])
+            ent.append(r["entropy"])
+            total += 1
+            if args.max_steps and total >= args.max_steps:
+                break
+        f = lambda lst: float(torch.stack([z.double() for z in lst]).mean()) if lst else float('nan')
+        mean_dist_gen.append(f(dg))
+        mean_dist_disc.append(f(dd))
+        if rank == 0:
+            print("Iteration %d, time = %ds, train distance before gen = %.6f, train distance before disc = %.6f, "
+                  "avg matching entropy = %.6f" % (epoch, time.time() - begin, mean_dist_gen[-1],
+                                                   mean_dist_disc[-1], f(ent)))          # train.py:231
+            save_tile_png(model.sample(100), os.path.join(args.save_dir, 'sample%d.png' % epoch))
+            save_tile_png(model.sample(100, ema=True), os.path.join(args.save_dir, 'ema_sample%d.png' % epoch))
+            if (epoch + 1) % 200 == 0 and epoch != current_epoch:                          # train.py:275-277
+                torch.save(model.state_dict(), os.path.join(args.save_dir, 'med_gan_params-%d' % epoch))
+                np.savez(os.path.join(args.save_dir, 'distances.npz'), mean_dist_gen=np.array(mean_dist_gen),
+                         mean_dist_disc=np.array(mean_dist_disc))
+                print('current epoch %d, elapsed hours from start epoch %.3f, total updates %d' % (
+                    epoch, (time.time() - start_time) / 3600, model.step_counter))
+            sys.stdout.flush()
+        if args.max_steps and total >= args.max_steps:
+            break
+    return model
+
+
+if __name__ == '__main__':
+    main()

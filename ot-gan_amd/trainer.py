@@ -1,0 +1,152 @@
+"""The OT-GAN training step (reference train.py:52-151 graph section + :207-226 hot loop),
+wired on the HIP kernels: generator / critic forward, mini-batch Sinkhorn matching, gradient
+injection (`grad_ys`), cross-rank gradient sum, optimiser and EMA updates."""
+import importlib
+
+import torch
+
+from . import parallel
+from .utils import matching, nn
+
+
+class OTGAN:
+    """State of one training run.  `args` carries the reference's flags (train.py:14-33)
+    plus: image_size, matching_scope ('global' = one OT problem set over all ranks, the
+    reference's semantics; 'local' = an independent problem set per rank)."""
+
+    def __init__(self, args, device):
+        self.args = args
+        self.device = device
+        self.rank, self.world = parallel.get_rank(), parallel.world_size()
+        if args.nr_gpu % 2 != 0:
+            raise AssertionError("nr_gpu must be even (train.py:34)")
+        if args.nr_gpu % self.world != 0:
+            raise ValueError("--nr_gpu (logical shards) must be a multiple of the number of ranks")
+        self.shards = args.nr_gpu // self.world           # logical shards on this rank
+        self.scope = getattr(args, "matching_scope", "global")
+        if self.world == 1:
+            self.scope = "local"
+        if self.scope == "local" and self.shards % 2 != 0:
+            raise ValueError("local matching needs an even number of shards per rank")
+        self.nb = self.shards * args.batch_size             # images per rank per step
+        mod = importlib.import_module(f".models.{args.model}", package=__package__)  # train.py:38-41
+        self.generator, self.discriminator = mod.generator, mod.discriminator
+        self.generator.reset(seed=args.seed, device=device)
+        self.discriminator.reset(seed=args.seed, device=device)
+        self.model_opts = {"nonlinearity": args.nonlinearity}
+        size = getattr(args, "image_size", 32)
+        # parameter creation pass (train.py:52-56; the data-dependent init it builds is never run)
+        with torch.no_grad():
+            f = self.discriminator(torch.zeros(2, size, size, 3, device=device), init=True, **self.model_opts)
+            self.generator(batch_size=2, init=True, device=device, **self.model_opts)
+        self.num_features = f.shape[-1]
+        self.disc_params = self.discriminator.trainable_variables()     # train.py:61
+        self.gen_params = self.generator.trainable_variables()          # train.py:62
+        self.ema = nn.ExponentialMovingAverage(decay=0.999)             # train.py:63
+        self.maintain_averages = self.ema.apply(self.gen_params)        # train.py:64
+        mk = {"adam": nn.adam_updates, "adamax": nn.adamax_updates, "nesterov": nn.nesterov_updates}
+        if args.optimizer not in mk:
+            raise ValueError("unsupported optimizer")
+        kw = {"mom1": 0.5} if args.optimizer == "nesterov" else {"mom1": 0.5, "mom2": 0.999}
+        self.gen_optimizer = mk[args.optimizer](self.gen_params, **kw)          # train.py:142
+        self.disc_optimizer = mk[args.optimizer](self.disc_params, **kw)        # train.py:143
+        self.step_counter = 0
+        self.last = {}
+
+    # ---------------------------------------------------------------- matching (train.py:88-98)
+    def _match(self, f_gen, f_dat):
+        a = self.args
+        if self.scope == "global" and self.world > 1:
+            fa = parallel.gather_feature_shards(f_gen, self.shards)
+            fb = parallel.gather_feature_shards(f_dat, self.shards)
+        else:
+            fa = list(torch.chunk(f_gen, self.shards, 0))
+            fb = list(torch.chunk(f_dat, self.shards, 0))
+        if a.single_batch:
+            m = matching.get_matched_features_single_batch(fa, fb, a.sinkhorn_lambda, a.nr_sinkhorn_iter)
+        elif a.no_sinkhorn:
+            m = matching.get_matched_features_random(fa, fb)
+        else:
+            m = matching.get_matched_features(fa, fb, a.sinkhorn_lambda, a.nr_sinkhorn_iter)
+        dist = m.distance if m.distance is not None else matching.calc_distance(fa, fb, m)
+        lo = self.rank * self.shards if (self.scope == "global" and self.world > 1) else 0
+        pick = lambda lst: torch.cat(lst[lo:lo + self.shards], 0)
+        # injected upstream gradients (train.py:111,125-126): un-normalised matched differences
+        grad_gen = pick(m[0]) - pick(m[2])
+        grad_dat = pick(m[1]) - pick(m[3])
+        return grad_gen, grad_dat, dist, m[4]
+
+    # ---------------------------------------------------------------- one sess.run
+    def step(self, x_data):
+        """x_data: [shards*batch_size, H, W, 3] in [-1, 1].  Runs a critic step when
+        step_counter % (nr_gen_per_disc+1) == 0, else a generator step (train.py:214-226)."""
+        a = self.args
+        assert x_data.shape[0] == self.nb
+        if self.step_counter % (a.nr_gen_per_disc + 1) == 0:
+            kind = "disc"
+            with torch.no_grad():
+                ema = self.ema if a.train_disc_against_ema else None    # train.py:119-123
+                x_gen = self.generator(batch_size=self.nb, ema=ema, device=self.device, **self.model_opts)
+            f_all = self.discriminator(torch.cat([x_data, x_gen], 0), **self.model_opts)
+            f_dat, f_gen = f_all[:self.nb], f_all[self.nb:]
+            g_gen, g_dat, dist, ent = self._match(f_gen.detach(), f_dat.detach())
+            grads = torch.autograd.grad(f_all, self.disc_params, torch.cat([g_dat, g_gen], 0))   # train.py:127-128
+            grads = parallel.allreduce_sum_(list(grads))                                          # train.py:134-139
+            self.disc_optimizer(grads, lr=-a.learning_rate_disc)                                  # train.py:143
+        else:
+            kind = "gen"
+            x_gen = self.generator(batch_size=self.nb, device=self.device, **self.model_opts)
+            with torch.no_grad():
+                f_dat = self.discriminator(x_data, **self.model_opts)
+            f_gen = self.discriminator(x_gen, **self.model_opts)
+            g_gen, _g_dat, dist, ent = self._match(f_gen.detach(), f_dat)
+            grads = torch.autograd.grad(f_gen, self.gen_params, g_gen)                            # train.py:112
+            grads = parallel.allreduce_sum_(list(grads))
+            self.gen_optimizer(grads, lr=a.learning_rate_gen)                                     # train.py:142
+            self.maintain_averages()                                                              # train.py:223
+        self.step_counter += 1
+        self.last = {"kind": kind, "distance": dist, "entropy": ent}      # device scalars, no sync
+        return self.last
+
+    @torch.no_grad()
+    def sample(self, n, ema=False):
+        return self.generator(batch_size=n, ema=self.ema if ema else None, device=self.device, **self.model_opts)
+
+    def state_dict(self):
+        sd = {"step_counter": self.step_counter}
+        for t in (self.discriminator, self.generator):
+            sd.update({k: v.detach().cpu() for k, v in t.named_variables().items()})
+        return sd
+
+    def load_state_dict(self, sd):
+        with torch.no_grad():
+            for t in (self.discriminator, self.generator):
+                for k, v in t.named_variables().items():
+                    v.copy_(sd[k].to(v.device))
+        self.step_counter = int(sd.get("step_counter", 0))
+
+
+def default_args(**over):
+    """The reference's flag defaults (train.py:14-33) plus the added ones."""
+    import argparse
+    d = dict(seed=1, batch_size=625, learning_rate_disc=0.0003, learning_rate_gen=0.0003,
+             data_dir='/home/tim/data', save_dir='/local_home/tim/med_gan', optimizer='adam',
+             nonlinearity='crelu', nr_gpu=8, nr_gen_per_disc=5, sinkhorn_lambda=500.,
+             nr_sinkhorn_iter=500, single_batch=False, train_disc_against_ema=False, model='dcgan',
+             load_params=False, model_name='med_gan_params-2399', no_sinkhorn=False,
+             image_size=32, matching_scope='global', synthetic=False, max_steps=0)
+    d.update(over)
+    return argparse.Namespace(**d)
+
+
+def smoke_step(device):
+    """One tiny critic step + one generator step (used by __graft_entry__.smoke())."""
+    args = default_args(batch_size=4, nr_gpu=2, nr_sinkhorn_iter=10, nr_gen_per_disc=1)
+    m = OTGAN(args, device)
+    x = torch.rand(m.nb, 32, 32, 3, device=device) * 2 - 1
+    r0 = m.step(x)
+    r1 = m.step(x)
+    assert r0["kind"] == "disc" and r1["kind"] == "gen"
+    for r in (r0, r1):
+        assert torch.isfinite(r["distance"]).item() and torch.isfinite(r["entropy"]).item()
+    print("smoke ok: train steps", float(r0["distance"]), float(r1["distance"]))

@@ -1,0 +1,309 @@
+"""Layers, parameter handling and optimisers -- the MI355X host-side mirror of the
+reference's `utils/nn.py` (same public names and argument meaning):
+
+    conv2d, dense           nn.py:327-338, 314-325  (weight norm, list inputs, pre-activation)
+    arg_scope               tensorflow.contrib.framework.arg_scope as used by models/*.py
+    make_template           tf.make_template (shared parameters across calls)
+    ExponentialMovingAverage  tf.train.ExponentialMovingAverage as used in train.py:63-64
+    adam_updates, adamax_updates, nesterov_updates   nn.py:29-87
+
+Tensors are NHWC float32 CUDA tensors; all arithmetic runs in the HIP library through
+`otgan_amd.ops` (torch.autograd Functions).  Parameters are created on first use with the
+reference's *effective* initialisation (the data-dependent init tensors of
+nn.py:133-162 are built but never run by train.py, so V ~ N(0, 0.05), g = 1, b = 0).
+"""
+import contextlib
+import threading
+from collections import OrderedDict
+
+import torch
+
+from .. import ops
+
+# --------------------------------------------------------------------------------- arg_scope
+_scope = threading.local()
+
+
+def _stack():
+    if not hasattr(_scope, "stack"):
+        _scope.stack = []
+    return _scope.stack
+
+
+@contextlib.contextmanager
+def arg_scope(funcs, **kwargs):
+    """Default keyword arguments for the listed layer functions inside the `with` block."""
+    _stack().append(({f.__name__ for f in funcs}, kwargs))
+    try:
+        yield
+    finally:
+        _stack().pop()
+
+
+def _scoped(fn):
+    def wrapper(*args, **kwargs):
+        merged = {}
+        for names, kw in _stack():
+            if fn.__name__ in names:
+                merged.update(kw)
+        merged.update(kwargs)
+        return fn(*args, **merged)
+    wrapper.__name__ = fn.__name__
+    wrapper.__doc__ = fn.__doc__
+    return wrapper
+
+
+# --------------------------------------------------------------------------------- variables
+class VariableStore:
+    """Named trainable tensors of one template ('discriminator/conv2d_0/V', ...), in creation
+    order (V, g, b per layer -- the order of the reference's first, init=True, call)."""
+
+    def __init__(self, scope, device=None, seed=1):
+        self.scope = scope
+        self.device = device
+        self.vars = OrderedDict()
+        self._gen = None
+        self._seed = seed
+
+    def _generator(self):
+        if self._gen is None:
+            self._gen = torch.Generator(device="cpu")
+            self._gen.manual_seed(self._seed + sum(map(ord, self.scope)))
+        return self._gen
+
+    def get(self, name, shape, kind, device):
+        full = f"{self.scope}/{name}"
+        v = self.vars.get(full)
+        if v is None:
+            if kind == "normal":      # tf.random_normal_initializer(0, 0.05)   nn.py:124
+                t = torch.empty(shape, dtype=torch.float32).normal_(0.0, 0.05, generator=self._generator())
+            elif kind == "ones":      # nn.py:143
+                t = torch.ones(shape, dtype=torch.float32)
+            else:                     # zeros, nn.py:160
+                t = torch.zeros(shape, dtype=torch.float32)
+            v = t.to(self.device or device).requires_grad_(True)
+            self.vars[full] = v
+        elif tuple(v.shape) != tuple(shape):
+            raise ValueError(f"variable {full} has shape {tuple(v.shape)}, requested {tuple(shape)}")
+        return v
+
+
+_current = threading.local()
+
+
+def _store():
+    st = getattr(_current, "store", None)
+    if st is None:
+        raise RuntimeError("layers must be called inside a template (nn.make_template)")
+    return st
+
+
+class Template:
+    """Callable with shared parameters -- the role tf.make_template plays in models/*.py."""
+
+    def __init__(self, name, fn, seed=1):
+        self.name = name
+        self.fn = fn
+        self.store = VariableStore(name, seed=seed)
+
+    def __call__(self, *args, **kwargs):
+        prev = getattr(_current, "store", None)
+        _current.store = self.store
+        try:
+            return self.fn(*args, **kwargs)
+        finally:
+            _current.store = prev
+
+    def trainable_variables(self):
+        return list(self.store.vars.values())
+
+    def named_variables(self):
+        return OrderedDict(self.store.vars)
+
+    def reset(self, seed=1, device=None):
+        self.store = VariableStore(self.name, device=device, seed=seed)
+
+
+def make_template(name, fn, seed=1):
+    return Template(name, fn, seed)
+
+
+class ExponentialMovingAverage:
+    """shadow <- decay*shadow + (1-decay)*param   (train.py:63-64; shadows start at the
+    parameter values like tf.train.ExponentialMovingAverage)."""
+
+    def __init__(self, decay=0.999):
+        self.decay = decay
+        self._shadow = {}
+        self._params = []
+
+    def apply(self, params):
+        for p in params:
+            if id(p) not in self._shadow:
+                self._shadow[id(p)] = p.detach().clone()
+                self._params.append(p)
+        return self.update
+
+    def update(self):
+        for p in self._params:
+            ops.ema_update(self._shadow[id(p)], p.detach(), self.decay)
+
+    def average(self, p):
+        return self._shadow[id(p)]
+
+    def state(self):
+        return [self._shadow[id(p)] for p in self._params]
+
+
+def get_var_maybe_avg(name, shape, kind, ema, device):
+    """nn.py:89-93"""
+    v = _store().get(name, shape, kind, device)
+    return ema.average(v) if ema is not None else v
+
+
+def get_name(layer_name, counters):
+    """nn.py:95-100"""
+    if layer_name not in counters:
+        counters[layer_name] = 0
+    name = f"{layer_name}_{counters[layer_name]}"
+    counters[layer_name] += 1
+    return name
+
+
+def _as_list(x):
+    if isinstance(x, tuple):
+        return list(x)
+    if not isinstance(x, list):
+        return [x]
+    return x
+
+
+def _channels_eff(xs, pre_activation):
+    c = sum(int(t.shape[-1]) for t in xs)
+    return c * (2 if pre_activation in ("celu", "crelu") else 1), c
+
+
+# --------------------------------------------------------------------------------- layers
+@_scoped
+def dense(x, num_units, pre_activation='celu', init_scale=1., counters={}, init=False, ema=None,
+          weight_norm=True, use_b=True, use_g=True, **kwargs):
+    """Fully connected layer on a [B, C] tensor or list of tensors (reference nn.py:314-325)."""
+    if not (weight_norm and use_g and use_b):
+        raise NotImplementedError("only the weight_norm=True, use_g=True, use_b=True layer of the "
+                                  "reference models is implemented")
+    name = get_name('dense', counters)
+    xs = _as_list(x)
+    nr_in, c = _channels_eff(xs, pre_activation)
+    dev = xs[0].device
+    V = get_var_maybe_avg(f"{name}/V", (nr_in, num_units), "normal", ema, dev)
+    g = get_var_maybe_avg(f"{name}/g", (num_units,), "ones", ema, dev)
+    b = get_var_maybe_avg(f"{name}/b", (num_units,), "zeros", ema, dev)
+    xin = xs[0] if len(xs) == 1 else torch.cat(xs, 1)
+    return ops.dense_op(xin, V, g, b, preact=ops.ACT[pre_activation], segs=[int(t.shape[-1]) for t in xs])
+
+
+@_scoped
+def conv2d(x, num_filters, pre_activation='celu', filter_size=[3, 3], stride=[1, 1], pad='SAME',
+           dilate=1, upsample=False, init_scale=1., counters={}, init=False, ema=None,
+           weight_norm=True, use_b=True, use_g=True, **kwargs):
+    """2-D convolution on an NHWC tensor or list of tensors (reference nn.py:327-338):
+    optional 2x nearest-neighbour upsample, pre-activation over the list, weight-normalised
+    HWIO filter, TF 'SAME' padding, bias."""
+    if pad != 'SAME' or dilate != 1:
+        raise NotImplementedError("the reference models only use pad='SAME', dilate=1")
+    if not (weight_norm and use_g and use_b):
+        raise NotImplementedError("only the weight_norm=True, use_g=True, use_b=True layer of the "
+                                  "reference models is implemented")
+    if stride[0] != stride[1]:
+        raise NotImplementedError("square strides only")
+    name = get_name('conv2d', counters)
+    xs = _as_list(x)
+    nr_in, c = _channels_eff(xs, pre_activation)
+    dev = xs[0].device
+    V = get_var_maybe_avg(f"{name}/V", (filter_size[0], filter_size[1], nr_in, num_filters), "normal", ema, dev)
+    g = get_var_maybe_avg(f"{name}/g", (num_filters,), "ones", ema, dev)
+    b = get_var_maybe_avg(f"{name}/b", (num_filters,), "zeros", ema, dev)
+    xin = xs[0] if len(xs) == 1 else torch.cat(xs, 3)
+    return ops.conv2d_op(xin, V, g, b, stride=stride[0], upsample=upsample,
+                         preact=ops.ACT[pre_activation], segs=[int(t.shape[-1]) for t in xs])
+
+
+def feature_head(x):
+    """CReLU -> flatten -> L2 row normalisation (models/dcgan.py:16-19)."""
+    return ops.feature_head(x)
+
+
+def glu(x):
+    """x[..., :C] * sigmoid(x[..., C:])  ("gated linear unit", models/dcgan.py:35-36)."""
+    return ops.glu(x)
+
+
+def tanh(x):
+    return ops.tanh(x)
+
+
+# --------------------------------------------------------------------------------- optimisers
+class _Updates:
+    """State + step of one optimiser over a fixed parameter list; gradients are supplied per
+    step as a list (the reference passes precomputed gradient lists, nn.py:52-55)."""
+
+    def __init__(self, params, lr, mom1, mom2):
+        self.params = list(params)
+        self.lr, self.mom1, self.mom2 = lr, mom1, mom2
+        self.state = [{} for _ in self.params]
+        self.t = 1.0
+
+    def __call__(self, grads, lr=None):
+        lr = self.lr if lr is None else lr
+        with torch.no_grad():
+            for p, g, st in zip(self.params, grads, self.state):
+                self._step(p, g.contiguous(), st, lr)
+        self.t += 1.0
+
+
+class _Adam(_Updates):
+    def _step(self, p, g, st, lr):
+        if not st:
+            st["mg"] = torch.zeros_like(p)
+            st["v"] = torch.zeros_like(p) if self.mom1 > 0 else None
+        ops.adam_step(p, g, st["v"], st["mg"], lr, self.mom1, self.mom2, self.t)
+
+
+class _Adamax(_Updates):
+    def _step(self, p, g, st, lr):
+        if not st:
+            st["mg"] = torch.zeros_like(p)
+            st["v"] = torch.zeros_like(p) if self.mom1 > 0 else None
+        ops.adamax_step(p, g, st["v"], st["mg"], lr, self.mom1, self.mom2)
+
+
+class _Nesterov(_Updates):
+    def _step(self, p, g, st, lr):
+        if not st:
+            st["v"] = torch.zeros_like(p)
+        ops.nesterov_step(p, g, st["v"], lr, self.mom1)
+
+
+def _maybe_apply(upd, cost_or_grads):
+    if isinstance(cost_or_grads, (list, tuple)):
+        upd(cost_or_grads)
+    elif cost_or_grads is not None:
+        upd(torch.autograd.grad(cost_or_grads, upd.params))
+    return upd
+
+
+def adam_updates(params, cost_or_grads=None, lr=0.001, mom1=0.9, mom2=0.999):
+    """Adam as the reference writes it (nn.py:50-73): epsilon inside the square root, one
+    step counter per optimiser starting at 1.  Returns the update callable `upd(grads, lr)`;
+    if `cost_or_grads` is given one step is applied immediately."""
+    return _maybe_apply(_Adam(params, lr, mom1, mom2), cost_or_grads)
+
+
+def adamax_updates(params, cost_or_grads=None, lr=0.001, mom1=0.9, mom2=0.999):
+    """nn.py:29-48"""
+    return _maybe_apply(_Adamax(params, lr, mom1, mom2), cost_or_grads)
+
+
+def nesterov_updates(params, cost_or_grads=None, lr=0.01, mom1=0.9):
+    """nn.py:75-87"""
+    return _maybe_apply(_Nesterov(params, lr, mom1, None), cost_or_grads)

@@ -157,7 +157,7 @@ def test_glu_tanh_head(dev):
     f = ops.feature_head(xh)
     assert f.shape == (5, 4 * 4 * 48)
     assert _rel(f, f_ref) < 1e-6
-    np.testing.assert_allclose(f.norm(dim=1).cpu().numpy(), 1.0, atol=1e-6)
+    np.testing.assert_allclose(f.detach().norm(dim=1).cpu().numpy(), 1.0, atol=1e-6)
     (dxh,) = torch.autograd.grad(f, [xh], df.float().to(dev))
     assert _rel(dxh, dxh_ref) < 1e-5
 
