@@ -49,6 +49,21 @@ typedef struct otgan_conv_desc {
 /* which: 0 fwd, 1 dgrad, 2 wgrad */
 size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which);
 
+/*
+ * Upsample folding.  conv(k x k) applied to a 2x nearest-neighbour upsampled image equals four
+ * output-parity-class convolutions on the SMALL image whose taps are sums of the original
+ * ones (k = 5: 3x3 per class instead of 5x5; k = 3: 2x2 instead of 3x3) -- identical
+ * mathematics with 25/9 (9/4) fewer multiply-adds in fwd, dgrad and wgrad.
+ * A layer is folded iff otgan_conv2d_folded_weight_elems(d) > 0 (a pure function of the
+ * descriptor: upsample == 1, stride == 1, Cin_eff % 16 == 0, 4-aligned channel strides).
+ * For a folded layer the caller runs otgan_conv2d_fold_weights_f32 once per weight update and
+ * passes `weffT` as the `wT` argument of otgan_conv2d_fwd_f32 and `weff` as the `w` argument
+ * of otgan_conv2d_dgrad_f32; otgan_conv2d_wgrad_f32 still returns the un-folded HWIO gradient.
+ */
+size_t otgan_conv2d_folded_weight_elems(const otgan_conv_desc* d);
+int otgan_conv2d_fold_weights_f32(const otgan_conv_desc* d, const float* w, float* weff,
+                                  float* weffT, void* stream);
+
 /* y = conv2d(preact(upsample(x)), W) + bias.   wT: [Cout][KH*KW*Cin_eff] (transposed copy
  * of the HWIO weight, produced by otgan_weightnorm_fwd_f32).  nn.py:241,337. */
 int otgan_conv2d_fwd_f32(const otgan_conv_desc* d, const float* x, const int32_t* cmap,

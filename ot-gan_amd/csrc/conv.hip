@@ -4,13 +4,22 @@
 // 'SAME' padding fused into the operand gathers.
 // Replaces reference utils/nn.py:190-206 (pre-activation), :234-241 (conv), :327-338.
 //
-// GEMM views (K index always = (tap, channel) or pixels):
+// GEMM views (K index = (tap, channel) or pixels):
 //   fwd   : Y[pixel, co]        = sum_{tap, d}  A(x)[pixel+tap, d] * W[tap, d, co]
 //   dgrad : dXe[in-pixel, d]    = sum_{tap, co} dY[in-pixel-tap, co] * W[tap, d, co]
-//           (stride 2: one launch per input-parity class, only the taps that hit it)
 //           then dX[c] = act'(x_c) (dXe[d+(c)] , dXe[d-(c)]) in the epilogue
 //   wgrad : dW[tap, d, co]      = sum_{pixel}  A(x)[pixel+tap, d] * dY[pixel, co]
 //           (split over pixels, slabs reduced afterwards)
+//
+// "Classes": a launch may cover up to four tap tables selected by blockIdx.z.
+//   * stride-2 dgrad: one class per input-pixel parity (only the taps that reach it);
+//   * upsample folding: conv(k x k) o nearest-upsample(2x) == four parity-class convs with
+//     ceil((k+1)/2)^2 pre-summed taps on the SMALL grid (k=5: 9 instead of 25 taps; k=3: 4
+//     instead of 9) -- identical mathematics, 25/9 (9/4) fewer MACs in fwd, dgrad and wgrad.
+//
+// Operand staging: load() only ISSUES the global loads of the next K tile (raw values into
+// registers); sign / activation are applied in store(), after the current tile's MFMAs, so
+// the memory latency hides under BK/2 * MT*NT * 64 cycles of matrix work.
 #include "gemm_tile.h"
 #include "../../include/otgan.h"
 
@@ -19,37 +28,43 @@ namespace {
 using CfgMain = GemmCfg<2, 2, 2, 2, 16>;    // 128 x 128 block tile
 using CfgNarrow = GemmCfg<4, 1, 2, 1, 16>;  // 256 x 32 block tile (Cout / Cin <= 32)
 
-constexpr int kMaxTaps = 25;
+constexpr int kMaxTaps = 36;
+constexpr int kMaxClass = 4;
 
 struct Taps {
   int n;
-  short dh[kMaxTaps];
-  short dw[kMaxTaps];
-  int boff[kMaxTaps];  // offset of this tap's weight block in the B operand
+  int dhw[kMaxTaps];   // (dh << 16) | (dw & 0xffff)
+  int boff[kMaxTaps];  // offset of this tap's weight block in the B operand (elements)
+};
+struct ClassTab {
+  int ncls;
+  int oa[kMaxClass], ob[kMaxClass];  // output-pixel offsets of the class
+  int zbase[kMaxClass + 1];          // prefix sums of taps (wgrad: blockIdx.z -> class, tap)
+  long woff[kMaxClass];              // offset of the class's weight block (elements)
+  Taps taps[kMaxClass];
 };
 
-// Source of the gathered ("A") operand: an NHWC tensor read through tap offsets, optional 2x
-// nearest upsampling, channel map (list interleave + sign) and activation.
+__device__ __forceinline__ int sx16(int v) { return (int)(short)(v & 0xffff); }
+
+// Source of the gathered ("A") operand.
 struct GatherA {
   const float* x;
   int ldx;
-  int H, W;      // stored dims
-  int logUp;     // virtual dims = H << logUp
-  int logGH, logGW;  // the row grid [*, GH, GW] (powers of two)
-  int Mtot;      // rows = N * GH * GW
-  int sa;        // virtual coord = grid coord * sa + tap offset
-  int Ck;        // effective channels per tap
+  int H, W;          // stored dims
+  int logUp;         // virtual dims = H << logUp (legacy un-folded upsample path)
+  int logGH, logGW;  // row grid [*, GH, GW] (powers of two)
+  int Mtot;          // rows = N * GH * GW
+  int sa;            // virtual coord = grid coord * sa + tap offset
+  int Ck;            // effective channels per tap
   const int* cmap;
   int Creal;
-  int doubled;   // default map: d < Creal -> +x[d], else -x[d - Creal]
-  int act;       // 0 none, 1 relu, 2 elu -- applied to sign * x
+  int doubled;       // default map: d < Creal -> +x[d], else -x[d - Creal]
 };
 
-__device__ __forceinline__ void map_channel(const GatherA& g, int d, int& c, float& sgn) {
+__device__ __forceinline__ void decode_map(const GatherA& g, int d, int cmv, int& c, float& sgn) {
   if (g.cmap) {
-    const int v = g.cmap[d];
-    c = v & 0x7fffffff;
-    sgn = v < 0 ? -1.f : 1.f;
+    c = cmv & 0x7fffffff;
+    sgn = cmv < 0 ? -1.f : 1.f;
   } else if (g.doubled && d >= g.Creal) {
     c = d - g.Creal;
     sgn = -1.f;
@@ -59,12 +74,12 @@ __device__ __forceinline__ void map_channel(const GatherA& g, int d, int& c, flo
   }
 }
 
-__device__ __forceinline__ float act_apply(int act, float v) {
-  if (act == 1) return fmaxf(v, 0.f);
-  if (act == 2) return v > 0.f ? v : expm1f(v);
+template <int ACT>
+__device__ __forceinline__ float act_apply(float v) {
+  if (ACT == 1) return fmaxf(v, 0.f);
+  if (ACT == 2) return v > 0.f ? v : expm1f(v);
   return v;
 }
-// derivative of act at v
 __device__ __forceinline__ float act_deriv(int act, float v) {
   if (act == 1) return v > 0.f ? 1.f : 0.f;
   if (act == 2) return v > 0.f ? 1.f : expf(v);
@@ -72,9 +87,9 @@ __device__ __forceinline__ float act_deriv(int act, float v) {
 }
 
 // ---------------------------------------------------------------------------------------
-// A loaders (rows = pixels, K = (tap, channel), K contiguous in memory)
+// A loader (rows = pixels, K = (tap, channel), K contiguous in memory)
 // ---------------------------------------------------------------------------------------
-template <class Cfg, int BR, bool VEC>
+template <class Cfg, int BR, bool VEC, int ACT>
 struct ConvALoader {
   static constexpr int BK = Cfg::BK;
   static constexpr int LD = BR + KPad<BK>::value;
@@ -86,6 +101,10 @@ struct ConvALoader {
   const Taps& taps;
   int pixbase[PASSES], ia[PASSES], ib[PASSES];
   float4 reg[PASSES];
+  unsigned neg[PASSES];  // scalar path: per-element sign bits
+  float sgn;             // vector path: sign of this thread's quad in the pending tile
+  int cm_next;           // prefetched channel-map entry of the next tile
+  int nt, nd;            // (tap, channel offset) of the next tile to load
   int vH, vW, Ktot;
 
   __device__ __forceinline__ ConvALoader(const GatherA& g_, const Taps& t_) : g(g_), taps(t_) {}
@@ -95,10 +114,15 @@ struct ConvALoader {
     vH = g.H << g.logUp;
     vW = g.W << g.logUp;
     Ktot = taps.n * g.Ck;
+    nt = 0;
+    nd = 0;
+    sgn = 1.f;
+    cm_next = (VEC && g.cmap) ? g.cmap[4 * (threadIdx.x % CPR)] : 0;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int r = r0 + p * RPP;
       const int m = m0 + r;
+      neg[p] = 0;
       if (r < BR && m < g.Mtot) {
         const int b = m & ((1 << g.logGW) - 1);
         const int a = (m >> g.logGW) & ((1 << g.logGH) - 1);
@@ -114,30 +138,17 @@ struct ConvALoader {
     }
   }
 
-  __device__ __forceinline__ float fetch1(int p, int k) const {
-    if (k >= Ktot) return 0.f;
-    const int t = k / g.Ck;
-    const int d = k - t * g.Ck;
-    const int ih = ia[p] + taps.dh[t], iw = ib[p] + taps.dw[t];
-    if ((unsigned)ih >= (unsigned)vH || (unsigned)iw >= (unsigned)vW) return 0.f;
-    int c;
-    float sgn;
-    map_channel(g, d, c, sgn);
-    const long pix = (long)pixbase[p] + (long)(ih >> g.logUp) * g.W + (iw >> g.logUp);
-    return act_apply(g.act, sgn * g.x[pix * g.ldx + c]);
-  }
-
+  // issue the loads of K tile kt (tiles are requested in order 0, 1, 2, ...)
   __device__ __forceinline__ void load(int kt) {
     const int c4 = threadIdx.x % CPR;
-    const int k = kt * BK + 4 * c4;
     if (VEC) {
       // Ck % BK == 0: the whole K tile lies inside one tap
-      const int t = (kt * BK) / g.Ck;
-      const int d = k - t * g.Ck;
+      const int t = __builtin_amdgcn_readfirstlane(nt);
+      const int d = __builtin_amdgcn_readfirstlane(nd) + 4 * c4;
       int sc;
-      float sgn;
-      map_channel(g, d, sc, sgn);
-      const int dh = taps.dh[t], dw = taps.dw[t];
+      decode_map(g, d, cm_next, sc, sgn);
+      const int dhw = taps.dhw[t];
+      const int dh = dhw >> 16, dw = sx16(dhw);
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {
         const int ih = ia[p] + dh, iw = ib[p] + dw;
@@ -145,22 +156,41 @@ struct ConvALoader {
         if ((unsigned)ih < (unsigned)vH && (unsigned)iw < (unsigned)vW) {
           const long pix = (long)pixbase[p] + (long)(ih >> g.logUp) * g.W + (iw >> g.logUp);
           v = *reinterpret_cast<const float4*>(g.x + pix * g.ldx + sc);
-          v.x = act_apply(g.act, sgn * v.x);
-          v.y = act_apply(g.act, sgn * v.y);
-          v.z = act_apply(g.act, sgn * v.z);
-          v.w = act_apply(g.act, sgn * v.w);
         }
         reg[p] = v;
       }
+      nd += BK;
+      if (nd >= g.Ck) {
+        nd = 0;
+        nt += 1;
+      }
+      if (g.cmap && nt < taps.n) cm_next = g.cmap[nd + 4 * c4];  // consumed one tile later
     } else {
+      const int k = kt * BK + 4 * c4;
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {
-        float4 v;
-        v.x = fetch1(p, k);
-        v.y = fetch1(p, k + 1);
-        v.z = fetch1(p, k + 2);
-        v.w = fetch1(p, k + 3);
-        reg[p] = v;
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+        unsigned nb = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int kk = k + q;
+          if (kk < Ktot) {
+            const int t = kk / g.Ck;
+            const int d = kk - t * g.Ck;
+            const int dhw = taps.dhw[t];
+            const int ih = ia[p] + (dhw >> 16), iw = ib[p] + sx16(dhw);
+            if ((unsigned)ih < (unsigned)vH && (unsigned)iw < (unsigned)vW) {
+              int c;
+              float s;
+              decode_map(g, d, g.cmap ? g.cmap[d] : 0, c, s);
+              const long pix = (long)pixbase[p] + (long)(ih >> g.logUp) * g.W + (iw >> g.logUp);
+              e[q] = g.x[pix * g.ldx + c];
+              if (s < 0.f) nb |= 1u << q;
+            }
+          }
+        }
+        reg[p] = make_float4(e[0], e[1], e[2], e[3]);
+        neg[p] = nb;
       }
     }
   }
@@ -171,11 +201,20 @@ struct ConvALoader {
     for (int p = 0; p < PASSES; ++p) {
       const int r = r0 + p * RPP;
       if (r < BR) {
+        float4 v = reg[p];
+        if (VEC) {
+          v.x *= sgn; v.y *= sgn; v.z *= sgn; v.w *= sgn;
+        } else {
+          if (neg[p] & 1u) v.x = -v.x;
+          if (neg[p] & 2u) v.y = -v.y;
+          if (neg[p] & 4u) v.z = -v.z;
+          if (neg[p] & 8u) v.w = -v.w;
+        }
         float* d = t + (4 * c4) * LD + r;
-        d[0] = reg[p].x;
-        d[LD] = reg[p].y;
-        d[2 * LD] = reg[p].z;
-        d[3 * LD] = reg[p].w;
+        d[0] = act_apply<ACT>(v.x);
+        d[LD] = act_apply<ACT>(v.y);
+        d[2 * LD] = act_apply<ACT>(v.z);
+        d[3 * LD] = act_apply<ACT>(v.w);
       }
     }
   }
@@ -202,16 +241,19 @@ struct ConvBLoader {
   static constexpr int PASSES = (BR + RPP - 1) / RPP;
   const WeightB& b;
   const Taps& taps;
+  const float* wbase;
   long rowoff[PASSES];  // row(n) * ldbn, or -1 when the row is invalid
   float4 reg[PASSES];
-  int Ktot;
+  int nt, nd, Ktot;
 
-  __device__ __forceinline__ ConvBLoader(const WeightB& b_, const Taps& t_) : b(b_), taps(t_) {}
+  __device__ __forceinline__ ConvBLoader(const WeightB& b_, const Taps& t_, const float* wb)
+      : b(b_), taps(t_), wbase(wb) {}
 
-  // nblk: index of the N tile
   __device__ __forceinline__ void init(int nblk) {
     const int r0 = threadIdx.x / CPR;
     Ktot = taps.n * b.Ck;
+    nt = 0;
+    nd = 0;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int r = r0 + p * RPP;
@@ -220,10 +262,10 @@ struct ConvBLoader {
         if (b.paired) {
           // block tile = 64 real channels; wave column wn owns 32 of them; its two 32-wide
           // MFMA column tiles hold the (+c) and the (-c) effective channels.
-          const int wn = r >> 6, nt = (r >> 5) & 1, j = r & 31;
+          const int wn = r >> 6, ntile = (r >> 5) & 1, j = r & 31;
           const int c = nblk * 64 + wn * 32 + j;
           if (c < b.Creal) {
-            const int d = b.inv ? b.inv[nt * b.Creal + c] : (nt * b.Creal + c);
+            const int d = b.inv ? b.inv[ntile * b.Creal + c] : (ntile * b.Creal + c);
             off = (long)d * b.ldbn;
           }
         } else {
@@ -237,18 +279,23 @@ struct ConvBLoader {
 
   __device__ __forceinline__ void load(int kt) {
     const int c4 = threadIdx.x % CPR;
-    const int k = kt * BK + 4 * c4;
     if (VEC) {
-      const int t = (kt * BK) / b.Ck;
-      const int d = k - t * b.Ck;
-      const float* base = b.w + taps.boff[t] + d;
+      const int t = __builtin_amdgcn_readfirstlane(nt);
+      const int d = __builtin_amdgcn_readfirstlane(nd) + 4 * c4;
+      const float* base = wbase + taps.boff[t] + d;
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (rowoff[p] >= 0) v = *reinterpret_cast<const float4*>(base + rowoff[p]);
         reg[p] = v;
       }
+      nd += BK;
+      if (nd >= b.Ck) {
+        nd = 0;
+        nt += 1;
+      }
     } else {
+      const int k = kt * BK + 4 * c4;
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {
         float e[4] = {0.f, 0.f, 0.f, 0.f};
@@ -259,7 +306,7 @@ struct ConvBLoader {
             if (kk < Ktot) {
               const int t = kk / b.Ck;
               const int d = kk - t * b.Ck;
-              e[q] = b.w[taps.boff[t] + rowoff[p] + d];
+              e[q] = wbase[taps.boff[t] + rowoff[p] + d];
             }
           }
         }
@@ -292,7 +339,7 @@ enum { EPI_FWD = 0, EPI_DG_PLAIN = 1, EPI_DG_ACT = 2, EPI_DG_PAIR = 3 };
 struct EpiArgs {
   float* out;
   int ldo, coff;
-  int so, oa, ob;        // out pixel = (n, a*so + oa, b*so + ob) on the [OHf, OWf] grid
+  int so;                // out pixel = (n, a*so + oa, b*so + ob) on the [OHf, OWf] grid
   int OHf, OWf;
   const float* bias;     // fwd
   int ncols;             // valid output columns (fwd: Cout; dgrad: real channels)
@@ -302,16 +349,18 @@ struct EpiArgs {
   int act;               // 1 relu-type, 2 elu-type
 };
 
-template <class Cfg, bool VEC, int EPI>
-__global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Taps taps, WeightB wb,
-                                                                 EpiArgs e) {
-  using LA = ConvALoader<Cfg, Cfg::BM, VEC>;
+template <class Cfg, bool VEC, int EPI, int ACT>
+__global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, ClassTab ct,
+                                                                 WeightB wb, EpiArgs e) {
+  using LA = ConvALoader<Cfg, Cfg::BM, VEC, ACT>;
   using LB = ConvBLoader<Cfg, Cfg::BN, VEC>;
   __shared__ __attribute__((aligned(16))) float smem[2 * LA::FLOATS + 2 * LB::FLOATS];
   const int m0 = blockIdx.x * Cfg::BM;
   const int nblk = blockIdx.y;
+  const int cls = blockIdx.z;
+  const Taps& taps = ct.taps[cls];
   LA la(g, taps);
-  LB lb(wb, taps);
+  LB lb(wb, taps, wb.w + ct.woff[cls]);
   la.init(m0);
   lb.init(nblk);
   f32x16 acc[Cfg::MT][Cfg::NT];
@@ -319,6 +368,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Tap
   const int nkt = (taps.n * g.Ck + Cfg::BK - 1) / Cfg::BK;
   gemm_mainloop<Cfg>(la, lb, nkt, smem, acc);
 
+  const int oa = ct.oa[cls], ob = ct.ob[cls];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int li = lane & 31, lh = lane >> 5;
@@ -331,7 +381,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Tap
       const int m = m0 + row;
       if (m >= g.Mtot) continue;
       const int b = m & gmask, a = (m >> g.logGW) & hmask, n = m >> (g.logGW + g.logGH);
-      const int oh = a * e.so + e.oa, ow = b * e.so + e.ob;
+      const int oh = a * e.so + oa, ow = b * e.so + ob;
       const long opix = ((long)n * e.OHf + oh) * e.OWf + ow;
       if (EPI == EPI_DG_PAIR) {
         static_assert(EPI != EPI_DG_PAIR || Cfg::NT == 2, "paired epilogue needs NT == 2");
@@ -371,15 +421,16 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Tap
 struct WgradArgs {
   const float* dy;   // already offset to the layer's channel range
   int ldy, Cout;
-  float* slab;       // [nsplit][Ktot * Cout]
+  int so, OHf, OWf;  // dy pixel of row-grid pixel (n,a,b): (n, a*so + oa, b*so + ob)
+  float* slab;       // [nsplit][slab_stride]
   int kt_per_split;  // pixel tiles (of BK) per split
   int tiles_n;
   long slab_stride;
 };
 
-// rows = effective channel d within tap blockIdx.z; float4 along d (needs Ck % 4 == 0,
-// contiguous cmap quads) and along co (Cout % 4 == 0, ldy % 4 == 0).
-template <class Cfg>
+// rows = effective channel d within one (class, tap) selected by blockIdx.z; float4 along d
+// (Ck % 4 == 0, contiguous cmap quads) and along co (Cout % 4 == 0, ldy % 4 == 0).
+template <class Cfg, int ACT>
 struct WgALoaderV {
   static constexpr int BK = Cfg::BK, BR = Cfg::BM;
   static constexpr int LD = BR + 4;
@@ -393,15 +444,15 @@ struct WgALoaderV {
   bool rowok;
   float4 reg[PASSES];
   __device__ __forceinline__ WgALoaderV(const GatherA& g_) : g(g_) {}
-  __device__ __forceinline__ void init(int d0, int tap_dh, int tap_dw, int mb) {
+  __device__ __forceinline__ void init(int d0, int dhw, int mb) {
     const int c = threadIdx.x % CPK;
     const int d = d0 + 4 * c;
     rowok = d < g.Ck;
     sc = 0;
     sgn = 1.f;
-    if (rowok) map_channel(g, d, sc, sgn);
-    dh = tap_dh;
-    dw = tap_dw;
+    if (rowok) decode_map(g, d, g.cmap ? g.cmap[d] : 0, sc, sgn);
+    dh = dhw >> 16;
+    dw = sx16(dhw);
     vH = g.H << g.logUp;
     vW = g.W << g.logUp;
     m_begin = mb;
@@ -421,10 +472,6 @@ struct WgALoaderV {
         if ((unsigned)ih < (unsigned)vH && (unsigned)iw < (unsigned)vW) {
           const long pix = (long)n * g.H * g.W + (long)(ih >> g.logUp) * g.W + (iw >> g.logUp);
           v = *reinterpret_cast<const float4*>(g.x + pix * g.ldx + sc);
-          v.x = act_apply(g.act, sgn * v.x);
-          v.y = act_apply(g.act, sgn * v.y);
-          v.z = act_apply(g.act, sgn * v.z);
-          v.w = act_apply(g.act, sgn * v.w);
         }
       }
       reg[p] = v;
@@ -435,7 +482,14 @@ struct WgALoaderV {
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int kk = k0 + p * KPP;
-      if (kk < BK) *reinterpret_cast<float4*>(t + kk * LD + 4 * c) = reg[p];
+      if (kk < BK) {
+        float4 v = reg[p];
+        v.x = act_apply<ACT>(sgn * v.x);
+        v.y = act_apply<ACT>(sgn * v.y);
+        v.z = act_apply<ACT>(sgn * v.z);
+        v.w = act_apply<ACT>(sgn * v.w);
+        *reinterpret_cast<float4*>(t + kk * LD + 4 * c) = v;
+      }
     }
   }
 };
@@ -450,11 +504,21 @@ struct WgBLoaderV {
   static constexpr int PASSES = (BK + KPP - 1) / KPP;
   const float* dy;
   int ldy, Cout, Mtot, co, m_begin;
+  int logGH, logGW, so, oa, ob, OHf, OWf;
   float4 reg[PASSES];
-  __device__ __forceinline__ void init(const WgradArgs& a, int co0, int Mtot_, int mb) {
-    dy = a.dy; ldy = a.ldy; Cout = a.Cout; Mtot = Mtot_;
+  __device__ __forceinline__ void init(const WgradArgs& a, const GatherA& g, int co0, int oa_,
+                                       int ob_, int mb) {
+    dy = a.dy; ldy = a.ldy; Cout = a.Cout; Mtot = g.Mtot;
+    logGH = g.logGH; logGW = g.logGW;
+    so = a.so; oa = oa_; ob = ob_; OHf = a.OHf; OWf = a.OWf;
     co = co0 + 4 * (threadIdx.x % CPK);
     m_begin = mb;
+  }
+  __device__ __forceinline__ long pixel(int m) const {
+    const int b = m & ((1 << logGW) - 1);
+    const int a = (m >> logGW) & ((1 << logGH) - 1);
+    const int n = m >> (logGW + logGH);
+    return ((long)n * OHf + a * so + oa) * OWf + b * so + ob;
   }
   __device__ __forceinline__ void load(int kt) {
     const int k0 = threadIdx.x / CPK;
@@ -464,7 +528,7 @@ struct WgBLoaderV {
       const int m = m_begin + kt * BK + kk;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (kk < BK && m < Mtot && co < Cout)
-        v = *reinterpret_cast<const float4*>(dy + (long)m * ldy + co);
+        v = *reinterpret_cast<const float4*>(dy + pixel(m) * ldy + co);
       reg[p] = v;
     }
   }
@@ -478,14 +542,20 @@ struct WgBLoaderV {
   }
 };
 
-template <class Cfg>
-__global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(GatherA g, Taps taps,
+template <class Cfg, int ACT>
+__global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(GatherA g, ClassTab ct,
                                                                  WgradArgs a) {
-  using LA = WgALoaderV<Cfg>;
+  using LA = WgALoaderV<Cfg, ACT>;
   using LB = WgBLoaderV<Cfg>;
   __shared__ __attribute__((aligned(16))) float smem[2 * LA::FLOATS + 2 * LB::FLOATS];
   const int tm = blockIdx.x / a.tiles_n, tn = blockIdx.x % a.tiles_n;
-  const int split = blockIdx.y, t = blockIdx.z;
+  const int split = blockIdx.y;
+  const int z = blockIdx.z;
+  int cls = 0;
+#pragma unroll
+  for (int c = 1; c < kMaxClass; ++c)
+    if (c < ct.ncls && z >= ct.zbase[c]) cls = c;
+  const int t = z - ct.zbase[cls];
   const int d0 = tm * Cfg::BM, co0 = tn * Cfg::BN;
   const int nkt_total = (g.Mtot + Cfg::BK - 1) / Cfg::BK;
   const int kt0 = split * a.kt_per_split;
@@ -493,12 +563,12 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(GatherA g, Tap
   if (nkt > a.kt_per_split) nkt = a.kt_per_split;
   LA la(g);
   LB lb;
-  la.init(d0, taps.dh[t], taps.dw[t], kt0 * Cfg::BK);
-  lb.init(a, co0, g.Mtot, kt0 * Cfg::BK);
+  la.init(d0, ct.taps[cls].dhw[t], kt0 * Cfg::BK);
+  lb.init(a, g, co0, ct.oa[cls], ct.ob[cls], kt0 * Cfg::BK);
   f32x16 acc[Cfg::MT][Cfg::NT];
   zero_acc<Cfg>(acc);
   gemm_mainloop<Cfg>(la, lb, nkt, smem, acc);
-  float* out = a.slab + (long)split * a.slab_stride + (long)t * g.Ck * a.Cout;
+  float* out = a.slab + (long)split * a.slab_stride + ct.woff[cls] + (long)t * g.Ck * a.Cout;
   const int Ck = g.Ck, Cout = a.Cout;
   foreach_acc<Cfg>(acc, [&](int r, int c, int, int, int, float v) {
     const int d = d0 + r, co = co0 + c;
@@ -506,8 +576,9 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(GatherA g, Tap
   });
 }
 
-// Generic scalar variant: rows = flattened (tap, d) index over ALL taps; any Ck / Cout / ld.
-template <class Cfg>
+// Generic scalar variant: rows = flattened (tap, d) index over ALL taps of a single class;
+// any Ck / Cout / ld.
+template <class Cfg, int ACT>
 struct WgALoaderS {
   static constexpr int BK = Cfg::BK, BR = Cfg::BM;
   static constexpr int LD = BR + 4;
@@ -532,9 +603,9 @@ struct WgALoaderS {
       sc[q] = 0; sgn[q] = 1.f; dh[q] = 0; dw[q] = 0;
       if (ok[q]) {
         const int t = r / g.Ck, d = r - t * g.Ck;
-        map_channel(g, d, sc[q], sgn[q]);
-        dh[q] = taps.dh[t];
-        dw[q] = taps.dw[t];
+        decode_map(g, d, g.cmap ? g.cmap[d] : 0, sc[q], sgn[q]);
+        dh[q] = taps.dhw[t] >> 16;
+        dw[q] = sx16(taps.dhw[t]);
       }
     }
     vH = g.H << g.logUp;
@@ -557,7 +628,7 @@ struct WgALoaderS {
           const int ih = a * g.sa + dh[q], iw = b * g.sa + dw[q];
           if (ok[q] && (unsigned)ih < (unsigned)vH && (unsigned)iw < (unsigned)vW) {
             const long pix = (long)n * g.H * g.W + (long)(ih >> g.logUp) * g.W + (iw >> g.logUp);
-            e[q] = act_apply(g.act, sgn[q] * g.x[pix * g.ldx + sc[q]]);
+            e[q] = g.x[pix * g.ldx + sc[q]];
           }
         }
       }
@@ -569,7 +640,14 @@ struct WgALoaderS {
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int kk = k0 + p * KPP;
-      if (kk < BK) *reinterpret_cast<float4*>(t + kk * LD + 4 * c) = reg[p];
+      if (kk < BK) {
+        float4 v = reg[p];
+        v.x = act_apply<ACT>(sgn[0] * v.x);
+        v.y = act_apply<ACT>(sgn[1] * v.y);
+        v.z = act_apply<ACT>(sgn[2] * v.z);
+        v.w = act_apply<ACT>(sgn[3] * v.w);
+        *reinterpret_cast<float4*>(t + kk * LD + 4 * c) = v;
+      }
     }
   }
 };
@@ -616,10 +694,10 @@ struct WgBLoaderS {
   }
 };
 
-template <class Cfg>
-__global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_scalar_kernel(GatherA g, Taps taps,
+template <class Cfg, int ACT>
+__global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_scalar_kernel(GatherA g, ClassTab ct,
                                                                         WgradArgs a) {
-  using LA = WgALoaderS<Cfg>;
+  using LA = WgALoaderS<Cfg, ACT>;
   using LB = WgBLoaderS<Cfg>;
   __shared__ __attribute__((aligned(16))) float smem[2 * LA::FLOATS + 2 * LB::FLOATS];
   const int tm = blockIdx.x / a.tiles_n, tn = blockIdx.x % a.tiles_n;
@@ -629,6 +707,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_scalar_kernel(GatherA
   const int kt0 = split * a.kt_per_split;
   int nkt = nkt_total - kt0;
   if (nkt > a.kt_per_split) nkt = a.kt_per_split;
+  const Taps& taps = ct.taps[0];
   LA la(g);
   LB lb;
   la.init(r0, taps, kt0 * Cfg::BK);
@@ -654,7 +733,7 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, int nsplit, l
   }
 }
 
-// dx[n,h,w,c] (+)= sum over the 2x2 replicas of dxv[n,2h+i,2w+j,c]   (backward of NN upsample)
+// dx[n,h,w,c] (+)= sum over the 2x2 replicas of dxv[n,2h+i,2w+j,c]  (legacy upsample dgrad)
 __global__ void pool2_sum_kernel(const float* __restrict__ dxv, int N, int H, int W, int C,
                                  float* __restrict__ dx, int lddx, int accumulate) {
   const long total = (long)N * H * W * C;
@@ -674,6 +753,88 @@ __global__ void pool2_sum_kernel(const float* __restrict__ dxv, int N, int H, in
 }
 
 // ---------------------------------------------------------------------------------------
+// upsample folding: weight transforms
+// ---------------------------------------------------------------------------------------
+// Source-pixel offset of filter tap k for output parity p:  floor((p + k - pad) / 2).
+__host__ __device__ inline int fold_delta(int p, int k, int pad) {
+  const int v = p + k - pad;
+  return v >= 0 ? v / 2 : -((1 - v) / 2);
+}
+
+struct FoldTab {
+  int KH, KW, pad_t, pad_l;
+  int nth[2], ntw[2];      // taps per parity along h / w
+  int dmin_h[2], dmin_w[2];  // smallest delta per parity
+  long woff[kMaxClass];    // class offsets (elements), class = ph*2 + pw
+  long total;              // total elements of weff
+};
+
+// weff[cls][th][tw][ci][co] = sum of w[kh][kw][ci][co] over the taps folded into (th, tw)
+__global__ void fold_weights_kernel(const float* __restrict__ w, FoldTab f, long CkCout,
+                                    float* __restrict__ weff) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < f.total;
+       i += (long)gridDim.x * blockDim.x) {
+    int cls = 0;
+#pragma unroll
+    for (int c = 1; c < kMaxClass; ++c)
+      if (i >= f.woff[c]) cls = c;
+    const int ph = cls >> 1, pw = cls & 1;
+    const long rem = i - f.woff[cls];
+    const int tap = (int)(rem / CkCout);
+    const long e = rem - (long)tap * CkCout;
+    const int th = tap / f.ntw[pw], tw = tap - th * f.ntw[pw];
+    const int dh = f.dmin_h[ph] + th, dw = f.dmin_w[pw] + tw;
+    float s = 0.f;
+    for (int kh = 0; kh < f.KH; ++kh) {
+      if (fold_delta(ph, kh, f.pad_t) != dh) continue;
+      for (int kw = 0; kw < f.KW; ++kw)
+        if (fold_delta(pw, kw, f.pad_l) == dw) s += w[(long)(kh * f.KW + kw) * CkCout + e];
+    }
+    weff[i] = s;
+  }
+}
+
+// dw[kh][kw][ci][co] = sum over the four classes of dweff[cls][tap(kh,kw)][ci][co]
+__global__ void unfold_wgrad_kernel(const float* __restrict__ dweff, FoldTab f, long CkCout,
+                                    float* __restrict__ dw) {
+  const long total = (long)f.KH * f.KW * CkCout;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i / CkCout);
+    const long e = i - (long)k * CkCout;
+    const int kh = k / f.KW, kw = k - kh * f.KW;
+    float s = 0.f;
+#pragma unroll
+    for (int cls = 0; cls < kMaxClass; ++cls) {
+      const int ph = cls >> 1, pw = cls & 1;
+      const int th = fold_delta(ph, kh, f.pad_t) - f.dmin_h[ph];
+      const int tw = fold_delta(pw, kw, f.pad_l) - f.dmin_w[pw];
+      s += dweff[f.woff[cls] + (long)(th * f.ntw[pw] + tw) * CkCout + e];
+    }
+    dw[i] = s;
+  }
+}
+
+// out[c][r] = in[r][c]   (32x32 LDS tiles)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int R, int C,
+                                                        float* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < R && c < C) ? in[(long)r * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (r < R && c < C) out[(long)c * R + r] = tile[tx][ty + 8 * i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // host-side geometry
 // ---------------------------------------------------------------------------------------
 inline int ilog2_exact(int v) {
@@ -687,16 +848,18 @@ inline int act_kind(int a) {  // 0 none, 1 relu-type, 2 elu-type
   if (a == OTGAN_ACT_CELU || a == OTGAN_ACT_ELU) return 2;
   return 0;
 }
+inline int pack_dhw(int dh, int dw) { return (dh << 16) | (dw & 0xffff); }
 
 struct Geo {
   int Hin, Win, OH, OW, pad_t, pad_l, Ceff, logUp;
+  bool fold;
 };
 int make_geo(const otgan_conv_desc* d, Geo* g) {
   OTGAN_CHECK_ARG(d, "null desc");
   OTGAN_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->Cout > 0, "bad conv sizes");
   OTGAN_CHECK_ARG(d->stride == 1 || d->stride == 2, "stride must be 1 or 2");
   OTGAN_CHECK_ARG(d->upsample == 0 || d->upsample == 1, "upsample must be 0 or 1");
-  OTGAN_CHECK_ARG(d->KH >= 1 && d->KW >= 1 && d->KH * d->KW <= kMaxTaps, "filter too large");
+  OTGAN_CHECK_ARG(d->KH >= 1 && d->KW >= 1 && d->KH * d->KW <= 25, "filter too large");
   OTGAN_CHECK_ARG(d->ldx >= d->C && d->ldy >= d->y_coff + d->Cout, "bad leading dimensions");
   OTGAN_CHECK_ARG(d->preact >= 0 && d->preact <= 4, "unknown pre-activation");
   g->logUp = d->upsample;
@@ -711,49 +874,85 @@ int make_geo(const otgan_conv_desc* d, Geo* g) {
   OTGAN_CHECK_ARG(ilog2_exact(g->OH) >= 0 && ilog2_exact(g->OW) >= 0 && ilog2_exact(g->Hin) >= 0 &&
                       ilog2_exact(g->Win) >= 0,
                   "spatial sizes must be powers of two (got %dx%d)", g->Hin, g->Win);
+  // Upsample folding is used whenever the vectorised gathers apply (deterministic in the
+  // descriptor: the caller must then supply folded weights, see otgan_layers.h).
+  g->fold = d->upsample == 1 && d->stride == 1 && g->Ceff % 16 == 0 && d->ldx % 4 == 0 &&
+            d->Cout % 4 == 0 && d->ldy % 4 == 0 && d->y_coff % 4 == 0 && d->KH >= 2 && d->KW >= 2;
   return OTGAN_OK;
 }
 
+FoldTab make_fold(const otgan_conv_desc* d, const Geo& g) {
+  FoldTab f;
+  memset(&f, 0, sizeof(f));
+  f.KH = d->KH; f.KW = d->KW; f.pad_t = g.pad_t; f.pad_l = g.pad_l;
+  for (int p = 0; p < 2; ++p) {
+    f.dmin_h[p] = fold_delta(p, 0, g.pad_t);
+    f.nth[p] = fold_delta(p, d->KH - 1, g.pad_t) - f.dmin_h[p] + 1;
+    f.dmin_w[p] = fold_delta(p, 0, g.pad_l);
+    f.ntw[p] = fold_delta(p, d->KW - 1, g.pad_l) - f.dmin_w[p] + 1;
+  }
+  const long CkCout = (long)g.Ceff * d->Cout;
+  long off = 0;
+  for (int cls = 0; cls < 4; ++cls) {
+    f.woff[cls] = off;
+    off += (long)f.nth[cls >> 1] * f.ntw[cls & 1] * CkCout;
+  }
+  f.total = off;
+  return f;
+}
+
 struct WgPlan {
-  bool vec;
-  int tiles_m, tiles_n, nsplit, kt_per_split, ntap_z;
-  long slab_elems;
+  bool vec, fold;
+  int tiles_m, tiles_n, nsplit, kt_per_split, nz;
+  long slab_elems;  // elements of one slab (= weff elements when folded)
+  long M;           // GEMM K extent (pixels of the row grid)
 };
 WgPlan plan_wgrad(const otgan_conv_desc* d, const Geo& g) {
   WgPlan p;
   const int taps = d->KH * d->KW;
-  const long M = (long)d->N * g.OH * g.OW;
   p.vec = (g.Ceff % 4 == 0) && (d->Cout % 4 == 0) && (d->ldy % 4 == 0) && (d->y_coff % 4 == 0) &&
           (d->ldx % 4 == 0) && (g.Ceff >= 32);
+  p.fold = g.fold && p.vec;
   const bool narrow = d->Cout <= 32;
   const int BM = narrow ? CfgNarrow::BM : CfgMain::BM, BN = narrow ? CfgNarrow::BN : CfgMain::BN;
-  if (p.vec) {
+  if (p.fold) {
+    const FoldTab f = make_fold(d, g);
+    p.slab_elems = f.total;
+    p.nz = 0;
+    for (int cls = 0; cls < 4; ++cls) p.nz += f.nth[cls >> 1] * f.ntw[cls & 1];
+    p.M = (long)d->N * d->H * d->W;
     p.tiles_m = ceil_div(g.Ceff, BM);
-    p.ntap_z = taps;
   } else {
-    p.tiles_m = ceil_div(taps * g.Ceff, BM);
-    p.ntap_z = 1;
+    p.slab_elems = (long)taps * g.Ceff * d->Cout;
+    p.M = (long)d->N * g.OH * g.OW;
+    if (p.vec) {
+      p.tiles_m = ceil_div(g.Ceff, BM);
+      p.nz = taps;
+    } else {
+      p.tiles_m = ceil_div(taps * g.Ceff, BM);
+      p.nz = 1;
+    }
   }
   p.tiles_n = ceil_div(d->Cout, BN);
-  const int nkt = (int)ceil_div_l(M, 16);
-  const int blocks = p.tiles_m * p.tiles_n * p.ntap_z;
+  const int nkt = (int)ceil_div_l(p.M, 16);
+  const int blocks = p.tiles_m * p.tiles_n * p.nz;
   int want = ceil_div(1024, blocks);
   if (want < 1) want = 1;
   if (want > 64) want = 64;
   if (want > nkt) want = nkt;
   p.kt_per_split = ceil_div(nkt, want);
   p.nsplit = ceil_div(nkt, p.kt_per_split);
-  p.slab_elems = (long)taps * g.Ceff * d->Cout;
   return p;
 }
 
 void fill_gather_x(const otgan_conv_desc* d, const Geo& g, const float* x, const int32_t* cmap,
-                   int GH, int GW, int sa, GatherA* ga) {
+                   int GH, int GW, int sa, int logUp, GatherA* ga) {
+  memset(ga, 0, sizeof(*ga));
   ga->x = x;
   ga->ldx = d->ldx;
   ga->H = d->H;
   ga->W = d->W;
-  ga->logUp = g.logUp;
+  ga->logUp = logUp;
   ga->logGH = ilog2_exact(GH);
   ga->logGW = ilog2_exact(GW);
   ga->Mtot = d->N * GH * GW;
@@ -762,34 +961,114 @@ void fill_gather_x(const otgan_conv_desc* d, const Geo& g, const float* x, const
   ga->cmap = cmap;
   ga->Creal = d->C;
   ga->doubled = doubled_act(d->preact) ? 1 : 0;
-  ga->act = act_kind(d->preact);
+}
+
+// class table of a plain conv: one class, taps in (kh, kw) order
+void single_class(const otgan_conv_desc* d, const Geo& g, ClassTab* ct) {
+  memset(ct, 0, sizeof(*ct));
+  ct->ncls = 1;
+  Taps& t = ct->taps[0];
+  t.n = d->KH * d->KW;
+  for (int kh = 0; kh < d->KH; ++kh)
+    for (int kw = 0; kw < d->KW; ++kw) {
+      const int i = kh * d->KW + kw;
+      t.dhw[i] = pack_dhw(kh - g.pad_t, kw - g.pad_l);
+    }
+  ct->zbase[1] = t.n;
+}
+
+// class table of a folded (upsample) conv on the SMALL grid: class = output parity.
+// boff_stride = distance between consecutive taps of a class in the B operand.
+void folded_classes(const FoldTab& f, long boff_stride, const long* woff, ClassTab* ct) {
+  memset(ct, 0, sizeof(*ct));
+  ct->ncls = 4;
+  int z = 0;
+  for (int cls = 0; cls < 4; ++cls) {
+    const int ph = cls >> 1, pw = cls & 1;
+    Taps& t = ct->taps[cls];
+    t.n = f.nth[ph] * f.ntw[pw];
+    for (int th = 0; th < f.nth[ph]; ++th)
+      for (int tw = 0; tw < f.ntw[pw]; ++tw) {
+        const int i = th * f.ntw[pw] + tw;
+        t.dhw[i] = pack_dhw(f.dmin_h[ph] + th, f.dmin_w[pw] + tw);
+        t.boff[i] = (int)(i * boff_stride);
+      }
+    ct->oa[cls] = ph;
+    ct->ob[cls] = pw;
+    ct->woff[cls] = woff[cls];
+    ct->zbase[cls] = z;
+    z += t.n;
+  }
+  ct->zbase[4] = z;
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <class Cfg, int EPI>
-void launch_igemm(bool vec, dim3 grid, hipStream_t s, const GatherA& ga, const Taps& taps,
-                  const WeightB& wb, const EpiArgs& e) {
+template <class Cfg, int EPI, int ACT>
+void launch_igemm2(bool vec, dim3 grid, hipStream_t s, const GatherA& ga, const ClassTab& ct,
+                   const WeightB& wb, const EpiArgs& e) {
   if (vec)
-    hipLaunchKernelGGL((conv_igemm_kernel<Cfg, true, EPI>), grid, dim3(Cfg::THREADS), 0, s, ga, taps, wb, e);
+    hipLaunchKernelGGL((conv_igemm_kernel<Cfg, true, EPI, ACT>), grid, dim3(Cfg::THREADS), 0, s, ga, ct, wb, e);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<Cfg, false, EPI>), grid, dim3(Cfg::THREADS), 0, s, ga, taps, wb, e);
+    hipLaunchKernelGGL((conv_igemm_kernel<Cfg, false, EPI, ACT>), grid, dim3(Cfg::THREADS), 0, s, ga, ct, wb, e);
+}
+// forward: activation applied in the gather (compile-time ACT)
+template <class Cfg>
+void launch_fwd(int act, bool vec, dim3 grid, hipStream_t s, const GatherA& ga, const ClassTab& ct,
+                const WeightB& wb, const EpiArgs& e) {
+  if (act == 1) launch_igemm2<Cfg, EPI_FWD, 1>(vec, grid, s, ga, ct, wb, e);
+  else if (act == 2) launch_igemm2<Cfg, EPI_FWD, 2>(vec, grid, s, ga, ct, wb, e);
+  else launch_igemm2<Cfg, EPI_FWD, 0>(vec, grid, s, ga, ct, wb, e);
 }
 
 }  // namespace
 
 extern "C" {
 
+size_t otgan_conv2d_folded_weight_elems(const otgan_conv_desc* d) {
+  Geo g;
+  if (make_geo(d, &g) != OTGAN_OK || !g.fold) return 0;
+  return (size_t)make_fold(d, g).total;
+}
+
+int otgan_conv2d_fold_weights_f32(const otgan_conv_desc* d, const float* w, float* weff,
+                                  float* weffT, void* stream) {
+  Geo g;
+  int rc = make_geo(d, &g);
+  if (rc) return rc;
+  OTGAN_CHECK_ARG(g.fold, "this layer is not folded (otgan_conv2d_folded_weight_elems == 0)");
+  OTGAN_CHECK_ARG(w && weff && weffT, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const FoldTab f = make_fold(d, g);
+  const long CkCout = (long)g.Ceff * d->Cout;
+  ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, 4.0 * 3 * (double)f.total, s);
+  long blocks = ceil_div_l(f.total, 256 * 4);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fold_weights_kernel, dim3((int)blocks), dim3(256), 0, s, w, f, CkCout, weff);
+  for (int cls = 0; cls < 4; ++cls) {
+    const int R = f.nth[cls >> 1] * f.ntw[cls & 1] * g.Ceff;  // K of the class
+    dim3 grid(ceil_div(d->Cout, 32), ceil_div(R, 32));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, weff + f.woff[cls], R, d->Cout,
+                       weffT + f.woff[cls]);
+  }
+  OTGAN_CHECK_LAUNCH("fold weights");
+  return OTGAN_OK;
+}
+
 size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which) {
   Geo g;
   if (make_geo(d, &g) != OTGAN_OK) return 0;
   if (which == 1) {
-    // dgrad through a 2x upsample: gradient w.r.t. the virtual (upsampled) input
-    return d->upsample ? align_up(sizeof(float) * (size_t)d->N * g.Hin * g.Win * d->C, 256) : 256;
+    // legacy (un-folded) dgrad through a 2x upsample: gradient on the virtual grid
+    return (d->upsample && !g.fold)
+               ? align_up(sizeof(float) * (size_t)d->N * g.Hin * g.Win * d->C, 256)
+               : 256;
   }
   if (which == 2) {
     const WgPlan p = plan_wgrad(d, g);
-    return p.nsplit > 1 ? align_up(sizeof(float) * (size_t)p.slab_elems * p.nsplit, 256) : 256;
+    size_t slabs = (p.nsplit > 1 || p.fold) ? (size_t)p.slab_elems * p.nsplit : 0;
+    if (p.fold && p.nsplit > 1) slabs += (size_t)p.slab_elems;  // reduced dweff before unfolding
+    return align_up(sizeof(float) * slabs, 256) + 256;
   }
   return 256;
 }
@@ -802,38 +1081,83 @@ int otgan_conv2d_fwd_f32(const otgan_conv_desc* d, const float* x, const int32_t
   OTGAN_CHECK_ARG(x && wT && y, "null pointer");
   hipStream_t s = (hipStream_t)stream;
   GatherA ga;
-  fill_gather_x(d, g, x, cmap, g.OH, g.OW, d->stride, &ga);
-  Taps taps;
-  memset(&taps, 0, sizeof(taps));
-  taps.n = d->KH * d->KW;
-  for (int kh = 0; kh < d->KH; ++kh)
-    for (int kw = 0; kw < d->KW; ++kw) {
-      const int t = kh * d->KW + kw;
-      taps.dh[t] = (short)(kh - g.pad_t);
-      taps.dw[t] = (short)(kw - g.pad_l);
-      taps.boff[t] = t * g.Ceff;
-    }
-  const int Ktot = taps.n * g.Ceff;
+  ClassTab ct;
   WeightB wb;
   memset(&wb, 0, sizeof(wb));
   wb.w = wT;
-  wb.ldbn = Ktot;
   wb.Nvalid = d->Cout;
   wb.Ck = g.Ceff;
   EpiArgs e;
   memset(&e, 0, sizeof(e));
   e.out = y; e.ldo = d->ldy; e.coff = d->y_coff;
-  e.so = 1; e.oa = 0; e.ob = 0; e.OHf = g.OH; e.OWf = g.OW;
+  e.OHf = g.OH; e.OWf = g.OW;
   e.bias = bias; e.ncols = d->Cout;
-  const bool vec = (g.Ceff % 16 == 0) && (d->ldx % 4 == 0) && aligned16(x) && aligned16(wT);
-  const double flops = 2.0 * ga.Mtot * (double)Ktot * d->Cout;
+  double flops;
+  bool vec;
+  if (g.fold) {
+    OTGAN_CHECK_ARG(aligned16(x) && aligned16(wT), "folded conv needs 16-byte aligned operands");
+    // rows = SMALL-grid pixels, one class per output parity, folded taps; wT = weffT
+    const FoldTab f = make_fold(d, g);
+    fill_gather_x(d, g, x, cmap, d->H, d->W, 1, 0, &ga);
+    folded_classes(f, g.Ceff, f.woff, &ct);
+    // per class the transposed block is [Cout][ntaps*Ceff]
+    e.so = 2;
+    vec = true;
+    flops = 0;
+    for (int cls = 0; cls < 4; ++cls) flops += 2.0 * ga.Mtot * (double)ct.taps[cls].n * g.Ceff * d->Cout;
+    ProfScope ps(OTGAN_PROF_CONV_FWD, flops, 0.0, s);
+    const int act = act_kind(d->preact);
+    const bool same_k = ct.taps[0].n == ct.taps[1].n && ct.taps[0].n == ct.taps[2].n &&
+                        ct.taps[0].n == ct.taps[3].n;
+    if (same_k) {
+      // the usual case (odd square filters): one launch, blockIdx.z = output parity class
+      wb.ldbn = (long)ct.taps[0].n * g.Ceff;
+      if (d->Cout <= 32) {
+        dim3 grid(ceil_div(ga.Mtot, CfgNarrow::BM), ceil_div(d->Cout, CfgNarrow::BN), 4);
+        launch_fwd<CfgNarrow>(act, vec, grid, s, ga, ct, wb, e);
+      } else {
+        dim3 grid(ceil_div(ga.Mtot, CfgMain::BM), ceil_div(d->Cout, CfgMain::BN), 4);
+        launch_fwd<CfgMain>(act, vec, grid, s, ga, ct, wb, e);
+      }
+    } else {
+      for (int cls = 0; cls < 4; ++cls) {
+        ClassTab one;
+        memset(&one, 0, sizeof(one));
+        one.ncls = 1;
+        one.taps[0] = ct.taps[cls];
+        one.oa[0] = ct.oa[cls];
+        one.ob[0] = ct.ob[cls];
+        one.woff[0] = ct.woff[cls];
+        one.zbase[1] = one.taps[0].n;
+        wb.ldbn = (long)ct.taps[cls].n * g.Ceff;
+        if (d->Cout <= 32) {
+          dim3 grid(ceil_div(ga.Mtot, CfgNarrow::BM), ceil_div(d->Cout, CfgNarrow::BN), 1);
+          launch_fwd<CfgNarrow>(act, vec, grid, s, ga, one, wb, e);
+        } else {
+          dim3 grid(ceil_div(ga.Mtot, CfgMain::BM), ceil_div(d->Cout, CfgMain::BN), 1);
+          launch_fwd<CfgMain>(act, vec, grid, s, ga, one, wb, e);
+        }
+      }
+    }
+    OTGAN_CHECK_LAUNCH("conv2d fwd (folded)");
+    return OTGAN_OK;
+  }
+  fill_gather_x(d, g, x, cmap, g.OH, g.OW, d->stride, g.logUp, &ga);
+  single_class(d, g, &ct);
+  for (int t = 0; t < ct.taps[0].n; ++t) ct.taps[0].boff[t] = t * g.Ceff;
+  const int Ktot = ct.taps[0].n * g.Ceff;
+  wb.ldbn = Ktot;
+  e.so = 1;
+  vec = (g.Ceff % 16 == 0) && (d->ldx % 4 == 0) && aligned16(x) && aligned16(wT);
+  flops = 2.0 * ga.Mtot * (double)Ktot * d->Cout;
   ProfScope ps(OTGAN_PROF_CONV_FWD, flops, 0.0, s);
+  const int act = act_kind(d->preact);
   if (d->Cout <= 32) {
-    dim3 grid(ceil_div(ga.Mtot, CfgNarrow::BM), ceil_div(d->Cout, CfgNarrow::BN));
-    launch_igemm<CfgNarrow, EPI_FWD>(vec, grid, s, ga, taps, wb, e);
+    dim3 grid(ceil_div(ga.Mtot, CfgNarrow::BM), ceil_div(d->Cout, CfgNarrow::BN), 1);
+    launch_fwd<CfgNarrow>(act, vec, grid, s, ga, ct, wb, e);
   } else {
-    dim3 grid(ceil_div(ga.Mtot, CfgMain::BM), ceil_div(d->Cout, CfgMain::BN));
-    launch_igemm<CfgMain, EPI_FWD>(vec, grid, s, ga, taps, wb, e);
+    dim3 grid(ceil_div(ga.Mtot, CfgMain::BM), ceil_div(d->Cout, CfgMain::BN), 1);
+    launch_fwd<CfgMain>(act, vec, grid, s, ga, ct, wb, e);
   }
   OTGAN_CHECK_LAUNCH("conv2d fwd");
   return OTGAN_OK;
@@ -849,91 +1173,132 @@ int otgan_conv2d_dgrad_f32(const otgan_conv_desc* d, const float* dy, const floa
   const int kind = act_kind(d->preact);
   OTGAN_CHECK_ARG(kind == 0 || x, "dgrad through a pre-activation needs the layer input x");
   hipStream_t s = (hipStream_t)stream;
-  const size_t need = otgan_conv2d_workspace_bytes(d, 1);
-  float* target = dx;
-  int tld = lddx, tacc = accumulate;
-  if (d->upsample) {
-    if (!workspace || workspace_bytes < need) {
-      otgan_set_error("conv2d dgrad workspace too small: need %zu, got %zu", need, workspace_bytes);
-      return OTGAN_ERR_WORKSPACE;
-    }
-    target = (float*)workspace;  // gradient on the virtual (upsampled) grid, dense [.,C]
-    tld = d->C;
-    tacc = 0;
-  }
-  // A operand: dy over the OUTPUT grid, one K block per (tap, co)
+  const bool paired = doubled_act(d->preact);
+  // A operand: dy, one K block per (tap, co)
   GatherA ga;
   memset(&ga, 0, sizeof(ga));
   ga.x = dy + d->y_coff;
   ga.ldx = d->ldy;
   ga.H = g.OH; ga.W = g.OW; ga.logUp = 0;
-  ga.sa = 1;
   ga.Ck = d->Cout;
-  ga.cmap = nullptr; ga.Creal = d->Cout; ga.doubled = 0; ga.act = 0;
+  ga.cmap = nullptr; ga.Creal = d->Cout; ga.doubled = 0;
   WeightB wb;
   memset(&wb, 0, sizeof(wb));
   wb.w = w;
   wb.ldbn = d->Cout;
   wb.Ck = d->Cout;
-  const bool paired = doubled_act(d->preact);
   wb.paired = paired ? 1 : 0;
   wb.Creal = d->C;
   wb.inv = inv;
   wb.Nvalid = g.Ceff;
   EpiArgs e;
   memset(&e, 0, sizeof(e));
-  e.out = target; e.ldo = tld; e.coff = 0;
-  e.OHf = g.Hin; e.OWf = g.Win;
   e.ncols = d->C;
-  e.accumulate = tacc;
-  e.xsrc = x; e.ldxs = d->ldx; e.xH = d->H; e.xW = d->W; e.logUpX = g.logUp;
+  e.xsrc = x; e.ldxs = d->ldx; e.xH = d->H; e.xW = d->W;
   e.act = kind;
   const bool vec = (d->Cout % 16 == 0) && (d->ldy % 4 == 0) && (d->y_coff % 4 == 0) &&
                    aligned16(dy) && aligned16(w);
-  const int st = d->stride;
-  const int nclass = st * st;
-  for (int cls = 0; cls < nclass; ++cls) {
-    const int ph = cls / st, pw = cls % st;
+  ClassTab ct;
+  memset(&ct, 0, sizeof(ct));
+  float* target = dx;
+  bool pool = false;
+  double flops = 0;
+  if (g.fold) {
+    // gradient w.r.t. the SMALL input directly: rows = small pixels, K = all 4 classes'
+    // folded taps; dy is read at (2(a - dh) + ph, 2(b - dw) + pw); w = weff.
+    const FoldTab f = make_fold(d, g);
+    ga.logGH = ilog2_exact(d->H);
+    ga.logGW = ilog2_exact(d->W);
+    ga.Mtot = d->N * d->H * d->W;
+    ga.sa = 2;
+    ct.ncls = 1;
+    Taps& t = ct.taps[0];
+    int n = 0;
+    const long CkCout = (long)g.Ceff * d->Cout;
+    for (int cls = 0; cls < 4; ++cls) {
+      const int ph = cls >> 1, pw = cls & 1;
+      for (int th = 0; th < f.nth[ph]; ++th)
+        for (int tw = 0; tw < f.ntw[pw]; ++tw) {
+          const int dh = f.dmin_h[ph] + th, dw = f.dmin_w[pw] + tw;
+          t.dhw[n] = pack_dhw(-2 * dh + ph, -2 * dw + pw);
+          t.boff[n] = (int)(f.woff[cls] + (long)(th * f.ntw[pw] + tw) * CkCout);
+          ++n;
+        }
+    }
+    t.n = n;
+    ct.zbase[1] = n;
+    e.out = dx; e.ldo = lddx; e.coff = 0;
+    e.so = 1; e.OHf = d->H; e.OWf = d->W;
+    e.logUpX = 0;
+    e.accumulate = accumulate;
+    flops = 2.0 * ga.Mtot * (double)n * d->Cout * g.Ceff;
+  } else {
+    const size_t need = otgan_conv2d_workspace_bytes(d, 1);
+    int tld = lddx, tacc = accumulate;
+    if (d->upsample) {
+      if (!workspace || workspace_bytes < need) {
+        otgan_set_error("conv2d dgrad workspace too small: need %zu, got %zu", need, workspace_bytes);
+        return OTGAN_ERR_WORKSPACE;
+      }
+      target = (float*)workspace;  // gradient on the virtual (upsampled) grid, dense [.,C]
+      tld = d->C;
+      tacc = 0;
+      pool = true;
+    }
+    const int st = d->stride;
     const int GH = g.Hin / st, GW = g.Win / st;
     ga.logGH = ilog2_exact(GH);
     ga.logGW = ilog2_exact(GW);
     OTGAN_CHECK_ARG(ga.logGH >= 0 && ga.logGW >= 0, "dgrad grid must be a power of two");
     ga.Mtot = d->N * GH * GW;
-    Taps taps;
-    memset(&taps, 0, sizeof(taps));
-    int nt = 0;
-    for (int kh = 0; kh < d->KH; ++kh) {
-      if (((ph + g.pad_t - kh) % st + st) % st != 0) continue;
-      for (int kw = 0; kw < d->KW; ++kw) {
-        if (((pw + g.pad_l - kw) % st + st) % st != 0) continue;
-        // oh = (ih + pad - kh) / stride, ih = a*st + ph
-        const int nh = ph + g.pad_t - kh, nw = pw + g.pad_l - kw;
-        taps.dh[nt] = (short)(nh >= 0 ? nh / st : -((-nh) / st));
-        taps.dw[nt] = (short)(nw >= 0 ? nw / st : -((-nw) / st));
-        taps.boff[nt] = (kh * d->KW + kw) * g.Ceff * d->Cout;
-        ++nt;
+    ga.sa = 1;
+    ct.ncls = st * st;
+    int z = 0;
+    for (int cls = 0; cls < ct.ncls; ++cls) {
+      const int ph = cls / st, pw = cls % st;
+      Taps& t = ct.taps[cls];
+      int nt = 0;
+      for (int kh = 0; kh < d->KH; ++kh) {
+        if (((ph + g.pad_t - kh) % st + st) % st != 0) continue;
+        for (int kw = 0; kw < d->KW; ++kw) {
+          if (((pw + g.pad_l - kw) % st + st) % st != 0) continue;
+          // oh = (ih + pad - kh) / stride, ih = a*st + ph
+          const int nh = ph + g.pad_t - kh, nw = pw + g.pad_l - kw;
+          t.dhw[nt] = pack_dhw(nh >= 0 ? nh / st : -((-nh) / st), nw >= 0 ? nw / st : -((-nw) / st));
+          t.boff[nt] = (kh * d->KW + kw) * g.Ceff * d->Cout;
+          ++nt;
+        }
       }
+      t.n = nt;
+      ct.oa[cls] = ph;
+      ct.ob[cls] = pw;
+      ct.zbase[cls] = z;
+      z += nt;
+      flops += 2.0 * ga.Mtot * (double)nt * d->Cout * g.Ceff;
     }
-    taps.n = nt;
-    e.so = st; e.oa = ph; e.ob = pw;
-    if (nt == 0) continue;  // (cannot happen for KH, KW >= stride)
-    const double flops = 2.0 * ga.Mtot * (double)nt * d->Cout * g.Ceff;
+    ct.zbase[ct.ncls] = z;
+    e.out = target; e.ldo = tld; e.coff = 0;
+    e.so = st; e.OHf = g.Hin; e.OWf = g.Win;
+    e.logUpX = g.logUp;
+    e.accumulate = tacc;
+  }
+  {
     ProfScope ps(OTGAN_PROF_CONV_DGRAD, flops, 0.0, s);
     if (paired) {
-      dim3 grid(ceil_div(ga.Mtot, CfgMain::BM), ceil_div(d->C, 64));
-      launch_igemm<CfgMain, EPI_DG_PAIR>(vec, grid, s, ga, taps, wb, e);
+      dim3 grid(ceil_div(ga.Mtot, CfgMain::BM), ceil_div(d->C, 64), ct.ncls);
+      launch_igemm2<CfgMain, EPI_DG_PAIR, 0>(vec, grid, s, ga, ct, wb, e);
     } else if (d->C <= 32) {
-      dim3 grid(ceil_div(ga.Mtot, CfgNarrow::BM), ceil_div(d->C, CfgNarrow::BN));
-      if (kind) launch_igemm<CfgNarrow, EPI_DG_ACT>(vec, grid, s, ga, taps, wb, e);
-      else launch_igemm<CfgNarrow, EPI_DG_PLAIN>(vec, grid, s, ga, taps, wb, e);
+      dim3 grid(ceil_div(ga.Mtot, CfgNarrow::BM), ceil_div(d->C, CfgNarrow::BN), ct.ncls);
+      if (kind) launch_igemm2<CfgNarrow, EPI_DG_ACT, 0>(vec, grid, s, ga, ct, wb, e);
+      else launch_igemm2<CfgNarrow, EPI_DG_PLAIN, 0>(vec, grid, s, ga, ct, wb, e);
     } else {
-      dim3 grid(ceil_div(ga.Mtot, CfgMain::BM), ceil_div(d->C, CfgMain::BN));
-      if (kind) launch_igemm<CfgMain, EPI_DG_ACT>(vec, grid, s, ga, taps, wb, e);
-      else launch_igemm<CfgMain, EPI_DG_PLAIN>(vec, grid, s, ga, taps, wb, e);
+      dim3 grid(ceil_div(ga.Mtot, CfgMain::BM), ceil_div(d->C, CfgMain::BN), ct.ncls);
+      if (kind) launch_igemm2<CfgMain, EPI_DG_ACT, 0>(vec, grid, s, ga, ct, wb, e);
+      else launch_igemm2<CfgMain, EPI_DG_PLAIN, 0>(vec, grid, s, ga, ct, wb, e);
     }
-    OTGAN_CHECK_LAUNCH("conv2d dgrad");
   }
-  if (d->upsample) {
+  OTGAN_CHECK_LAUNCH("conv2d dgrad");
+  if (pool) {
     const long total = (long)d->N * d->H * d->W * d->C;
     long blocks = ceil_div_l(total, 256);
     if (blocks > 4096) blocks = 4096;
@@ -953,51 +1318,75 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
   OTGAN_CHECK_ARG(x && dy && dw, "null pointer");
   hipStream_t s = (hipStream_t)stream;
   WgPlan p = plan_wgrad(d, g);
-  p.vec = p.vec && aligned16(x) && aligned16(dy);
+  OTGAN_CHECK_ARG(!p.vec || (aligned16(x) && aligned16(dy)), "operands must be 16-byte aligned");
   const size_t need = otgan_conv2d_workspace_bytes(d, 2);
-  if (p.nsplit > 1 && (!workspace || workspace_bytes < need)) {
+  if ((p.nsplit > 1 || p.fold) && (!workspace || workspace_bytes < need)) {
     otgan_set_error("conv2d wgrad workspace too small: need %zu, got %zu", need, workspace_bytes);
     return OTGAN_ERR_WORKSPACE;
   }
   GatherA ga;
-  fill_gather_x(d, g, x, cmap, g.OH, g.OW, d->stride, &ga);
-  Taps taps;
-  memset(&taps, 0, sizeof(taps));
-  taps.n = d->KH * d->KW;
-  for (int kh = 0; kh < d->KH; ++kh)
-    for (int kw = 0; kw < d->KW; ++kw) {
-      const int t = kh * d->KW + kw;
-      taps.dh[t] = (short)(kh - g.pad_t);
-      taps.dw[t] = (short)(kw - g.pad_l);
-    }
+  ClassTab ct;
   WgradArgs a;
   memset(&a, 0, sizeof(a));
   a.dy = dy + d->y_coff;
   a.ldy = d->ldy;
   a.Cout = d->Cout;
-  a.slab = p.nsplit > 1 ? (float*)workspace : dw;
   a.kt_per_split = p.kt_per_split;
   a.tiles_n = p.tiles_n;
   a.slab_stride = p.slab_elems;
+  FoldTab f;
+  memset(&f, 0, sizeof(f));
+  float* slabs = (float*)workspace;
+  float* dweff = nullptr;
+  if (p.fold) {
+    f = make_fold(d, g);
+    fill_gather_x(d, g, x, cmap, d->H, d->W, 1, 0, &ga);
+    folded_classes(f, (long)g.Ceff * d->Cout, f.woff, &ct);
+    a.so = 2; a.OHf = g.OH; a.OWf = g.OW;
+    dweff = p.nsplit > 1 ? slabs + (size_t)p.slab_elems * p.nsplit : slabs;
+    a.slab = slabs;
+  } else {
+    fill_gather_x(d, g, x, cmap, g.OH, g.OW, d->stride, g.logUp, &ga);
+    single_class(d, g, &ct);
+    a.so = 1; a.OHf = g.OH; a.OWf = g.OW;
+    a.slab = p.nsplit > 1 ? slabs : dw;
+  }
   const bool narrow = d->Cout <= 32;
-  dim3 grid(p.tiles_m * p.tiles_n, p.nsplit, p.ntap_z);
+  const int act = act_kind(d->preact);
+  dim3 grid(p.tiles_m * p.tiles_n, p.nsplit, p.nz);
   {
-    ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * ga.Mtot * (double)p.slab_elems, 0.0, s);
+    ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * (double)p.M * (double)p.slab_elems, 0.0, s);
+#define OTGAN_WG(KERNEL, CFG)                                                                      \
+  do {                                                                                             \
+    if (act == 1) hipLaunchKernelGGL((KERNEL<CFG, 1>), grid, dim3(CFG::THREADS), 0, s, ga, ct, a);  \
+    else if (act == 2) hipLaunchKernelGGL((KERNEL<CFG, 2>), grid, dim3(CFG::THREADS), 0, s, ga, ct, a); \
+    else hipLaunchKernelGGL((KERNEL<CFG, 0>), grid, dim3(CFG::THREADS), 0, s, ga, ct, a);          \
+  } while (0)
     if (p.vec) {
-      if (narrow) hipLaunchKernelGGL((conv_wgrad_kernel<CfgNarrow>), grid, dim3(CfgNarrow::THREADS), 0, s, ga, taps, a);
-      else hipLaunchKernelGGL((conv_wgrad_kernel<CfgMain>), grid, dim3(CfgMain::THREADS), 0, s, ga, taps, a);
+      if (narrow) OTGAN_WG(conv_wgrad_kernel, CfgNarrow);
+      else OTGAN_WG(conv_wgrad_kernel, CfgMain);
     } else {
-      if (narrow) hipLaunchKernelGGL((conv_wgrad_scalar_kernel<CfgNarrow>), grid, dim3(CfgNarrow::THREADS), 0, s, ga, taps, a);
-      else hipLaunchKernelGGL((conv_wgrad_scalar_kernel<CfgMain>), grid, dim3(CfgMain::THREADS), 0, s, ga, taps, a);
+      if (narrow) OTGAN_WG(conv_wgrad_scalar_kernel, CfgNarrow);
+      else OTGAN_WG(conv_wgrad_scalar_kernel, CfgMain);
     }
+#undef OTGAN_WG
   }
   OTGAN_CHECK_LAUNCH("conv2d wgrad");
   if (p.nsplit > 1) {
     long blocks = ceil_div_l(p.slab_elems, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)blocks), dim3(256), 0, s, (const float*)workspace,
-                       p.nsplit, p.slab_elems, dw);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)blocks), dim3(256), 0, s, (const float*)slabs,
+                       p.nsplit, p.slab_elems, p.fold ? dweff : dw);
     OTGAN_CHECK_LAUNCH("slab_reduce");
+  }
+  if (p.fold) {
+    const long CkCout = (long)g.Ceff * d->Cout;
+    const long total = (long)d->KH * d->KW * CkCout;
+    long blocks = ceil_div_l(total, 256 * 4);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(unfold_wgrad_kernel, dim3((int)blocks), dim3(256), 0, s, (const float*)dweff, f,
+                       CkCout, dw);
+    OTGAN_CHECK_LAUNCH("unfold_wgrad");
   }
   return OTGAN_OK;
 }

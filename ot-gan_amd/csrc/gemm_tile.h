@@ -65,18 +65,29 @@ __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int nkt, float* sm
     }
     const float* pa = sA + cur * LA::FLOATS + a_off;
     const float* pb = sB + cur * LB::FLOATS + b_off;
+    // fragment reads run one k-step ahead of the MFMAs that consume them
+    float a[2][MT], b[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[0][mt] = pa[mt * 32];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[0][nt] = pb[nt * 32];
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
-      float a[MT], b[NT];
+      const int cb = ks & 1, nb = cb ^ 1;
+      if (ks + 1 < BK / 2) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[mt] = pa[(2 * ks) * LA::LD + mt * 32];
+        for (int mt = 0; mt < MT; ++mt) a[nb][mt] = pa[(2 * ks + 2) * LA::LD + mt * 32];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b[nt] = pb[(2 * ks) * LB::LD + nt * 32];
+        for (int nt = 0; nt < NT; ++nt) b[nb][nt] = pb[(2 * ks + 2) * LB::LD + nt * 32];
+        // keep the next step's LDS reads ahead of this step's MFMAs (hipcc otherwise sinks
+        // them behind the MFMAs and waits lgkmcnt(0) right before the next group)
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cb][mt], b[cb][nt], acc[mt][nt], 0, 0, 0);
     }
     if (more) {
       la.store(sA + (cur ^ 1) * LA::FLOATS);

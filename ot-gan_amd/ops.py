@@ -161,8 +161,17 @@ class Conv2dFunction(torch.autograd.Function):
         # with upsample the reference concatenates the list BEFORE the pre-activation
         # (nn.py:235-237), so the doubled ordering is [x_all, -x_all], not per element
         cmap, inv = channel_maps(segs if (segs and not upsample) else (C,), preact, x.device)
+        wd = w                       # operand of dgrad
+        nfold = _lib.lib().otgan_conv2d_folded_weight_elems(ctypes.byref(desc))
+        if nfold:
+            # conv o upsample == four parity-class convs with pre-summed taps (otgan_layers.h)
+            wd = torch.empty(nfold, dtype=w.dtype, device=w.device)
+            wT = torch.empty(nfold, dtype=w.dtype, device=w.device)
+            _lib.check(_lib.lib().otgan_conv2d_fold_weights_f32(ctypes.byref(desc), w.data_ptr(),
+                                                                wd.data_ptr(), wT.data_ptr(),
+                                                                _lib.stream_ptr()), "fold_weights")
         conv_fwd_raw(desc, x, cmap, wT, b, y)
-        ctx.save_for_backward(x, V2d, g, w, inv_norm)
+        ctx.save_for_backward(x, V2d, g, wd, inv_norm)
         ctx.desc, ctx.cmap, ctx.inv = desc, cmap, inv
         ctx.vshape = V.shape
         ctx.has_b = b is not None
@@ -178,7 +187,7 @@ class Conv2dFunction(torch.autograd.Function):
             dx = torch.empty_like(x)
             conv_dgrad_raw(desc, dy, w, x, ctx.inv, dx, x.shape[3], False)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            dw = torch.empty_like(w)
+            dw = torch.empty_like(V2d)
             conv_wgrad_raw(desc, x, ctx.cmap, dy, dw)
             dV2d, dg = weightnorm_bwd(V2d, g, inv_norm, dw)
             dV = dV2d.view(ctx.vshape)
