@@ -90,7 +90,7 @@ int otgan_weightnorm_bwd_f32(const float* V, const float* g, const float* inv_no
                              const float* dw, int K, int Cout, float* dV, float* dg,
                              float* scratch, void* stream);
 
-/* out[c] = sum_r a[r*lda + c]   (bias gradients; rows = pixels).  scratch: 64*cols floats */
+/* out[c] = sum_r a[r*lda + c]   (bias gradients; rows = pixels).  scratch: 256*cols floats */
 int otgan_colsum_f32(const float* a, long rows, int cols, long lda, float* out, float* scratch,
                      void* stream);
 

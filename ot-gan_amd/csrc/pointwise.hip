@@ -8,7 +8,7 @@
 
 namespace {
 
-constexpr int kChunks = 64;  // row chunks of the two-stage (deterministic) column reductions
+constexpr int kChunks = 256;  // max row chunks of the two-stage (deterministic) column reductions
 
 inline int grid_for(long n, int per_thread = 4) {
   long b = ceil_div_l(n, 256L * per_thread);
@@ -59,14 +59,65 @@ __global__ void colreduce_finish_kernel(const float* __restrict__ partial, int n
   out[c] = MODE == 1 ? rsqrtf(fmaxf(s, 1e-12f)) : s;
 }
 
+// float4 variant: a block covers 64 columns (16 lanes x float4) and 16 row lanes
+// (4 per wave), i.e. every wave-load moves 4 rows x 256 bytes.
+template <int OP>
+__global__ __launch_bounds__(256) void colreduce4_kernel(const float* __restrict__ a,
+                                                         const float* __restrict__ b, long rows,
+                                                         int cols, long lda,
+                                                         float* __restrict__ partial) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cq = lane & 15, rsub = (lane >> 4) + 4 * wave;  // 16 column quads x 16 row lanes
+  const int c = blockIdx.x * 64 + 4 * cq;
+  const int chunk = blockIdx.y;
+  const long per = ceil_div_l(rows, (long)gridDim.y);
+  const long r0 = chunk * per;
+  long r1 = r0 + per;
+  if (r1 > rows) r1 = rows;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < cols) {
+    for (long r = r0 + rsub; r < r1; r += 16) {
+      const float4 av = *reinterpret_cast<const float4*>(a + r * lda + c);
+      if (OP == 0) {
+        s.x += av.x; s.y += av.y; s.z += av.z; s.w += av.w;
+      } else if (OP == 1) {
+        s.x += av.x * av.x; s.y += av.y * av.y; s.z += av.z * av.z; s.w += av.w * av.w;
+      } else {
+        const float4 bv = *reinterpret_cast<const float4*>(b + r * lda + c);
+        s.x += av.x * bv.x; s.y += av.y * bv.y; s.z += av.z * bv.z; s.w += av.w * bv.w;
+      }
+    }
+  }
+  __shared__ float4 red[16][17];
+  red[rsub][cq] = s;
+  __syncthreads();
+  if (threadIdx.x < 16 && c < cols) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float4 v = red[k][threadIdx.x];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    const int cc = blockIdx.x * 64 + 4 * threadIdx.x;
+    *reinterpret_cast<float4*>(partial + (long)chunk * cols + cc) = t;
+  }
+}
+
 template <int OP>
 int colreduce(const float* a, const float* b, long rows, int cols, long lda, float* partial,
               int* nchunk_out, hipStream_t s) {
-  int nchunk = (int)(rows < 64 * kChunks ? ceil_div_l(rows, 64) : kChunks);
+  const int colblocks = ceil_div(cols, 64);
+  long nchunk = ceil_div(1024, colblocks);              // aim for >= 1024 workgroups
+  if (nchunk > kChunks) nchunk = kChunks;
+  if (nchunk > ceil_div_l(rows, 64)) nchunk = ceil_div_l(rows, 64);
   if (nchunk < 1) nchunk = 1;
-  dim3 grid(ceil_div(cols, 64), nchunk);
-  hipLaunchKernelGGL(colreduce_kernel<OP>, grid, dim3(256), 0, s, a, b, rows, cols, lda, partial);
-  *nchunk_out = nchunk;
+  dim3 grid(colblocks, (int)nchunk);
+  const bool vec = (cols % 4 == 0) && (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0) &&
+                   (!b || (reinterpret_cast<uintptr_t>(b) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(partial) & 15) == 0);
+  if (vec) hipLaunchKernelGGL(colreduce4_kernel<OP>, grid, dim3(256), 0, s, a, b, rows, cols, lda, partial);
+  else hipLaunchKernelGGL(colreduce_kernel<OP>, grid, dim3(256), 0, s, a, b, rows, cols, lda, partial);
+  *nchunk_out = (int)nchunk;
   OTGAN_CHECK_LAUNCH("colreduce");
   return OTGAN_OK;
 }
@@ -276,8 +327,7 @@ int otgan_weightnorm_fwd_f32(const float* V, const float* g, int K, int Cout, fl
   OTGAN_CHECK_ARG(V && g && w && inv_norm && K > 0 && Cout > 0, "bad arguments");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, 4.0 * 3 * (double)K * Cout, s);
-  // the partial sums live in the (not yet written) w buffer: K*Cout >= kChunks*Cout whenever
-  // K >= kChunks; small K uses fewer chunks (nchunk <= ceil(K/64) <= K).
+  // the partial sums live in the (not yet written) w buffer: nchunk <= ceil(K/64) <= K rows.
   float* partial = w;
   int nchunk = 0;
   int rc = colreduce<1>(V, nullptr, K, Cout, Cout, partial, &nchunk, s);

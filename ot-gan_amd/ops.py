@@ -106,7 +106,7 @@ def weightnorm_bwd(V2d, g, inv, dw):
 
 def colsum(a2d_ptr, rows, cols, lda, device):
     out = torch.empty(cols, dtype=torch.float32, device=device)
-    scratch = torch.empty(64 * cols, dtype=torch.float32, device=device)
+    scratch = torch.empty(256 * cols, dtype=torch.float32, device=device)
     _lib.check(_lib.lib().otgan_colsum_f32(a2d_ptr, rows, cols, lda, out.data_ptr(),
                                            scratch.data_ptr(), _lib.stream_ptr()), "colsum")
     return out
@@ -208,6 +208,79 @@ def dense_op(x, V, g, b, preact=0, segs=None):
     y = Conv2dFunction.apply(x.view(N, 1, 1, C), V.view(1, 1, *V.shape), g, b, 1, False,
                              int(preact), tuple(segs) if segs else None)
     return y.view(N, -1)
+
+
+class DenseBlockFunction(torch.autograd.Function):
+    """L weight-normalised convolutions that each read the concatenation of everything before
+    them and append `F` channels (reference models/densenet.py:11-16: `x.append(conv2d(x, F))`).
+
+    The block grows IN PLACE: one [N,H,W,C0+L*F] buffer, layer k reads channels [0, Ck) through
+    the channel map of its list segmentation and writes channels [Ck, Ck+F) (ldy / y_coff of
+    the conv ABI).  The backward pass walks the layers in reverse over one gradient buffer:
+    layer k's dy is a channel slice of it and its dgrad accumulates into channels [0, Ck).
+    No concatenation copies, no per-layer activation tensors.
+
+    args: x0 [N,H,W,C0] (concatenated initial list), then V_k, g_k, b_k for every layer."""
+
+    @staticmethod
+    def forward(ctx, x0, segs0, ksize, preact, *params):
+        _need_cuda(x0)
+        L = len(params) // 3
+        N, H, W, C0 = x0.shape
+        F = params[0].shape[-1]
+        Ctot = C0 + L * F
+        buf = torch.empty((N, H, W, Ctot), dtype=x0.dtype, device=x0.device)
+        buf[..., :C0].copy_(x0)
+        mult = 2 if preact in DOUBLED else 1
+        saved, descs, maps = [], [], []
+        segs = list(segs0)
+        for k in range(L):
+            V, g, b = params[3 * k:3 * k + 3]
+            Ck = C0 + k * F
+            assert tuple(V.shape) == (ksize, ksize, Ck * mult, F), (V.shape, Ck, mult)
+            V2d = V.contiguous().view(-1, F)
+            w, wT, inv_norm = weightnorm_fwd(V2d, g)
+            desc = ConvDesc(N, H, W, Ck, Ctot, 0, ksize, ksize, 1, F, Ctot, Ck, preact)
+            cmap, inv = channel_maps(tuple(segs), preact, x0.device)
+            conv_fwd_raw(desc, buf, cmap, wT, b, buf)
+            saved += [V2d, g, w, inv_norm]
+            descs.append(desc)
+            maps.append((cmap, inv))
+            segs.append(F)
+        ctx.save_for_backward(buf, *saved)
+        ctx.descs, ctx.maps, ctx.L, ctx.C0, ctx.F = descs, maps, L, C0, F
+        ctx.vshapes = [p.shape for p in params[0::3]]
+        return buf
+
+    @staticmethod
+    def backward(ctx, dbuf):
+        buf, *saved = ctx.saved_tensors
+        L, C0, F = ctx.L, ctx.C0, ctx.F
+        N, H, W, Ctot = buf.shape
+        G = dbuf.contiguous().clone()          # gradient w.r.t. the whole concatenation
+        need_w = any(ctx.needs_input_grad[4:])
+        grads = [None] * (3 * L)
+        rows = N * H * W
+        for k in reversed(range(L)):
+            V2d, g, w, inv_norm = saved[4 * k:4 * k + 4]
+            desc = ctx.descs[k]
+            cmap, inv = ctx.maps[k]
+            Ck = C0 + k * F
+            if need_w:
+                dw = torch.empty_like(V2d)
+                conv_wgrad_raw(desc, buf, cmap, G, dw)
+                dV2d, dg = weightnorm_bwd(V2d, g, inv_norm, dw)
+                db = colsum(G.data_ptr() + 4 * Ck, rows, F, Ctot, G.device)
+                grads[3 * k:3 * k + 3] = [dV2d.view(ctx.vshapes[k]), dg, db]
+            # d/d(inputs of layer k) accumulates into the first Ck channels of G
+            conv_dgrad_raw(desc, G, w, buf, inv, G, Ctot, True)
+        dx0 = G[..., :C0].contiguous() if ctx.needs_input_grad[0] else None
+        return (dx0, None, None, None, *grads)
+
+
+def dense_block_op(x0, segs0, params, ksize=3, preact=1):
+    flat = [t for p in params for t in p]
+    return DenseBlockFunction.apply(x0, tuple(segs0), int(ksize), int(preact), *flat)
 
 
 # ------------------------------------------------------------------------------- pointwise

@@ -77,35 +77,44 @@ class OTGAN:
         return grad_gen, grad_dat, dist, m[4]
 
     # ---------------------------------------------------------------- one sess.run
-    def step(self, x_data):
+    def step(self, x_data, noise=None, apply_updates=True):
         """x_data: [shards*batch_size, H, W, 3] in [-1, 1].  Runs a critic step when
-        step_counter % (nr_gen_per_disc+1) == 0, else a generator step (train.py:214-226)."""
+        step_counter % (nr_gen_per_disc+1) == 0, else a generator step (train.py:214-226).
+        `noise` (tests) replaces the generator's own latent draw; `apply_updates=False`
+        (tests) leaves the parameters untouched and returns the summed gradients."""
         a = self.args
         assert x_data.shape[0] == self.nb
+        gkw = dict(self.model_opts)
+        if noise is not None:
+            gkw["noise"] = noise
         if self.step_counter % (a.nr_gen_per_disc + 1) == 0:
             kind = "disc"
             with torch.no_grad():
                 ema = self.ema if a.train_disc_against_ema else None    # train.py:119-123
-                x_gen = self.generator(batch_size=self.nb, ema=ema, device=self.device, **self.model_opts)
+                x_gen = self.generator(batch_size=self.nb, ema=ema, device=self.device, **gkw)
             f_all = self.discriminator(torch.cat([x_data, x_gen], 0), **self.model_opts)
             f_dat, f_gen = f_all[:self.nb], f_all[self.nb:]
             g_gen, g_dat, dist, ent = self._match(f_gen.detach(), f_dat.detach())
             grads = torch.autograd.grad(f_all, self.disc_params, torch.cat([g_dat, g_gen], 0))   # train.py:127-128
             grads = parallel.allreduce_sum_(list(grads))                                          # train.py:134-139
-            self.disc_optimizer(grads, lr=-a.learning_rate_disc)                                  # train.py:143
+            if apply_updates:
+                self.disc_optimizer(grads, lr=-a.learning_rate_disc)                              # train.py:143
         else:
             kind = "gen"
-            x_gen = self.generator(batch_size=self.nb, device=self.device, **self.model_opts)
+            x_gen = self.generator(batch_size=self.nb, device=self.device, **gkw)
             with torch.no_grad():
                 f_dat = self.discriminator(x_data, **self.model_opts)
             f_gen = self.discriminator(x_gen, **self.model_opts)
             g_gen, _g_dat, dist, ent = self._match(f_gen.detach(), f_dat)
             grads = torch.autograd.grad(f_gen, self.gen_params, g_gen)                            # train.py:112
             grads = parallel.allreduce_sum_(list(grads))
-            self.gen_optimizer(grads, lr=a.learning_rate_gen)                                     # train.py:142
-            self.maintain_averages()                                                              # train.py:223
+            if apply_updates:
+                self.gen_optimizer(grads, lr=a.learning_rate_gen)                                 # train.py:142
+                self.maintain_averages()                                                          # train.py:223
         self.step_counter += 1
         self.last = {"kind": kind, "distance": dist, "entropy": ent}      # device scalars, no sync
+        if not apply_updates:
+            self.last["grads"] = grads
         return self.last
 
     @torch.no_grad()

@@ -223,9 +223,48 @@ def conv2d(x, num_filters, pre_activation='celu', filter_size=[3, 3], stride=[1,
     V = get_var_maybe_avg(f"{name}/V", (filter_size[0], filter_size[1], nr_in, num_filters), "normal", ema, dev)
     g = get_var_maybe_avg(f"{name}/g", (num_filters,), "ones", ema, dev)
     b = get_var_maybe_avg(f"{name}/b", (num_filters,), "zeros", ema, dev)
-    xin = xs[0] if len(xs) == 1 else torch.cat(xs, 3)
+    if isinstance(xs, ConcatList) and xs.buffer is not None:
+        xin = xs.buffer
+    else:
+        xin = xs[0] if len(xs) == 1 else torch.cat(xs, 3)
     return ops.conv2d_op(xin, V, g, b, stride=stride[0], upsample=upsample,
                          preact=ops.ACT[pre_activation], segs=[int(t.shape[-1]) for t in xs])
+
+
+class ConcatList(list):
+    """A list of NHWC tensors that are channel slices of ONE buffer (`.buffer`), in order --
+    what a DenseNet block returns.  It behaves as the reference's Python list (indexable,
+    usable as the input of conv2d) while letting the next layer read the concatenation without
+    a copy."""
+    buffer = None
+
+
+@_scoped
+def dense_block(x, layers_per_block, filters_per_layer, pre_activation='celu', filter_size=[3, 3],
+                counters={}, init=False, ema=None, weight_norm=True, **kwargs):
+    """`for rep in range(L): x.append(conv2d(x, F, pre_activation))` of the reference
+    (models/densenet.py:11-16, 60-65) as one in-place growing block.  Layer names / variables
+    are the same `conv2d_<k>/{V,g,b}` the loop would have created."""
+    xs = _as_list(x)
+    dev = xs[0].device
+    segs0 = [int(t.shape[-1]) for t in xs]
+    x0 = xs.buffer if isinstance(xs, ConcatList) and xs.buffer is not None else (
+        xs[0] if len(xs) == 1 else torch.cat(xs, 3))
+    mult = 2 if pre_activation in ("celu", "crelu") else 1
+    params = []
+    c = sum(segs0)
+    for _ in range(layers_per_block):
+        name = get_name('conv2d', counters)
+        V = get_var_maybe_avg(f"{name}/V", (filter_size[0], filter_size[1], c * mult, filters_per_layer),
+                              "normal", ema, dev)
+        g = get_var_maybe_avg(f"{name}/g", (filters_per_layer,), "ones", ema, dev)
+        b = get_var_maybe_avg(f"{name}/b", (filters_per_layer,), "zeros", ema, dev)
+        params.append((V, g, b))
+        c += filters_per_layer
+    buf = ops.dense_block_op(x0, segs0, params, ksize=filter_size[0], preact=ops.ACT[pre_activation])
+    out = ConcatList(torch.split(buf, segs0 + [filters_per_layer] * layers_per_block, dim=3))
+    out.buffer = buf
+    return out
 
 
 def feature_head(x):

@@ -102,3 +102,63 @@ def test_dcgan_ema_generator(dev):
     upd()
     p0 = dcgan.generator.trainable_variables()[0]
     assert _rel(ema.average(p0), p0.detach() - 0.01 + 0.001 * 0.01) < 1e-6
+
+
+# ------------------------------------------------------------------------------- DenseNet
+def test_densenet_shapes(dev):
+    from otgan_amd.models import densenet
+    densenet.discriminator.reset(seed=1)
+    densenet.generator.reset(seed=1)
+    x = torch.rand(2, 32, 32, 3, device=dev) * 2 - 1
+    f = densenet.discriminator(x, init=True, nonlinearity="crelu")
+    assert f.shape == (2, 7296)
+    img = densenet.generator(batch_size=2, init=True, nonlinearity="crelu", device=dev)
+    assert img.shape == (2, 32, 32, 3)
+    nd = sum(v.numel() for v in densenet.discriminator.trainable_variables())
+    ng = sum(v.numel() for v in densenet.generator.trainable_variables())
+    assert nd == 7453016 and ng == 6012422
+    assert len(densenet.discriminator.trainable_variables()) == 52 * 3
+
+
+@pytest.mark.parametrize("L", [2, 16])
+def test_densenet_critic_parity(dev, L):
+    from otgan_amd.models import densenet
+    densenet.discriminator.reset(seed=5)
+    gen = torch.Generator().manual_seed(0)
+    x = torch.rand(2, 32, 32, 3, generator=gen) * 2 - 1
+    xg = x.to(dev).requires_grad_(True)
+    f = densenet.discriminator(xg, nonlinearity="crelu", layers_per_block=L)
+    P = _oracle_params(densenet.discriminator)
+    x64 = x.double().requires_grad_(True)
+    f_ref = NT.densenet_discriminator(x64, P, "crelu", L)
+    assert _rel(f, f_ref) < 5e-5
+    gy = torch.randn(f_ref.shape, generator=gen, dtype=torch.float64).float()
+    params = densenet.discriminator.trainable_variables()
+    got = torch.autograd.grad(f, [xg] + params, gy.to(dev))
+    names = list(densenet.discriminator.named_variables())
+    leaves = [x64] + [P[n.rsplit("/", 1)[0]][n.rsplit("/", 1)[1]] for n in names]
+    ref = torch.autograd.grad(f_ref, leaves, gy.double())
+    for n, a, r in zip(["dx"] + names, got, ref):
+        assert _rel(a, r) < 2e-4, n
+
+
+def test_densenet_generator_parity(dev):
+    from otgan_amd.models import densenet
+    densenet.generator.reset(seed=6)
+    gen = torch.Generator().manual_seed(1)
+    L = 3
+    us = [torch.rand(2, 100, generator=gen) * 2 - 1, torch.rand(2, 8, 8, 16, generator=gen) * 2 - 1,
+          torch.rand(2, 16, 16, 16, generator=gen) * 2 - 1, torch.rand(2, 32, 32, 16, generator=gen) * 2 - 1]
+    img = densenet.generator(batch_size=2, nonlinearity="crelu", layers_per_block=L,
+                             noise=[u.to(dev) for u in us])
+    P = _oracle_params(densenet.generator)
+    img_ref = NT.densenet_generator([u.double() for u in us], P, "crelu", L)
+    assert _rel(img, img_ref) < 5e-5
+    gy = torch.randn(img_ref.shape, generator=gen, dtype=torch.float64).float()
+    params = densenet.generator.trainable_variables()
+    got = torch.autograd.grad(img, params, gy.to(dev))
+    names = list(densenet.generator.named_variables())
+    leaves = [P[n.rsplit("/", 1)[0]][n.rsplit("/", 1)[1]] for n in names]
+    ref = torch.autograd.grad(img_ref, leaves, gy.double())
+    for n, a, r in zip(names, got, ref):
+        assert _rel(a, r) < 2e-4, n

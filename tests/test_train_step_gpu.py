@@ -1,0 +1,107 @@
+"""GPU: one whole OT-GAN step (generator / critic forward, Sinkhorn matching, gradient
+injection, gradient lists) of the HIP trainer vs the CPU oracle step (oracle/train_step_cpu.py:
+PyTorch fp64 nets + NumPy fp64 matching) with identical parameters, data and latents.
+Also: the parameter update itself (Adam with the reference's epsilon placement, EMA)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets_torch as NT
+from oracle.train_step_cpu import CpuOTGAN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _noise(model, nb, gen):
+    if model == "dcgan":
+        return torch.rand(nb, 100, generator=gen) * 2 - 1
+    return [torch.rand(nb, 100, generator=gen) * 2 - 1, torch.rand(nb, 8, 8, 16, generator=gen) * 2 - 1,
+            torch.rand(nb, 16, 16, 16, generator=gen) * 2 - 1, torch.rand(nb, 32, 32, 16, generator=gen) * 2 - 1]
+
+
+@pytest.mark.parametrize("model", ["dcgan", "densenet"])
+@pytest.mark.parametrize("kind", ["disc", "gen"])
+def test_step_gradients_match_oracle(dev, model, kind):
+    from otgan_amd.trainer import OTGAN, default_args
+    lam, iters = 100.0, 20
+    args = default_args(model=model, batch_size=3, nr_gpu=2, sinkhorn_lambda=lam, nr_sinkhorn_iter=iters,
+                        nr_gen_per_disc=1, seed=7)
+    m = OTGAN(args, dev)
+    if kind == "gen":
+        m.step_counter = 1
+    gen = torch.Generator().manual_seed(11)
+    x = torch.rand(m.nb, 32, 32, 3, generator=gen) * 2 - 1
+    noise = _noise(model, m.nb, gen)
+    to_dev = lambda z: [t.to(dev) for t in z] if isinstance(z, list) else z.to(dev)
+    r = m.step(x.to(dev), noise=to_dev(noise), apply_updates=False)
+    assert r["kind"] == kind
+
+    o = CpuOTGAN(model, "crelu", dtype=torch.float64, use_c_matching=False)
+    named = {}
+    named.update(m.discriminator.named_variables())
+    named.update(m.generator.named_variables())
+    o.load(named)
+    to64 = lambda z: [t.double() for t in z] if isinstance(z, list) else z.double()
+    gr, dist, ent = o.grads(kind, x.double(), to64(noise), 2, lam, iters)
+    assert float(r["distance"]) == pytest.approx(dist, rel=2e-4, abs=1e-7)
+    assert float(r["entropy"]) == pytest.approx(ent, rel=2e-4)
+    names = list((m.generator if kind == "gen" else m.discriminator).named_variables())
+    worst = max(_rel(a, b) for a, b in zip(r["grads"], gr))
+    for n, a, b in zip(names, r["grads"], gr):
+        assert _rel(a, b) < 2e-3, (n, _rel(a, b), worst)
+
+
+def test_updates_and_ema(dev):
+    """Two full steps: parameters move by the reference's Adam (critic ascends: lr = -lr,
+    train.py:143), the EMA shadows follow the generator (train.py:63-64,223)."""
+    from otgan_amd.trainer import OTGAN, default_args
+    args = default_args(model="dcgan", batch_size=2, nr_gpu=2, sinkhorn_lambda=50.0, nr_sinkhorn_iter=5,
+                        nr_gen_per_disc=1, seed=3)
+    m = OTGAN(args, dev)
+    d0 = [p.detach().clone() for p in m.disc_params]
+    g0 = [p.detach().clone() for p in m.gen_params]
+    x = torch.rand(m.nb, 32, 32, 3, device=dev) * 2 - 1
+    u = torch.rand(m.nb, 100, device=dev) * 2 - 1
+    r = m.step(x, noise=u, apply_updates=False)          # peek at the critic gradients
+    grads = [t.clone() for t in r["grads"]]
+    m.step_counter = 0
+    m.step(x, noise=u)                                   # critic step
+    for p, p0, gr in zip(m.disc_params, d0, grads):
+        st = {"t": 1.0, "v": torch.zeros_like(p0, dtype=torch.float64).cpu(),
+              "mg": torch.zeros_like(p0, dtype=torch.float64).cpu()}
+        ref = NT.adam_update(p0.double().cpu(), gr.double().cpu(), st, -args.learning_rate_disc, 0.5, 0.999)
+        assert _rel(p, ref) < 1e-6
+    for p, p0 in zip(m.gen_params, g0):
+        assert torch.equal(p.detach(), p0)               # untouched by the critic step
+    m.step(x, noise=u)                                   # generator step
+    moved = [not torch.equal(p.detach(), p0) for p, p0 in zip(m.gen_params, g0)]
+    assert all(moved)
+    for p, p0 in zip(m.gen_params, g0):
+        sh = m.ema.average(p)
+        ref = 0.999 * p0.double() + 0.001 * p.detach().double()
+        assert _rel(sh, ref) < 1e-6
+
+
+def test_random_and_single_batch_modes_run(dev):
+    from otgan_amd.trainer import OTGAN, default_args
+    x = None
+    for kw in ({"no_sinkhorn": True}, {"single_batch": True}, {"train_disc_against_ema": True},
+               {"optimizer": "adamax"}, {"optimizer": "nesterov"}):
+        args = default_args(model="dcgan", batch_size=2, nr_gpu=2, nr_sinkhorn_iter=5, nr_gen_per_disc=1, **kw)
+        m = OTGAN(args, dev)
+        x = torch.rand(m.nb, 32, 32, 3, device=dev) * 2 - 1
+        for _ in range(2):
+            r = m.step(x)
+            assert torch.isfinite(r["distance"]).item()
