@@ -101,9 +101,17 @@ def main():
         dom = max(conv, key=lambda k: conv[k]["ms"])
         d = conv[dom]
         ach = d["flop"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+        # HBM traffic per launch of that kernel class: from the committed rocprofv3 PMC passes
+        # (tools/pmc_bench.sh -> profiles/r01_pmc_summary.json), not measurable in-process.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", f"r01_pmc_summary_{a.model}.json")) as f:
+                traffic = round(json.load(f)[dom]["hbm_bytes_per_launch"])
+        except Exception:
+            pass
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2),
                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                            "launches": d["launches"], "avg_ms": round(d["ms"] / max(d["launches"], 1), 4)}
         out["kernel_classes"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                      "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flop"] > 0 else None}
