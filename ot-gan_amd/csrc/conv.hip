@@ -25,8 +25,25 @@
 
 namespace {
 
-using CfgMain = GemmCfg<2, 2, 2, 2, 16>;    // 128 x 128 block tile
-using CfgNarrow = GemmCfg<4, 1, 2, 1, 16>;  // 256 x 32 block tile (Cout / Cin <= 32)
+// Tile configurations (measured with tools/ablate/gemm_ablate.hip on MI355X, fp32 MFMA):
+// 128x128x32 is the best general tile (111-127 TFLOP/s, 2 workgroups/CU at 66 KB LDS);
+// 64x128x32 wins when the 128x128 grid would have < 2 workgroups per CU (113 vs 102);
+// BK = 16 variants serve channel counts that are not a multiple of 32 and the scalar paths.
+using CfgMain = GemmCfg<2, 2, 2, 2, 32>;    // 128 x 128 x 32
+using CfgSmall = GemmCfg<2, 2, 1, 2, 32>;   // 64 x 128 x 32
+using CfgMain16 = GemmCfg<2, 2, 2, 2, 16>;  // 128 x 128 x 16
+using CfgNarrow = GemmCfg<4, 1, 2, 1, 16>;  // 256 x 32 x 16 (Cout / Cin <= 32)
+
+// Kernels use dynamic LDS (the 128x128x32 tile needs 66 KB > the 64 KB static limit).
+template <auto Kern>
+inline void ensure_lds(size_t bytes) {
+  static const bool done = [bytes] {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(Kern),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return true;
+  }();
+  (void)done;
+}
 
 constexpr int kMaxTaps = 36;
 constexpr int kMaxClass = 4;
@@ -354,7 +371,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Cla
                                                                  WeightB wb, EpiArgs e) {
   using LA = ConvALoader<Cfg, Cfg::BM, VEC, ACT>;
   using LB = ConvBLoader<Cfg, Cfg::BN, VEC>;
-  __shared__ __attribute__((aligned(16))) float smem[2 * LA::FLOATS + 2 * LB::FLOATS];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int m0 = blockIdx.x * Cfg::BM;
   const int nblk = blockIdx.y;
   const int cls = blockIdx.z;
@@ -547,7 +564,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(GatherA g, Cla
                                                                  WgradArgs a) {
   using LA = WgALoaderV<Cfg, ACT>;
   using LB = WgBLoaderV<Cfg>;
-  __shared__ __attribute__((aligned(16))) float smem[2 * LA::FLOATS + 2 * LB::FLOATS];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tm = blockIdx.x / a.tiles_n, tn = blockIdx.x % a.tiles_n;
   const int split = blockIdx.y;
   const int z = blockIdx.z;
@@ -699,7 +716,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_scalar_kernel(GatherA
                                                                         WgradArgs a) {
   using LA = WgALoaderS<Cfg, ACT>;
   using LB = WgBLoaderS<Cfg>;
-  __shared__ __attribute__((aligned(16))) float smem[2 * LA::FLOATS + 2 * LB::FLOATS];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tm = blockIdx.x / a.tiles_n, tn = blockIdx.x % a.tiles_n;
   const int split = blockIdx.y;
   const int r0 = tm * Cfg::BM, co0 = tn * Cfg::BN;
@@ -902,7 +919,8 @@ FoldTab make_fold(const otgan_conv_desc* d, const Geo& g) {
 }
 
 struct WgPlan {
-  bool vec, fold;
+  bool vec, fold, narrow;
+  int bk;
   int tiles_m, tiles_n, nsplit, kt_per_split, nz;
   long slab_elems;  // elements of one slab (= weff elements when folded)
   long M;           // GEMM K extent (pixels of the row grid)
@@ -913,8 +931,10 @@ WgPlan plan_wgrad(const otgan_conv_desc* d, const Geo& g) {
   p.vec = (g.Ceff % 4 == 0) && (d->Cout % 4 == 0) && (d->ldy % 4 == 0) && (d->y_coff % 4 == 0) &&
           (d->ldx % 4 == 0) && (g.Ceff >= 32);
   p.fold = g.fold && p.vec;
-  const bool narrow = d->Cout <= 32;
-  const int BM = narrow ? CfgNarrow::BM : CfgMain::BM, BN = narrow ? CfgNarrow::BN : CfgMain::BN;
+  p.narrow = d->Cout <= 32;
+  // vector path: 128x128x32 (256x32x16 when narrow); scalar path: BK = 16 tiles
+  const int BM = p.narrow ? CfgNarrow::BM : 128, BN = p.narrow ? CfgNarrow::BN : 128;
+  p.bk = (p.vec && !p.narrow) ? CfgMain::BK : 16;
   if (p.fold) {
     const FoldTab f = make_fold(d, g);
     p.slab_elems = f.total;
@@ -934,7 +954,7 @@ WgPlan plan_wgrad(const otgan_conv_desc* d, const Geo& g) {
     }
   }
   p.tiles_n = ceil_div(d->Cout, BN);
-  const int nkt = (int)ceil_div_l(p.M, 16);
+  const int nkt = (int)ceil_div_l(p.M, p.bk);
   const int blocks = p.tiles_m * p.tiles_n * p.nz;
   int want = ceil_div(1024, blocks);
   if (want < 1) want = 1;
@@ -1004,21 +1024,77 @@ void folded_classes(const FoldTab& f, long boff_stride, const long* woff, ClassT
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <class Cfg, int EPI, int ACT>
-void launch_igemm2(bool vec, dim3 grid, hipStream_t s, const GatherA& ga, const ClassTab& ct,
-                   const WeightB& wb, const EpiArgs& e) {
-  if (vec)
-    hipLaunchKernelGGL((conv_igemm_kernel<Cfg, true, EPI, ACT>), grid, dim3(Cfg::THREADS), 0, s, ga, ct, wb, e);
-  else
-    hipLaunchKernelGGL((conv_igemm_kernel<Cfg, false, EPI, ACT>), grid, dim3(Cfg::THREADS), 0, s, ga, ct, wb, e);
+template <class Cfg, bool VEC, int EPI, int ACT>
+void launch_igemm3(dim3 grid, hipStream_t s, const GatherA& ga, const ClassTab& ct, const WeightB& wb,
+                   const EpiArgs& e) {
+  using LA = ConvALoader<Cfg, Cfg::BM, VEC, ACT>;
+  using LB = ConvBLoader<Cfg, Cfg::BN, VEC>;
+  constexpr size_t lds = sizeof(float) * (2 * LA::FLOATS + 2 * LB::FLOATS);
+  ensure_lds<conv_igemm_kernel<Cfg, VEC, EPI, ACT>>(lds);
+  hipLaunchKernelGGL((conv_igemm_kernel<Cfg, VEC, EPI, ACT>), grid, dim3(Cfg::THREADS), lds, s, ga, ct, wb, e);
 }
+
+// Picks the tile configuration for an implicit GEMM with `rows` x `cols_tiles128` output
+// (cols_tiles = number of 128-wide N tiles, i.e. 64 real channels when paired) and launches.
+// vec_ok: all alignment conditions for float4 gathers hold; Ck: channels per tap in K.
+template <int EPI, int ACT>
+void launch_igemm(bool vec_ok, int Ck, int rows, int ncols, bool paired, int ncls, hipStream_t s,
+                  const GatherA& ga, const ClassTab& ct, const WeightB& wb, const EpiArgs& e) {
+  const int ntiles = paired ? ceil_div(ncols, 64) : ceil_div(ncols, 128);
+  if (!paired && ncols <= 32) {
+    dim3 grid(ceil_div(rows, CfgNarrow::BM), 1, ncls);
+    if constexpr (EPI != EPI_DG_PAIR) {
+      if (vec_ok && Ck % 16 == 0) launch_igemm3<CfgNarrow, true, EPI, ACT>(grid, s, ga, ct, wb, e);
+      else launch_igemm3<CfgNarrow, false, EPI, ACT>(grid, s, ga, ct, wb, e);
+    }
+    return;
+  }
+  if (vec_ok && Ck % 32 == 0) {
+    const long tiles128 = (long)ceil_div(rows, 128) * ntiles * ncls;
+    if (tiles128 < 512) {
+      dim3 grid(ceil_div(rows, CfgSmall::BM), ntiles, ncls);
+      launch_igemm3<CfgSmall, true, EPI, ACT>(grid, s, ga, ct, wb, e);
+    } else {
+      dim3 grid(ceil_div(rows, CfgMain::BM), ntiles, ncls);
+      launch_igemm3<CfgMain, true, EPI, ACT>(grid, s, ga, ct, wb, e);
+    }
+    return;
+  }
+  dim3 grid(ceil_div(rows, CfgMain16::BM), ntiles, ncls);
+  if (vec_ok && Ck % 16 == 0) launch_igemm3<CfgMain16, true, EPI, ACT>(grid, s, ga, ct, wb, e);
+  else launch_igemm3<CfgMain16, false, EPI, ACT>(grid, s, ga, ct, wb, e);
+}
+
 // forward: activation applied in the gather (compile-time ACT)
-template <class Cfg>
-void launch_fwd(int act, bool vec, dim3 grid, hipStream_t s, const GatherA& ga, const ClassTab& ct,
-                const WeightB& wb, const EpiArgs& e) {
-  if (act == 1) launch_igemm2<Cfg, EPI_FWD, 1>(vec, grid, s, ga, ct, wb, e);
-  else if (act == 2) launch_igemm2<Cfg, EPI_FWD, 2>(vec, grid, s, ga, ct, wb, e);
-  else launch_igemm2<Cfg, EPI_FWD, 0>(vec, grid, s, ga, ct, wb, e);
+void launch_fwd(int act, bool vec_ok, int Ck, int rows, int ncols, int ncls, hipStream_t s,
+                const GatherA& ga, const ClassTab& ct, const WeightB& wb, const EpiArgs& e) {
+  if (act == 1) launch_igemm<EPI_FWD, 1>(vec_ok, Ck, rows, ncols, false, ncls, s, ga, ct, wb, e);
+  else if (act == 2) launch_igemm<EPI_FWD, 2>(vec_ok, Ck, rows, ncols, false, ncls, s, ga, ct, wb, e);
+  else launch_igemm<EPI_FWD, 0>(vec_ok, Ck, rows, ncols, false, ncls, s, ga, ct, wb, e);
+}
+
+template <class Cfg, int ACT, bool VEC>
+void launch_wgrad3(dim3 grid, hipStream_t s, const GatherA& ga, const ClassTab& ct, const WgradArgs& a) {
+  if constexpr (VEC) {
+    using LA = WgALoaderV<Cfg, ACT>;
+    using LB = WgBLoaderV<Cfg>;
+    constexpr size_t lds = sizeof(float) * (2 * LA::FLOATS + 2 * LB::FLOATS);
+    ensure_lds<conv_wgrad_kernel<Cfg, ACT>>(lds);
+    hipLaunchKernelGGL((conv_wgrad_kernel<Cfg, ACT>), grid, dim3(Cfg::THREADS), lds, s, ga, ct, a);
+  } else {
+    using LA = WgALoaderS<Cfg, ACT>;
+    using LB = WgBLoaderS<Cfg>;
+    constexpr size_t lds = sizeof(float) * (2 * LA::FLOATS + 2 * LB::FLOATS);
+    ensure_lds<conv_wgrad_scalar_kernel<Cfg, ACT>>(lds);
+    hipLaunchKernelGGL((conv_wgrad_scalar_kernel<Cfg, ACT>), grid, dim3(Cfg::THREADS), lds, s, ga, ct, a);
+  }
+}
+template <class Cfg, bool VEC>
+void launch_wgrad(int act, dim3 grid, hipStream_t s, const GatherA& ga, const ClassTab& ct,
+                  const WgradArgs& a) {
+  if (act == 1) launch_wgrad3<Cfg, 1, VEC>(grid, s, ga, ct, a);
+  else if (act == 2) launch_wgrad3<Cfg, 2, VEC>(grid, s, ga, ct, a);
+  else launch_wgrad3<Cfg, 0, VEC>(grid, s, ga, ct, a);
 }
 
 }  // namespace
@@ -1112,13 +1188,7 @@ int otgan_conv2d_fwd_f32(const otgan_conv_desc* d, const float* x, const int32_t
     if (same_k) {
       // the usual case (odd square filters): one launch, blockIdx.z = output parity class
       wb.ldbn = (long)ct.taps[0].n * g.Ceff;
-      if (d->Cout <= 32) {
-        dim3 grid(ceil_div(ga.Mtot, CfgNarrow::BM), ceil_div(d->Cout, CfgNarrow::BN), 4);
-        launch_fwd<CfgNarrow>(act, vec, grid, s, ga, ct, wb, e);
-      } else {
-        dim3 grid(ceil_div(ga.Mtot, CfgMain::BM), ceil_div(d->Cout, CfgMain::BN), 4);
-        launch_fwd<CfgMain>(act, vec, grid, s, ga, ct, wb, e);
-      }
+      launch_fwd(act, vec, g.Ceff, ga.Mtot, d->Cout, 4, s, ga, ct, wb, e);
     } else {
       for (int cls = 0; cls < 4; ++cls) {
         ClassTab one;
@@ -1130,13 +1200,7 @@ int otgan_conv2d_fwd_f32(const otgan_conv_desc* d, const float* x, const int32_t
         one.woff[0] = ct.woff[cls];
         one.zbase[1] = one.taps[0].n;
         wb.ldbn = (long)ct.taps[cls].n * g.Ceff;
-        if (d->Cout <= 32) {
-          dim3 grid(ceil_div(ga.Mtot, CfgNarrow::BM), ceil_div(d->Cout, CfgNarrow::BN), 1);
-          launch_fwd<CfgNarrow>(act, vec, grid, s, ga, one, wb, e);
-        } else {
-          dim3 grid(ceil_div(ga.Mtot, CfgMain::BM), ceil_div(d->Cout, CfgMain::BN), 1);
-          launch_fwd<CfgMain>(act, vec, grid, s, ga, one, wb, e);
-        }
+        launch_fwd(act, vec, g.Ceff, ga.Mtot, d->Cout, 1, s, ga, one, wb, e);
       }
     }
     OTGAN_CHECK_LAUNCH("conv2d fwd (folded)");
@@ -1152,13 +1216,7 @@ int otgan_conv2d_fwd_f32(const otgan_conv_desc* d, const float* x, const int32_t
   flops = 2.0 * ga.Mtot * (double)Ktot * d->Cout;
   ProfScope ps(OTGAN_PROF_CONV_FWD, flops, 0.0, s);
   const int act = act_kind(d->preact);
-  if (d->Cout <= 32) {
-    dim3 grid(ceil_div(ga.Mtot, CfgNarrow::BM), ceil_div(d->Cout, CfgNarrow::BN), 1);
-    launch_fwd<CfgNarrow>(act, vec, grid, s, ga, ct, wb, e);
-  } else {
-    dim3 grid(ceil_div(ga.Mtot, CfgMain::BM), ceil_div(d->Cout, CfgMain::BN), 1);
-    launch_fwd<CfgMain>(act, vec, grid, s, ga, ct, wb, e);
-  }
+  launch_fwd(act, vec, g.Ceff, ga.Mtot, d->Cout, 1, s, ga, ct, wb, e);
   OTGAN_CHECK_LAUNCH("conv2d fwd");
   return OTGAN_OK;
 }
@@ -1284,18 +1342,9 @@ int otgan_conv2d_dgrad_f32(const otgan_conv_desc* d, const float* dy, const floa
   }
   {
     ProfScope ps(OTGAN_PROF_CONV_DGRAD, flops, 0.0, s);
-    if (paired) {
-      dim3 grid(ceil_div(ga.Mtot, CfgMain::BM), ceil_div(d->C, 64), ct.ncls);
-      launch_igemm2<CfgMain, EPI_DG_PAIR, 0>(vec, grid, s, ga, ct, wb, e);
-    } else if (d->C <= 32) {
-      dim3 grid(ceil_div(ga.Mtot, CfgNarrow::BM), ceil_div(d->C, CfgNarrow::BN), ct.ncls);
-      if (kind) launch_igemm2<CfgNarrow, EPI_DG_ACT, 0>(vec, grid, s, ga, ct, wb, e);
-      else launch_igemm2<CfgNarrow, EPI_DG_PLAIN, 0>(vec, grid, s, ga, ct, wb, e);
-    } else {
-      dim3 grid(ceil_div(ga.Mtot, CfgMain::BM), ceil_div(d->C, CfgMain::BN), ct.ncls);
-      if (kind) launch_igemm2<CfgMain, EPI_DG_ACT, 0>(vec, grid, s, ga, ct, wb, e);
-      else launch_igemm2<CfgMain, EPI_DG_PLAIN, 0>(vec, grid, s, ga, ct, wb, e);
-    }
+    if (paired) launch_igemm<EPI_DG_PAIR, 0>(vec, d->Cout, ga.Mtot, d->C, true, ct.ncls, s, ga, ct, wb, e);
+    else if (kind) launch_igemm<EPI_DG_ACT, 0>(vec, d->Cout, ga.Mtot, d->C, false, ct.ncls, s, ga, ct, wb, e);
+    else launch_igemm<EPI_DG_PLAIN, 0>(vec, d->Cout, ga.Mtot, d->C, false, ct.ncls, s, ga, ct, wb, e);
   }
   OTGAN_CHECK_LAUNCH("conv2d dgrad");
   if (pool) {
@@ -1351,25 +1400,17 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
     a.so = 1; a.OHf = g.OH; a.OWf = g.OW;
     a.slab = p.nsplit > 1 ? slabs : dw;
   }
-  const bool narrow = d->Cout <= 32;
   const int act = act_kind(d->preact);
   dim3 grid(p.tiles_m * p.tiles_n, p.nsplit, p.nz);
   {
     ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * (double)p.M * (double)p.slab_elems, 0.0, s);
-#define OTGAN_WG(KERNEL, CFG)                                                                      \
-  do {                                                                                             \
-    if (act == 1) hipLaunchKernelGGL((KERNEL<CFG, 1>), grid, dim3(CFG::THREADS), 0, s, ga, ct, a);  \
-    else if (act == 2) hipLaunchKernelGGL((KERNEL<CFG, 2>), grid, dim3(CFG::THREADS), 0, s, ga, ct, a); \
-    else hipLaunchKernelGGL((KERNEL<CFG, 0>), grid, dim3(CFG::THREADS), 0, s, ga, ct, a);          \
-  } while (0)
     if (p.vec) {
-      if (narrow) OTGAN_WG(conv_wgrad_kernel, CfgNarrow);
-      else OTGAN_WG(conv_wgrad_kernel, CfgMain);
+      if (p.narrow) launch_wgrad<CfgNarrow, true>(act, grid, s, ga, ct, a);
+      else launch_wgrad<CfgMain, true>(act, grid, s, ga, ct, a);
     } else {
-      if (narrow) OTGAN_WG(conv_wgrad_scalar_kernel, CfgNarrow);
-      else OTGAN_WG(conv_wgrad_scalar_kernel, CfgMain);
+      if (p.narrow) launch_wgrad<CfgNarrow, false>(act, grid, s, ga, ct, a);
+      else launch_wgrad<CfgMain16, false>(act, grid, s, ga, ct, a);
     }
-#undef OTGAN_WG
   }
   OTGAN_CHECK_LAUNCH("conv2d wgrad");
   if (p.nsplit > 1) {

@@ -61,15 +61,14 @@ int main(int argc, char** argv) {
   hipMemcpy(B, h.data(), sizeof(float) * (size_t)N * K, hipMemcpyHostToDevice);
   printf("M=%d N=%d K=%d\n", M, N, K);
   run<GemmCfg<2, 2, 2, 2, 16>>("128x128 bk16 (3 blk/CU)", A, B, C, M, N, K, 0);
-  run<GemmCfg<2, 2, 2, 2, 16>>("128x128 bk16 (2 blk/CU)", A, B, C, M, N, K, 30000);
-  run<GemmCfg<2, 2, 2, 2, 16>>("128x128 bk16 (1 blk/CU)", A, B, C, M, N, K, 60000);
   run<GemmCfg<2, 2, 2, 2, 32>>("128x128 bk32", A, B, C, M, N, K, 0);
-  run<GemmCfg<2, 2, 2, 2, 8>>("128x128 bk8", A, B, C, M, N, K, 0);
-  run<GemmCfg<4, 2, 2, 2, 16>>("256x128 bk16 8 waves", A, B, C, M, N, K, 0);
-  run<GemmCfg<2, 4, 2, 2, 16>>("128x256 bk16 8 waves", A, B, C, M, N, K, 0);
-  run<GemmCfg<2, 2, 4, 2, 16>>("256x128 bk16 4 waves", A, B, C, M, N, K, 0);
-  run<GemmCfg<2, 2, 2, 4, 16>>("128x256 bk16 4 waves", A, B, C, M, N, K, 0);
-  run<GemmCfg<2, 2, 4, 4, 16>>("256x256 bk16 4 waves", A, B, C, M, N, K, 0);
-  run<GemmCfg<1, 4, 2, 1, 16>>("64x128 bk16", A, B, C, M, N, K, 0);
+  run<GemmCfg<2, 2, 2, 2, 64>>("128x128 bk64", A, B, C, M, N, K, 0);
+  run<GemmCfg<2, 2, 4, 2, 32>>("256x128 bk32 4 waves", A, B, C, M, N, K, 0);
+  run<GemmCfg<2, 2, 2, 4, 32>>("128x256 bk32 4 waves", A, B, C, M, N, K, 0);
+  run<GemmCfg<4, 2, 2, 2, 32>>("256x128 bk32 8 waves", A, B, C, M, N, K, 0);
+  run<GemmCfg<2, 2, 3, 2, 16>>("192x128 bk16 4 waves", A, B, C, M, N, K, 0);
+  run<GemmCfg<1, 4, 2, 1, 32>>("64x128 bk32", A, B, C, M, N, K, 0);
+  run<GemmCfg<1, 4, 2, 2, 32>>("64x256 bk32", A, B, C, M, N, K, 0);
+  run<GemmCfg<2, 2, 1, 2, 32>>("64x128 bk32 (2x2 waves)", A, B, C, M, N, K, 0);
   return 0;
 }
