@@ -85,6 +85,20 @@ int otgan_matching_two_batch_f32(const float* fa, const float* fb, int N, int D,
                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Row-range variant for data-parallel training: the six problems are solved in full, but only
+ * rows [row_begin, row_begin + row_count) of the [2N, D] outputs are produced (into
+ * [row_count, D] buffers) -- the rows of the samples a rank owns; the range must lie inside one
+ * mini-batch.  dist is the cancellation-free closed form
+ * [sum_ab (sum(M)-<M,C>) - ...] / (4N) of the same quantity (cosine cost only).
+ */
+int otgan_matching_two_batch_rows_f32(const float* fa, const float* fb, int N, int D, long ldf,
+                                      float sinkhorn_lambda, int iters, int row_begin,
+                                      int row_count, float* f_aa, float* f_bb, float* f_ab,
+                                      float* f_ba, long ldo, float* entropy, double* dist,
+                                      double* stats, void* workspace, size_t workspace_bytes,
+                                      void* stream);
+
+/*
  * Single-batch matching (matching.py:88-136): fa, fb [n, D]; 999 is added to the a-a and
  * b-b cost diagonals.  stats: [3][4] doubles (aa, bb, ab).
  */

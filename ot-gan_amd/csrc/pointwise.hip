@@ -49,14 +49,23 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
 }
 
 // MODE 0: out = sum; 1: out = rsqrt(max(sum, 1e-12))  (tf.nn.l2_normalize epsilon, nn.py:176)
+// 256 threads = 64 columns x 4 chunk lanes (fixed summation order: deterministic).
 template <int MODE>
-__global__ void colreduce_finish_kernel(const float* __restrict__ partial, int nchunk, int cols,
-                                        float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+__global__ __launch_bounds__(256) void colreduce_finish_kernel(const float* __restrict__ partial,
+                                                               int nchunk, int cols,
+                                                               float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int k = 0; k < nchunk; ++k) s += partial[(long)k * cols + c];
-  out[c] = MODE == 1 ? rsqrtf(fmaxf(s, 1e-12f)) : s;
+  if (c < cols)
+    for (int k = part; k < nchunk; k += 4) s += partial[(long)k * cols + c];
+  __shared__ float red[4][64];
+  red[part][lane] = s;
+  __syncthreads();
+  if (part == 0 && c < cols) {
+    const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    out[c] = MODE == 1 ? rsqrtf(fmaxf(t, 1e-12f)) : t;
+  }
 }
 
 // float4 variant: a block covers 64 columns (16 lanes x float4) and 16 row lanes
@@ -332,7 +341,7 @@ int otgan_weightnorm_fwd_f32(const float* V, const float* g, int K, int Cout, fl
   int nchunk = 0;
   int rc = colreduce<1>(V, nullptr, K, Cout, Cout, partial, &nchunk, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(colreduce_finish_kernel<1>, dim3(ceil_div(Cout, 256)), dim3(256), 0, s, partial,
+  hipLaunchKernelGGL(colreduce_finish_kernel<1>, dim3(ceil_div(Cout, 64)), dim3(256), 0, s, partial,
                      nchunk, Cout, inv_norm);
   dim3 grid(ceil_div(Cout, 32), ceil_div(K, 32));
   hipLaunchKernelGGL(weightnorm_apply_kernel, grid, dim3(256), 0, s, V, g, inv_norm, K, Cout, w, wT);
@@ -349,7 +358,7 @@ int otgan_weightnorm_bwd_f32(const float* V, const float* g, const float* inv_no
   int nchunk = 0;
   int rc = colreduce<2>(dw, V, K, Cout, Cout, partial, &nchunk, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(colreduce_finish_kernel<0>, dim3(ceil_div(Cout, 256)), dim3(256), 0, s, partial,
+  hipLaunchKernelGGL(colreduce_finish_kernel<0>, dim3(ceil_div(Cout, 64)), dim3(256), 0, s, partial,
                      nchunk, Cout, scratch);
   hipLaunchKernelGGL(weightnorm_dg_kernel, dim3(ceil_div(Cout, 256)), dim3(256), 0, s, scratch,
                      inv_norm, Cout, dg);
@@ -368,7 +377,7 @@ int otgan_colsum_f32(const float* a, long rows, int cols, long lda, float* out, 
   int nchunk = 0;
   int rc = colreduce<0>(a, nullptr, rows, cols, lda, scratch, &nchunk, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(colreduce_finish_kernel<0>, dim3(ceil_div(cols, 256)), dim3(256), 0, s, scratch,
+  hipLaunchKernelGGL(colreduce_finish_kernel<0>, dim3(ceil_div(cols, 64)), dim3(256), 0, s, scratch,
                      nchunk, cols, out);
   OTGAN_CHECK_LAUNCH("colsum");
   return OTGAN_OK;

@@ -408,6 +408,15 @@ __global__ void entropy_finalize_kernel(const double* stats, int P, int n, float
   entropy[0] = (float)(e / P);                                     // mean over problems (:61)
 }
 
+// two-batch distance from the per-problem statistics (cancellation-free closed form of
+// SURVEY.md section 3.4): nd = sum(M) - <M,C> per problem (cosine cost),
+// dist = [2 T(a1a2) + 2 T(b2b1) - T(a1b1) - T(a1b2) - T(a2b1) - T(a2b2)] / (4N)
+__global__ void closed_form_distance_kernel(const double* stats, int N, double* dist) {
+  double T[6];
+  for (int p = 0; p < 6; ++p) T[p] = stats[p * 4 + 2] - stats[p * 4 + 1];
+  dist[0] = (2.0 * T[0] + 2.0 * T[1] - (T[2] + T[3] + T[4] + T[5])) / (4.0 * N);
+}
+
 // ---------------------------------------------------------------------------------------
 // host-side planning helpers
 // ---------------------------------------------------------------------------------------
@@ -659,6 +668,67 @@ int otgan_matching_two_batch_f32(const float* fa, const float* fb, int N, int D,
                                                         : 2.0 * (2.0 * N) * (double)D;  // matching_cpu.py:158-163
   rc = launch_distance(fa, fb, f_aa, f_bb, f_ab, (long)2 * N * D, denom, dist, w.dot3, s);
   if (rc) return rc;
+  if (stats) hipMemcpyAsync(stats, w.stats, sizeof(double) * 24, hipMemcpyDeviceToDevice, s);
+  return OTGAN_OK;
+}
+
+int otgan_matching_two_batch_rows_f32(const float* fa, const float* fb, int N, int D, long ldf,
+                                      float lambda, int iters, int row_begin, int row_count,
+                                      float* f_aa, float* f_bb, float* f_ab, float* f_ba, long ldo,
+                                      float* entropy, double* dist, double* stats, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  OTGAN_CHECK_ARG(fa && fb && f_aa && f_bb && f_ab && f_ba && entropy && dist, "null pointer");
+  OTGAN_CHECK_ARG(N > 0 && D > 0 && ldf >= D && ldo >= D && iters >= 0, "bad sizes N=%d D=%d", N, D);
+  OTGAN_CHECK_ARG(row_begin >= 0 && row_count > 0 && row_begin + row_count <= 2 * N,
+                  "row range [%d, %d) outside [0, %d)", row_begin, row_begin + row_count, 2 * N);
+  const int half = row_begin / N;
+  OTGAN_CHECK_ARG((row_begin + row_count - 1) / N == half, "row range must not straddle the two mini-batches");
+  hipStream_t s = (hipStream_t)stream;
+  MatchWs w = carve_match(workspace, workspace_bytes, 6, N, D, 2 * N);
+  if (!workspace || workspace_bytes < w.bytes) {
+    otgan_set_error("workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
+    return OTGAN_ERR_WORKSPACE;
+  }
+  const float *fa1 = fa, *fa2 = fa + (long)N * ldf, *fb1 = fb, *fb2 = fb + (long)N * ldf;
+  const float* X[6] = {fa1, fb2, fa1, fa1, fa2, fa2};
+  const float* Y[6] = {fa2, fb1, fb1, fb2, fb1, fb2};
+  int rc = launch_cost(X, Y, nullptr, nullptr, nullptr, 6, N, N, D, ldf, lambda, OTGAN_COST_COSINE,
+                       w.partial, w.K, s);
+  if (rc) return rc;
+  rc = launch_sinkhorn(w.K, 6, N, N, iters, lambda, w.plan, w.planT, w.stats, w.fg, s);
+  if (rc) return rc;
+  const size_t nn = (size_t)N * N;
+  const long ro = (long)(row_begin - half * N) * N;  // first plan row of the range
+  const float* M[6];
+  const float* T[6];
+  for (int p = 0; p < 6; ++p) {
+    M[p] = w.plan + p * nn + ro;
+    T[p] = w.planT + p * nn + ro;
+  }
+  ApplyBlock blk[4];
+  memset(blk, 0, sizeof(blk));
+  auto set = [&](int i, float* out, const float* P0, const float* F0, const float* P1, const float* F1,
+                 float alpha) {
+    blk[i].out = out; blk[i].rows = row_count; blk[i].nterms = P1 ? 2 : 1; blk[i].alpha = alpha;
+    blk[i].t[0] = ApplyTerm{P0, F0, (long)N, N};
+    if (P1) blk[i].t[1] = ApplyTerm{P1, F1, (long)N, N};
+  };
+  if (half == 0) {  // rows of a1 / b1  (matching.py:64-67,72,74)
+    set(0, f_aa, M[0], fa2, nullptr, nullptr, 1.f);
+    set(1, f_bb, T[1], fb2, nullptr, nullptr, 1.f);
+    set(2, f_ab, M[2], fb1, M[3], fb2, 0.5f);
+    set(3, f_ba, T[2], fa1, T[4], fa2, 0.5f);
+  } else {          // rows of a2 / b2  (matching.py:68-71,73,75)
+    set(0, f_aa, T[0], fa1, nullptr, nullptr, 1.f);
+    set(1, f_bb, M[1], fb1, nullptr, nullptr, 1.f);
+    set(2, f_ab, M[4], fb1, M[5], fb2, 0.5f);
+    set(3, f_ba, T[3], fa1, T[5], fa2, 0.5f);
+  }
+  rc = launch_apply(blk, 4, row_count, D, ldf, ldo, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(entropy_finalize_kernel, dim3(1), dim3(1), 0, s, w.stats, 6, N, entropy);
+  hipLaunchKernelGGL(closed_form_distance_kernel, dim3(1), dim3(1), 0, s, w.stats, N, dist);
+  OTGAN_CHECK_LAUNCH("matching finalize");
   if (stats) hipMemcpyAsync(stats, w.stats, sizeof(double) * 24, hipMemcpyDeviceToDevice, s);
   return OTGAN_OK;
 }

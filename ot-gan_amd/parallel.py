@@ -46,12 +46,21 @@ def get_rank():
     return dist.get_rank() if dist.is_initialized() else 0
 
 
+def _staged():
+    """gloo has no CUDA all-gather: stage through host memory (tests only; RCCL is direct)."""
+    return dist.get_backend() == "gloo"
+
+
 def all_gather_rows(x):
     """[n, D] per rank -> [world*n, D] in rank order (one collective)."""
     w = world_size()
     if w == 1:
         return x
     x = x.contiguous()
+    if _staged() and x.is_cuda:
+        parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(w)]
+        dist.all_gather(parts, x.cpu())
+        return torch.cat(parts, 0).to(x.device)
     out = torch.empty((w * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     dist.all_gather_into_tensor(out, x)
     return out
@@ -79,7 +88,12 @@ def allreduce_sum_(tensors):
     if world_size() == 1 or not tensors:
         return tensors
     flat = torch.cat([t.reshape(-1) for t in tensors])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if _staged() and flat.is_cuda:
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat = host.to(flat.device)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     off = 0
     for t in tensors:
         n = t.numel()

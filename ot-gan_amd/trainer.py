@@ -59,6 +59,12 @@ class OTGAN:
         if self.scope == "global" and self.world > 1:
             fa = parallel.gather_feature_shards(f_gen, self.shards)
             fb = parallel.gather_feature_shards(f_dat, self.shards)
+            if not (a.single_batch or a.no_sinkhorn):
+                # every rank solves the six global problems, but only applies the plans to the
+                # rows of its own samples (1/world of the matched-feature GEMMs)
+                outs, ent, dist = matching.get_matched_features_rows(
+                    fa, fb, a.sinkhorn_lambda, a.nr_sinkhorn_iter, self.rank * self.nb, self.nb)
+                return outs[0] - outs[2], outs[1] - outs[3], dist, ent
         else:
             fa = list(torch.chunk(f_gen, self.shards, 0))
             fb = list(torch.chunk(f_dat, self.shards, 0))

@@ -110,6 +110,35 @@ def get_matched_features(features_a, features_b, sinkhorn_lambda, nr_sinkhorn_it
                 nr_sinkhorn_iter, COST_COSINE)
 
 
+def get_matched_features_rows(features_a, features_b, sinkhorn_lambda, nr_sinkhorn_iter, row_begin,
+                              row_count):
+    """Two-batch matching over the full shard lists, producing only rows
+    [row_begin, row_begin+row_count) of the four matched-feature arrays (the rows of the samples
+    one data-parallel rank owns).  Returns (f_aa, f_bb, f_ab, f_ba) as [row_count, D] tensors,
+    entropy, and the fp64 distance (closed form of calc_distance)."""
+    _check_lists(features_a, features_b)
+    if len(features_a) % 2 != 0:
+        raise ValueError("the two-batch matching needs an even number of shards (train.py:34)")
+    fa, fb = _stack(features_a), _stack(features_b)
+    L = _lib.lib()
+    rows_total, D = fa.shape
+    N = rows_total // 2
+    dev = fa.device
+    outs = [torch.empty((row_count, D), dtype=fa.dtype, device=dev) for _ in range(4)]
+    entropy = torch.empty((), dtype=torch.float32, device=dev)
+    dist = torch.empty((), dtype=torch.float64, device=dev)
+    stats = torch.empty((6, 4), dtype=torch.float64, device=dev)
+    need = L.otgan_matching_workspace_bytes(_MODE_TWO, N, D)
+    ws = _workspace(need, dev)
+    rc = L.otgan_matching_two_batch_rows_f32(fa.data_ptr(), fb.data_ptr(), N, D, D, float(sinkhorn_lambda),
+                                             int(nr_sinkhorn_iter), int(row_begin), int(row_count),
+                                             outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
+                                             outs[3].data_ptr(), D, entropy.data_ptr(), dist.data_ptr(),
+                                             stats.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+    _lib.check(rc, "otgan_matching_two_batch_rows_f32")
+    return outs, entropy, dist
+
+
 def get_matched_features_single_batch(features_a, features_b, sinkhorn_lambda, nr_sinkhorn_iter):
     """Single-batch matching (reference utils/matching.py:88-136)."""
     _check_lists(features_a, features_b)

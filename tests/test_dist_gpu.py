@@ -1,0 +1,91 @@
+"""GPU: two ranks (two processes sharing cuda:0, gloo transport) run one critic and one
+generator step with the reference-faithful GLOBAL matching; the all-reduced gradients must equal
+those of a single process holding both shards (the reference sums tower gradients,
+train.py:134-139, and forms mini-batch 1 / 2 from the first / second half of the shards,
+utils/matching.py:16-19).  RCCL replaces gloo on a multi-GPU node; the trainer code path
+(feature all-gather -> row-range matching -> gradient SUM all-reduce) is the same."""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+LAM, ITERS, B = 100.0, 20, 4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _data():
+    g = torch.Generator().manual_seed(123)
+    x = torch.rand(2 * B, 32, 32, 3, generator=g) * 2 - 1
+    u = torch.rand(2 * B, 100, generator=g) * 2 - 1
+    return x, u
+
+
+def _run_steps(model, x, u):
+    out = {}
+    for kind, ctr in (("disc", 0), ("gen", 1)):
+        model.step_counter = ctr
+        r = model.step(x, noise=u, apply_updates=False)
+        assert r["kind"] == kind
+        out[kind] = [t.detach().cpu() for t in r["grads"]]
+        out[kind + "_dist"] = float(r["distance"])
+    return out
+
+
+def _worker(rank, world, port, path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from otgan_amd import parallel
+    from otgan_amd.trainer import OTGAN, default_args
+    parallel.init_from_env(backend="gloo")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    args = default_args(model="dcgan", batch_size=B, nr_gpu=2, sinkhorn_lambda=LAM, nr_sinkhorn_iter=ITERS,
+                        nr_gen_per_disc=1, seed=5, matching_scope="global")
+    m = OTGAN(args, dev)
+    assert m.shards == 1 and m.scope == "global"
+    x, u = _data()
+    sl = slice(rank * B, (rank + 1) * B)
+    res = _run_steps(m, x[sl].to(dev), u[sl].to(dev))
+    if rank == 0:
+        torch.save(res, path)
+    parallel.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_equal_single_process():
+    assert torch.cuda.is_available()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "r0.pt")
+        port = _free_port()
+        ctx = mp.get_context("spawn")
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, path)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(600)
+            assert p.exitcode == 0
+        got = torch.load(path)
+    from otgan_amd.trainer import OTGAN, default_args
+    dev = torch.device("cuda:0")
+    args = default_args(model="dcgan", batch_size=B, nr_gpu=2, sinkhorn_lambda=LAM, nr_sinkhorn_iter=ITERS,
+                        nr_gen_per_disc=1, seed=5)
+    m = OTGAN(args, dev)          # world 1: both shards local
+    x, u = _data()
+    ref = _run_steps(m, x.to(dev), u.to(dev))
+    for kind in ("disc", "gen"):
+        assert got[kind + "_dist"] == pytest.approx(ref[kind + "_dist"], rel=1e-5, abs=1e-8)
+        for a, b in zip(got[kind], ref[kind]):
+            err = float((a - b).norm() / b.norm().clamp_min(1e-30))
+            assert err < 2e-3, (kind, err)
