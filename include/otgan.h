@@ -90,13 +90,16 @@ int otgan_matching_two_batch_f32(const float* fa, const float* fb, int N, int D,
  * [row_count, D] buffers) -- the rows of the samples a rank owns; the range must lie inside one
  * mini-batch.  dist is the cancellation-free closed form
  * [sum_ab (sum(M)-<M,C>) - ...] / (4N) of the same quantity (cosine cost only).
+ * K_pre (nullable): the six log-kernels [6][N][N] = -lambda*cost in the reference's problem
+ * order, when the caller already has them (ranks compute their own row slices with
+ * otgan_cost_matrix_f32 and all-gather them, as the reference shards matching.py:29-39).
  */
 int otgan_matching_two_batch_rows_f32(const float* fa, const float* fb, int N, int D, long ldf,
                                       float sinkhorn_lambda, int iters, int row_begin,
-                                      int row_count, float* f_aa, float* f_bb, float* f_ab,
-                                      float* f_ba, long ldo, float* entropy, double* dist,
-                                      double* stats, void* workspace, size_t workspace_bytes,
-                                      void* stream);
+                                      int row_count, const float* K_pre, float* f_aa, float* f_bb,
+                                      float* f_ab, float* f_ba, long ldo, float* entropy,
+                                      double* dist, double* stats, void* workspace,
+                                      size_t workspace_bytes, void* stream);
 
 /*
  * Single-batch matching (matching.py:88-136): fa, fb [n, D]; 999 is added to the a-a and

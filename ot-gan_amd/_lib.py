@@ -24,7 +24,7 @@ SIGNATURES = {
                                              c_fp, c_fp, c_fp, c_fp, c_long, c_fp, c_fp, c_fp,
                                              c_fp, c_size_t, c_fp]),
     "otgan_matching_two_batch_rows_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_long, c_float, c_int, c_int,
-                                                  c_int, c_fp, c_fp, c_fp, c_fp, c_long, c_fp, c_fp,
+                                                  c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_long, c_fp, c_fp,
                                                   c_fp, c_fp, c_size_t, c_fp]),
     "otgan_matching_single_batch_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_long, c_float, c_int,
                                                 c_fp, c_fp, c_fp, c_fp, c_long, c_fp, c_fp, c_fp,

@@ -220,6 +220,195 @@ __global__ __launch_bounds__(512) void sinkhorn_small_kernel(const float* __rest
   }
 }
 
+// ---- 2a'. 128 < N <= 1024 (square): persistent multi-workgroup kernel ----------------------
+// Problem p is split over R = ceil(N / RPW) workgroups of 1024 threads.  Workgroup r keeps
+// on chip both a row panel K[r*RPW .. +RPW][all columns] (row role, REGISTERS: 32 values per
+// thread) and a column panel K[all rows][r*RPW .. +RPW] (column role, LDS: <= 128 KiB).
+// A half-sweep is a local reduction over the panel; the only traffic between workgroups is
+// the potential vector (N floats per problem) and one counter barrier per half-sweep
+// (agent-scope release/acquire, placement independent; spins are bounded so a mis-launch
+// cannot hang the GPU).  Thread t: line = t % RPW (its row / column inside the panel),
+// q = t / RPW (which 32-wide slice of the other dimension it reduces).
+constexpr int kPanelThreads = 1024;
+
+struct PanelArgs {
+  const float* K;      // [P][N][N]
+  int N, iters, R;
+  float inv_lambda;
+  float* f;            // [P][N] exchange buffers
+  float* g;            // [P][N]
+  unsigned* bar;       // [P] arrival counters (zeroed before the launch)
+  unsigned* fail;      // [1] set when a spin gave up
+  float* plan;
+  float* planT;
+  double* stats;       // zeroed before the launch
+};
+
+// Exchange protocol (cdna_hip_programming.md Guideline 16, form R1): potentials are PUBLISHED
+// with write-through (sc1) 4-byte stores, every storing wave drains its stores, one lane
+// bumps the arrival counter; consumers poll the counter relaxed and then READ the potentials
+// with sc1 loads (L1 bypass) -- no release/acquire fences on the critical path.
+__device__ __forceinline__ void publish_f32(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float consume_f32(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool panel_barrier(unsigned* ctr, unsigned target, unsigned* fail) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its sc1 stores
+  __syncthreads();
+  __shared__ int s_ok;
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 23)) {  // ~1 s: give up instead of hanging the device
+        __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    s_ok = ok;
+  }
+  __syncthreads();
+  return s_ok != 0;
+}
+
+// combine the TPR partial (max, sum) pairs of one line and publish -LSE to global memory
+template <int TPR, int RPW>
+__device__ __forceinline__ void panel_combine(float mx, float s, float* s_pm, float* s_ps, int line,
+                                              int q, int gline, int N, float* out_global) {
+  s_pm[q * RPW + line] = mx;
+  s_ps[q * RPW + line] = s;
+  __syncthreads();
+  if (q == 0) {
+    float M = s_pm[line];
+#pragma unroll 4
+    for (int k = 1; k < TPR; ++k) M = fmaxf(M, s_pm[k * RPW + line]);
+    float S = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < TPR; ++k) S += s_ps[k * RPW + line] * exp_neg(s_pm[k * RPW + line] - M);
+    if (gline < N) publish_f32(out_global + gline, -(M + logf(S)));
+  }
+}
+
+template <int TPR>  // slices per line: 8 (RPW 128, N <= 256), 16 (RPW 64, N <= 512), 32 (RPW 32)
+__global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs a) {
+  constexpr int RPW = kPanelThreads / TPR;
+  extern __shared__ __attribute__((aligned(16))) float psm[];
+  float* s_kc = psm;                         // [TPR*32][RPW] column panel
+  float* s_pot = s_kc + TPR * 32 * RPW;      // [1024] potentials of the other side
+  float* s_pm = s_pot + 1024;                // [TPR][RPW]
+  float* s_ps = s_pm + TPR * RPW;            // [TPR][RPW]
+  const int p = blockIdx.x / a.R, r = blockIdx.x % a.R;
+  const int N = a.N;
+  const float* K = a.K + (long)p * N * N;
+  const int t = threadIdx.x, line = t % RPW, q = t / RPW;
+  const int gline = r * RPW + line;  // global row (row role) / column (column role)
+  float kr[32];
+#pragma unroll
+  for (int e = 0; e < 32; ++e) {
+    const int j = q * 32 + e;
+    kr[e] = (j < N && gline < N) ? K[(long)gline * N + j] : kNegBig;
+  }
+#pragma unroll 4
+  for (int e = 0; e < 32; ++e) {
+    const int i = q * 32 + e;
+    s_kc[i * RPW + line] = (i < N && gline < N) ? K[(long)i * N + gline] : kNegBig;
+  }
+  float* f = a.f + (long)p * N;
+  float* g = a.g + (long)p * N;
+  unsigned* bar = a.bar + p;
+  unsigned phase = 0;
+  s_pot[t] = 0.f;  // g = 0 (1024 threads cover the 1024 slots)
+  __syncthreads();
+  bool ok = true;
+  for (int it = 0; it <= a.iters && ok; ++it) {
+    {  // rows: f from g (s_pot holds g); the extra pass it == iters is the final row softmax
+      float v[32];
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) {
+        v[e] = kr[e] + s_pot[q * 32 + e];
+        mx = fmaxf(mx, v[e]);
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) s += exp_neg(v[e] - mx);
+      panel_combine<TPR, RPW>(mx, s, s_pm, s_ps, line, q, gline, N, f);
+    }
+    ok = panel_barrier(bar, (++phase) * a.R, a.fail);
+    s_pot[t] = t < N ? consume_f32(f + t) : 0.f;
+    __syncthreads();
+    if (it == a.iters) break;
+    {  // columns: g from f (s_pot holds f)
+      float v[32];
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) {
+        v[e] = s_kc[(q * 32 + e) * RPW + line] + s_pot[q * 32 + e];
+        mx = fmaxf(mx, v[e]);
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) s += exp_neg(v[e] - mx);
+      panel_combine<TPR, RPW>(mx, s, s_pm, s_ps, line, q, gline, N, g);
+    }
+    ok = ok && panel_barrier(bar, (++phase) * a.R, a.fail);
+    s_pot[t] = t < N ? consume_f32(g + t) : 0.f;
+    __syncthreads();
+  }
+  // here s_pot = final f (all rows); g of the last column step is in global memory.
+  // column role: plan[i][gline] = exp(K[i][gline] + f_i + g_gline), coalesced along the line
+  const float gl = gline < N ? consume_f32(g + gline) : 0.f;
+#pragma unroll 4
+  for (int e = 0; e < 32; ++e) {
+    const int i = q * 32 + e;
+    if (i < N && gline < N)
+      a.plan[(long)p * N * N + (long)i * N + gline] = expf(s_kc[i * RPW + line] + s_pot[i] + gl);
+  }
+  // row role: transposed plan and statistics; needs g for all columns
+  const float fl = gline < N ? s_pot[gline] : 0.f;
+  __syncthreads();
+  s_pot[t] = t < N ? consume_f32(g + t) : 0.f;
+  __syncthreads();
+  float h = 0.f, w = 0.f, sm = 0.f;
+#pragma unroll
+  for (int e = 0; e < 32; ++e) {
+    const int j = q * 32 + e;
+    if (j < N && gline < N) {
+      const float lm = kr[e] + fl + s_pot[j];
+      const float mij = expf(lm);
+      a.planT[(long)p * N * N + (long)j * N + gline] = mij;
+      h -= mij * lm;
+      w -= mij * kr[e];
+      sm += mij;
+    }
+  }
+  const double dh = wave_sum_d((double)h), dw = wave_sum_d((double)w), ds = wave_sum_d((double)sm);
+  if ((t & 63) == 0) {
+    atomicAdd(&a.stats[p * 4 + 0], dh);
+    atomicAdd(&a.stats[p * 4 + 1], dw * (double)a.inv_lambda);
+    atomicAdd(&a.stats[p * 4 + 2], ds);
+  }
+  if (!ok && t == 0) a.stats[p * 4 + 3] = __builtin_nan("");
+}
+
+template <int TPR>
+void launch_panel(const PanelArgs& a, int P, hipStream_t s) {
+  constexpr int RPW = kPanelThreads / TPR;
+  const size_t lds = sizeof(float) * ((size_t)TPR * 32 * RPW + 1024 + 2 * TPR * RPW);
+  static const bool once = [lds] {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_panel_kernel<TPR>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return true;
+  }();
+  (void)once;
+  hipLaunchKernelGGL(sinkhorn_panel_kernel<TPR>, dim3(P * a.R), dim3(kPanelThreads), lds, s, a);
+}
+
 // ---- 2b. general sizes: K stays in HBM/L2, two kernels per sweep -------------------------
 // rows: one wave per row.  out[p][i] = -LSE_j(K[p][i][j] + in[p][j])
 __global__ __launch_bounds__(256) void sinkhorn_row_kernel(const float* __restrict__ Kmat,
@@ -498,8 +687,26 @@ int launch_sinkhorn(const float* K, int P, int n, int m, int iters, float lambda
   }
   float* f = fg_ws;
   float* g = fg_ws + (size_t)P * n;
-  hipMemsetAsync(g, 0, sizeof(float) * (size_t)P * m, s);
   hipMemsetAsync(stats, 0, sizeof(double) * 4 * P, s);
+  if (n == m && n <= 1024) {
+    // persistent panel kernel: all P*R workgroups are co-resident (<= 192 of 256 CUs)
+    const int rpw = n <= 256 ? 128 : (n <= 512 ? 64 : 32);
+    PanelArgs a;
+    memset(&a, 0, sizeof(a));
+    a.K = K; a.N = n; a.iters = iters; a.R = ceil_div(n, rpw);
+    a.inv_lambda = 1.f / lambda;
+    a.f = f; a.g = g;
+    a.bar = (unsigned*)(fg_ws + (size_t)P * (n + m));
+    a.fail = a.bar + P;
+    a.plan = plan; a.planT = planT; a.stats = stats;
+    hipMemsetAsync(a.bar, 0, sizeof(unsigned) * (P + 1), s);
+    if (rpw == 128) launch_panel<8>(a, P, s);
+    else if (rpw == 64) launch_panel<16>(a, P, s);
+    else launch_panel<32>(a, P, s);
+    OTGAN_CHECK_LAUNCH("sinkhorn_panel_kernel");
+    return OTGAN_OK;
+  }
+  hipMemsetAsync(g, 0, sizeof(float) * (size_t)P * m, s);
   const dim3 grow(ceil_div(n, 4), P), gcol(ceil_div(m, 64), P);
   for (int it = 0; it < iters; ++it) {
     hipLaunchKernelGGL(sinkhorn_row_kernel, grow, dim3(256), 0, s, K, n, m, g, f);
@@ -575,7 +782,7 @@ MatchWs carve_match(void* base, size_t cap, int P, int n, int D, int feat_rows) 
   w.K = (float*)c.take(sizeof(float) * pnm);
   w.plan = (float*)c.take(sizeof(float) * pnm);
   w.planT = (float*)c.take(sizeof(float) * pnm);
-  w.fg = (float*)c.take(sizeof(float) * (size_t)P * 2 * n);
+  w.fg = (float*)c.take(sizeof(float) * (size_t)P * 2 * n + 64);  // potentials + barrier words
   w.stats = (double*)c.take(sizeof(double) * 4 * P);
   w.dot3 = (double*)c.take(sizeof(double) * 4);
   w.bytes = c.off;
@@ -674,9 +881,10 @@ int otgan_matching_two_batch_f32(const float* fa, const float* fb, int N, int D,
 
 int otgan_matching_two_batch_rows_f32(const float* fa, const float* fb, int N, int D, long ldf,
                                       float lambda, int iters, int row_begin, int row_count,
-                                      float* f_aa, float* f_bb, float* f_ab, float* f_ba, long ldo,
-                                      float* entropy, double* dist, double* stats, void* workspace,
-                                      size_t workspace_bytes, void* stream) {
+                                      const float* K_pre, float* f_aa, float* f_bb, float* f_ab,
+                                      float* f_ba, long ldo, float* entropy, double* dist,
+                                      double* stats, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
   OTGAN_CHECK_ARG(fa && fb && f_aa && f_bb && f_ab && f_ba && entropy && dist, "null pointer");
   OTGAN_CHECK_ARG(N > 0 && D > 0 && ldf >= D && ldo >= D && iters >= 0, "bad sizes N=%d D=%d", N, D);
   OTGAN_CHECK_ARG(row_begin >= 0 && row_count > 0 && row_begin + row_count <= 2 * N,
@@ -692,10 +900,15 @@ int otgan_matching_two_batch_rows_f32(const float* fa, const float* fb, int N, i
   const float *fa1 = fa, *fa2 = fa + (long)N * ldf, *fb1 = fb, *fb2 = fb + (long)N * ldf;
   const float* X[6] = {fa1, fb2, fa1, fa1, fa2, fa2};
   const float* Y[6] = {fa2, fb1, fb1, fb2, fb1, fb2};
-  int rc = launch_cost(X, Y, nullptr, nullptr, nullptr, 6, N, N, D, ldf, lambda, OTGAN_COST_COSINE,
-                       w.partial, w.K, s);
-  if (rc) return rc;
-  rc = launch_sinkhorn(w.K, 6, N, N, iters, lambda, w.plan, w.planT, w.stats, w.fg, s);
+  int rc = OTGAN_OK;
+  const float* Kuse = K_pre;
+  if (!K_pre) {
+    rc = launch_cost(X, Y, nullptr, nullptr, nullptr, 6, N, N, D, ldf, lambda, OTGAN_COST_COSINE,
+                     w.partial, w.K, s);
+    if (rc) return rc;
+    Kuse = w.K;
+  }
+  rc = launch_sinkhorn(Kuse, 6, N, N, iters, lambda, w.plan, w.planT, w.stats, w.fg, s);
   if (rc) return rc;
   const size_t nn = (size_t)N * N;
   const long ro = (long)(row_begin - half * N) * N;  // first plan row of the range
@@ -813,7 +1026,7 @@ int otgan_cost_matrix_f32(const float* X, const float* Y, int n, int m, int D, l
 
 size_t otgan_sinkhorn_workspace_bytes(int P, int n, int m) {
   if (P <= 0 || n <= 0 || m <= 0) return 0;
-  return align_up(sizeof(float) * (size_t)P * (n + m), 256);
+  return align_up(sizeof(float) * (size_t)P * (n + m) + 64, 256);  // potentials + barrier words
 }
 
 int otgan_sinkhorn_plan_f32(const float* K, int P, int n, int m, int iters, float lambda,

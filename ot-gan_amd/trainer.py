@@ -60,10 +60,14 @@ class OTGAN:
             fa = parallel.gather_feature_shards(f_gen, self.shards)
             fb = parallel.gather_feature_shards(f_dat, self.shards)
             if not (a.single_batch or a.no_sinkhorn):
-                # every rank solves the six global problems, but only applies the plans to the
-                # rows of its own samples (1/world of the matched-feature GEMMs)
+                # The cost matrices are row-sharded like the reference (matching.py:29-39): a rank
+                # of the first half computes its rows of (a1,a2) (a1,b1) (a1,b2), a rank of the
+                # second half its rows of (b2,b1) (a2,b1) (a2,b2); the slices are all-gathered.
+                # Every rank then solves the six (small, on-chip) Sinkhorn problems and applies the
+                # plans only to the rows of its own samples.
+                K = self._sharded_log_kernels(f_gen, f_dat, fa, fb)
                 outs, ent, dist = matching.get_matched_features_rows(
-                    fa, fb, a.sinkhorn_lambda, a.nr_sinkhorn_iter, self.rank * self.nb, self.nb)
+                    fa, fb, a.sinkhorn_lambda, a.nr_sinkhorn_iter, self.rank * self.nb, self.nb, K)
                 return outs[0] - outs[2], outs[1] - outs[3], dist, ent
         else:
             fa = list(torch.chunk(f_gen, self.shards, 0))
@@ -81,6 +85,25 @@ class OTGAN:
         grad_gen = pick(m[0]) - pick(m[2])
         grad_dat = pick(m[1]) - pick(m[3])
         return grad_gen, grad_dat, dist, m[4]
+
+    def _sharded_log_kernels(self, f_gen, f_dat, fa, fb):
+        lam = self.args.sinkhorn_lambda
+        h = len(fa) // 2
+        a1, a2 = torch.cat(fa[:h], 0), torch.cat(fa[h:], 0)
+        b1, b2 = torch.cat(fb[:h], 0), torch.cat(fb[h:], 0)
+        N = a1.shape[0]
+        first = self.rank < self.world // 2
+        if first:   # my rows belong to a1 / b1
+            mine = [matching.cost_log_kernel(f_gen, y, lam) for y in (a2, b1, b2)]      # p0, p2, p3
+        else:       # my rows belong to a2 / b2
+            mine = [matching.cost_log_kernel(f_dat, b1, lam),                            # p1 (b2,b1)
+                    matching.cost_log_kernel(f_gen, b1, lam),                            # p4 (a2,b1)
+                    matching.cost_log_kernel(f_gen, b2, lam)]                            # p5 (a2,b2)
+        allk = parallel.all_gather_rows(torch.stack(mine, 0).unsqueeze(0))              # [W,3,nb,N]
+        W2 = self.world // 2
+        lo = allk[:W2].permute(1, 0, 2, 3).reshape(3, N, N)     # problems 0, 2, 3
+        hi = allk[W2:].permute(1, 0, 2, 3).reshape(3, N, N)     # problems 1, 4, 5
+        return torch.stack([lo[0], hi[0], lo[1], lo[2], hi[1], hi[2]], 0).contiguous()
 
     # ---------------------------------------------------------------- one sess.run
     def step(self, x_data, noise=None, apply_updates=True):

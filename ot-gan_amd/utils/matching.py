@@ -110,8 +110,25 @@ def get_matched_features(features_a, features_b, sinkhorn_lambda, nr_sinkhorn_it
                 nr_sinkhorn_iter, COST_COSINE)
 
 
+def cost_log_kernel(x, y, sinkhorn_lambda, diag_add=0.0, cost_kind=COST_COSINE):
+    """K[n,m] = -lambda * (cost(x[n,D], y[m,D]) + diag_add*I)  (matching.py:31,50) -- staged
+    entry point, used by data-parallel ranks to compute their own row slices."""
+    L = _lib.lib()
+    x, y = x.detach().contiguous(), y.detach().contiguous()
+    n, D = x.shape
+    m = y.shape[0]
+    K = torch.empty((n, m), dtype=x.dtype, device=x.device)
+    need = L.otgan_cost_matrix_workspace_bytes(n, m, D)
+    ws = torch.empty(int(need), dtype=torch.uint8, device=x.device)
+    rc = L.otgan_cost_matrix_f32(x.data_ptr(), y.data_ptr(), n, m, D, D, float(sinkhorn_lambda),
+                                 int(cost_kind), float(diag_add), K.data_ptr(), ws.data_ptr(), int(need),
+                                 _lib.stream_ptr())
+    _lib.check(rc, "otgan_cost_matrix_f32")
+    return K
+
+
 def get_matched_features_rows(features_a, features_b, sinkhorn_lambda, nr_sinkhorn_iter, row_begin,
-                              row_count):
+                              row_count, log_kernels=None):
     """Two-batch matching over the full shard lists, producing only rows
     [row_begin, row_begin+row_count) of the four matched-feature arrays (the rows of the samples
     one data-parallel rank owns).  Returns (f_aa, f_bb, f_ab, f_ba) as [row_count, D] tensors,
@@ -124,6 +141,9 @@ def get_matched_features_rows(features_a, features_b, sinkhorn_lambda, nr_sinkho
     rows_total, D = fa.shape
     N = rows_total // 2
     dev = fa.device
+    if log_kernels is not None:
+        log_kernels = log_kernels.contiguous()
+        assert tuple(log_kernels.shape) == (6, N, N) and log_kernels.dtype == torch.float32
     outs = [torch.empty((row_count, D), dtype=fa.dtype, device=dev) for _ in range(4)]
     entropy = torch.empty((), dtype=torch.float32, device=dev)
     dist = torch.empty((), dtype=torch.float64, device=dev)
@@ -132,6 +152,7 @@ def get_matched_features_rows(features_a, features_b, sinkhorn_lambda, nr_sinkho
     ws = _workspace(need, dev)
     rc = L.otgan_matching_two_batch_rows_f32(fa.data_ptr(), fb.data_ptr(), N, D, D, float(sinkhorn_lambda),
                                              int(nr_sinkhorn_iter), int(row_begin), int(row_count),
+                                             _lib.ptr(log_kernels),
                                              outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
                                              outs[3].data_ptr(), D, entropy.data_ptr(), dist.data_ptr(),
                                              stats.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())

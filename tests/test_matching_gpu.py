@@ -86,7 +86,11 @@ def test_cost_matrix(dev, n, m, D, kind):
 
 
 @pytest.mark.parametrize("P,n,m,iters", [(6, 128, 128, 50), (3, 40, 72, 13), (2, 200, 136, 21),
-                                         (1, 1, 1, 3), (2, 128, 96, 0)])
+                                         (1, 1, 1, 3), (2, 128, 96, 0),
+                                         # square, 128 < N <= 1024: persistent multi-workgroup kernel
+                                         (6, 256, 256, 30), (3, 200, 200, 17), (2, 384, 384, 9),
+                                         (6, 512, 512, 12), (6, 1024, 1024, 7), (1, 1000, 1000, 5),
+                                         (2, 1100, 1100, 3)])
 def test_sinkhorn_plan(dev, P, n, m, iters):
     from otgan_amd import _lib
     L = _lib.lib()
