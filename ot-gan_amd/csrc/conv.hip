@@ -740,6 +740,211 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_scalar_kernel(GatherA
   });
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Few-channel layers (RGB in / RGB out): one side of the GEMM has <= 4 columns, where an MFMA
+// tile would idle >= 28 of 32 columns.  These run on the vector ALU instead:
+//   fewout : out[pix][j<4] = sum_{tap, d} act(src[pix (+) tap][d]) * Wf[tap][d][j]
+//            (forward with Cout <= 4, and dgrad with Cin <= 4 where src = dy)
+//            thread = pixel, weights are wave-uniform (scalar loads), 16 FMAs per 16-byte load
+//   outer  : dW[tap][wide][j<4] = sum_pix wide[pix][.] * narrow[pix][j]
+//            (wgrad with Cout <= 4 or Cin <= 4)   thread = wide channel, pixels streamed
+// ---------------------------------------------------------------------------------------
+struct FewOutArgs {
+  const float* w;      // weight of (tap t, output j, channel d) at w[boff[t] + j*sJ + d]
+  long sJ;
+  float* out;
+  int ldo, coff, J;    // J valid outputs (<= 4)
+  int so, OHf, OWf;
+  const float* bias;
+  int accumulate;
+};
+
+// Lanes run along the channels (coalesced 16-byte loads: one wave-load = two full pixel rows of
+// 128 channels); a wave owns 16 consecutive pixels (8 per 32-lane half), keeps the tap's
+// weights in registers while it sweeps them, and finishes with a 32-lane shuffle reduction.
+template <int ACT>
+__global__ __launch_bounds__(256) void conv_fewout_kernel(GatherA g, Taps taps, FewOutArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ps = lane >> 5, q = lane & 31;
+  const int m0 = (blockIdx.x * 4 + wave) * 16;
+  if (m0 >= g.Mtot) return;
+  const int vH = g.H << g.logUp, vW = g.W << g.logUp;
+  int pa[8], pb[8];
+  long pbase[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + 2 * i + ps;
+    if (m < g.Mtot) {
+      pb[i] = (m & ((1 << g.logGW) - 1)) * g.sa;
+      pa[i] = ((m >> g.logGW) & ((1 << g.logGH) - 1)) * g.sa;
+      pbase[i] = (long)(m >> (g.logGW + g.logGH)) * g.H * g.W;
+    } else {
+      pa[i] = pb[i] = -100000;
+      pbase[i] = 0;
+    }
+  }
+  float acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int t = 0; t < taps.n; ++t) {
+    const int dhw = taps.dhw[t];
+    const int dh = dhw >> 16, dw = sx16(dhw);
+    const float* wt = a.w + taps.boff[t];
+    for (int d0 = 0; d0 < g.Ck; d0 += 128) {
+      const int d = d0 + 4 * q;
+      const bool dok = d < g.Ck;
+      int sc = 0;
+      float sgn = 1.f;
+      if (dok) decode_map(g, d, g.cmap ? g.cmap[d] : 0, sc, sgn);
+      float4 w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        w[j] = (dok && j < a.J) ? *reinterpret_cast<const float4*>(wt + j * a.sJ + d)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int ih = pa[i] + dh, iw = pb[i] + dw;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dok && (unsigned)ih < (unsigned)vH && (unsigned)iw < (unsigned)vW) {
+          const long pix = pbase[i] + (long)(ih >> g.logUp) * g.W + (iw >> g.logUp);
+          v = *reinterpret_cast<const float4*>(g.x + pix * g.ldx + sc);
+        }
+        v.x = act_apply<ACT>(sgn * v.x);
+        v.y = act_apply<ACT>(sgn * v.y);
+        v.z = act_apply<ACT>(sgn * v.z);
+        v.w = act_apply<ACT>(sgn * v.w);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] += v.x * w[j].x + v.y * w[j].y + v.z * w[j].z + v.w * w[j].w;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = acc[i][j];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);  // stays inside the 32-lane half
+      acc[i][j] = v;
+    }
+  if (q == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + 2 * i + ps;
+      if (m >= g.Mtot) continue;
+      const int b = m & ((1 << g.logGW) - 1);
+      const int aa = (m >> g.logGW) & ((1 << g.logGH) - 1);
+      const int n = m >> (g.logGW + g.logGH);
+      float* dst = a.out + (((long)n * a.OHf + aa * a.so) * a.OWf + b * a.so) * a.ldo + a.coff;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < a.J) {
+          const float v = acc[i][j] + (a.bias ? a.bias[j] : 0.f);
+          dst[j] = a.accumulate ? dst[j] + v : v;
+        }
+      }
+    }
+  }
+}
+
+struct OuterArgs {
+  // wide operand: value(pix, c) ; narrow operand: value(pix, j)
+  const float* wide; int ldw; int wideC;      // channels of the wide side
+  const float* narrow; int ldn; int J;        // J <= 4
+  int wide_shift;      // 1: the tap shift applies to the wide operand (x), 0: to the narrow one
+  int H, W, logGH, logGW, Mtot, sa;           // pixel grid of the un-shifted operand; shifted dims H,W
+  const int* cmap; int Creal, doubled;        // channel map of the x operand
+  int chunk;           // pixels per block
+  float* slab;         // [nchunks][ntaps*wideC*J or ...]
+  long slab_stride;
+  long sT, sC, sJ;     // out index = t*sT + c*sC + j*sJ
+};
+
+// thread = 4 consecutive wide channels (one 16-byte load per pixel); the block's 8 pixel
+// streams are combined through LDS at the end.
+template <int ACT>
+__global__ __launch_bounds__(256) void conv_outer_kernel(OuterArgs a, Taps taps) {
+  const int cq = threadIdx.x & 31, ps = threadIdx.x >> 5;
+  const int c = blockIdx.x * 128 + 4 * cq;
+  const int t = blockIdx.z;
+  const int p0 = blockIdx.y * a.chunk;
+  int p1 = p0 + a.chunk;
+  if (p1 > a.Mtot) p1 = a.Mtot;
+  const int dh = taps.dhw[t] >> 16, dw = sx16(taps.dhw[t]);
+  const bool cok = c < a.wideC;
+  int sc = c;
+  float sgn = 1.f;
+  if (a.wide_shift && cok) {
+    GatherA gm;
+    gm.cmap = a.cmap; gm.Creal = a.Creal; gm.doubled = a.doubled;
+    decode_map(gm, c, a.cmap ? a.cmap[c] : 0, sc, sgn);
+  }
+  float acc[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[k][j] = 0.f;
+  if (cok) {
+    for (int m = p0 + ps; m < p1; m += 8) {
+      const int b = m & ((1 << a.logGW) - 1);
+      const int aa = (m >> a.logGW) & ((1 << a.logGH) - 1);
+      const int n = m >> (a.logGW + a.logGH);
+      const int ih = aa * a.sa + dh, iw = b * a.sa + dw;
+      if ((unsigned)ih >= (unsigned)a.H || (unsigned)iw >= (unsigned)a.W) continue;
+      const long spix = ((long)n * a.H + ih) * a.W + iw;   // shifted (x) pixel
+      float4 wv;
+      const float* np;
+      if (a.wide_shift) {
+        wv = *reinterpret_cast<const float4*>(a.wide + spix * a.ldw + sc);
+        wv.x = act_apply<ACT>(sgn * wv.x);
+        wv.y = act_apply<ACT>(sgn * wv.y);
+        wv.z = act_apply<ACT>(sgn * wv.z);
+        wv.w = act_apply<ACT>(sgn * wv.w);
+        np = a.narrow + (long)m * a.ldn;
+      } else {
+        wv = *reinterpret_cast<const float4*>(a.wide + (long)m * a.ldw + c);
+        np = a.narrow + spix * a.ldn;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < a.J) {
+          const float nv = a.wide_shift ? np[j] : act_apply<ACT>(np[j]);
+          acc[0][j] += wv.x * nv;
+          acc[1][j] += wv.y * nv;
+          acc[2][j] += wv.z * nv;
+          acc[3][j] += wv.w * nv;
+        }
+      }
+    }
+  }
+  __shared__ float red[8][128][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[ps][4 * cq + k][j] = acc[k][j];
+  __syncthreads();
+  // 256 threads finish 128 channels x (up to) 4 outputs: thread -> (channel, j pair)
+  const int ch = threadIdx.x & 127, jh = threadIdx.x >> 7;
+  const int cc = blockIdx.x * 128 + ch;
+  if (cc < a.wideC) {
+    float* out = a.slab + (long)blockIdx.y * a.slab_stride + t * a.sT + (long)cc * a.sC;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = 2 * jh + jj;
+      if (j < a.J) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += red[k][ch][j];
+        out[j * a.sJ] = v;
+      }
+    }
+  }
+}
+
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, int nsplit, long n,
                                    float* __restrict__ out) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -919,6 +1124,8 @@ FoldTab make_fold(const otgan_conv_desc* d, const Geo& g) {
 }
 
 struct WgPlan {
+  int outer;       // 0 no, 1 few outputs (Cout <= 4), 2 few inputs (Cin_eff <= 4)
+  int chunk, nchunks;
   bool vec, fold, narrow;
   int bk;
   int tiles_m, tiles_n, nsplit, kt_per_split, nz;
@@ -931,6 +1138,23 @@ WgPlan plan_wgrad(const otgan_conv_desc* d, const Geo& g) {
   p.vec = (g.Ceff % 4 == 0) && (d->Cout % 4 == 0) && (d->ldy % 4 == 0) && (d->y_coff % 4 == 0) &&
           (d->ldx % 4 == 0) && (g.Ceff >= 32);
   p.fold = g.fold && p.vec;
+  p.outer = 0;
+  p.chunk = p.nchunks = 0;
+  if (d->upsample == 0) {
+    if (d->Cout <= 4) p.outer = 1;
+    else if (g.Ceff <= 4 && d->preact == OTGAN_ACT_NONE) p.outer = 2;
+  }
+  if (p.outer) {
+    p.fold = false;
+    p.M = (long)d->N * g.OH * g.OW;
+    p.nchunks = p.M >= 256 * 64 ? 256 : (int)ceil_div_l(p.M, 64);
+    p.chunk = (int)ceil_div_l(p.M, p.nchunks);
+    p.nchunks = (int)ceil_div_l(p.M, p.chunk);
+    p.slab_elems = (long)taps * g.Ceff * d->Cout;
+    p.nsplit = p.nchunks;
+    p.vec = false; p.narrow = false; p.bk = 16; p.tiles_m = p.tiles_n = 1; p.nz = taps; p.kt_per_split = 1;
+    return p;
+  }
   p.narrow = d->Cout <= 32;
   // vector path: 128x128x32 (256x32x16 when narrow); scalar path: BK = 16 tiles
   const int BM = p.narrow ? CfgNarrow::BM : 128, BN = p.narrow ? CfgNarrow::BN : 128;
@@ -1210,6 +1434,23 @@ int otgan_conv2d_fwd_f32(const otgan_conv_desc* d, const float* x, const int32_t
   single_class(d, g, &ct);
   for (int t = 0; t < ct.taps[0].n; ++t) ct.taps[0].boff[t] = t * g.Ceff;
   const int Ktot = ct.taps[0].n * g.Ceff;
+  if (d->Cout <= 4 && d->upsample == 0 && g.Ceff % 4 == 0 && d->ldx % 4 == 0 && aligned16(x) &&
+      aligned16(wT)) {
+    // RGB-out layer: vector-ALU kernel, thread = pixel (an MFMA tile would idle 29 of 32 columns)
+    FewOutArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.w = wT; fa.sJ = Ktot;
+    fa.out = y; fa.ldo = d->ldy; fa.coff = d->y_coff; fa.J = d->Cout;
+    fa.so = 1; fa.OHf = g.OH; fa.OWf = g.OW; fa.bias = bias;
+    ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * ga.Mtot * (double)Ktot * d->Cout, 0.0, s);
+    const dim3 grid(ceil_div(ga.Mtot, 64));
+    const int act = act_kind(d->preact);
+    if (act == 1) hipLaunchKernelGGL(conv_fewout_kernel<1>, grid, dim3(256), 0, s, ga, ct.taps[0], fa);
+    else if (act == 2) hipLaunchKernelGGL(conv_fewout_kernel<2>, grid, dim3(256), 0, s, ga, ct.taps[0], fa);
+    else hipLaunchKernelGGL(conv_fewout_kernel<0>, grid, dim3(256), 0, s, ga, ct.taps[0], fa);
+    OTGAN_CHECK_LAUNCH("conv2d fwd (few outputs)");
+    return OTGAN_OK;
+  }
   wb.ldbn = Ktot;
   e.so = 1;
   vec = (g.Ceff % 16 == 0) && (d->ldx % 4 == 0) && aligned16(x) && aligned16(wT);
@@ -1261,6 +1502,31 @@ int otgan_conv2d_dgrad_f32(const otgan_conv_desc* d, const float* dy, const floa
   float* target = dx;
   bool pool = false;
   double flops = 0;
+  if (d->C <= 4 && kind == 0 && d->stride == 1 && d->upsample == 0 && d->Cout % 4 == 0 &&
+      d->ldy % 4 == 0 && d->y_coff % 4 == 0 && aligned16(dy) && aligned16(w)) {
+    // RGB-in layer: dx[pix][ci<4] = sum_{tap, co} dy[pix - tap][co] * W[tap][ci][co] on the VALU
+    ga.logGH = ilog2_exact(g.Hin);
+    ga.logGW = ilog2_exact(g.Win);
+    ga.Mtot = d->N * g.Hin * g.Win;
+    ga.sa = 1;
+    Taps& t = ct.taps[0];
+    t.n = d->KH * d->KW;
+    for (int kh = 0; kh < d->KH; ++kh)
+      for (int kw = 0; kw < d->KW; ++kw) {
+        const int i = kh * d->KW + kw;
+        t.dhw[i] = pack_dhw(g.pad_t - kh, g.pad_l - kw);
+        t.boff[i] = i * g.Ceff * d->Cout;
+      }
+    FewOutArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.w = w; fa.sJ = d->Cout;
+    fa.out = dx; fa.ldo = lddx; fa.coff = 0; fa.J = d->C;
+    fa.so = 1; fa.OHf = g.Hin; fa.OWf = g.Win; fa.accumulate = accumulate;
+    ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * ga.Mtot * (double)t.n * d->Cout * d->C, 0.0, s);
+    hipLaunchKernelGGL(conv_fewout_kernel<0>, dim3(ceil_div(ga.Mtot, 64)), dim3(256), 0, s, ga, t, fa);
+    OTGAN_CHECK_LAUNCH("conv2d dgrad (few inputs)");
+    return OTGAN_OK;
+  }
   if (g.fold) {
     // gradient w.r.t. the SMALL input directly: rows = small pixels, K = all 4 classes'
     // folded taps; dy is read at (2(a - dh) + ph, 2(b - dw) + pw); w = weff.
@@ -1375,6 +1641,42 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
   }
   GatherA ga;
   ClassTab ct;
+  if (p.outer) {
+    single_class(d, g, &ct);
+    OuterArgs oa;
+    memset(&oa, 0, sizeof(oa));
+    oa.H = d->H; oa.W = d->W;
+    oa.logGH = ilog2_exact(g.OH); oa.logGW = ilog2_exact(g.OW);
+    oa.Mtot = (int)p.M; oa.sa = d->stride;
+    oa.cmap = cmap; oa.Creal = d->C; oa.doubled = doubled_act(d->preact) ? 1 : 0;
+    oa.chunk = p.chunk;
+    oa.slab = (float*)workspace; oa.slab_stride = p.slab_elems;
+    oa.sT = (long)g.Ceff * d->Cout;
+    if (p.outer == 1) {   // few outputs: wide = act(x) shifted by the tap, narrow = dy
+      oa.wide = x; oa.ldw = d->ldx; oa.wideC = g.Ceff; oa.wide_shift = 1;
+      oa.narrow = dy + d->y_coff; oa.ldn = d->ldy; oa.J = d->Cout;
+      oa.sC = d->Cout; oa.sJ = 1;
+    } else {              // few inputs: wide = dy, narrow = x shifted by the tap
+      oa.wide = dy + d->y_coff; oa.ldw = d->ldy; oa.wideC = d->Cout; oa.wide_shift = 0;
+      oa.narrow = x; oa.ldn = d->ldx; oa.J = d->C;
+      oa.sC = 1; oa.sJ = d->Cout;
+    }
+    const dim3 grid(ceil_div(oa.wideC, 128), p.nchunks, ct.taps[0].n);
+    const int act = act_kind(d->preact);
+    {
+      ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * (double)p.M * (double)p.slab_elems, 0.0, s);
+      if (act == 1) hipLaunchKernelGGL(conv_outer_kernel<1>, grid, dim3(256), 0, s, oa, ct.taps[0]);
+      else if (act == 2) hipLaunchKernelGGL(conv_outer_kernel<2>, grid, dim3(256), 0, s, oa, ct.taps[0]);
+      else hipLaunchKernelGGL(conv_outer_kernel<0>, grid, dim3(256), 0, s, oa, ct.taps[0]);
+    }
+    OTGAN_CHECK_LAUNCH("conv2d wgrad (few channels)");
+    long blocks = ceil_div_l(p.slab_elems, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)blocks), dim3(256), 0, s, (const float*)workspace,
+                       p.nchunks, p.slab_elems, dw);
+    OTGAN_CHECK_LAUNCH("slab_reduce");
+    return OTGAN_OK;
+  }
   WgradArgs a;
   memset(&a, 0, sizeof(a));
   a.dy = dy + d->y_coff;
