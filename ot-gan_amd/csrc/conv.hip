@@ -33,6 +33,7 @@ using CfgMain = GemmCfg<2, 2, 2, 2, 32>;    // 128 x 128 x 32
 using CfgSmall = GemmCfg<2, 2, 1, 2, 32>;   // 64 x 128 x 32
 using CfgMain16 = GemmCfg<2, 2, 2, 2, 16>;  // 128 x 128 x 16
 using CfgNarrow = GemmCfg<4, 1, 2, 1, 16>;  // 256 x 32 x 16 (Cout / Cin <= 32)
+using CfgN16 = GemmCfg<4, 1, 4, 1, 16, 16>;  // 256 x 16 x 16 on v_mfma_f32_16x16x4_f32 (Cout <= 16: DenseNet)
 
 // Kernels use dynamic LDS (the 128x128x32 tile needs 66 KB > the 64 KB static limit).
 template <auto Kern>
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Cla
   LB lb(wb, taps, wb.w + ct.woff[cls]);
   la.init(m0);
   lb.init(nblk);
-  f32x16 acc[Cfg::MT][Cfg::NT];
+  typename Cfg::acc_t acc[Cfg::MT][Cfg::NT];
   zero_acc<Cfg>(acc);
   const int nkt = (taps.n * g.Ck + Cfg::BK - 1) / Cfg::BK;
   gemm_mainloop<Cfg>(la, lb, nkt, smem, acc);
@@ -388,21 +389,21 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Cla
   const int oa = ct.oa[cls], ob = ct.ob[cls];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
-  const int li = lane & 31, lh = lane >> 5;
+  const int lcol = Cfg::acc_col(lane);
   const int gmask = (1 << g.logGW) - 1, hmask = (1 << g.logGH) - 1;
 #pragma unroll
   for (int mt = 0; mt < Cfg::MT; ++mt) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wm * Cfg::MT * 32 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    for (int r = 0; r < Cfg::ACC; ++r) {
+      const int row = (wm * Cfg::MT + mt) * Cfg::TS + Cfg::acc_row(lane, r);
       const int m = m0 + row;
       if (m >= g.Mtot) continue;
       const int b = m & gmask, a = (m >> g.logGW) & hmask, n = m >> (g.logGW + g.logGH);
       const int oh = a * e.so + oa, ow = b * e.so + ob;
       const long opix = ((long)n * e.OHf + oh) * e.OWf + ow;
       if (EPI == EPI_DG_PAIR) {
-        static_assert(EPI != EPI_DG_PAIR || Cfg::NT == 2, "paired epilogue needs NT == 2");
-        const int c = nblk * 64 + wn * 32 + li;
+        static_assert(EPI != EPI_DG_PAIR || (Cfg::NT == 2 && Cfg::TS == 32), "paired epilogue needs 2 x 32 columns");
+        const int c = nblk * 64 + wn * 32 + lcol;
         if (c < e.ncols) {
           const long xpix = ((long)n * e.xH + (oh >> e.logUpX)) * e.xW + (ow >> e.logUpX);
           const float xv = e.xsrc[xpix * e.ldxs + c];
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Cla
       } else {
 #pragma unroll
         for (int nt = 0; nt < Cfg::NT; ++nt) {
-          const int col = nblk * Cfg::BN + wn * Cfg::NT * 32 + nt * 32 + li;
+          const int col = nblk * Cfg::BN + (wn * Cfg::NT + nt) * Cfg::TS + lcol;
           if (col >= e.ncols) continue;
           float v = acc[mt][nt][r];
           if (EPI == EPI_FWD) {
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(GatherA g, Cla
   LB lb;
   la.init(d0, ct.taps[cls].dhw[t], kt0 * Cfg::BK);
   lb.init(a, g, co0, ct.oa[cls], ct.ob[cls], kt0 * Cfg::BK);
-  f32x16 acc[Cfg::MT][Cfg::NT];
+  typename Cfg::acc_t acc[Cfg::MT][Cfg::NT];
   zero_acc<Cfg>(acc);
   gemm_mainloop<Cfg>(la, lb, nkt, smem, acc);
   float* out = a.slab + (long)split * a.slab_stride + ct.woff[cls] + (long)t * g.Ck * a.Cout;
@@ -729,7 +730,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_scalar_kernel(GatherA
   LB lb;
   la.init(r0, taps, kt0 * Cfg::BK);
   lb.init(a, co0, g.Mtot, kt0 * Cfg::BK);
-  f32x16 acc[Cfg::MT][Cfg::NT];
+  typename Cfg::acc_t acc[Cfg::MT][Cfg::NT];
   zero_acc<Cfg>(acc);
   gemm_mainloop<Cfg>(la, lb, nkt, smem, acc);
   float* out = a.slab + (long)split * a.slab_stride;
@@ -1126,7 +1127,7 @@ FoldTab make_fold(const otgan_conv_desc* d, const Geo& g) {
 struct WgPlan {
   int outer;       // 0 no, 1 few outputs (Cout <= 4), 2 few inputs (Cin_eff <= 4)
   int chunk, nchunks;
-  bool vec, fold, narrow;
+  bool vec, fold, narrow, n16;
   int bk;
   int tiles_m, tiles_n, nsplit, kt_per_split, nz;
   long slab_elems;  // elements of one slab (= weff elements when folded)
@@ -1152,12 +1153,13 @@ WgPlan plan_wgrad(const otgan_conv_desc* d, const Geo& g) {
     p.nchunks = (int)ceil_div_l(p.M, p.chunk);
     p.slab_elems = (long)taps * g.Ceff * d->Cout;
     p.nsplit = p.nchunks;
-    p.vec = false; p.narrow = false; p.bk = 16; p.tiles_m = p.tiles_n = 1; p.nz = taps; p.kt_per_split = 1;
+    p.vec = false; p.narrow = false; p.n16 = false; p.bk = 16; p.tiles_m = p.tiles_n = 1; p.nz = taps; p.kt_per_split = 1;
     return p;
   }
   p.narrow = d->Cout <= 32;
-  // vector path: 128x128x32 (256x32x16 when narrow); scalar path: BK = 16 tiles
-  const int BM = p.narrow ? CfgNarrow::BM : 128, BN = p.narrow ? CfgNarrow::BN : 128;
+  p.n16 = d->Cout <= 16;
+  // vector path: 128x128x32 (256x32x16 / 256x16x16 when narrow); scalar path: BK = 16 tiles
+  const int BM = p.narrow ? CfgNarrow::BM : 128, BN = p.n16 ? CfgN16::BN : (p.narrow ? CfgNarrow::BN : 128);
   p.bk = (p.vec && !p.narrow) ? CfgMain::BK : 16;
   if (p.fold) {
     const FoldTab f = make_fold(d, g);
@@ -1180,10 +1182,21 @@ WgPlan plan_wgrad(const otgan_conv_desc* d, const Geo& g) {
   p.tiles_n = ceil_div(d->Cout, BN);
   const int nkt = (int)ceil_div_l(p.M, p.bk);
   const int blocks = p.tiles_m * p.tiles_n * p.nz;
-  int want = ceil_div(1024, blocks);
-  if (want < 1) want = 1;
-  if (want > 64) want = 64;
-  if (want > nkt) want = nkt;
+  // Split the pixel (K) dimension so that the grid fills whole "rounds" of resident workgroups
+  // (256 CUs x 2 workgroups of the 128x128x32 tile, x4 of the narrow tile): a 2.25-round grid
+  // runs as long as a 3-round one.  Extra splits only cost slab traffic (weight-sized).
+  const int per_round = 256 * ((p.vec && !p.narrow) ? 2 : 4);
+  int want = 1;
+  double best = -1.0;
+  for (int ns = 1; ns <= 16; ++ns) {
+    if (ns > 1 && nkt / ns < 16) break;
+    const long b = (long)blocks * ns;
+    const double eff = (double)b / (double)(ceil_div_l(b, per_round) * per_round) - 0.004 * (ns - 1);
+    if (eff > best + 1e-9) {
+      best = eff;
+      want = ns;
+    }
+  }
   p.kt_per_split = ceil_div(nkt, want);
   p.nsplit = ceil_div(nkt, p.kt_per_split);
   return p;
@@ -1266,10 +1279,16 @@ void launch_igemm(bool vec_ok, int Ck, int rows, int ncols, bool paired, int ncl
                   const GatherA& ga, const ClassTab& ct, const WeightB& wb, const EpiArgs& e) {
   const int ntiles = paired ? ceil_div(ncols, 64) : ceil_div(ncols, 128);
   if (!paired && ncols <= 32) {
-    dim3 grid(ceil_div(rows, CfgNarrow::BM), 1, ncls);
     if constexpr (EPI != EPI_DG_PAIR) {
-      if (vec_ok && Ck % 16 == 0) launch_igemm3<CfgNarrow, true, EPI, ACT>(grid, s, ga, ct, wb, e);
-      else launch_igemm3<CfgNarrow, false, EPI, ACT>(grid, s, ga, ct, wb, e);
+      if (ncols <= 16) {
+        dim3 grid(ceil_div(rows, CfgN16::BM), 1, ncls);
+        if (vec_ok && Ck % 16 == 0) launch_igemm3<CfgN16, true, EPI, ACT>(grid, s, ga, ct, wb, e);
+        else launch_igemm3<CfgN16, false, EPI, ACT>(grid, s, ga, ct, wb, e);
+      } else {
+        dim3 grid(ceil_div(rows, CfgNarrow::BM), 1, ncls);
+        if (vec_ok && Ck % 16 == 0) launch_igemm3<CfgNarrow, true, EPI, ACT>(grid, s, ga, ct, wb, e);
+        else launch_igemm3<CfgNarrow, false, EPI, ACT>(grid, s, ga, ct, wb, e);
+      }
     }
     return;
   }
@@ -1707,10 +1726,12 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
   {
     ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * (double)p.M * (double)p.slab_elems, 0.0, s);
     if (p.vec) {
-      if (p.narrow) launch_wgrad<CfgNarrow, true>(act, grid, s, ga, ct, a);
+      if (p.n16) launch_wgrad<CfgN16, true>(act, grid, s, ga, ct, a);
+      else if (p.narrow) launch_wgrad<CfgNarrow, true>(act, grid, s, ga, ct, a);
       else launch_wgrad<CfgMain, true>(act, grid, s, ga, ct, a);
     } else {
-      if (p.narrow) launch_wgrad<CfgNarrow, false>(act, grid, s, ga, ct, a);
+      if (p.n16) launch_wgrad<CfgN16, false>(act, grid, s, ga, ct, a);
+      else if (p.narrow) launch_wgrad<CfgNarrow, false>(act, grid, s, ga, ct, a);
       else launch_wgrad<CfgMain16, false>(act, grid, s, ga, ct, a);
     }
   }

@@ -24,12 +24,22 @@
 #pragma once
 #include "common.h"
 
-template <int WM_, int WN_, int MT_, int NT_, int BK_>
+// TS = MFMA tile size: 32 (v_mfma_f32_32x32x2_f32, 16 accumulator registers) or
+// 16 (v_mfma_f32_16x16x4_f32, 4 accumulator registers; for outputs only 16 columns wide).
+template <int WM_, int WN_, int MT_, int NT_, int BK_, int TS_ = 32>
 struct GemmCfg {
-  static constexpr int WM = WM_, WN = WN_, MT = MT_, NT = NT_, BK = BK_;
+  static constexpr int WM = WM_, WN = WN_, MT = MT_, NT = NT_, BK = BK_, TS = TS_;
   static constexpr int THREADS = 64 * WM * WN;
-  static constexpr int BM = WM * MT * 32;
-  static constexpr int BN = WN * NT * 32;
+  static constexpr int BM = WM * MT * TS;
+  static constexpr int BN = WN * NT * TS;
+  static constexpr int ACC = TS == 32 ? 16 : 4;           // accumulator registers per tile
+  static constexpr int KSTEP = TS == 32 ? 2 : 4;          // k consumed per MFMA
+  typedef float acc_t __attribute__((ext_vector_type(TS == 32 ? 16 : 4)));
+  // accumulator register r of lane -> (row, col) inside the TS x TS tile
+  __device__ static __forceinline__ int acc_row(int lane, int r) {
+    return TS == 32 ? (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) : 4 * (lane >> 4) + r;
+  }
+  __device__ static __forceinline__ int acc_col(int lane) { return TS == 32 ? (lane & 31) : (lane & 15); }
 };
 
 // LDS row padding: chosen so that the scattered ds_write_b32 of a k-contiguous loader
@@ -41,15 +51,15 @@ struct KPad {
 
 template <class Cfg, class LA, class LB>
 __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int nkt, float* smem,
-                                              f32x16 (&acc)[Cfg::MT][Cfg::NT]) {
-  constexpr int BK = Cfg::BK, MT = Cfg::MT, NT = Cfg::NT;
+                                              typename Cfg::acc_t (&acc)[Cfg::MT][Cfg::NT]) {
+  constexpr int BK = Cfg::BK, MT = Cfg::MT, NT = Cfg::NT, TS = Cfg::TS, KS = Cfg::KSTEP;
   float* sA = smem;
   float* sB = smem + 2 * LA::FLOATS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
-  const int li = lane & 31, lh = lane >> 5;
-  const int a_off = lh * LA::LD + wm * MT * 32 + li;
-  const int b_off = lh * LB::LD + wn * NT * 32 + li;
+  const int li = lane & (TS - 1), lh = lane / TS;  // row/col inside the tile, k sub-index
+  const int a_off = lh * LA::LD + wm * MT * TS + li;
+  const int b_off = lh * LB::LD + wn * NT * TS + li;
   if (nkt <= 0) return;
   la.load(0);
   lb.load(0);
@@ -68,17 +78,17 @@ __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int nkt, float* sm
     // fragment reads run one k-step ahead of the MFMAs that consume them
     float a[2][MT], b[2][NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[0][mt] = pa[mt * 32];
+    for (int mt = 0; mt < MT; ++mt) a[0][mt] = pa[mt * TS];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[0][nt] = pb[nt * 32];
+    for (int nt = 0; nt < NT; ++nt) b[0][nt] = pb[nt * TS];
 #pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
+    for (int ks = 0; ks < BK / KS; ++ks) {
       const int cb = ks & 1, nb = cb ^ 1;
-      if (ks + 1 < BK / 2) {
+      if (ks + 1 < BK / KS) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[nb][mt] = pa[(2 * ks + 2) * LA::LD + mt * 32];
+        for (int mt = 0; mt < MT; ++mt) a[nb][mt] = pa[(KS * ks + KS) * LA::LD + mt * TS];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nb][nt] = pb[(2 * ks + 2) * LB::LD + nt * 32];
+        for (int nt = 0; nt < NT; ++nt) b[nb][nt] = pb[(KS * ks + KS) * LB::LD + nt * TS];
         // keep the next step's LDS reads ahead of this step's MFMAs (hipcc otherwise sinks
         // them behind the MFMAs and waits lgkmcnt(0) right before the next group)
         __builtin_amdgcn_sched_barrier(0);
@@ -86,8 +96,12 @@ __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int nkt, float* sm
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cb][mt], b[cb][nt], acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) {
+          if constexpr (TS == 32)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cb][mt], b[cb][nt], acc[mt][nt], 0, 0, 0);
+          else
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb][mt], b[cb][nt], acc[mt][nt], 0, 0, 0);
+        }
     }
     if (more) {
       la.store(sA + (cur ^ 1) * LA::FLOATS);
@@ -98,31 +112,30 @@ __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int nkt, float* sm
 }
 
 template <class Cfg>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[Cfg::MT][Cfg::NT]) {
+__device__ __forceinline__ void zero_acc(typename Cfg::acc_t (&acc)[Cfg::MT][Cfg::NT]) {
 #pragma unroll
   for (int mt = 0; mt < Cfg::MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < Cfg::NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+      for (int r = 0; r < Cfg::ACC; ++r) acc[mt][nt][r] = 0.f;
 }
 
 // Visit every accumulator element: f(row_in_block, col_in_block, mt, nt, r, value).
-// For a fixed (mt, nt, r) the 32 lanes of a half-wave cover 32 consecutive columns of one
-// row, so a store of `value` to out[row*ld + col] is a coalesced 128-byte segment.
+// For a fixed (mt, nt, r) the lanes of a (half-)wave cover consecutive columns of one row, so a
+// store of `value` to out[row*ld + col] is coalesced.
 template <class Cfg, class F>
-__device__ __forceinline__ void foreach_acc(const f32x16 (&acc)[Cfg::MT][Cfg::NT], F&& f) {
+__device__ __forceinline__ void foreach_acc(const typename Cfg::acc_t (&acc)[Cfg::MT][Cfg::NT], F&& f) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
-  const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int mt = 0; mt < Cfg::MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < Cfg::NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * Cfg::MT * 32 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int col = wn * Cfg::NT * 32 + nt * 32 + li;
+      for (int r = 0; r < Cfg::ACC; ++r) {
+        const int row = (wm * Cfg::MT + mt) * Cfg::TS + Cfg::acc_row(lane, r);
+        const int col = (wn * Cfg::NT + nt) * Cfg::TS + Cfg::acc_col(lane);
         f(row, col, mt, nt, r, acc[mt][nt][r]);
       }
 }

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void cost_partial_kernel(CostArgs a) {
   LB lb;
   la.init(a.X[p] + (long)tmi * 128 * a.ldf + k0, a.ldf, a.n - tmi * 128, a.D - k0);
   lb.init(a.Y[p] + (long)tni * 128 * a.ldf + k0, a.ldf, a.m - tni * 128, a.D - k0);
-  f32x16 acc[SCfg::MT][SCfg::NT];
+  typename SCfg::acc_t acc[SCfg::MT][SCfg::NT];
   zero_acc<SCfg>(acc);
   gemm_mainloop<SCfg>(la, lb, nkt, smem, acc);
   float* out = a.ws + ((long)split * a.P + p) * a.n * a.m;
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void plan_apply_kernel(ApplyArgs a) {
   const int tmi = blockIdx.x / a.tiles_d, tdi = blockIdx.x % a.tiles_d;
   const int row0 = tmi * 128, d0 = tdi * 128;
   if (row0 >= blk.rows) return;
-  f32x16 acc[SCfg::MT][SCfg::NT];
+  typename SCfg::acc_t acc[SCfg::MT][SCfg::NT];
   zero_acc<SCfg>(acc);
   for (int t = 0; t < blk.nterms; ++t) {
     LA la;

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void gemm_kernel(const float* A, cons
   LA la; LB lb;
   la.init(A + (long)tm * Cfg::BM * K, K, M - tm * Cfg::BM, K);
   lb.init(B + (long)tn * Cfg::BN * K, K, N - tn * Cfg::BN, K);
-  f32x16 acc[Cfg::MT][Cfg::NT];
+  typename Cfg::acc_t acc[Cfg::MT][Cfg::NT];
   zero_acc<Cfg>(acc);
   gemm_mainloop<Cfg>(la, lb, K / Cfg::BK, smem, acc);
   foreach_acc<Cfg>(acc, [&](int r, int c, int, int, int, float v) {
