@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--batch_per_gpu", type=int, default=256)
     ap.add_argument("--nr_sinkhorn_iter", type=int, default=100)
     ap.add_argument("--matching_scope", type=str, default="global")
+    ap.add_argument("--image_size", type=int, default=32)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_prof", action="store_true")
     a = ap.parse_args()
@@ -51,10 +52,11 @@ def main():
     shards_per_rank = 2
     args = default_args(model=a.model, batch_size=a.batch_per_gpu // shards_per_rank,
                         nr_gpu=shards_per_rank * world, nr_sinkhorn_iter=a.nr_sinkhorn_iter,
-                        sinkhorn_lambda=500.0, nr_gen_per_disc=5, matching_scope=a.matching_scope, seed=1)
+                        sinkhorn_lambda=500.0, nr_gen_per_disc=5, matching_scope=a.matching_scope, seed=1,
+                        image_size=a.image_size)
     model = OTGAN(args, dev)
     torch.manual_seed(1 + rank)
-    x = torch.rand(model.nb, 32, 32, 3, device=dev) * 2 - 1     # synthetic CIFAR-shaped batch in [-1,1]
+    x = torch.rand(model.nb, a.image_size, a.image_size, 3, device=dev) * 2 - 1   # synthetic batch in [-1,1]
 
     for _ in range(a.warmup):
         model.step(x)
@@ -89,7 +91,7 @@ def main():
         "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[1]: {a.model.upper()} generator+critic train step, synthetic "
-                               f"CIFAR-10-shaped 32x32x3, {a.batch_per_gpu} img/GPU as 2 logical shards x "
+                               f"CIFAR-10-shaped {a.image_size}x{a.image_size}x3, {a.batch_per_gpu} img/GPU as 2 logical shards x "
                                f"{a.batch_per_gpu // 2} (Sinkhorn rows N={world * a.batch_per_gpu // 2 if a.matching_scope == 'global' else a.batch_per_gpu // 2}), "
                                f"{a.nr_sinkhorn_iter} Sinkhorn iters, lambda 500, 5:1 generator:critic steps, Adam",
                    "global_batch": world * a.batch_per_gpu, "parallelism": f"dp{world}",

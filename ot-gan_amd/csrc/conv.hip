@@ -177,12 +177,16 @@ struct ConvALoader {
         }
         reg[p] = v;
       }
-      nd += BK;
-      if (nd >= g.Ck) {
-        nd = 0;
-        nt += 1;
+      // K order of the vector path: taps run FASTEST, channel slices slowest.  A block then reads
+      // one BK-wide channel slice of its (haloed) pixel patch for all taps back to back, so the
+      // patch slice (pixels x 128 B) stays L1/L2 resident instead of being re-fetched per tap
+      // (tap-major order re-streams pixels x Ck x 4 B per tap and misses L2).
+      nt += 1;
+      if (nt >= taps.n) {
+        nt = 0;
+        nd += BK;
       }
-      if (g.cmap && nt < taps.n) cm_next = g.cmap[nd + 4 * c4];  // consumed one tile later
+      if (g.cmap && nd < g.Ck) cm_next = g.cmap[nd + 4 * c4];  // consumed one tile later
     } else {
       const int k = kt * BK + 4 * c4;
 #pragma unroll
@@ -307,10 +311,10 @@ struct ConvBLoader {
         if (rowoff[p] >= 0) v = *reinterpret_cast<const float4*>(base + rowoff[p]);
         reg[p] = v;
       }
-      nd += BK;
-      if (nd >= b.Ck) {
-        nd = 0;
-        nt += 1;
+      nt += 1;  // taps fastest, channel slices slowest (same order as the A loader)
+      if (nt >= taps.n) {
+        nt = 0;
+        nd += BK;
       }
     } else {
       const int k = kt * BK + 4 * c4;
@@ -442,7 +446,7 @@ struct WgradArgs {
   int so, OHf, OWf;  // dy pixel of row-grid pixel (n,a,b): (n, a*so + oa, b*so + ob)
   float* slab;       // [nsplit][slab_stride]
   int kt_per_split;  // pixel tiles (of BK) per split
-  int tiles_n;
+  int tiles_m, tiles_n;
   long slab_stride;
 };
 
@@ -566,9 +570,12 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_wgrad_kernel(GatherA g, Cla
   using LA = WgALoaderV<Cfg, ACT>;
   using LB = WgBLoaderV<Cfg>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tm = blockIdx.x / a.tiles_n, tn = blockIdx.x % a.tiles_n;
+  // blockIdx.x = tile + ntiles * (class,tap): all taps and tiles of ONE pixel range are
+  // dispatched together, so the concurrently resident blocks share the same x / dy pixels in L2
+  const int ntiles = a.tiles_m * a.tiles_n;
+  const int tile = blockIdx.x % ntiles, z = blockIdx.x / ntiles;
+  const int tm = tile / a.tiles_n, tn = tile % a.tiles_n;
   const int split = blockIdx.y;
-  const int z = blockIdx.z;
   int cls = 0;
 #pragma unroll
   for (int c = 1; c < kMaxClass; ++c)
@@ -1702,6 +1709,7 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
   a.ldy = d->ldy;
   a.Cout = d->Cout;
   a.kt_per_split = p.kt_per_split;
+  a.tiles_m = p.tiles_m;
   a.tiles_n = p.tiles_n;
   a.slab_stride = p.slab_elems;
   FoldTab f;
@@ -1722,7 +1730,7 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
     a.slab = p.nsplit > 1 ? slabs : dw;
   }
   const int act = act_kind(d->preact);
-  dim3 grid(p.tiles_m * p.tiles_n, p.nsplit, p.nz);
+  dim3 grid(p.tiles_m * p.tiles_n * p.nz, p.nsplit, 1);
   {
     ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * (double)p.M * (double)p.slab_elems, 0.0, s);
     if (p.vec) {

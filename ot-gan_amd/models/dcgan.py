@@ -33,13 +33,17 @@ def disc_spec(x, init=False, nonlinearity='crelu', ema=None, **kwargs):
 discriminator = nn.make_template('discriminator', disc_spec)
 
 
-def gen_spec(batch_size, init=False, nonlinearity='crelu', ema=None, noise=None, device=None, **kwargs):
+def gen_spec(batch_size, init=False, nonlinearity='crelu', ema=None, noise=None, device=None,
+             image_size=32, **kwargs):
+    """`image_size` (added; the reference hard-codes 32x32, train.py:52,67): the stem starts at
+    image_size/8 so that the three upsampling stages end at image_size (64 -> BASELINE config 5)."""
+    base = image_size // 8
     if noise is None:
         # models/dcgan.py:30 -- fresh uniform(-1, 1) latent on every call
         noise = torch.rand((batch_size, 100), device=device or 'cuda') * 2.0 - 1.0
     with nn.arg_scope([nn.conv2d, nn.dense], counters={}, init=init, weight_norm=True, ema=ema):
-        x = nn.glu(nn.dense(noise, 2 * 4 * 4 * 1024, pre_activation=None))   # split along axis 1
-        x = x.view(noise.shape[0], 4, 4, 1024)
+        x = nn.glu(nn.dense(noise, 2 * base * base * 1024, pre_activation=None))   # split along axis 1
+        x = x.view(noise.shape[0], base, base, 1024)
         for filters in _GEN:
             # nearest-neighbour x2 (fused into the conv's gather) -> 5x5 conv -> gated linear unit
             x = nn.glu(nn.conv2d(x, filters, filter_size=[5, 5], pre_activation=None, upsample=True))

@@ -79,6 +79,34 @@ def out_hw(H, W, upsample, stride):
     return -(-Hin // stride), -(-Win // stride)
 
 
+# ------------------------------------------------------------------------------- weight cache
+# Normalised (and, for upsampling layers, folded) weights depend only on (V, g); the critic
+# runs two or three forward passes per step on the same parameters.  Entries are keyed by the
+# parameter object and validated by (global epoch, tensor versions): the optimiser / EMA kernels
+# write parameters through raw pointers, so they bump `weights_epoch` explicitly.
+weights_epoch = 0
+_wcache = {}
+_WCACHE_MAX = 512
+
+
+def bump_weights_epoch():
+    global weights_epoch
+    weights_epoch += 1
+
+
+def cached_weights(V, g, compute):
+    key = id(V)
+    token = (weights_epoch, V._version, g._version)
+    hit = _wcache.get(key)
+    if hit is not None and hit[0] is V and hit[1] is g and hit[2] == token:
+        return hit[3]
+    val = compute()
+    if len(_wcache) >= _WCACHE_MAX:
+        _wcache.clear()
+    _wcache[key] = (V, g, token, val)      # holding V keeps id(V) from being reused
+    return val
+
+
 # ------------------------------------------------------------------------------- raw launchers
 def weightnorm_fwd(V2d, g):
     """V2d: [K, Cout] view of the HWIO direction tensor.  Returns (w, wT, inv_norm)."""
@@ -154,22 +182,27 @@ class Conv2dFunction(torch.autograd.Function):
             raise ValueError(f"weight expects {Cin_eff} effective input channels, input gives "
                              f"{C * (2 if preact in DOUBLED else 1)}")
         V2d = V.contiguous().view(KH * KW * Cin_eff, Cout)
-        w, wT, inv_norm = weightnorm_fwd(V2d, g)
         OH, OW = out_hw(H, W, upsample, stride)
         y = torch.empty((N, OH, OW, Cout), dtype=x.dtype, device=x.device)
         desc = make_desc(x, C, upsample, KH, KW, stride, Cout, Cout, 0, preact)
         # with upsample the reference concatenates the list BEFORE the pre-activation
         # (nn.py:235-237), so the doubled ordering is [x_all, -x_all], not per element
         cmap, inv = channel_maps(segs if (segs and not upsample) else (C,), preact, x.device)
-        wd = w                       # operand of dgrad
         nfold = _lib.lib().otgan_conv2d_folded_weight_elems(ctypes.byref(desc))
-        if nfold:
-            # conv o upsample == four parity-class convs with pre-summed taps (otgan_layers.h)
-            wd = torch.empty(nfold, dtype=w.dtype, device=w.device)
-            wT = torch.empty(nfold, dtype=w.dtype, device=w.device)
-            _lib.check(_lib.lib().otgan_conv2d_fold_weights_f32(ctypes.byref(desc), w.data_ptr(),
-                                                                wd.data_ptr(), wT.data_ptr(),
-                                                                _lib.stream_ptr()), "fold_weights")
+
+        def compute():
+            w, wT, inv_norm = weightnorm_fwd(V2d, g)
+            wd = w                       # operand of dgrad
+            if nfold:
+                # conv o upsample == four parity-class convs with pre-summed taps (otgan_layers.h)
+                wd = torch.empty(nfold, dtype=w.dtype, device=w.device)
+                wT = torch.empty(nfold, dtype=w.dtype, device=w.device)
+                _lib.check(_lib.lib().otgan_conv2d_fold_weights_f32(ctypes.byref(desc), w.data_ptr(),
+                                                                    wd.data_ptr(), wT.data_ptr(),
+                                                                    _lib.stream_ptr()), "fold_weights")
+            return wd, wT, inv_norm
+
+        wd, wT, inv_norm = cached_weights(V, g, compute)
         conv_fwd_raw(desc, x, cmap, wT, b, y)
         ctx.save_for_backward(x, V2d, g, wd, inv_norm)
         ctx.desc, ctx.cmap, ctx.inv = desc, cmap, inv
@@ -239,7 +272,7 @@ class DenseBlockFunction(torch.autograd.Function):
             Ck = C0 + k * F
             assert tuple(V.shape) == (ksize, ksize, Ck * mult, F), (V.shape, Ck, mult)
             V2d = V.contiguous().view(-1, F)
-            w, wT, inv_norm = weightnorm_fwd(V2d, g)
+            w, wT, inv_norm = cached_weights(V, g, lambda V2d=V2d, g=g: weightnorm_fwd(V2d, g))
             desc = ConvDesc(N, H, W, Ck, Ctot, 0, ksize, ksize, 1, F, Ctot, Ck, preact)
             cmap, inv = channel_maps(tuple(segs), preact, x0.device)
             conv_fwd_raw(desc, buf, cmap, wT, b, buf)
@@ -366,23 +399,27 @@ feature_head = FeatureHeadFunction.apply
 
 # ------------------------------------------------------------------------------- optimiser steps
 def adam_step(p, grad, v, mg, lr, mom1, mom2, t):
+    bump_weights_epoch()
     _lib.check(_lib.lib().otgan_adam_step_f32(p.data_ptr(), grad.data_ptr(), _lib.ptr(v), mg.data_ptr(),
                                               p.numel(), float(lr), float(mom1), float(mom2),
                                               float(t), _lib.stream_ptr()), "adam_step")
 
 
 def adamax_step(p, grad, v, mg, lr, mom1, mom2):
+    bump_weights_epoch()
     _lib.check(_lib.lib().otgan_adamax_step_f32(p.data_ptr(), grad.data_ptr(), _lib.ptr(v),
                                                 mg.data_ptr(), p.numel(), float(lr), float(mom1),
                                                 float(mom2), _lib.stream_ptr()), "adamax_step")
 
 
 def nesterov_step(p, grad, v, lr, mom1):
+    bump_weights_epoch()
     _lib.check(_lib.lib().otgan_nesterov_step_f32(p.data_ptr(), grad.data_ptr(), v.data_ptr(),
                                                   p.numel(), float(lr), float(mom1),
                                                   _lib.stream_ptr()), "nesterov_step")
 
 
 def ema_update(shadow, p, decay):
+    bump_weights_epoch()
     _lib.check(_lib.lib().otgan_ema_update_f32(shadow.data_ptr(), p.data_ptr(), p.numel(),
                                                float(decay), _lib.stream_ptr()), "ema_update")

@@ -35,6 +35,10 @@ class OTGAN:
         self.discriminator.reset(seed=args.seed, device=device)
         self.model_opts = {"nonlinearity": args.nonlinearity}
         size = getattr(args, "image_size", 32)
+        if size != 32:
+            if args.model != "dcgan":
+                raise ValueError("--image_size other than 32 is only available for --model dcgan")
+            self.model_opts["image_size"] = size
         # parameter creation pass (train.py:52-56; the data-dependent init it builds is never run)
         with torch.no_grad():
             f = self.discriminator(torch.zeros(2, size, size, 3, device=device), init=True, **self.model_opts)
@@ -161,6 +165,8 @@ class OTGAN:
             for t in (self.discriminator, self.generator):
                 for k, v in t.named_variables().items():
                     v.copy_(sd[k].to(v.device))
+        from . import ops
+        ops.bump_weights_epoch()
         self.step_counter = int(sd.get("step_counter", 0))
 
 

@@ -117,3 +117,40 @@ def test_random_and_single_batch_modes_run(dev):
         for _ in range(2):
             r = m.step(x)
             assert torch.isfinite(r["distance"]).item()
+
+
+def test_image_size_64_config5(dev):
+    """BASELINE config 5 shape (64x64 images, D = 131072): outside the reference (its generator is
+    hard-coded to 32x32); the critic is size-agnostic and the generator takes an added
+    image_size option."""
+    from otgan_amd.trainer import OTGAN, default_args
+    args = default_args(model="dcgan", batch_size=2, nr_gpu=2, nr_sinkhorn_iter=5, nr_gen_per_disc=1,
+                        image_size=64)
+    m = OTGAN(args, dev)
+    assert m.num_features == 131072
+    x = torch.rand(m.nb, 64, 64, 3, device=dev) * 2 - 1
+    for _ in range(2):
+        r = m.step(x)
+        assert torch.isfinite(r["distance"]).item()
+    assert m.sample(2).shape == (2, 64, 64, 3)
+
+
+def test_weight_cache_invalidation(dev):
+    """The normalised-weight cache must not survive a parameter update."""
+    from otgan_amd.models import dcgan
+    from otgan_amd import ops
+    dcgan.discriminator.reset(seed=9)
+    x = torch.rand(2, 32, 32, 3, device=dev) * 2 - 1
+    with torch.no_grad():
+        f0 = dcgan.discriminator(x).clone()
+        f1 = dcgan.discriminator(x)
+        assert torch.equal(f0, f1)
+        p = dcgan.discriminator.trainable_variables()[3]          # conv2d_1/V
+        grad = torch.randn_like(p)
+        ops.adam_step(p, grad, torch.zeros_like(p), torch.zeros_like(p), 1e-2, 0.5, 0.999, 1)
+        f2 = dcgan.discriminator(x)
+        assert not torch.equal(f0, f2)
+        p.mul_(1.5)                                              # torch in-place op (version bump)
+        f3 = dcgan.discriminator(x)
+        # weight norm makes the output invariant to the scale of V: equal up to rounding
+        assert float((f3 - f2).norm() / f2.norm()) < 1e-5
