@@ -121,10 +121,10 @@ def main():
         out["kernel_time_frac_of_wall"] = round(sum(v["ms"] for v in prof.values()) / (dt * 1e3), 4)
     if world == 1 and not a.no_cpu_baseline:
         from oracle import train_step_cpu
-        # bounded sample: 2 shards x 4 images, at most 32 host threads (torch's CPU convs
+        # bounded sample: 2 shards x 16 images (~10 s of CPU work), at most 32 host threads (torch's CPU convs
         # degrade badly when oversubscribed: 256 threads took >4 min for this sample)
         torch.set_num_threads(min(32, os.cpu_count() or 1))
-        bps = 4
+        bps = 16
         ips, best, nb = train_step_cpu.time_cpu_steps(batch_per_shard=bps, shards=2, iters=a.nr_sinkhorn_iter,
                                                       model=a.model)
         out["cpu_baseline"] = {"value": round(ips, 3), "unit": "images/sec", "cores": torch.get_num_threads(),
