@@ -43,6 +43,8 @@ def main():
     rank, world, local = parallel.init_from_env()
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if os.environ.get("OTGAN_SINGLE_DEVICE"):   # test mode: all ranks on cuda:0 (with gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.lib()
@@ -73,7 +75,7 @@ def main():
     parallel.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if torch.distributed.get_backend() == "gloo" else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     prof = None

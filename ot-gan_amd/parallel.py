@@ -31,7 +31,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # OTGAN_DIST_BACKEND=gloo lets several ranks share one GPU (tests of the multi-rank
+            # logic on a single-GPU box; RCCL refuses two ranks on one device)
+            backend = os.environ.get("OTGAN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -305,3 +305,23 @@ def test_abi_errors(dev):
         matching.get_matched_features([x, x, x], [x, x, x], 1.0, 1)   # odd shard count (train.py:34)
     with pytest.raises(_lib.OtganError):
         matching.get_matched_features([x.cpu(), x.cpu()], [x.cpu(), x.cpu()], 1.0, 1)  # no CPU fallback
+
+
+def test_reference_default_size_general_path(dev):
+    """The reference's default problem size N = 2500 (8 x 625 / 2, train.py:16,23) is beyond the
+    on-chip kernels (N <= 1024): the multi-launch path must agree with the oracle too."""
+    from otgan_amd.utils import matching
+    rng = np.random.RandomState(8)
+    S, B, D, L = 2, 1300, 96, 6
+    ca, cb = rng.randn(16, D), rng.randn(16, D)
+    fa = np.stack([M.clustered_features(rng, B, D, ca) for _ in range(S)]).astype(np.float32)
+    fb = np.stack([M.clustered_features(rng, B, D, cb) for _ in range(S)]).astype(np.float32)
+    A = [_t(x, dev) for x in fa]
+    Bt = [_t(x, dev) for x in fb]
+    out = matching.get_matched_features(A, Bt, 200.0, L)
+    ref = M.get_matched_features(list(fa), list(fb), 200.0, L)
+    dref = float(M.calc_distance(list(fa), list(fb), ref))
+    assert _rel(torch.stack(out[0]).cpu().numpy(), np.stack(ref[0])) < REL_FEAT
+    assert _rel(torch.stack(out[3]).cpu().numpy(), np.stack(ref[3])) < REL_FEAT
+    assert abs(float(out.distance) - dref) <= REL_LOSS * abs(dref) + 1e-7
+    assert float(out[4]) == pytest.approx(float(ref[4]), rel=2e-4)
