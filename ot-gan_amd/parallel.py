@@ -68,6 +68,32 @@ def all_gather_rows(x):
     return out
 
 
+class PendingGather:
+    """An all-gather in flight (RCCL runs it on its own stream, so it overlaps the compute that
+    is enqueued after the call); `.wait()` returns the gathered [world*n, D] tensor."""
+
+    def __init__(self, out, work):
+        self.out, self.work = out, work
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self.out
+
+
+def all_gather_rows_async(x):
+    w = world_size()
+    if w == 1:
+        return PendingGather(x, None)
+    x = x.contiguous()
+    if _staged() and x.is_cuda:
+        return PendingGather(all_gather_rows(x), None)
+    out = torch.empty((w * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    work = dist.all_gather_into_tensor(out, x, async_op=True)
+    return PendingGather(out, work)
+
+
 def gather_feature_shards(f_local, shards_per_rank):
     """Local features [shards_per_rank*B, D] -> the reference's global shard list of
     `world*shards_per_rank` tensors [B, D]; shard s lives on rank s // shards_per_rank, so the

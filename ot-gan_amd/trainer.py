@@ -58,11 +58,13 @@ class OTGAN:
         self.last = {}
 
     # ---------------------------------------------------------------- matching (train.py:88-98)
-    def _match(self, f_gen, f_dat):
+    def _match(self, f_gen, f_dat, pending_dat=None):
         a = self.args
         if self.scope == "global" and self.world > 1:
+            S = self.world * self.shards
             fa = parallel.gather_feature_shards(f_gen, self.shards)
-            fb = parallel.gather_feature_shards(f_dat, self.shards)
+            fb = (list(torch.chunk(pending_dat.wait(), S, 0)) if pending_dat is not None
+                  else parallel.gather_feature_shards(f_dat, self.shards))
             if not (a.single_batch or a.no_sinkhorn):
                 # The cost matrices are row-sharded like the reference (matching.py:29-39): a rank
                 # of the first half computes its rows of (a1,a2) (a1,b1) (a1,b2), a rank of the
@@ -134,11 +136,15 @@ class OTGAN:
                 self.disc_optimizer(grads, lr=-a.learning_rate_disc)                              # train.py:143
         else:
             kind = "gen"
-            x_gen = self.generator(batch_size=self.nb, device=self.device, **gkw)
             with torch.no_grad():
                 f_dat = self.discriminator(x_data, **self.model_opts)
+            # the real-data features are final here: start their all-gather now, it overlaps the
+            # generator forward and the second critic pass
+            pending = (parallel.all_gather_rows_async(f_dat)
+                       if (self.scope == "global" and self.world > 1) else None)
+            x_gen = self.generator(batch_size=self.nb, device=self.device, **gkw)
             f_gen = self.discriminator(x_gen, **self.model_opts)
-            g_gen, _g_dat, dist, ent = self._match(f_gen.detach(), f_dat)
+            g_gen, _g_dat, dist, ent = self._match(f_gen.detach(), f_dat, pending)
             grads = torch.autograd.grad(f_gen, self.gen_params, g_gen)                            # train.py:112
             grads = parallel.allreduce_sum_(list(grads))
             if apply_updates:

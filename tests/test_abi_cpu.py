@@ -48,3 +48,16 @@ def test_no_cpu_fallback():
     x = torch.zeros(4, 8)
     with pytest.raises(_lib.OtganError):
         matching.get_matched_features([x, x], [x, x], 1.0, 1)
+
+
+def test_operator_argument_errors():
+    """Contract violations of the operator API raise Python exceptions like the reference's
+    (an odd shard count is the reference's `assert args.nr_gpu % 2 == 0`, train.py:34)."""
+    import pytest
+    import torch
+    from otgan_amd.utils import matching
+    with pytest.raises(ValueError):
+        matching.get_matched_features([], [], 1.0, 1)                       # empty lists
+    x = torch.zeros(4, 8)
+    with pytest.raises(ValueError):
+        matching.get_matched_features([x, x], [x], 1.0, 1)                  # list length mismatch
