@@ -21,6 +21,7 @@
 // registers); sign / activation are applied in store(), after the current tile's MFMAs, so
 // the memory latency hides under BK/2 * MT*NT * 64 cycles of matrix work.
 #include "gemm_tile.h"
+#include "dense16.h"
 #include "../../include/otgan.h"
 
 namespace {
@@ -1476,6 +1477,18 @@ int otgan_conv2d_fwd_f32(const otgan_conv_desc* d, const float* x, const int32_t
     else hipLaunchKernelGGL(conv_fewout_kernel<0>, grid, dim3(256), 0, s, ga, ct.taps[0], fa);
     OTGAN_CHECK_LAUNCH("conv2d fwd (few outputs)");
     return OTGAN_OK;
+  }
+  if (d->Cout == 16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->upsample == 0 && d->C % 8 == 0 &&
+      d->ldx % 4 == 0 && aligned16(x) && aligned16(wT) && aligned16(cmap) && dense16_enabled()) {
+    // DenseNet growth layer: LDS-free streaming MFMA kernel (dense16.hip)
+    Dense16Geo dg;
+    dg.N = d->N; dg.H = d->H; dg.W = d->W; dg.logH = ilog2_exact(d->H); dg.logW = ilog2_exact(d->W);
+    dg.C = d->C; dg.Ceff = g.Ceff; dg.doubled = doubled_act(d->preact) ? 1 : 0;
+    dg.act = act_kind(d->preact); dg.ldx = d->ldx; dg.cmap = cmap;
+    ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * ga.Mtot * (double)Ktot * d->Cout, 0.0, s);
+    rc = dense16_fwd(dg, x, wT, bias, y, d->ldy, d->y_coff, s);
+    OTGAN_CHECK_LAUNCH("conv2d fwd (dense16)");
+    return rc;
   }
   wb.ldbn = Ktot;
   e.so = 1;

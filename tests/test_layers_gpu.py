@@ -44,6 +44,14 @@ CONV_CASES = [
     ("dcgan_like_up", 2, 8, 8, (64,), 128, 5, 1, True, None),
     ("ragged_cout", 2, 8, 8, (16,), 40, 3, 1, False, "crelu"),
     ("scalar_cin", 2, 8, 8, (6,), 20, 3, 1, False, "crelu"),
+    # DenseNet growth layers (3x3 -> 16 channels): the LDS-free dense16 kernels
+    ("dense16_list", 2, 8, 8, (32, 16, 16), 16, 3, 1, False, "crelu"),
+    ("dense16_tail", 3, 8, 8, (24, 16), 16, 3, 1, False, "crelu"),
+    ("dense16_plain", 2, 16, 16, (40,), 16, 3, 1, False, None),
+    ("dense16_celu", 2, 8, 8, (16, 8), 16, 3, 1, False, "celu"),
+    ("dense16_relu", 1, 4, 4, (8,), 16, 3, 1, False, "relu"),
+    ("dense16_many_tiles", 130, 32, 32, (16,), 16, 3, 1, False, "crelu"),
+    ("dense16_mid_tiles", 260, 16, 16, (24,), 16, 3, 1, False, "crelu"),
 ]
 
 
