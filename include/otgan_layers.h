@@ -36,6 +36,10 @@ typedef struct otgan_conv_desc {
   int ldy;      /* channel stride of the output buffer */
   int y_coff;   /* channel offset of this layer's output inside the output buffer */
   int preact;   /* OTGAN_ACT_* */
+  int list_quads; /* CRELU/CELU only: 1 = every list element (or C itself for a single tensor)
+                     is a multiple of 4 channels wide, i.e. aligned groups of 4 effective
+                     channels map to 4 consecutive source channels with one sign -> 16-byte
+                     gathers; 0 = arbitrary widths -> per-channel gathers */
 } otgan_conv_desc;
 
 /*

@@ -1081,6 +1081,8 @@ inline int act_kind(int a) {  // 0 none, 1 relu-type, 2 elu-type
 }
 inline int pack_dhw(int dh, int dw) { return (dh << 16) | (dw & 0xffff); }
 
+// 16-byte gathers need aligned quads of effective channels to be contiguous in the source
+inline bool map_quads(const otgan_conv_desc* d) { return !doubled_act(d->preact) || d->list_quads != 0; }
 struct Geo {
   int Hin, Win, OH, OW, pad_t, pad_l, Ceff, logUp;
   bool fold;
@@ -1107,7 +1109,7 @@ int make_geo(const otgan_conv_desc* d, Geo* g) {
                   "spatial sizes must be powers of two (got %dx%d)", g->Hin, g->Win);
   // Upsample folding is used whenever the vectorised gathers apply (deterministic in the
   // descriptor: the caller must then supply folded weights, see otgan_layers.h).
-  g->fold = d->upsample == 1 && d->stride == 1 && g->Ceff % 16 == 0 && d->ldx % 4 == 0 &&
+  g->fold = d->upsample == 1 && d->stride == 1 && map_quads(d) && g->Ceff % 16 == 0 && d->ldx % 4 == 0 &&
             d->Cout % 4 == 0 && d->ldy % 4 == 0 && d->y_coff % 4 == 0 && d->KH >= 2 && d->KW >= 2;
   return OTGAN_OK;
 }
@@ -1144,7 +1146,7 @@ struct WgPlan {
 WgPlan plan_wgrad(const otgan_conv_desc* d, const Geo& g) {
   WgPlan p;
   const int taps = d->KH * d->KW;
-  p.vec = (g.Ceff % 4 == 0) && (d->Cout % 4 == 0) && (d->ldy % 4 == 0) && (d->y_coff % 4 == 0) &&
+  p.vec = map_quads(d) && (g.Ceff % 4 == 0) && (d->Cout % 4 == 0) && (d->ldy % 4 == 0) && (d->y_coff % 4 == 0) &&
           (d->ldx % 4 == 0) && (g.Ceff >= 32);
   p.fold = g.fold && p.vec;
   p.outer = 0;
@@ -1492,7 +1494,7 @@ int otgan_conv2d_fwd_f32(const otgan_conv_desc* d, const float* x, const int32_t
   }
   wb.ldbn = Ktot;
   e.so = 1;
-  vec = (g.Ceff % 16 == 0) && (d->ldx % 4 == 0) && aligned16(x) && aligned16(wT);
+  vec = map_quads(d) && (g.Ceff % 16 == 0) && (d->ldx % 4 == 0) && aligned16(x) && aligned16(wT);
   flops = 2.0 * ga.Mtot * (double)Ktot * d->Cout;
   ProfScope ps(OTGAN_PROF_CONV_FWD, flops, 0.0, s);
   const int act = act_kind(d->preact);

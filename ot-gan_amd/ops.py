@@ -47,9 +47,6 @@ def channel_maps(segs, preact, device):
     hit = _map_cache.get(key)
     if hit is not None:
         return hit
-    if any(s % 4 for s in segs):
-        raise _lib.OtganError("list elements must have a multiple of 4 channels for the "
-                              "vectorised gathers (got %r)" % (segs,))
     C = sum(segs)
     cmap, invp, invn = [], [0] * C, [0] * C
     off = 0
@@ -69,9 +66,10 @@ def channel_maps(segs, preact, device):
     return cm, inv
 
 
-def make_desc(x, C, upsample, kh, kw, stride, cout, ldy, y_coff, preact):
+def make_desc(x, C, upsample, kh, kw, stride, cout, ldy, y_coff, preact, segs=None):
     N, H, W, ldx = x.shape
-    return ConvDesc(N, H, W, C, ldx, 1 if upsample else 0, kh, kw, stride, cout, ldy, y_coff, preact)
+    quads = 1 if all(int(s) % 4 == 0 for s in (segs or (C,))) else 0
+    return ConvDesc(N, H, W, C, ldx, 1 if upsample else 0, kh, kw, stride, cout, ldy, y_coff, preact, quads)
 
 
 def out_hw(H, W, upsample, stride):
@@ -184,7 +182,8 @@ class Conv2dFunction(torch.autograd.Function):
         V2d = V.contiguous().view(KH * KW * Cin_eff, Cout)
         OH, OW = out_hw(H, W, upsample, stride)
         y = torch.empty((N, OH, OW, Cout), dtype=x.dtype, device=x.device)
-        desc = make_desc(x, C, upsample, KH, KW, stride, Cout, Cout, 0, preact)
+        desc = make_desc(x, C, upsample, KH, KW, stride, Cout, Cout, 0, preact,
+                         segs if (segs and not upsample) else None)
         # with upsample the reference concatenates the list BEFORE the pre-activation
         # (nn.py:235-237), so the doubled ordering is [x_all, -x_all], not per element
         cmap, inv = channel_maps(segs if (segs and not upsample) else (C,), preact, x.device)
@@ -273,7 +272,8 @@ class DenseBlockFunction(torch.autograd.Function):
             assert tuple(V.shape) == (ksize, ksize, Ck * mult, F), (V.shape, Ck, mult)
             V2d = V.contiguous().view(-1, F)
             w, wT, inv_norm = cached_weights(V, g, lambda V2d=V2d, g=g: weightnorm_fwd(V2d, g))
-            desc = ConvDesc(N, H, W, Ck, Ctot, 0, ksize, ksize, 1, F, Ctot, Ck, preact)
+            desc = ConvDesc(N, H, W, Ck, Ctot, 0, ksize, ksize, 1, F, Ctot, Ck, preact,
+                            1 if all(s % 4 == 0 for s in segs) else 0)
             cmap, inv = channel_maps(tuple(segs), preact, x0.device)
             conv_fwd_raw(desc, buf, cmap, wT, b, buf)
             saved += [V2d, g, w, inv_norm]

@@ -50,6 +50,10 @@ CONV_CASES = [
     ("dense16_plain", 2, 16, 16, (40,), 16, 3, 1, False, None),
     ("dense16_celu", 2, 8, 8, (16, 8), 16, 3, 1, False, "celu"),
     ("dense16_relu", 1, 4, 4, (8,), 16, 3, 1, False, "relu"),
+    # list elements that are not multiples of 4 channels wide: per-channel gathers
+    ("odd_list_crelu", 2, 8, 8, (22, 8, 6), 32, 3, 1, False, "crelu"),
+    ("odd_single_crelu", 2, 8, 8, (18,), 32, 3, 1, False, "crelu"),
+    ("odd_list_dense16", 2, 8, 8, (22, 10), 16, 3, 1, False, "celu"),
     ("dense16_many_tiles", 130, 32, 32, (16,), 16, 3, 1, False, "crelu"),
     ("dense16_mid_tiles", 260, 16, 16, (24,), 16, 3, 1, False, "crelu"),
 ]
