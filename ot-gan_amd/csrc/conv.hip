@@ -1138,6 +1138,7 @@ struct WgPlan {
   int outer;       // 0 no, 1 few outputs (Cout <= 4), 2 few inputs (Cin_eff <= 4)
   int chunk, nchunks;
   bool vec, fold, narrow, n16;
+  bool dense16;    // DenseNet growth layer: dense16.hip kernel, nsplit slabs
   int bk;
   int tiles_m, tiles_n, nsplit, kt_per_split, nz;
   long slab_elems;  // elements of one slab (= weff elements when folded)
@@ -1146,6 +1147,19 @@ struct WgPlan {
 WgPlan plan_wgrad(const otgan_conv_desc* d, const Geo& g) {
   WgPlan p;
   const int taps = d->KH * d->KW;
+  p.dense16 = false;
+  if (d->Cout == 16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->upsample == 0 && d->C % 4 == 0 &&
+      d->ldx % 4 == 0 && d->ldy % 4 == 0 && d->y_coff % 4 == 0 && dense16_enabled()) {
+    const Dense16Tiling t = dense16_tiling(d->N, d->H, d->W, g.Ceff);
+    if (t.ok) {
+      memset(&p, 0, sizeof(p));
+      p.dense16 = true;
+      p.nsplit = t.nsplit;
+      p.slab_elems = (long)taps * g.Ceff * d->Cout;
+      p.M = (long)d->N * d->H * d->W;
+      return p;
+    }
+  }
   p.vec = map_quads(d) && (g.Ceff % 4 == 0) && (d->Cout % 4 == 0) && (d->ldy % 4 == 0) && (d->y_coff % 4 == 0) &&
           (d->ldx % 4 == 0) && (g.Ceff >= 32);
   p.fold = g.fold && p.vec;
@@ -1679,6 +1693,28 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
   if ((p.nsplit > 1 || p.fold) && (!workspace || workspace_bytes < need)) {
     otgan_set_error("conv2d wgrad workspace too small: need %zu, got %zu", need, workspace_bytes);
     return OTGAN_ERR_WORKSPACE;
+  }
+  if (p.dense16) {
+    OTGAN_CHECK_ARG(aligned16(x) && aligned16(dy) && aligned16(cmap), "operands must be 16-byte aligned");
+    Dense16Geo dg;
+    dg.N = d->N; dg.H = d->H; dg.W = d->W; dg.logH = ilog2_exact(d->H); dg.logW = ilog2_exact(d->W);
+    dg.C = d->C; dg.Ceff = g.Ceff; dg.doubled = doubled_act(d->preact) ? 1 : 0;
+    dg.act = act_kind(d->preact); dg.ldx = d->ldx; dg.cmap = cmap;
+    float* slabs = p.nsplit > 1 ? (float*)workspace : dw;
+    {
+      ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * (double)p.M * (double)p.slab_elems, 0.0, s);
+      rc = dense16_wgrad(dg, x, dy, d->ldy, d->y_coff, slabs, s);
+      if (rc) return rc;
+    }
+    OTGAN_CHECK_LAUNCH("conv2d wgrad (dense16)");
+    if (p.nsplit > 1) {
+      long blocks = ceil_div_l(p.slab_elems, 256);
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)blocks), dim3(256), 0, s, (const float*)slabs, p.nsplit,
+                         p.slab_elems, dw);
+      OTGAN_CHECK_LAUNCH("slab_reduce");
+    }
+    return OTGAN_OK;
   }
   GatherA ga;
   ClassTab ct;

@@ -18,3 +18,20 @@ bool dense16_enabled();
 // y[pix, coff + n] = bias[n] + sum_{tap, e} act(+-x[pix + tap, c(e)]) * wT[n][tap*Ceff + e]
 int dense16_fwd(const Dense16Geo& g, const float* x, const float* wT, const float* bias, float* y,
                 int ldy, int coff, hipStream_t s);
+
+// ---- weight gradient ----------------------------------------------------------------------
+// Tiling shared by the LDS kernels: a block tile is TR full rows (64*PT pixels) of one image.
+struct Dense16Tiling {
+  int ok;        // 0: geometry not supported by the LDS kernels
+  int PT, TR, RS;
+  int tiles;     // N * H / TR
+  int nchunk;    // ceil(Ceff / 32)
+  int nsplit;    // pixel splits of the wgrad grid (slabs)
+  int tiles_per_split;
+};
+// pure function of the geometry (used for the workspace query as well)
+Dense16Tiling dense16_tiling(int N, int H, int W, int Ceff);
+// slab[split][tap][e][n] = sum over the split's pixels of act(+-x[pix + tap, c(e)]) * dy[pix, n]
+// (nsplit slabs of 9*Ceff*16 floats; the caller reduces them)
+int dense16_wgrad(const Dense16Geo& g, const float* x, const float* dy, int ldy, int coff, float* slabs,
+                  hipStream_t s);

@@ -191,6 +191,383 @@ __global__ __launch_bounds__(256) void dense16_fwd_kernel(FwdArgs a) {
     }
 }
 
+
+// =======================================================================================
+// Forward, version 2: haloed spatial tile in LDS.
+//
+// The streaming kernel above re-fetches every activation nine times (once per tap) from L2:
+// at 8 FLOP per fetched byte that path saturates near 57 TFLOP/s.  Here a block owns TR full
+// image rows (64*PT pixels); per 32-channel slice it stages the (TR+2)-row halo tile ONCE
+// (1.25x instead of 9x), with the activation and the CReLU sign applied on the way in, and all
+// nine taps read their MFMA operands from LDS.
+//
+// LDS layout: pixel-major, 40 floats per pixel (32 channels + 8 pad): quad s of a pixel holds
+// channels 4s..4s+3; lane (p, g) reads quads g and g+4 with two ds_read_b128.  Pixel stride
+// 10 quads (2 * odd) plus the one-quad lane-group offset is conflict-free for the hardware's
+// b128 lane grouping (brute-forced over all four groups); stores put the 8 quads of a pixel in
+// 8 consecutive lanes = one 128-byte row of banks.  K permutation: MFMA (h, i) contracts
+// channel 16h + 4g + i in k-slot g, so lane (n, g) takes its weights as the float4s
+// wT[n][tap*Ceff + c0 + 16h + 4g ..] straight from global memory.
+// =======================================================================================
+struct FwdLdsArgs {
+  const float* x;
+  const int32_t* cmap;
+  const float* wT;
+  const float* bias;
+  float* y;
+  int N, H, W, logW, ldx, C, Ceff, doubled, K, ldy, coff;
+  int TR, RS;  // tile rows, LDS row stride in pixels
+};
+
+constexpr int kPixQuads = 10;  // LDS quads (16 B) per pixel
+
+struct QuadMap {
+  int c;
+  float sg;
+  bool valid, contig;
+  int e;
+};
+
+__device__ __forceinline__ QuadMap d16_quad(const FwdLdsArgs& a, int e, i32x4 cm) {
+  QuadMap r;
+  r.valid = e < a.Ceff;
+  r.e = r.valid ? e : 0;
+  if (a.cmap) {
+    r.c = cm.x & 0x7fffffff;
+    r.sg = cm.x < 0 ? -1.f : 1.f;
+    r.contig = cm.y == cm.x + 1 && cm.z == cm.x + 2 && cm.w == cm.x + 3 && (r.c & 3) == 0;
+  } else {
+    const bool neg = a.doubled && r.e >= a.C;
+    r.c = neg ? r.e - a.C : r.e;
+    r.sg = neg ? -1.f : 1.f;
+    r.contig = true;
+  }
+  return r;
+}
+
+template <int PT, int ACT, bool W8>
+__global__ __launch_bounds__(256, 2) void dense16_fwd_lds_kernel(FwdLdsArgs a) {
+  extern __shared__ f32x4 smem4[];
+  constexpr int NITMAX = 2 * PT + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 15, g = lane >> 4;
+  const int tiles_per_img = a.H / a.TR;
+  const int n = blockIdx.x / tiles_per_img;
+  const int r0 = (blockIdx.x - n * tiles_per_img) * a.TR;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const int lds_quads = (a.TR + 2) * a.RS * kPixQuads;
+  for (int i = tid; i < lds_quads; i += 256) smem4[i] = zero;
+
+  // staging: item = (pixel of the (TR+2) x W row band, quad); 8 consecutive lanes = one pixel
+  const int slot = tid & 7;
+  const int total = (a.TR + 2) * a.W * 8;
+  const long img_base = (long)n * a.H * a.W;
+  f32x4 R[NITMAX];
+  auto stage_load = [&](const QuadMap& q) {
+#pragma unroll
+    for (int it = 0; it < NITMAX; ++it) {
+      const int i = it * 256 + tid;
+      const int px = i >> 3;
+      const int row = px >> a.logW, col = px & (a.W - 1);
+      const int ir = r0 - 1 + row;
+      const bool ok = i < total && q.valid && (unsigned)ir < (unsigned)a.H;
+      const float* xp = a.x + (img_base + (long)ir * a.W + col) * a.ldx;
+      if (q.contig) {
+        R[it] = ok ? *reinterpret_cast<const f32x4*>(xp + q.c) : zero;
+      } else {
+        f32x4 v = zero;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int cm = a.cmap[q.e + j];
+          float t = ok ? xp[cm & 0x7fffffff] : 0.f;
+          v[j] = cm < 0 ? -t : t;
+        }
+        R[it] = v;
+      }
+    }
+  };
+  auto stage_store = [&](float sg) {
+#pragma unroll
+    for (int it = 0; it < NITMAX; ++it) {
+      const int i = it * 256 + tid;
+      if (i < total) {
+        const int px = i >> 3;
+        const int row = px >> a.logW, col = px & (a.W - 1);
+        f32x4 v = R[it];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = d16_act<ACT>(v[j] * sg);
+        smem4[(row * a.RS + col + 1) * kPixQuads + slot] = v;
+      }
+    }
+  };
+  auto load_cm = [&](int chunk) {
+    const int e = chunk * 32 + 4 * slot;
+    i32x4 cm = {0, 0, 0, 0};
+    if (a.cmap && e < a.Ceff) cm = *reinterpret_cast<const i32x4*>(a.cmap + e);
+    return cm;
+  };
+
+  // fragment addressing: M-tile = 16 consecutive pixels of the row band
+  int ab[PT];
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    const int q0 = (wave * PT + t) * 16;
+    int rr, cc;
+    if (W8) {
+      rr = (q0 >> 3) + (p >> 3);
+      cc = p & 7;
+    } else {
+      rr = q0 >> a.logW;
+      cc = (q0 & (a.W - 1)) + p;
+    }
+    ab[t] = ((rr + 1) * a.RS + cc + 1) * kPixQuads + g;
+  }
+  f32x4 acc[PT];
+#pragma unroll
+  for (int t = 0; t < PT; ++t) acc[t] = zero;
+
+  const int nchunk = (a.Ceff + 31) >> 5;
+  const float* wlane = a.wT + (long)p * a.K + 4 * g;   // + tap*Ceff + chunk*32 + 16h
+  auto load_w = [&](int chunk, int tap, f32x4 (&Wv)[2]) {
+    const int e0 = chunk * 32 + 4 * g;
+    const float* wp = wlane + (long)tap * a.Ceff + chunk * 32;
+    Wv[0] = (e0 < a.Ceff) ? *reinterpret_cast<const f32x4*>(wp) : zero;
+    Wv[1] = (e0 + 16 < a.Ceff) ? *reinterpret_cast<const f32x4*>(wp + 16) : zero;
+  };
+
+  QuadMap q = d16_quad(a, 4 * slot, load_cm(0));
+  i32x4 cm_next = load_cm(1);
+  stage_load(q);
+  f32x4 Wa[2], Wb[2];
+  load_w(0, 0, Wa);
+  __syncthreads();  // zero fill complete
+  stage_store(q.contig ? q.sg : 1.f);
+  __syncthreads();
+
+  for (int c = 0; c < nchunk; ++c) {
+    const bool more = c + 1 < nchunk;
+    if (more) {
+      q = d16_quad(a, (c + 1) * 32 + 4 * slot, cm_next);
+      cm_next = load_cm(c + 2);
+      stage_load(q);  // lands while the nine taps below run
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      f32x4 (&Wc)[2] = (tap & 1) ? Wb : Wa;
+      f32x4 (&Wn)[2] = (tap & 1) ? Wa : Wb;
+      if (tap < 8) load_w(c, tap + 1, Wn);
+      else if (more) load_w(c + 1, 0, Wn);
+      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+      const int sh = (dy * a.RS + dx) * kPixQuads;
+      f32x4 A[PT][2];
+#pragma unroll
+      for (int t = 0; t < PT; ++t) {
+        A[t][0] = smem4[ab[t] + sh];
+        A[t][1] = smem4[ab[t] + sh + 4];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float w = Wc[j >> 2][j & 3];
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[t][j >> 2][j & 3], w, acc[t], 0, 0, 0);
+      }
+    }
+    if (more) {  // nine taps: the prefetch of (c+1, tap 0) landed in the odd buffer
+      Wa[0] = Wb[0];
+      Wa[1] = Wb[1];
+    }
+    __syncthreads();
+    if (more) {
+      stage_store(q.contig ? q.sg : 1.f);
+      __syncthreads();
+    }
+  }
+  const float b = a.bias ? a.bias[p] : 0.f;
+  const long m0 = (img_base + (long)r0 * a.W);
+#pragma unroll
+  for (int t = 0; t < PT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long m = m0 + (wave * PT + t) * 16 + 4 * g + r;
+      a.y[m * a.ldy + a.coff + p] = acc[t][r] + b;
+    }
+}
+
+// =======================================================================================
+// Weight gradient:  dW[tap][e][n] = sum_q act(x)[q][e] * dy[q - tap][n]
+//
+// MFMA roles: M = 16 effective channels, N = the 16 output channels, K = pixels.  A block owns
+// one 32-channel slice (blockIdx.y) and a range of pixel tiles (blockIdx.x); per tile it stages
+// act(x) (64*PT pixels x 32 channels, no halo) and the dy rows with a one-pixel halo, and every
+// staged activation fragment (one ds_read_b32) feeds nine MFMAs -- one per tap, against the nine
+// shifted dy fragments, which are shared by the two channel tiles: 11 LDS reads per 18 MFMAs.
+// k-slot g of a step holds pixel 4s + {0,2,1,3}[g]: the two pixels read by one 32-lane LDS
+// group are 2 apart, which puts them 16 banks apart for both pixel strides (40 and 24 floats).
+// The four waves take different pixels; their accumulators are summed through LDS and written
+// as one slab per pixel split (deterministic, reduced by the caller).
+// =======================================================================================
+struct WgArgs {
+  const float* x;
+  const int32_t* cmap;
+  const float* dy;
+  float* slabs;
+  int N, H, W, logW, ldx, C, Ceff, doubled, ldy;
+  int TR, RS, tiles, tiles_per_split;
+  long slab_elems;
+};
+
+constexpr int kDyStride = 24;   // floats per pixel of the dy halo tile (16 + 8 pad)
+constexpr int kAStride = 40;    // floats per pixel of the activation tile
+
+template <int PT, int ACT>
+__global__ __launch_bounds__(256, 2) void dense16_wgrad_kernel(WgArgs a) {
+  extern __shared__ f32x4 smem4[];
+  float* sA = reinterpret_cast<float*>(smem4);                       // [64*PT][40]
+  float* sD = sA + 64 * PT * kAStride;                               // [(TR+2)*RS][24]
+  constexpr int NA = 2 * PT;           // float4 staging items per thread: activations
+  constexpr int ND = PT + 2;           // dy halo rows: (64*PT + 2W)*4/256 = PT + W/32 <= PT + 2
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 15, g = lane >> 4;
+  const int chunk = blockIdx.y;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const int t_begin = blockIdx.x * a.tiles_per_split;
+  const int t_end = min(t_begin + a.tiles_per_split, a.tiles);
+  const int tiles_per_img = a.H / a.TR;
+
+  // zero the dy tile once: halo columns and out-of-image rows stay zero
+  const int dquads = (a.TR + 2) * a.RS * (kDyStride / 4);
+  for (int i = tid; i < dquads; i += 256) reinterpret_cast<f32x4*>(sD)[i] = zero;
+
+  const int slot = tid & 7;
+  FwdLdsArgs fa;   // only the fields d16_quad reads
+  fa.cmap = a.cmap; fa.C = a.C; fa.Ceff = a.Ceff; fa.doubled = a.doubled;
+  i32x4 cm = {0, 0, 0, 0};
+  {
+    const int e = chunk * 32 + 4 * slot;
+    if (a.cmap && e < a.Ceff) cm = *reinterpret_cast<const i32x4*>(a.cmap + e);
+  }
+  const QuadMap q = d16_quad(fa, chunk * 32 + 4 * slot, cm);
+  const float sg = q.contig ? q.sg : 1.f;
+
+  f32x4 RA[NA], RD[ND];
+  const int dtotal = (a.TR + 2) * a.W * 4;
+  auto stage_load = [&](int tile) {
+    const int n = tile / tiles_per_img;
+    const int r0 = (tile - n * tiles_per_img) * a.TR;
+    const long img_base = (long)n * a.H * a.W;
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const int i = it * 256 + tid;
+      const int px = i >> 3;                       // < 64*PT
+      const float* xp = a.x + (img_base + (long)r0 * a.W + px) * a.ldx;
+      if (q.contig) {
+        RA[it] = q.valid ? *reinterpret_cast<const f32x4*>(xp + q.c) : zero;
+      } else {
+        f32x4 v = zero;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int cmj = a.cmap[q.e + j];
+          const float t = q.valid ? xp[cmj & 0x7fffffff] : 0.f;
+          v[j] = cmj < 0 ? -t : t;
+        }
+        RA[it] = v;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < ND; ++it) {
+      const int i = it * 256 + tid;
+      const int px = i >> 2;
+      const int row = px >> a.logW, col = px & (a.W - 1);
+      const int ir = r0 - 1 + row;
+      const bool ok = i < dtotal && (unsigned)ir < (unsigned)a.H;
+      RD[it] = ok ? *reinterpret_cast<const f32x4*>(a.dy + (img_base + (long)ir * a.W + col) * a.ldy + 4 * (i & 3))
+                  : zero;
+    }
+  };
+  auto stage_store = [&]() {
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const int i = it * 256 + tid;
+      f32x4 v = RA[it];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = d16_act<ACT>(v[j] * sg);
+      *reinterpret_cast<f32x4*>(sA + (i >> 3) * kAStride + 4 * slot) = v;
+    }
+#pragma unroll
+    for (int it = 0; it < ND; ++it) {
+      const int i = it * 256 + tid;
+      if (i < dtotal) {
+        const int px = i >> 2;
+        const int row = px >> a.logW, col = px & (a.W - 1);
+        *reinterpret_cast<f32x4*>(sD + (row * a.RS + col + 1) * kDyStride + 4 * (i & 3)) = RD[it];
+      }
+    }
+  };
+
+  f32x4 acc[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    acc[t][0] = zero;
+    acc[t][1] = zero;
+  }
+
+  if (t_begin < t_end) stage_load(t_begin);
+  __syncthreads();
+  if (t_begin < t_end) stage_store();
+  __syncthreads();
+  const int perm = ((g & 1) << 1) | (g >> 1);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const bool more = tile + 1 < t_end;
+    if (more) stage_load(tile + 1);
+#pragma unroll 2
+    for (int s = 0; s < 4 * PT; ++s) {
+      const int qq = (wave * 4 * PT + s) * 4 + perm;          // tile pixel of this k-slot
+      const int row = qq >> a.logW, col = qq & (a.W - 1);
+      const float a0 = sA[qq * kAStride + p];
+      const float a1 = sA[qq * kAStride + 16 + p];
+      const float* dp = sD + ((row + 1) * a.RS + col + 1) * kDyStride + p;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy_ = tap / 3 - 1, dx_ = tap % 3 - 1;
+        const float b = dp[-(dy_ * a.RS + dx_) * kDyStride];
+        acc[tap][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[tap][0], 0, 0, 0);
+        acc[tap][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[tap][1], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (more) {
+      stage_store();
+      __syncthreads();
+    }
+  }
+  // sum the four waves' accumulators through LDS: [tap][mt][lane] float4
+  f32x4* red = smem4;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int idx = (t * 2 + mt) * 64 + lane;
+          red[idx] = (w == 0) ? acc[t][mt] : red[idx] + acc[t][mt];
+        }
+    }
+    __syncthreads();
+  }
+  // D[m = 4g + r][n = p]  ->  slab[tap][chunk*32 + 16mt + m][n]; thread = (e_local, n): coalesced
+  float* slab = a.slabs + (long)blockIdx.x * a.slab_elems;
+  const float* redf = reinterpret_cast<const float*>(red);
+  const int n_out = tid & 15, el = tid >> 4;
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    const int tap = i >> 1, mt = i & 1;
+    const int e = chunk * 32 + 16 * mt + el;
+    const int src_lane = (el >> 2) * 16 + n_out;
+    if (e < a.Ceff) slab[((long)tap * a.Ceff + e) * 16 + n_out] = redf[(i * 64 + src_lane) * 4 + (el & 3)];
+  }
+}
+
 template <int PT>
 void launch_fwd_pt(const FwdArgs& a, int act, bool sgn, int blocks, hipStream_t s) {
   const dim3 grid(blocks), blk(256);
@@ -226,11 +603,107 @@ int dense16_fwd(const Dense16Geo& g, const float* x, const float* wT, const floa
   a.H = g.H; a.W = g.W; a.logW = ilog2i(g.W);
   a.ldx = g.ldx; a.C = g.C; a.Ceff = g.Ceff; a.doubled = g.doubled;
   a.K = 9 * g.Ceff; a.ldy = ldy; a.coff = coff;
+  static const bool v1_only = [] {
+    const char* e = getenv("OTGAN_DENSE16_V1");
+    return e && e[0] == '1';
+  }();
+  if (!v1_only && g.W >= 8 && g.W <= 64 && g.H * g.W >= 64) {
+    // haloed LDS tile: block = TR full rows = 64*PT pixels of one image
+    int PT = g.H * g.W >= 256 ? 4 : g.H * g.W / 64;
+    while (PT > 1 && (long)g.N * g.H * g.W / (64 * PT) < 512) PT >>= 1;
+    FwdLdsArgs l;
+    l.x = x; l.cmap = g.cmap; l.wT = wT; l.bias = bias; l.y = y;
+    l.N = g.N; l.H = g.H; l.W = g.W; l.logW = ilog2i(g.W); l.ldx = g.ldx; l.C = g.C; l.Ceff = g.Ceff;
+    l.doubled = g.doubled; l.K = 9 * g.Ceff; l.ldy = ldy; l.coff = coff;
+    l.TR = 64 * PT / g.W;
+    l.RS = g.W == 8 ? 16 : g.W + 2;
+    if (l.TR >= 1 && g.H % l.TR == 0) {
+      const size_t lds = (size_t)(l.TR + 2) * l.RS * kPixQuads * 16;
+      const dim3 grid(g.N * (g.H / l.TR)), blk(256);
+      const bool w8 = g.W == 8;
+#define D16_LAUNCH(PT_, ACT_)                                                                       \
+  do {                                                                                              \
+    if (w8) hipLaunchKernelGGL((dense16_fwd_lds_kernel<PT_, ACT_, true>), grid, blk, lds, s, l);    \
+    else hipLaunchKernelGGL((dense16_fwd_lds_kernel<PT_, ACT_, false>), grid, blk, lds, s, l);      \
+  } while (0)
+#define D16_LAUNCH_ACT(PT_)                       \
+  do {                                            \
+    if (g.act == 1) D16_LAUNCH(PT_, 1);           \
+    else if (g.act == 2) D16_LAUNCH(PT_, 2);      \
+    else D16_LAUNCH(PT_, 0);                      \
+  } while (0)
+      if (PT == 4) D16_LAUNCH_ACT(4);
+      else if (PT == 2) D16_LAUNCH_ACT(2);
+      else D16_LAUNCH_ACT(1);
+#undef D16_LAUNCH_ACT
+#undef D16_LAUNCH
+      return OTGAN_OK;
+    }
+  }
   const int tiles = (a.M + 15) / 16;
   const bool sgn = g.doubled || g.cmap != nullptr;
   // enough waves to fill 256 CUs x 4 SIMDs a few times over; fewer, fatter waves when there are plenty
   if (tiles >= 8192) launch_fwd_pt<4>(a, g.act, sgn, (tiles + 15) / 16, s);
   else if (tiles >= 4096) launch_fwd_pt<2>(a, g.act, sgn, (tiles + 7) / 8, s);
   else launch_fwd_pt<1>(a, g.act, sgn, (tiles + 3) / 4, s);
+  return OTGAN_OK;
+}
+
+Dense16Tiling dense16_tiling(int N, int H, int W, int Ceff) {
+  Dense16Tiling t;
+  memset(&t, 0, sizeof(t));
+  if (!(W >= 8 && W <= 64 && H * W >= 64)) return t;
+  int PT = H * W >= 256 ? 4 : H * W / 64;
+  while (PT > 1 && (long)N * H * W / (64 * PT) < 512) PT >>= 1;
+  t.PT = PT;
+  t.TR = 64 * PT / W;
+  if (t.TR < 1 || H % t.TR) return t;
+  t.RS = W == 8 ? 16 : W + 2;
+  t.tiles = N * (H / t.TR);
+  t.nchunk = (Ceff + 31) / 32;
+  int want = (1536 + t.nchunk - 1) / t.nchunk;
+  if (want > t.tiles) want = t.tiles;
+  if (want < 1) want = 1;
+  t.tiles_per_split = (t.tiles + want - 1) / want;
+  t.nsplit = (t.tiles + t.tiles_per_split - 1) / t.tiles_per_split;
+  t.ok = 1;
+  return t;
+}
+
+int dense16_wgrad(const Dense16Geo& g, const float* x, const float* dy, int ldy, int coff, float* slabs,
+                  hipStream_t s) {
+  const Dense16Tiling t = dense16_tiling(g.N, g.H, g.W, g.Ceff);
+  if (!t.ok) {
+    otgan_set_error("dense16 wgrad: unsupported geometry");
+    return OTGAN_ERR_UNSUPPORTED;
+  }
+  WgArgs a;
+  a.x = x; a.cmap = g.cmap; a.dy = dy + coff; a.slabs = slabs;
+  a.N = g.N; a.H = g.H; a.W = g.W; a.logW = ilog2i(g.W); a.ldx = g.ldx; a.C = g.C; a.Ceff = g.Ceff;
+  a.doubled = g.doubled; a.ldy = ldy;
+  a.TR = t.TR; a.RS = t.RS; a.tiles = t.tiles; a.tiles_per_split = t.tiles_per_split;
+  a.slab_elems = (long)9 * g.Ceff * 16;
+  size_t lds = ((size_t)64 * t.PT * kAStride + (size_t)(t.TR + 2) * t.RS * kDyStride) * 4;
+  if (lds < 18 * 64 * 16) lds = 18 * 64 * 16;   // wave-reduction scratch
+  const dim3 grid(t.nsplit, t.nchunk), blk(256);
+#define D16_WG(PT_)                                                                             \
+  do {                                                                                          \
+    if (g.act == 1) hipLaunchKernelGGL((dense16_wgrad_kernel<PT_, 1>), grid, blk, lds, s, a);   \
+    else if (g.act == 2) hipLaunchKernelGGL((dense16_wgrad_kernel<PT_, 2>), grid, blk, lds, s, a); \
+    else hipLaunchKernelGGL((dense16_wgrad_kernel<PT_, 0>), grid, blk, lds, s, a);              \
+  } while (0)
+  if (t.PT == 4) {
+    // 72.6 KB of LDS: above the 64 KB default of dynamic shared memory
+    static const bool once = [] {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&dense16_wgrad_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&dense16_wgrad_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&dense16_wgrad_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      return true;
+    }();
+    (void)once;
+    D16_WG(4);
+  } else if (t.PT == 2) D16_WG(2);
+  else D16_WG(1);
+#undef D16_WG
   return OTGAN_OK;
 }
