@@ -1582,6 +1582,19 @@ int otgan_conv2d_dgrad_f32(const otgan_conv_desc* d, const float* dy, const floa
     OTGAN_CHECK_LAUNCH("conv2d dgrad (few inputs)");
     return OTGAN_OK;
   }
+  if (d->Cout == 16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->upsample == 0 && d->ldy % 4 == 0 &&
+      d->y_coff % 4 == 0 && d->C % 4 == 0 && d->ldx % 4 == 0 && lddx % 4 == 0 && aligned16(dy) && aligned16(w) &&
+      aligned16(x) && aligned16(dx) && dense16_enabled() && dense16_tiling(d->N, d->H, d->W, g.Ceff).ok) {
+    // DenseNet growth layer: dy tile in LDS, weights streamed, pos/neg halves combined in registers
+    Dense16Geo dg;
+    dg.N = d->N; dg.H = d->H; dg.W = d->W; dg.logH = ilog2_exact(d->H); dg.logW = ilog2_exact(d->W);
+    dg.C = d->C; dg.Ceff = g.Ceff; dg.doubled = paired ? 1 : 0;
+    dg.act = kind; dg.ldx = d->ldx; dg.cmap = nullptr;
+    ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * (double)d->N * d->H * d->W * 9.0 * d->Cout * g.Ceff, 0.0, s);
+    rc = dense16_dgrad(dg, dy, d->ldy, d->y_coff, w, x, inv, dx, lddx, accumulate, s);
+    OTGAN_CHECK_LAUNCH("conv2d dgrad (dense16)");
+    return rc;
+  }
   if (g.fold) {
     // gradient w.r.t. the SMALL input directly: rows = small pixels, K = all 4 classes'
     // folded taps; dy is read at (2(a - dh) + ph, 2(b - dw) + pw); w = weff.

@@ -35,3 +35,9 @@ Dense16Tiling dense16_tiling(int N, int H, int W, int Ceff);
 // (nsplit slabs of 9*Ceff*16 floats; the caller reduces them)
 int dense16_wgrad(const Dense16Geo& g, const float* x, const float* dy, int ldy, int coff, float* slabs,
                   hipStream_t s);
+
+// ---- input gradient -----------------------------------------------------------------------
+// dx[q, c] (+)= act'(x[q,c]) * G+[q,c] - act'(-x[q,c]) * G-[q,c],
+// G+-[q, c] = sum_{tap, n} dy[q - tap, n] * w[tap][e+-(c)][n]   (w: HWIO, e+- from `inv` or c, C + c)
+int dense16_dgrad(const Dense16Geo& g, const float* dy, int ldy, int coff, const float* w, const float* x,
+                  const int32_t* inv, float* dx, int lddx, int accumulate, hipStream_t s);

@@ -568,6 +568,147 @@ __global__ __launch_bounds__(256, 2) void dense16_wgrad_kernel(WgArgs a) {
   }
 }
 
+// =======================================================================================
+// Input gradient.  MFMA roles: M = 16 pixels, N = 16 SOURCE channels, K = 9 taps x 16 output
+// channels.  The dy rows of the block's pixel tile (one-pixel halo) are staged in LDS once;
+// there is no K loop over global memory and no barrier after the staging.  Per source-channel
+// tile the lanes fetch the positive and the negative weight rows of "their" channel (64-byte
+// rows of the HWIO tensor: lanes 0-15 x 4 groups = 1 KB contiguous when the rows are
+// consecutive), contract them against the nine dy fragments (one ds_read_b128 per tap), and
+// combine both halves with the activation derivative in registers before the single
+// read-modify-write of the gradient buffer.
+// =======================================================================================
+struct DgArgs {
+  const float* dy;
+  const float* w;
+  const float* x;
+  const int32_t* inv;
+  float* dx;
+  int N, H, W, logW, ldx, lddx, C, Ceff, ldy, accumulate;
+  int TR, RS, csplit;
+};
+
+__device__ __forceinline__ float d16_deriv(int act, float v) {
+  if (act == 1) return v > 0.f ? 1.f : 0.f;
+  if (act == 2) return v > 0.f ? 1.f : expf(v);
+  return 1.f;
+}
+
+template <int PT, int ACT, bool PAIRED, bool W8>
+__global__ __launch_bounds__(256, 2) void dense16_dgrad_kernel(DgArgs a) {
+  extern __shared__ f32x4 smem4[];
+  float* sD = reinterpret_cast<float*>(smem4);   // [(TR+2)*RS][24]
+  constexpr int ND = PT + 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 15, g = lane >> 4;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const int tiles_per_img = a.H / a.TR;
+  const int n = blockIdx.x / tiles_per_img;
+  const int r0 = (blockIdx.x - n * tiles_per_img) * a.TR;
+  const long img_base = (long)n * a.H * a.W;
+
+  const int dquads = (a.TR + 2) * a.RS * (kDyStride / 4);
+  for (int i = tid; i < dquads; i += 256) smem4[i] = zero;
+  __syncthreads();
+  const int dtotal = (a.TR + 2) * a.W * 4;
+#pragma unroll
+  for (int it = 0; it < ND; ++it) {
+    const int i = it * 256 + tid;
+    const int px = i >> 2;
+    const int row = px >> a.logW, col = px & (a.W - 1);
+    const int ir = r0 - 1 + row;
+    if (i < dtotal && (unsigned)ir < (unsigned)a.H)
+      *reinterpret_cast<f32x4*>(sD + (row * a.RS + col + 1) * kDyStride + 4 * (i & 3)) =
+          *reinterpret_cast<const f32x4*>(a.dy + (img_base + (long)ir * a.W + col) * a.ldy + 4 * (i & 3));
+  }
+  __syncthreads();
+
+  // fragment base of an M-tile: dy[q - tap][4g ..]
+  auto frag_base = [&](int t) {
+    const int q0 = (wave * PT + t) * 16;
+    int rr, cc;
+    if (W8) {
+      rr = (q0 >> 3) + (p >> 3);
+      cc = p & 7;
+    } else {
+      rr = q0 >> a.logW;
+      cc = (q0 & (a.W - 1)) + p;
+    }
+    return ((rr + 1) * a.RS + cc + 1) * kDyStride + 4 * g;
+  };
+
+  const int nct = (a.C + 15) >> 4;
+  const int per = (nct + a.csplit - 1) / a.csplit;
+  const int ct_begin = blockIdx.y * per;
+  const int ct_end = min(ct_begin + per, nct);
+  const long tapstride = (long)a.Ceff * 16;
+
+  auto load_w = [&](int ct, f32x4 (&Wp)[9], f32x4 (&Wn)[9]) {
+    const int c = ct * 16 + p;
+    const bool ok = c < a.C;
+    const int cc = ok ? c : 0;
+    const int ep = a.inv ? a.inv[cc] : cc;
+    const float* wp = a.w + (long)ep * 16 + 4 * g;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) Wp[tap] = ok ? *reinterpret_cast<const f32x4*>(wp + tap * tapstride) : zero;
+    if (PAIRED) {
+      const int en = a.inv ? a.inv[a.C + cc] : a.C + cc;
+      const float* wn = a.w + (long)en * 16 + 4 * g;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) Wn[tap] = ok ? *reinterpret_cast<const f32x4*>(wn + tap * tapstride) : zero;
+    }
+  };
+
+  f32x4 Wp0[9], Wn0[9], Wp1[9], Wn1[9];
+  if (ct_begin < ct_end) load_w(ct_begin, Wp0, Wn0);
+  // MFMA roles are swapped (weights as the row operand): D[m = channel 4g + r][n = pixel p], so a
+  // lane ends up with FOUR CONSECUTIVE channels of one pixel -- 16-byte x / dx accesses.
+  auto body = [&](int ct, const f32x4 (&Wp)[9], const f32x4 (&Wn)[9]) {
+    const int c4 = ct * 16 + 4 * g;
+    const bool cok = c4 < a.C;
+#pragma unroll 1
+    for (int t = 0; t < PT; ++t) {
+      f32x4 gp = zero, gn = zero;
+      const int abt = frag_base(t);
+      const long m = img_base + (long)r0 * a.W + (wave * PT + t) * 16 + p;
+      // issue the epilogue's loads first: they land while the 36 / 72 MFMAs run
+      f32x4 xv = zero, old = zero;
+      if ((ACT != 0 || PAIRED) && cok) xv = *reinterpret_cast<const f32x4*>(a.x + m * a.ldx + c4);
+      float* dst = a.dx + m * a.lddx + c4;
+      if (a.accumulate && cok) old = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy_ = tap / 3 - 1, dx_ = tap % 3 - 1;
+        const f32x4 A = *reinterpret_cast<const f32x4*>(sD + abt - (dy_ * a.RS + dx_) * kDyStride);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          gp = __builtin_amdgcn_mfma_f32_16x16x4f32(Wp[tap][i], A[i], gp, 0, 0, 0);
+          if (PAIRED) gn = __builtin_amdgcn_mfma_f32_16x16x4f32(Wn[tap][i], A[i], gn, 0, 0, 0);
+        }
+      }
+      if (cok) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float t_ = gp[r];
+          if (ACT != 0 || PAIRED) {
+            t_ = d16_deriv(ACT, xv[r]) * gp[r];
+            if (PAIRED) t_ -= d16_deriv(ACT, -xv[r]) * gn[r];
+          }
+          v[r] = old[r] + t_;
+        }
+        *reinterpret_cast<f32x4*>(dst) = v;
+      }
+    }
+  };
+  for (int ct = ct_begin; ct < ct_end; ct += 2) {
+    if (ct + 1 < ct_end) load_w(ct + 1, Wp1, Wn1);
+    body(ct, Wp0, Wn0);
+    if (ct + 2 < ct_end) load_w(ct + 2, Wp0, Wn0);
+    if (ct + 1 < ct_end) body(ct + 1, Wp1, Wn1);
+  }
+}
+
 template <int PT>
 void launch_fwd_pt(const FwdArgs& a, int act, bool sgn, int blocks, hipStream_t s) {
   const dim3 grid(blocks), blk(256);
@@ -705,5 +846,47 @@ int dense16_wgrad(const Dense16Geo& g, const float* x, const float* dy, int ldy,
   } else if (t.PT == 2) D16_WG(2);
   else D16_WG(1);
 #undef D16_WG
+  return OTGAN_OK;
+}
+
+int dense16_dgrad(const Dense16Geo& g, const float* dy, int ldy, int coff, const float* w, const float* x,
+                  const int32_t* inv, float* dx, int lddx, int accumulate, hipStream_t s) {
+  const Dense16Tiling t = dense16_tiling(g.N, g.H, g.W, g.Ceff);
+  if (!t.ok) {
+    otgan_set_error("dense16 dgrad: unsupported geometry");
+    return OTGAN_ERR_UNSUPPORTED;
+  }
+  DgArgs a;
+  a.dy = dy + coff; a.w = w; a.x = x; a.inv = inv; a.dx = dx;
+  a.N = g.N; a.H = g.H; a.W = g.W; a.logW = ilog2i(g.W); a.ldx = g.ldx; a.lddx = lddx; a.C = g.C;
+  a.Ceff = g.Ceff; a.ldy = ldy; a.accumulate = accumulate;
+  a.TR = t.TR; a.RS = t.RS;
+  const int nct = (g.C + 15) / 16;
+  int cs = (1024 + t.tiles - 1) / t.tiles;      // spread channel tiles over blockIdx.y on small grids
+  if (cs > nct) cs = nct;
+  if (cs < 1) cs = 1;
+  a.csplit = cs;
+  const size_t lds = (size_t)(t.TR + 2) * t.RS * kDyStride * 4;
+  const dim3 grid(t.tiles, cs), blk(256);
+  const bool w8 = g.W == 8;
+#define D16_DG3(PT_, ACT_, PAIR_)                                                                       \
+  do {                                                                                                  \
+    if (w8) hipLaunchKernelGGL((dense16_dgrad_kernel<PT_, ACT_, PAIR_, true>), grid, blk, lds, s, a);   \
+    else hipLaunchKernelGGL((dense16_dgrad_kernel<PT_, ACT_, PAIR_, false>), grid, blk, lds, s, a);     \
+  } while (0)
+#define D16_DG(PT_)                                                   \
+  do {                                                                \
+    if (g.doubled) {                                                  \
+      if (g.act == 2) D16_DG3(PT_, 2, true);                          \
+      else D16_DG3(PT_, 1, true);                                     \
+    } else if (g.act == 1) D16_DG3(PT_, 1, false);                    \
+    else if (g.act == 2) D16_DG3(PT_, 2, false);                      \
+    else D16_DG3(PT_, 0, false);                                      \
+  } while (0)
+  if (t.PT == 4) D16_DG(4);
+  else if (t.PT == 2) D16_DG(2);
+  else D16_DG(1);
+#undef D16_DG
+#undef D16_DG3
   return OTGAN_OK;
 }
