@@ -82,19 +82,29 @@ def out_hw(H, W, upsample, stride):
 # runs two or three forward passes per step on the same parameters.  Entries are keyed by the
 # parameter object and validated by (global epoch, tensor versions): the optimiser / EMA kernels
 # write parameters through raw pointers, so they bump `weights_epoch` explicitly.
-weights_epoch = 0
+weights_epoch = 0          # global: bumped when anything may have changed (checkpoint load, tests)
+_storage_epoch = {}        # per storage: bumped by the optimiser / EMA kernels that write into it
 _wcache = {}
 _WCACHE_MAX = 512
 
 
-def bump_weights_epoch():
+def bump_weights_epoch(t=None):
+    """Invalidate cached normalised weights: of the storage `t` lives in, or (no argument) all."""
     global weights_epoch
-    weights_epoch += 1
+    if t is None:
+        weights_epoch += 1
+    else:
+        key = t.untyped_storage().data_ptr()
+        _storage_epoch[key] = _storage_epoch.get(key, 0) + 1
+
+
+def _epoch_of(t):
+    return _storage_epoch.get(t.untyped_storage().data_ptr(), 0)
 
 
 def cached_weights(V, g, compute):
     key = id(V)
-    token = (weights_epoch, V._version, g._version)
+    token = (weights_epoch, _epoch_of(V), _epoch_of(g), V._version, g._version)
     hit = _wcache.get(key)
     if hit is not None and hit[0] is V and hit[1] is g and hit[2] == token:
         return hit[3]
@@ -303,10 +313,16 @@ class DenseBlockFunction(torch.autograd.Function):
                 dw = torch.empty_like(V2d)
                 conv_wgrad_raw(desc, buf, cmap, G, dw)
                 dV2d, dg = weightnorm_bwd(V2d, g, inv_norm, dw)
-                db = colsum(G.data_ptr() + 4 * Ck, rows, F, Ctot, G.device)
-                grads[3 * k:3 * k + 3] = [dV2d.view(ctx.vshapes[k]), dg, db]
+                grads[3 * k:3 * k + 2] = [dV2d.view(ctx.vshapes[k]), dg]
             # d/d(inputs of layer k) accumulates into the first Ck channels of G
             conv_dgrad_raw(desc, G, w, buf, inv, G, Ctot, True)
+        if need_w:
+            # Layer k's output gradient G[..., Ck:Ck+F] is final once the layers after it have been
+            # processed, and no earlier layer writes there: all L bias gradients are the column sums
+            # of the finished G -- one reduction instead of L.
+            db_all = colsum(G.data_ptr() + 4 * C0, rows, L * F, Ctot, G.device)
+            for k in range(L):
+                grads[3 * k + 2] = db_all[k * F:(k + 1) * F]
         dx0 = G[..., :C0].contiguous() if ctx.needs_input_grad[0] else None
         return (dx0, None, None, None, *grads)
 
@@ -399,27 +415,27 @@ feature_head = FeatureHeadFunction.apply
 
 # ------------------------------------------------------------------------------- optimiser steps
 def adam_step(p, grad, v, mg, lr, mom1, mom2, t):
-    bump_weights_epoch()
+    bump_weights_epoch(p)
     _lib.check(_lib.lib().otgan_adam_step_f32(p.data_ptr(), grad.data_ptr(), _lib.ptr(v), mg.data_ptr(),
                                               p.numel(), float(lr), float(mom1), float(mom2),
                                               float(t), _lib.stream_ptr()), "adam_step")
 
 
 def adamax_step(p, grad, v, mg, lr, mom1, mom2):
-    bump_weights_epoch()
+    bump_weights_epoch(p)
     _lib.check(_lib.lib().otgan_adamax_step_f32(p.data_ptr(), grad.data_ptr(), _lib.ptr(v),
                                                 mg.data_ptr(), p.numel(), float(lr), float(mom1),
                                                 float(mom2), _lib.stream_ptr()), "adamax_step")
 
 
 def nesterov_step(p, grad, v, lr, mom1):
-    bump_weights_epoch()
+    bump_weights_epoch(p)
     _lib.check(_lib.lib().otgan_nesterov_step_f32(p.data_ptr(), grad.data_ptr(), v.data_ptr(),
                                                   p.numel(), float(lr), float(mom1),
                                                   _lib.stream_ptr()), "nesterov_step")
 
 
 def ema_update(shadow, p, decay):
-    bump_weights_epoch()
+    bump_weights_epoch(shadow)
     _lib.check(_lib.lib().otgan_ema_update_f32(shadow.data_ptr(), p.data_ptr(), p.numel(),
                                                float(decay), _lib.stream_ptr()), "ema_update")

@@ -111,7 +111,7 @@ def local_rows(flat_global, rows_per_rank):
 
 
 def allreduce_sum_(tensors):
-    """In-place SUM all-reduce of a list of tensors through ONE flat bucket (a single large
+    """SUM all-reduce of a list of tensors through ONE flat bucket; returns the reduced tensors (a single large
     collective suits xGMI's point-to-point links better than many small ones)."""
     if world_size() == 1 or not tensors:
         return tensors
@@ -122,12 +122,12 @@ def allreduce_sum_(tensors):
         flat = host.to(flat.device)
     else:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    off = 0
-    for t in tensors:
+    out, off = [], 0
+    for t in tensors:       # hand back views of the reduced bucket (no per-tensor copies)
         n = t.numel()
-        t.copy_(flat[off:off + n].view_as(t))
+        out.append(flat[off:off + n].view_as(t))
         off += n
-    return tensors
+    return out
 
 
 def barrier():

@@ -44,6 +44,9 @@ class OTGAN:
             f = self.discriminator(torch.zeros(2, size, size, 3, device=device), init=True, **self.model_opts)
             self.generator(batch_size=2, init=True, device=device, **self.model_opts)
         self.num_features = f.shape[-1]
+        # one flat buffer per network: optimiser / EMA / gradient all-reduce act on it in one go
+        self.discriminator.flatten()
+        self.generator.flatten()
         self.disc_params = self.discriminator.trainable_variables()     # train.py:61
         self.gen_params = self.generator.trainable_variables()          # train.py:62
         self.ema = nn.ExponentialMovingAverage(decay=0.999)             # train.py:63

@@ -48,7 +48,7 @@ def _worker(rank, world, port, out):
     # 3. gradient all-reduce is a SUM over ranks (train.py:134-139), through one flat bucket
     g1 = torch.full((3, 4), float(rank + 1))
     g2 = torch.arange(5, dtype=torch.float32) * (rank + 1)
-    parallel.allreduce_sum_([g1, g2])
+    g1, g2 = parallel.allreduce_sum_([g1, g2])
     tot = sum(range(1, world + 1))
     assert torch.all(g1 == tot) and torch.equal(g2, torch.arange(5, dtype=torch.float32) * tot)
     parallel.barrier()
