@@ -4,16 +4,17 @@ TEST INFRASTRUCTURE ONLY -- the "plain PyTorch reference of the same op" the HIP
 kernels are compared against (fp64 on CPU, or fp32 on the GPU), and the nets of the
 `cpu_baseline` leg of bench.py.  Never imported by the product path (ot-gan_amd/).
 
-The reference's models cannot be imported here (TensorFlow-1.x graph API: tf.make_template,
-arg_scope, tf.get_variable ...), so this file restates them from:
+An independent restatement (torch.nn.functional.conv2d etc.) of:
     utils/nn.py:103-183   get_params (weight norm, non-init branch)
     utils/nn.py:190-206   apply_pre_activation (list interleave [x0,-x0,x1,-x1,...])
     utils/nn.py:234-241   conv (NHWC x HWIO, TF 'SAME', optional 2x NN upsample first)
     utils/nn.py:314-338   dense / conv2d (+ bias)
     utils/nn.py:29-87     adam / adamax / nesterov updates
     models/dcgan.py:7-52, models/densenet.py:7-88
-"Parity unpinned" by the reference (it has no numeric fixtures for the nets): pins are the
-layer semantics above plus shapes (D = 32768 / 7296, output [B,32,32,3] in (-1,1)).
+PINNED: tests/test_oracle_nets.py checks this file against golden vectors produced by running
+the reference's own utils/nn.py, models/dcgan.py and models/densenet.py unmodified over a NumPy
+stand-in for TensorFlow (oracle/tf_standin_nets.py, oracle/make_golden_nets.py): features,
+images, variable names/shapes and three steps of every optimiser, to 1e-12 (fp64) / 2e-7 (fp32).
 
 Activations are NHWC like the reference; torch's conv wants NCHW, so tensors are permuted
 around F.conv2d.
