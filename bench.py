@@ -85,6 +85,9 @@ def main():
 
     if rank != 0:
         return
+    default_cfg = a.model == "dcgan" and a.image_size == 32 and a.batch_per_gpu == 256
+    cfg_tag = ("configs[1]" if default_cfg else "configs[3]-shaped (DenseNet)" if a.model == "densenet"
+               else "configs[4]-shaped (64x64)" if a.image_size == 64 else "custom")
     images = world * model.nb * a.steps
     value = images / dt
     out = {
@@ -92,7 +95,7 @@ def main():
         "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs[1]: {a.model.upper()} generator+critic train step, synthetic "
+        "config": {"workload": f"{cfg_tag}: {a.model.upper()} generator+critic train step, synthetic "
                                f"CIFAR-10-shaped {a.image_size}x{a.image_size}x3, {a.batch_per_gpu} img/GPU as 2 logical shards x "
                                f"{a.batch_per_gpu // 2} (Sinkhorn rows N={world * a.batch_per_gpu // 2 if a.matching_scope == 'global' else a.batch_per_gpu // 2}), "
                                f"{a.nr_sinkhorn_iter} Sinkhorn iters, lambda 500, 5:1 generator:critic steps, Adam",
@@ -109,6 +112,8 @@ def main():
         # (tools/pmc_bench.sh -> profiles/r01_pmc_summary.json), not measurable in-process.
         traffic = None
         try:
+            if not (default_cfg or a.model == "densenet"):
+                raise LookupError("no PMC summary for this configuration")
             with open(os.path.join(ROOT, "profiles", f"r01_pmc_summary_{a.model}.json")) as f:
                 traffic = round(json.load(f)[dom]["hbm_bytes_per_launch"])
         except Exception:

@@ -11,6 +11,12 @@ def cls_of(name):
         return "conv_fwd" if m.group(2) == "0" else "conv_dgrad"
     if "conv_fewout_kernel" in name:
         return "conv_fewout(fwd|dgrad)"
+    if "dense16_fwd" in name:
+        return "conv_fwd"
+    if "dense16_dgrad" in name:
+        return "conv_dgrad"
+    if "dense16_wgrad" in name:
+        return "conv_wgrad"
     if "conv_wgrad" in name or "conv_outer_kernel" in name:
         return "conv_wgrad"
     if "cost_partial_kernel" in name:

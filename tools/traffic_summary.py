@@ -10,6 +10,12 @@ def cls_of(name):
     m = re.search(r"conv_igemm_kernel<GemmCfg<[^>]*>, (true|false), (\d), (\d)>", name)
     if m:
         return "conv_fwd" if m.group(2) == "0" else "conv_dgrad"
+    if "dense16_fwd" in name:
+        return "conv_fwd"
+    if "dense16_dgrad" in name:
+        return "conv_dgrad"
+    if "dense16_wgrad" in name:
+        return "conv_wgrad"
     if "conv_wgrad" in name:
         return "conv_wgrad"
     if "cost_partial_kernel" in name:
