@@ -54,6 +54,13 @@ typedef struct otgan_conv_desc {
 size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which);
 
 /*
+ * Folded 5x5 upsampling layers without pre-activation (the DCGAN generator, models/dcgan.py:33-46)
+ * additionally run in Winograd F(2x2,3x3) form on the small image -- 2.25x fewer multiply-adds
+ * again; the three passes then need scratch for the transformed operands, reported by
+ * otgan_conv2d_workspace_bytes.  Nothing else changes for the caller (same folded weights).
+ */
+
+/*
  * Upsample folding.  conv(k x k) applied to a 2x nearest-neighbour upsampled image equals four
  * output-parity-class convolutions on the SMALL image whose taps are sums of the original
  * ones (k = 5: 3x3 per class instead of 5x5; k = 3: 2x2 instead of 3x3) -- identical
@@ -71,7 +78,8 @@ int otgan_conv2d_fold_weights_f32(const otgan_conv_desc* d, const float* w, floa
 /* y = conv2d(preact(upsample(x)), W) + bias.   wT: [Cout][KH*KW*Cin_eff] (transposed copy
  * of the HWIO weight, produced by otgan_weightnorm_fwd_f32).  nn.py:241,337. */
 int otgan_conv2d_fwd_f32(const otgan_conv_desc* d, const float* x, const int32_t* cmap,
-                         const float* wT, const float* bias, float* y, void* stream);
+                         const float* wT, const float* bias, float* y, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* dx (+)= d(loss)/d(x) given dy; w is the HWIO weight.  x (the layer input) is needed for
  * the activation derivative.  dx: [N,H,W,lddx] (first C channels written).

@@ -20,7 +20,7 @@ SIGNATURES = {
     "otgan_conv2d_workspace_bytes": (c_size_t, [P_DESC, c_int]),
     "otgan_conv2d_folded_weight_elems": (c_size_t, [P_DESC]),
     "otgan_conv2d_fold_weights_f32": (c_int, [P_DESC, c_fp, c_fp, c_fp, c_fp]),
-    "otgan_conv2d_fwd_f32": (c_int, [P_DESC, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "otgan_conv2d_fwd_f32": (c_int, [P_DESC, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_size_t, c_fp]),
     "otgan_conv2d_dgrad_f32": (c_int, [P_DESC, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp,
                                        c_size_t, c_fp]),
     "otgan_conv2d_wgrad_f32": (c_int, [P_DESC, c_fp, c_fp, c_fp, c_fp, c_fp, c_size_t, c_fp]),

@@ -22,6 +22,7 @@
 // the memory latency hides under BK/2 * MT*NT * 64 cycles of matrix work.
 #include "gemm_tile.h"
 #include "dense16.h"
+#include "winograd.h"
 #include "../../include/otgan.h"
 
 namespace {
@@ -1134,6 +1135,18 @@ FoldTab make_fold(const otgan_conv_desc* d, const Geo& g) {
   return f;
 }
 
+// Winograd F(2x2,3x3) applies to folded 5x5 upsampling layers without pre-activation.
+inline bool wino_ok(const otgan_conv_desc* d, const Geo& g) {
+  return g.fold && d->KH == 5 && d->KW == 5 && d->preact == OTGAN_ACT_NONE && d->C % 32 == 0 &&
+         d->Cout % 4 == 0 && d->H % 2 == 0 && d->W % 2 == 0 && d->H >= 2 && d->W >= 2 && winograd_enabled();
+}
+inline WinoGeo wino_geo(const otgan_conv_desc* d) {
+  WinoGeo w;
+  w.N = d->N; w.H = d->H; w.W = d->W; w.Cin = d->C; w.Cout = d->Cout; w.ldx = d->ldx; w.ldy = d->ldy;
+  w.y_coff = d->y_coff;
+  return w;
+}
+
 struct WgPlan {
   int outer;       // 0 no, 1 few outputs (Cout <= 4), 2 few inputs (Cin_eff <= 4)
   int chunk, nchunks;
@@ -1401,6 +1414,12 @@ int otgan_conv2d_fold_weights_f32(const otgan_conv_desc* d, const float* w, floa
 size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which) {
   Geo g;
   if (make_geo(d, &g) != OTGAN_OK) return 0;
+  if (wino_ok(d, g)) {
+    const WinoGeo w = wino_geo(d);
+    const size_t fl = which == 0 ? wino_fwd_ws_floats(w) : which == 1 ? wino_dgrad_ws_floats(w)
+                                                                      : wino_wgrad_ws_floats(w) + make_fold(d, g).total;
+    return align_up(sizeof(float) * fl, 256) + 256;
+  }
   if (which == 1) {
     // legacy (un-folded) dgrad through a 2x upsample: gradient on the virtual grid
     return (d->upsample && !g.fold)
@@ -1417,7 +1436,8 @@ size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which) {
 }
 
 int otgan_conv2d_fwd_f32(const otgan_conv_desc* d, const float* x, const int32_t* cmap,
-                         const float* wT, const float* bias, float* y, void* stream) {
+                         const float* wT, const float* bias, float* y, void* workspace,
+                         size_t workspace_bytes, void* stream) {
   Geo g;
   int rc = make_geo(d, &g);
   if (rc) return rc;
@@ -1437,6 +1457,22 @@ int otgan_conv2d_fwd_f32(const otgan_conv_desc* d, const float* x, const int32_t
   e.bias = bias; e.ncols = d->Cout;
   double flops;
   bool vec;
+  if (wino_ok(d, g)) {
+    OTGAN_CHECK_ARG(aligned16(x) && aligned16(wT) && aligned16(y) && aligned16(bias) && aligned16(workspace),
+                    "winograd conv needs 16-byte aligned operands");
+    const size_t need = otgan_conv2d_workspace_bytes(d, 0);
+    if (!workspace || workspace_bytes < need) {
+      otgan_set_error("conv2d fwd workspace too small: need %zu, got %zu", need, workspace_bytes);
+      return OTGAN_ERR_WORKSPACE;
+    }
+    const FoldTab f = make_fold(d, g);
+    const WinoGeo w = wino_geo(d);
+    // executed FLOP: 16 GEMMs of tiles x 4*Cout x Cin
+    ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * 16.0 * (double)wino_tiles(w) * 4.0 * d->Cout * d->C, 0.0, s);
+    rc = wino_fwd(w, x, wT, f.woff[1] - f.woff[0], bias, y, (float*)workspace, s);
+    OTGAN_CHECK_LAUNCH("conv2d fwd (winograd)");
+    return rc;
+  }
   if (g.fold) {
     OTGAN_CHECK_ARG(aligned16(x) && aligned16(wT), "folded conv needs 16-byte aligned operands");
     // rows = SMALL-grid pixels, one class per output parity, folded taps; wT = weffT
@@ -1595,6 +1631,21 @@ int otgan_conv2d_dgrad_f32(const otgan_conv_desc* d, const float* dy, const floa
     OTGAN_CHECK_LAUNCH("conv2d dgrad (dense16)");
     return rc;
   }
+  if (wino_ok(d, g)) {
+    OTGAN_CHECK_ARG(aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(workspace) && lddx % 4 == 0,
+                    "winograd dgrad needs 16-byte aligned operands");
+    const size_t need = otgan_conv2d_workspace_bytes(d, 1);
+    if (!workspace || workspace_bytes < need) {
+      otgan_set_error("conv2d dgrad workspace too small: need %zu, got %zu", need, workspace_bytes);
+      return OTGAN_ERR_WORKSPACE;
+    }
+    const FoldTab f = make_fold(d, g);
+    const WinoGeo wg = wino_geo(d);
+    ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * 16.0 * (double)wino_tiles(wg) * 4.0 * d->Cout * d->C, 0.0, s);
+    rc = wino_dgrad(wg, dy, w, f.woff[1] - f.woff[0], dx, lddx, accumulate, (float*)workspace, s);
+    OTGAN_CHECK_LAUNCH("conv2d dgrad (winograd)");
+    return rc;
+  }
   if (g.fold) {
     // gradient w.r.t. the SMALL input directly: rows = small pixels, K = all 4 classes'
     // folded taps; dy is read at (2(a - dh) + ph, 2(b - dw) + pw); w = weff.
@@ -1706,6 +1757,32 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
   if ((p.nsplit > 1 || p.fold) && (!workspace || workspace_bytes < need)) {
     otgan_set_error("conv2d wgrad workspace too small: need %zu, got %zu", need, workspace_bytes);
     return OTGAN_ERR_WORKSPACE;
+  }
+  if (wino_ok(d, g)) {
+    OTGAN_CHECK_ARG(aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace),
+                    "winograd wgrad needs 16-byte aligned operands");
+    const size_t need = otgan_conv2d_workspace_bytes(d, 2);
+    if (!workspace || workspace_bytes < need) {
+      otgan_set_error("conv2d wgrad workspace too small: need %zu, got %zu", need, workspace_bytes);
+      return OTGAN_ERR_WORKSPACE;
+    }
+    const FoldTab f = make_fold(d, g);
+    const WinoGeo wg = wino_geo(d);
+    float* ws = (float*)workspace;
+    float* dweff = ws + wino_wgrad_ws_floats(wg);
+    {
+      ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * 16.0 * (double)wino_tiles(wg) * 4.0 * d->Cout * d->C, 0.0, s);
+      rc = wino_wgrad(wg, x, dy, dweff, f.woff[1] - f.woff[0], ws, s);
+      if (rc) return rc;
+    }
+    OTGAN_CHECK_LAUNCH("conv2d wgrad (winograd)");
+    const long CkCout = (long)g.Ceff * d->Cout;
+    const long total = (long)d->KH * d->KW * CkCout;
+    long blocks = ceil_div_l(total, 256 * 4);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(unfold_wgrad_kernel, dim3((int)blocks), dim3(256), 0, s, (const float*)dweff, f, CkCout, dw);
+    OTGAN_CHECK_LAUNCH("unfold_wgrad");
+    return OTGAN_OK;
   }
   if (p.dense16) {
     OTGAN_CHECK_ARG(aligned16(x) && aligned16(dy) && aligned16(cmap), "operands must be 16-byte aligned");

@@ -1,0 +1,532 @@
+// winograd.hip -- Winograd F(2x2,3x3) for the folded 5x5 upsampling convolutions (see winograd.h).
+//
+// Pipeline of one pass (all in the NHWC / channel-contiguous layouts of the rest of the library):
+//   forward : V = B^T d B  (x, 4x4 patches)          [16][T][Cin]
+//             U = G g G^T  (four class filters)      [16][4*Cout][Cin]
+//             M[f] = V[f] . U[f]^T   16 GEMMs        [16][T][4*Cout]      <- all the MFMA work
+//             y = A^T M A + bias, scattered to the class's output parity
+//   dgrad   : the same with d = dy sampled per class, flipped filters, K = 4*Cout, N = Cin
+//   wgrad   : dU[f] = V[f]^T . (A dY A^T)[f]  (K = tiles), then dweff = G^T dU G
+// The transforms are streaming float4 kernels; the GEMMs use the shared block-GEMM engine.
+#include "winograd.h"
+
+#include <stdlib.h>
+
+#include "gemm_tile.h"
+
+namespace {
+
+using Cfg = GemmCfg<2, 2, 2, 2, 32>;   // 128 x 128 x 32, 66 KB LDS, 2 workgroups / CU
+
+template <auto Kern>
+inline void ensure_lds(size_t bytes) {
+  static const bool done = [bytes] {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)bytes);
+    return true;
+  }();
+  (void)done;
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// ---- the four small transforms, on float4 = four channels at once -------------------------
+// V = B^T d B
+__device__ __forceinline__ void tf_input(const f32x4 (&d)[4][4], f32x4 (&V)[4][4]) {
+  f32x4 t[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    t[0][j] = d[0][j] - d[2][j];
+    t[1][j] = d[1][j] + d[2][j];
+    t[2][j] = d[2][j] - d[1][j];
+    t[3][j] = d[1][j] - d[3][j];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    V[i][0] = t[i][0] - t[i][2];
+    V[i][1] = t[i][1] + t[i][2];
+    V[i][2] = t[i][2] - t[i][1];
+    V[i][3] = t[i][1] - t[i][3];
+  }
+}
+// U = G g G^T
+__device__ __forceinline__ void tf_filter(const f32x4 (&g)[3][3], f32x4 (&U)[4][4]) {
+  f32x4 t[4][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    t[0][j] = g[0][j];
+    t[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
+    t[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
+    t[3][j] = g[2][j];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    U[i][0] = t[i][0];
+    U[i][1] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+    U[i][2] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+    U[i][3] = t[i][2];
+  }
+}
+// Y = A^T M A
+__device__ __forceinline__ void tf_output(const f32x4 (&M)[4][4], f32x4 (&Y)[2][2]) {
+  f32x4 s[2][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s[0][j] = M[0][j] + M[1][j] + M[2][j];
+    s[1][j] = M[1][j] - M[2][j] - M[3][j];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    Y[i][0] = s[i][0] + s[i][1] + s[i][2];
+    Y[i][1] = s[i][1] - s[i][2] - s[i][3];
+  }
+}
+// dM = A dY A^T  (adjoint of tf_output)
+__device__ __forceinline__ void tf_output_adj(const f32x4 (&dY)[2][2], f32x4 (&dM)[4][4]) {
+  f32x4 u[4][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    u[0][j] = dY[0][j];
+    u[1][j] = dY[0][j] + dY[1][j];
+    u[2][j] = dY[0][j] - dY[1][j];
+    u[3][j] = -dY[1][j];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    dM[i][0] = u[i][0];
+    dM[i][1] = u[i][0] + u[i][1];
+    dM[i][2] = u[i][0] - u[i][1];
+    dM[i][3] = -u[i][1];
+  }
+}
+// dg = G^T dU G  (adjoint of tf_filter)
+__device__ __forceinline__ void tf_filter_adj(const f32x4 (&dU)[4][4], f32x4 (&dg)[3][3]) {
+  f32x4 p[3][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    p[0][j] = dU[0][j] + 0.5f * (dU[1][j] + dU[2][j]);
+    p[1][j] = 0.5f * (dU[1][j] - dU[2][j]);
+    p[2][j] = 0.5f * (dU[1][j] + dU[2][j]) + dU[3][j];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    dg[i][0] = p[i][0] + 0.5f * (p[i][1] + p[i][2]);
+    dg[i][1] = 0.5f * (p[i][1] - p[i][2]);
+    dg[i][2] = 0.5f * (p[i][1] + p[i][2]) + p[i][3];
+  }
+}
+
+// ---- streaming kernels --------------------------------------------------------------------
+// A "view" of a small-grid image: element (n, a, b, c) at p[n*sn + a*sh + b*sw + c].
+struct View {
+  const float* p;
+  long sn, sh, sw;
+};
+struct WView {
+  float* p;
+  long sn, sh, sw;
+};
+
+// V[f][t][coff + c] = (B^T d B)[f];  d = 4x4 patch at (2ta-1, 2tb-1), zero outside [0,H)x[0,W).
+// blockIdx.z selects one of up to four views (dgrad: the four output-parity classes of dy).
+struct InArgs {
+  View v[4];
+  int coff[4];
+  int H, W, TH, TW, C;   // C = channels of the view
+  long T;
+  int ldv;               // row length of V
+  float* V;
+};
+__global__ __launch_bounds__(256) void wino_input_kernel(InArgs a) {
+  const int c4n = a.C >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.T * c4n) return;
+  const int c = (int)(idx % c4n) * 4;
+  const long t = idx / c4n;
+  const int tb = (int)(t % a.TW), ta = (int)((t / a.TW) % a.TH);
+  const long n = t / ((long)a.TW * a.TH);
+  const View v = a.v[blockIdx.z];
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 d[4][4], V[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 2 * ta - 1 + i;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = 2 * tb - 1 + j;
+      const bool ok = (unsigned)r < (unsigned)a.H && (unsigned)q < (unsigned)a.W;
+      d[i][j] = ok ? ld4(v.p + n * v.sn + r * v.sh + q * v.sw + c) : zero;
+    }
+  }
+  tf_input(d, V);
+  float* out = a.V + t * a.ldv + a.coff[blockIdx.z] + c;
+  const long fs = a.T * a.ldv;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st4(out + (i * 4 + j) * fs, V[i][j]);
+}
+
+// dst(n, 2ta+i, 2tb+j, c) (+)= (A^T M A)[i][j] + bias[c],  M[f] = Mh[f][t][coff + c]
+struct OutArgs {
+  WView v[4];
+  int coff[4];
+  int TH, TW, C;
+  long T;
+  int ldm;
+  const float* Mh;
+  const float* bias;
+  int accumulate;
+};
+__global__ __launch_bounds__(256) void wino_output_kernel(OutArgs a) {
+  const int c4n = a.C >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.T * c4n) return;
+  const int c = (int)(idx % c4n) * 4;
+  const long t = idx / c4n;
+  const int tb = (int)(t % a.TW), ta = (int)((t / a.TW) % a.TH);
+  const long n = t / ((long)a.TW * a.TH);
+  const WView v = a.v[blockIdx.z];
+  const float* in = a.Mh + t * a.ldm + a.coff[blockIdx.z] + c;
+  const long fs = a.T * a.ldm;
+  f32x4 M[4][4], Y[2][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) M[i][j] = ld4(in + (i * 4 + j) * fs);
+  tf_output(M, Y);
+  f32x4 b = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) b = ld4(a.bias + c);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float* dst = v.p + n * v.sn + (2 * ta + i) * v.sh + (2 * tb + j) * v.sw + c;
+      f32x4 o = Y[i][j] + b;
+      if (a.accumulate) o += ld4(dst);
+      st4(dst, o);
+    }
+}
+
+// dM[f][t][coff + c] = (A dY A^T)[f],  dY = the 2x2 tile of the view at (2ta, 2tb)
+__global__ __launch_bounds__(256) void wino_outadj_kernel(InArgs a) {
+  const int c4n = a.C >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.T * c4n) return;
+  const int c = (int)(idx % c4n) * 4;
+  const long t = idx / c4n;
+  const int tb = (int)(t % a.TW), ta = (int)((t / a.TW) % a.TH);
+  const long n = t / ((long)a.TW * a.TH);
+  const View v = a.v[blockIdx.z];
+  f32x4 dY[2][2], dM[4][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dY[i][j] = ld4(v.p + n * v.sn + (2 * ta + i) * v.sh + (2 * tb + j) * v.sw + c);
+  tf_output_adj(dY, dM);
+  float* out = a.V + t * a.ldv + a.coff[blockIdx.z] + c;
+  const long fs = a.T * a.ldv;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st4(out + (i * 4 + j) * fs, dM[i][j]);
+}
+
+// forward filters: U[f][cls*Cout + co][ci] from weffT[cls][co][tap*Cin + ci]
+__global__ __launch_bounds__(256) void wino_filter_fwd_kernel(const float* __restrict__ weffT, long cls_stride,
+                                                            int Cin, int Cout, float* __restrict__ U) {
+  const int c4n = Cin >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long rows = 4L * Cout;
+  if (idx >= rows * c4n) return;
+  const int ci = (int)(idx % c4n) * 4;
+  const long row = idx / c4n;
+  const int cls = (int)(row / Cout), co = (int)(row % Cout);
+  const float* src = weffT + cls * cls_stride + (long)co * 9 * Cin + ci;
+  f32x4 g[3][3], Uv[4][4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) g[i][j] = ld4(src + (long)(i * 3 + j) * Cin);
+  tf_filter(g, Uv);
+  const long fs = rows * Cin;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st4(U + (i * 4 + j) * fs + row * Cin + ci, Uv[i][j]);
+}
+
+// backward filters (flipped taps): U'[f][ci][cls*Cout + co] from weff[cls][tap][ci][co]
+__global__ __launch_bounds__(256) void wino_filter_bwd_kernel(const float* __restrict__ weff, long cls_stride,
+                                                            int Cin, int Cout, float* __restrict__ U) {
+  const int c4n = Cout >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 4L * Cin * c4n) return;
+  const int co = (int)(idx % c4n) * 4;
+  const long r = idx / c4n;
+  const int ci = (int)(r % Cin), cls = (int)(r / Cin);
+  const float* src = weff + cls * cls_stride + (long)ci * Cout + co;
+  f32x4 g[3][3], Uv[4][4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) g[i][j] = ld4(src + (long)((2 - i) * 3 + (2 - j)) * Cin * Cout);
+  tf_filter(g, Uv);
+  const long ldu = 4L * Cout, fs = (long)Cin * ldu;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st4(U + (i * 4 + j) * fs + (long)ci * ldu + (long)cls * Cout + co, Uv[i][j]);
+}
+
+// dweff[cls][tap][ci][co] = (G^T dU G)[tap],  dU[f] = sum over splits of slab[split][f][ci][cls*Cout + co]
+__global__ __launch_bounds__(256) void wino_filter_adj_kernel(const float* __restrict__ slabs, int nsplit,
+                                                            long split_stride, int Cin, int Cout,
+                                                            float* __restrict__ dweff, long cls_stride) {
+  const int c4n = Cout >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 4L * Cin * c4n) return;
+  const int co = (int)(idx % c4n) * 4;
+  const long r = idx / c4n;
+  const int ci = (int)(r % Cin), cls = (int)(r / Cin);
+  const long ldu = 4L * Cout, fs = (long)Cin * ldu;
+  const float* src = slabs + (long)ci * ldu + (long)cls * Cout + co;
+  f32x4 dU[4][4], dg[3][3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 s = ld4(src + (i * 4 + j) * fs);
+      for (int k = 1; k < nsplit; ++k) s += ld4(src + k * split_stride + (i * 4 + j) * fs);
+      dU[i][j] = s;
+    }
+  tf_filter_adj(dU, dg);
+  float* dst = dweff + cls * cls_stride + (long)ci * Cout + co;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) st4(dst + (long)(i * 3 + j) * Cin * Cout, dg[i][j]);
+}
+
+// ---- the batched GEMM ---------------------------------------------------------------------
+// blockIdx.z = frequency f; blockIdx.y = K split; blockIdx.x -> (tm, tn) with the 8 XCDs taking
+// different row tiles, so that the column tiles that share an A row tile share an L2.
+//   TN = false: C[f] = A[f] (M x K, k contiguous) . B[f]^T (N x K, k contiguous)
+//   TN = true : C[f] = A[f]^T (K x M, m contiguous) . B[f] (K x N, n contiguous)
+struct BgArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;
+  long lda, ldb, ldc;
+  long sA, sB, sC, sSplit;
+  int tiles_m, tiles_n, kt_per_split;
+  int xmap;   // 1: XCD = row-tile residue, 2: XCD = column-tile residue, 0: linear
+};
+
+template <bool TN>
+__global__ __launch_bounds__(Cfg::THREADS) void wino_bgemm_kernel(BgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // workgroups go round-robin over the 8 XCDs (one L2 each): give each XCD its own row tiles
+  // (or column tiles when there are too few row tiles), so that tiles sharing an operand share an L2
+  const int x = blockIdx.x;
+  int tm, tn;
+  if (a.xmap == 1) {
+    const int xcd = x & 7, idx = x >> 3;
+    tn = idx % a.tiles_n;
+    tm = (idx / a.tiles_n) * 8 + xcd;
+  } else if (a.xmap == 2) {
+    const int xcd = x & 7, idx = x >> 3;
+    tm = idx % a.tiles_m;
+    tn = (idx / a.tiles_m) * 8 + xcd;
+  } else {
+    tn = x % a.tiles_n;
+    tm = x / a.tiles_n;
+  }
+  const int f = blockIdx.z;
+  const int nkt_all = (a.K + Cfg::BK - 1) / Cfg::BK;
+  const int kt0 = blockIdx.y * a.kt_per_split;
+  int nkt = nkt_all - kt0;
+  if (nkt > a.kt_per_split) nkt = a.kt_per_split;
+  typename Cfg::acc_t acc[Cfg::MT][Cfg::NT];
+  zero_acc<Cfg>(acc);
+  const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
+  if (nkt > 0) {
+    if (TN) {
+      using LA = MatLoaderR<Cfg, Cfg::BM, true>;
+      using LB = MatLoaderR<Cfg, Cfg::BN, true>;
+      LA la;
+      LB lb;
+      la.init(a.A + f * a.sA + (long)kt0 * Cfg::BK * a.lda + m0, a.lda, a.M - m0, a.K - kt0 * Cfg::BK);
+      lb.init(a.B + f * a.sB + (long)kt0 * Cfg::BK * a.ldb + n0, a.ldb, a.N - n0, a.K - kt0 * Cfg::BK);
+      gemm_mainloop<Cfg>(la, lb, nkt, smem, acc);
+    } else {
+      using LA = MatLoaderK<Cfg, Cfg::BM, true>;
+      using LB = MatLoaderK<Cfg, Cfg::BN, true>;
+      LA la;
+      LB lb;
+      la.init(a.A + f * a.sA + (long)m0 * a.lda + (long)kt0 * Cfg::BK, a.lda, a.M - m0, a.K - kt0 * Cfg::BK);
+      lb.init(a.B + f * a.sB + (long)n0 * a.ldb + (long)kt0 * Cfg::BK, a.ldb, a.N - n0, a.K - kt0 * Cfg::BK);
+      gemm_mainloop<Cfg>(la, lb, nkt, smem, acc);
+    }
+  }
+  float* C = a.C + f * a.sC + blockIdx.y * a.sSplit;
+  foreach_acc<Cfg>(acc, [&](int r, int c, int, int, int, float v) {
+    const int m = m0 + r, n = n0 + c;
+    if (m < a.M && n < a.N) C[(long)m * a.ldc + n] = v;
+  });
+}
+
+template <bool TN>
+void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
+  size_t lds;
+  if (TN) lds = sizeof(float) * 2 * (MatLoaderR<Cfg, Cfg::BM, true>::FLOATS + MatLoaderR<Cfg, Cfg::BN, true>::FLOATS);
+  else lds = sizeof(float) * 2 * (MatLoaderK<Cfg, Cfg::BM, true>::FLOATS + MatLoaderK<Cfg, Cfg::BN, true>::FLOATS);
+  ensure_lds<wino_bgemm_kernel<TN>>(lds);
+  BgArgs b = a;
+  b.xmap = (a.tiles_m % 8 == 0) ? 1 : (a.tiles_n % 8 == 0) ? 2 : 0;
+  const dim3 grid(a.tiles_m * a.tiles_n, nsplit, 16);
+  hipLaunchKernelGGL((wino_bgemm_kernel<TN>), grid, dim3(Cfg::THREADS), lds, s, b);
+}
+
+inline int grid1(long n) { return (int)((n + 255) / 256); }
+
+// the four output-parity classes of a [N, 2H, 2W, ld] buffer as small-grid views
+template <class V, class P>
+void class_views(const WinoGeo& g, P base, int ld, V (&v)[4]) {
+  const long OW = 2L * g.W, OH = 2L * g.H;
+  for (int cls = 0; cls < 4; ++cls) {
+    const int ph = cls >> 1, pw = cls & 1;
+    v[cls].p = base + (ph * OW + pw) * ld;
+    v[cls].sn = OH * OW * ld;
+    v[cls].sh = 2 * OW * ld;
+    v[cls].sw = 2L * ld;
+  }
+}
+
+int wgrad_splits(const WinoGeo& g) {
+  const long T = wino_tiles(g);
+  const int blocks = ((g.Cin + 127) / 128) * ((4 * g.Cout + 127) / 128) * 16;
+  int ns = (1024 + blocks - 1) / blocks;
+  if (ns > 8) ns = 8;
+  const int nkt = (int)((T + Cfg::BK - 1) / Cfg::BK);
+  while (ns > 1 && nkt / ns < 8) --ns;
+  return ns < 1 ? 1 : ns;
+}
+
+}  // namespace
+
+bool winograd_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("OTGAN_DISABLE_WINOGRAD");
+    return !(e && e[0] == '1');
+  }();
+  return on;
+}
+
+size_t wino_fwd_ws_floats(const WinoGeo& g) {
+  const size_t T = (size_t)wino_tiles(g);
+  return 16 * T * g.Cin + 16 * T * 4 * g.Cout + 16 * (size_t)4 * g.Cout * g.Cin;
+}
+size_t wino_dgrad_ws_floats(const WinoGeo& g) { return wino_fwd_ws_floats(g); }
+size_t wino_wgrad_ws_floats(const WinoGeo& g) {
+  const size_t T = (size_t)wino_tiles(g);
+  return 16 * T * g.Cin + 16 * T * 4 * g.Cout + (size_t)wgrad_splits(g) * 16 * 4 * g.Cout * g.Cin;
+}
+
+int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stride, const float* bias, float* y,
+             float* ws, hipStream_t s) {
+  const long T = wino_tiles(g);
+  const int N4 = 4 * g.Cout;
+  float* V = ws;
+  float* Mh = V + 16 * T * g.Cin;
+  float* U = Mh + 16 * T * N4;
+  hipLaunchKernelGGL(wino_filter_fwd_kernel, dim3(grid1((long)N4 * (g.Cin / 4))), dim3(256), 0, s, weffT, cls_stride,
+                     g.Cin, g.Cout, U);
+  InArgs ia;
+  memset(&ia, 0, sizeof(ia));
+  ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
+  ia.H = g.H; ia.W = g.W; ia.TH = g.H / 2; ia.TW = g.W / 2; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.V = V;
+  hipLaunchKernelGGL(wino_input_kernel, dim3(grid1(T * (g.Cin / 4)), 1, 1), dim3(256), 0, s, ia);
+  BgArgs b;
+  memset(&b, 0, sizeof(b));
+  b.A = V; b.B = U; b.C = Mh; b.M = (int)T; b.N = N4; b.K = g.Cin;
+  b.lda = g.Cin; b.ldb = g.Cin; b.ldc = N4;
+  b.sA = T * g.Cin; b.sB = (long)N4 * g.Cin; b.sC = T * N4;
+  b.tiles_m = (int)((T + Cfg::BM - 1) / Cfg::BM); b.tiles_n = (N4 + Cfg::BN - 1) / Cfg::BN;
+  b.kt_per_split = (g.Cin + Cfg::BK - 1) / Cfg::BK;
+  launch_bgemm<false>(b, 1, s);
+  OutArgs oa;
+  memset(&oa, 0, sizeof(oa));
+  class_views(g, y + g.y_coff, g.ldy, oa.v);
+  for (int cls = 0; cls < 4; ++cls) oa.coff[cls] = cls * g.Cout;
+  oa.TH = g.H / 2; oa.TW = g.W / 2; oa.C = g.Cout; oa.T = T; oa.ldm = N4; oa.Mh = Mh; oa.bias = bias;
+  hipLaunchKernelGGL(wino_output_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 4), dim3(256), 0, s, oa);
+  return OTGAN_OK;
+}
+
+int wino_dgrad(const WinoGeo& g, const float* dy, const float* weff, long cls_stride, float* dx, int lddx,
+               int accumulate, float* ws, hipStream_t s) {
+  const long T = wino_tiles(g);
+  const int K4 = 4 * g.Cout;
+  float* DV = ws;                       // [16][T][4*Cout]
+  float* Xh = DV + 16 * T * K4;         // [16][T][Cin]
+  float* U = Xh + 16 * T * g.Cin;       // [16][Cin][4*Cout]
+  hipLaunchKernelGGL(wino_filter_bwd_kernel, dim3(grid1(4L * g.Cin * (g.Cout / 4))), dim3(256), 0, s, weff, cls_stride,
+                     g.Cin, g.Cout, U);
+  InArgs ia;
+  memset(&ia, 0, sizeof(ia));
+  class_views(g, dy + g.y_coff, g.ldy, ia.v);
+  for (int cls = 0; cls < 4; ++cls) ia.coff[cls] = cls * g.Cout;
+  ia.H = g.H; ia.W = g.W; ia.TH = g.H / 2; ia.TW = g.W / 2; ia.C = g.Cout; ia.T = T; ia.ldv = K4; ia.V = DV;
+  hipLaunchKernelGGL(wino_input_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 4), dim3(256), 0, s, ia);
+  BgArgs b;
+  memset(&b, 0, sizeof(b));
+  b.A = DV; b.B = U; b.C = Xh; b.M = (int)T; b.N = g.Cin; b.K = K4;
+  b.lda = K4; b.ldb = K4; b.ldc = g.Cin;
+  b.sA = T * K4; b.sB = (long)g.Cin * K4; b.sC = T * g.Cin;
+  b.tiles_m = (int)((T + Cfg::BM - 1) / Cfg::BM); b.tiles_n = (g.Cin + Cfg::BN - 1) / Cfg::BN;
+  b.kt_per_split = (K4 + Cfg::BK - 1) / Cfg::BK;
+  launch_bgemm<false>(b, 1, s);
+  OutArgs oa;
+  memset(&oa, 0, sizeof(oa));
+  oa.v[0].p = dx; oa.v[0].sn = (long)g.H * g.W * lddx; oa.v[0].sh = (long)g.W * lddx; oa.v[0].sw = lddx;
+  oa.TH = g.H / 2; oa.TW = g.W / 2; oa.C = g.Cin; oa.T = T; oa.ldm = g.Cin; oa.Mh = Xh; oa.bias = nullptr;
+  oa.accumulate = accumulate;
+  hipLaunchKernelGGL(wino_output_kernel, dim3(grid1(T * (g.Cin / 4)), 1, 1), dim3(256), 0, s, oa);
+  return OTGAN_OK;
+}
+
+int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, long cls_stride, float* ws,
+               hipStream_t s) {
+  const long T = wino_tiles(g);
+  const int N4 = 4 * g.Cout;
+  const int ns = wgrad_splits(g);
+  float* V = ws;                        // [16][T][Cin]
+  float* dM = V + 16 * T * g.Cin;       // [16][T][4*Cout]
+  float* slabs = dM + 16 * T * N4;      // [ns][16][Cin][4*Cout]
+  InArgs ia;
+  memset(&ia, 0, sizeof(ia));
+  ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
+  ia.H = g.H; ia.W = g.W; ia.TH = g.H / 2; ia.TW = g.W / 2; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.V = V;
+  hipLaunchKernelGGL(wino_input_kernel, dim3(grid1(T * (g.Cin / 4)), 1, 1), dim3(256), 0, s, ia);
+  InArgs da;
+  memset(&da, 0, sizeof(da));
+  class_views(g, dy + g.y_coff, g.ldy, da.v);
+  for (int cls = 0; cls < 4; ++cls) da.coff[cls] = cls * g.Cout;
+  da.H = g.H; da.W = g.W; da.TH = g.H / 2; da.TW = g.W / 2; da.C = g.Cout; da.T = T; da.ldv = N4; da.V = dM;
+  hipLaunchKernelGGL(wino_outadj_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 4), dim3(256), 0, s, da);
+  BgArgs b;
+  memset(&b, 0, sizeof(b));
+  b.A = V; b.B = dM; b.C = slabs; b.M = g.Cin; b.N = N4; b.K = (int)T;
+  b.lda = g.Cin; b.ldb = N4; b.ldc = N4;
+  b.sA = T * g.Cin; b.sB = T * N4; b.sC = (long)g.Cin * N4; b.sSplit = 16L * g.Cin * N4;
+  b.tiles_m = (g.Cin + Cfg::BM - 1) / Cfg::BM; b.tiles_n = (N4 + Cfg::BN - 1) / Cfg::BN;
+  const int nkt = (int)((T + Cfg::BK - 1) / Cfg::BK);
+  b.kt_per_split = (nkt + ns - 1) / ns;
+  launch_bgemm<true>(b, ns, s);
+  hipLaunchKernelGGL(wino_filter_adj_kernel, dim3(grid1(4L * g.Cin * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
+                     16L * g.Cin * N4, g.Cin, g.Cout, dweff, cls_stride);
+  return OTGAN_OK;
+}

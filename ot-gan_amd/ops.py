@@ -149,9 +149,12 @@ def colsum(a2d_ptr, rows, cols, lda, device):
 
 
 def conv_fwd_raw(desc, x, cmap, wT, bias, y):
-    _lib.check(_lib.lib().otgan_conv2d_fwd_f32(ctypes.byref(desc), x.data_ptr(), _lib.ptr(cmap),
-                                               wT.data_ptr(), _lib.ptr(bias), y.data_ptr(),
-                                               _lib.stream_ptr()), "conv2d_fwd")
+    L = _lib.lib()
+    need = L.otgan_conv2d_workspace_bytes(ctypes.byref(desc), 0)
+    ws = workspace(need, x.device)
+    _lib.check(L.otgan_conv2d_fwd_f32(ctypes.byref(desc), x.data_ptr(), _lib.ptr(cmap),
+                                      wT.data_ptr(), _lib.ptr(bias), y.data_ptr(), ws.data_ptr(),
+                                      ws.numel(), _lib.stream_ptr()), "conv2d_fwd")
 
 
 def conv_dgrad_raw(desc, dy, w, x, inv, dx, lddx, accumulate):

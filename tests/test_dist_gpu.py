@@ -85,7 +85,10 @@ def test_two_ranks_equal_single_process():
     x, u = _data()
     ref = _run_steps(m, x.to(dev), u.to(dev))
     for kind in ("disc", "gen"):
-        assert got[kind + "_dist"] == pytest.approx(ref[kind + "_dist"], rel=1e-5, abs=1e-8)
+        # two evaluations of the same loss: the sharded path uses the closed form over row slices of
+        # separately computed cost blocks, the single-process path calc_distance; the loss is a
+        # cancellation of O(1) terms (here 0.016), so fp32 rounding of the features shows at ~1e-5
+        assert got[kind + "_dist"] == pytest.approx(ref[kind + "_dist"], rel=1e-4, abs=1e-8)
         for a, b in zip(got[kind], ref[kind]):
             err = float((a - b).norm() / b.norm().clamp_min(1e-30))
             assert err < 2e-3, (kind, err)

@@ -44,6 +44,10 @@ CONV_CASES = [
     ("dcgan_like_up", 2, 8, 8, (64,), 128, 5, 1, True, None),
     ("ragged_cout", 2, 8, 8, (16,), 40, 3, 1, False, "crelu"),
     ("scalar_cin", 2, 8, 8, (6,), 20, 3, 1, False, "crelu"),
+    # folded 5x5 upsampling layers without pre-activation: Winograd F(2x2,3x3) path
+    ("wino_ragged", 3, 8, 8, (96,), 24, 5, 1, True, None),
+    ("wino_wide", 5, 16, 16, (32,), 160, 5, 1, True, None),
+    ("wino_split_k", 16, 16, 16, (64,), 32, 5, 1, True, None),
     # DenseNet growth layers (3x3 -> 16 channels): the LDS-free dense16 kernels
     ("dense16_list", 2, 8, 8, (32, 16, 16), 16, 3, 1, False, "crelu"),
     ("dense16_tail", 3, 8, 8, (24, 16), 16, 3, 1, False, "crelu"),
