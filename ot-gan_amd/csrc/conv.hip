@@ -1147,6 +1147,19 @@ inline WinoGeo wino_geo(const otgan_conv_desc* d) {
   return w;
 }
 
+// 5x5 stride-2 layers (single-tensor input): four 3x3 sub-convolutions in Winograd form.
+inline bool wino_s2_ok(const otgan_conv_desc* d, const Geo& g) {
+  return d->stride == 2 && d->upsample == 0 && d->KH == 5 && d->KW == 5 && d->C % 4 == 0 && g.Ceff % 32 == 0 &&
+         d->Cout % 4 == 0 && d->H % 4 == 0 && d->W % 4 == 0 && d->ldx % 4 == 0 && d->ldy % 4 == 0 &&
+         d->y_coff % 4 == 0 && winograd_enabled();
+}
+inline WinoS2Geo wino_s2_geo(const otgan_conv_desc* d, const Geo& g) {
+  WinoS2Geo w;
+  w.N = d->N; w.H = d->H; w.W = d->W; w.C = d->C; w.Ceff = g.Ceff; w.doubled = doubled_act(d->preact) ? 1 : 0;
+  w.act = act_kind(d->preact); w.ldx = d->ldx; w.Cout = d->Cout; w.ldy = d->ldy; w.y_coff = d->y_coff;
+  return w;
+}
+
 struct WgPlan {
   int outer;       // 0 no, 1 few outputs (Cout <= 4), 2 few inputs (Cin_eff <= 4)
   int chunk, nchunks;
@@ -1420,19 +1433,28 @@ size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which) {
                                                                       : wino_wgrad_ws_floats(w) + make_fold(d, g).total;
     return align_up(sizeof(float) * fl, 256) + 256;
   }
+  size_t s2 = 0;   // the strided Winograd path falls back to the generic one for list inputs: max of both
+  if (wino_s2_ok(d, g)) {
+    const WinoS2Geo w = wino_s2_geo(d, g);
+    const size_t fl = which == 0 ? wino_s2_fwd_ws_floats(w) : which == 1 ? wino_s2_dgrad_ws_floats(w)
+                                                                         : wino_s2_wgrad_ws_floats(w);
+    s2 = align_up(sizeof(float) * fl, 256) + 256;
+  }
   if (which == 1) {
     // legacy (un-folded) dgrad through a 2x upsample: gradient on the virtual grid
-    return (d->upsample && !g.fold)
+    const size_t gen = (d->upsample && !g.fold)
                ? align_up(sizeof(float) * (size_t)d->N * g.Hin * g.Win * d->C, 256)
                : 256;
+    return gen > s2 ? gen : s2;
   }
   if (which == 2) {
     const WgPlan p = plan_wgrad(d, g);
     size_t slabs = (p.nsplit > 1 || p.fold) ? (size_t)p.slab_elems * p.nsplit : 0;
     if (p.fold && p.nsplit > 1) slabs += (size_t)p.slab_elems;  // reduced dweff before unfolding
-    return align_up(sizeof(float) * slabs, 256) + 256;
+    const size_t gen = align_up(sizeof(float) * slabs, 256) + 256;
+    return gen > s2 ? gen : s2;
   }
-  return 256;
+  return s2 > 256 ? s2 : 256;
 }
 
 int otgan_conv2d_fwd_f32(const otgan_conv_desc* d, const float* x, const int32_t* cmap,
@@ -1457,6 +1479,14 @@ int otgan_conv2d_fwd_f32(const otgan_conv_desc* d, const float* x, const int32_t
   e.bias = bias; e.ncols = d->Cout;
   double flops;
   bool vec;
+  if (wino_s2_ok(d, g) && cmap == nullptr && aligned16(x) && aligned16(wT) && aligned16(y) && aligned16(bias) &&
+      aligned16(workspace) && workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 0)) {
+    const WinoS2Geo w = wino_s2_geo(d, g);
+    ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * 16.0 * (double)wino_s2_tiles(w) * 4.0 * g.Ceff * d->Cout, 0.0, s);
+    rc = wino_s2_fwd(w, x, wT, bias, y, (float*)workspace, s);
+    OTGAN_CHECK_LAUNCH("conv2d fwd (winograd, stride 2)");
+    return rc;
+  }
   if (wino_ok(d, g)) {
     OTGAN_CHECK_ARG(aligned16(x) && aligned16(wT) && aligned16(y) && aligned16(bias) && aligned16(workspace),
                     "winograd conv needs 16-byte aligned operands");
@@ -1631,6 +1661,14 @@ int otgan_conv2d_dgrad_f32(const otgan_conv_desc* d, const float* dy, const floa
     OTGAN_CHECK_LAUNCH("conv2d dgrad (dense16)");
     return rc;
   }
+  if (wino_s2_ok(d, g) && inv == nullptr && lddx % 4 == 0 && aligned16(dy) && aligned16(w) && aligned16(dx) &&
+      aligned16(x) && aligned16(workspace) && workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 1)) {
+    const WinoS2Geo wg = wino_s2_geo(d, g);
+    ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * 16.0 * (double)wino_s2_tiles(wg) * 4.0 * g.Ceff * d->Cout, 0.0, s);
+    rc = wino_s2_dgrad(wg, dy, w, x, dx, lddx, accumulate, (float*)workspace, s);
+    OTGAN_CHECK_LAUNCH("conv2d dgrad (winograd, stride 2)");
+    return rc;
+  }
   if (wino_ok(d, g)) {
     OTGAN_CHECK_ARG(aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(workspace) && lddx % 4 == 0,
                     "winograd dgrad needs 16-byte aligned operands");
@@ -1757,6 +1795,14 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
   if ((p.nsplit > 1 || p.fold) && (!workspace || workspace_bytes < need)) {
     otgan_set_error("conv2d wgrad workspace too small: need %zu, got %zu", need, workspace_bytes);
     return OTGAN_ERR_WORKSPACE;
+  }
+  if (wino_s2_ok(d, g) && cmap == nullptr && aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace) &&
+      workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 2)) {
+    const WinoS2Geo wg = wino_s2_geo(d, g);
+    ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * 16.0 * (double)wino_s2_tiles(wg) * 4.0 * g.Ceff * d->Cout, 0.0, s);
+    rc = wino_s2_wgrad(wg, x, dy, dw, (float*)workspace, s);
+    OTGAN_CHECK_LAUNCH("conv2d wgrad (winograd, stride 2)");
+    return rc;
   }
   if (wino_ok(d, g)) {
     OTGAN_CHECK_ARG(aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace),

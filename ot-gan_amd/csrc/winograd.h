@@ -34,3 +34,22 @@ int wino_dgrad(const WinoGeo& g, const float* dy, const float* weff, long cls_st
 // dweff[cls][9][Cin][Cout] (class stride cls_stride) = folded weight gradient
 int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, long cls_stride, float* ws,
                hipStream_t s);
+
+// ---- 5x5 stride-2 layers (DCGAN critic, models/dcgan.py:12-14) --------------------------------
+struct WinoS2Geo {
+  int N, H, W;             // input image (H, W multiples of 4); output is H/2 x W/2
+  int C, Ceff;             // real / effective input channels
+  int doubled, act;        // CReLU/CELU doubling; 0 none, 1 relu-type, 2 elu-type
+  int ldx;
+  int Cout, ldy, y_coff;
+};
+inline long wino_s2_tiles(const WinoS2Geo& g) { return (long)g.N * (g.H / 4) * (g.W / 4); }
+size_t wino_s2_fwd_ws_floats(const WinoS2Geo& g);
+size_t wino_s2_dgrad_ws_floats(const WinoS2Geo& g);
+size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g);
+// wT: [Cout][25*Ceff];  w: HWIO [25][Ceff][Cout];  single-tensor inputs only (default channel map)
+int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float* bias, float* y, float* ws,
+                hipStream_t s);
+int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const float* x, float* dx, int lddx,
+                  int accumulate, float* ws, hipStream_t s);
+int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw, float* ws, hipStream_t s);

@@ -138,6 +138,18 @@ struct InArgs {
   int ldv;               // row length of V
   float* V;
 };
+template <int ACT>
+__device__ __forceinline__ f32x4 wino_act(f32x4 v) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (ACT == 1) v[j] = fmaxf(v[j], 0.f);
+    if (ACT == 2) v[j] = v[j] > 0.f ? v[j] : expm1f(v[j]);
+  }
+  return v;
+}
+// ACT / DOUBLED: the pre-activation of the strided layers is applied to the patch before the
+// transform; CReLU / CELU emit two transformed patches (channels c and Creal + c of the view's slot).
+template <int ACT, bool DOUBLED>
 __global__ __launch_bounds__(256) void wino_input_kernel(InArgs a) {
   const int c4n = a.C >> 2;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -159,13 +171,37 @@ __global__ __launch_bounds__(256) void wino_input_kernel(InArgs a) {
       d[i][j] = ok ? ld4(v.p + n * v.sn + r * v.sh + q * v.sw + c) : zero;
     }
   }
-  tf_input(d, V);
   float* out = a.V + t * a.ldv + a.coff[blockIdx.z] + c;
   const long fs = a.T * a.ldv;
+  if (ACT == 0 && !DOUBLED) {
+    tf_input(d, V);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) st4(out + (i * 4 + j) * fs, V[i][j]);
+      for (int j = 0; j < 4; ++j) st4(out + (i * 4 + j) * fs, V[i][j]);
+  } else {
+    f32x4 e[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) e[i][j] = wino_act<ACT>(d[i][j]);
+    tf_input(e, V);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) st4(out + (i * 4 + j) * fs, V[i][j]);
+    if (DOUBLED) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[i][j] = wino_act<ACT>(-d[i][j]);
+      tf_input(e, V);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st4(out + a.C + (i * 4 + j) * fs, V[i][j]);
+    }
+  }
 }
 
 // dst(n, 2ta+i, 2tb+j, c) (+)= (A^T M A)[i][j] + bias[c],  M[f] = Mh[f][t][coff + c]
@@ -309,6 +345,167 @@ __global__ __launch_bounds__(256) void wino_filter_adj_kernel(const float* __res
     for (int j = 0; j < 3; ++j) st4(dst + (long)(i * 3 + j) * Cin * Cout, dg[i][j]);
 }
 
+
+// ---- 5x5 stride-2 layers as four stride-1 3x3 sub-convolutions ------------------------------
+// Input row 2a + kh - 1 of output row a: kh = 0,2,4 read the ODD input rows at sub-image offsets
+// -1,0,+1, kh = 1,3 the EVEN rows at offsets 0,+1.  With the 2-tap windows zero-padded to three
+// taps every (row parity, column parity) class is a 3x3 'SAME' correlation of the class's
+// sub-image X[r][c] = act(x)[2r+pi][2c+pj] on the OUTPUT grid, and the sum over the four classes
+// folds into the contraction index: 16 GEMMs with K = 4*Ceff (64 products per 2x2 output tile
+// and channel pair instead of 100).
+__device__ __forceinline__ int s2_tap(int parity, int i) {   // filter tap of window slot i, or -1
+  return parity ? 2 * i : (i == 0 ? -1 : 2 * i - 1);
+}
+
+// forward filters: U[f][co][cls*Ceff + ce] from wT[co][(kh*5+kw)*Ceff + ce]
+__global__ __launch_bounds__(256) void wino_s2_filter_fwd_kernel(const float* __restrict__ wT, int Ceff, int Cout,
+                                                               float* __restrict__ U) {
+  const int c4n = Ceff >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 4L * Cout * c4n) return;
+  const int ce = (int)(idx % c4n) * 4;
+  const long r = idx / c4n;
+  const int cls = (int)(r % 4), co = (int)(r / 4);
+  const int pi = cls >> 1, pj = cls & 1;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 g[3][3], Uv[4][4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int kh = s2_tap(pi, i), kw = s2_tap(pj, j);
+      g[i][j] = (kh >= 0 && kw >= 0) ? ld4(wT + ((long)co * 25 + kh * 5 + kw) * Ceff + ce) : zero;
+    }
+  tf_filter(g, Uv);
+  const long ldu = 4L * Ceff, fs = (long)Cout * ldu;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st4(U + (i * 4 + j) * fs + (long)co * ldu + (long)cls * Ceff + ce, Uv[i][j]);
+}
+
+// backward filters (flipped): U'[f][cls*Ceff + ce][co] from w[kh*5+kw][ce][co]
+__global__ __launch_bounds__(256) void wino_s2_filter_bwd_kernel(const float* __restrict__ w, int Ceff, int Cout,
+                                                               float* __restrict__ U) {
+  const int c4n = Cout >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 4L * Ceff * c4n) return;
+  const int co = (int)(idx % c4n) * 4;
+  const long r = idx / c4n;             // cls*Ceff + ce
+  const int ce = (int)(r % Ceff), cls = (int)(r / Ceff);
+  const int pi = cls >> 1, pj = cls & 1;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 g[3][3], Uv[4][4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int kh = s2_tap(pi, 2 - i), kw = s2_tap(pj, 2 - j);
+      g[i][j] = (kh >= 0 && kw >= 0) ? ld4(w + ((long)(kh * 5 + kw) * Ceff + ce) * Cout + co) : zero;
+    }
+  tf_filter(g, Uv);
+  const long fs = 4L * Ceff * Cout;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st4(U + (i * 4 + j) * fs + r * Cout + co, Uv[i][j]);
+}
+
+// dw[kh*5+kw][ce][co] = (G^T dU G)[i][j] of the tap's class; dU[f] = sum of slab[split][f][cls*Ceff+ce][co]
+__global__ __launch_bounds__(256) void wino_s2_filter_adj_kernel(const float* __restrict__ slabs, int nsplit,
+                                                               long split_stride, int Ceff, int Cout,
+                                                               float* __restrict__ dw) {
+  const int c4n = Cout >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 4L * Ceff * c4n) return;
+  const int co = (int)(idx % c4n) * 4;
+  const long r = idx / c4n;
+  const int ce = (int)(r % Ceff), cls = (int)(r / Ceff);
+  const int pi = cls >> 1, pj = cls & 1;
+  const long fs = 4L * Ceff * Cout;
+  const float* src = slabs + r * Cout + co;
+  f32x4 dU[4][4], dg[3][3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 sacc = ld4(src + (i * 4 + j) * fs);
+      for (int k = 1; k < nsplit; ++k) sacc += ld4(src + k * split_stride + (i * 4 + j) * fs);
+      dU[i][j] = sacc;
+    }
+  tf_filter_adj(dU, dg);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int kh = s2_tap(pi, i), kw = s2_tap(pj, j);
+      if (kh >= 0 && kw >= 0) st4(dw + ((long)(kh * 5 + kw) * Ceff + ce) * Cout + co, dg[i][j]);
+    }
+}
+
+// input gradient of a strided layer: per class the 2x2 tile of d/d(act(+-x)) at the class's
+// sub-image positions, combined through the activation derivative:
+//   dx = act'(x) * G[c] - act'(-x) * G[C + c]        (DOUBLED),   dx = act'(x) * G[c]  otherwise
+struct OutS2Args {
+  WView dx[4];          // per class: sub-image view of dx
+  View x[4];            // per class: sub-image view of x (activation derivative)
+  int TH, TW, C, Ceff;  // C = real channels
+  long T;
+  int ldm;              // 4*Ceff
+  const float* Xh;
+  int accumulate;
+};
+template <int ACT, bool DOUBLED>
+__global__ __launch_bounds__(256) void wino_s2_output_kernel(OutS2Args a) {
+  const int c4n = a.C >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.T * c4n) return;
+  const int c = (int)(idx % c4n) * 4;
+  const long t = idx / c4n;
+  const int tb = (int)(t % a.TW), ta = (int)((t / a.TW) % a.TH);
+  const long n = t / ((long)a.TW * a.TH);
+  const int cls = blockIdx.z;
+  const WView dv = a.dx[cls];
+  const View xv = a.x[cls];
+  const float* in = a.Xh + t * a.ldm + (long)cls * a.Ceff + c;
+  const long fs = a.T * a.ldm;
+  f32x4 M[4][4], Yp[2][2], Yn[2][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) M[i][j] = ld4(in + (i * 4 + j) * fs);
+  tf_output(M, Yp);
+  if (DOUBLED) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) M[i][j] = ld4(in + a.C + (i * 4 + j) * fs);
+    tf_output(M, Yn);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long off = n * dv.sn + (2 * ta + i) * dv.sh + (2 * tb + j) * dv.sw + c;
+      f32x4 o = Yp[i][j];
+      if (ACT != 0 || DOUBLED) {
+        const f32x4 x4 = ld4(xv.p + n * xv.sn + (2 * ta + i) * xv.sh + (2 * tb + j) * xv.sw + c);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float xq = x4[q];
+          float dp = 1.f, dn = 1.f;
+          if (ACT == 1) { dp = xq > 0.f ? 1.f : 0.f; dn = -xq > 0.f ? 1.f : 0.f; }
+          if (ACT == 2) { dp = xq > 0.f ? 1.f : expf(xq); dn = -xq > 0.f ? 1.f : expf(-xq); }
+          o[q] = dp * Yp[i][j][q];
+          if (DOUBLED) o[q] -= dn * Yn[i][j][q];
+        }
+      }
+      float* dst = dv.p + off;
+      if (a.accumulate) o += ld4(dst);
+      st4(dst, o);
+    }
+}
+
 // ---- the batched GEMM ---------------------------------------------------------------------
 // blockIdx.z = frequency f; blockIdx.y = K split; blockIdx.x -> (tm, tn) with the 8 XCDs taking
 // different row tiles, so that the column tiles that share an A row tile share an L2.
@@ -448,7 +645,7 @@ int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stri
   memset(&ia, 0, sizeof(ia));
   ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
   ia.H = g.H; ia.W = g.W; ia.TH = g.H / 2; ia.TW = g.W / 2; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.V = V;
-  hipLaunchKernelGGL(wino_input_kernel, dim3(grid1(T * (g.Cin / 4)), 1, 1), dim3(256), 0, s, ia);
+  hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(grid1(T * (g.Cin / 4)), 1, 1), dim3(256), 0, s, ia);
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.A = V; b.B = U; b.C = Mh; b.M = (int)T; b.N = N4; b.K = g.Cin;
@@ -480,7 +677,7 @@ int wino_dgrad(const WinoGeo& g, const float* dy, const float* weff, long cls_st
   class_views(g, dy + g.y_coff, g.ldy, ia.v);
   for (int cls = 0; cls < 4; ++cls) ia.coff[cls] = cls * g.Cout;
   ia.H = g.H; ia.W = g.W; ia.TH = g.H / 2; ia.TW = g.W / 2; ia.C = g.Cout; ia.T = T; ia.ldv = K4; ia.V = DV;
-  hipLaunchKernelGGL(wino_input_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 4), dim3(256), 0, s, ia);
+  hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(grid1(T * (g.Cout / 4)), 1, 4), dim3(256), 0, s, ia);
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.A = DV; b.B = U; b.C = Xh; b.M = (int)T; b.N = g.Cin; b.K = K4;
@@ -510,7 +707,7 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
   memset(&ia, 0, sizeof(ia));
   ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
   ia.H = g.H; ia.W = g.W; ia.TH = g.H / 2; ia.TW = g.W / 2; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.V = V;
-  hipLaunchKernelGGL(wino_input_kernel, dim3(grid1(T * (g.Cin / 4)), 1, 1), dim3(256), 0, s, ia);
+  hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(grid1(T * (g.Cin / 4)), 1, 1), dim3(256), 0, s, ia);
   InArgs da;
   memset(&da, 0, sizeof(da));
   class_views(g, dy + g.y_coff, g.ldy, da.v);
@@ -528,5 +725,155 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
   launch_bgemm<true>(b, ns, s);
   hipLaunchKernelGGL(wino_filter_adj_kernel, dim3(grid1(4L * g.Cin * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
                      16L * g.Cin * N4, g.Cin, g.Cout, dweff, cls_stride);
+  return OTGAN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stride-2 layers
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// the four input-parity sub-images of a [N, H, W, ld] buffer as views on the H/2 x W/2 grid
+template <class V, class P>
+void parity_views(int H, int W, P base, int ld, V (&v)[4]) {
+  for (int cls = 0; cls < 4; ++cls) {
+    const int pi = cls >> 1, pj = cls & 1;
+    v[cls].p = base + ((long)pi * W + pj) * ld;
+    v[cls].sn = (long)H * W * ld;
+    v[cls].sh = 2L * W * ld;
+    v[cls].sw = 2L * ld;
+  }
+}
+
+int s2_wgrad_splits(const WinoS2Geo& g) {
+  const long T = wino_s2_tiles(g);
+  const int blocks = ((4 * g.Ceff + 127) / 128) * ((g.Cout + 127) / 128) * 16;
+  int ns = (1024 + blocks - 1) / blocks;
+  if (ns > 8) ns = 8;
+  const int nkt = (int)((T + Cfg::BK - 1) / Cfg::BK);
+  while (ns > 1 && nkt / ns < 8) --ns;
+  return ns < 1 ? 1 : ns;
+}
+
+void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, hipStream_t s) {
+  const long T = wino_s2_tiles(g);
+  InArgs ia;
+  memset(&ia, 0, sizeof(ia));
+  parity_views(g.H, g.W, x, g.ldx, ia.v);
+  for (int cls = 0; cls < 4; ++cls) ia.coff[cls] = cls * g.Ceff;
+  ia.H = g.H / 2; ia.W = g.W / 2; ia.TH = g.H / 4; ia.TW = g.W / 4; ia.C = g.C; ia.T = T; ia.ldv = 4 * g.Ceff;
+  ia.V = V;
+  const dim3 grid(grid1(T * (g.C / 4)), 1, 4), blk(256);
+  if (g.doubled) {
+    if (g.act == 2) hipLaunchKernelGGL((wino_input_kernel<2, true>), grid, blk, 0, s, ia);
+    else hipLaunchKernelGGL((wino_input_kernel<1, true>), grid, blk, 0, s, ia);
+  } else if (g.act == 1) hipLaunchKernelGGL((wino_input_kernel<1, false>), grid, blk, 0, s, ia);
+  else if (g.act == 2) hipLaunchKernelGGL((wino_input_kernel<2, false>), grid, blk, 0, s, ia);
+  else hipLaunchKernelGGL((wino_input_kernel<0, false>), grid, blk, 0, s, ia);
+}
+
+}  // namespace
+
+size_t wino_s2_fwd_ws_floats(const WinoS2Geo& g) {
+  const size_t T = (size_t)wino_s2_tiles(g), K4 = 4 * (size_t)g.Ceff;
+  return 16 * T * K4 + 16 * T * g.Cout + 16 * K4 * g.Cout;
+}
+size_t wino_s2_dgrad_ws_floats(const WinoS2Geo& g) { return wino_s2_fwd_ws_floats(g); }
+size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g) {
+  const size_t T = (size_t)wino_s2_tiles(g), K4 = 4 * (size_t)g.Ceff;
+  return 16 * T * K4 + 16 * T * g.Cout + (size_t)s2_wgrad_splits(g) * 16 * K4 * g.Cout;
+}
+
+int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float* bias, float* y, float* ws,
+                hipStream_t s) {
+  const long T = wino_s2_tiles(g);
+  const int K4 = 4 * g.Ceff;
+  float* V = ws;                         // [16][T][4*Ceff]
+  float* Mh = V + 16 * T * K4;           // [16][T][Cout]
+  float* U = Mh + 16 * T * g.Cout;       // [16][Cout][4*Ceff]
+  hipLaunchKernelGGL(wino_s2_filter_fwd_kernel, dim3(grid1(4L * g.Cout * (g.Ceff / 4))), dim3(256), 0, s, wT, g.Ceff,
+                     g.Cout, U);
+  s2_input_transform(g, x, V, s);
+  BgArgs b;
+  memset(&b, 0, sizeof(b));
+  b.A = V; b.B = U; b.C = Mh; b.M = (int)T; b.N = g.Cout; b.K = K4;
+  b.lda = K4; b.ldb = K4; b.ldc = g.Cout;
+  b.sA = T * K4; b.sB = (long)g.Cout * K4; b.sC = T * g.Cout;
+  b.tiles_m = (int)((T + Cfg::BM - 1) / Cfg::BM); b.tiles_n = (g.Cout + Cfg::BN - 1) / Cfg::BN;
+  b.kt_per_split = (K4 + Cfg::BK - 1) / Cfg::BK;
+  launch_bgemm<false>(b, 1, s);
+  OutArgs oa;
+  memset(&oa, 0, sizeof(oa));
+  const int OH = g.H / 2, OW = g.W / 2;
+  oa.v[0].p = y + g.y_coff; oa.v[0].sn = (long)OH * OW * g.ldy; oa.v[0].sh = (long)OW * g.ldy; oa.v[0].sw = g.ldy;
+  oa.TH = OH / 2; oa.TW = OW / 2; oa.C = g.Cout; oa.T = T; oa.ldm = g.Cout; oa.Mh = Mh; oa.bias = bias;
+  hipLaunchKernelGGL(wino_output_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 1), dim3(256), 0, s, oa);
+  return OTGAN_OK;
+}
+
+int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const float* x, float* dx, int lddx,
+                  int accumulate, float* ws, hipStream_t s) {
+  const long T = wino_s2_tiles(g);
+  const int K4 = 4 * g.Ceff;
+  const int OH = g.H / 2, OW = g.W / 2;
+  float* DV = ws;                        // [16][T][Cout]
+  float* Xh = DV + 16 * T * g.Cout;      // [16][T][4*Ceff]
+  float* U = Xh + 16 * T * K4;           // [16][4*Ceff][Cout]
+  hipLaunchKernelGGL(wino_s2_filter_bwd_kernel, dim3(grid1(4L * g.Ceff * (g.Cout / 4))), dim3(256), 0, s, w, g.Ceff,
+                     g.Cout, U);
+  InArgs ia;
+  memset(&ia, 0, sizeof(ia));
+  ia.v[0].p = dy + g.y_coff; ia.v[0].sn = (long)OH * OW * g.ldy; ia.v[0].sh = (long)OW * g.ldy; ia.v[0].sw = g.ldy;
+  ia.H = OH; ia.W = OW; ia.TH = OH / 2; ia.TW = OW / 2; ia.C = g.Cout; ia.T = T; ia.ldv = g.Cout; ia.V = DV;
+  hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(grid1(T * (g.Cout / 4)), 1, 1), dim3(256), 0, s, ia);
+  BgArgs b;
+  memset(&b, 0, sizeof(b));
+  b.A = DV; b.B = U; b.C = Xh; b.M = (int)T; b.N = K4; b.K = g.Cout;
+  b.lda = g.Cout; b.ldb = g.Cout; b.ldc = K4;
+  b.sA = T * g.Cout; b.sB = (long)K4 * g.Cout; b.sC = T * K4;
+  b.tiles_m = (int)((T + Cfg::BM - 1) / Cfg::BM); b.tiles_n = (K4 + Cfg::BN - 1) / Cfg::BN;
+  b.kt_per_split = (g.Cout + Cfg::BK - 1) / Cfg::BK;
+  launch_bgemm<false>(b, 1, s);
+  OutS2Args oa;
+  memset(&oa, 0, sizeof(oa));
+  parity_views(g.H, g.W, dx, lddx, oa.dx);
+  parity_views(g.H, g.W, x, g.ldx, oa.x);
+  oa.TH = OH / 2; oa.TW = OW / 2; oa.C = g.C; oa.Ceff = g.Ceff; oa.T = T; oa.ldm = K4; oa.Xh = Xh;
+  oa.accumulate = accumulate;
+  const dim3 grid(grid1(T * (g.C / 4)), 1, 4), blk(256);
+  if (g.doubled) {
+    if (g.act == 2) hipLaunchKernelGGL((wino_s2_output_kernel<2, true>), grid, blk, 0, s, oa);
+    else hipLaunchKernelGGL((wino_s2_output_kernel<1, true>), grid, blk, 0, s, oa);
+  } else if (g.act == 1) hipLaunchKernelGGL((wino_s2_output_kernel<1, false>), grid, blk, 0, s, oa);
+  else if (g.act == 2) hipLaunchKernelGGL((wino_s2_output_kernel<2, false>), grid, blk, 0, s, oa);
+  else hipLaunchKernelGGL((wino_s2_output_kernel<0, false>), grid, blk, 0, s, oa);
+  return OTGAN_OK;
+}
+
+int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw, float* ws, hipStream_t s) {
+  const long T = wino_s2_tiles(g);
+  const int K4 = 4 * g.Ceff;
+  const int OH = g.H / 2, OW = g.W / 2;
+  const int ns = s2_wgrad_splits(g);
+  float* V = ws;                         // [16][T][4*Ceff]
+  float* dM = V + 16 * T * K4;           // [16][T][Cout]
+  float* slabs = dM + 16 * T * g.Cout;   // [ns][16][4*Ceff][Cout]
+  s2_input_transform(g, x, V, s);
+  InArgs da;
+  memset(&da, 0, sizeof(da));
+  da.v[0].p = dy + g.y_coff; da.v[0].sn = (long)OH * OW * g.ldy; da.v[0].sh = (long)OW * g.ldy; da.v[0].sw = g.ldy;
+  da.H = OH; da.W = OW; da.TH = OH / 2; da.TW = OW / 2; da.C = g.Cout; da.T = T; da.ldv = g.Cout; da.V = dM;
+  hipLaunchKernelGGL(wino_outadj_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 1), dim3(256), 0, s, da);
+  BgArgs b;
+  memset(&b, 0, sizeof(b));
+  b.A = V; b.B = dM; b.C = slabs; b.M = K4; b.N = g.Cout; b.K = (int)T;
+  b.lda = K4; b.ldb = g.Cout; b.ldc = g.Cout;
+  b.sA = T * K4; b.sB = T * g.Cout; b.sC = (long)K4 * g.Cout; b.sSplit = 16L * K4 * g.Cout;
+  b.tiles_m = (K4 + Cfg::BM - 1) / Cfg::BM; b.tiles_n = (g.Cout + Cfg::BN - 1) / Cfg::BN;
+  const int nkt = (int)((T + Cfg::BK - 1) / Cfg::BK);
+  b.kt_per_split = (nkt + ns - 1) / ns;
+  launch_bgemm<true>(b, ns, s);
+  hipLaunchKernelGGL(wino_s2_filter_adj_kernel, dim3(grid1(4L * g.Ceff * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
+                     16L * K4 * g.Cout, g.Ceff, g.Cout, dw);
   return OTGAN_OK;
 }

@@ -48,6 +48,13 @@ CONV_CASES = [
     ("wino_ragged", 3, 8, 8, (96,), 24, 5, 1, True, None),
     ("wino_wide", 5, 16, 16, (32,), 160, 5, 1, True, None),
     ("wino_split_k", 16, 16, 16, (64,), 32, 5, 1, True, None),
+    # 5x5 stride-2 layers: four 3x3 sub-convolutions in Winograd form (single-tensor inputs)
+    ("wino_s2_plain", 2, 8, 8, (32,), 24, 5, 2, False, None),
+    ("wino_s2_elu", 2, 8, 8, (32,), 16, 5, 2, False, "elu"),
+    ("wino_s2_celu", 2, 16, 16, (16,), 40, 5, 2, False, "celu"),
+    ("wino_s2_relu", 3, 4, 4, (64,), 132, 5, 2, False, "relu"),
+    ("wino_s2_split_k", 24, 16, 16, (32,), 32, 5, 2, False, "crelu"),
+    ("list_s2_k5_generic", 2, 8, 8, (16, 16), 32, 5, 2, False, "crelu"),
     # DenseNet growth layers (3x3 -> 16 channels): the LDS-free dense16 kernels
     ("dense16_list", 2, 8, 8, (32, 16, 16), 16, 3, 1, False, "crelu"),
     ("dense16_tail", 3, 8, 8, (24, 16), 16, 3, 1, False, "crelu"),
