@@ -575,6 +575,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void wino_bgemm_kernel(BgArgs a) {
   });
 }
 
+
 template <bool TN>
 void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
   size_t lds;
