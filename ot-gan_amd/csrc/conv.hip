@@ -1482,7 +1482,7 @@ int otgan_conv2d_fwd_f32(const otgan_conv_desc* d, const float* x, const int32_t
   if (wino_s2_ok(d, g) && cmap == nullptr && aligned16(x) && aligned16(wT) && aligned16(y) && aligned16(bias) &&
       aligned16(workspace) && workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 0)) {
     const WinoS2Geo w = wino_s2_geo(d, g);
-    ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * 16.0 * (double)wino_s2_tiles(w) * 4.0 * g.Ceff * d->Cout, 0.0, s);
+    ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * 49.0 * (double)wino_s2_tiles(w) * g.Ceff * d->Cout, 0.0, s);
     rc = wino_s2_fwd(w, x, wT, bias, y, (float*)workspace, s);
     OTGAN_CHECK_LAUNCH("conv2d fwd (winograd, stride 2)");
     return rc;
@@ -1664,7 +1664,7 @@ int otgan_conv2d_dgrad_f32(const otgan_conv_desc* d, const float* dy, const floa
   if (wino_s2_ok(d, g) && inv == nullptr && lddx % 4 == 0 && aligned16(dy) && aligned16(w) && aligned16(dx) &&
       aligned16(x) && aligned16(workspace) && workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 1)) {
     const WinoS2Geo wg = wino_s2_geo(d, g);
-    ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * 16.0 * (double)wino_s2_tiles(wg) * 4.0 * g.Ceff * d->Cout, 0.0, s);
+    ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * 49.0 * (double)wino_s2_tiles(wg) * g.Ceff * d->Cout, 0.0, s);
     rc = wino_s2_dgrad(wg, dy, w, x, dx, lddx, accumulate, (float*)workspace, s);
     OTGAN_CHECK_LAUNCH("conv2d dgrad (winograd, stride 2)");
     return rc;
@@ -1799,7 +1799,7 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
   if (wino_s2_ok(d, g) && cmap == nullptr && aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace) &&
       workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 2)) {
     const WinoS2Geo wg = wino_s2_geo(d, g);
-    ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * 16.0 * (double)wino_s2_tiles(wg) * 4.0 * g.Ceff * d->Cout, 0.0, s);
+    ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * 49.0 * (double)wino_s2_tiles(wg) * g.Ceff * d->Cout, 0.0, s);
     rc = wino_s2_wgrad(wg, x, dy, dw, (float*)workspace, s);
     OTGAN_CHECK_LAUNCH("conv2d wgrad (winograd, stride 2)");
     return rc;

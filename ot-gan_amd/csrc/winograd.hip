@@ -28,6 +28,11 @@ inline void ensure_lds(size_t bytes) {
   (void)done;
 }
 
+__host__ __device__ __forceinline__ bool s2_present(int cls, int f, int skip) {
+  const int pi = cls >> 1, pj = cls & 1, fi = f >> 2, fj = f & 3;
+  return (pi || fi != skip) && (pj || fj != skip);
+}
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
@@ -137,6 +142,7 @@ struct InArgs {
   long T;
   int ldv;               // row length of V
   float* V;
+  int s2_skip;           // >= 0: strided layer, the (class = blockIdx.z, f) blocks absent under this index are not stored
 };
 template <int ACT>
 __device__ __forceinline__ f32x4 wino_act(f32x4 v) {
@@ -178,18 +184,21 @@ __global__ __launch_bounds__(256) void wino_input_kernel(InArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) st4(out + (i * 4 + j) * fs, V[i][j]);
+      for (int j = 0; j < 4; ++j)
+        if (a.s2_skip < 0 || s2_present(blockIdx.z, i * 4 + j, a.s2_skip)) st4(out + (i * 4 + j) * fs, V[i][j]);
   } else {
     f32x4 e[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) e[i][j] = wino_act<ACT>(d[i][j]);
+    const int cls = blockIdx.z;
     tf_input(e, V);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) st4(out + (i * 4 + j) * fs, V[i][j]);
+      for (int j = 0; j < 4; ++j)
+        if (a.s2_skip < 0 || s2_present(cls, i * 4 + j, a.s2_skip)) st4(out + (i * 4 + j) * fs, V[i][j]);
     if (DOUBLED) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -199,7 +208,8 @@ __global__ __launch_bounds__(256) void wino_input_kernel(InArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) st4(out + a.C + (i * 4 + j) * fs, V[i][j]);
+        for (int j = 0; j < 4; ++j)
+          if (a.s2_skip < 0 || s2_present(cls, i * 4 + j, a.s2_skip)) st4(out + a.C + (i * 4 + j) * fs, V[i][j]);
     }
   }
 }
@@ -429,8 +439,11 @@ __global__ __launch_bounds__(256) void wino_s2_filter_adj_kernel(const float* __
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      f32x4 sacc = ld4(src + (i * 4 + j) * fs);
-      for (int k = 1; k < nsplit; ++k) sacc += ld4(src + k * split_stride + (i * 4 + j) * fs);
+      f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+      if (s2_present(cls, i * 4 + j, 0)) {
+        sacc = ld4(src + (i * 4 + j) * fs);
+        for (int k = 1; k < nsplit; ++k) sacc += ld4(src + k * split_stride + (i * 4 + j) * fs);
+      }
       dU[i][j] = sacc;
     }
   tf_filter_adj(dU, dg);
@@ -469,17 +482,18 @@ __global__ __launch_bounds__(256) void wino_s2_output_kernel(OutS2Args a) {
   const View xv = a.x[cls];
   const float* in = a.Xh + t * a.ldm + (long)cls * a.Ceff + c;
   const long fs = a.T * a.ldm;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   f32x4 M[4][4], Yp[2][2], Yn[2][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) M[i][j] = ld4(in + (i * 4 + j) * fs);
+    for (int j = 0; j < 4; ++j) M[i][j] = s2_present(cls, i * 4 + j, 3) ? ld4(in + (i * 4 + j) * fs) : zero;
   tf_output(M, Yp);
   if (DOUBLED) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) M[i][j] = ld4(in + a.C + (i * 4 + j) * fs);
+      for (int j = 0; j < 4; ++j) M[i][j] = s2_present(cls, i * 4 + j, 3) ? ld4(in + a.C + (i * 4 + j) * fs) : zero;
     tf_output(M, Yn);
   }
 #pragma unroll
@@ -520,7 +534,14 @@ struct BgArgs {
   long sA, sB, sC, sSplit;
   int tiles_m, tiles_n, kt_per_split;
   int xmap;   // 1: XCD = row-tile residue, 2: XCD = column-tile residue, 0: linear
+  // Strided layers: the zero-padded 2-tap windows make the filter transform of an even-parity
+  // class vanish at one frequency index per dimension (G row 0 picks the zero tap in the forward
+  // orientation, row 3 in the flipped one), so 15 of the 64 (class, frequency) blocks are
+  // structurally zero and are skipped: seg_mode 1 = classes along K (forward), 2 = along N
+  // (dgrad), 3 = along M (wgrad); seg_len = channels per class; seg_skip = vanishing index.
+  int seg_mode, seg_len, seg_skip;
 };
+
 
 template <bool TN>
 __global__ __launch_bounds__(Cfg::THREADS) void wino_bgemm_kernel(BgArgs a) {
@@ -542,6 +563,16 @@ __global__ __launch_bounds__(Cfg::THREADS) void wino_bgemm_kernel(BgArgs a) {
     tm = x / a.tiles_n;
   }
   const int f = blockIdx.z;
+  if (a.seg_mode == 2 || a.seg_mode == 3) {
+    // skip a tile whose rows (wgrad) / columns (dgrad) all belong to classes absent at f
+    const int lo = (a.seg_mode == 2 ? tn * Cfg::BN : tm * Cfg::BM);
+    const int ext = (a.seg_mode == 2 ? a.N : a.M);
+    int hi = lo + (a.seg_mode == 2 ? Cfg::BN : Cfg::BM) - 1;
+    if (hi >= ext) hi = ext - 1;
+    bool any = false;
+    for (int c = lo / a.seg_len; c <= hi / a.seg_len; ++c) any = any || s2_present(c, f, a.seg_skip);
+    if (!any) return;
+  }
   const int nkt_all = (a.K + Cfg::BK - 1) / Cfg::BK;
   const int kt0 = blockIdx.y * a.kt_per_split;
   int nkt = nkt_all - kt0;
@@ -558,6 +589,26 @@ __global__ __launch_bounds__(Cfg::THREADS) void wino_bgemm_kernel(BgArgs a) {
       la.init(a.A + f * a.sA + (long)kt0 * Cfg::BK * a.lda + m0, a.lda, a.M - m0, a.K - kt0 * Cfg::BK);
       lb.init(a.B + f * a.sB + (long)kt0 * Cfg::BK * a.ldb + n0, a.ldb, a.N - n0, a.K - kt0 * Cfg::BK);
       gemm_mainloop<Cfg>(la, lb, nkt, smem, acc);
+    } else if (a.seg_mode == 1) {
+      // forward of a strided layer: contract only over the classes present at f (<= 2 contiguous runs)
+      using LA = MatLoaderK<Cfg, Cfg::BM, true>;
+      using LB = MatLoaderK<Cfg, Cfg::BN, true>;
+      int c = 0;
+      while (c < 4) {
+        if (!s2_present(c, f, a.seg_skip)) {
+          ++c;
+          continue;
+        }
+        int e = c + 1;
+        while (e < 4 && s2_present(e, f, a.seg_skip)) ++e;
+        const int klen = (e - c) * a.seg_len;
+        LA la;
+        LB lb;
+        la.init(a.A + f * a.sA + (long)m0 * a.lda + (long)c * a.seg_len, a.lda, a.M - m0, klen);
+        lb.init(a.B + f * a.sB + (long)n0 * a.ldb + (long)c * a.seg_len, a.ldb, a.N - n0, klen);
+        gemm_mainloop<Cfg>(la, lb, klen / Cfg::BK, smem, acc);
+        c = e;
+      }
     } else {
       using LA = MatLoaderK<Cfg, Cfg::BM, true>;
       using LB = MatLoaderK<Cfg, Cfg::BN, true>;
@@ -644,6 +695,7 @@ int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stri
                      g.Cin, g.Cout, U);
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
+  ia.s2_skip = -1;
   ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
   ia.H = g.H; ia.W = g.W; ia.TH = g.H / 2; ia.TW = g.W / 2; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.V = V;
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(grid1(T * (g.Cin / 4)), 1, 1), dim3(256), 0, s, ia);
@@ -675,6 +727,7 @@ int wino_dgrad(const WinoGeo& g, const float* dy, const float* weff, long cls_st
                      g.Cin, g.Cout, U);
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
+  ia.s2_skip = -1;
   class_views(g, dy + g.y_coff, g.ldy, ia.v);
   for (int cls = 0; cls < 4; ++cls) ia.coff[cls] = cls * g.Cout;
   ia.H = g.H; ia.W = g.W; ia.TH = g.H / 2; ia.TW = g.W / 2; ia.C = g.Cout; ia.T = T; ia.ldv = K4; ia.V = DV;
@@ -706,11 +759,13 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
   float* slabs = dM + 16 * T * N4;      // [ns][16][Cin][4*Cout]
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
+  ia.s2_skip = -1;
   ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
   ia.H = g.H; ia.W = g.W; ia.TH = g.H / 2; ia.TW = g.W / 2; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.V = V;
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(grid1(T * (g.Cin / 4)), 1, 1), dim3(256), 0, s, ia);
   InArgs da;
   memset(&da, 0, sizeof(da));
+  da.s2_skip = -1;
   class_views(g, dy + g.y_coff, g.ldy, da.v);
   for (int cls = 0; cls < 4; ++cls) da.coff[cls] = cls * g.Cout;
   da.H = g.H; da.W = g.W; da.TH = g.H / 2; da.TW = g.W / 2; da.C = g.Cout; da.T = T; da.ldv = N4; da.V = dM;
@@ -760,10 +815,12 @@ void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, hipStream_
   const long T = wino_s2_tiles(g);
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
+  ia.s2_skip = -1;
   parity_views(g.H, g.W, x, g.ldx, ia.v);
   for (int cls = 0; cls < 4; ++cls) ia.coff[cls] = cls * g.Ceff;
   ia.H = g.H / 2; ia.W = g.W / 2; ia.TH = g.H / 4; ia.TW = g.W / 4; ia.C = g.C; ia.T = T; ia.ldv = 4 * g.Ceff;
   ia.V = V;
+  ia.s2_skip = 0;
   const dim3 grid(grid1(T * (g.C / 4)), 1, 4), blk(256);
   if (g.doubled) {
     if (g.act == 2) hipLaunchKernelGGL((wino_input_kernel<2, true>), grid, blk, 0, s, ia);
@@ -802,6 +859,7 @@ int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float
   b.sA = T * K4; b.sB = (long)g.Cout * K4; b.sC = T * g.Cout;
   b.tiles_m = (int)((T + Cfg::BM - 1) / Cfg::BM); b.tiles_n = (g.Cout + Cfg::BN - 1) / Cfg::BN;
   b.kt_per_split = (K4 + Cfg::BK - 1) / Cfg::BK;
+  b.seg_mode = 1; b.seg_len = g.Ceff; b.seg_skip = 0;
   launch_bgemm<false>(b, 1, s);
   OutArgs oa;
   memset(&oa, 0, sizeof(oa));
@@ -824,6 +882,7 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
                      g.Cout, U);
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
+  ia.s2_skip = -1;
   ia.v[0].p = dy + g.y_coff; ia.v[0].sn = (long)OH * OW * g.ldy; ia.v[0].sh = (long)OW * g.ldy; ia.v[0].sw = g.ldy;
   ia.H = OH; ia.W = OW; ia.TH = OH / 2; ia.TW = OW / 2; ia.C = g.Cout; ia.T = T; ia.ldv = g.Cout; ia.V = DV;
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(grid1(T * (g.Cout / 4)), 1, 1), dim3(256), 0, s, ia);
@@ -834,6 +893,7 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   b.sA = T * g.Cout; b.sB = (long)K4 * g.Cout; b.sC = T * K4;
   b.tiles_m = (int)((T + Cfg::BM - 1) / Cfg::BM); b.tiles_n = (K4 + Cfg::BN - 1) / Cfg::BN;
   b.kt_per_split = (g.Cout + Cfg::BK - 1) / Cfg::BK;
+  b.seg_mode = 2; b.seg_len = g.Ceff; b.seg_skip = 3;
   launch_bgemm<false>(b, 1, s);
   OutS2Args oa;
   memset(&oa, 0, sizeof(oa));
@@ -862,6 +922,7 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
   s2_input_transform(g, x, V, s);
   InArgs da;
   memset(&da, 0, sizeof(da));
+  da.s2_skip = -1;
   da.v[0].p = dy + g.y_coff; da.v[0].sn = (long)OH * OW * g.ldy; da.v[0].sh = (long)OW * g.ldy; da.v[0].sw = g.ldy;
   da.H = OH; da.W = OW; da.TH = OH / 2; da.TW = OW / 2; da.C = g.Cout; da.T = T; da.ldv = g.Cout; da.V = dM;
   hipLaunchKernelGGL(wino_outadj_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 1), dim3(256), 0, s, da);
@@ -873,6 +934,7 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
   b.tiles_m = (K4 + Cfg::BM - 1) / Cfg::BM; b.tiles_n = (g.Cout + Cfg::BN - 1) / Cfg::BN;
   const int nkt = (int)((T + Cfg::BK - 1) / Cfg::BK);
   b.kt_per_split = (nkt + ns - 1) / ns;
+  b.seg_mode = 3; b.seg_len = g.Ceff; b.seg_skip = 0;
   launch_bgemm<true>(b, ns, s);
   hipLaunchKernelGGL(wino_s2_filter_adj_kernel, dim3(grid1(4L * g.Ceff * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
                      16L * K4 * g.Cout, g.Ceff, g.Cout, dw);
