@@ -96,7 +96,7 @@ def ptr(t):
 
 # ---- profiler helpers -------------------------------------------------------------------
 PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "cost_gemm", "sinkhorn", "plan_apply",
-                "pointwise")
+                "pointwise", "wino_gemm")
 
 
 def prof_enable(on=True):

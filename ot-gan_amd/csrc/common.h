@@ -46,7 +46,8 @@ enum OtganProfClass {
   OTGAN_PROF_SINKHORN = 4,
   OTGAN_PROF_PLAN_APPLY = 5,
   OTGAN_PROF_POINTWISE = 6,
-  OTGAN_PROF_NCLASS = 7
+  OTGAN_PROF_WINO_GEMM = 7,  // the batched Winograd-domain GEMM alone (nested inside the conv classes)
+  OTGAN_PROF_NCLASS = 8
 };
 void otgan_prof_begin(int cls, double flops, double bytes, hipStream_t s);
 void otgan_prof_end(int cls, hipStream_t s);

@@ -633,6 +633,10 @@ void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
   if (TN) lds = sizeof(float) * 2 * (MatLoaderR<Cfg, Cfg::BM, true>::FLOATS + MatLoaderR<Cfg, Cfg::BN, true>::FLOATS);
   else lds = sizeof(float) * 2 * (MatLoaderK<Cfg, Cfg::BM, true>::FLOATS + MatLoaderK<Cfg, Cfg::BN, true>::FLOATS);
   ensure_lds<wino_bgemm_kernel<TN>>(lds);
+  // executed FLOP: 16 GEMMs, minus the skipped (class, frequency) blocks of the strided layers
+  double flop = 2.0 * 16.0 * (double)a.M * a.N * a.K;
+  if (a.seg_mode) flop *= 49.0 / 64.0;
+  ProfScope ps(OTGAN_PROF_WINO_GEMM, flop, 0.0, s);
   BgArgs b = a;
   b.xmap = (a.tiles_m % 8 == 0) ? 1 : (a.tiles_n % 8 == 0) ? 2 : 0;
   const dim3 grid(a.tiles_m * a.tiles_n, nsplit, 16);
