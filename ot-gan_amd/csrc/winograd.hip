@@ -638,7 +638,11 @@ void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
   if (a.seg_mode) flop *= 49.0 / 64.0;
   ProfScope ps(OTGAN_PROF_WINO_GEMM, flop, 0.0, s);
   BgArgs b = a;
-  b.xmap = (a.tiles_m % 8 == 0) ? 1 : (a.tiles_n % 8 == 0) ? 2 : 0;
+  // partition the LARGER operand across the XCDs (each part is then fetched by one L2 only);
+  // the smaller one is re-read by all eight
+  const bool m_ok = a.tiles_m % 8 == 0, n_ok = a.tiles_n % 8 == 0;
+  if (a.M >= a.N) b.xmap = m_ok ? 1 : n_ok ? 2 : 0;
+  else b.xmap = n_ok ? 2 : m_ok ? 1 : 0;
   const dim3 grid(a.tiles_m * a.tiles_n, nsplit, 16);
   hipLaunchKernelGGL((wino_bgemm_kernel<TN>), grid, dim3(Cfg::THREADS), lds, s, b);
 }
