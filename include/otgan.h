@@ -44,8 +44,10 @@ const char* otgan_last_error(void);
 /* ---------------------------------------------------------------------------------------
  * Per-kernel-class HIP-event timing (measurement support for bench.py's roofline leg).
  * Classes: 0 conv_fwd, 1 conv_dgrad, 2 conv_wgrad, 3 cost_gemm, 4 sinkhorn, 5 plan_apply,
- * 6 pointwise, 7 wino_gemm (the batched Winograd-domain GEMM kernel alone; its launches are also
- * part of the conv class they belong to).  While enabled every launch of a class is bracketed by hipEvents on its
+ * 6 pointwise, 7 wino_gemm (the batched Winograd-domain GEMM kernel alone, fp32 MFMA; its launches
+ * are also part of the conv class they belong to), 8 wino_gemm_bf16x3 (the same GEMM on the bf16
+ * pipe with split-precision operands; FLOP counted as executed bf16 FLOP = 6 per fp32 product).
+ * While enabled every launch of a class is bracketed by hipEvents on its
  * launch stream; otgan_prof_collect() synchronises and returns the totals since the last
  * reset: out[0]=launches, out[1]=sum of milliseconds, out[2]=sum of algorithmic FLOP,
  * out[3]=sum of algorithmic bytes.

@@ -96,7 +96,7 @@ def ptr(t):
 
 # ---- profiler helpers -------------------------------------------------------------------
 PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "cost_gemm", "sinkhorn", "plan_apply",
-                "pointwise", "wino_gemm")
+                "pointwise", "wino_gemm", "wino_gemm_bf16x3")
 
 
 def prof_enable(on=True):

@@ -46,8 +46,9 @@ enum OtganProfClass {
   OTGAN_PROF_SINKHORN = 4,
   OTGAN_PROF_PLAN_APPLY = 5,
   OTGAN_PROF_POINTWISE = 6,
-  OTGAN_PROF_WINO_GEMM = 7,  // the batched Winograd-domain GEMM alone (nested inside the conv classes)
-  OTGAN_PROF_NCLASS = 8
+  OTGAN_PROF_WINO_GEMM = 7,     // the batched Winograd-domain GEMM alone, fp32 MFMA engine (nested inside the conv classes)
+  OTGAN_PROF_WINO_GEMM_X3 = 8,  // the same on the bf16 pipe with split-precision operands; FLOP = executed bf16 FLOP (6 per fp32 product)
+  OTGAN_PROF_NCLASS = 9
 };
 void otgan_prof_begin(int cls, double flops, double bytes, hipStream_t s);
 void otgan_prof_end(int cls, hipStream_t s);

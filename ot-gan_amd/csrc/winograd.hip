@@ -36,6 +36,45 @@ __host__ __device__ __forceinline__ bool s2_present(int cls, int f, int skip) {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// ---- split-precision operands -----------------------------------------------------------------
+// The NT GEMMs (forward / dgrad of both layer families) run on the bf16 matrix pipe with
+// fp32-exact products: every fp32 operand is stored as three bf16 planes x = hi + mid + lo
+// (8 + 8 + 8 mantissa bits) by the kernel that produces it, and the GEMM issues the six MFMAs
+// hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid per k slab, accumulating in fp32.  Measured
+// 2.3e-7 .. 5e-7 relative L2 against fp64 at K = 256 .. 1024 (the fp32 MFMA chain: 1.3e-6).
+typedef unsigned short u16;
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned bf16_rne(float x) {
+  unsigned u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+// planes[p][idx .. idx+3] = p-th bf16 piece of v
+__device__ __forceinline__ void st_split4(u16* planes, long plane_stride, long idx, f32x4 v) {
+  u16x4 h, m, l;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned a1 = bf16_rne(v[j]);
+    const float r1 = v[j] - __uint_as_float(a1 << 16);
+    const unsigned a2 = bf16_rne(r1);
+    const float r2 = r1 - __uint_as_float(a2 << 16);
+    h[j] = (u16)a1;
+    m[j] = (u16)a2;
+    l[j] = (u16)bf16_rne(r2);
+  }
+  *reinterpret_cast<u16x4*>(planes + idx) = h;
+  *reinterpret_cast<u16x4*>(planes + plane_stride + idx) = m;
+  *reinterpret_cast<u16x4*>(planes + 2 * plane_stride + idx) = l;
+}
+// store element group idx of a [16][rows][ld] operand either as fp32 or as three bf16 planes
+__device__ __forceinline__ void st_operand(float* F, u16* P, long plane_stride, long idx, f32x4 v) {
+  if (P) st_split4(P, plane_stride, idx, v);
+  else st4(F + idx, v);
+}
+
 // ---- the four small transforms, on float4 = four channels at once -------------------------
 // V = B^T d B
 __device__ __forceinline__ void tf_input(const f32x4 (&d)[4][4], f32x4 (&V)[4][4]) {
@@ -143,6 +182,7 @@ struct InArgs {
   int ldv;               // row length of V
   float* V;
   int s2_skip;           // >= 0: strided layer, the (class = blockIdx.z, f) blocks absent under this index are not stored
+  u16* P;                // non-null: write the operand as three bf16 planes (plane stride 16*T*ldv) instead of V
 };
 template <int ACT>
 __device__ __forceinline__ f32x4 wino_act(f32x4 v) {
@@ -177,15 +217,15 @@ __global__ __launch_bounds__(256) void wino_input_kernel(InArgs a) {
       d[i][j] = ok ? ld4(v.p + n * v.sn + r * v.sh + q * v.sw + c) : zero;
     }
   }
-  float* out = a.V + t * a.ldv + a.coff[blockIdx.z] + c;
-  const long fs = a.T * a.ldv;
+  const long o0 = t * a.ldv + a.coff[blockIdx.z] + c;
+  const long fs = a.T * a.ldv, ps = 16 * fs;
   if (ACT == 0 && !DOUBLED) {
     tf_input(d, V);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (a.s2_skip < 0 || s2_present(blockIdx.z, i * 4 + j, a.s2_skip)) st4(out + (i * 4 + j) * fs, V[i][j]);
+        if (a.s2_skip < 0 || s2_present(blockIdx.z, i * 4 + j, a.s2_skip)) st_operand(a.V, a.P, ps, o0 + (i * 4 + j) * fs, V[i][j]);
   } else {
     f32x4 e[4][4];
 #pragma unroll
@@ -198,7 +238,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(InArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (a.s2_skip < 0 || s2_present(cls, i * 4 + j, a.s2_skip)) st4(out + (i * 4 + j) * fs, V[i][j]);
+        if (a.s2_skip < 0 || s2_present(cls, i * 4 + j, a.s2_skip)) st_operand(a.V, a.P, ps, o0 + (i * 4 + j) * fs, V[i][j]);
     if (DOUBLED) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -209,7 +249,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(InArgs a) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (a.s2_skip < 0 || s2_present(cls, i * 4 + j, a.s2_skip)) st4(out + a.C + (i * 4 + j) * fs, V[i][j]);
+          if (a.s2_skip < 0 || s2_present(cls, i * 4 + j, a.s2_skip)) st_operand(a.V, a.P, ps, o0 + a.C + (i * 4 + j) * fs, V[i][j]);
     }
   }
 }
@@ -281,7 +321,7 @@ __global__ __launch_bounds__(256) void wino_outadj_kernel(InArgs a) {
 
 // forward filters: U[f][cls*Cout + co][ci] from weffT[cls][co][tap*Cin + ci]
 __global__ __launch_bounds__(256) void wino_filter_fwd_kernel(const float* __restrict__ weffT, long cls_stride,
-                                                            int Cin, int Cout, float* __restrict__ U) {
+                                                            int Cin, int Cout, float* __restrict__ U, u16* P) {
   const int c4n = Cin >> 2;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   const long rows = 4L * Cout;
@@ -300,12 +340,12 @@ __global__ __launch_bounds__(256) void wino_filter_fwd_kernel(const float* __res
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) st4(U + (i * 4 + j) * fs + row * Cin + ci, Uv[i][j]);
+    for (int j = 0; j < 4; ++j) st_operand(U, P, 16 * fs, (i * 4 + j) * fs + row * Cin + ci, Uv[i][j]);
 }
 
 // backward filters (flipped taps): U'[f][ci][cls*Cout + co] from weff[cls][tap][ci][co]
 __global__ __launch_bounds__(256) void wino_filter_bwd_kernel(const float* __restrict__ weff, long cls_stride,
-                                                            int Cin, int Cout, float* __restrict__ U) {
+                                                            int Cin, int Cout, float* __restrict__ U, u16* P) {
   const int c4n = Cout >> 2;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= 4L * Cin * c4n) return;
@@ -323,7 +363,7 @@ __global__ __launch_bounds__(256) void wino_filter_bwd_kernel(const float* __res
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) st4(U + (i * 4 + j) * fs + (long)ci * ldu + (long)cls * Cout + co, Uv[i][j]);
+    for (int j = 0; j < 4; ++j) st_operand(U, P, 16 * fs, (i * 4 + j) * fs + (long)ci * ldu + (long)cls * Cout + co, Uv[i][j]);
 }
 
 // dweff[cls][tap][ci][co] = (G^T dU G)[tap],  dU[f] = sum over splits of slab[split][f][ci][cls*Cout + co]
@@ -369,7 +409,7 @@ __device__ __forceinline__ int s2_tap(int parity, int i) {   // filter tap of wi
 
 // forward filters: U[f][co][cls*Ceff + ce] from wT[co][(kh*5+kw)*Ceff + ce]
 __global__ __launch_bounds__(256) void wino_s2_filter_fwd_kernel(const float* __restrict__ wT, int Ceff, int Cout,
-                                                               float* __restrict__ U) {
+                                                               float* __restrict__ U, u16* P) {
   const int c4n = Ceff >> 2;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= 4L * Cout * c4n) return;
@@ -391,12 +431,12 @@ __global__ __launch_bounds__(256) void wino_s2_filter_fwd_kernel(const float* __
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) st4(U + (i * 4 + j) * fs + (long)co * ldu + (long)cls * Ceff + ce, Uv[i][j]);
+    for (int j = 0; j < 4; ++j) st_operand(U, P, 16 * fs, (i * 4 + j) * fs + (long)co * ldu + (long)cls * Ceff + ce, Uv[i][j]);
 }
 
 // backward filters (flipped): U'[f][cls*Ceff + ce][co] from w[kh*5+kw][ce][co]
 __global__ __launch_bounds__(256) void wino_s2_filter_bwd_kernel(const float* __restrict__ w, int Ceff, int Cout,
-                                                               float* __restrict__ U) {
+                                                               float* __restrict__ U, u16* P) {
   const int c4n = Cout >> 2;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= 4L * Ceff * c4n) return;
@@ -418,7 +458,7 @@ __global__ __launch_bounds__(256) void wino_s2_filter_bwd_kernel(const float* __
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) st4(U + (i * 4 + j) * fs + r * Cout + co, Uv[i][j]);
+    for (int j = 0; j < 4; ++j) st_operand(U, P, 16 * fs, (i * 4 + j) * fs + r * Cout + co, Uv[i][j]);
 }
 
 // dw[kh*5+kw][ce][co] = (G^T dU G)[i][j] of the tap's class; dU[f] = sum of slab[split][f][cls*Ceff+ce][co]
@@ -540,6 +580,10 @@ struct BgArgs {
   // structurally zero and are skipped: seg_mode 1 = classes along K (forward), 2 = along N
   // (dgrad), 3 = along M (wgrad); seg_len = channels per class; seg_skip = vanishing index.
   int seg_mode, seg_len, seg_skip;
+  // split-precision operands (NT only): three bf16 planes each, plane strides in elements
+  const u16* Ap;
+  const u16* Bp;
+  long pA, pB;
 };
 
 
@@ -627,16 +671,193 @@ __global__ __launch_bounds__(Cfg::THREADS) void wino_bgemm_kernel(BgArgs a) {
 }
 
 
+
+// ---- the NT GEMM on the bf16 pipe (split-precision operands) --------------------------------
+// 256 x 256 x 32 tile, 8 waves (2 x 4, wave tile 128 x 64 = 4 x 2 MFMA tiles of 32x32x16), one
+// workgroup per CU.  LDS: per (operand, piece) [256 rows][80 bytes] (64 data + 16 pad: the row
+// stride is an odd number of 16-byte slots, conflict-free ds_read_b128 with lane = row and eight
+// consecutive k per lane); single buffer, the next K step's tiles are prefetched into registers
+// while the 96 MFMAs of the current one run.  Larger tiles than the fp32 engine because the
+// bf16 pipe is fast enough to make the L2 -> LDS operand stream the limit (measured on the
+// Winograd shapes, tools/ablate/gemm_bf16x3_v2.hip: 128x128: 120-138, 256x256: 156-175
+// TFLOP/s-equivalent; the fp32 engine: 110-120).
+constexpr int X3_WM = 2, X3_WN = 4, X3_MT = 4, X3_NT = 2, X3_BK = 32, X3_RS = X3_BK * 2 + 16;
+constexpr int X3_BM = X3_WM * X3_MT * 32, X3_BN = X3_WN * X3_NT * 32, X3_THREADS = X3_WM * X3_WN * 64;
+constexpr int X3_TA = X3_BM * X3_RS, X3_TB = X3_BN * X3_RS;
+constexpr size_t X3_LDS = 3 * (size_t)(X3_TA + X3_TB);
+
+__global__ __launch_bounds__(X3_THREADS) void wino_bgemm_x3_kernel(BgArgs a) {
+  constexpr int CPR = X3_BK / 8;
+  constexpr int PER_A = 3 * X3_BM * CPR / X3_THREADS, PER_B = 3 * X3_BN * CPR / X3_THREADS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  unsigned char* sA = smem3;
+  unsigned char* sB = smem3 + 3 * X3_TA;
+  const int x = blockIdx.x;
+  int tm, tn;
+  if (a.xmap == 1) {
+    const int xcd = x & 7, idx = x >> 3;
+    tn = idx % a.tiles_n;
+    tm = (idx / a.tiles_n) * 8 + xcd;
+  } else if (a.xmap == 2) {
+    const int xcd = x & 7, idx = x >> 3;
+    tm = idx % a.tiles_m;
+    tn = (idx / a.tiles_m) * 8 + xcd;
+  } else {
+    tn = x % a.tiles_n;
+    tm = x / a.tiles_n;
+  }
+  const int f = blockIdx.z;
+  const int m0 = tm * X3_BM, n0 = tn * X3_BN;
+  if (a.seg_mode == 2) {   // dgrad of a strided layer: skip column tiles whose classes are all absent at f
+    int hi = n0 + X3_BN - 1;
+    if (hi >= a.N) hi = a.N - 1;
+    bool any = false;
+    for (int c = n0 / a.seg_len; c <= hi / a.seg_len; ++c) any = any || s2_present(c, f, a.seg_skip);
+    if (!any) return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / X3_WN, wn = wave % X3_WN;
+  const int r = lane & 31, g = lane >> 5;
+  const u16* Ab = a.Ap + f * a.sA + (long)m0 * a.lda;
+  const u16* Bb = a.Bp + f * a.sB + (long)n0 * a.ldb;
+  const int mrows = a.M - m0, nrows = a.N - n0;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  u32x4 ra[PER_A], rb[PER_B];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < PER_A; ++i) {
+      const int id = i * X3_THREADS + tid;
+      const int c = id % CPR, row = (id / CPR) % X3_BM, piece = id / (X3_BM * CPR);
+      ra[i] = row < mrows ? *reinterpret_cast<const u32x4*>(Ab + piece * a.pA + (long)row * a.lda + k0 + c * 8) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < PER_B; ++i) {
+      const int id = i * X3_THREADS + tid;
+      const int c = id % CPR, row = (id / CPR) % X3_BN, piece = id / (X3_BN * CPR);
+      rb[i] = row < nrows ? *reinterpret_cast<const u32x4*>(Bb + piece * a.pB + (long)row * a.ldb + k0 + c * 8) : zero4;
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < PER_A; ++i) {
+      const int id = i * X3_THREADS + tid;
+      const int c = id % CPR, row = (id / CPR) % X3_BM, piece = id / (X3_BM * CPR);
+      *reinterpret_cast<u32x4*>(sA + piece * X3_TA + row * X3_RS + c * 16) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < PER_B; ++i) {
+      const int id = i * X3_THREADS + tid;
+      const int c = id % CPR, row = (id / CPR) % X3_BN, piece = id / (X3_BN * CPR);
+      *reinterpret_cast<u32x4*>(sB + piece * X3_TB + row * X3_RS + c * 16) = rb[i];
+    }
+  };
+  f32x16 acc[X3_MT][X3_NT];
+#pragma unroll
+  for (int i = 0; i < X3_MT; ++i)
+#pragma unroll
+    for (int j = 0; j < X3_NT; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  const unsigned char* pa = sA + (wm * X3_MT * 32 + r) * X3_RS + 16 * g;
+  const unsigned char* pb = sB + (wn * X3_NT * 32 + r) * X3_RS + 16 * g;
+
+  // K runs: the whole K, or (forward of a strided layer) the classes present at this frequency
+  int run_lo[2], run_len[2], nrun = 0;
+  if (a.seg_mode == 1) {
+    int c = 0;
+    while (c < 4) {
+      if (!s2_present(c, f, a.seg_skip)) {
+        ++c;
+        continue;
+      }
+      int e = c + 1;
+      while (e < 4 && s2_present(e, f, a.seg_skip)) ++e;
+      run_lo[nrun] = c * a.seg_len;
+      run_len[nrun] = (e - c) * a.seg_len;
+      ++nrun;
+      c = e;
+    }
+  } else {
+    run_lo[0] = 0;
+    run_len[0] = a.K;
+    nrun = 1;
+  }
+  // flatten the runs into one sequence of K steps
+  const int steps0 = run_len[0] / X3_BK;
+  const int nsteps = steps0 + (nrun > 1 ? run_len[1] / X3_BK : 0);
+  auto kof = [&](int st) { return st < steps0 ? run_lo[0] + st * X3_BK : run_lo[1] + (st - steps0) * X3_BK; };
+  gload(kof(0));
+  sstore();
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    if (st + 1 < nsteps) gload(kof(st + 1));
+#pragma unroll
+    for (int sl = 0; sl < X3_BK / 16; ++sl) {
+      bf16x8 A[X3_MT][3], B[X3_NT][3];
+#pragma unroll
+      for (int t = 0; t < X3_MT; ++t)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+          A[t][pc] = *reinterpret_cast<const bf16x8*>(pa + pc * X3_TA + t * 32 * X3_RS + 32 * sl);
+#pragma unroll
+      for (int t = 0; t < X3_NT; ++t)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+          B[t][pc] = *reinterpret_cast<const bf16x8*>(pb + pc * X3_TB + t * 32 * X3_RS + 32 * sl);
+#pragma unroll
+      for (int i = 0; i < X3_MT; ++i)
+#pragma unroll
+        for (int j = 0; j < X3_NT; ++j) {
+          // smallest terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][2], B[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][1], B[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][1], B[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[j][0], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (st + 1 < nsteps) {
+      sstore();
+      __syncthreads();
+    }
+  }
+  float* C = a.C + f * a.sC;
+#pragma unroll
+  for (int i = 0; i < X3_MT; ++i)
+#pragma unroll
+    for (int j = 0; j < X3_NT; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int rr = (q & 3) + 8 * (q >> 2) + 4 * g;
+        const int m = m0 + (wm * X3_MT + i) * 32 + rr;
+        const int n = n0 + (wn * X3_NT + j) * 32 + r;
+        if (m < a.M && n < a.N) C[(long)m * a.ldc + n] = acc[i][j][q];
+      }
+}
+
 template <bool TN>
 void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
   size_t lds;
   if (TN) lds = sizeof(float) * 2 * (MatLoaderR<Cfg, Cfg::BM, true>::FLOATS + MatLoaderR<Cfg, Cfg::BN, true>::FLOATS);
   else lds = sizeof(float) * 2 * (MatLoaderK<Cfg, Cfg::BM, true>::FLOATS + MatLoaderK<Cfg, Cfg::BN, true>::FLOATS);
-  ensure_lds<wino_bgemm_kernel<TN>>(lds);
-  // executed FLOP: 16 GEMMs, minus the skipped (class, frequency) blocks of the strided layers
+  // executed fp32-equivalent FLOP: 16 GEMMs, minus the skipped (class, frequency) blocks of the strided layers
   double flop = 2.0 * 16.0 * (double)a.M * a.N * a.K;
   if (a.seg_mode) flop *= 49.0 / 64.0;
-  ProfScope ps(OTGAN_PROF_WINO_GEMM, flop, 0.0, s);
+  const bool x3 = !TN && a.Ap;
+  ProfScope ps(x3 ? OTGAN_PROF_WINO_GEMM_X3 : OTGAN_PROF_WINO_GEMM, x3 ? 6.0 * flop : flop, 0.0, s);
+  if (x3) {
+    ensure_lds<wino_bgemm_x3_kernel>(X3_LDS);
+    BgArgs b = a;
+    b.tiles_m = (a.M + X3_BM - 1) / X3_BM;
+    b.tiles_n = (a.N + X3_BN - 1) / X3_BN;
+    const bool m_ok = b.tiles_m % 8 == 0, n_ok = b.tiles_n % 8 == 0;
+    if (a.M >= a.N) b.xmap = m_ok ? 1 : n_ok ? 2 : 0;
+    else b.xmap = n_ok ? 2 : m_ok ? 1 : 0;
+    hipLaunchKernelGGL(wino_bgemm_x3_kernel, dim3(b.tiles_m * b.tiles_n, 1, 16), dim3(X3_THREADS), X3_LDS, s, b);
+    return;
+  }
+  ensure_lds<wino_bgemm_kernel<TN>>(lds);
   BgArgs b = a;
   // partition the LARGER operand across the XCDs (each part is then fetched by one L2 only);
   // the smaller one is re-read by all eight
@@ -648,6 +869,17 @@ void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
 }
 
 inline int grid1(long n) { return (int)((n + 255) / 256); }
+
+// split-precision (bf16 x 3) operands for the NT GEMMs unless OTGAN_WINO_FP32=1
+bool use_x3() {
+  static const bool on = [] {
+    const char* e = getenv("OTGAN_WINO_FP32");
+    return !(e && e[0] == '1');
+  }();
+  return on;
+}
+// floats of workspace that hold n operand elements (three bf16 planes = 6 bytes per element)
+inline size_t operand_floats(size_t n) { return (3 * n + 1) / 2; }
 
 // the four output-parity classes of a [N, 2H, 2W, ld] buffer as small-grid views
 template <class V, class P>
@@ -684,7 +916,8 @@ bool winograd_enabled() {
 
 size_t wino_fwd_ws_floats(const WinoGeo& g) {
   const size_t T = (size_t)wino_tiles(g);
-  return 16 * T * g.Cin + 16 * T * 4 * g.Cout + 16 * (size_t)4 * g.Cout * g.Cin;
+  return operand_floats(16 * T * g.Cin) + operand_floats(16 * T * 4 * g.Cout) + operand_floats(16 * (size_t)4 * g.Cout * g.Cin) +
+         16 * T * (size_t)(4 * g.Cout > g.Cin ? 4 * g.Cout : g.Cin);
 }
 size_t wino_dgrad_ws_floats(const WinoGeo& g) { return wino_fwd_ws_floats(g); }
 size_t wino_wgrad_ws_floats(const WinoGeo& g) {
@@ -696,19 +929,25 @@ int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stri
              float* ws, hipStream_t s) {
   const long T = wino_tiles(g);
   const int N4 = 4 * g.Cout;
+  const bool x3 = use_x3() && g.Cin % X3_BK == 0;
+  const size_t nV = 16 * (size_t)T * g.Cin, nU = 16 * (size_t)N4 * g.Cin;
   float* V = ws;
-  float* Mh = V + 16 * T * g.Cin;
-  float* U = Mh + 16 * T * N4;
+  float* U = V + operand_floats(nV);
+  float* Mh = U + operand_floats(nU);
+  u16* VP = x3 ? reinterpret_cast<u16*>(V) : nullptr;
+  u16* UP = x3 ? reinterpret_cast<u16*>(U) : nullptr;
   hipLaunchKernelGGL(wino_filter_fwd_kernel, dim3(grid1((long)N4 * (g.Cin / 4))), dim3(256), 0, s, weffT, cls_stride,
-                     g.Cin, g.Cout, U);
+                     g.Cin, g.Cout, U, UP);
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
   ia.s2_skip = -1;
   ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
   ia.H = g.H; ia.W = g.W; ia.TH = g.H / 2; ia.TW = g.W / 2; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.V = V;
+  ia.P = VP;
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(grid1(T * (g.Cin / 4)), 1, 1), dim3(256), 0, s, ia);
   BgArgs b;
   memset(&b, 0, sizeof(b));
+  b.Ap = VP; b.Bp = UP; b.pA = (long)nV; b.pB = (long)nU;
   b.A = V; b.B = U; b.C = Mh; b.M = (int)T; b.N = N4; b.K = g.Cin;
   b.lda = g.Cin; b.ldb = g.Cin; b.ldc = N4;
   b.sA = T * g.Cin; b.sB = (long)N4 * g.Cin; b.sC = T * N4;
@@ -728,20 +967,26 @@ int wino_dgrad(const WinoGeo& g, const float* dy, const float* weff, long cls_st
                int accumulate, float* ws, hipStream_t s) {
   const long T = wino_tiles(g);
   const int K4 = 4 * g.Cout;
-  float* DV = ws;                       // [16][T][4*Cout]
-  float* Xh = DV + 16 * T * K4;         // [16][T][Cin]
-  float* U = Xh + 16 * T * g.Cin;       // [16][Cin][4*Cout]
+  const bool x3 = use_x3() && K4 % X3_BK == 0;
+  const size_t nV = 16 * (size_t)T * K4, nU = 16 * (size_t)g.Cin * K4;
+  float* DV = ws;                            // [16][T][4*Cout]
+  float* U = DV + operand_floats(nV);        // [16][Cin][4*Cout]
+  float* Xh = U + operand_floats(nU);        // [16][T][Cin]
+  u16* VP = x3 ? reinterpret_cast<u16*>(DV) : nullptr;
+  u16* UP = x3 ? reinterpret_cast<u16*>(U) : nullptr;
   hipLaunchKernelGGL(wino_filter_bwd_kernel, dim3(grid1(4L * g.Cin * (g.Cout / 4))), dim3(256), 0, s, weff, cls_stride,
-                     g.Cin, g.Cout, U);
+                     g.Cin, g.Cout, U, UP);
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
   ia.s2_skip = -1;
   class_views(g, dy + g.y_coff, g.ldy, ia.v);
   for (int cls = 0; cls < 4; ++cls) ia.coff[cls] = cls * g.Cout;
   ia.H = g.H; ia.W = g.W; ia.TH = g.H / 2; ia.TW = g.W / 2; ia.C = g.Cout; ia.T = T; ia.ldv = K4; ia.V = DV;
+  ia.P = VP;
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(grid1(T * (g.Cout / 4)), 1, 4), dim3(256), 0, s, ia);
   BgArgs b;
   memset(&b, 0, sizeof(b));
+  b.Ap = VP; b.Bp = UP; b.pA = (long)nV; b.pB = (long)nU;
   b.A = DV; b.B = U; b.C = Xh; b.M = (int)T; b.N = g.Cin; b.K = K4;
   b.lda = K4; b.ldb = K4; b.ldc = g.Cin;
   b.sA = T * K4; b.sB = (long)g.Cin * K4; b.sC = T * g.Cin;
@@ -819,7 +1064,7 @@ int s2_wgrad_splits(const WinoS2Geo& g) {
   return ns < 1 ? 1 : ns;
 }
 
-void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, hipStream_t s) {
+void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, u16* VP, hipStream_t s) {
   const long T = wino_s2_tiles(g);
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
@@ -828,6 +1073,7 @@ void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, hipStream_
   for (int cls = 0; cls < 4; ++cls) ia.coff[cls] = cls * g.Ceff;
   ia.H = g.H / 2; ia.W = g.W / 2; ia.TH = g.H / 4; ia.TW = g.W / 4; ia.C = g.C; ia.T = T; ia.ldv = 4 * g.Ceff;
   ia.V = V;
+  ia.P = VP;
   ia.s2_skip = 0;
   const dim3 grid(grid1(T * (g.C / 4)), 1, 4), blk(256);
   if (g.doubled) {
@@ -842,7 +1088,7 @@ void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, hipStream_
 
 size_t wino_s2_fwd_ws_floats(const WinoS2Geo& g) {
   const size_t T = (size_t)wino_s2_tiles(g), K4 = 4 * (size_t)g.Ceff;
-  return 16 * T * K4 + 16 * T * g.Cout + 16 * K4 * g.Cout;
+  return operand_floats(16 * T * K4) + operand_floats(16 * T * g.Cout) + operand_floats(16 * K4 * g.Cout) + 16 * T * K4;
 }
 size_t wino_s2_dgrad_ws_floats(const WinoS2Geo& g) { return wino_s2_fwd_ws_floats(g); }
 size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g) {
@@ -854,14 +1100,19 @@ int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float
                 hipStream_t s) {
   const long T = wino_s2_tiles(g);
   const int K4 = 4 * g.Ceff;
-  float* V = ws;                         // [16][T][4*Ceff]
-  float* Mh = V + 16 * T * K4;           // [16][T][Cout]
-  float* U = Mh + 16 * T * g.Cout;       // [16][Cout][4*Ceff]
+  const bool x3 = use_x3() && g.Ceff % X3_BK == 0;
+  const size_t nV = 16 * (size_t)T * K4, nU = 16 * (size_t)g.Cout * K4;
+  float* V = ws;                              // [16][T][4*Ceff]
+  float* U = V + operand_floats(nV);          // [16][Cout][4*Ceff]
+  float* Mh = U + operand_floats(nU);         // [16][T][Cout]
+  u16* VP = x3 ? reinterpret_cast<u16*>(V) : nullptr;
+  u16* UP = x3 ? reinterpret_cast<u16*>(U) : nullptr;
   hipLaunchKernelGGL(wino_s2_filter_fwd_kernel, dim3(grid1(4L * g.Cout * (g.Ceff / 4))), dim3(256), 0, s, wT, g.Ceff,
-                     g.Cout, U);
-  s2_input_transform(g, x, V, s);
+                     g.Cout, U, UP);
+  s2_input_transform(g, x, V, VP, s);
   BgArgs b;
   memset(&b, 0, sizeof(b));
+  b.Ap = VP; b.Bp = UP; b.pA = (long)nV; b.pB = (long)nU;
   b.A = V; b.B = U; b.C = Mh; b.M = (int)T; b.N = g.Cout; b.K = K4;
   b.lda = K4; b.ldb = K4; b.ldc = g.Cout;
   b.sA = T * K4; b.sB = (long)g.Cout * K4; b.sC = T * g.Cout;
@@ -883,19 +1134,25 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   const long T = wino_s2_tiles(g);
   const int K4 = 4 * g.Ceff;
   const int OH = g.H / 2, OW = g.W / 2;
-  float* DV = ws;                        // [16][T][Cout]
-  float* Xh = DV + 16 * T * g.Cout;      // [16][T][4*Ceff]
-  float* U = Xh + 16 * T * K4;           // [16][4*Ceff][Cout]
+  const bool x3 = use_x3() && g.Cout % X3_BK == 0;
+  const size_t nV = 16 * (size_t)T * g.Cout, nU = 16 * (size_t)K4 * g.Cout;
+  float* DV = ws;                             // [16][T][Cout]
+  float* U = DV + operand_floats(nV);         // [16][4*Ceff][Cout]
+  float* Xh = U + operand_floats(nU);         // [16][T][4*Ceff]
+  u16* VP = x3 ? reinterpret_cast<u16*>(DV) : nullptr;
+  u16* UP = x3 ? reinterpret_cast<u16*>(U) : nullptr;
   hipLaunchKernelGGL(wino_s2_filter_bwd_kernel, dim3(grid1(4L * g.Ceff * (g.Cout / 4))), dim3(256), 0, s, w, g.Ceff,
-                     g.Cout, U);
+                     g.Cout, U, UP);
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
   ia.s2_skip = -1;
   ia.v[0].p = dy + g.y_coff; ia.v[0].sn = (long)OH * OW * g.ldy; ia.v[0].sh = (long)OW * g.ldy; ia.v[0].sw = g.ldy;
   ia.H = OH; ia.W = OW; ia.TH = OH / 2; ia.TW = OW / 2; ia.C = g.Cout; ia.T = T; ia.ldv = g.Cout; ia.V = DV;
+  ia.P = VP;
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(grid1(T * (g.Cout / 4)), 1, 1), dim3(256), 0, s, ia);
   BgArgs b;
   memset(&b, 0, sizeof(b));
+  b.Ap = VP; b.Bp = UP; b.pA = (long)nV; b.pB = (long)nU;
   b.A = DV; b.B = U; b.C = Xh; b.M = (int)T; b.N = K4; b.K = g.Cout;
   b.lda = g.Cout; b.ldb = g.Cout; b.ldc = K4;
   b.sA = T * g.Cout; b.sB = (long)K4 * g.Cout; b.sC = T * K4;
@@ -927,7 +1184,7 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
   float* V = ws;                         // [16][T][4*Ceff]
   float* dM = V + 16 * T * K4;           // [16][T][Cout]
   float* slabs = dM + 16 * T * g.Cout;   // [ns][16][4*Ceff][Cout]
-  s2_input_transform(g, x, V, s);
+  s2_input_transform(g, x, V, nullptr, s);
   InArgs da;
   memset(&da, 0, sizeof(da));
   da.s2_skip = -1;
