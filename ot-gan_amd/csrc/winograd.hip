@@ -12,6 +12,8 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "gemm_tile.h"
 
 namespace {
@@ -311,12 +313,12 @@ __global__ __launch_bounds__(256) void wino_outadj_kernel(InArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) dY[i][j] = ld4(v.p + n * v.sn + (2 * ta + i) * v.sh + (2 * tb + j) * v.sw + c);
   tf_output_adj(dY, dM);
-  float* out = a.V + t * a.ldv + a.coff[blockIdx.z] + c;
+  const long o0 = t * a.ldv + a.coff[blockIdx.z] + c;
   const long fs = a.T * a.ldv;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) st4(out + (i * 4 + j) * fs, dM[i][j]);
+    for (int j = 0; j < 4; ++j) st_operand(a.V, a.P, 16 * fs, o0 + (i * 4 + j) * fs, dM[i][j]);
 }
 
 // forward filters: U[f][cls*Cout + co][ci] from weffT[cls][co][tap*Cin + ci]
@@ -686,6 +688,11 @@ constexpr int X3_BM = X3_WM * X3_MT * 32, X3_BN = X3_WN * X3_NT * 32, X3_THREADS
 constexpr int X3_TA = X3_BM * X3_RS, X3_TB = X3_BN * X3_RS;
 constexpr size_t X3_LDS = 3 * (size_t)(X3_TA + X3_TB);
 
+// TN = true (wgrad): operands are [K][rows] (rows contiguous, K = tiles); the staging pass
+// transposes on the way into LDS -- a thread fetches the same 8-row chunk of four consecutive k,
+// permutes the 16-bit halves in registers and writes eight 8-byte row segments -- so the fragment
+// reads and the MFMA loop are identical to the NT case.  blockIdx.y = K split (slabs).
+template <bool TN>
 __global__ __launch_bounds__(X3_THREADS) void wino_bgemm_x3_kernel(BgArgs a) {
   constexpr int CPR = X3_BK / 8;
   constexpr int PER_A = 3 * X3_BM * CPR / X3_THREADS, PER_B = 3 * X3_BN * CPR / X3_THREADS;
@@ -708,20 +715,62 @@ __global__ __launch_bounds__(X3_THREADS) void wino_bgemm_x3_kernel(BgArgs a) {
   }
   const int f = blockIdx.z;
   const int m0 = tm * X3_BM, n0 = tn * X3_BN;
-  if (a.seg_mode == 2) {   // dgrad of a strided layer: skip column tiles whose classes are all absent at f
-    int hi = n0 + X3_BN - 1;
-    if (hi >= a.N) hi = a.N - 1;
+  if (a.seg_mode == 2 || a.seg_mode == 3) {
+    // strided layers: skip tiles whose columns (dgrad) / rows (wgrad) belong to classes all absent at f
+    const int lo = a.seg_mode == 2 ? n0 : m0, ext = a.seg_mode == 2 ? a.N : a.M;
+    int hi = lo + (a.seg_mode == 2 ? X3_BN : X3_BM) - 1;
+    if (hi >= ext) hi = ext - 1;
     bool any = false;
-    for (int c = n0 / a.seg_len; c <= hi / a.seg_len; ++c) any = any || s2_present(c, f, a.seg_skip);
+    for (int c = lo / a.seg_len; c <= hi / a.seg_len; ++c) any = any || s2_present(c, f, a.seg_skip);
     if (!any) return;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / X3_WN, wn = wave % X3_WN;
   const int r = lane & 31, g = lane >> 5;
-  const u16* Ab = a.Ap + f * a.sA + (long)m0 * a.lda;
-  const u16* Bb = a.Bp + f * a.sB + (long)n0 * a.ldb;
+  const u16* Ab = TN ? a.Ap + f * a.sA + m0 : a.Ap + f * a.sA + (long)m0 * a.lda;
+  const u16* Bb = TN ? a.Bp + f * a.sB + n0 : a.Bp + f * a.sB + (long)n0 * a.ldb;
   const int mrows = a.M - m0, nrows = a.N - n0;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   u32x4 ra[PER_A], rb[PER_B];
+  // TN staging unit: (piece tile, 8-row chunk mc, group of four k tg); 32 chunks x 8 groups per piece tile
+  constexpr int UNITS = 6 * 32 * 8 / X3_THREADS;   // 3 per thread
+  auto gload_t = [&](int k0, int kend) {
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) {
+      const int id = u * X3_THREADS + tid;
+      const int tg = id & 7, mc = (id >> 3) & 31, pt = id >> 8;        // pt = operand*3 + piece
+      const bool isA = pt < 3;
+      const int rows = isA ? mrows : nrows;
+      const u16* base = isA ? Ab + pt * a.pA : Bb + (pt - 3) * a.pB;
+      const long ld = isA ? a.lda : a.ldb;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = k0 + 4 * tg + q;
+        const bool ok = 8 * mc < rows && k < kend;
+        const u32x4 v = ok ? *reinterpret_cast<const u32x4*>(base + (long)k * ld + 8 * mc) : zero4;
+        if (u * 4 + q < PER_A) ra[u * 4 + q] = v;
+        else rb[u * 4 + q - PER_A] = v;
+      }
+    }
+  };
+  auto sstore_t = [&]() {
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) {
+      const int id = u * X3_THREADS + tid;
+      const int tg = id & 7, mc = (id >> 3) & 31, pt = id >> 8;
+      unsigned char* tile = (pt < 3 ? sA + pt * X3_TA : sB + (pt - 3) * X3_TB) + (8 * mc) * X3_RS + 8 * tg;
+      u32x4 c[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c[q] = (u * 4 + q < PER_A) ? ra[u * 4 + q] : rb[u * 4 + q - PER_A];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        // row j of the chunk: halves (j & 1) of dword j/2 of the four k
+        const unsigned sel = (j & 1) ? 0x07060302u : 0x05040100u;
+        const unsigned lo = __builtin_amdgcn_perm(c[1][j >> 1], c[0][j >> 1], sel);
+        const unsigned hi2 = __builtin_amdgcn_perm(c[3][j >> 1], c[2][j >> 1], sel);
+        *reinterpret_cast<uint2*>(tile + j * X3_RS) = make_uint2(lo, hi2);
+      }
+    }
+  };
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < PER_A; ++i) {
@@ -760,10 +809,10 @@ __global__ __launch_bounds__(X3_THREADS) void wino_bgemm_x3_kernel(BgArgs a) {
   const unsigned char* pa = sA + (wm * X3_MT * 32 + r) * X3_RS + 16 * g;
   const unsigned char* pb = sB + (wn * X3_NT * 32 + r) * X3_RS + 16 * g;
 
-  // K runs: the whole K, or (forward of a strided layer) the classes present at this frequency
-  int run_lo[2], run_len[2], nrun = 0;
+  // K runs: the whole K, or (forward of a strided layer) the <= 2 runs of classes present at this frequency
+  int lo0 = 0, len0 = 0, lo1 = 0, len1 = 0;
   if (a.seg_mode == 1) {
-    int c = 0;
+    int c = 0, nrun = 0;
     while (c < 4) {
       if (!s2_present(c, f, a.seg_skip)) {
         ++c;
@@ -771,25 +820,47 @@ __global__ __launch_bounds__(X3_THREADS) void wino_bgemm_x3_kernel(BgArgs a) {
       }
       int e = c + 1;
       while (e < 4 && s2_present(e, f, a.seg_skip)) ++e;
-      run_lo[nrun] = c * a.seg_len;
-      run_len[nrun] = (e - c) * a.seg_len;
+      if (nrun == 0) {
+        lo0 = c * a.seg_len;
+        len0 = (e - c) * a.seg_len;
+      } else {
+        lo1 = c * a.seg_len;
+        len1 = (e - c) * a.seg_len;
+      }
       ++nrun;
       c = e;
     }
+  } else if (TN) {
+    // K split: blockIdx.y takes kt_per_split steps; the last step of the tensor may be ragged (zero-filled)
+    const int nkt_all = (a.K + X3_BK - 1) / X3_BK;
+    const int kt0 = blockIdx.y * a.kt_per_split;
+    int nkt = nkt_all - kt0;
+    if (nkt > a.kt_per_split) nkt = a.kt_per_split;
+    if (nkt < 0) nkt = 0;
+    lo0 = kt0 * X3_BK;
+    len0 = nkt * X3_BK;
   } else {
-    run_lo[0] = 0;
-    run_len[0] = a.K;
-    nrun = 1;
+    len0 = a.K;
   }
   // flatten the runs into one sequence of K steps
-  const int steps0 = run_len[0] / X3_BK;
-  const int nsteps = steps0 + (nrun > 1 ? run_len[1] / X3_BK : 0);
-  auto kof = [&](int st) { return st < steps0 ? run_lo[0] + st * X3_BK : run_lo[1] + (st - steps0) * X3_BK; };
-  gload(kof(0));
-  sstore();
+  const int steps0 = len0 / X3_BK;
+  const int nsteps = steps0 + len1 / X3_BK;
+  auto kof = [&](int st) { return st < steps0 ? lo0 + st * X3_BK : lo1 + (st - steps0) * X3_BK; };
+  auto load_step = [&](int st) {
+    if (TN) gload_t(kof(st), a.K);
+    else gload(kof(st));
+  };
+  auto store_step = [&]() {
+    if (TN) sstore_t();
+    else sstore();
+  };
+  if (nsteps > 0) {
+    load_step(0);
+    store_step();
+  }
   __syncthreads();
   for (int st = 0; st < nsteps; ++st) {
-    if (st + 1 < nsteps) gload(kof(st + 1));
+    if (st + 1 < nsteps) load_step(st + 1);
 #pragma unroll
     for (int sl = 0; sl < X3_BK / 16; ++sl) {
       bf16x8 A[X3_MT][3], B[X3_NT][3];
@@ -818,11 +889,11 @@ __global__ __launch_bounds__(X3_THREADS) void wino_bgemm_x3_kernel(BgArgs a) {
     }
     __syncthreads();
     if (st + 1 < nsteps) {
-      sstore();
+      store_step();
       __syncthreads();
     }
   }
-  float* C = a.C + f * a.sC;
+  float* C = a.C + f * a.sC + (TN ? blockIdx.y * a.sSplit : 0);
 #pragma unroll
   for (int i = 0; i < X3_MT; ++i)
 #pragma unroll
@@ -844,17 +915,18 @@ void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
   // executed fp32-equivalent FLOP: 16 GEMMs, minus the skipped (class, frequency) blocks of the strided layers
   double flop = 2.0 * 16.0 * (double)a.M * a.N * a.K;
   if (a.seg_mode) flop *= 49.0 / 64.0;
-  const bool x3 = !TN && a.Ap;
+  const bool x3 = a.Ap != nullptr;
   ProfScope ps(x3 ? OTGAN_PROF_WINO_GEMM_X3 : OTGAN_PROF_WINO_GEMM, x3 ? 6.0 * flop : flop, 0.0, s);
   if (x3) {
-    ensure_lds<wino_bgemm_x3_kernel>(X3_LDS);
+    ensure_lds<wino_bgemm_x3_kernel<TN>>(X3_LDS);
     BgArgs b = a;
     b.tiles_m = (a.M + X3_BM - 1) / X3_BM;
     b.tiles_n = (a.N + X3_BN - 1) / X3_BN;
     const bool m_ok = b.tiles_m % 8 == 0, n_ok = b.tiles_n % 8 == 0;
     if (a.M >= a.N) b.xmap = m_ok ? 1 : n_ok ? 2 : 0;
     else b.xmap = n_ok ? 2 : m_ok ? 1 : 0;
-    hipLaunchKernelGGL(wino_bgemm_x3_kernel, dim3(b.tiles_m * b.tiles_n, 1, 16), dim3(X3_THREADS), X3_LDS, s, b);
+    hipLaunchKernelGGL((wino_bgemm_x3_kernel<TN>), dim3(b.tiles_m * b.tiles_n, TN ? nsplit : 1, 16), dim3(X3_THREADS),
+                       X3_LDS, s, b);
     return;
   }
   ensure_lds<wino_bgemm_kernel<TN>>(lds);
@@ -878,6 +950,16 @@ bool use_x3() {
   }();
   return on;
 }
+// wgrad (TN) on the bf16 pipe: the transposing staging pass (8-byte LDS writes, 2-way bank conflicts,
+// in-register 16-bit permutes) costs what the faster MFMAs save -- measured 1.14-1.25 ms against
+// 1.1-1.28 ms for the fp32 engine on the six wgrad GEMMs -- so it is off unless OTGAN_WINO_WGRAD_X3=1.
+bool use_x3_wgrad() {
+  static const bool on = [] {
+    const char* e = getenv("OTGAN_WINO_WGRAD_X3");
+    return e && e[0] == '1';
+  }();
+  return on && use_x3();
+}
 // floats of workspace that hold n operand elements (three bf16 planes = 6 bytes per element)
 inline size_t operand_floats(size_t n) { return (3 * n + 1) / 2; }
 
@@ -892,6 +974,16 @@ void class_views(const WinoGeo& g, P base, int ld, V (&v)[4]) {
     v[cls].sh = 2 * OW * ld;
     v[cls].sw = 2L * ld;
   }
+}
+
+// K splits of the wgrad GEMM on the bf16 pipe (256 x 256 tiles: few tiles, long K)
+int x3_wgrad_splits(int M, int N, long T) {
+  const int blocks = ((M + X3_BM - 1) / X3_BM) * ((N + X3_BN - 1) / X3_BN) * 16;
+  int ns = (768 + blocks - 1) / blocks;
+  if (ns > 16) ns = 16;
+  const int nkt = (int)((T + X3_BK - 1) / X3_BK);
+  while (ns > 1 && nkt / ns < 8) --ns;
+  return ns < 1 ? 1 : ns;
 }
 
 int wgrad_splits(const WinoGeo& g) {
@@ -922,7 +1014,8 @@ size_t wino_fwd_ws_floats(const WinoGeo& g) {
 size_t wino_dgrad_ws_floats(const WinoGeo& g) { return wino_fwd_ws_floats(g); }
 size_t wino_wgrad_ws_floats(const WinoGeo& g) {
   const size_t T = (size_t)wino_tiles(g);
-  return 16 * T * g.Cin + 16 * T * 4 * g.Cout + (size_t)wgrad_splits(g) * 16 * 4 * g.Cout * g.Cin;
+  const int ns = std::max(wgrad_splits(g), x3_wgrad_splits(g.Cin, 4 * g.Cout, (long)T));
+  return operand_floats(16 * T * g.Cin) + operand_floats(16 * T * 4 * g.Cout) + (size_t)ns * 16 * 4 * g.Cout * g.Cin;
 }
 
 int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stride, const float* bias, float* y,
@@ -1006,15 +1099,20 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
                hipStream_t s) {
   const long T = wino_tiles(g);
   const int N4 = 4 * g.Cout;
-  const int ns = wgrad_splits(g);
-  float* V = ws;                        // [16][T][Cin]
-  float* dM = V + 16 * T * g.Cin;       // [16][T][4*Cout]
-  float* slabs = dM + 16 * T * N4;      // [ns][16][Cin][4*Cout]
+  const bool x3 = use_x3_wgrad() && g.Cin % 8 == 0 && N4 % 8 == 0;
+  const int ns = x3 ? x3_wgrad_splits(g.Cin, N4, T) : wgrad_splits(g);
+  const size_t nV = 16 * (size_t)T * g.Cin, nM = 16 * (size_t)T * N4;
+  float* V = ws;                              // [16][T][Cin]
+  float* dM = V + operand_floats(nV);         // [16][T][4*Cout]
+  float* slabs = dM + operand_floats(nM);     // [ns][16][Cin][4*Cout]
+  u16* VP = x3 ? reinterpret_cast<u16*>(V) : nullptr;
+  u16* MP = x3 ? reinterpret_cast<u16*>(dM) : nullptr;
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
   ia.s2_skip = -1;
   ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
   ia.H = g.H; ia.W = g.W; ia.TH = g.H / 2; ia.TW = g.W / 2; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.V = V;
+  ia.P = VP;
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(grid1(T * (g.Cin / 4)), 1, 1), dim3(256), 0, s, ia);
   InArgs da;
   memset(&da, 0, sizeof(da));
@@ -1022,9 +1120,11 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
   class_views(g, dy + g.y_coff, g.ldy, da.v);
   for (int cls = 0; cls < 4; ++cls) da.coff[cls] = cls * g.Cout;
   da.H = g.H; da.W = g.W; da.TH = g.H / 2; da.TW = g.W / 2; da.C = g.Cout; da.T = T; da.ldv = N4; da.V = dM;
+  da.P = MP;
   hipLaunchKernelGGL(wino_outadj_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 4), dim3(256), 0, s, da);
   BgArgs b;
   memset(&b, 0, sizeof(b));
+  b.Ap = VP; b.Bp = MP; b.pA = (long)nV; b.pB = (long)nM;
   b.A = V; b.B = dM; b.C = slabs; b.M = g.Cin; b.N = N4; b.K = (int)T;
   b.lda = g.Cin; b.ldb = N4; b.ldc = N4;
   b.sA = T * g.Cin; b.sB = T * N4; b.sC = (long)g.Cin * N4; b.sSplit = 16L * g.Cin * N4;
@@ -1093,7 +1193,8 @@ size_t wino_s2_fwd_ws_floats(const WinoS2Geo& g) {
 size_t wino_s2_dgrad_ws_floats(const WinoS2Geo& g) { return wino_s2_fwd_ws_floats(g); }
 size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g) {
   const size_t T = (size_t)wino_s2_tiles(g), K4 = 4 * (size_t)g.Ceff;
-  return 16 * T * K4 + 16 * T * g.Cout + (size_t)s2_wgrad_splits(g) * 16 * K4 * g.Cout;
+  const int ns = std::max(s2_wgrad_splits(g), x3_wgrad_splits((int)K4, g.Cout, (long)T));
+  return operand_floats(16 * T * K4) + operand_floats(16 * T * g.Cout) + (size_t)ns * 16 * K4 * g.Cout;
 }
 
 int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float* bias, float* y, float* ws,
@@ -1180,19 +1281,25 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
   const long T = wino_s2_tiles(g);
   const int K4 = 4 * g.Ceff;
   const int OH = g.H / 2, OW = g.W / 2;
-  const int ns = s2_wgrad_splits(g);
-  float* V = ws;                         // [16][T][4*Ceff]
-  float* dM = V + 16 * T * K4;           // [16][T][Cout]
-  float* slabs = dM + 16 * T * g.Cout;   // [ns][16][4*Ceff][Cout]
-  s2_input_transform(g, x, V, nullptr, s);
+  const bool x3 = use_x3_wgrad() && g.Cout % 8 == 0;
+  const int ns = x3 ? x3_wgrad_splits(K4, g.Cout, T) : s2_wgrad_splits(g);
+  const size_t nV = 16 * (size_t)T * K4, nM = 16 * (size_t)T * g.Cout;
+  float* V = ws;                              // [16][T][4*Ceff]
+  float* dM = V + operand_floats(nV);         // [16][T][Cout]
+  float* slabs = dM + operand_floats(nM);     // [ns][16][4*Ceff][Cout]
+  u16* VP = x3 ? reinterpret_cast<u16*>(V) : nullptr;
+  u16* MP = x3 ? reinterpret_cast<u16*>(dM) : nullptr;
+  s2_input_transform(g, x, V, VP, s);
   InArgs da;
   memset(&da, 0, sizeof(da));
   da.s2_skip = -1;
   da.v[0].p = dy + g.y_coff; da.v[0].sn = (long)OH * OW * g.ldy; da.v[0].sh = (long)OW * g.ldy; da.v[0].sw = g.ldy;
   da.H = OH; da.W = OW; da.TH = OH / 2; da.TW = OW / 2; da.C = g.Cout; da.T = T; da.ldv = g.Cout; da.V = dM;
+  da.P = MP;
   hipLaunchKernelGGL(wino_outadj_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 1), dim3(256), 0, s, da);
   BgArgs b;
   memset(&b, 0, sizeof(b));
+  b.Ap = VP; b.Bp = MP; b.pA = (long)nV; b.pB = (long)nM;
   b.A = V; b.B = dM; b.C = slabs; b.M = K4; b.N = g.Cout; b.K = (int)T;
   b.lda = K4; b.ldb = g.Cout; b.ldc = g.Cout;
   b.sA = T * K4; b.sB = T * g.Cout; b.sC = (long)K4 * g.Cout; b.sSplit = 16L * K4 * g.Cout;
