@@ -321,6 +321,106 @@ __global__ __launch_bounds__(256) void wino_outadj_kernel(InArgs a) {
     for (int j = 0; j < 4; ++j) st_operand(a.V, a.P, 16 * fs, o0 + (i * 4 + j) * fs, dM[i][j]);
 }
 
+
+// ---- transposed operand producers (wgrad on the bf16 pipe) ------------------------------------
+// The wgrad GEMM contracts over the tiles, so its operands must be tile-contiguous:
+// P[piece][f][row][t].  These kernels compute the same transforms as wino_input_kernel /
+// wino_outadj_kernel for a block of 64 tiles x 16 channels and transpose through LDS (four
+// frequencies at a time), so that every global store is a full 128-byte row segment of 64 tiles.
+// Tiles >= T (padding up to a multiple of 64) are written as zeros.
+struct ProdTArgs {
+  View v[4];
+  int coff[4];
+  int H, W, TH, TW, C;   // C = channels of the view (multiple of 16)
+  long T, Tpad;
+  int rows;              // rows of the transposed operand per frequency
+  u16* P;                // [3][16][rows][Tpad]
+};
+
+template <int KIND, int ACT, bool DOUBLED>   // KIND 0: B^T d B of the 4x4 patch, 1: A dY A^T of the 2x2 tile
+__global__ __launch_bounds__(256) void wino_prodT_kernel(ProdTArgs a) {
+  __shared__ __attribute__((aligned(16))) u16 lds[3][4][16][72];
+  const int tid = threadIdx.x, cq = tid & 3, tl = tid >> 2;
+  const long t = (long)blockIdx.x * 64 + tl;
+  const int c = blockIdx.y * 16 + 4 * cq;
+  const View v = a.v[blockIdx.z];
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 d[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[i][j] = zero;
+  if (t < a.T) {
+    const int tb = (int)(t % a.TW), ta = (int)((t / a.TW) % a.TH);
+    const long n = t / ((long)a.TW * a.TH);
+    if (KIND == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 2 * ta - 1 + i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = 2 * tb - 1 + j;
+          if ((unsigned)r < (unsigned)a.H && (unsigned)q < (unsigned)a.W) d[i][j] = ld4(v.p + n * v.sn + r * v.sh + q * v.sw + c);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) d[i][j] = ld4(v.p + n * v.sn + (2 * ta + i) * v.sh + (2 * tb + j) * v.sw + c);
+    }
+  }
+  const long ps = 16L * a.rows * a.Tpad;
+#pragma unroll
+  for (int pass = 0; pass < (DOUBLED ? 2 : 1); ++pass) {
+    f32x4 V[4][4];
+    if (KIND == 0) {
+      f32x4 e[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[i][j] = wino_act<ACT>(pass ? -d[i][j] : d[i][j]);
+      tf_input(e, V);
+    } else {
+      f32x4 y[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) y[i][j] = d[i][j];
+      tf_output_adj(y, V);
+    }
+    const int rowbase = a.coff[blockIdx.z] + blockIdx.y * 16 + (pass ? a.C : 0);
+#pragma unroll
+    for (int round = 0; round < 4; ++round) {
+#pragma unroll
+      for (int fl = 0; fl < 4; ++fl)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float x = V[round][fl][k];
+          const unsigned a1 = bf16_rne(x);
+          const float r1 = x - __uint_as_float(a1 << 16);
+          const unsigned a2 = bf16_rne(r1);
+          const float r2 = r1 - __uint_as_float(a2 << 16);
+          lds[0][fl][4 * cq + k][tl] = (u16)a1;
+          lds[1][fl][4 * cq + k][tl] = (u16)a2;
+          lds[2][fl][4 * cq + k][tl] = (u16)bf16_rne(r2);
+        }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 6; ++it) {
+        const int id = it * 256 + tid;
+        const int ch = id & 7, row = id >> 3;            // row = (piece, fl, cc)
+        const int piece = row >> 6, fl = (row >> 4) & 3, cc = row & 15;
+        const u32x4 val = *reinterpret_cast<const u32x4*>(&lds[piece][fl][cc][8 * ch]);
+        const long f = 4 * round + fl;
+        u16* dst = a.P + piece * ps + ((f * a.rows + rowbase + cc) * a.Tpad + (long)blockIdx.x * 64 + 8 * ch);
+        *reinterpret_cast<u32x4*>(dst) = val;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // forward filters: U[f][cls*Cout + co][ci] from weffT[cls][co][tap*Cin + ci]
 __global__ __launch_bounds__(256) void wino_filter_fwd_kernel(const float* __restrict__ weffT, long cls_stride,
                                                             int Cin, int Cout, float* __restrict__ U, u16* P) {
@@ -688,11 +788,7 @@ constexpr int X3_BM = X3_WM * X3_MT * 32, X3_BN = X3_WN * X3_NT * 32, X3_THREADS
 constexpr int X3_TA = X3_BM * X3_RS, X3_TB = X3_BN * X3_RS;
 constexpr size_t X3_LDS = 3 * (size_t)(X3_TA + X3_TB);
 
-// TN = true (wgrad): operands are [K][rows] (rows contiguous, K = tiles); the staging pass
-// transposes on the way into LDS -- a thread fetches the same 8-row chunk of four consecutive k,
-// permutes the 16-bit halves in registers and writes eight 8-byte row segments -- so the fragment
-// reads and the MFMA loop are identical to the NT case.  blockIdx.y = K split (slabs).
-template <bool TN>
+// blockIdx.y = K split (wgrad: slabs, reduced by the adjoint filter transform).
 __global__ __launch_bounds__(X3_THREADS) void wino_bgemm_x3_kernel(BgArgs a) {
   constexpr int CPR = X3_BK / 8;
   constexpr int PER_A = 3 * X3_BM * CPR / X3_THREADS, PER_B = 3 * X3_BN * CPR / X3_THREADS;
@@ -726,51 +822,11 @@ __global__ __launch_bounds__(X3_THREADS) void wino_bgemm_x3_kernel(BgArgs a) {
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / X3_WN, wn = wave % X3_WN;
   const int r = lane & 31, g = lane >> 5;
-  const u16* Ab = TN ? a.Ap + f * a.sA + m0 : a.Ap + f * a.sA + (long)m0 * a.lda;
-  const u16* Bb = TN ? a.Bp + f * a.sB + n0 : a.Bp + f * a.sB + (long)n0 * a.ldb;
+  const u16* Ab = a.Ap + f * a.sA + (long)m0 * a.lda;
+  const u16* Bb = a.Bp + f * a.sB + (long)n0 * a.ldb;
   const int mrows = a.M - m0, nrows = a.N - n0;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   u32x4 ra[PER_A], rb[PER_B];
-  // TN staging unit: (piece tile, 8-row chunk mc, group of four k tg); 32 chunks x 8 groups per piece tile
-  constexpr int UNITS = 6 * 32 * 8 / X3_THREADS;   // 3 per thread
-  auto gload_t = [&](int k0, int kend) {
-#pragma unroll
-    for (int u = 0; u < UNITS; ++u) {
-      const int id = u * X3_THREADS + tid;
-      const int tg = id & 7, mc = (id >> 3) & 31, pt = id >> 8;        // pt = operand*3 + piece
-      const bool isA = pt < 3;
-      const int rows = isA ? mrows : nrows;
-      const u16* base = isA ? Ab + pt * a.pA : Bb + (pt - 3) * a.pB;
-      const long ld = isA ? a.lda : a.ldb;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int k = k0 + 4 * tg + q;
-        const bool ok = 8 * mc < rows && k < kend;
-        const u32x4 v = ok ? *reinterpret_cast<const u32x4*>(base + (long)k * ld + 8 * mc) : zero4;
-        if (u * 4 + q < PER_A) ra[u * 4 + q] = v;
-        else rb[u * 4 + q - PER_A] = v;
-      }
-    }
-  };
-  auto sstore_t = [&]() {
-#pragma unroll
-    for (int u = 0; u < UNITS; ++u) {
-      const int id = u * X3_THREADS + tid;
-      const int tg = id & 7, mc = (id >> 3) & 31, pt = id >> 8;
-      unsigned char* tile = (pt < 3 ? sA + pt * X3_TA : sB + (pt - 3) * X3_TB) + (8 * mc) * X3_RS + 8 * tg;
-      u32x4 c[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) c[q] = (u * 4 + q < PER_A) ? ra[u * 4 + q] : rb[u * 4 + q - PER_A];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        // row j of the chunk: halves (j & 1) of dword j/2 of the four k
-        const unsigned sel = (j & 1) ? 0x07060302u : 0x05040100u;
-        const unsigned lo = __builtin_amdgcn_perm(c[1][j >> 1], c[0][j >> 1], sel);
-        const unsigned hi2 = __builtin_amdgcn_perm(c[3][j >> 1], c[2][j >> 1], sel);
-        *reinterpret_cast<uint2*>(tile + j * X3_RS) = make_uint2(lo, hi2);
-      }
-    }
-  };
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < PER_A; ++i) {
@@ -830,37 +886,27 @@ __global__ __launch_bounds__(X3_THREADS) void wino_bgemm_x3_kernel(BgArgs a) {
       ++nrun;
       c = e;
     }
-  } else if (TN) {
-    // K split: blockIdx.y takes kt_per_split steps; the last step of the tensor may be ragged (zero-filled)
-    const int nkt_all = (a.K + X3_BK - 1) / X3_BK;
+  } else {
+    // K split: blockIdx.y takes kt_per_split steps (all of K when there is one split)
+    const int nkt_all = a.K / X3_BK;
     const int kt0 = blockIdx.y * a.kt_per_split;
     int nkt = nkt_all - kt0;
     if (nkt > a.kt_per_split) nkt = a.kt_per_split;
     if (nkt < 0) nkt = 0;
     lo0 = kt0 * X3_BK;
     len0 = nkt * X3_BK;
-  } else {
-    len0 = a.K;
   }
   // flatten the runs into one sequence of K steps
   const int steps0 = len0 / X3_BK;
   const int nsteps = steps0 + len1 / X3_BK;
   auto kof = [&](int st) { return st < steps0 ? lo0 + st * X3_BK : lo1 + (st - steps0) * X3_BK; };
-  auto load_step = [&](int st) {
-    if (TN) gload_t(kof(st), a.K);
-    else gload(kof(st));
-  };
-  auto store_step = [&]() {
-    if (TN) sstore_t();
-    else sstore();
-  };
   if (nsteps > 0) {
-    load_step(0);
-    store_step();
+    gload(kof(0));
+    sstore();
   }
   __syncthreads();
   for (int st = 0; st < nsteps; ++st) {
-    if (st + 1 < nsteps) load_step(st + 1);
+    if (st + 1 < nsteps) gload(kof(st + 1));
 #pragma unroll
     for (int sl = 0; sl < X3_BK / 16; ++sl) {
       bf16x8 A[X3_MT][3], B[X3_NT][3];
@@ -889,11 +935,11 @@ __global__ __launch_bounds__(X3_THREADS) void wino_bgemm_x3_kernel(BgArgs a) {
     }
     __syncthreads();
     if (st + 1 < nsteps) {
-      store_step();
+      sstore();
       __syncthreads();
     }
   }
-  float* C = a.C + f * a.sC + (TN ? blockIdx.y * a.sSplit : 0);
+  float* C = a.C + f * a.sC + blockIdx.y * a.sSplit;
 #pragma unroll
   for (int i = 0; i < X3_MT; ++i)
 #pragma unroll
@@ -915,18 +961,18 @@ void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
   // executed fp32-equivalent FLOP: 16 GEMMs, minus the skipped (class, frequency) blocks of the strided layers
   double flop = 2.0 * 16.0 * (double)a.M * a.N * a.K;
   if (a.seg_mode) flop *= 49.0 / 64.0;
-  const bool x3 = a.Ap != nullptr;
+  const bool x3 = !TN && a.Ap != nullptr;
   ProfScope ps(x3 ? OTGAN_PROF_WINO_GEMM_X3 : OTGAN_PROF_WINO_GEMM, x3 ? 6.0 * flop : flop, 0.0, s);
   if (x3) {
-    ensure_lds<wino_bgemm_x3_kernel<TN>>(X3_LDS);
+    ensure_lds<wino_bgemm_x3_kernel>(X3_LDS);
     BgArgs b = a;
     b.tiles_m = (a.M + X3_BM - 1) / X3_BM;
     b.tiles_n = (a.N + X3_BN - 1) / X3_BN;
     const bool m_ok = b.tiles_m % 8 == 0, n_ok = b.tiles_n % 8 == 0;
     if (a.M >= a.N) b.xmap = m_ok ? 1 : n_ok ? 2 : 0;
     else b.xmap = n_ok ? 2 : m_ok ? 1 : 0;
-    hipLaunchKernelGGL((wino_bgemm_x3_kernel<TN>), dim3(b.tiles_m * b.tiles_n, TN ? nsplit : 1, 16), dim3(X3_THREADS),
-                       X3_LDS, s, b);
+    if (nsplit == 1) b.kt_per_split = a.K / X3_BK;
+    hipLaunchKernelGGL(wino_bgemm_x3_kernel, dim3(b.tiles_m * b.tiles_n, nsplit, 16), dim3(X3_THREADS), X3_LDS, s, b);
     return;
   }
   ensure_lds<wino_bgemm_kernel<TN>>(lds);
@@ -950,13 +996,12 @@ bool use_x3() {
   }();
   return on;
 }
-// wgrad (TN) on the bf16 pipe: the transposing staging pass (8-byte LDS writes, 2-way bank conflicts,
-// in-register 16-bit permutes) costs what the faster MFMAs save -- measured 1.14-1.25 ms against
-// 1.1-1.28 ms for the fp32 engine on the six wgrad GEMMs -- so it is off unless OTGAN_WINO_WGRAD_X3=1.
+// wgrad on the bf16 pipe (tile-contiguous operands from the transposing producers) unless
+// OTGAN_WINO_WGRAD_X3=0
 bool use_x3_wgrad() {
   static const bool on = [] {
     const char* e = getenv("OTGAN_WINO_WGRAD_X3");
-    return e && e[0] == '1';
+    return !(e && e[0] == '0');
   }();
   return on && use_x3();
 }
@@ -1014,8 +1059,9 @@ size_t wino_fwd_ws_floats(const WinoGeo& g) {
 size_t wino_dgrad_ws_floats(const WinoGeo& g) { return wino_fwd_ws_floats(g); }
 size_t wino_wgrad_ws_floats(const WinoGeo& g) {
   const size_t T = (size_t)wino_tiles(g);
-  const int ns = std::max(wgrad_splits(g), x3_wgrad_splits(g.Cin, 4 * g.Cout, (long)T));
-  return operand_floats(16 * T * g.Cin) + operand_floats(16 * T * 4 * g.Cout) + (size_t)ns * 16 * 4 * g.Cout * g.Cin;
+  const size_t Tp = (T + 63) / 64 * 64;
+  const int ns = std::max(wgrad_splits(g), x3_wgrad_splits(g.Cin, 4 * g.Cout, (long)Tp));
+  return operand_floats(16 * Tp * g.Cin) + operand_floats(16 * Tp * 4 * g.Cout) + (size_t)ns * 16 * 4 * g.Cout * g.Cin;
 }
 
 int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stride, const float* bias, float* y,
@@ -1099,20 +1145,49 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
                hipStream_t s) {
   const long T = wino_tiles(g);
   const int N4 = 4 * g.Cout;
-  const bool x3 = use_x3_wgrad() && g.Cin % 8 == 0 && N4 % 8 == 0;
-  const int ns = x3 ? x3_wgrad_splits(g.Cin, N4, T) : wgrad_splits(g);
+  if (use_x3_wgrad() && g.Cin % 16 == 0 && g.Cout % 16 == 0) {
+    // operands tile-contiguous (transposing producers), NT GEMM on the bf16 pipe with K = tiles
+    const long Tp = (T + 63) / 64 * 64;
+    const int ns = x3_wgrad_splits(g.Cin, N4, Tp);
+    const size_t nV = 16 * (size_t)Tp * g.Cin, nM = 16 * (size_t)Tp * N4;
+    u16* VP = reinterpret_cast<u16*>(ws);
+    u16* MP = reinterpret_cast<u16*>(ws + operand_floats(nV));
+    float* slabs = ws + operand_floats(nV) + operand_floats(nM);
+    ProdTArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.v[0].p = x; pa.v[0].sn = (long)g.H * g.W * g.ldx; pa.v[0].sh = (long)g.W * g.ldx; pa.v[0].sw = g.ldx;
+    pa.H = g.H; pa.W = g.W; pa.TH = g.H / 2; pa.TW = g.W / 2; pa.C = g.Cin; pa.T = T; pa.Tpad = Tp; pa.rows = g.Cin;
+    pa.P = VP;
+    hipLaunchKernelGGL((wino_prodT_kernel<0, 0, false>), dim3((int)(Tp / 64), g.Cin / 16, 1), dim3(256), 0, s, pa);
+    ProdTArgs pd;
+    memset(&pd, 0, sizeof(pd));
+    class_views(g, dy + g.y_coff, g.ldy, pd.v);
+    for (int cls = 0; cls < 4; ++cls) pd.coff[cls] = cls * g.Cout;
+    pd.H = g.H; pd.W = g.W; pd.TH = g.H / 2; pd.TW = g.W / 2; pd.C = g.Cout; pd.T = T; pd.Tpad = Tp; pd.rows = N4;
+    pd.P = MP;
+    hipLaunchKernelGGL((wino_prodT_kernel<1, 0, false>), dim3((int)(Tp / 64), g.Cout / 16, 4), dim3(256), 0, s, pd);
+    BgArgs b;
+    memset(&b, 0, sizeof(b));
+    b.Ap = VP; b.Bp = MP; b.pA = (long)nV; b.pB = (long)nM;
+    b.C = slabs; b.M = g.Cin; b.N = N4; b.K = (int)Tp;
+    b.lda = Tp; b.ldb = Tp; b.ldc = N4;
+    b.sA = (long)g.Cin * Tp; b.sB = (long)N4 * Tp; b.sC = (long)g.Cin * N4; b.sSplit = 16L * g.Cin * N4;
+    b.kt_per_split = (int)((Tp / X3_BK + ns - 1) / ns);
+    launch_bgemm<false>(b, ns, s);
+    hipLaunchKernelGGL(wino_filter_adj_kernel, dim3(grid1(4L * g.Cin * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
+                       16L * g.Cin * N4, g.Cin, g.Cout, dweff, cls_stride);
+    return OTGAN_OK;
+  }
+  const int ns = wgrad_splits(g);
   const size_t nV = 16 * (size_t)T * g.Cin, nM = 16 * (size_t)T * N4;
   float* V = ws;                              // [16][T][Cin]
   float* dM = V + operand_floats(nV);         // [16][T][4*Cout]
   float* slabs = dM + operand_floats(nM);     // [ns][16][Cin][4*Cout]
-  u16* VP = x3 ? reinterpret_cast<u16*>(V) : nullptr;
-  u16* MP = x3 ? reinterpret_cast<u16*>(dM) : nullptr;
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
   ia.s2_skip = -1;
   ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
   ia.H = g.H; ia.W = g.W; ia.TH = g.H / 2; ia.TW = g.W / 2; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.V = V;
-  ia.P = VP;
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(grid1(T * (g.Cin / 4)), 1, 1), dim3(256), 0, s, ia);
   InArgs da;
   memset(&da, 0, sizeof(da));
@@ -1120,11 +1195,9 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
   class_views(g, dy + g.y_coff, g.ldy, da.v);
   for (int cls = 0; cls < 4; ++cls) da.coff[cls] = cls * g.Cout;
   da.H = g.H; da.W = g.W; da.TH = g.H / 2; da.TW = g.W / 2; da.C = g.Cout; da.T = T; da.ldv = N4; da.V = dM;
-  da.P = MP;
   hipLaunchKernelGGL(wino_outadj_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 4), dim3(256), 0, s, da);
   BgArgs b;
   memset(&b, 0, sizeof(b));
-  b.Ap = VP; b.Bp = MP; b.pA = (long)nV; b.pB = (long)nM;
   b.A = V; b.B = dM; b.C = slabs; b.M = g.Cin; b.N = N4; b.K = (int)T;
   b.lda = g.Cin; b.ldb = N4; b.ldc = N4;
   b.sA = T * g.Cin; b.sB = T * N4; b.sC = (long)g.Cin * N4; b.sSplit = 16L * g.Cin * N4;
@@ -1193,8 +1266,9 @@ size_t wino_s2_fwd_ws_floats(const WinoS2Geo& g) {
 size_t wino_s2_dgrad_ws_floats(const WinoS2Geo& g) { return wino_s2_fwd_ws_floats(g); }
 size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g) {
   const size_t T = (size_t)wino_s2_tiles(g), K4 = 4 * (size_t)g.Ceff;
-  const int ns = std::max(s2_wgrad_splits(g), x3_wgrad_splits((int)K4, g.Cout, (long)T));
-  return operand_floats(16 * T * K4) + operand_floats(16 * T * g.Cout) + (size_t)ns * 16 * K4 * g.Cout;
+  const size_t Tp = (T + 63) / 64 * 64;
+  const int ns = std::max(s2_wgrad_splits(g), x3_wgrad_splits((int)K4, g.Cout, (long)Tp));
+  return operand_floats(16 * Tp * K4) + operand_floats(16 * Tp * g.Cout) + (size_t)ns * 16 * K4 * g.Cout;
 }
 
 int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float* bias, float* y, float* ws,
@@ -1281,25 +1355,58 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
   const long T = wino_s2_tiles(g);
   const int K4 = 4 * g.Ceff;
   const int OH = g.H / 2, OW = g.W / 2;
-  const bool x3 = use_x3_wgrad() && g.Cout % 8 == 0;
-  const int ns = x3 ? x3_wgrad_splits(K4, g.Cout, T) : s2_wgrad_splits(g);
+  if (use_x3_wgrad() && g.C % 16 == 0 && g.Cout % 16 == 0) {
+    const long Tp = (T + 63) / 64 * 64;
+    const int ns = x3_wgrad_splits(K4, g.Cout, Tp);
+    const size_t nV = 16 * (size_t)Tp * K4, nM = 16 * (size_t)Tp * g.Cout;
+    u16* VP = reinterpret_cast<u16*>(ws);
+    u16* MP = reinterpret_cast<u16*>(ws + operand_floats(nV));
+    float* slabs = ws + operand_floats(nV) + operand_floats(nM);
+    ProdTArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    parity_views(g.H, g.W, x, g.ldx, pa.v);
+    for (int cls = 0; cls < 4; ++cls) pa.coff[cls] = cls * g.Ceff;
+    pa.H = OH; pa.W = OW; pa.TH = OH / 2; pa.TW = OW / 2; pa.C = g.C; pa.T = T; pa.Tpad = Tp; pa.rows = K4; pa.P = VP;
+    const dim3 grid((int)(Tp / 64), g.C / 16, 4), blk(256);
+    if (g.doubled) {
+      if (g.act == 2) hipLaunchKernelGGL((wino_prodT_kernel<0, 2, true>), grid, blk, 0, s, pa);
+      else hipLaunchKernelGGL((wino_prodT_kernel<0, 1, true>), grid, blk, 0, s, pa);
+    } else if (g.act == 1) hipLaunchKernelGGL((wino_prodT_kernel<0, 1, false>), grid, blk, 0, s, pa);
+    else if (g.act == 2) hipLaunchKernelGGL((wino_prodT_kernel<0, 2, false>), grid, blk, 0, s, pa);
+    else hipLaunchKernelGGL((wino_prodT_kernel<0, 0, false>), grid, blk, 0, s, pa);
+    ProdTArgs pd;
+    memset(&pd, 0, sizeof(pd));
+    pd.v[0].p = dy + g.y_coff; pd.v[0].sn = (long)OH * OW * g.ldy; pd.v[0].sh = (long)OW * g.ldy; pd.v[0].sw = g.ldy;
+    pd.H = OH; pd.W = OW; pd.TH = OH / 2; pd.TW = OW / 2; pd.C = g.Cout; pd.T = T; pd.Tpad = Tp; pd.rows = g.Cout;
+    pd.P = MP;
+    hipLaunchKernelGGL((wino_prodT_kernel<1, 0, false>), dim3((int)(Tp / 64), g.Cout / 16, 1), dim3(256), 0, s, pd);
+    BgArgs b;
+    memset(&b, 0, sizeof(b));
+    b.Ap = VP; b.Bp = MP; b.pA = (long)nV; b.pB = (long)nM;
+    b.C = slabs; b.M = K4; b.N = g.Cout; b.K = (int)Tp;
+    b.lda = Tp; b.ldb = Tp; b.ldc = g.Cout;
+    b.sA = (long)K4 * Tp; b.sB = (long)g.Cout * Tp; b.sC = (long)K4 * g.Cout; b.sSplit = 16L * K4 * g.Cout;
+    b.kt_per_split = (int)((Tp / X3_BK + ns - 1) / ns);
+    b.seg_mode = 3; b.seg_len = g.Ceff; b.seg_skip = 0;
+    launch_bgemm<false>(b, ns, s);
+    hipLaunchKernelGGL(wino_s2_filter_adj_kernel, dim3(grid1(4L * g.Ceff * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
+                       16L * K4 * g.Cout, g.Ceff, g.Cout, dw);
+    return OTGAN_OK;
+  }
+  const int ns = s2_wgrad_splits(g);
   const size_t nV = 16 * (size_t)T * K4, nM = 16 * (size_t)T * g.Cout;
   float* V = ws;                              // [16][T][4*Ceff]
   float* dM = V + operand_floats(nV);         // [16][T][Cout]
   float* slabs = dM + operand_floats(nM);     // [ns][16][4*Ceff][Cout]
-  u16* VP = x3 ? reinterpret_cast<u16*>(V) : nullptr;
-  u16* MP = x3 ? reinterpret_cast<u16*>(dM) : nullptr;
-  s2_input_transform(g, x, V, VP, s);
+  s2_input_transform(g, x, V, nullptr, s);
   InArgs da;
   memset(&da, 0, sizeof(da));
   da.s2_skip = -1;
   da.v[0].p = dy + g.y_coff; da.v[0].sn = (long)OH * OW * g.ldy; da.v[0].sh = (long)OW * g.ldy; da.v[0].sw = g.ldy;
   da.H = OH; da.W = OW; da.TH = OH / 2; da.TW = OW / 2; da.C = g.Cout; da.T = T; da.ldv = g.Cout; da.V = dM;
-  da.P = MP;
   hipLaunchKernelGGL(wino_outadj_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 1), dim3(256), 0, s, da);
   BgArgs b;
   memset(&b, 0, sizeof(b));
-  b.Ap = VP; b.Bp = MP; b.pA = (long)nV; b.pB = (long)nM;
   b.A = V; b.B = dM; b.C = slabs; b.M = K4; b.N = g.Cout; b.K = (int)T;
   b.lda = K4; b.ldb = g.Cout; b.ldc = g.Cout;
   b.sA = T * K4; b.sB = T * g.Cout; b.sC = (long)K4 * g.Cout; b.sSplit = 16L * K4 * g.Cout;
