@@ -54,10 +54,19 @@ typedef struct otgan_conv_desc {
 size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which);
 
 /*
- * Folded 5x5 upsampling layers without pre-activation (the DCGAN generator, models/dcgan.py:33-46)
- * additionally run in Winograd F(2x2,3x3) form on the small image -- 2.25x fewer multiply-adds
- * again; the three passes then need scratch for the transformed operands, reported by
- * otgan_conv2d_workspace_bytes.  Nothing else changes for the caller (same folded weights).
+ * Winograd F(2x2,3x3) paths (fwd, dgrad and wgrad; scratch for the transformed operands is
+ * reported by otgan_conv2d_workspace_bytes; nothing else changes for the caller):
+ *   - folded 5x5 upsampling layers without pre-activation (the DCGAN generator,
+ *     models/dcgan.py:33-46): each output-parity class is a 3x3 convolution on the small image;
+ *   - 5x5 stride-2 layers with a single-tensor input (the DCGAN critic, models/dcgan.py:12-14):
+ *     four 3x3 sub-convolutions of the input-parity sub-images, classes folded into the
+ *     contraction index, structurally-zero blocks skipped (49 instead of 100 products per tile).
+ * The batched GEMMs of these paths run on the bf16 matrix pipe with operands stored as three bf16
+ * planes (hi + mid + lo): six MFMAs per fp32-exact product, fp32 accumulation -- results are at
+ * least as accurate as the fp32 MFMA chain of the direct path.
+ * Environment switches (debugging / A-B measurements): OTGAN_DISABLE_WINOGRAD=1,
+ * OTGAN_WINO_FP32=1 (Winograd GEMMs on the fp32 engine), OTGAN_WINO_WGRAD_X3=0,
+ * OTGAN_DISABLE_DENSE16=1, OTGAN_DENSE16_V1=1.
  */
 
 /*
