@@ -533,7 +533,9 @@ __global__ __launch_bounds__(256) void wino_s2_filter_fwd_kernel(const float* __
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) st_operand(U, P, 16 * fs, (i * 4 + j) * fs + (long)co * ldu + (long)cls * Ceff + ce, Uv[i][j]);
+    for (int j = 0; j < 4; ++j)
+      if (s2_present(cls, i * 4 + j, 0))   // absent blocks are never read by the GEMM
+        st_operand(U, P, 16 * fs, (i * 4 + j) * fs + (long)co * ldu + (long)cls * Ceff + ce, Uv[i][j]);
 }
 
 // backward filters (flipped): U'[f][cls*Ceff + ce][co] from w[kh*5+kw][ce][co]
