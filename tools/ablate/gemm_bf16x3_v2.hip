@@ -315,6 +315,131 @@ void run_big(const char* name, const Args& a, const std::vector<float>& hA, cons
          lds, ms, tf, sqrt(num / den));
 }
 
+// DMA-staged variant: global_load_lds (16 bytes per lane, lane-linear LDS image) with an XOR swizzle
+// applied on the SOURCE address and on the fragment READ; BK = 16 (32-byte rows), two LDS buffers,
+// one barrier per K step, no VGPR staging and no ds_write pass.
+template <int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(Args a) {
+  constexpr int BK = 16, RB = BK * 2, THREADS = WM * WN * 64, WAVES = WM * WN;
+  constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+  constexpr int TA = BM * RB, TB = BN * RB, BUF = 3 * (TA + TB);
+  // one glds instruction of a wave fills 64 consecutive 16-byte slots = 32 rows x 2 chunks
+  constexpr int ROWS_PER_INST = 32;
+  constexpr int INST_A = 3 * BM / ROWS_PER_INST, INST_B = 3 * BN / ROWS_PER_INST;   // per K step, whole block
+  constexpr int PER_WAVE = (INST_A + INST_B) / WAVES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, g = lane >> 5;
+  const int f = blockIdx.z;
+  const long planeA = (long)a.F * a.M * a.K, planeB = (long)a.F * a.N * a.K;
+  const u16* Ab = a.Ap + ((long)f * a.M + (long)blockIdx.x * BM) * a.K;
+  const u16* Bb = a.Bp + ((long)f * a.N + (long)blockIdx.y * BN) * a.K;
+  // lane -> (row within the 32-row group, physical chunk); logical chunk = physical ^ swz(row)
+  const int lrow = lane >> 1, pc = lane & 1;
+  auto issue = [&](int kt, int buf) {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int inst = wave * PER_WAVE + i;            // 0 .. INST_A + INST_B - 1
+      const bool isA = inst < INST_A;
+      const int li = isA ? inst : inst - INST_A;
+      const int rows_per_piece = (isA ? BM : BN) / ROWS_PER_INST;
+      const int piece = li / rows_per_piece, rg = li % rows_per_piece;
+      const int row = rg * ROWS_PER_INST + lrow;
+      const int c = pc ^ ((row >> 3) & 1);
+      const u16* src = (isA ? Ab + piece * planeA : Bb + piece * planeB) + (long)row * a.K + kt * BK + c * 8;
+      unsigned char* dst = smem + buf * BUF + (isA ? piece * TA : 3 * TA + piece * TB) + rg * ROWS_PER_INST * RB;
+      __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  const int nk = a.K / BK;
+  issue(0, 0);
+  __syncthreads();
+  // fragment byte offset inside a piece tile: row * 32 + 16 * (g ^ swz(row)); rows of a 32-row MFMA tile
+  const int sw = (r >> 3) & 1;
+  const int fa = (wm * MT * 32 + r) * RB + 16 * (g ^ sw);
+  const int fb = (wn * NT * 32 + r) * RB + 16 * (g ^ sw);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+    const unsigned char* base = smem + cur * BUF;
+    bf16x8 A[MT][3], B[NT][3];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) A[t][p] = *reinterpret_cast<const bf16x8*>(base + p * TA + fa + t * 32 * RB);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) B[t][p] = *reinterpret_cast<const bf16x8*>(base + 3 * TA + p * TB + fb + t * 32 * RB);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][2], B[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[j][2], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][1], B[j][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][1], B[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[j][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[j][0], acc[i][j], 0, 0, 0);
+      }
+    __syncthreads();
+  }
+  float* C = a.C + (long)f * a.M * a.N;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int rr = (q & 3) + 8 * (q >> 2) + 4 * g;
+        const long m = (long)blockIdx.x * BM + (wm * MT + i) * 32 + rr;
+        const long n = (long)blockIdx.y * BN + (wn * NT + j) * 32 + r;
+        C[m * a.N + n] = acc[i][j][q];
+      }
+}
+
+template <int WM, int WN, int MT, int NT>
+void run_glds(const char* name, const Args& a, const std::vector<float>& hA, const std::vector<float>& hB) {
+  constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+  if (a.M % BM || a.N % BN) { printf("%-26s skipped (shape)\n", name); return; }
+  const size_t lds = (size_t)2 * 3 * (BM + BN) * 32;
+  auto kern = gemm_glds_kernel<WM, WN, MT, NT>;
+  hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  dim3 grid(a.M / BM, a.N / BN, a.F);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, 0, a);
+  hipEventRecord(e0);
+  const int reps = 5;
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, 0, a);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  ms /= reps;
+  const double tf = 2.0 * a.F * (double)a.M * a.N * a.K / (ms * 1e-3) / 1e12;
+  std::vector<float> c(64 * 64);
+  for (int m = 0; m < 64; ++m) hipMemcpy(&c[m * 64], a.C + (long)m * a.N, 64 * 4, hipMemcpyDeviceToHost);
+  double num = 0, den = 0;
+  for (int m = 0; m < 64; ++m)
+    for (int n = 0; n < 64; ++n) {
+      double s = 0;
+      for (int k = 0; k < a.K; ++k) s += (double)hA[(long)m * a.K + k] * (double)hB[(long)n * a.K + k];
+      num += (s - c[m * 64 + n]) * (s - c[m * 64 + n]);
+      den += s * s;
+    }
+  printf("%-26s grid %4dx%-3dx%-2d lds %6zu  %8.3f ms  %7.1f TF/s-equiv  relL2 %.2e\n", name, grid.x, grid.y, grid.z,
+         lds, ms, tf, sqrt(num / den));
+}
+
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 16384, N = argc > 2 ? atoi(argv[2]) : 1024, K = argc > 3 ? atoi(argv[3]) : 256;
   const int F = argc > 4 ? atoi(argv[4]) : 16;
@@ -338,6 +463,9 @@ int main(int argc, char** argv) {
   run<16, true, 6>("bk16 double 6t", a, hA, hB);
   run<16, false, 6>("bk16 single 6t", a, hA, hB);
   run_big<2, 4, 4, 2>("256x256 8w (128x64/wave)", a, hA, hB);
+  hipMemset(a.C, 0, (size_t)a.F * a.M * a.N * 4);
+  run_glds<2, 4, 4, 2>("glds 256x256 8w bk16", a, hA, hB);
+  run_glds<2, 2, 2, 2>("glds 128x128 4w bk16", a, hA, hB);
   run_big<4, 2, 2, 4>("256x256 8w (64x128/wave)", a, hA, hB);
   run_big<2, 4, 2, 2>("128x256 8w (64x64/wave)", a, hA, hB);
   run_big<4, 2, 2, 2>("256x128 8w (64x64/wave)", a, hA, hB);
