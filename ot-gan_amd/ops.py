@@ -176,6 +176,16 @@ def conv_wgrad_raw(desc, x, cmap, dy, dw):
                                         _lib.stream_ptr()), "conv2d_wgrad")
 
 
+def fold_weights(desc, w):
+    """(weff, weffT) of an upsampling layer that the library folds (otgan_layers.h); `w` is HWIO."""
+    nfold = _lib.lib().otgan_conv2d_folded_weight_elems(ctypes.byref(desc))
+    weff = torch.empty(nfold, dtype=w.dtype, device=w.device)
+    weffT = torch.empty(nfold, dtype=w.dtype, device=w.device)
+    _lib.check(_lib.lib().otgan_conv2d_fold_weights_f32(ctypes.byref(desc), w.data_ptr(), weff.data_ptr(),
+                                                        weffT.data_ptr(), _lib.stream_ptr()), "fold_weights")
+    return weff, weffT
+
+
 # ------------------------------------------------------------------------------- conv2d / dense
 class Conv2dFunction(torch.autograd.Function):
     """y = conv2d(preact(upsample(x)), g*V/||V||) + b     (reference nn.py:327-338).
@@ -207,11 +217,7 @@ class Conv2dFunction(torch.autograd.Function):
             wd = w                       # operand of dgrad
             if nfold:
                 # conv o upsample == four parity-class convs with pre-summed taps (otgan_layers.h)
-                wd = torch.empty(nfold, dtype=w.dtype, device=w.device)
-                wT = torch.empty(nfold, dtype=w.dtype, device=w.device)
-                _lib.check(_lib.lib().otgan_conv2d_fold_weights_f32(ctypes.byref(desc), w.data_ptr(),
-                                                                    wd.data_ptr(), wT.data_ptr(),
-                                                                    _lib.stream_ptr()), "fold_weights")
+                wd, wT = fold_weights(desc, w)
             return wd, wT, inv_norm
 
         wd, wT, inv_norm = cached_weights(V, g, compute)
