@@ -49,27 +49,31 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ unsigned bf16_rne(float x) {
-  unsigned u = __float_as_uint(x);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return u >> 16;
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// (hi, mid, lo) bf16 pieces of two floats, each packed in one dword (round-to-nearest-even through
+// v_cvt_pk_bf16_f32; the residuals are exact in fp32)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  f32x2_t v = {x0, x1};
+  const bf16x2_t hb = __builtin_convertvector(v, bf16x2_t);
+  v -= __builtin_convertvector(hb, f32x2_t);
+  const bf16x2_t mb = __builtin_convertvector(v, bf16x2_t);
+  v -= __builtin_convertvector(mb, f32x2_t);
+  const bf16x2_t lb = __builtin_convertvector(v, bf16x2_t);
+  h = __builtin_bit_cast(unsigned, hb);
+  m = __builtin_bit_cast(unsigned, mb);
+  l = __builtin_bit_cast(unsigned, lb);
 }
 // planes[p][idx .. idx+3] = p-th bf16 piece of v
 __device__ __forceinline__ void st_split4(u16* planes, long plane_stride, long idx, f32x4 v) {
-  u16x4 h, m, l;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const unsigned a1 = bf16_rne(v[j]);
-    const float r1 = v[j] - __uint_as_float(a1 << 16);
-    const unsigned a2 = bf16_rne(r1);
-    const float r2 = r1 - __uint_as_float(a2 << 16);
-    h[j] = (u16)a1;
-    m[j] = (u16)a2;
-    l[j] = (u16)bf16_rne(r2);
-  }
-  *reinterpret_cast<u16x4*>(planes + idx) = h;
-  *reinterpret_cast<u16x4*>(planes + plane_stride + idx) = m;
-  *reinterpret_cast<u16x4*>(planes + 2 * plane_stride + idx) = l;
+  unsigned h0, m0, l0, h1, m1, l1;
+  split2(v[0], v[1], h0, m0, l0);
+  split2(v[2], v[3], h1, m1, l1);
+  *reinterpret_cast<u32x2*>(planes + idx) = u32x2{h0, h1};
+  *reinterpret_cast<u32x2*>(planes + plane_stride + idx) = u32x2{m0, m1};
+  *reinterpret_cast<u32x2*>(planes + 2 * plane_stride + idx) = u32x2{l0, l1};
 }
 // store element group idx of a [16][rows][ld] operand either as fp32 or as three bf16 planes
 __device__ __forceinline__ void st_operand(float* F, u16* P, long plane_stride, long idx, f32x4 v) {
@@ -395,15 +399,15 @@ __global__ __launch_bounds__(256) void wino_prodT_kernel(ProdTArgs a) {
 #pragma unroll
       for (int fl = 0; fl < 4; ++fl)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float x = V[round][fl][k];
-          const unsigned a1 = bf16_rne(x);
-          const float r1 = x - __uint_as_float(a1 << 16);
-          const unsigned a2 = bf16_rne(r1);
-          const float r2 = r1 - __uint_as_float(a2 << 16);
-          lds[0][fl][4 * cq + k][tl] = (u16)a1;
-          lds[1][fl][4 * cq + k][tl] = (u16)a2;
-          lds[2][fl][4 * cq + k][tl] = (u16)bf16_rne(r2);
+        for (int k = 0; k < 4; k += 2) {
+          unsigned h, m, l;
+          split2(V[round][fl][k], V[round][fl][k + 1], h, m, l);
+          lds[0][fl][4 * cq + k][tl] = (u16)h;
+          lds[0][fl][4 * cq + k + 1][tl] = (u16)(h >> 16);
+          lds[1][fl][4 * cq + k][tl] = (u16)m;
+          lds[1][fl][4 * cq + k + 1][tl] = (u16)(m >> 16);
+          lds[2][fl][4 * cq + k][tl] = (u16)l;
+          lds[2][fl][4 * cq + k + 1][tl] = (u16)(l >> 16);
         }
       __syncthreads();
 #pragma unroll
