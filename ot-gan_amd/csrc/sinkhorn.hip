@@ -235,51 +235,50 @@ struct PanelArgs {
   const float* K;      // [P][N][N]
   int N, iters, R;
   float inv_lambda;
-  float* f;            // [P][N] exchange buffers
-  float* g;            // [P][N]
-  unsigned* bar;       // [P] arrival counters (zeroed before the launch)
-  unsigned* fail;      // [1] set when a spin gave up
+  unsigned long long* f;   // [P][N] exchange buffers: (sequence number << 32) | float bits; zeroed before the launch
+  unsigned long long* g;   // [P][N]
+  unsigned* fail;          // [1] set when a spin gave up
   float* plan;
   float* planT;
   double* stats;       // zeroed before the launch
 };
 
-// Exchange protocol (cdna_hip_programming.md Guideline 16, form R1): potentials are PUBLISHED
-// with write-through (sc1) 4-byte stores, every storing wave drains its stores, one lane
-// bumps the arrival counter; consumers poll the counter relaxed and then READ the potentials
-// with sc1 loads (L1 bypass) -- no release/acquire fences on the critical path.
-__device__ __forceinline__ void publish_f32(float* p, float v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Exchange protocol: every potential travels as ONE naturally aligned 8-byte word
+// (half-sweep sequence number << 32 | float bits), published with a relaxed agent-scope atomic
+// store (write-through, sc1) and polled by the thread that needs it with relaxed agent-scope
+// atomic loads (L1 bypass) until the sequence number matches.  An 8-byte atomic is single-copy
+// atomic, so value and tag arrive together: no counter, no flag line, no fence, no store drain --
+// one store and one load round trip per half-sweep instead of store drain + counter atomic +
+// counter poll + data load (measured: N = 1024, 100 sweeps 2.25 ms -> see profiles/README.md).
+// Reuse of the two buffers is safe: a workgroup can publish f of sweep k+1 only after it consumed
+// every g of sweep k, which every workgroup publishes only after consuming every f of sweep k.
+__device__ __forceinline__ void publish_tagged(unsigned long long* p, float v, unsigned seq) {
+  const unsigned long long w = ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(v);
+  __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ float consume_f32(const float* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ bool panel_barrier(unsigned* ctr, unsigned target, unsigned* fail) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its sc1 stores
-  __syncthreads();
-  __shared__ int s_ok;
-  if (threadIdx.x == 0) {
-    int ok = 1;
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned spins = 0;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 23)) {  // ~1 s: give up instead of hanging the device
-        __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0;
-        break;
-      }
+__device__ __forceinline__ float consume_tagged(const unsigned long long* p, unsigned seq, unsigned* fail,
+                                                bool& ok) {
+  unsigned spins = 0;
+  for (;;) {
+    const unsigned long long w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(w >> 32) == seq) return __uint_as_float((unsigned)w);
+    if (++spins > (1u << 22)) {  // ~1 s: give up instead of hanging the device
+      __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ok = false;
+      return 0.f;
     }
-    s_ok = ok;
+    __builtin_amdgcn_s_sleep(1);
   }
-  __syncthreads();
-  return s_ok != 0;
+}
+__device__ __forceinline__ float value_of(const unsigned long long* p) {   // a completed exchange slot
+  return __uint_as_float((unsigned)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
 // combine the TPR partial (max, sum) pairs of one line and publish -LSE to global memory
 template <int TPR, int RPW>
 __device__ __forceinline__ void panel_combine(float mx, float s, float* s_pm, float* s_ps, int line,
-                                              int q, int gline, int N, float* out_global) {
+                                              int q, int gline, int N, unsigned long long* out_global,
+                                              unsigned seq) {
   s_pm[q * RPW + line] = mx;
   s_ps[q * RPW + line] = s;
   __syncthreads();
@@ -290,7 +289,7 @@ __device__ __forceinline__ void panel_combine(float mx, float s, float* s_pm, fl
     float S = 0.f;
 #pragma unroll 4
     for (int k = 0; k < TPR; ++k) S += s_ps[k * RPW + line] * exp_neg(s_pm[k * RPW + line] - M);
-    if (gline < N) publish_f32(out_global + gline, -(M + logf(S)));
+    if (gline < N) publish_tagged(out_global + gline, -(M + logf(S)), seq);
   }
 }
 
@@ -318,9 +317,8 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
     const int i = q * 32 + e;
     s_kc[i * RPW + line] = (i < N && gline < N) ? K[(long)i * N + gline] : kNegBig;
   }
-  float* f = a.f + (long)p * N;
-  float* g = a.g + (long)p * N;
-  unsigned* bar = a.bar + p;
+  unsigned long long* f = a.f + (long)p * N;
+  unsigned long long* g = a.g + (long)p * N;
   unsigned phase = 0;
   s_pot[t] = 0.f;  // g = 0 (1024 threads cover the 1024 slots)
   __syncthreads();
@@ -337,12 +335,14 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
       float s = 0.f;
 #pragma unroll
       for (int e = 0; e < 32; ++e) s += exp_neg(v[e] - mx);
-      panel_combine<TPR, RPW>(mx, s, s_pm, s_ps, line, q, gline, N, f);
+      panel_combine<TPR, RPW>(mx, s, s_pm, s_ps, line, q, gline, N, f, ++phase);
     }
-    ok = panel_barrier(bar, (++phase) * a.R, a.fail);
-    s_pot[t] = t < N ? consume_f32(f + t) : 0.f;
-    __syncthreads();
-    if (it == a.iters) break;
+    {
+      bool okl = true;
+      s_pot[t] = t < N ? consume_tagged(f + t, phase, a.fail, okl) : 0.f;
+      ok = __syncthreads_and(okl) != 0;
+    }
+    if (it == a.iters || !ok) break;
     {  // columns: g from f (s_pot holds f)
       float v[32];
       float mx = -3.0e38f;
@@ -354,15 +354,17 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
       float s = 0.f;
 #pragma unroll
       for (int e = 0; e < 32; ++e) s += exp_neg(v[e] - mx);
-      panel_combine<TPR, RPW>(mx, s, s_pm, s_ps, line, q, gline, N, g);
+      panel_combine<TPR, RPW>(mx, s, s_pm, s_ps, line, q, gline, N, g, ++phase);
     }
-    ok = ok && panel_barrier(bar, (++phase) * a.R, a.fail);
-    s_pot[t] = t < N ? consume_f32(g + t) : 0.f;
-    __syncthreads();
+    {
+      bool okl = true;
+      s_pot[t] = t < N ? consume_tagged(g + t, phase, a.fail, okl) : 0.f;
+      ok = __syncthreads_and(okl) != 0;
+    }
   }
   // here s_pot = final f (all rows); g of the last column step is in global memory.
   // column role: plan[i][gline] = exp(K[i][gline] + f_i + g_gline), coalesced along the line
-  const float gl = gline < N ? consume_f32(g + gline) : 0.f;
+  const float gl = gline < N ? value_of(g + gline) : 0.f;
 #pragma unroll 4
   for (int e = 0; e < 32; ++e) {
     const int i = q * 32 + e;
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
   // row role: transposed plan and statistics; needs g for all columns
   const float fl = gline < N ? s_pot[gline] : 0.f;
   __syncthreads();
-  s_pot[t] = t < N ? consume_f32(g + t) : 0.f;
+  s_pot[t] = t < N ? value_of(g + t) : 0.f;
   __syncthreads();
   float h = 0.f, w = 0.f, sm = 0.f;
 #pragma unroll
@@ -695,11 +697,11 @@ int launch_sinkhorn(const float* K, int P, int n, int m, int iters, float lambda
     memset(&a, 0, sizeof(a));
     a.K = K; a.N = n; a.iters = iters; a.R = ceil_div(n, rpw);
     a.inv_lambda = 1.f / lambda;
-    a.f = f; a.g = g;
-    a.bar = (unsigned*)(fg_ws + (size_t)P * (n + m));
-    a.fail = a.bar + P;
+    a.f = reinterpret_cast<unsigned long long*>(fg_ws);
+    a.g = a.f + (size_t)P * n;
+    a.fail = reinterpret_cast<unsigned*>(a.g + (size_t)P * n);
     a.plan = plan; a.planT = planT; a.stats = stats;
-    hipMemsetAsync(a.bar, 0, sizeof(unsigned) * (P + 1), s);
+    hipMemsetAsync(fg_ws, 0, sizeof(unsigned long long) * 2 * (size_t)P * n + sizeof(unsigned), s);
     if (rpw == 128) launch_panel<8>(a, P, s);
     else if (rpw == 64) launch_panel<16>(a, P, s);
     else launch_panel<32>(a, P, s);
@@ -782,7 +784,7 @@ MatchWs carve_match(void* base, size_t cap, int P, int n, int D, int feat_rows) 
   w.K = (float*)c.take(sizeof(float) * pnm);
   w.plan = (float*)c.take(sizeof(float) * pnm);
   w.planT = (float*)c.take(sizeof(float) * pnm);
-  w.fg = (float*)c.take(sizeof(float) * (size_t)P * 2 * n + 64);  // potentials + barrier words
+  w.fg = (float*)c.take(sizeof(unsigned long long) * (size_t)P * 2 * n + 64);  // tagged potentials + fail word
   w.stats = (double*)c.take(sizeof(double) * 4 * P);
   w.dot3 = (double*)c.take(sizeof(double) * 4);
   w.bytes = c.off;
@@ -1026,7 +1028,7 @@ int otgan_cost_matrix_f32(const float* X, const float* Y, int n, int m, int D, l
 
 size_t otgan_sinkhorn_workspace_bytes(int P, int n, int m) {
   if (P <= 0 || n <= 0 || m <= 0) return 0;
-  return align_up(sizeof(float) * (size_t)P * (n + m) + 64, 256);  // potentials + barrier words
+  return align_up(sizeof(unsigned long long) * (size_t)P * (n + m) + 64, 256);  // tagged potentials + fail word
 }
 
 int otgan_sinkhorn_plan_f32(const float* K, int P, int n, int m, int iters, float lambda,
