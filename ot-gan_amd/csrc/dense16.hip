@@ -395,6 +395,204 @@ __global__ __launch_bounds__(256, 2) void dense16_fwd_lds_kernel(FwdLdsArgs a) {
 }
 
 // =======================================================================================
+// Forward, version 3: the same halo tile, on the bf16 matrix pipe with split-precision operands.
+// Activations are split into three bf16 pieces (x = hi + mid + lo) on the way into LDS, weights in
+// registers after the load; six v_mfma_f32_16x16x32_bf16 (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi,
+// mid*mid) replace eight fp32 MFMAs at 2.7x fewer matrix-pipe cycles, products fp32-exact.
+// The 32-wide contraction of one MFMA is (2 taps) x (16 effective channels): k-groups 0,1 of the
+// lanes take channels 0-7 / 8-15 of tap 2t, k-groups 2,3 the same channels of tap 2t+1 (the fifth
+// pair is half empty).  With 16 channels per chunk a pixel is exactly 32 bytes per piece and the
+// fragment reads (lane = pixel, 16 bytes at offset 16*(g&1)) are conflict-free without padding.
+// =======================================================================================
+typedef unsigned short u16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void d16_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  f32x2_t v = {x0, x1};
+  const bf16x2_t hb = __builtin_convertvector(v, bf16x2_t);
+  v -= __builtin_convertvector(hb, f32x2_t);
+  const bf16x2_t mb = __builtin_convertvector(v, bf16x2_t);
+  v -= __builtin_convertvector(mb, f32x2_t);
+  const bf16x2_t lb = __builtin_convertvector(v, bf16x2_t);
+  h = __builtin_bit_cast(unsigned, hb);
+  m = __builtin_bit_cast(unsigned, mb);
+  l = __builtin_bit_cast(unsigned, lb);
+}
+
+template <int PT, int ACT, bool W8>
+__global__ __launch_bounds__(256, 2) void dense16_fwd_x3_kernel(FwdLdsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  constexpr int NITMAX = PT + 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 15, g = lane >> 4;
+  const int tiles_per_img = a.H / a.TR;
+  const int n = blockIdx.x / tiles_per_img;
+  const int r0 = (blockIdx.x - n * tiles_per_img) * a.TR;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const int TILE = (a.TR + 2) * a.RS * 32;                  // bytes of one piece plane
+  for (int i = tid; i < 3 * TILE / 16; i += 256) reinterpret_cast<u32x4*>(smem3)[i] = u32x4{0u, 0u, 0u, 0u};
+
+  // staging: item = (pixel of the (TR+2) x W row band, quad of 4 channels); 4 lanes = one pixel
+  const int slot = tid & 3;
+  const int total = (a.TR + 2) * a.W * 4;
+  const long img_base = (long)n * a.H * a.W;
+  f32x4 R[NITMAX];
+  auto stage_load = [&](const QuadMap& q) {
+#pragma unroll
+    for (int it = 0; it < NITMAX; ++it) {
+      const int i = it * 256 + tid;
+      const int px = i >> 2;
+      const int row = px >> a.logW, col = px & (a.W - 1);
+      const int ir = r0 - 1 + row;
+      const bool ok = i < total && q.valid && (unsigned)ir < (unsigned)a.H;
+      const float* xp = a.x + (img_base + (long)ir * a.W + col) * a.ldx;
+      if (q.contig) {
+        R[it] = ok ? *reinterpret_cast<const f32x4*>(xp + q.c) : zero;
+      } else {
+        f32x4 v = zero;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int cm = a.cmap[q.e + j];
+          float t = ok ? xp[cm & 0x7fffffff] : 0.f;
+          v[j] = cm < 0 ? -t : t;
+        }
+        R[it] = v;
+      }
+    }
+  };
+  auto stage_store = [&](float sg) {
+#pragma unroll
+    for (int it = 0; it < NITMAX; ++it) {
+      const int i = it * 256 + tid;
+      if (i < total) {
+        const int px = i >> 2;
+        const int row = px >> a.logW, col = px & (a.W - 1);
+        f32x4 v = R[it];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = d16_act<ACT>(v[j] * sg);
+        unsigned h0, m0, l0, h1, m1, l1;
+        d16_split2(v[0], v[1], h0, m0, l0);
+        d16_split2(v[2], v[3], h1, m1, l1);
+        unsigned char* dst = smem3 + (row * a.RS + col + 1) * 32 + slot * 8;
+        *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(dst + TILE) = u32x2{m0, m1};
+        *reinterpret_cast<u32x2*>(dst + 2 * TILE) = u32x2{l0, l1};
+      }
+    }
+  };
+  auto load_cm = [&](int chunk) {
+    const int e = chunk * 16 + 4 * slot;
+    i32x4 cm = {0, 0, 0, 0};
+    if (a.cmap && e < a.Ceff) cm = *reinterpret_cast<const i32x4*>(a.cmap + e);
+    return cm;
+  };
+
+  // fragment addressing (bytes): M-tile = 16 consecutive pixels of the row band
+  int ab[PT];
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    const int q0 = (wave * PT + t) * 16;
+    int rr, cc;
+    if (W8) {
+      rr = (q0 >> 3) + (p >> 3);
+      cc = p & 7;
+    } else {
+      rr = q0 >> a.logW;
+      cc = (q0 & (a.W - 1)) + p;
+    }
+    ab[t] = ((rr + 1) * a.RS + cc + 1) * 32 + 16 * (g & 1);
+  }
+  f32x4 acc[PT];
+#pragma unroll
+  for (int t = 0; t < PT; ++t) acc[t] = zero;
+
+  const int nchunk = (a.Ceff + 15) >> 4;
+  const int hiTap = g >> 1;                                  // 0: first tap of a pair, 1: second
+  const float* wlane = a.wT + (long)p * a.K + 8 * (g & 1);   // + tap*Ceff + chunk*16
+  // weights of one (chunk, tap pair) for this lane: 8 consecutive effective channels of its tap
+  auto load_w = [&](int chunk, int tp, f32x4 (&Wv)[2]) {
+    const int tap = 2 * tp + hiTap;
+    const int e0 = chunk * 16 + 8 * (g & 1);
+    const bool ok = tap < 9 && e0 < a.Ceff;
+    const float* wp = wlane + (long)(ok ? tap : 0) * a.Ceff + chunk * 16;
+    Wv[0] = ok ? *reinterpret_cast<const f32x4*>(wp) : zero;
+    Wv[1] = ok ? *reinterpret_cast<const f32x4*>(wp + 4) : zero;
+  };
+
+  QuadMap q = d16_quad(a, 4 * slot, load_cm(0));
+  i32x4 cm_next = load_cm(1);
+  stage_load(q);
+  f32x4 Wa[2], Wb[2];
+  load_w(0, 0, Wa);
+  __syncthreads();  // zero fill complete
+  stage_store(q.contig ? q.sg : 1.f);
+  __syncthreads();
+
+  for (int c = 0; c < nchunk; ++c) {
+    const bool more = c + 1 < nchunk;
+    if (more) {
+      q = d16_quad(a, (c + 1) * 16 + 4 * slot, cm_next);
+      cm_next = load_cm(c + 2);
+      stage_load(q);
+    }
+#pragma unroll
+    for (int tp = 0; tp < 5; ++tp) {
+      f32x4 (&Wc)[2] = (tp & 1) ? Wb : Wa;
+      f32x4 (&Wn)[2] = (tp & 1) ? Wa : Wb;
+      if (tp < 4) load_w(c, tp + 1, Wn);
+      else if (more) load_w(c + 1, 0, Wn);
+      // weight pieces
+      unsigned wh[4], wm[4], wl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d16_split2(Wc[j >> 1][2 * (j & 1)], Wc[j >> 1][2 * (j & 1) + 1], wh[j], wm[j], wl[j]);
+      const bf16x8 Bh = __builtin_bit_cast(bf16x8, u32x4{wh[0], wh[1], wh[2], wh[3]});
+      const bf16x8 Bm = __builtin_bit_cast(bf16x8, u32x4{wm[0], wm[1], wm[2], wm[3]});
+      const bf16x8 Bl = __builtin_bit_cast(bf16x8, u32x4{wl[0], wl[1], wl[2], wl[3]});
+      // this lane's tap of the pair (the ninth tap has no partner: its upper k-groups re-read tap 8 against zero weights)
+      const int t0 = 2 * tp, t1 = (2 * tp + 1 < 9) ? 2 * tp + 1 : 8;
+      const int sh0 = ((t0 / 3 - 1) * a.RS + (t0 % 3 - 1)) * 32;
+      const int sh1 = ((t1 / 3 - 1) * a.RS + (t1 % 3 - 1)) * 32;
+      const int sh = hiTap ? sh1 : sh0;
+#pragma unroll
+      for (int t = 0; t < PT; ++t) {
+        const unsigned char* ap = smem3 + ab[t] + sh;
+        const bf16x8 Ah = *reinterpret_cast<const bf16x8*>(ap);
+        const bf16x8 Am = *reinterpret_cast<const bf16x8*>(ap + TILE);
+        const bf16x8 Al = *reinterpret_cast<const bf16x8*>(ap + 2 * TILE);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bm, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bm, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, acc[t], 0, 0, 0);
+      }
+    }
+    if (more) {  // five pairs: the prefetch of (c+1, pair 0) landed in the odd buffer
+      Wa[0] = Wb[0];
+      Wa[1] = Wb[1];
+    }
+    __syncthreads();
+    if (more) {
+      stage_store(q.contig ? q.sg : 1.f);
+      __syncthreads();
+    }
+  }
+  const float b = a.bias ? a.bias[p] : 0.f;
+  const long m0 = (img_base + (long)r0 * a.W);
+#pragma unroll
+  for (int t = 0; t < PT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long m = m0 + (wave * PT + t) * 16 + 4 * g + r;
+      a.y[m * a.ldy + a.coff + p] = acc[t][r] + b;
+    }
+}
+
+// =======================================================================================
 // Weight gradient:  dW[tap][e][n] = sum_q act(x)[q][e] * dy[q - tap][n]
 //
 // MFMA roles: M = 16 effective channels, N = the 16 output channels, K = pixels.  A block owns
@@ -762,10 +960,21 @@ int dense16_fwd(const Dense16Geo& g, const float* x, const float* wT, const floa
       const size_t lds = (size_t)(l.TR + 2) * l.RS * kPixQuads * 16;
       const dim3 grid(g.N * (g.H / l.TR)), blk(256);
       const bool w8 = g.W == 8;
-#define D16_LAUNCH(PT_, ACT_)                                                                       \
-  do {                                                                                              \
-    if (w8) hipLaunchKernelGGL((dense16_fwd_lds_kernel<PT_, ACT_, true>), grid, blk, lds, s, l);    \
-    else hipLaunchKernelGGL((dense16_fwd_lds_kernel<PT_, ACT_, false>), grid, blk, lds, s, l);      \
+      // split-precision forward only where it pays: the 64*4-pixel tiles of the 32x32 (and larger) stages
+      // (measured 1.18x there; the 16x16 / 8x8 stages are bound by their chunk barriers, not by the matrix pipe)
+      static const bool x3_on = [] {
+        const char* e = getenv("OTGAN_DENSE16_FP32");
+        return !(e && e[0] == '1');
+      }();
+      const bool x3 = x3_on && PT == 4;
+      const size_t lds3 = (size_t)3 * (l.TR + 2) * l.RS * 32;
+#define D16_LAUNCH(PT_, ACT_)                                                                               \
+  do {                                                                                                      \
+    if (x3) {                                                                                               \
+      if (w8) hipLaunchKernelGGL((dense16_fwd_x3_kernel<PT_, ACT_, true>), grid, blk, lds3, s, l);          \
+      else hipLaunchKernelGGL((dense16_fwd_x3_kernel<PT_, ACT_, false>), grid, blk, lds3, s, l);            \
+    } else if (w8) hipLaunchKernelGGL((dense16_fwd_lds_kernel<PT_, ACT_, true>), grid, blk, lds, s, l);     \
+    else hipLaunchKernelGGL((dense16_fwd_lds_kernel<PT_, ACT_, false>), grid, blk, lds, s, l);              \
   } while (0)
 #define D16_LAUNCH_ACT(PT_)                       \
   do {                                            \
