@@ -102,7 +102,12 @@ def main():
                                f"{a.nr_sinkhorn_iter} Sinkhorn iters, lambda 500, 5:1 generator:critic steps, Adam",
                    "global_batch": world * a.batch_per_gpu, "parallelism": f"dp{world}",
                    "matching_scope": args.matching_scope if world > 1 else "local",
-                   "last_distance": float(last["distance"]), "last_entropy": float(last["entropy"])},
+                   "last_distance": float(last["distance"]), "last_entropy": float(last["entropy"]),
+                   "precision_note": ("fp32 tensors and fp32 accumulation everywhere; the Winograd-domain GEMMs multiply "
+                                      "operands stored as three bf16 pieces (hi+mid+lo = the full 24-bit significand) with six "
+                                      "bf16 MFMAs per product, measured 2e-7..5e-7 rel. L2 vs fp64 (fp32 MFMA chain: 1.3e-6); "
+                                      "OTGAN_WINO_FP32=1 runs the same GEMMs on the fp32 MFMA engine (8045 img/s, "
+                                      "profiles/README.md)") if a.model == "dcgan" and os.environ.get("OTGAN_WINO_FP32") != "1" else "fp32 MFMA"},
     }
     if prof:
         conv = {k: prof[k] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")}
