@@ -955,6 +955,122 @@ __global__ __launch_bounds__(256) void conv_outer_kernel(OuterArgs a, Taps taps)
   }
 }
 
+
+// Stride-1 variant of the few-channel weight gradient: ALL taps in one block.  The kernel above reads
+// the wide operand once per tap (25x for a 5x5 filter: L2-bound); here a thread owns (4 wide channels,
+// one filter row kh, one of two pixel streams), loads each wide pixel ONCE for its KW taps and takes the
+// narrow operand (<= 4 channels per pixel, padded to a float4) from an LDS tile of the unit's rows plus
+// halo.  out[tap][c][j] = sum_q wide(q, c) * narrow(q + sgn * off(tap), j): sgn = -1 when the wide
+// operand is the layer input (few outputs), +1 when it is dy (few inputs).
+struct Outer2Args {
+  const float* wide; int ldw; int wideC;
+  const float* narrow; int ldn; int J;
+  int sgn, wide_is_x;
+  int N, H, W, logW;
+  int KH, KW, ph, pw;
+  const int* cmap; int Creal, doubled;
+  int TRo, units, units_per_block;
+  float* slab; long slab_stride; long sT, sC, sJ;
+};
+constexpr int kOuterHalo = 2;
+
+template <int ACT, int KW>
+__global__ __launch_bounds__(320) void conv_outer2_kernel(Outer2Args a) {
+  extern __shared__ __attribute__((aligned(16))) float4 s_nar[];   // [(TRo + 4)][(W + 4)] float4
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  const int cq = tid & 31, kh = (tid >> 5) % a.KH, ps = tid / (32 * a.KH);
+  const int c = blockIdx.x * 128 + 4 * cq;
+  const bool cok = c < a.wideC;
+  int sc = c;
+  float sgnw = 1.f;
+  if (a.wide_is_x && cok) {
+    GatherA gm;
+    gm.cmap = a.cmap; gm.Creal = a.Creal; gm.doubled = a.doubled;
+    decode_map(gm, c, a.cmap ? a.cmap[c] : 0, sc, sgnw);
+  }
+  float acc[KW][4][4];
+#pragma unroll
+  for (int w = 0; w < KW; ++w)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[w][k][j] = 0.f;
+  const int LW = a.W + 2 * kOuterHalo;
+  const int units_per_img = a.H / a.TRo;
+  const int u0 = blockIdx.y * a.units_per_block;
+  int u1 = u0 + a.units_per_block;
+  if (u1 > a.units) u1 = a.units;
+  const int dh = a.sgn * (kh - a.ph);
+  for (int u = u0; u < u1; ++u) {
+    const int n = u / units_per_img, r0 = (u - n * units_per_img) * a.TRo;
+    const long img = (long)n * a.H * a.W;
+    __syncthreads();   // previous unit's tile fully consumed
+    for (int i = tid; i < (a.TRo + 2 * kOuterHalo) * LW; i += nthreads) {
+      const int lr = i / LW, lc = i - lr * LW;
+      const int r = r0 - kOuterHalo + lr, q = lc - kOuterHalo;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)r < (unsigned)a.H && (unsigned)q < (unsigned)a.W) {
+        const float* np = a.narrow + (img + (long)r * a.W + q) * a.ldn;
+        v.x = np[0];
+        if (a.J > 1) v.y = np[1];
+        if (a.J > 2) v.z = np[2];
+        if (a.J > 3) v.w = np[3];
+        if (!a.wide_is_x) {   // the narrow operand is the layer input: pre-activation applies to it
+          v.x = act_apply<ACT>(v.x); v.y = act_apply<ACT>(v.y); v.z = act_apply<ACT>(v.z); v.w = act_apply<ACT>(v.w);
+        }
+      }
+      s_nar[i] = v;
+    }
+    __syncthreads();
+    if (cok) {
+      for (int q = ps; q < a.TRo * a.W; q += 2) {
+        const int row = q >> a.logW, col = q & (a.W - 1);
+        float4 wv = *reinterpret_cast<const float4*>(a.wide + (img + (long)(r0 + row) * a.W + col) * a.ldw + sc);
+        if (a.wide_is_x) {
+          wv.x = act_apply<ACT>(sgnw * wv.x); wv.y = act_apply<ACT>(sgnw * wv.y);
+          wv.z = act_apply<ACT>(sgnw * wv.z); wv.w = act_apply<ACT>(sgnw * wv.w);
+        }
+        const float4* nrow = s_nar + (row + kOuterHalo + dh) * LW + col + kOuterHalo;
+#pragma unroll
+        for (int w = 0; w < KW; ++w) {
+          const float4 nv = nrow[a.sgn * (w - a.pw)];
+          acc[w][0][0] += wv.x * nv.x; acc[w][0][1] += wv.x * nv.y; acc[w][0][2] += wv.x * nv.z; acc[w][0][3] += wv.x * nv.w;
+          acc[w][1][0] += wv.y * nv.x; acc[w][1][1] += wv.y * nv.y; acc[w][1][2] += wv.y * nv.z; acc[w][1][3] += wv.y * nv.w;
+          acc[w][2][0] += wv.z * nv.x; acc[w][2][1] += wv.z * nv.y; acc[w][2][2] += wv.z * nv.z; acc[w][2][3] += wv.z * nv.w;
+          acc[w][3][0] += wv.w * nv.x; acc[w][3][1] += wv.w * nv.y; acc[w][3][2] += wv.w * nv.z; acc[w][3][3] += wv.w * nv.w;
+        }
+      }
+    }
+  }
+  // combine the two pixel streams through LDS, then one thread per (kh, channel quad) writes its taps
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(s_nar);      // [KH][32][KW*16]
+  const int slot = (kh * 32 + cq) * (KW * 16);
+  if (ps == 1) {
+#pragma unroll
+    for (int w = 0; w < KW; ++w)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[slot + (w * 4 + k) * 4 + j] = acc[w][k][j];
+  }
+  __syncthreads();
+  if (ps == 0 && cok) {
+    float* out = a.slab + (long)blockIdx.y * a.slab_stride;
+#pragma unroll
+    for (int w = 0; w < KW; ++w)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (c + k >= a.wideC) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < a.J)
+            out[(long)(kh * KW + w) * a.sT + (long)(c + k) * a.sC + j * a.sJ] =
+                acc[w][k][j] + red[slot + (w * 4 + k) * 4 + j];
+      }
+  }
+}
+
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, int nsplit, long n,
                                    float* __restrict__ out) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -1160,6 +1276,8 @@ inline WinoS2Geo wino_s2_geo(const otgan_conv_desc* d, const Geo& g) {
   return w;
 }
 
+inline int outer_unit_rows(int H) { return H >= 8 ? 8 : H; }
+
 struct WgPlan {
   int outer;       // 0 no, 1 few outputs (Cout <= 4), 2 few inputs (Cin_eff <= 4)
   int chunk, nchunks;
@@ -1200,6 +1318,11 @@ WgPlan plan_wgrad(const otgan_conv_desc* d, const Geo& g) {
     p.M = (long)d->N * g.OH * g.OW;
     p.nchunks = p.M >= 256 * 64 ? 256 : (int)ceil_div_l(p.M, 64);
     p.chunk = (int)ceil_div_l(p.M, p.nchunks);
+    if (d->stride == 1) {
+      // whole units of TRo image rows per block (conv_outer2_kernel stages the narrow operand per unit)
+      const int unit = outer_unit_rows(d->H) * d->W;
+      p.chunk = ceil_div(p.chunk, unit) * unit;
+    }
     p.nchunks = (int)ceil_div_l(p.M, p.chunk);
     p.slab_elems = (long)taps * g.Ceff * d->Cout;
     p.nsplit = p.nchunks;
@@ -1876,13 +1999,45 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
     }
     const dim3 grid(ceil_div(oa.wideC, 128), p.nchunks, ct.taps[0].n);
     const int act = act_kind(d->preact);
-    {
+    if (d->stride == 1 && (d->KW == 5 || d->KW == 3) && d->KH <= 5 && g.pad_t <= kOuterHalo && g.pad_l <= kOuterHalo &&
+        d->KH - 1 - g.pad_t <= kOuterHalo && d->KW - 1 - g.pad_l <= kOuterHalo && d->H % outer_unit_rows(d->H) == 0 &&
+        oa.ldw % 4 == 0 && aligned16(oa.wide) && (oa.wideC % 4 == 0)) {
+      Outer2Args o2;
+      memset(&o2, 0, sizeof(o2));
+      o2.wide = oa.wide; o2.ldw = oa.ldw; o2.wideC = oa.wideC;
+      o2.narrow = oa.narrow; o2.ldn = oa.ldn; o2.J = oa.J;
+      o2.wide_is_x = oa.wide_shift; o2.sgn = oa.wide_shift ? -1 : 1;
+      o2.N = d->N; o2.H = d->H; o2.W = d->W; o2.logW = ilog2_exact(d->W);
+      o2.KH = d->KH; o2.KW = d->KW; o2.ph = g.pad_t; o2.pw = g.pad_l;
+      o2.cmap = cmap; o2.Creal = d->C; o2.doubled = oa.doubled;
+      o2.TRo = outer_unit_rows(d->H);
+      o2.units = d->N * (d->H / o2.TRo);
+      o2.units_per_block = p.chunk / (o2.TRo * d->W);
+      o2.slab = oa.slab; o2.slab_stride = oa.slab_stride; o2.sT = oa.sT; o2.sC = oa.sC; o2.sJ = oa.sJ;
+      const dim3 g2(ceil_div(oa.wideC, 128), p.nchunks), blk(32 * d->KH * 2);
+      size_t lds = sizeof(float4) * (o2.TRo + 2 * kOuterHalo) * (d->W + 2 * kOuterHalo);
+      const size_t red = sizeof(float) * (size_t)d->KH * 32 * d->KW * 16;
+      if (red > lds) lds = red;
+      {
+        ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * (double)p.M * (double)p.slab_elems, 0.0, s);
+#define OTGAN_OUTER2(ACT_)                                                                              \
+  do {                                                                                                  \
+    if (d->KW == 5) hipLaunchKernelGGL((conv_outer2_kernel<ACT_, 5>), g2, blk, lds, s, o2);             \
+    else hipLaunchKernelGGL((conv_outer2_kernel<ACT_, 3>), g2, blk, lds, s, o2);                        \
+  } while (0)
+        if (act == 1) OTGAN_OUTER2(1);
+        else if (act == 2) OTGAN_OUTER2(2);
+        else OTGAN_OUTER2(0);
+#undef OTGAN_OUTER2
+      }
+      OTGAN_CHECK_LAUNCH("conv2d wgrad (few channels, all taps)");
+    } else {
       ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * (double)p.M * (double)p.slab_elems, 0.0, s);
       if (act == 1) hipLaunchKernelGGL(conv_outer_kernel<1>, grid, dim3(256), 0, s, oa, ct.taps[0]);
       else if (act == 2) hipLaunchKernelGGL(conv_outer_kernel<2>, grid, dim3(256), 0, s, oa, ct.taps[0]);
       else hipLaunchKernelGGL(conv_outer_kernel<0>, grid, dim3(256), 0, s, oa, ct.taps[0]);
+      OTGAN_CHECK_LAUNCH("conv2d wgrad (few channels)");
     }
-    OTGAN_CHECK_LAUNCH("conv2d wgrad (few channels)");
     long blocks = ceil_div_l(p.slab_elems, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)blocks), dim3(256), 0, s, (const float*)workspace,

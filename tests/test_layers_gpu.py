@@ -67,6 +67,13 @@ CONV_CASES = [
     ("odd_list_dense16", 2, 8, 8, (22, 10), 16, 3, 1, False, "celu"),
     ("dense16_many_tiles", 130, 32, 32, (16,), 16, 3, 1, False, "crelu"),
     ("dense16_mid_tiles", 260, 16, 16, (24,), 16, 3, 1, False, "crelu"),
+    # few-channel weight gradients, all taps per block (conv_outer2_kernel): several units per block, H < 8, 3x3
+    ("rgb_in_k3", 2, 16, 16, (3,), 64, 3, 1, False, None),
+    ("rgb_out_k3_elu", 3, 8, 8, (32,), 3, 3, 1, False, "elu"),
+    ("rgb_out_many", 72, 32, 32, (64,), 3, 5, 1, False, None),
+    ("rgb_in_many", 72, 32, 32, (3,), 32, 5, 1, False, None),
+    ("few_out_small_crelu", 2, 4, 4, (16,), 2, 5, 1, False, "crelu"),
+    ("few_out_list", 2, 8, 8, (16, 8), 3, 3, 1, False, "crelu"),
 ]
 
 
