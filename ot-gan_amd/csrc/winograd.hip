@@ -9,6 +9,7 @@
 //   wgrad   : dU[f] = V[f]^T . (A dY A^T)[f]  (K = tiles), then dweff = G^T dU G
 // The transforms are streaming float4 kernels; the GEMMs use the shared block-GEMM engine.
 #include "winograd.h"
+#include <type_traits>
 
 #include <stdlib.h>
 
@@ -75,11 +76,48 @@ __device__ __forceinline__ void st_split4(u16* planes, long plane_stride, long i
   *reinterpret_cast<u32x2*>(planes + plane_stride + idx) = u32x2{m0, m1};
   *reinterpret_cast<u32x2*>(planes + 2 * plane_stride + idx) = u32x2{l0, l1};
 }
-// store element group idx of a [16][rows][ld] operand either as fp32 or as three bf16 planes
-__device__ __forceinline__ void st_operand(float* F, u16* P, long plane_stride, long idx, f32x4 v) {
-  if (P) st_split4(P, plane_stride, idx, v);
-  else st4(F + idx, v);
+// Layout of a split-precision operand: per (piece, frequency) the [rows][K] matrix is stored as
+// [row block of 32][k block of 16] chunks of 1 KiB, and a chunk is exactly the LDS image that one
+// global_load_lds instruction of the GEMM deposits (64 lanes x 16 bytes): 16-byte slot
+// (row % 32) * 2 + ((k / 8) % 2 ^ (row / 8) % 2) -- the XOR keeps the GEMM's ds_read_b128 fragment
+// reads conflict-free with 32-byte rows.  A row-major operand made the GEMM's global reads 32-byte
+// row segments (one cache line per lane pair); blocked, every instruction reads 8 full lines
+// (measured on the DCGAN shapes: 141-156 -> 205-254 TFLOP/s fp32-equivalent, tools/ablate/gemm_bf16x3_v3.hip).
+// Rows are padded to a multiple of 32 (padding never written, only feeds C rows that are not stored).
+__host__ __device__ inline long op_fstride(long rows, long K) { return ((rows + 31) >> 5) * (K >> 4) * 512; }
+__device__ __forceinline__ long op_off(long row, int k, int kblocks) {
+  const int rr = (int)(row & 31);
+  return (((row >> 5) * kblocks + (k >> 4)) << 9) + ((rr * 2 + (((k >> 3) & 1) ^ ((rr >> 3) & 1))) << 3) + (k & 7);
 }
+// store k .. k+3 of row `row`, frequency f, of a [16][rows][ld] operand: fp32 row-major in F, or (P non-null)
+// as three bf16 planes in the blocked layout
+__device__ __forceinline__ void st_operand(float* F, u16* P, long rows, int ld, int f, long row, int k, f32x4 v) {
+  if (P) {
+    const long fs = op_fstride(rows, ld);
+    st_split4(P, 16 * fs, f * fs + op_off(row, k, ld >> 4), v);
+  } else {
+    st4(F + ((long)f * rows + row) * ld + k, v);
+  }
+}
+
+// thread -> (row, group of four k) of an operand producer.  Blocked operands: a wave covers 16 rows x 16 k
+// = half a chunk, so every store instruction writes 512 contiguous bytes (whole cache lines; 32-byte row
+// segments written from k-fastest threads measured 2-3x slower), a block 16 rows x 64 k.  fp32 operands: k
+// fastest across the block.  Launch op_grid(rows, nk4) blocks of 256 threads.
+__device__ __forceinline__ bool op_thread(bool blocked, long rows, int nk4, long& row, int& k4) {
+  if (blocked) {
+    const int kgroups = (nk4 + 15) >> 4;
+    const long b = blockIdx.x;
+    k4 = (int)(b % kgroups) * 16 + (threadIdx.x >> 6) * 4 + (threadIdx.x & 3);
+    row = (b / kgroups) * 16 + ((threadIdx.x >> 2) & 15);
+  } else {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    k4 = (int)(idx % nk4);
+    row = idx / nk4;
+  }
+  return row < rows && k4 < nk4;
+}
+inline int op_grid(long rows, long nk4) { return (int)(((rows + 15) / 16) * ((nk4 + 15) / 16)); }
 
 // ---- the four small transforms, on float4 = four channels at once -------------------------
 // V = B^T d B
@@ -188,7 +226,7 @@ struct InArgs {
   int ldv;               // row length of V
   float* V;
   int s2_skip;           // >= 0: strided layer, the (class = blockIdx.z, f) blocks absent under this index are not stored
-  u16* P;                // non-null: write the operand as three bf16 planes (plane stride 16*T*ldv) instead of V
+  u16* P;                // non-null: write the operand as three bf16 planes (blocked layout, op_off) instead of V
 };
 template <int ACT>
 __device__ __forceinline__ f32x4 wino_act(f32x4 v) {
@@ -203,11 +241,10 @@ __device__ __forceinline__ f32x4 wino_act(f32x4 v) {
 // transform; CReLU / CELU emit two transformed patches (channels c and Creal + c of the view's slot).
 template <int ACT, bool DOUBLED>
 __global__ __launch_bounds__(256) void wino_input_kernel(InArgs a) {
-  const int c4n = a.C >> 2;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= a.T * c4n) return;
-  const int c = (int)(idx % c4n) * 4;
-  const long t = idx / c4n;
+  long t;
+  int k4;
+  if (!op_thread(a.P != nullptr, a.T, a.C >> 2, t, k4)) return;
+  const int c = k4 * 4;
   const int tb = (int)(t % a.TW), ta = (int)((t / a.TW) % a.TH);
   const long n = t / ((long)a.TW * a.TH);
   const View v = a.v[blockIdx.z];
@@ -223,15 +260,14 @@ __global__ __launch_bounds__(256) void wino_input_kernel(InArgs a) {
       d[i][j] = ok ? ld4(v.p + n * v.sn + r * v.sh + q * v.sw + c) : zero;
     }
   }
-  const long o0 = t * a.ldv + a.coff[blockIdx.z] + c;
-  const long fs = a.T * a.ldv, ps = 16 * fs;
+  const int k0 = a.coff[blockIdx.z] + c;
   if (ACT == 0 && !DOUBLED) {
     tf_input(d, V);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (a.s2_skip < 0 || s2_present(blockIdx.z, i * 4 + j, a.s2_skip)) st_operand(a.V, a.P, ps, o0 + (i * 4 + j) * fs, V[i][j]);
+        if (a.s2_skip < 0 || s2_present(blockIdx.z, i * 4 + j, a.s2_skip)) st_operand(a.V, a.P, a.T, a.ldv, i * 4 + j, t, k0, V[i][j]);
   } else {
     f32x4 e[4][4];
 #pragma unroll
@@ -244,7 +280,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(InArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (a.s2_skip < 0 || s2_present(cls, i * 4 + j, a.s2_skip)) st_operand(a.V, a.P, ps, o0 + (i * 4 + j) * fs, V[i][j]);
+        if (a.s2_skip < 0 || s2_present(cls, i * 4 + j, a.s2_skip)) st_operand(a.V, a.P, a.T, a.ldv, i * 4 + j, t, k0, V[i][j]);
     if (DOUBLED) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -255,7 +291,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(InArgs a) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (a.s2_skip < 0 || s2_present(cls, i * 4 + j, a.s2_skip)) st_operand(a.V, a.P, ps, o0 + a.C + (i * 4 + j) * fs, V[i][j]);
+          if (a.s2_skip < 0 || s2_present(cls, i * 4 + j, a.s2_skip)) st_operand(a.V, a.P, a.T, a.ldv, i * 4 + j, t, k0 + a.C, V[i][j]);
     }
   }
 }
@@ -303,11 +339,10 @@ __global__ __launch_bounds__(256) void wino_output_kernel(OutArgs a) {
 
 // dM[f][t][coff + c] = (A dY A^T)[f],  dY = the 2x2 tile of the view at (2ta, 2tb)
 __global__ __launch_bounds__(256) void wino_outadj_kernel(InArgs a) {
-  const int c4n = a.C >> 2;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= a.T * c4n) return;
-  const int c = (int)(idx % c4n) * 4;
-  const long t = idx / c4n;
+  long t;
+  int k4;
+  if (!op_thread(a.P != nullptr, a.T, a.C >> 2, t, k4)) return;
+  const int c = k4 * 4;
   const int tb = (int)(t % a.TW), ta = (int)((t / a.TW) % a.TH);
   const long n = t / ((long)a.TW * a.TH);
   const View v = a.v[blockIdx.z];
@@ -317,18 +352,16 @@ __global__ __launch_bounds__(256) void wino_outadj_kernel(InArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) dY[i][j] = ld4(v.p + n * v.sn + (2 * ta + i) * v.sh + (2 * tb + j) * v.sw + c);
   tf_output_adj(dY, dM);
-  const long o0 = t * a.ldv + a.coff[blockIdx.z] + c;
-  const long fs = a.T * a.ldv;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) st_operand(a.V, a.P, 16 * fs, o0 + (i * 4 + j) * fs, dM[i][j]);
+    for (int j = 0; j < 4; ++j) st_operand(a.V, a.P, a.T, a.ldv, i * 4 + j, t, a.coff[blockIdx.z] + c, dM[i][j]);
 }
 
 
 // ---- transposed operand producers (wgrad on the bf16 pipe) ------------------------------------
 // The wgrad GEMM contracts over the tiles, so its operands must be tile-contiguous:
-// P[piece][f][row][t].  These kernels compute the same transforms as wino_input_kernel /
+// P[piece][f] = the [row][t] matrix in the blocked operand layout.  These kernels compute the same transforms as wino_input_kernel /
 // wino_outadj_kernel for a block of 64 tiles x 16 channels and transpose through LDS (four
 // frequencies at a time), so that every global store is a full 128-byte row segment of 64 tiles.
 // Tiles >= T (padding up to a multiple of 64) are written as zeros.
@@ -338,7 +371,7 @@ struct ProdTArgs {
   int H, W, TH, TW, C;   // C = channels of the view (multiple of 16)
   long T, Tpad;
   int rows;              // rows of the transposed operand per frequency
-  u16* P;                // [3][16][rows][Tpad]
+  u16* P;                // [3][16] x blocked [rows][Tpad] (op_off)
 };
 
 template <int KIND, int ACT, bool DOUBLED>   // KIND 0: B^T d B of the 4x4 patch, 1: A dY A^T of the 2x2 tile
@@ -374,7 +407,8 @@ __global__ __launch_bounds__(256) void wino_prodT_kernel(ProdTArgs a) {
         for (int j = 0; j < 2; ++j) d[i][j] = ld4(v.p + n * v.sn + (2 * ta + i) * v.sh + (2 * tb + j) * v.sw + c);
     }
   }
-  const long ps = 16L * a.rows * a.Tpad;
+  const int kblocks = (int)(a.Tpad >> 4);
+  const long fsP = op_fstride(a.rows, a.Tpad), ps = 16 * fsP;
 #pragma unroll
   for (int pass = 0; pass < (DOUBLED ? 2 : 1); ++pass) {
     f32x4 V[4][4];
@@ -412,12 +446,13 @@ __global__ __launch_bounds__(256) void wino_prodT_kernel(ProdTArgs a) {
       __syncthreads();
 #pragma unroll
       for (int it = 0; it < 6; ++it) {
+        // 32 consecutive lanes = 16 channel rows x 2 chunks = 512 contiguous bytes of one operand chunk
         const int id = it * 256 + tid;
-        const int ch = id & 7, row = id >> 3;            // row = (piece, fl, cc)
-        const int piece = row >> 6, fl = (row >> 4) & 3, cc = row & 15;
+        const int ch = ((id >> 5) & 3) * 2 + (id & 1), cc = (id >> 1) & 15, pf = id >> 7;
+        const int piece = pf >> 2, fl = pf & 3;
         const u32x4 val = *reinterpret_cast<const u32x4*>(&lds[piece][fl][cc][8 * ch]);
         const long f = 4 * round + fl;
-        u16* dst = a.P + piece * ps + ((f * a.rows + rowbase + cc) * a.Tpad + (long)blockIdx.x * 64 + 8 * ch);
+        u16* dst = a.P + piece * ps + f * fsP + op_off(rowbase + cc, blockIdx.x * 64 + 8 * ch, kblocks);
         *reinterpret_cast<u32x4*>(dst) = val;
       }
       __syncthreads();
@@ -428,12 +463,11 @@ __global__ __launch_bounds__(256) void wino_prodT_kernel(ProdTArgs a) {
 // forward filters: U[f][cls*Cout + co][ci] from weffT[cls][co][tap*Cin + ci]
 __global__ __launch_bounds__(256) void wino_filter_fwd_kernel(const float* __restrict__ weffT, long cls_stride,
                                                             int Cin, int Cout, float* __restrict__ U, u16* P) {
-  const int c4n = Cin >> 2;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   const long rows = 4L * Cout;
-  if (idx >= rows * c4n) return;
-  const int ci = (int)(idx % c4n) * 4;
-  const long row = idx / c4n;
+  long row;
+  int k4;
+  if (!op_thread(P != nullptr, rows, Cin >> 2, row, k4)) return;
+  const int ci = k4 * 4;
   const int cls = (int)(row / Cout), co = (int)(row % Cout);
   const float* src = weffT + cls * cls_stride + (long)co * 9 * Cin + ci;
   f32x4 g[3][3], Uv[4][4];
@@ -442,22 +476,20 @@ __global__ __launch_bounds__(256) void wino_filter_fwd_kernel(const float* __res
 #pragma unroll
     for (int j = 0; j < 3; ++j) g[i][j] = ld4(src + (long)(i * 3 + j) * Cin);
   tf_filter(g, Uv);
-  const long fs = rows * Cin;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) st_operand(U, P, 16 * fs, (i * 4 + j) * fs + row * Cin + ci, Uv[i][j]);
+    for (int j = 0; j < 4; ++j) st_operand(U, P, rows, Cin, i * 4 + j, row, ci, Uv[i][j]);
 }
 
 // backward filters (flipped taps): U'[f][ci][cls*Cout + co] from weff[cls][tap][ci][co]
 __global__ __launch_bounds__(256) void wino_filter_bwd_kernel(const float* __restrict__ weff, long cls_stride,
                                                             int Cin, int Cout, float* __restrict__ U, u16* P) {
   const int c4n = Cout >> 2;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= 4L * Cin * c4n) return;
-  const int co = (int)(idx % c4n) * 4;
-  const long r = idx / c4n;
-  const int ci = (int)(r % Cin), cls = (int)(r / Cin);
+  long row;
+  int k4;
+  if (!op_thread(P != nullptr, Cin, 4 * c4n, row, k4)) return;
+  const int ci = (int)row, cls = k4 / c4n, co = (k4 % c4n) * 4;
   const float* src = weff + cls * cls_stride + (long)ci * Cout + co;
   f32x4 g[3][3], Uv[4][4];
 #pragma unroll
@@ -465,11 +497,10 @@ __global__ __launch_bounds__(256) void wino_filter_bwd_kernel(const float* __res
 #pragma unroll
     for (int j = 0; j < 3; ++j) g[i][j] = ld4(src + (long)((2 - i) * 3 + (2 - j)) * Cin * Cout);
   tf_filter(g, Uv);
-  const long ldu = 4L * Cout, fs = (long)Cin * ldu;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) st_operand(U, P, 16 * fs, (i * 4 + j) * fs + (long)ci * ldu + (long)cls * Cout + co, Uv[i][j]);
+    for (int j = 0; j < 4; ++j) st_operand(U, P, Cin, 4 * Cout, i * 4 + j, ci, cls * Cout + co, Uv[i][j]);
 }
 
 // dweff[cls][tap][ci][co] = (G^T dU G)[tap],  dU[f] = sum over splits of slab[split][f][ci][cls*Cout + co]
@@ -517,11 +548,10 @@ __device__ __forceinline__ int s2_tap(int parity, int i) {   // filter tap of wi
 __global__ __launch_bounds__(256) void wino_s2_filter_fwd_kernel(const float* __restrict__ wT, int Ceff, int Cout,
                                                                float* __restrict__ U, u16* P) {
   const int c4n = Ceff >> 2;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= 4L * Cout * c4n) return;
-  const int ce = (int)(idx % c4n) * 4;
-  const long r = idx / c4n;
-  const int cls = (int)(r % 4), co = (int)(r / 4);
+  long row;
+  int k4;
+  if (!op_thread(P != nullptr, Cout, 4 * c4n, row, k4)) return;
+  const int co = (int)row, cls = k4 / c4n, ce = (k4 % c4n) * 4;
   const int pi = cls >> 1, pj = cls & 1;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   f32x4 g[3][3], Uv[4][4];
@@ -533,23 +563,21 @@ __global__ __launch_bounds__(256) void wino_s2_filter_fwd_kernel(const float* __
       g[i][j] = (kh >= 0 && kw >= 0) ? ld4(wT + ((long)co * 25 + kh * 5 + kw) * Ceff + ce) : zero;
     }
   tf_filter(g, Uv);
-  const long ldu = 4L * Ceff, fs = (long)Cout * ldu;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (s2_present(cls, i * 4 + j, 0))   // absent blocks are never read by the GEMM
-        st_operand(U, P, 16 * fs, (i * 4 + j) * fs + (long)co * ldu + (long)cls * Ceff + ce, Uv[i][j]);
+        st_operand(U, P, Cout, 4 * Ceff, i * 4 + j, co, cls * Ceff + ce, Uv[i][j]);
 }
 
 // backward filters (flipped): U'[f][cls*Ceff + ce][co] from w[kh*5+kw][ce][co]
 __global__ __launch_bounds__(256) void wino_s2_filter_bwd_kernel(const float* __restrict__ w, int Ceff, int Cout,
                                                                float* __restrict__ U, u16* P) {
-  const int c4n = Cout >> 2;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= 4L * Ceff * c4n) return;
-  const int co = (int)(idx % c4n) * 4;
-  const long r = idx / c4n;             // cls*Ceff + ce
+  long r;                               // cls*Ceff + ce
+  int k4;
+  if (!op_thread(P != nullptr, 4L * Ceff, Cout >> 2, r, k4)) return;
+  const int co = k4 * 4;
   const int ce = (int)(r % Ceff), cls = (int)(r / Ceff);
   const int pi = cls >> 1, pj = cls & 1;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -562,11 +590,10 @@ __global__ __launch_bounds__(256) void wino_s2_filter_bwd_kernel(const float* __
       g[i][j] = (kh >= 0 && kw >= 0) ? ld4(w + ((long)(kh * 5 + kw) * Ceff + ce) * Cout + co) : zero;
     }
   tf_filter(g, Uv);
-  const long fs = 4L * Ceff * Cout;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) st_operand(U, P, 16 * fs, (i * 4 + j) * fs + r * Cout + co, Uv[i][j]);
+    for (int j = 0; j < 4; ++j) st_operand(U, P, 4L * Ceff, Cout, i * 4 + j, r, co, Uv[i][j]);
 }
 
 // dw[kh*5+kw][ce][co] = (G^T dU G)[i][j] of the tap's class; dU[f] = sum of slab[split][f][cls*Ceff+ce][co]
@@ -688,10 +715,12 @@ struct BgArgs {
   // structurally zero and are skipped: seg_mode 1 = classes along K (forward), 2 = along N
   // (dgrad), 3 = along M (wgrad); seg_len = channels per class; seg_skip = vanishing index.
   int seg_mode, seg_len, seg_skip;
-  // split-precision operands (NT only): three bf16 planes each, plane strides in elements
+  // split-precision operands (NT only): three bf16 planes each in the blocked layout (op_off);
+  // pA / pB = plane strides, sAp / sBp = frequency strides, rbA / rbB = row blocks of 32, kblocks = K / 16
   const u16* Ap;
   const u16* Bp;
-  long pA, pB;
+  long pA, pB, sAp, sBp;
+  int rbA, rbB, kblocks;
 };
 
 
@@ -781,26 +810,33 @@ __global__ __launch_bounds__(Cfg::THREADS) void wino_bgemm_kernel(BgArgs a) {
 
 
 // ---- the NT GEMM on the bf16 pipe (split-precision operands) --------------------------------
-// 256 x 256 x 32 tile, 8 waves (2 x 4, wave tile 128 x 64 = 4 x 2 MFMA tiles of 32x32x16), one
-// workgroup per CU.  LDS: per (operand, piece) [256 rows][80 bytes] (64 data + 16 pad: the row
-// stride is an odd number of 16-byte slots, conflict-free ds_read_b128 with lane = row and eight
-// consecutive k per lane); single buffer, the next K step's tiles are prefetched into registers
-// while the 96 MFMAs of the current one run.  Larger tiles than the fp32 engine because the
-// bf16 pipe is fast enough to make the L2 -> LDS operand stream the limit (measured on the
-// Winograd shapes, tools/ablate/gemm_bf16x3_v2.hip: 128x128: 120-138, 256x256: 156-175
-// TFLOP/s-equivalent; the fp32 engine: 110-120).
-constexpr int X3_WM = 2, X3_WN = 4, X3_MT = 4, X3_NT = 2, X3_BK = 32, X3_RS = X3_BK * 2 + 16;
-constexpr int X3_BM = X3_WM * X3_MT * 32, X3_BN = X3_WN * X3_NT * 32, X3_THREADS = X3_WM * X3_WN * 64;
-constexpr int X3_TA = X3_BM * X3_RS, X3_TB = X3_BN * X3_RS;
-constexpr size_t X3_LDS = 3 * (size_t)(X3_TA + X3_TB);
+// 256 x 256 block tile, FOUR waves (2 x 2) = one wave per SIMD with a 128 x 128 wave tile: 16 accumulator
+// tiles of 32x32 (256 AGPRs) and both fragment sets of a K stage double-buffered in VGPRs, so the 24
+// ds_read_b128 of stage k+1 are interleaved with the 96 MFMAs of stage k (one read per four MFMAs) and
+// no MFMA waits for an LDS round trip.  K stage = 16: per (operand, piece) 256 rows x 32 bytes, three
+// stages in LDS (144 KiB) filled by global_load_lds straight from the blocked operand layout (op_off:
+// one instruction = one contiguous 1 KiB chunk = 32 rows; no VGPR staging, no ds_write pass), issued
+// three stages ahead; one barrier per stage.  Waves 0,1 fetch A, waves 2,3 fetch B (12 chunks each).
+// tools/ablate/gemm_bf16x3_v3.hip has the prototypes and the measurements behind these choices.
+constexpr int X3_BM = 256, X3_BN = 256, X3_BK = 32;     // X3_BK: granularity of K (two stages)
+constexpr int X3_SK = 16, X3_MT = 4, X3_NT = 4, X3_THREADS = 256, X3_NSTAGE = 3;
+constexpr int X3_TA = X3_BM * X3_SK * 2, X3_TB = X3_BN * X3_SK * 2;   // bytes per (operand, piece, stage)
+constexpr int X3_STAGE = 3 * (X3_TA + X3_TB);
+constexpr size_t X3_LDS = (size_t)X3_NSTAGE * X3_STAGE;
+constexpr int X3_PER_WAVE = 3 * (X3_BM + X3_BN) / 32 / 4;              // global_load_lds per wave per stage
+
+struct X3Frags {
+  bf16x8 a[X3_MT][3];
+  bf16x8 b[X3_NT][3];
+};
+
+// s_waitcnt vmcnt(n) only (expcnt / lgkmcnt untouched): gfx9 encoding vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14
+#define X3_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(0x0f70 | ((n) & 15) | (((n) >> 4) << 14))
 
 // blockIdx.y = K split (wgrad: slabs, reduced by the adjoint filter transform).
-__global__ __launch_bounds__(X3_THREADS) void wino_bgemm_x3_kernel(BgArgs a) {
-  constexpr int CPR = X3_BK / 8;
-  constexpr int PER_A = 3 * X3_BM * CPR / X3_THREADS, PER_B = 3 * X3_BN * CPR / X3_THREADS;
+template <bool PIPE>
+__global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_bgemm_x3_kernel(BgArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-  unsigned char* sA = smem3;
-  unsigned char* sB = smem3 + 3 * X3_TA;
   const int x = blockIdx.x;
   int tm, tn;
   if (a.xmap == 1) {
@@ -826,50 +862,9 @@ __global__ __launch_bounds__(X3_THREADS) void wino_bgemm_x3_kernel(BgArgs a) {
     for (int c = lo / a.seg_len; c <= hi / a.seg_len; ++c) any = any || s2_present(c, f, a.seg_skip);
     if (!any) return;
   }
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / X3_WN, wn = wave % X3_WN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, g = lane >> 5;
-  const u16* Ab = a.Ap + f * a.sA + (long)m0 * a.lda;
-  const u16* Bb = a.Bp + f * a.sB + (long)n0 * a.ldb;
-  const int mrows = a.M - m0, nrows = a.N - n0;
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  u32x4 ra[PER_A], rb[PER_B];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < PER_A; ++i) {
-      const int id = i * X3_THREADS + tid;
-      const int c = id % CPR, row = (id / CPR) % X3_BM, piece = id / (X3_BM * CPR);
-      ra[i] = row < mrows ? *reinterpret_cast<const u32x4*>(Ab + piece * a.pA + (long)row * a.lda + k0 + c * 8) : zero4;
-    }
-#pragma unroll
-    for (int i = 0; i < PER_B; ++i) {
-      const int id = i * X3_THREADS + tid;
-      const int c = id % CPR, row = (id / CPR) % X3_BN, piece = id / (X3_BN * CPR);
-      rb[i] = row < nrows ? *reinterpret_cast<const u32x4*>(Bb + piece * a.pB + (long)row * a.ldb + k0 + c * 8) : zero4;
-    }
-  };
-  auto sstore = [&]() {
-#pragma unroll
-    for (int i = 0; i < PER_A; ++i) {
-      const int id = i * X3_THREADS + tid;
-      const int c = id % CPR, row = (id / CPR) % X3_BM, piece = id / (X3_BM * CPR);
-      *reinterpret_cast<u32x4*>(sA + piece * X3_TA + row * X3_RS + c * 16) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < PER_B; ++i) {
-      const int id = i * X3_THREADS + tid;
-      const int c = id % CPR, row = (id / CPR) % X3_BN, piece = id / (X3_BN * CPR);
-      *reinterpret_cast<u32x4*>(sB + piece * X3_TB + row * X3_RS + c * 16) = rb[i];
-    }
-  };
-  f32x16 acc[X3_MT][X3_NT];
-#pragma unroll
-  for (int i = 0; i < X3_MT; ++i)
-#pragma unroll
-    for (int j = 0; j < X3_NT; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-  const unsigned char* pa = sA + (wm * X3_MT * 32 + r) * X3_RS + 16 * g;
-  const unsigned char* pb = sB + (wn * X3_NT * 32 + r) * X3_RS + 16 * g;
 
   // K runs: the whole K, or (forward of a strided layer) the <= 2 runs of classes present at this frequency
   int lo0 = 0, len0 = 0, lo1 = 0, len1 = 0;
@@ -893,7 +888,7 @@ __global__ __launch_bounds__(X3_THREADS) void wino_bgemm_x3_kernel(BgArgs a) {
       c = e;
     }
   } else {
-    // K split: blockIdx.y takes kt_per_split steps (all of K when there is one split)
+    // K split: blockIdx.y takes kt_per_split granules of X3_BK (all of K when there is one split)
     const int nkt_all = a.K / X3_BK;
     const int kt0 = blockIdx.y * a.kt_per_split;
     int nkt = nkt_all - kt0;
@@ -902,47 +897,125 @@ __global__ __launch_bounds__(X3_THREADS) void wino_bgemm_x3_kernel(BgArgs a) {
     lo0 = kt0 * X3_BK;
     len0 = nkt * X3_BK;
   }
-  // flatten the runs into one sequence of K steps
-  const int steps0 = len0 / X3_BK;
-  const int nsteps = steps0 + len1 / X3_BK;
-  auto kof = [&](int st) { return st < steps0 ? lo0 + st * X3_BK : lo1 + (st - steps0) * X3_BK; };
-  if (nsteps > 0) {
-    gload(kof(0));
-    sstore();
-  }
-  __syncthreads();
-  for (int st = 0; st < nsteps; ++st) {
-    if (st + 1 < nsteps) gload(kof(st + 1));
+  // the runs as one sequence of stages; kb_of = k block (of 16) of a stage
+  const int steps0 = len0 / X3_SK;
+  const int nst = steps0 + len1 / X3_SK;
+  const int kb0 = lo0 / X3_SK, kb1 = lo1 / X3_SK - steps0;
+  auto kb_of = [&](int st) { return st < steps0 ? kb0 + st : kb1 + st; };
+
+  // this wave's 12 chunk streams: operand (A for waves 0,1), piece, row block (clamped at the operand's end:
+  // the duplicated rows only feed C rows / columns that are not stored)
+  const bool isA = wave < 2;
+  const int half = wave & 1;
+  const u16* opb = isA ? a.Ap + f * a.sAp : a.Bp + f * a.sBp;
+  const long plane = isA ? a.pA : a.pB;
+  const int rb0 = (isA ? m0 : n0) >> 5, rbmax = (isA ? a.rbA : a.rbB) - 1;
+  const unsigned voff = (unsigned)lane * 16u;
+  const unsigned lds_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smem3;
+  auto issue = [&](int st, int buf) {
+    const long kb = kb_of(st);
 #pragma unroll
-    for (int sl = 0; sl < X3_BK / 16; ++sl) {
-      bf16x8 A[X3_MT][3], B[X3_NT][3];
+    for (int i = 0; i < X3_PER_WAVE; ++i) {
+      const int li = half * X3_PER_WAVE + i;   // 0..23 within the operand: piece = li / 8, row group = li % 8
+      const int piece = li >> 3, rg = li & 7;
+      int rb = rb0 + rg;
+      if (rb > rbmax) rb = rbmax;
+      const u16* src = opb + piece * plane + (((long)rb * a.kblocks + kb) << 9);
+      const unsigned dst = lds_base + buf * X3_STAGE + (isA ? 0 : 3 * X3_TA) + piece * X3_TA + rg * 1024;
+      // scalar base + per-lane 32-bit offset (the builtin expands to 64-bit per-lane addresses inside the loop);
+      // M0 = LDS address of the chunk.  Nothing else in this kernel uses M0.
+      asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst) : "memory");
+    }
+  };
+  f32x16 acc[X3_MT][X3_NT];
 #pragma unroll
-      for (int t = 0; t < X3_MT; ++t)
+  for (int i = 0; i < X3_MT; ++i)
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
-          A[t][pc] = *reinterpret_cast<const bf16x8*>(pa + pc * X3_TA + t * 32 * X3_RS + 32 * sl);
+    for (int j = 0; j < X3_NT; ++j)
 #pragma unroll
-      for (int t = 0; t < X3_NT; ++t)
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  // fragment of MFMA tile t, piece p: row r of the tile, k half g; the XOR matches op_off's slot swizzle
+  const int sw = (r >> 3) & 1;
+  const int fa = (wm * X3_MT * 32 + r) * 32 + 16 * (g ^ sw);
+  const int fb = 3 * X3_TA + (wn * X3_NT * 32 + r) * 32 + 16 * (g ^ sw);
+  auto load_frags = [&](X3Frags& F, int buf) {
+    const unsigned char* pa = smem3 + buf * X3_STAGE + fa;
+    const unsigned char* pb = smem3 + buf * X3_STAGE + fb;
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
-          B[t][pc] = *reinterpret_cast<const bf16x8*>(pb + pc * X3_TB + t * 32 * X3_RS + 32 * sl);
+    for (int t = 0; t < X3_MT; ++t)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) F.a[t][p] = *reinterpret_cast<const bf16x8*>(pa + p * X3_TA + t * 1024);
+#pragma unroll
+    for (int t = 0; t < X3_NT; ++t)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) F.b[t][p] = *reinterpret_cast<const bf16x8*>(pb + p * X3_TB + t * 1024);
+  };
+  // six products per fp32-exact product, smallest terms first; consecutive MFMAs hit different accumulators
+  auto mfmas = [&](const X3Frags& F) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
 #pragma unroll
       for (int i = 0; i < X3_MT; ++i)
 #pragma unroll
-        for (int j = 0; j < X3_NT; ++j) {
-          // smallest terms first
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][2], B[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[j][2], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][1], B[j][1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][1], B[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[j][1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[j][0], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < X3_NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][PA[t]], F.b[j][PB[t]], acc[i][j], 0, 0, 0);
+  };
+  if (PIPE) {
+    // nst is even and >= 4 (host contract).  One stage: stage st+1 has landed (barrier), the buffer stage st
+    // was read from is refilled with stage st+3, then the 96 MFMAs of stage st on F with the 24 fragment
+    // reads of stage st+1 (into G) in between.  ISSUE: stage st+3 exists; PEND: stage st+2 is in flight;
+    // LOAD: stage st+1 exists.
+    auto stage = [&](int st, int bufn, const X3Frags& F, X3Frags& G, auto issue_c, auto pend_c, auto load_c) {
+      constexpr bool ISSUE = decltype(issue_c)::value, PEND = decltype(pend_c)::value, LOAD = decltype(load_c)::value;
+      if (PEND) X3_WAIT_VM(X3_PER_WAVE);
+      else X3_WAIT_VM(0);
+      __builtin_amdgcn_s_barrier();
+      if (ISSUE) issue(st + 3, bufn == 0 ? X3_NSTAGE - 1 : bufn - 1);
+      if (LOAD) load_frags(G, bufn);
+      mfmas(F);
+      if (LOAD) {
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // four MFMAs
         }
+      }
+    };
+    using Y = std::true_type;
+    using N = std::false_type;
+    X3Frags F0, F1;
+    issue(0, 0);
+    issue(1, 1);
+    issue(2, 2);
+    X3_WAIT_VM(2 * X3_PER_WAVE);
+    __builtin_amdgcn_s_barrier();
+    load_frags(F0, 0);
+    int st = 0, bufn = 1;   // bufn = buffer of stage st + 1
+    auto next = [&]() { bufn = bufn == X3_NSTAGE - 1 ? 0 : bufn + 1; };
+    for (; st + 6 <= nst; st += 2) {
+      stage(st, bufn, F0, F1, Y{}, Y{}, Y{});
+      next();
+      stage(st + 1, bufn, F1, F0, Y{}, Y{}, Y{});
+      next();
     }
-    __syncthreads();
-    if (st + 1 < nsteps) {
-      sstore();
-      __syncthreads();
+    stage(st, bufn, F0, F1, Y{}, Y{}, Y{});
+    next();
+    stage(st + 1, bufn, F1, F0, N{}, Y{}, Y{});
+    next();
+    stage(st + 2, bufn, F0, F1, N{}, N{}, Y{});
+    next();
+    stage(st + 3, bufn, F1, F0, N{}, N{}, N{});
+  } else {
+    // any stage count (short K runs, ragged K splits: small layers only): one stage at a time
+    X3Frags F;
+    for (int st = 0; st < nst; ++st) {
+      issue(st, 0);
+      X3_WAIT_VM(0);
+      __builtin_amdgcn_s_barrier();
+      load_frags(F, 0);
+      mfmas(F);
+      __builtin_amdgcn_s_barrier();
     }
   }
   float* C = a.C + f * a.sC + blockIdx.y * a.sSplit;
@@ -970,7 +1043,8 @@ void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
   const bool x3 = !TN && a.Ap != nullptr;
   ProfScope ps(x3 ? OTGAN_PROF_WINO_GEMM_X3 : OTGAN_PROF_WINO_GEMM, x3 ? 6.0 * flop : flop, 0.0, s);
   if (x3) {
-    ensure_lds<wino_bgemm_x3_kernel>(X3_LDS);
+    ensure_lds<wino_bgemm_x3_kernel<true>>(X3_LDS);
+    ensure_lds<wino_bgemm_x3_kernel<false>>(X3_LDS);
     BgArgs b = a;
     b.tiles_m = (a.M + X3_BM - 1) / X3_BM;
     b.tiles_n = (a.N + X3_BN - 1) / X3_BN;
@@ -978,7 +1052,17 @@ void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
     if (a.M >= a.N) b.xmap = m_ok ? 1 : n_ok ? 2 : 0;
     else b.xmap = n_ok ? 2 : m_ok ? 1 : 0;
     if (nsplit == 1) b.kt_per_split = a.K / X3_BK;
-    hipLaunchKernelGGL(wino_bgemm_x3_kernel, dim3(b.tiles_m * b.tiles_n, nsplit, 16), dim3(X3_THREADS), X3_LDS, s, b);
+    b.sAp = op_fstride(a.M, a.K); b.sBp = op_fstride(a.N, a.K);
+    b.pA = 16 * b.sAp; b.pB = 16 * b.sBp;
+    b.rbA = (a.M + 31) / 32; b.rbB = (a.N + 31) / 32; b.kblocks = a.K / 16;
+    // the pipelined kernel needs >= 4 stages of 16 in every block: the shortest K run of a strided forward is one
+    // class (seg_len), the shortest K split is the last one
+    int min_k = a.K;
+    if (a.seg_mode == 1) min_k = a.seg_len;
+    else if (nsplit > 1) min_k = a.K - (nsplit - 1) * b.kt_per_split * X3_BK;
+    const dim3 grid(b.tiles_m * b.tiles_n, nsplit, 16);
+    if (min_k >= 4 * X3_SK) hipLaunchKernelGGL(wino_bgemm_x3_kernel<true>, grid, dim3(X3_THREADS), X3_LDS, s, b);
+    else hipLaunchKernelGGL(wino_bgemm_x3_kernel<false>, grid, dim3(X3_THREADS), X3_LDS, s, b);
     return;
   }
   ensure_lds<wino_bgemm_kernel<TN>>(lds);
@@ -1013,6 +1097,8 @@ bool use_x3_wgrad() {
 }
 // floats of workspace that hold n operand elements (three bf16 planes = 6 bytes per element)
 inline size_t operand_floats(size_t n) { return (3 * n + 1) / 2; }
+// elements of a [16][rows][K] operand in either layout (rows padded to 32, K to 16)
+inline size_t op_elems(size_t rows, size_t K) { return 16 * ((rows + 31) / 32 * 32) * ((K + 15) / 16 * 16); }
 
 // the four output-parity classes of a [N, 2H, 2W, ld] buffer as small-grid views
 template <class V, class P>
@@ -1059,7 +1145,8 @@ bool winograd_enabled() {
 
 size_t wino_fwd_ws_floats(const WinoGeo& g) {
   const size_t T = (size_t)wino_tiles(g);
-  return operand_floats(16 * T * g.Cin) + operand_floats(16 * T * 4 * g.Cout) + operand_floats(16 * (size_t)4 * g.Cout * g.Cin) +
+  return operand_floats(op_elems(T, g.Cin)) + operand_floats(op_elems(T, 4 * g.Cout)) +
+         operand_floats(std::max(op_elems(4 * g.Cout, g.Cin), op_elems(g.Cin, 4 * g.Cout))) +
          16 * T * (size_t)(4 * g.Cout > g.Cin ? 4 * g.Cout : g.Cin);
 }
 size_t wino_dgrad_ws_floats(const WinoGeo& g) { return wino_fwd_ws_floats(g); }
@@ -1067,7 +1154,7 @@ size_t wino_wgrad_ws_floats(const WinoGeo& g) {
   const size_t T = (size_t)wino_tiles(g);
   const size_t Tp = (T + 63) / 64 * 64;
   const int ns = std::max(wgrad_splits(g), x3_wgrad_splits(g.Cin, 4 * g.Cout, (long)Tp));
-  return operand_floats(16 * Tp * g.Cin) + operand_floats(16 * Tp * 4 * g.Cout) + (size_t)ns * 16 * 4 * g.Cout * g.Cin;
+  return operand_floats(op_elems(g.Cin, Tp)) + operand_floats(op_elems(4 * g.Cout, Tp)) + (size_t)ns * 16 * 4 * g.Cout * g.Cin;
 }
 
 int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stride, const float* bias, float* y,
@@ -1075,13 +1162,13 @@ int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stri
   const long T = wino_tiles(g);
   const int N4 = 4 * g.Cout;
   const bool x3 = use_x3() && g.Cin % X3_BK == 0;
-  const size_t nV = 16 * (size_t)T * g.Cin, nU = 16 * (size_t)N4 * g.Cin;
+  const size_t nV = op_elems(T, g.Cin), nU = op_elems(N4, g.Cin);
   float* V = ws;
   float* U = V + operand_floats(nV);
   float* Mh = U + operand_floats(nU);
   u16* VP = x3 ? reinterpret_cast<u16*>(V) : nullptr;
   u16* UP = x3 ? reinterpret_cast<u16*>(U) : nullptr;
-  hipLaunchKernelGGL(wino_filter_fwd_kernel, dim3(grid1((long)N4 * (g.Cin / 4))), dim3(256), 0, s, weffT, cls_stride,
+  hipLaunchKernelGGL(wino_filter_fwd_kernel, dim3(op_grid(N4, g.Cin / 4)), dim3(256), 0, s, weffT, cls_stride,
                      g.Cin, g.Cout, U, UP);
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
@@ -1089,7 +1176,7 @@ int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stri
   ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
   ia.H = g.H; ia.W = g.W; ia.TH = g.H / 2; ia.TW = g.W / 2; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.V = V;
   ia.P = VP;
-  hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(grid1(T * (g.Cin / 4)), 1, 1), dim3(256), 0, s, ia);
+  hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cin / 4), 1, 1), dim3(256), 0, s, ia);
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.Ap = VP; b.Bp = UP; b.pA = (long)nV; b.pB = (long)nU;
@@ -1113,13 +1200,13 @@ int wino_dgrad(const WinoGeo& g, const float* dy, const float* weff, long cls_st
   const long T = wino_tiles(g);
   const int K4 = 4 * g.Cout;
   const bool x3 = use_x3() && K4 % X3_BK == 0;
-  const size_t nV = 16 * (size_t)T * K4, nU = 16 * (size_t)g.Cin * K4;
+  const size_t nV = op_elems(T, K4), nU = op_elems(g.Cin, K4);
   float* DV = ws;                            // [16][T][4*Cout]
   float* U = DV + operand_floats(nV);        // [16][Cin][4*Cout]
   float* Xh = U + operand_floats(nU);        // [16][T][Cin]
   u16* VP = x3 ? reinterpret_cast<u16*>(DV) : nullptr;
   u16* UP = x3 ? reinterpret_cast<u16*>(U) : nullptr;
-  hipLaunchKernelGGL(wino_filter_bwd_kernel, dim3(grid1(4L * g.Cin * (g.Cout / 4))), dim3(256), 0, s, weff, cls_stride,
+  hipLaunchKernelGGL(wino_filter_bwd_kernel, dim3(op_grid(g.Cin, g.Cout)), dim3(256), 0, s, weff, cls_stride,
                      g.Cin, g.Cout, U, UP);
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
@@ -1128,7 +1215,7 @@ int wino_dgrad(const WinoGeo& g, const float* dy, const float* weff, long cls_st
   for (int cls = 0; cls < 4; ++cls) ia.coff[cls] = cls * g.Cout;
   ia.H = g.H; ia.W = g.W; ia.TH = g.H / 2; ia.TW = g.W / 2; ia.C = g.Cout; ia.T = T; ia.ldv = K4; ia.V = DV;
   ia.P = VP;
-  hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(grid1(T * (g.Cout / 4)), 1, 4), dim3(256), 0, s, ia);
+  hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cout / 4), 1, 4), dim3(256), 0, s, ia);
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.Ap = VP; b.Bp = UP; b.pA = (long)nV; b.pB = (long)nU;
@@ -1155,7 +1242,7 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
     // operands tile-contiguous (transposing producers), NT GEMM on the bf16 pipe with K = tiles
     const long Tp = (T + 63) / 64 * 64;
     const int ns = x3_wgrad_splits(g.Cin, N4, Tp);
-    const size_t nV = 16 * (size_t)Tp * g.Cin, nM = 16 * (size_t)Tp * N4;
+    const size_t nV = op_elems(g.Cin, Tp), nM = op_elems(N4, Tp);
     u16* VP = reinterpret_cast<u16*>(ws);
     u16* MP = reinterpret_cast<u16*>(ws + operand_floats(nV));
     float* slabs = ws + operand_floats(nV) + operand_floats(nM);
@@ -1194,14 +1281,14 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
   ia.s2_skip = -1;
   ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
   ia.H = g.H; ia.W = g.W; ia.TH = g.H / 2; ia.TW = g.W / 2; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.V = V;
-  hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(grid1(T * (g.Cin / 4)), 1, 1), dim3(256), 0, s, ia);
+  hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cin / 4), 1, 1), dim3(256), 0, s, ia);
   InArgs da;
   memset(&da, 0, sizeof(da));
   da.s2_skip = -1;
   class_views(g, dy + g.y_coff, g.ldy, da.v);
   for (int cls = 0; cls < 4; ++cls) da.coff[cls] = cls * g.Cout;
   da.H = g.H; da.W = g.W; da.TH = g.H / 2; da.TW = g.W / 2; da.C = g.Cout; da.T = T; da.ldv = N4; da.V = dM;
-  hipLaunchKernelGGL(wino_outadj_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 4), dim3(256), 0, s, da);
+  hipLaunchKernelGGL(wino_outadj_kernel, dim3(op_grid(T, g.Cout / 4), 1, 4), dim3(256), 0, s, da);
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.A = V; b.B = dM; b.C = slabs; b.M = g.Cin; b.N = N4; b.K = (int)T;
@@ -1254,7 +1341,7 @@ void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, u16* VP, h
   ia.V = V;
   ia.P = VP;
   ia.s2_skip = 0;
-  const dim3 grid(grid1(T * (g.C / 4)), 1, 4), blk(256);
+  const dim3 grid(op_grid(T, g.C / 4), 1, 4), blk(256);
   if (g.doubled) {
     if (g.act == 2) hipLaunchKernelGGL((wino_input_kernel<2, true>), grid, blk, 0, s, ia);
     else hipLaunchKernelGGL((wino_input_kernel<1, true>), grid, blk, 0, s, ia);
@@ -1267,14 +1354,15 @@ void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, u16* VP, h
 
 size_t wino_s2_fwd_ws_floats(const WinoS2Geo& g) {
   const size_t T = (size_t)wino_s2_tiles(g), K4 = 4 * (size_t)g.Ceff;
-  return operand_floats(16 * T * K4) + operand_floats(16 * T * g.Cout) + operand_floats(16 * K4 * g.Cout) + 16 * T * K4;
+  return operand_floats(op_elems(T, K4)) + operand_floats(op_elems(T, g.Cout)) +
+         operand_floats(std::max(op_elems(g.Cout, K4), op_elems(K4, g.Cout))) + 16 * T * K4;
 }
 size_t wino_s2_dgrad_ws_floats(const WinoS2Geo& g) { return wino_s2_fwd_ws_floats(g); }
 size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g) {
   const size_t T = (size_t)wino_s2_tiles(g), K4 = 4 * (size_t)g.Ceff;
   const size_t Tp = (T + 63) / 64 * 64;
   const int ns = std::max(s2_wgrad_splits(g), x3_wgrad_splits((int)K4, g.Cout, (long)Tp));
-  return operand_floats(16 * Tp * K4) + operand_floats(16 * Tp * g.Cout) + (size_t)ns * 16 * K4 * g.Cout;
+  return operand_floats(op_elems(K4, Tp)) + operand_floats(op_elems(g.Cout, Tp)) + (size_t)ns * 16 * K4 * g.Cout;
 }
 
 int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float* bias, float* y, float* ws,
@@ -1282,13 +1370,13 @@ int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float
   const long T = wino_s2_tiles(g);
   const int K4 = 4 * g.Ceff;
   const bool x3 = use_x3() && g.Ceff % X3_BK == 0;
-  const size_t nV = 16 * (size_t)T * K4, nU = 16 * (size_t)g.Cout * K4;
+  const size_t nV = op_elems(T, K4), nU = op_elems(g.Cout, K4);
   float* V = ws;                              // [16][T][4*Ceff]
   float* U = V + operand_floats(nV);          // [16][Cout][4*Ceff]
   float* Mh = U + operand_floats(nU);         // [16][T][Cout]
   u16* VP = x3 ? reinterpret_cast<u16*>(V) : nullptr;
   u16* UP = x3 ? reinterpret_cast<u16*>(U) : nullptr;
-  hipLaunchKernelGGL(wino_s2_filter_fwd_kernel, dim3(grid1(4L * g.Cout * (g.Ceff / 4))), dim3(256), 0, s, wT, g.Ceff,
+  hipLaunchKernelGGL(wino_s2_filter_fwd_kernel, dim3(op_grid(g.Cout, g.Ceff)), dim3(256), 0, s, wT, g.Ceff,
                      g.Cout, U, UP);
   s2_input_transform(g, x, V, VP, s);
   BgArgs b;
@@ -1316,13 +1404,13 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   const int K4 = 4 * g.Ceff;
   const int OH = g.H / 2, OW = g.W / 2;
   const bool x3 = use_x3() && g.Cout % X3_BK == 0;
-  const size_t nV = 16 * (size_t)T * g.Cout, nU = 16 * (size_t)K4 * g.Cout;
+  const size_t nV = op_elems(T, g.Cout), nU = op_elems(K4, g.Cout);
   float* DV = ws;                             // [16][T][Cout]
   float* U = DV + operand_floats(nV);         // [16][4*Ceff][Cout]
   float* Xh = U + operand_floats(nU);         // [16][T][4*Ceff]
   u16* VP = x3 ? reinterpret_cast<u16*>(DV) : nullptr;
   u16* UP = x3 ? reinterpret_cast<u16*>(U) : nullptr;
-  hipLaunchKernelGGL(wino_s2_filter_bwd_kernel, dim3(grid1(4L * g.Ceff * (g.Cout / 4))), dim3(256), 0, s, w, g.Ceff,
+  hipLaunchKernelGGL(wino_s2_filter_bwd_kernel, dim3(op_grid(4L * g.Ceff, g.Cout / 4)), dim3(256), 0, s, w, g.Ceff,
                      g.Cout, U, UP);
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
@@ -1330,7 +1418,7 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   ia.v[0].p = dy + g.y_coff; ia.v[0].sn = (long)OH * OW * g.ldy; ia.v[0].sh = (long)OW * g.ldy; ia.v[0].sw = g.ldy;
   ia.H = OH; ia.W = OW; ia.TH = OH / 2; ia.TW = OW / 2; ia.C = g.Cout; ia.T = T; ia.ldv = g.Cout; ia.V = DV;
   ia.P = VP;
-  hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(grid1(T * (g.Cout / 4)), 1, 1), dim3(256), 0, s, ia);
+  hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cout / 4), 1, 1), dim3(256), 0, s, ia);
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.Ap = VP; b.Bp = UP; b.pA = (long)nV; b.pB = (long)nU;
@@ -1364,7 +1452,7 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
   if (use_x3_wgrad() && g.C % 16 == 0 && g.Cout % 16 == 0) {
     const long Tp = (T + 63) / 64 * 64;
     const int ns = x3_wgrad_splits(K4, g.Cout, Tp);
-    const size_t nV = 16 * (size_t)Tp * K4, nM = 16 * (size_t)Tp * g.Cout;
+    const size_t nV = op_elems(K4, Tp), nM = op_elems(g.Cout, Tp);
     u16* VP = reinterpret_cast<u16*>(ws);
     u16* MP = reinterpret_cast<u16*>(ws + operand_floats(nV));
     float* slabs = ws + operand_floats(nV) + operand_floats(nM);
@@ -1410,7 +1498,7 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
   da.s2_skip = -1;
   da.v[0].p = dy + g.y_coff; da.v[0].sn = (long)OH * OW * g.ldy; da.v[0].sh = (long)OW * g.ldy; da.v[0].sw = g.ldy;
   da.H = OH; da.W = OW; da.TH = OH / 2; da.TW = OW / 2; da.C = g.Cout; da.T = T; da.ldv = g.Cout; da.V = dM;
-  hipLaunchKernelGGL(wino_outadj_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 1), dim3(256), 0, s, da);
+  hipLaunchKernelGGL(wino_outadj_kernel, dim3(op_grid(T, g.Cout / 4), 1, 1), dim3(256), 0, s, da);
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.A = V; b.B = dM; b.C = slabs; b.M = K4; b.N = g.Cout; b.K = (int)T;
