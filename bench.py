@@ -106,7 +106,7 @@ def main():
                    "precision_note": ("fp32 tensors and fp32 accumulation everywhere; the Winograd-domain GEMMs multiply "
                                       "operands stored as three bf16 pieces (hi+mid+lo = the full 24-bit significand) with six "
                                       "bf16 MFMAs per product, measured 2e-7..5e-7 rel. L2 vs fp64 (fp32 MFMA chain: 1.3e-6); "
-                                      "OTGAN_WINO_FP32=1 runs the same GEMMs on the fp32 MFMA engine (8045 img/s, "
+                                      "OTGAN_WINO_FP32=1 runs the same GEMMs on the fp32 MFMA engine (≈8000 img/s, "
                                       "profiles/README.md)") if a.model == "dcgan" and os.environ.get("OTGAN_WINO_FP32") != "1"
                                      else "fp32 MFMA" + ("; the forward of the 32x32 growth layers uses the same three-way bf16 "
                                                          "split (fp32-exact products)" if a.model == "densenet" else "")},

@@ -31,8 +31,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const long planeA = (long)a.F * a.M * a.K, planeB = (long)a.F * a.N * a.K;
   // ORDER >= 2: every block reads tile (0, 0) of frequency 0 (all operand loads hit in L2): separates the
   // in-core limit from the memory-system limit
-  const u16* Ab = a.Ap + (ORDER >= 2 ? 0 : ((long)f * a.M + (long)blockIdx.x * BM) * a.K);
-  const u16* Bb = a.Bp + (ORDER >= 2 ? 0 : ((long)f * a.N + (long)blockIdx.y * BN) * a.K);
+  const u16* Ab = a.Ap + ((ORDER == 2 || ORDER == 3 || ORDER >= 5) ? 0 : ((long)f * a.M + (long)blockIdx.x * BM) * a.K);
+  const u16* Bb = a.Bp + ((ORDER == 2 || ORDER == 3 || ORDER >= 5) ? 0 : ((long)f * a.N + (long)blockIdx.y * BN) * a.K);
   const int lrow = lane >> 1, pc = lane & 1;
   // per-lane byte offset inside a 32-row group (same for every instruction): row * K * 2 + chunk * 16
   const unsigned voff = (unsigned)lrow * (unsigned)a.K * 2u + (unsigned)((pc ^ ((lrow >> 3) & 1)) * 16);
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const int li = half * PER_WAVE + i;          // 0..23 within the operand
       const int piece = li >> 3, rg = li & 7;
       const u16* sb = opb + piece * plane + (long)rg * 32 * a.K + kt * BK;
-      if (ORDER == 4) {
+      if (ORDER >= 4) {
         // timing experiment: operands stored tile-blocked [row block of 32][k block of 16][32 rows][16 k], one
         // instruction = one contiguous 1 KiB chunk (the data read differ from the row-major case: timing only)
         sb = opb + piece * plane + ((long)rg * (a.K / BK) + kt) * 512 - (voff >> 1) + lane * 8;
@@ -106,13 +106,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // LOAD: stage kt+1 exists.
   auto stage = [&](int kt, int bufn, const Frags& F, Frags& G, auto issue_c, auto pend_c, auto load_c) {
     constexpr bool ISSUE = decltype(issue_c)::value, PEND = decltype(pend_c)::value, LOAD = decltype(load_c)::value;
-    if (PEND) __builtin_amdgcn_s_waitcnt(0x0f70 | (PER_WAVE & 15) | ((PER_WAVE >> 4) << 14));   // vmcnt(12)
+    if (ORDER == 7 || ORDER == 8) {
+    } else if (PEND) __builtin_amdgcn_s_waitcnt(0x0f70 | (PER_WAVE & 15) | ((PER_WAVE >> 4) << 14));   // vmcnt(12)
     else __builtin_amdgcn_s_waitcnt(0x0f70);                                                      // vmcnt(0)
-    __builtin_amdgcn_s_barrier();
-    if (ISSUE) issue(kt + 3, bufn == 0 ? 2 : bufn - 1);   // the buffer stage kt was read from
-    if (LOAD) load_frags(G, bufn);
+    // in-core breakdown experiments (wrong results, timing only): 6 = no barrier, 7 = no refills, 8 = no fragment reads
+    if (ORDER != 6) __builtin_amdgcn_s_barrier();
+    if (ISSUE && ORDER != 7 && ORDER != 8) issue(kt + 3, bufn == 0 ? 2 : bufn - 1);   // the buffer stage kt was read from
+    if (LOAD && ORDER != 8) load_frags(G, bufn);
     mfmas(F);
-    if (LOAD) {
+    if (LOAD && ORDER != 8) {
 #pragma unroll
       for (int q = 0; q < 24; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read
@@ -226,5 +228,9 @@ int main(int argc, char** argv) {
   v3::run<1>("v3 4w 128x128 term-major", a, dRef);
   v3::run<3>("v3 term-major, L2-resident", a, dRef);
   v3::run<4>("v3 term-major, blocked operands", a, dRef);
+  v3::run<5>("v3 blocked + L2-resident", a, dRef);
+  v3::run<6>("  .. no barrier", a, dRef);
+  v3::run<7>("  .. no refills", a, dRef);
+  v3::run<8>("  .. MFMA only", a, dRef);
   return 0;
 }
