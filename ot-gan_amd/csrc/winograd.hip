@@ -912,10 +912,10 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
   const int rb0 = (isA ? m0 : n0) >> 5, rbmax = (isA ? a.rbA : a.rbB) - 1;
   const unsigned voff = (unsigned)lane * 16u;
   const unsigned lds_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smem3;
-  auto issue = [&](int st, int buf) {
+  auto issue = [&](int st, int buf, int i0 = 0, int n = X3_PER_WAVE) {
     const long kb = kb_of(st);
 #pragma unroll
-    for (int i = 0; i < X3_PER_WAVE; ++i) {
+    for (int i = i0; i < i0 + n; ++i) {
       const int li = half * X3_PER_WAVE + i;   // 0..23 within the operand: piece = li / 8, row group = li % 8
       const int piece = li >> 3, rg = li & 7;
       int rb = rb0 + rg;
@@ -971,14 +971,35 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
       if (PEND) X3_WAIT_VM(X3_PER_WAVE);
       else X3_WAIT_VM(0);
       __builtin_amdgcn_s_barrier();
-      if (ISSUE) issue(st + 3, bufn == 0 ? X3_NSTAGE - 1 : bufn - 1);
-      if (LOAD) load_frags(G, bufn);
-      mfmas(F);
-      if (LOAD) {
+      // six term groups of 16 MFMAs; in front of each: two of the twelve refill loads (all twelve at once keep the
+      // wave in its VMEM issue queue for several hundred cycles while the matrix pipe drains) and four of the 24
+      // fragment reads of the next stage
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+      const int rbuf = bufn == 0 ? X3_NSTAGE - 1 : bufn - 1;
+      const unsigned char* pa = smem3 + bufn * X3_STAGE + fa;
+      const unsigned char* pb = smem3 + bufn * X3_STAGE + fb;
 #pragma unroll
-        for (int q = 0; q < 24; ++q) {
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // four MFMAs
+      for (int t = 0; t < 6; ++t) {
+        if (ISSUE) issue(st + 3, rbuf, 2 * t, 2);
+        if (LOAD) {
+#pragma unroll
+          for (int q = 4 * t; q < 4 * t + 4; ++q) {
+            const int tt = (q % 12) / 3, p = q % 3;   // q < 12: A fragments, else B
+            if (q < 12) G.a[tt][p] = *reinterpret_cast<const bf16x8*>(pa + p * X3_TA + tt * 1024);
+            else G.b[tt][p] = *reinterpret_cast<const bf16x8*>(pb + p * X3_TB + tt * 1024);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < X3_MT; ++i)
+#pragma unroll
+          for (int j = 0; j < X3_NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][PA[t]], F.b[j][PB[t]], acc[i][j], 0, 0, 0);
+        if (LOAD) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // four MFMAs
+          }
         }
       }
     };
