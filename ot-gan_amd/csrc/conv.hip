@@ -861,6 +861,151 @@ __global__ __launch_bounds__(256) void conv_fewout_kernel(GatherA g, Taps taps, 
   }
 }
 
+
+// Tile variant of the few-output kernel for stride-1 layers (the RGB-out convolution of both generators,
+// the input gradient of the RGB-in convolution): the kernel above re-reads the source once per tap
+// (25x for a 5x5 filter, L2-bound at ~10 TB/s).  Here a block owns TR rows x W columns of one image
+// (256 pixels, thread = pixel), stages the tile plus halo for 32 channels at a time in LDS -- sign /
+// activation applied once, at fill time -- and every tap reads its shifted pixel as eight ds_read_b128
+// (pixel stride 9 slots of 16 bytes: conflict-free); the weights of a (tap, channel chunk) are
+// wave-uniform scalar loads.
+struct FewTileArgs {
+  int TR, LH, LW, dh0, dw0;   // tile rows; LDS tile = LH x LW pixels starting at (r0 + dh0, dw0)
+  unsigned lw_magic;          // ceil(2^20 / LW)
+};
+
+template <int ACT, int NJ>
+__global__ __launch_bounds__(256) void conv_fewout_tile_kernel(GatherA g, Taps taps, FewOutArgs a, FewTileArgs ft) {
+  extern __shared__ __attribute__((aligned(16))) float4 s_fx[];   // [LH * LW][9]
+  const int tid = threadIdx.x;
+  const int W = 1 << g.logGW, H = 1 << g.logGH;
+  const int tiles_per_img = H / ft.TR;
+  const int n = blockIdx.x / tiles_per_img, r0 = (blockIdx.x - n * tiles_per_img) * ft.TR;
+  const int pr = tid >> g.logGW, pc = tid & (W - 1);
+  const long img = (long)n * H * W;
+  // two partial sums per output (even / odd channel pairs): the inner product is written as packed FMAs
+  // (v_pk_fma_f32 with the weight pair in SGPRs), two per output and float4
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 acc2[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) acc2[j] = f32x2{0.f, 0.f};
+  const int npix = ft.LH * ft.LW;
+  for (int d0 = 0; d0 < g.Ck; d0 += 32) {
+    __syncthreads();   // the previous chunk's tile is fully consumed
+    // all loads of a batch in flight before the first LDS store (a load-store loop exposes one memory round trip
+    // per element); p / LW through a multiply-shift (exact for p < 4096, LW <= 68)
+    constexpr int kBatch = 9;
+    for (int i0 = tid; i0 < npix * 8; i0 += 256 * kBatch) {
+      float4 v[kBatch];
+      float sg[kBatch];
+#pragma unroll
+      for (int b = 0; b < kBatch; ++b) {
+        const int i = i0 + b * 256;
+        const int q = i & 7, p = i >> 3;
+        const int lr = (int)(((unsigned)p * ft.lw_magic) >> 20), lc = p - lr * ft.LW;
+        const int ih = r0 + lr + ft.dh0, iw = lc + ft.dw0;
+        const int d = d0 + 4 * q;
+        v[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sg[b] = 1.f;
+        if (i < npix * 8 && d < g.Ck && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+          int sc;
+          decode_map(g, d, g.cmap ? g.cmap[d] : 0, sc, sg[b]);
+          v[b] = *reinterpret_cast<const float4*>(g.x + (img + (long)ih * W + iw) * g.ldx + sc);
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < kBatch; ++b) {
+        const int i = i0 + b * 256;
+        if (i < npix * 8) {
+          float4 o;
+          o.x = act_apply<ACT>(sg[b] * v[b].x);
+          o.y = act_apply<ACT>(sg[b] * v[b].y);
+          o.z = act_apply<ACT>(sg[b] * v[b].z);
+          o.w = act_apply<ACT>(sg[b] * v[b].w);
+          s_fx[(i >> 3) * 9 + (i & 7)] = o;
+        }
+      }
+    }
+    __syncthreads();
+    const int nq = (g.Ck - d0) >= 32 ? 8 : (g.Ck - d0) >> 2;
+    for (int t = 0; t < taps.n; ++t) {
+      const int dhw = taps.dhw[t];
+      const int dh = dhw >> 16, dw = sx16(dhw);
+      const float4* src = s_fx + ((pr + dh - ft.dh0) * ft.LW + (pc + dw - ft.dw0)) * 9;
+      const float* __restrict__ wt = a.w + taps.boff[t] + d0;
+      if (nq == 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float4 v = src[q];
+          const f32x2 v01 = {v.x, v.y}, v23 = {v.z, v.w};
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const f32x2* wj = reinterpret_cast<const f32x2*>(wt + j * a.sJ + 4 * q);
+            acc2[j] = __builtin_elementwise_fma(v01, wj[0], acc2[j]);
+            acc2[j] = __builtin_elementwise_fma(v23, wj[1], acc2[j]);
+          }
+        }
+      } else {
+        for (int q = 0; q < nq; ++q) {
+          const float4 v = src[q];
+          const f32x2 v01 = {v.x, v.y}, v23 = {v.z, v.w};
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const f32x2* wj = reinterpret_cast<const f32x2*>(wt + j * a.sJ + 4 * q);
+            acc2[j] = __builtin_elementwise_fma(v01, wj[0], acc2[j]);
+            acc2[j] = __builtin_elementwise_fma(v23, wj[1], acc2[j]);
+          }
+        }
+      }
+    }
+  }
+  float acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) acc[j] = acc2[j][0] + acc2[j][1];
+  float* dst = a.out + (img + (long)(r0 + pr) * W + pc) * a.ldo + a.coff;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const float v = acc[j] + (a.bias ? a.bias[j] : 0.f);
+    dst[j] = a.accumulate ? dst[j] + v : v;
+  }
+}
+
+// launches the tile kernel when the layer qualifies (stride 1 on a power-of-two grid of 16..64 columns, whole
+// tiles, 3 or 4 outputs); returns false otherwise
+template <int ACT>
+static bool launch_fewout_tile(const GatherA& ga, const Taps& t, const FewOutArgs& fa, hipStream_t s) {
+  if (ga.sa != 1 || ga.logUp != 0 || (fa.J != 3 && fa.J != 4) || fa.so != 1) return false;
+  const int W = 1 << ga.logGW, H = 1 << ga.logGH;
+  if (W != ga.W || H != ga.H || W < 16 || W > 64) return false;
+  FewTileArgs ft;
+  ft.TR = 256 / W;
+  if (ft.TR > H || H % ft.TR) return false;
+  int dh0 = 1 << 20, dh1 = -(1 << 20), dw0 = 1 << 20, dw1 = -(1 << 20);
+  for (int i = 0; i < t.n; ++i) {
+    const int dh = t.dhw[i] >> 16, dw = (int)(short)(t.dhw[i] & 0xffff);
+    dh0 = dh < dh0 ? dh : dh0; dh1 = dh > dh1 ? dh : dh1;
+    dw0 = dw < dw0 ? dw : dw0; dw1 = dw > dw1 ? dw : dw1;
+  }
+  ft.dh0 = dh0; ft.dw0 = dw0;
+  ft.LH = ft.TR + dh1 - dh0; ft.LW = W + dw1 - dw0;
+  ft.lw_magic = ((1u << 20) + ft.LW - 1) / ft.LW;
+  const size_t lds = sizeof(float4) * 9 * (size_t)ft.LH * ft.LW;
+  if (lds > 80 * 1024) return false;
+  const dim3 grid(ga.Mtot / 256);
+  if (fa.J == 3) {
+    static bool once3 = (hipFuncSetAttribute((const void*)conv_fewout_tile_kernel<ACT, 3>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), true);
+    (void)once3;
+    hipLaunchKernelGGL((conv_fewout_tile_kernel<ACT, 3>), grid, dim3(256), lds, s, ga, t, fa, ft);
+  } else {
+    static bool once4 = (hipFuncSetAttribute((const void*)conv_fewout_tile_kernel<ACT, 4>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), true);
+    (void)once4;
+    hipLaunchKernelGGL((conv_fewout_tile_kernel<ACT, 4>), grid, dim3(256), lds, s, ga, t, fa, ft);
+  }
+  return true;
+}
+
 struct OuterArgs {
   // wide operand: value(pix, c) ; narrow operand: value(pix, j)
   const float* wide; int ldw; int wideC;      // channels of the wide side
@@ -1677,9 +1822,13 @@ int otgan_conv2d_fwd_f32(const otgan_conv_desc* d, const float* x, const int32_t
     ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * ga.Mtot * (double)Ktot * d->Cout, 0.0, s);
     const dim3 grid(ceil_div(ga.Mtot, 64));
     const int act = act_kind(d->preact);
-    if (act == 1) hipLaunchKernelGGL(conv_fewout_kernel<1>, grid, dim3(256), 0, s, ga, ct.taps[0], fa);
-    else if (act == 2) hipLaunchKernelGGL(conv_fewout_kernel<2>, grid, dim3(256), 0, s, ga, ct.taps[0], fa);
-    else hipLaunchKernelGGL(conv_fewout_kernel<0>, grid, dim3(256), 0, s, ga, ct.taps[0], fa);
+    if (act == 1) {
+      if (!launch_fewout_tile<1>(ga, ct.taps[0], fa, s)) hipLaunchKernelGGL(conv_fewout_kernel<1>, grid, dim3(256), 0, s, ga, ct.taps[0], fa);
+    } else if (act == 2) {
+      if (!launch_fewout_tile<2>(ga, ct.taps[0], fa, s)) hipLaunchKernelGGL(conv_fewout_kernel<2>, grid, dim3(256), 0, s, ga, ct.taps[0], fa);
+    } else {
+      if (!launch_fewout_tile<0>(ga, ct.taps[0], fa, s)) hipLaunchKernelGGL(conv_fewout_kernel<0>, grid, dim3(256), 0, s, ga, ct.taps[0], fa);
+    }
     OTGAN_CHECK_LAUNCH("conv2d fwd (few outputs)");
     return OTGAN_OK;
   }
@@ -1767,7 +1916,8 @@ int otgan_conv2d_dgrad_f32(const otgan_conv_desc* d, const float* dy, const floa
     fa.out = dx; fa.ldo = lddx; fa.coff = 0; fa.J = d->C;
     fa.so = 1; fa.OHf = g.Hin; fa.OWf = g.Win; fa.accumulate = accumulate;
     ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * ga.Mtot * (double)t.n * d->Cout * d->C, 0.0, s);
-    hipLaunchKernelGGL(conv_fewout_kernel<0>, dim3(ceil_div(ga.Mtot, 64)), dim3(256), 0, s, ga, t, fa);
+    if (!launch_fewout_tile<0>(ga, t, fa, s))
+      hipLaunchKernelGGL(conv_fewout_kernel<0>, dim3(ceil_div(ga.Mtot, 64)), dim3(256), 0, s, ga, t, fa);
     OTGAN_CHECK_LAUNCH("conv2d dgrad (few inputs)");
     return OTGAN_OK;
   }
