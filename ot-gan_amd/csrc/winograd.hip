@@ -721,6 +721,7 @@ struct BgArgs {
   const u16* Bp;
   long pA, pB, sAp, sBp;
   int rbA, rbB, kblocks;
+  int cbA, cbB;   // TL operands: column blocks of 16 (M / 16, N / 16)
 };
 
 
@@ -834,7 +835,12 @@ struct X3Frags {
 #define X3_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(0x0f70 | ((n) & 15) | (((n) >> 4) << 14))
 
 // blockIdx.y = K split (wgrad: slabs, reduced by the adjoint filter transform).
-template <bool PIPE>
+// TL ("t-leading"): both operands are stored with the CONTRACTION index as the row of the blocked layout
+// (A = [K][M], B = [K][N]: the weight-gradient GEMMs contract over the tiles and read the forward / dgrad
+// operands V[tile][channel] as they are).  A stage is then 16 rows of 16 + 16 column blocks; the fragments
+// (eight consecutive k of one column per lane) come out of ds_read_b64_tr_b16: a 16-lane group reads a
+// [4 k][16 columns] block, lane l the four columns 4(l%4).. of row l/4, and receives column l of all four rows.
+template <bool PIPE, bool TL>
 __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_bgemm_x3_kernel(BgArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
   const int x = blockIdx.x;
@@ -910,7 +916,9 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
   const u16* opb = isA ? a.Ap + f * a.sAp : a.Bp + f * a.sBp;
   const long plane = isA ? a.pA : a.pB;
   const int rb0 = (isA ? m0 : n0) >> 5, rbmax = (isA ? a.rbA : a.rbB) - 1;
-  const unsigned voff = (unsigned)lane * 16u;
+  // TL: column blocks of 16; one instruction fetches the same 16 rows of two adjacent column blocks
+  const int cb0 = (isA ? m0 : n0) >> 4, cbn = isA ? a.cbA : a.cbB;
+  const unsigned voff = TL ? (unsigned)(lane >> 5) * 1024u + (unsigned)(lane & 31) * 16u : (unsigned)lane * 16u;
   const unsigned lds_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smem3;
   auto issue = [&](int st, int buf, int i0 = 0, int n = X3_PER_WAVE) {
     const long kb = kb_of(st);
@@ -918,9 +926,16 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     for (int i = i0; i < i0 + n; ++i) {
       const int li = half * X3_PER_WAVE + i;   // 0..23 within the operand: piece = li / 8, row group = li % 8
       const int piece = li >> 3, rg = li & 7;
-      int rb = rb0 + rg;
-      if (rb > rbmax) rb = rbmax;
-      const u16* src = opb + piece * plane + (((long)rb * a.kblocks + kb) << 9);
+      const u16* src;
+      if (TL) {
+        int cb = cb0 + 2 * rg;
+        if (cb > cbn - 2) cb = cbn - 2;   // past the operand's last column: duplicates feed C rows / columns never stored
+        src = opb + piece * plane + ((((long)(kb >> 1) * cbn + cb) << 9) + ((kb & 1) << 8));
+      } else {
+        int rb = rb0 + rg;
+        if (rb > rbmax) rb = rbmax;
+        src = opb + piece * plane + (((long)rb * a.kblocks + kb) << 9);
+      }
       const unsigned dst = lds_base + buf * X3_STAGE + (isA ? 0 : 3 * X3_TA) + piece * X3_TA + rg * 1024;
       // scalar base + per-lane 32-bit offset (the builtin expands to 64-bit per-lane addresses inside the loop);
       // M0 = LDS address of the chunk.  Nothing else in this kernel uses M0.
@@ -934,21 +949,37 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     for (int j = 0; j < X3_NT; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-  // fragment of MFMA tile t, piece p: row r of the tile, k half g; the XOR matches op_off's slot swizzle
+  // fragment of MFMA tile t, piece p: row r of the tile, k half g; the XOR matches op_off's slot swizzle.
+  // TL: LDS image per (operand, piece) = [16 column blocks][16 k rows][32 bytes]; lane = (group g4 of 16, l):
+  // column block 2t + g4 % 2 of the wave's eight, rows 8 (g4 / 2) + l / 4 (+ 4 for the second read), 8-byte
+  // column group l % 4; the row's swizzle bit is g4 / 2.
   const int sw = (r >> 3) & 1;
-  const int fa = (wm * X3_MT * 32 + r) * 32 + 16 * (g ^ sw);
-  const int fb = 3 * X3_TA + (wn * X3_NT * 32 + r) * 32 + 16 * (g ^ sw);
+  const int g4 = lane >> 4, l16 = lane & 15;
+  const int ftl = (g4 & 1) * 512 + (8 * (g4 >> 1) + (l16 >> 2)) * 32 + ((((l16 >> 1) & 1) ^ (g4 >> 1)) * 16) + (l16 & 1) * 8;
+  const int fa = TL ? wm * 4096 + ftl : (wm * X3_MT * 32 + r) * 32 + 16 * (g ^ sw);
+  const int fb = 3 * X3_TA + (TL ? wn * 4096 + ftl : (wn * X3_NT * 32 + r) * 32 + 16 * (g ^ sw));
+  auto read_frag = [&](const unsigned char* p) -> bf16x8 {
+    if (TL) {
+      typedef short s16x4 __attribute__((ext_vector_type(4)));
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 128));
+      return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    } else {
+      return *reinterpret_cast<const bf16x8*>(p);
+    }
+  };
   auto load_frags = [&](X3Frags& F, int buf) {
     const unsigned char* pa = smem3 + buf * X3_STAGE + fa;
     const unsigned char* pb = smem3 + buf * X3_STAGE + fb;
 #pragma unroll
     for (int t = 0; t < X3_MT; ++t)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) F.a[t][p] = *reinterpret_cast<const bf16x8*>(pa + p * X3_TA + t * 1024);
+      for (int p = 0; p < 3; ++p) F.a[t][p] = read_frag(pa + p * X3_TA + t * 1024);
 #pragma unroll
     for (int t = 0; t < X3_NT; ++t)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) F.b[t][p] = *reinterpret_cast<const bf16x8*>(pb + p * X3_TB + t * 1024);
+      for (int p = 0; p < 3; ++p) F.b[t][p] = read_frag(pb + p * X3_TB + t * 1024);
   };
   // six products per fp32-exact product, smallest terms first; consecutive MFMAs hit different accumulators
   auto mfmas = [&](const X3Frags& F) {
@@ -985,8 +1016,8 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
           for (int q = 4 * t; q < 4 * t + 4; ++q) {
             const int tt = (q % 12) / 3, p = q % 3;   // q < 12: A fragments, else B
-            if (q < 12) G.a[tt][p] = *reinterpret_cast<const bf16x8*>(pa + p * X3_TA + tt * 1024);
-            else G.b[tt][p] = *reinterpret_cast<const bf16x8*>(pb + p * X3_TB + tt * 1024);
+            if (q < 12) G.a[tt][p] = read_frag(pa + p * X3_TA + tt * 1024);
+            else G.b[tt][p] = read_frag(pb + p * X3_TB + tt * 1024);
           }
         }
 #pragma unroll
@@ -997,8 +1028,8 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         if (LOAD) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // four MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, TL ? 2 : 1, 0);   // the DS reads of one fragment
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);            // four MFMAs
           }
         }
       }
@@ -1064,8 +1095,8 @@ void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
   const bool x3 = !TN && a.Ap != nullptr;
   ProfScope ps(x3 ? OTGAN_PROF_WINO_GEMM_X3 : OTGAN_PROF_WINO_GEMM, x3 ? 6.0 * flop : flop, 0.0, s);
   if (x3) {
-    ensure_lds<wino_bgemm_x3_kernel<true>>(X3_LDS);
-    ensure_lds<wino_bgemm_x3_kernel<false>>(X3_LDS);
+    ensure_lds<wino_bgemm_x3_kernel<true, false>>(X3_LDS);
+    ensure_lds<wino_bgemm_x3_kernel<false, false>>(X3_LDS);
     BgArgs b = a;
     b.tiles_m = (a.M + X3_BM - 1) / X3_BM;
     b.tiles_n = (a.N + X3_BN - 1) / X3_BN;
@@ -1082,8 +1113,8 @@ void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
     if (a.seg_mode == 1) min_k = a.seg_len;
     else if (nsplit > 1) min_k = a.K - (nsplit - 1) * b.kt_per_split * X3_BK;
     const dim3 grid(b.tiles_m * b.tiles_n, nsplit, 16);
-    if (min_k >= 4 * X3_SK) hipLaunchKernelGGL(wino_bgemm_x3_kernel<true>, grid, dim3(X3_THREADS), X3_LDS, s, b);
-    else hipLaunchKernelGGL(wino_bgemm_x3_kernel<false>, grid, dim3(X3_THREADS), X3_LDS, s, b);
+    if (min_k >= 4 * X3_SK) hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, false>), grid, dim3(X3_THREADS), X3_LDS, s, b);
+    else hipLaunchKernelGGL((wino_bgemm_x3_kernel<false, false>), grid, dim3(X3_THREADS), X3_LDS, s, b);
     return;
   }
   ensure_lds<wino_bgemm_kernel<TN>>(lds);
@@ -1095,6 +1126,30 @@ void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
   else b.xmap = n_ok ? 2 : m_ok ? 1 : 0;
   const dim3 grid(a.tiles_m * a.tiles_n, nsplit, 16);
   hipLaunchKernelGGL((wino_bgemm_kernel<TN>), grid, dim3(Cfg::THREADS), lds, s, b);
+}
+
+// C[f][M][N] (slabs per K split) = sum_k A[f][k][m] B[f][k][n] with t-leading split-precision operands
+// (Ap: blocked [K rows][M cols], Bp: blocked [K rows][N cols]); K % 32 == 0, M % 32 == 0, N % 32 == 0.
+void launch_bgemm_tl(const BgArgs& a, int nsplit, hipStream_t s) {
+  double flop = 2.0 * 16.0 * (double)a.M * a.N * a.K;
+  if (a.seg_mode) flop *= 49.0 / 64.0;
+  ProfScope ps(OTGAN_PROF_WINO_GEMM_X3, 6.0 * flop, 0.0, s);
+  ensure_lds<wino_bgemm_x3_kernel<true, true>>(X3_LDS);
+  ensure_lds<wino_bgemm_x3_kernel<false, true>>(X3_LDS);
+  BgArgs b = a;
+  b.tiles_m = (a.M + X3_BM - 1) / X3_BM;
+  b.tiles_n = (a.N + X3_BN - 1) / X3_BN;
+  const bool m_ok = b.tiles_m % 8 == 0, n_ok = b.tiles_n % 8 == 0;
+  if (a.M >= a.N) b.xmap = m_ok ? 1 : n_ok ? 2 : 0;
+  else b.xmap = n_ok ? 2 : m_ok ? 1 : 0;
+  if (nsplit == 1) b.kt_per_split = a.K / X3_BK;
+  b.sAp = op_fstride(a.K, a.M); b.sBp = op_fstride(a.K, a.N);
+  b.pA = 16 * b.sAp; b.pB = 16 * b.sBp;
+  b.cbA = a.M / 16; b.cbB = a.N / 16;
+  const int min_k = nsplit > 1 ? a.K - (nsplit - 1) * b.kt_per_split * X3_BK : a.K;
+  const dim3 grid(b.tiles_m * b.tiles_n, nsplit, 16);
+  if (min_k >= 4 * X3_SK) hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, true>), grid, dim3(X3_THREADS), X3_LDS, s, b);
+  else hipLaunchKernelGGL((wino_bgemm_x3_kernel<false, true>), grid, dim3(X3_THREADS), X3_LDS, s, b);
 }
 
 inline int grid1(long n) { return (int)((n + 255) / 256); }
@@ -1115,6 +1170,15 @@ bool use_x3_wgrad() {
     return !(e && e[0] == '0');
   }();
   return on && use_x3();
+}
+// wgrad straight from the forward-layout operands (t-leading GEMM, no transposing producers) unless
+// OTGAN_WINO_WGRAD_TL=0
+bool use_x3_wgrad_tl() {
+  static const bool on = [] {
+    const char* e = getenv("OTGAN_WINO_WGRAD_TL");
+    return !(e && e[0] == '0');
+  }();
+  return on && use_x3_wgrad();
 }
 // floats of workspace that hold n operand elements (three bf16 planes = 6 bytes per element)
 inline size_t operand_floats(size_t n) { return (3 * n + 1) / 2; }
@@ -1175,7 +1239,8 @@ size_t wino_wgrad_ws_floats(const WinoGeo& g) {
   const size_t T = (size_t)wino_tiles(g);
   const size_t Tp = (T + 63) / 64 * 64;
   const int ns = std::max(wgrad_splits(g), x3_wgrad_splits(g.Cin, 4 * g.Cout, (long)Tp));
-  return operand_floats(op_elems(g.Cin, Tp)) + operand_floats(op_elems(4 * g.Cout, Tp)) + (size_t)ns * 16 * 4 * g.Cout * g.Cin;
+  return operand_floats(std::max(op_elems(g.Cin, Tp), op_elems(Tp, g.Cin))) +
+         operand_floats(std::max(op_elems(4 * g.Cout, Tp), op_elems(Tp, 4 * g.Cout))) + (size_t)ns * 16 * 4 * g.Cout * g.Cin;
 }
 
 int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stride, const float* bias, float* y,
@@ -1259,6 +1324,37 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
                hipStream_t s) {
   const long T = wino_tiles(g);
   const int N4 = 4 * g.Cout;
+  if (use_x3_wgrad_tl() && T % 32 == 0 && g.Cin % 32 == 0 && N4 % 32 == 0) {
+    // the operands of forward (V[tile][Cin]) and dgrad (dM[tile][4 Cout]) as they are: t-leading GEMM over the tiles
+    const int ns = x3_wgrad_splits(g.Cin, N4, T);
+    const size_t nV = op_elems(T, g.Cin), nM = op_elems(T, N4);
+    u16* VP = reinterpret_cast<u16*>(ws);
+    u16* MP = reinterpret_cast<u16*>(ws + operand_floats(nV));
+    float* slabs = ws + operand_floats(nV) + operand_floats(nM);
+    InArgs ia;
+    memset(&ia, 0, sizeof(ia));
+    ia.s2_skip = -1;
+    ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
+    ia.H = g.H; ia.W = g.W; ia.TH = g.H / 2; ia.TW = g.W / 2; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.P = VP;
+    hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cin / 4), 1, 1), dim3(256), 0, s, ia);
+    InArgs da;
+    memset(&da, 0, sizeof(da));
+    da.s2_skip = -1;
+    class_views(g, dy + g.y_coff, g.ldy, da.v);
+    for (int cls = 0; cls < 4; ++cls) da.coff[cls] = cls * g.Cout;
+    da.H = g.H; da.W = g.W; da.TH = g.H / 2; da.TW = g.W / 2; da.C = g.Cout; da.T = T; da.ldv = N4; da.P = MP;
+    hipLaunchKernelGGL(wino_outadj_kernel, dim3(op_grid(T, g.Cout / 4), 1, 4), dim3(256), 0, s, da);
+    BgArgs b;
+    memset(&b, 0, sizeof(b));
+    b.Ap = VP; b.Bp = MP;
+    b.C = slabs; b.M = g.Cin; b.N = N4; b.K = (int)T;
+    b.ldc = N4; b.sC = (long)g.Cin * N4; b.sSplit = 16L * g.Cin * N4;
+    b.kt_per_split = (int)((T / X3_BK + ns - 1) / ns);
+    launch_bgemm_tl(b, ns, s);
+    hipLaunchKernelGGL(wino_filter_adj_kernel, dim3(grid1(4L * g.Cin * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
+                       16L * g.Cin * N4, g.Cin, g.Cout, dweff, cls_stride);
+    return OTGAN_OK;
+  }
   if (use_x3_wgrad() && g.Cin % 16 == 0 && g.Cout % 16 == 0) {
     // operands tile-contiguous (transposing producers), NT GEMM on the bf16 pipe with K = tiles
     const long Tp = (T + 63) / 64 * 64;
@@ -1383,7 +1479,8 @@ size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g) {
   const size_t T = (size_t)wino_s2_tiles(g), K4 = 4 * (size_t)g.Ceff;
   const size_t Tp = (T + 63) / 64 * 64;
   const int ns = std::max(s2_wgrad_splits(g), x3_wgrad_splits((int)K4, g.Cout, (long)Tp));
-  return operand_floats(op_elems(K4, Tp)) + operand_floats(op_elems(g.Cout, Tp)) + (size_t)ns * 16 * K4 * g.Cout;
+  return operand_floats(std::max(op_elems(K4, Tp), op_elems(Tp, K4))) + operand_floats(std::max(op_elems(g.Cout, Tp), op_elems(Tp, g.Cout))) +
+         (size_t)ns * 16 * K4 * g.Cout;
 }
 
 int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float* bias, float* y, float* ws,
@@ -1470,6 +1567,33 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
   const long T = wino_s2_tiles(g);
   const int K4 = 4 * g.Ceff;
   const int OH = g.H / 2, OW = g.W / 2;
+  if (use_x3_wgrad_tl() && T % 32 == 0 && g.Ceff % 32 == 0 && g.Cout % 32 == 0) {
+    // the forward operand V[tile][4 Ceff] (absent (class, frequency) blocks unwritten: their rows of the result are
+    // masked by the adjoint filter transform) and the dgrad operand dM[tile][Cout]: t-leading GEMM over the tiles
+    const int ns = x3_wgrad_splits(K4, g.Cout, T);
+    const size_t nV = op_elems(T, K4), nM = op_elems(T, g.Cout);
+    u16* VP = reinterpret_cast<u16*>(ws);
+    u16* MP = reinterpret_cast<u16*>(ws + operand_floats(nV));
+    float* slabs = ws + operand_floats(nV) + operand_floats(nM);
+    s2_input_transform(g, x, nullptr, VP, s);
+    InArgs da;
+    memset(&da, 0, sizeof(da));
+    da.s2_skip = -1;
+    da.v[0].p = dy + g.y_coff; da.v[0].sn = (long)OH * OW * g.ldy; da.v[0].sh = (long)OW * g.ldy; da.v[0].sw = g.ldy;
+    da.H = OH; da.W = OW; da.TH = OH / 2; da.TW = OW / 2; da.C = g.Cout; da.T = T; da.ldv = g.Cout; da.P = MP;
+    hipLaunchKernelGGL(wino_outadj_kernel, dim3(op_grid(T, g.Cout / 4), 1, 1), dim3(256), 0, s, da);
+    BgArgs b;
+    memset(&b, 0, sizeof(b));
+    b.Ap = VP; b.Bp = MP;
+    b.C = slabs; b.M = K4; b.N = g.Cout; b.K = (int)T;
+    b.ldc = g.Cout; b.sC = (long)K4 * g.Cout; b.sSplit = 16L * K4 * g.Cout;
+    b.kt_per_split = (int)((T / X3_BK + ns - 1) / ns);
+    b.seg_mode = 3; b.seg_len = g.Ceff; b.seg_skip = 0;
+    launch_bgemm_tl(b, ns, s);
+    hipLaunchKernelGGL(wino_s2_filter_adj_kernel, dim3(grid1(4L * g.Ceff * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
+                       16L * K4 * g.Cout, g.Ceff, g.Cout, dw);
+    return OTGAN_OK;
+  }
   if (use_x3_wgrad() && g.C % 16 == 0 && g.Cout % 16 == 0) {
     const long Tp = (T + 63) / 64 * 64;
     const int ns = x3_wgrad_splits(K4, g.Cout, Tp);

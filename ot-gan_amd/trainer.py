@@ -9,6 +9,22 @@ from . import parallel
 from .utils import matching, nn
 
 
+class _frozen:
+    """Context manager: the given leaf tensors do not require grad inside the block."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+
+    def __enter__(self):
+        for p in self.params:
+            p.requires_grad_(False)
+
+    def __exit__(self, *exc):
+        for p in self.params:
+            p.requires_grad_(True)
+        return False
+
+
 class OTGAN:
     """State of one training run.  `args` carries the reference's flags (train.py:14-33)
     plus: image_size, matching_scope ('global' = one OT problem set over all ranks, the
@@ -146,7 +162,11 @@ class OTGAN:
             pending = (parallel.all_gather_rows_async(f_dat)
                        if (self.scope == "global" and self.world > 1) else None)
             x_gen = self.generator(batch_size=self.nb, device=self.device, **gkw)
-            f_gen = self.discriminator(x_gen, **self.model_opts)
+            # only the generator's variables are differentiated in this step (train.py:112): run the critic with
+            # its variables frozen, so that its layers skip their weight gradients (autograd's needs_input_grad
+            # follows requires_grad, not the `inputs` list of autograd.grad) and only propagate d/dx
+            with _frozen(self.disc_params):
+                f_gen = self.discriminator(x_gen, **self.model_opts)
             g_gen, _g_dat, dist, ent = self._match(f_gen.detach(), f_dat, pending)
             grads = torch.autograd.grad(f_gen, self.gen_params, g_gen)                            # train.py:112
             grads = parallel.allreduce_sum_(list(grads))
