@@ -65,8 +65,9 @@ size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which);
  * planes (hi + mid + lo): six MFMAs per fp32-exact product, fp32 accumulation -- results are at
  * least as accurate as the fp32 MFMA chain of the direct path.
  * Environment switches (debugging / A-B measurements): OTGAN_DISABLE_WINOGRAD=1,
- * OTGAN_WINO_FP32=1 (Winograd GEMMs on the fp32 engine), OTGAN_WINO_WGRAD_X3=0,
- * OTGAN_DISABLE_DENSE16=1, OTGAN_DENSE16_V1=1.
+ * OTGAN_WINO_FP32=1 (Winograd GEMMs on the fp32 engine), OTGAN_WINO_WGRAD_X3=0 (weight-gradient GEMMs on
+ * the fp32 engine), OTGAN_WINO_WGRAD_TL=0 (weight-gradient operands from the transposing producers instead
+ * of the forward-layout ones), OTGAN_DISABLE_DENSE16=1, OTGAN_DENSE16_V1=1.
  */
 
 /*
