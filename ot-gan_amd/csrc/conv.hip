@@ -865,42 +865,47 @@ __global__ __launch_bounds__(256) void conv_fewout_kernel(GatherA g, Taps taps, 
 // Tile variant of the few-output kernel for stride-1 layers (the RGB-out convolution of both generators,
 // the input gradient of the RGB-in convolution): the kernel above re-reads the source once per tap
 // (25x for a 5x5 filter, L2-bound at ~10 TB/s).  Here a block owns TR rows x W columns of one image
-// (256 pixels, thread = pixel), stages the tile plus halo for 32 channels at a time in LDS -- sign /
-// activation applied once, at fill time -- and every tap reads its shifted pixel as eight ds_read_b128
-// (pixel stride 9 slots of 16 bytes: conflict-free); the weights of a (tap, channel chunk) are
-// wave-uniform scalar loads.
+// (256 pixels, 128 threads x two vertically adjacent pixels), stages the tile plus halo for 32 channels at a
+// time in LDS -- sign / activation applied once, at fill time -- and every tap reads its shifted pixels as
+// eight ds_read_b128 each (pixel stride 9 slots of 16 bytes: conflict-free).  The chunk's weights sit in LDS
+// too and are read as broadcasts, one read serving both pixels (scalar loads left the loop waiting on the
+// scalar cache for most of its time: SQ_WAIT_ANY 79 %).
 struct FewTileArgs {
   int TR, LH, LW, dh0, dw0;   // tile rows; LDS tile = LH x LW pixels starting at (r0 + dh0, dw0)
   unsigned lw_magic;          // ceil(2^20 / LW)
 };
 
+constexpr int kFewTileThreads = 128;
 template <int ACT, int NJ>
-__global__ __launch_bounds__(256) void conv_fewout_tile_kernel(GatherA g, Taps taps, FewOutArgs a, FewTileArgs ft) {
-  extern __shared__ __attribute__((aligned(16))) float4 s_fx[];   // [LH * LW][9]
+__global__ __launch_bounds__(kFewTileThreads) void conv_fewout_tile_kernel(GatherA g, Taps taps, FewOutArgs a, FewTileArgs ft) {
+  extern __shared__ __attribute__((aligned(16))) float4 s_fx[];   // [LH * LW][9] source tile, then [taps][NJ][8] weights
   const int tid = threadIdx.x;
   const int W = 1 << g.logGW, H = 1 << g.logGH;
   const int tiles_per_img = H / ft.TR;
   const int n = blockIdx.x / tiles_per_img, r0 = (blockIdx.x - n * tiles_per_img) * ft.TR;
-  const int pr = tid >> g.logGW, pc = tid & (W - 1);
+  // a thread owns the two vertically adjacent pixels (2 pr2, pc), (2 pr2 + 1, pc): one weight read serves both
+  const int pr2 = tid >> g.logGW, pc = tid & (W - 1);
   const long img = (long)n * H * W;
-  // two partial sums per output (even / odd channel pairs): the inner product is written as packed FMAs
-  // (v_pk_fma_f32 with the weight pair in SGPRs), two per output and float4
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  f32x2 acc2[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) acc2[j] = f32x2{0.f, 0.f};
   const int npix = ft.LH * ft.LW;
+  float4* s_w = s_fx + npix * 9;
+  // two partial sums per output (even / odd channel pairs): the inner product is written as packed FMAs
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 acc2[2][NJ];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc2[p][j] = f32x2{0.f, 0.f};
   for (int d0 = 0; d0 < g.Ck; d0 += 32) {
     __syncthreads();   // the previous chunk's tile is fully consumed
     // all loads of a batch in flight before the first LDS store (a load-store loop exposes one memory round trip
     // per element); p / LW through a multiply-shift (exact for p < 4096, LW <= 68)
     constexpr int kBatch = 9;
-    for (int i0 = tid; i0 < npix * 8; i0 += 256 * kBatch) {
+    for (int i0 = tid; i0 < npix * 8; i0 += kFewTileThreads * kBatch) {
       float4 v[kBatch];
       float sg[kBatch];
 #pragma unroll
       for (int b = 0; b < kBatch; ++b) {
-        const int i = i0 + b * 256;
+        const int i = i0 + b * kFewTileThreads;
         const int q = i & 7, p = i >> 3;
         const int lr = (int)(((unsigned)p * ft.lw_magic) >> 20), lc = p - lr * ft.LW;
         const int ih = r0 + lr + ft.dh0, iw = lc + ft.dw0;
@@ -915,7 +920,7 @@ __global__ __launch_bounds__(256) void conv_fewout_tile_kernel(GatherA g, Taps t
       }
 #pragma unroll
       for (int b = 0; b < kBatch; ++b) {
-        const int i = i0 + b * 256;
+        const int i = i0 + b * kFewTileThreads;
         if (i < npix * 8) {
           float4 o;
           o.x = act_apply<ACT>(sg[b] * v[b].x);
@@ -926,47 +931,73 @@ __global__ __launch_bounds__(256) void conv_fewout_tile_kernel(GatherA g, Taps t
         }
       }
     }
+    // the chunk's weights: s_w[(t * NJ + j) * 8 + q] = w[tap t][output j][d0 + 4q .. +3] (zero past the last channel)
+    for (int i = tid; i < taps.n * NJ * 8; i += kFewTileThreads) {
+      const int q = i & 7, tj = i >> 3;
+      const int t = tj / NJ, j = tj - t * NJ;
+      float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (d0 + 4 * q < g.Ck && j < a.J) wv = *reinterpret_cast<const float4*>(a.w + taps.boff[t] + j * a.sJ + d0 + 4 * q);
+      s_w[i] = wv;
+    }
     __syncthreads();
-    const int nq = (g.Ck - d0) >= 32 ? 8 : (g.Ck - d0) >> 2;
-    for (int t = 0; t < taps.n; ++t) {
+    // Software pipeline over half taps (four float4 = 16 channels each): the LDS reads of the next half are issued
+    // before the FMAs of the current one, and a compiler barrier keeps them there -- left alone, the scheduler sinks
+    // every read next to its use (read, wait, four FMAs), and with one wave per SIMD resident (72 KiB of LDS per
+    // block) nothing else hides the LDS round trip.
+    struct Half {
+      float4 d0[4], d1[4], w[NJ][4];
+    };
+    auto load_half = [&](Half& h, int t, int hq) {
       const int dhw = taps.dhw[t];
       const int dh = dhw >> 16, dw = sx16(dhw);
-      const float4* src = s_fx + ((pr + dh - ft.dh0) * ft.LW + (pc + dw - ft.dw0)) * 9;
-      const float* __restrict__ wt = a.w + taps.boff[t] + d0;
-      if (nq == 8) {
+      const float4* src0 = s_fx + ((2 * pr2 + dh - ft.dh0) * ft.LW + (pc + dw - ft.dw0)) * 9 + 4 * hq;
+      const float4* src1 = src0 + ft.LW * 9;
+      const float4* wt = s_w + t * NJ * 8 + 4 * hq;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float4 v = src[q];
-          const f32x2 v01 = {v.x, v.y}, v23 = {v.z, v.w};
+      for (int q = 0; q < 4; ++q) {
+        h.d0[q] = src0[q];
+        h.d1[q] = src1[q];
+      }
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            const f32x2* wj = reinterpret_cast<const f32x2*>(wt + j * a.sJ + 4 * q);
-            acc2[j] = __builtin_elementwise_fma(v01, wj[0], acc2[j]);
-            acc2[j] = __builtin_elementwise_fma(v23, wj[1], acc2[j]);
-          }
-        }
-      } else {
-        for (int q = 0; q < nq; ++q) {
-          const float4 v = src[q];
-          const f32x2 v01 = {v.x, v.y}, v23 = {v.z, v.w};
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            const f32x2* wj = reinterpret_cast<const f32x2*>(wt + j * a.sJ + 4 * q);
-            acc2[j] = __builtin_elementwise_fma(v01, wj[0], acc2[j]);
-            acc2[j] = __builtin_elementwise_fma(v23, wj[1], acc2[j]);
-          }
+        for (int q = 0; q < 4; ++q) h.w[j][q] = wt[j * 8 + q];   // the same address in every lane: LDS broadcast
+      asm volatile("" ::: "memory");
+    };
+    auto fma_half = [&](const Half& h) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x2 a01 = {h.d0[q].x, h.d0[q].y}, a23 = {h.d0[q].z, h.d0[q].w};
+        const f32x2 b01 = {h.d1[q].x, h.d1[q].y}, b23 = {h.d1[q].z, h.d1[q].w};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const f32x2 w01 = {h.w[j][q].x, h.w[j][q].y}, w23 = {h.w[j][q].z, h.w[j][q].w};
+          acc2[0][j] = __builtin_elementwise_fma(a01, w01, acc2[0][j]);
+          acc2[0][j] = __builtin_elementwise_fma(a23, w23, acc2[0][j]);
+          acc2[1][j] = __builtin_elementwise_fma(b01, w01, acc2[1][j]);
+          acc2[1][j] = __builtin_elementwise_fma(b23, w23, acc2[1][j]);
         }
       }
+    };
+    Half h0, h1;
+    load_half(h0, 0, 0);
+    for (int t = 0; t < taps.n; ++t) {
+      load_half(h1, t, 1);
+      fma_half(h0);
+      load_half(h0, t + 1 < taps.n ? t + 1 : t, 0);   // past the last tap: a redundant reload, never used
+      fma_half(h1);
     }
   }
-  float acc[NJ];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) acc[j] = acc2[j][0] + acc2[j][1];
-  float* dst = a.out + (img + (long)(r0 + pr) * W + pc) * a.ldo + a.coff;
+  for (int p = 0; p < 2; ++p) {
+    float* dst = a.out + (img + (long)(r0 + 2 * pr2 + p) * W + pc) * a.ldo + a.coff;
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const float v = acc[j] + (a.bias ? a.bias[j] : 0.f);
-    dst[j] = a.accumulate ? dst[j] + v : v;
+    for (int j = 0; j < NJ; ++j) {
+      if (j < a.J) {
+        const float v = acc2[p][j][0] + acc2[p][j][1] + (a.bias ? a.bias[j] : 0.f);
+        dst[j] = a.accumulate ? dst[j] + v : v;
+      }
+    }
   }
 }
 
@@ -989,19 +1020,21 @@ static bool launch_fewout_tile(const GatherA& ga, const Taps& t, const FewOutArg
   ft.dh0 = dh0; ft.dw0 = dw0;
   ft.LH = ft.TR + dh1 - dh0; ft.LW = W + dw1 - dw0;
   ft.lw_magic = ((1u << 20) + ft.LW - 1) / ft.LW;
-  const size_t lds = sizeof(float4) * 9 * (size_t)ft.LH * ft.LW;
+  if (ft.TR % 2) return false;
+  const int nj = fa.J == 3 ? 3 : 4;
+  const size_t lds = sizeof(float4) * (9 * (size_t)ft.LH * ft.LW + (size_t)t.n * nj * 8);
   if (lds > 80 * 1024) return false;
   const dim3 grid(ga.Mtot / 256);
   if (fa.J == 3) {
     static bool once3 = (hipFuncSetAttribute((const void*)conv_fewout_tile_kernel<ACT, 3>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), true);
     (void)once3;
-    hipLaunchKernelGGL((conv_fewout_tile_kernel<ACT, 3>), grid, dim3(256), lds, s, ga, t, fa, ft);
+    hipLaunchKernelGGL((conv_fewout_tile_kernel<ACT, 3>), grid, dim3(kFewTileThreads), lds, s, ga, t, fa, ft);
   } else {
     static bool once4 = (hipFuncSetAttribute((const void*)conv_fewout_tile_kernel<ACT, 4>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), true);
     (void)once4;
-    hipLaunchKernelGGL((conv_fewout_tile_kernel<ACT, 4>), grid, dim3(256), lds, s, ga, t, fa, ft);
+    hipLaunchKernelGGL((conv_fewout_tile_kernel<ACT, 4>), grid, dim3(kFewTileThreads), lds, s, ga, t, fa, ft);
   }
   return true;
 }
