@@ -55,6 +55,11 @@ CONV_CASES = [
     ("wino_s2_relu", 3, 4, 4, (64,), 132, 5, 2, False, "relu"),
     ("wino_s2_split_k", 24, 16, 16, (32,), 32, 5, 2, False, "crelu"),
     ("list_s2_k5_generic", 2, 8, 8, (16, 16), 32, 5, 2, False, "crelu"),
+    # weight gradient from forward-layout operands (t-leading GEMM): 32 tiles = two K stages (unpipelined kernel),
+    # and a ragged last K split
+    ("wino_s2_tl_short", 2, 16, 16, (32,), 32, 5, 2, False, None),
+    ("wino_tl_short", 2, 8, 8, (32,), 32, 5, 1, True, None),
+    ("wino_s2_tl_crelu", 10, 16, 16, (32,), 64, 5, 2, False, "crelu"),
     # DenseNet growth layers (3x3 -> 16 channels): the LDS-free dense16 kernels
     ("dense16_list", 2, 8, 8, (32, 16, 16), 16, 3, 1, False, "crelu"),
     ("dense16_tail", 3, 8, 8, (24, 16), 16, 3, 1, False, "crelu"),
