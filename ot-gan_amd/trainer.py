@@ -71,6 +71,9 @@ class OTGAN:
         if args.optimizer not in mk:
             raise ValueError("unsupported optimizer")
         kw = {"mom1": 0.5} if args.optimizer == "nesterov" else {"mom1": 0.5, "mom2": 0.999}
+        # more than one rank: the gradient all-reduce runs bucket by bucket underneath the backward pass
+        self.disc_buckets = parallel.GradBuckets(self.disc_params) if self.world > 1 else None
+        self.gen_buckets = parallel.GradBuckets(self.gen_params) if self.world > 1 else None
         self.gen_optimizer = mk[args.optimizer](self.gen_params, **kw)          # train.py:142
         self.disc_optimizer = mk[args.optimizer](self.disc_params, **kw)        # train.py:143
         self.step_counter = 0
@@ -149,8 +152,10 @@ class OTGAN:
             f_all = self.discriminator(torch.cat([x_data, x_gen], 0), **self.model_opts)
             f_dat, f_gen = f_all[:self.nb], f_all[self.nb:]
             g_gen, g_dat, dist, ent = self._match(f_gen.detach(), f_dat.detach())
+            if self.disc_buckets is not None:
+                self.disc_buckets.arm()
             grads = torch.autograd.grad(f_all, self.disc_params, torch.cat([g_dat, g_gen], 0))   # train.py:127-128
-            grads = parallel.allreduce_sum_(list(grads))                                          # train.py:134-139
+            grads = self.disc_buckets.finish() if self.disc_buckets is not None else list(grads)  # train.py:134-139
             if apply_updates:
                 self.disc_optimizer(grads, lr=-a.learning_rate_disc)                              # train.py:143
         else:
@@ -168,8 +173,10 @@ class OTGAN:
             with _frozen(self.disc_params):
                 f_gen = self.discriminator(x_gen, **self.model_opts)
             g_gen, _g_dat, dist, ent = self._match(f_gen.detach(), f_dat, pending)
+            if self.gen_buckets is not None:
+                self.gen_buckets.arm()
             grads = torch.autograd.grad(f_gen, self.gen_params, g_gen)                            # train.py:112
-            grads = parallel.allreduce_sum_(list(grads))
+            grads = self.gen_buckets.finish() if self.gen_buckets is not None else list(grads)
             if apply_updates:
                 self.gen_optimizer(grads, lr=a.learning_rate_gen)                                 # train.py:142
                 self.maintain_averages()                                                          # train.py:223

@@ -51,6 +51,34 @@ def _worker(rank, world, port, out):
     g1, g2 = parallel.allreduce_sum_([g1, g2])
     tot = sum(range(1, world + 1))
     assert torch.all(g1 == tot) and torch.equal(g2, torch.arange(5, dtype=torch.float32) * tot)
+    # 4. bucketed all-reduce underneath backward == SUM over ranks of the plain gradients; variables that are
+    #    evaluated but not differentiated (frozen) and un-armed passes leave the buckets alone
+    torch.manual_seed(7)
+    ws = [torch.randn(5, 4, requires_grad=True), torch.randn(4, requires_grad=True),
+          torch.randn(4, 3, requires_grad=True), torch.randn(3, requires_grad=True)]
+    x = torch.randn(6, 5) * (rank + 1)                      # rank-dependent data, same weights
+
+    def net(inp):
+        return (torch.tanh(inp @ ws[0] + ws[1]) @ ws[2] + ws[3]).pow(2).sum()
+
+    plain = torch.autograd.grad(net(x), ws)
+    ref = parallel.allreduce_sum_([g.clone() for g in plain])
+    gb = parallel.GradBuckets(ws, nbuckets=3)
+    assert len(gb.ranges) >= 2 and sum(gb.count) == len(ws)
+    torch.autograd.grad(net(x), ws)                         # not armed: hooks must not touch the buckets
+    assert float(gb.flat.abs().sum()) == 0.0
+    for _ in range(2):                                      # re-armed every step
+        gb.arm()
+        torch.autograd.grad(net(x), ws)
+        got = gb.finish()
+        for a_, b_ in zip(got, ref):
+            np.testing.assert_allclose(a_.numpy(), b_.numpy(), rtol=1e-6, atol=1e-7)
+    gb.arm()
+    ws[3].requires_grad_(False)
+    torch.autograd.grad(net(x), ws[:3])
+    ws[3].requires_grad_(True)
+    with pytest.raises(RuntimeError):
+        gb.finish()                                         # a variable without gradient is an error, not a hang
     parallel.barrier()
     out.put((rank, True))
     dist.destroy_process_group()
