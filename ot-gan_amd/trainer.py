@@ -2,6 +2,7 @@
 wired on the HIP kernels: generator / critic forward, mini-batch Sinkhorn matching, gradient
 injection (`grad_ys`), cross-rank gradient sum, optimiser and EMA updates."""
 import importlib
+import os
 
 import torch
 
@@ -72,8 +73,10 @@ class OTGAN:
             raise ValueError("unsupported optimizer")
         kw = {"mom1": 0.5} if args.optimizer == "nesterov" else {"mom1": 0.5, "mom2": 0.999}
         # more than one rank: the gradient all-reduce runs bucket by bucket underneath the backward pass
-        self.disc_buckets = parallel.GradBuckets(self.disc_params) if self.world > 1 else None
-        self.gen_buckets = parallel.GradBuckets(self.gen_params) if self.world > 1 else None
+        # (OTGAN_GRAD_OVERLAP=0: one all-reduce after the backward pass instead)
+        overlap = self.world > 1 and os.environ.get("OTGAN_GRAD_OVERLAP", "1") != "0"
+        self.disc_buckets = parallel.GradBuckets(self.disc_params) if overlap else None
+        self.gen_buckets = parallel.GradBuckets(self.gen_params) if overlap else None
         self.gen_optimizer = mk[args.optimizer](self.gen_params, **kw)          # train.py:142
         self.disc_optimizer = mk[args.optimizer](self.disc_params, **kw)        # train.py:143
         self.step_counter = 0
@@ -155,7 +158,8 @@ class OTGAN:
             if self.disc_buckets is not None:
                 self.disc_buckets.arm()
             grads = torch.autograd.grad(f_all, self.disc_params, torch.cat([g_dat, g_gen], 0))   # train.py:127-128
-            grads = self.disc_buckets.finish() if self.disc_buckets is not None else list(grads)  # train.py:134-139
+            grads = (self.disc_buckets.finish() if self.disc_buckets is not None
+                     else parallel.allreduce_sum_(list(grads)))                                   # train.py:134-139
             if apply_updates:
                 self.disc_optimizer(grads, lr=-a.learning_rate_disc)                              # train.py:143
         else:
@@ -176,7 +180,8 @@ class OTGAN:
             if self.gen_buckets is not None:
                 self.gen_buckets.arm()
             grads = torch.autograd.grad(f_gen, self.gen_params, g_gen)                            # train.py:112
-            grads = self.gen_buckets.finish() if self.gen_buckets is not None else list(grads)
+            grads = (self.gen_buckets.finish() if self.gen_buckets is not None
+                     else parallel.allreduce_sum_(list(grads)))
             if apply_updates:
                 self.gen_optimizer(grads, lr=a.learning_rate_gen)                                 # train.py:142
                 self.maintain_averages()                                                          # train.py:223
