@@ -98,6 +98,28 @@ int otgan_conv2d_dgrad_f32(const otgan_conv_desc* d, const float* dy, const floa
                            const float* x, const int32_t* inv, float* dx, int lddx,
                            int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * Winograd-domain filters made once per weight update.  The layers that run as Winograd GEMMs derive
+ * their filter operand from the weights inside every forward / dgrad call; a caller that knows the
+ * weights are unchanged (the critic during the generator steps: five steps out of six) can derive it
+ * once into its own buffer and pass it to the _pf variants.
+ *   otgan_conv2d_filter_bytes(d, which)   which = 0 forward, 1 dgrad; 0: the layer / pass has none
+ *   otgan_conv2d_prepare_filters_f32      `w` = what the pass itself takes (wT for forward, w for dgrad;
+ *                                         folded layers: weffT / weff)
+ *   otgan_conv2d_fwd_pf_f32 / otgan_conv2d_dgrad_pf_f32: as the plain calls; `filters` may be NULL
+ *                                         (then identical to them) and is ignored by the non-Winograd paths.
+ * The buffer's content is tied to the descriptor and to the OTGAN_WINO_* switches of the process.
+ */
+size_t otgan_conv2d_filter_bytes(const otgan_conv_desc* d, int which);
+int otgan_conv2d_prepare_filters_f32(const otgan_conv_desc* d, int which, const float* w, void* filters,
+                                     size_t filter_bytes, void* stream);
+int otgan_conv2d_fwd_pf_f32(const otgan_conv_desc* d, const float* x, const int32_t* cmap,
+                            const float* wT, const void* filters, const float* bias, float* y,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int otgan_conv2d_dgrad_pf_f32(const otgan_conv_desc* d, const float* dy, const float* w, const void* filters,
+                              const float* x, const int32_t* inv, float* dx, int lddx,
+                              int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 /* dw[KH][KW][Cin_eff][Cout] = sum over pixels of preact(x)^T . dy  (overwrites dw). */
 int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32_t* cmap,
                            const float* dy, float* dw, void* workspace, size_t workspace_bytes,

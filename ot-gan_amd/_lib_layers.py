@@ -24,6 +24,11 @@ SIGNATURES = {
     "otgan_conv2d_dgrad_f32": (c_int, [P_DESC, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp,
                                        c_size_t, c_fp]),
     "otgan_conv2d_wgrad_f32": (c_int, [P_DESC, c_fp, c_fp, c_fp, c_fp, c_fp, c_size_t, c_fp]),
+    "otgan_conv2d_filter_bytes": (c_size_t, [P_DESC, c_int]),
+    "otgan_conv2d_prepare_filters_f32": (c_int, [P_DESC, c_int, c_fp, c_fp, c_size_t, c_fp]),
+    "otgan_conv2d_fwd_pf_f32": (c_int, [P_DESC, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_size_t, c_fp]),
+    "otgan_conv2d_dgrad_pf_f32": (c_int, [P_DESC, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp,
+                                          c_size_t, c_fp]),
     "otgan_weightnorm_fwd_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp]),
     "otgan_weightnorm_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp]),
     "otgan_colsum_f32": (c_int, [c_fp, c_long, c_int, c_long, c_fp, c_fp, c_fp]),

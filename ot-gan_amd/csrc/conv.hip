@@ -1758,9 +1758,57 @@ size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which) {
   return s2 > 256 ? s2 : 256;
 }
 
+size_t otgan_conv2d_filter_bytes(const otgan_conv_desc* d, int which) {
+  Geo g;
+  if (make_geo(d, &g) != OTGAN_OK || (which != 0 && which != 1)) return 0;
+  if (wino_s2_ok(d, g)) return sizeof(float) * wino_s2_filter_floats(wino_s2_geo(d, g), which);
+  if (wino_ok(d, g)) return sizeof(float) * wino_filter_floats(wino_geo(d), which);
+  return 0;
+}
+
+int otgan_conv2d_prepare_filters_f32(const otgan_conv_desc* d, int which, const float* w, void* filters,
+                                     size_t filter_bytes, void* stream) {
+  Geo g;
+  int rc = make_geo(d, &g);
+  if (rc) return rc;
+  const size_t need = otgan_conv2d_filter_bytes(d, which);
+  OTGAN_CHECK_ARG(need > 0, "this layer / pass has no Winograd-domain filters");
+  OTGAN_CHECK_ARG(w && filters && aligned16(w) && aligned16(filters), "null or misaligned pointer");
+  if (filter_bytes < need) {
+    otgan_set_error("conv2d filter buffer too small: need %zu, got %zu", need, filter_bytes);
+    return OTGAN_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (wino_s2_ok(d, g)) {
+    rc = wino_s2_prepare_filters(wino_s2_geo(d, g), which, w, (float*)filters, s);
+  } else {
+    const FoldTab f = make_fold(d, g);
+    rc = wino_prepare_filters(wino_geo(d), which, w, f.woff[1] - f.woff[0], (float*)filters, s);
+  }
+  OTGAN_CHECK_LAUNCH("conv2d prepare filters");
+  return rc;
+}
+
+static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32_t* cmap, const float* wT,
+                           const float* filters, const float* bias, float* y, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 int otgan_conv2d_fwd_f32(const otgan_conv_desc* d, const float* x, const int32_t* cmap,
                          const float* wT, const float* bias, float* y, void* workspace,
                          size_t workspace_bytes, void* stream) {
+  return conv2d_fwd_impl(d, x, cmap, wT, nullptr, bias, y, workspace, workspace_bytes, stream);
+}
+
+int otgan_conv2d_fwd_pf_f32(const otgan_conv_desc* d, const float* x, const int32_t* cmap,
+                            const float* wT, const void* filters, const float* bias, float* y,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  OTGAN_CHECK_ARG(filters == nullptr || aligned16(filters), "misaligned filter buffer");
+  return conv2d_fwd_impl(d, x, cmap, wT, (const float*)filters, bias, y, workspace, workspace_bytes, stream);
+}
+
+static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32_t* cmap, const float* wT,
+                           const float* filters, const float* bias, float* y, void* workspace,
+                           size_t workspace_bytes, void* stream) {
   Geo g;
   int rc = make_geo(d, &g);
   if (rc) return rc;
@@ -1784,7 +1832,7 @@ int otgan_conv2d_fwd_f32(const otgan_conv_desc* d, const float* x, const int32_t
       aligned16(workspace) && workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 0)) {
     const WinoS2Geo w = wino_s2_geo(d, g);
     ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * 49.0 * (double)wino_s2_tiles(w) * g.Ceff * d->Cout, 0.0, s);
-    rc = wino_s2_fwd(w, x, wT, bias, y, (float*)workspace, s);
+    rc = wino_s2_fwd(w, x, wT, bias, y, (float*)workspace, s, filters);
     OTGAN_CHECK_LAUNCH("conv2d fwd (winograd, stride 2)");
     return rc;
   }
@@ -1800,7 +1848,7 @@ int otgan_conv2d_fwd_f32(const otgan_conv_desc* d, const float* x, const int32_t
     const WinoGeo w = wino_geo(d);
     // executed FLOP: 16 GEMMs of tiles x 4*Cout x Cin
     ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * 16.0 * (double)wino_tiles(w) * 4.0 * d->Cout * d->C, 0.0, s);
-    rc = wino_fwd(w, x, wT, f.woff[1] - f.woff[0], bias, y, (float*)workspace, s);
+    rc = wino_fwd(w, x, wT, f.woff[1] - f.woff[0], bias, y, (float*)workspace, s, filters);
     OTGAN_CHECK_LAUNCH("conv2d fwd (winograd)");
     return rc;
   }
@@ -1888,9 +1936,27 @@ int otgan_conv2d_fwd_f32(const otgan_conv_desc* d, const float* x, const int32_t
   return OTGAN_OK;
 }
 
+static int conv2d_dgrad_impl(const otgan_conv_desc* d, const float* dy, const float* w, const float* filters,
+                             const float* x, const int32_t* inv, float* dx, int lddx, int accumulate,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 int otgan_conv2d_dgrad_f32(const otgan_conv_desc* d, const float* dy, const float* w,
                            const float* x, const int32_t* inv, float* dx, int lddx,
                            int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  return conv2d_dgrad_impl(d, dy, w, nullptr, x, inv, dx, lddx, accumulate, workspace, workspace_bytes, stream);
+}
+
+int otgan_conv2d_dgrad_pf_f32(const otgan_conv_desc* d, const float* dy, const float* w, const void* filters,
+                              const float* x, const int32_t* inv, float* dx, int lddx,
+                              int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  OTGAN_CHECK_ARG(filters == nullptr || aligned16(filters), "misaligned filter buffer");
+  return conv2d_dgrad_impl(d, dy, w, (const float*)filters, x, inv, dx, lddx, accumulate, workspace, workspace_bytes,
+                           stream);
+}
+
+static int conv2d_dgrad_impl(const otgan_conv_desc* d, const float* dy, const float* w, const float* filters,
+                             const float* x, const int32_t* inv, float* dx, int lddx, int accumulate,
+                             void* workspace, size_t workspace_bytes, void* stream) {
   Geo g;
   int rc = make_geo(d, &g);
   if (rc) return rc;
@@ -1971,7 +2037,7 @@ int otgan_conv2d_dgrad_f32(const otgan_conv_desc* d, const float* dy, const floa
       aligned16(x) && aligned16(workspace) && workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 1)) {
     const WinoS2Geo wg = wino_s2_geo(d, g);
     ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * 49.0 * (double)wino_s2_tiles(wg) * g.Ceff * d->Cout, 0.0, s);
-    rc = wino_s2_dgrad(wg, dy, w, x, dx, lddx, accumulate, (float*)workspace, s);
+    rc = wino_s2_dgrad(wg, dy, w, x, dx, lddx, accumulate, (float*)workspace, s, filters);
     OTGAN_CHECK_LAUNCH("conv2d dgrad (winograd, stride 2)");
     return rc;
   }
@@ -1986,7 +2052,7 @@ int otgan_conv2d_dgrad_f32(const otgan_conv_desc* d, const float* dy, const floa
     const FoldTab f = make_fold(d, g);
     const WinoGeo wg = wino_geo(d);
     ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * 16.0 * (double)wino_tiles(wg) * 4.0 * d->Cout * d->C, 0.0, s);
-    rc = wino_dgrad(wg, dy, w, f.woff[1] - f.woff[0], dx, lddx, accumulate, (float*)workspace, s);
+    rc = wino_dgrad(wg, dy, w, f.woff[1] - f.woff[0], dx, lddx, accumulate, (float*)workspace, s, filters);
     OTGAN_CHECK_LAUNCH("conv2d dgrad (winograd)");
     return rc;
   }

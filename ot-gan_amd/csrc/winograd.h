@@ -26,11 +26,15 @@ size_t wino_dgrad_ws_floats(const WinoGeo& g);
 size_t wino_wgrad_ws_floats(const WinoGeo& g);
 
 // y = folded conv of x with the class weights given as weffT[cls][Cout][9*Cin] (class stride cls_stride)
+// `prep` (optional): the Winograd-domain filters of this pass, made once by wino_prepare_filters() and reused while
+// the weights do not change (wino_filter_floats() floats); null: derived from the weights into the workspace
+size_t wino_filter_floats(const WinoGeo& g, int which);   // which: 0 forward (from weffT), 1 dgrad (from weff)
+int wino_prepare_filters(const WinoGeo& g, int which, const float* w, long cls_stride, float* out, hipStream_t s);
 int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stride, const float* bias, float* y,
-             float* ws, hipStream_t s);
+             float* ws, hipStream_t s, const float* prep = nullptr);
 // dx[N,H,W,lddx] (+)= gradient w.r.t. the small input; weff[cls][9][Cin][Cout]
 int wino_dgrad(const WinoGeo& g, const float* dy, const float* weff, long cls_stride, float* dx, int lddx,
-               int accumulate, float* ws, hipStream_t s);
+               int accumulate, float* ws, hipStream_t s, const float* prep = nullptr);
 // dweff[cls][9][Cin][Cout] (class stride cls_stride) = folded weight gradient
 int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, long cls_stride, float* ws,
                hipStream_t s);
@@ -48,8 +52,10 @@ size_t wino_s2_fwd_ws_floats(const WinoS2Geo& g);
 size_t wino_s2_dgrad_ws_floats(const WinoS2Geo& g);
 size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g);
 // wT: [Cout][25*Ceff];  w: HWIO [25][Ceff][Cout];  single-tensor inputs only (default channel map)
+size_t wino_s2_filter_floats(const WinoS2Geo& g, int which);   // which: 0 forward (from wT), 1 dgrad (from w)
+int wino_s2_prepare_filters(const WinoS2Geo& g, int which, const float* w, float* out, hipStream_t s);
 int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float* bias, float* y, float* ws,
-                hipStream_t s);
+                hipStream_t s, const float* prep = nullptr);
 int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const float* x, float* dx, int lddx,
-                  int accumulate, float* ws, hipStream_t s);
+                  int accumulate, float* ws, hipStream_t s, const float* prep = nullptr);
 int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw, float* ws, hipStream_t s);

@@ -1243,19 +1243,36 @@ size_t wino_wgrad_ws_floats(const WinoGeo& g) {
          operand_floats(std::max(op_elems(4 * g.Cout, Tp), op_elems(Tp, 4 * g.Cout))) + (size_t)ns * 16 * 4 * g.Cout * g.Cin;
 }
 
+size_t wino_filter_floats(const WinoGeo& g, int which) {
+  return which == 0 ? operand_floats(op_elems(4 * g.Cout, g.Cin)) : operand_floats(op_elems(g.Cin, 4 * g.Cout));
+}
+int wino_prepare_filters(const WinoGeo& g, int which, const float* w, long cls_stride, float* out, hipStream_t s) {
+  const int N4 = 4 * g.Cout;
+  if (which == 0) {
+    const bool x3 = use_x3() && g.Cin % X3_BK == 0;
+    hipLaunchKernelGGL(wino_filter_fwd_kernel, dim3(op_grid(N4, g.Cin / 4)), dim3(256), 0, s, w, cls_stride, g.Cin,
+                       g.Cout, out, x3 ? reinterpret_cast<u16*>(out) : nullptr);
+  } else {
+    const bool x3 = use_x3() && N4 % X3_BK == 0;
+    hipLaunchKernelGGL(wino_filter_bwd_kernel, dim3(op_grid(g.Cin, g.Cout)), dim3(256), 0, s, w, cls_stride, g.Cin,
+                       g.Cout, out, x3 ? reinterpret_cast<u16*>(out) : nullptr);
+  }
+  return OTGAN_OK;
+}
+
 int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stride, const float* bias, float* y,
-             float* ws, hipStream_t s) {
+             float* ws, hipStream_t s, const float* prep) {
   const long T = wino_tiles(g);
   const int N4 = 4 * g.Cout;
   const bool x3 = use_x3() && g.Cin % X3_BK == 0;
   const size_t nV = op_elems(T, g.Cin), nU = op_elems(N4, g.Cin);
   float* V = ws;
-  float* U = V + operand_floats(nV);
-  float* Mh = U + operand_floats(nU);
+  float* Uws = V + operand_floats(nV);
+  float* Mh = Uws + operand_floats(nU);
+  float* U = prep ? const_cast<float*>(prep) : Uws;
   u16* VP = x3 ? reinterpret_cast<u16*>(V) : nullptr;
   u16* UP = x3 ? reinterpret_cast<u16*>(U) : nullptr;
-  hipLaunchKernelGGL(wino_filter_fwd_kernel, dim3(op_grid(N4, g.Cin / 4)), dim3(256), 0, s, weffT, cls_stride,
-                     g.Cin, g.Cout, U, UP);
+  if (!prep) wino_prepare_filters(g, 0, weffT, cls_stride, U, s);
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
   ia.s2_skip = -1;
@@ -1282,18 +1299,18 @@ int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stri
 }
 
 int wino_dgrad(const WinoGeo& g, const float* dy, const float* weff, long cls_stride, float* dx, int lddx,
-               int accumulate, float* ws, hipStream_t s) {
+               int accumulate, float* ws, hipStream_t s, const float* prep) {
   const long T = wino_tiles(g);
   const int K4 = 4 * g.Cout;
   const bool x3 = use_x3() && K4 % X3_BK == 0;
   const size_t nV = op_elems(T, K4), nU = op_elems(g.Cin, K4);
   float* DV = ws;                            // [16][T][4*Cout]
-  float* U = DV + operand_floats(nV);        // [16][Cin][4*Cout]
-  float* Xh = U + operand_floats(nU);        // [16][T][Cin]
+  float* Uws = DV + operand_floats(nV);      // [16][Cin][4*Cout]
+  float* Xh = Uws + operand_floats(nU);      // [16][T][Cin]
+  float* U = prep ? const_cast<float*>(prep) : Uws;
   u16* VP = x3 ? reinterpret_cast<u16*>(DV) : nullptr;
   u16* UP = x3 ? reinterpret_cast<u16*>(U) : nullptr;
-  hipLaunchKernelGGL(wino_filter_bwd_kernel, dim3(op_grid(g.Cin, g.Cout)), dim3(256), 0, s, weff, cls_stride,
-                     g.Cin, g.Cout, U, UP);
+  if (!prep) wino_prepare_filters(g, 1, weff, cls_stride, U, s);
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
   ia.s2_skip = -1;
@@ -1483,19 +1500,35 @@ size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g) {
          (size_t)ns * 16 * K4 * g.Cout;
 }
 
+size_t wino_s2_filter_floats(const WinoS2Geo& g, int which) {
+  return which == 0 ? operand_floats(op_elems(g.Cout, 4 * g.Ceff)) : operand_floats(op_elems(4 * g.Ceff, g.Cout));
+}
+int wino_s2_prepare_filters(const WinoS2Geo& g, int which, const float* w, float* out, hipStream_t s) {
+  if (which == 0) {
+    const bool x3 = use_x3() && g.Ceff % X3_BK == 0;
+    hipLaunchKernelGGL(wino_s2_filter_fwd_kernel, dim3(op_grid(g.Cout, g.Ceff)), dim3(256), 0, s, w, g.Ceff, g.Cout, out,
+                       x3 ? reinterpret_cast<u16*>(out) : nullptr);
+  } else {
+    const bool x3 = use_x3() && g.Cout % X3_BK == 0;
+    hipLaunchKernelGGL(wino_s2_filter_bwd_kernel, dim3(op_grid(4L * g.Ceff, g.Cout / 4)), dim3(256), 0, s, w, g.Ceff,
+                       g.Cout, out, x3 ? reinterpret_cast<u16*>(out) : nullptr);
+  }
+  return OTGAN_OK;
+}
+
 int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float* bias, float* y, float* ws,
-                hipStream_t s) {
+                hipStream_t s, const float* prep) {
   const long T = wino_s2_tiles(g);
   const int K4 = 4 * g.Ceff;
   const bool x3 = use_x3() && g.Ceff % X3_BK == 0;
   const size_t nV = op_elems(T, K4), nU = op_elems(g.Cout, K4);
   float* V = ws;                              // [16][T][4*Ceff]
-  float* U = V + operand_floats(nV);          // [16][Cout][4*Ceff]
-  float* Mh = U + operand_floats(nU);         // [16][T][Cout]
+  float* Uws = V + operand_floats(nV);        // [16][Cout][4*Ceff]
+  float* Mh = Uws + operand_floats(nU);       // [16][T][Cout]
+  float* U = prep ? const_cast<float*>(prep) : Uws;
   u16* VP = x3 ? reinterpret_cast<u16*>(V) : nullptr;
   u16* UP = x3 ? reinterpret_cast<u16*>(U) : nullptr;
-  hipLaunchKernelGGL(wino_s2_filter_fwd_kernel, dim3(op_grid(g.Cout, g.Ceff)), dim3(256), 0, s, wT, g.Ceff,
-                     g.Cout, U, UP);
+  if (!prep) wino_s2_prepare_filters(g, 0, wT, U, s);
   s2_input_transform(g, x, V, VP, s);
   BgArgs b;
   memset(&b, 0, sizeof(b));
@@ -1517,19 +1550,19 @@ int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float
 }
 
 int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const float* x, float* dx, int lddx,
-                  int accumulate, float* ws, hipStream_t s) {
+                  int accumulate, float* ws, hipStream_t s, const float* prep) {
   const long T = wino_s2_tiles(g);
   const int K4 = 4 * g.Ceff;
   const int OH = g.H / 2, OW = g.W / 2;
   const bool x3 = use_x3() && g.Cout % X3_BK == 0;
   const size_t nV = op_elems(T, g.Cout), nU = op_elems(K4, g.Cout);
   float* DV = ws;                             // [16][T][Cout]
-  float* U = DV + operand_floats(nV);         // [16][4*Ceff][Cout]
-  float* Xh = U + operand_floats(nU);         // [16][T][4*Ceff]
+  float* Uws = DV + operand_floats(nV);       // [16][4*Ceff][Cout]
+  float* Xh = Uws + operand_floats(nU);       // [16][T][4*Ceff]
+  float* U = prep ? const_cast<float*>(prep) : Uws;
   u16* VP = x3 ? reinterpret_cast<u16*>(DV) : nullptr;
   u16* UP = x3 ? reinterpret_cast<u16*>(U) : nullptr;
-  hipLaunchKernelGGL(wino_s2_filter_bwd_kernel, dim3(op_grid(4L * g.Ceff, g.Cout / 4)), dim3(256), 0, s, w, g.Ceff,
-                     g.Cout, U, UP);
+  if (!prep) wino_s2_prepare_filters(g, 1, w, U, s);
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
   ia.s2_skip = -1;

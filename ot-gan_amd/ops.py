@@ -148,23 +148,36 @@ def colsum(a2d_ptr, rows, cols, lda, device):
     return out
 
 
-def conv_fwd_raw(desc, x, cmap, wT, bias, y):
+def conv_fwd_raw(desc, x, cmap, wT, bias, y, filters=None):
     L = _lib.lib()
     need = L.otgan_conv2d_workspace_bytes(ctypes.byref(desc), 0)
     ws = workspace(need, x.device)
-    _lib.check(L.otgan_conv2d_fwd_f32(ctypes.byref(desc), x.data_ptr(), _lib.ptr(cmap),
-                                      wT.data_ptr(), _lib.ptr(bias), y.data_ptr(), ws.data_ptr(),
-                                      ws.numel(), _lib.stream_ptr()), "conv2d_fwd")
+    _lib.check(L.otgan_conv2d_fwd_pf_f32(ctypes.byref(desc), x.data_ptr(), _lib.ptr(cmap),
+                                         wT.data_ptr(), _lib.ptr(filters), _lib.ptr(bias), y.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "conv2d_fwd")
 
 
-def conv_dgrad_raw(desc, dy, w, x, inv, dx, lddx, accumulate):
+def conv_dgrad_raw(desc, dy, w, x, inv, dx, lddx, accumulate, filters=None):
     L = _lib.lib()
     need = L.otgan_conv2d_workspace_bytes(ctypes.byref(desc), 1)
     ws = workspace(need, dy.device)
-    _lib.check(L.otgan_conv2d_dgrad_f32(ctypes.byref(desc), dy.data_ptr(), w.data_ptr(),
-                                        _lib.ptr(x), _lib.ptr(inv), dx.data_ptr(), lddx,
-                                        1 if accumulate else 0, ws.data_ptr(), ws.numel(),
-                                        _lib.stream_ptr()), "conv2d_dgrad")
+    _lib.check(L.otgan_conv2d_dgrad_pf_f32(ctypes.byref(desc), dy.data_ptr(), w.data_ptr(), _lib.ptr(filters),
+                                           _lib.ptr(x), _lib.ptr(inv), dx.data_ptr(), lddx,
+                                           1 if accumulate else 0, ws.data_ptr(), ws.numel(),
+                                           _lib.stream_ptr()), "conv2d_dgrad")
+
+
+def prepare_filters(desc, which, w):
+    """Winograd-domain filters of a layer's forward (which=0, from wT) or dgrad (which=1, from w) pass, or None
+    when the pass does not run as a Winograd GEMM (otgan_layers.h)."""
+    L = _lib.lib()
+    nbytes = L.otgan_conv2d_filter_bytes(ctypes.byref(desc), which)
+    if not nbytes:
+        return None
+    buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=w.device)
+    _lib.check(L.otgan_conv2d_prepare_filters_f32(ctypes.byref(desc), which, w.data_ptr(), buf.data_ptr(),
+                                                  buf.numel() * 4, _lib.stream_ptr()), "prepare_filters")
+    return buf
 
 
 def conv_wgrad_raw(desc, x, cmap, dy, dw):
@@ -218,11 +231,14 @@ class Conv2dFunction(torch.autograd.Function):
             if nfold:
                 # conv o upsample == four parity-class convs with pre-summed taps (otgan_layers.h)
                 wd, wT = fold_weights(desc, w)
-            return wd, wT, inv_norm
+            # Winograd-domain filters live as long as the normalised weights (the critic's survive the five
+            # generator steps between its updates); the dgrad ones are made by the first backward that needs them
+            return wd, wT, inv_norm, {"fwd": prepare_filters(desc, 0, wT), "bwd": None, "bwd_done": False}
 
-        wd, wT, inv_norm = cached_weights(V, g, compute)
-        conv_fwd_raw(desc, x, cmap, wT, b, y)
+        wd, wT, inv_norm, filt = cached_weights(V, g, compute)
+        conv_fwd_raw(desc, x, cmap, wT, b, y, filt["fwd"])
         ctx.save_for_backward(x, V2d, g, wd, inv_norm)
+        ctx.filt = filt
         ctx.desc, ctx.cmap, ctx.inv = desc, cmap, inv
         ctx.vshape = V.shape
         ctx.has_b = b is not None
@@ -236,7 +252,10 @@ class Conv2dFunction(torch.autograd.Function):
         dx = dV = dg = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            conv_dgrad_raw(desc, dy, w, x, ctx.inv, dx, x.shape[3], False)
+            filt = ctx.filt
+            if not filt["bwd_done"]:
+                filt["bwd"], filt["bwd_done"] = prepare_filters(desc, 1, w), True
+            conv_dgrad_raw(desc, dy, w, x, ctx.inv, dx, x.shape[3], False, filt["bwd"])
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw = torch.empty_like(V2d)
             conv_wgrad_raw(desc, x, ctx.cmap, dy, dw)

@@ -127,6 +127,35 @@ def test_conv2d_only_needed_grads(dev):
     assert dx.shape == x.shape and torch.isfinite(dx).all()
 
 
+def test_prepared_filters_match_inline(dev):
+    # Winograd-domain filters made once (otgan_conv2d_prepare_filters_f32) == derived inside the call, bit for bit;
+    # layers without a Winograd path report no filters; a short buffer is refused
+    import ctypes
+    from otgan_amd import ops, _lib
+    x = torch.randn(4, 16, 16, 32, device=dev)
+    V2d = (torch.randn(5 * 5 * 64, 48, device=dev) * 0.05).contiguous()
+    g = torch.ones(48, device=dev)
+    w, wT, _ = ops.weightnorm_fwd(V2d, g)
+    desc = ops.make_desc(x, 32, False, 5, 5, 2, 48, 48, 0, ops.ACT["crelu"])
+    filt = ops.prepare_filters(desc, 0, wT)
+    assert filt is not None
+    ya, yb = torch.empty(4, 8, 8, 48, device=dev), torch.empty(4, 8, 8, 48, device=dev)
+    ops.conv_fwd_raw(desc, x, None, wT, None, ya)
+    ops.conv_fwd_raw(desc, x, None, wT, None, yb, filt)
+    assert torch.equal(ya, yb)
+    dy = torch.randn_like(ya)
+    fb = ops.prepare_filters(desc, 1, w)
+    da, db = torch.empty_like(x), torch.empty_like(x)
+    ops.conv_dgrad_raw(desc, dy, w, x, None, da, 32, False)
+    ops.conv_dgrad_raw(desc, dy, w, x, None, db, 32, False, fb)
+    assert torch.equal(da, db)
+    L = _lib.lib()
+    rc = L.otgan_conv2d_prepare_filters_f32(ctypes.byref(desc), 0, wT.data_ptr(), filt.data_ptr(), 16, _lib.stream_ptr())
+    assert rc == -2 and b"too small" in L.otgan_last_error()
+    plain = ops.make_desc(torch.empty(2, 8, 8, 16, device=dev), 16, False, 3, 3, 1, 32, 32, 0, 0)
+    assert ops.prepare_filters(plain, 0, wT) is None and L.otgan_conv2d_filter_bytes(ctypes.byref(plain), 2) == 0
+
+
 @pytest.mark.parametrize("pre", [None, "crelu"])
 def test_dense(dev, pre):
     from otgan_amd import ops
