@@ -1495,6 +1495,12 @@ WgPlan plan_wgrad(const otgan_conv_desc* d, const Geo& g) {
     p.fold = false;
     p.M = (long)d->N * g.OH * g.OW;
     p.nchunks = p.M >= 256 * 64 ? 256 : (int)ceil_div_l(p.M, 64);
+    if (d->stride == 1) {
+      // the all-taps kernel streams its pixels serially per thread: 5 waves per workgroup and 256 workgroups leave
+      // ~1 wave per SIMD, nothing to hide the load latency with -> more, shorter chunks (OTGAN_OUTER_CHUNKS to vary)
+      static const int want = [] { const char* e = getenv("OTGAN_OUTER_CHUNKS"); return e ? atoi(e) : 512; }();
+      if (p.M >= (long)want * 64) p.nchunks = want;
+    }
     p.chunk = (int)ceil_div_l(p.M, p.nchunks);
     if (d->stride == 1) {
       // whole units of TRo image rows per block (conv_outer2_kernel stages the narrow operand per unit)
