@@ -865,9 +865,9 @@ __global__ __launch_bounds__(256) void conv_fewout_kernel(GatherA g, Taps taps, 
 // Tile variant of the few-output kernel for stride-1 layers (the RGB-out convolution of both generators,
 // the input gradient of the RGB-in convolution): the kernel above re-reads the source once per tap
 // (25x for a 5x5 filter, L2-bound at ~10 TB/s).  Here a block owns TR rows x W columns of one image
-// (256 pixels, 128 threads x two vertically adjacent pixels), stages the tile plus halo for 32 channels at a
-// time in LDS -- sign / activation applied once, at fill time -- and every tap reads its shifted pixels as
-// eight ds_read_b128 each (pixel stride 9 slots of 16 bytes: conflict-free).  The chunk's weights sit in LDS
+// (256 pixels, 128 threads x two vertically adjacent pixels), stages the tile plus halo for 16 channels at a
+// time in LDS (39 KiB: four workgroups per CU; 32 channels = two per CU measured 0.18 vs 0.14 ms, 8 channels 0.18) -- sign / activation applied once, at fill time -- and every tap reads its shifted pixels as
+// ds_read_b128 (pixel stride 5 slots of 16 bytes: conflict-free).  The chunk's weights sit in LDS
 // too and are read as broadcasts, one read serving both pixels (scalar loads left the loop waiting on the
 // scalar cache for most of its time: SQ_WAIT_ANY 79 %).
 struct FewTileArgs {
@@ -876,9 +876,11 @@ struct FewTileArgs {
 };
 
 constexpr int kFewTileThreads = 128;
+constexpr int kFewQ = 4;            // float4 (= 4 channels) per pixel and channel chunk; pixel stride kFewQ + 1 slots (odd)
+constexpr int kFewS = kFewQ + 1;
 template <int ACT, int NJ>
 __global__ __launch_bounds__(kFewTileThreads) void conv_fewout_tile_kernel(GatherA g, Taps taps, FewOutArgs a, FewTileArgs ft) {
-  extern __shared__ __attribute__((aligned(16))) float4 s_fx[];   // [LH * LW][9] source tile, then [taps][NJ][8] weights
+  extern __shared__ __attribute__((aligned(16))) float4 s_fx[];   // [LH * LW][kFewS] source tile, then [taps][NJ][kFewQ] weights
   const int tid = threadIdx.x;
   const int W = 1 << g.logGW, H = 1 << g.logGH;
   const int tiles_per_img = H / ft.TR;
@@ -887,7 +889,7 @@ __global__ __launch_bounds__(kFewTileThreads) void conv_fewout_tile_kernel(Gathe
   const int pr2 = tid >> g.logGW, pc = tid & (W - 1);
   const long img = (long)n * H * W;
   const int npix = ft.LH * ft.LW;
-  float4* s_w = s_fx + npix * 9;
+  float4* s_w = s_fx + npix * kFewS;
   // two partial sums per output (even / odd channel pairs): the inner product is written as packed FMAs
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   f32x2 acc2[2][NJ];
@@ -895,24 +897,24 @@ __global__ __launch_bounds__(kFewTileThreads) void conv_fewout_tile_kernel(Gathe
   for (int p = 0; p < 2; ++p)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc2[p][j] = f32x2{0.f, 0.f};
-  for (int d0 = 0; d0 < g.Ck; d0 += 32) {
+  for (int d0 = 0; d0 < g.Ck; d0 += 4 * kFewQ) {
     __syncthreads();   // the previous chunk's tile is fully consumed
     // all loads of a batch in flight before the first LDS store (a load-store loop exposes one memory round trip
     // per element); p / LW through a multiply-shift (exact for p < 4096, LW <= 68)
     constexpr int kBatch = 9;
-    for (int i0 = tid; i0 < npix * 8; i0 += kFewTileThreads * kBatch) {
+    for (int i0 = tid; i0 < npix * kFewQ; i0 += kFewTileThreads * kBatch) {
       float4 v[kBatch];
       float sg[kBatch];
 #pragma unroll
       for (int b = 0; b < kBatch; ++b) {
         const int i = i0 + b * kFewTileThreads;
-        const int q = i & 7, p = i >> 3;
+        const int q = i % kFewQ, p = i / kFewQ;
         const int lr = (int)(((unsigned)p * ft.lw_magic) >> 20), lc = p - lr * ft.LW;
         const int ih = r0 + lr + ft.dh0, iw = lc + ft.dw0;
         const int d = d0 + 4 * q;
         v[b] = make_float4(0.f, 0.f, 0.f, 0.f);
         sg[b] = 1.f;
-        if (i < npix * 8 && d < g.Ck && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+        if (i < npix * kFewQ && d < g.Ck && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
           int sc;
           decode_map(g, d, g.cmap ? g.cmap[d] : 0, sc, sg[b]);
           v[b] = *reinterpret_cast<const float4*>(g.x + (img + (long)ih * W + iw) * g.ldx + sc);
@@ -921,52 +923,52 @@ __global__ __launch_bounds__(kFewTileThreads) void conv_fewout_tile_kernel(Gathe
 #pragma unroll
       for (int b = 0; b < kBatch; ++b) {
         const int i = i0 + b * kFewTileThreads;
-        if (i < npix * 8) {
+        if (i < npix * kFewQ) {
           float4 o;
           o.x = act_apply<ACT>(sg[b] * v[b].x);
           o.y = act_apply<ACT>(sg[b] * v[b].y);
           o.z = act_apply<ACT>(sg[b] * v[b].z);
           o.w = act_apply<ACT>(sg[b] * v[b].w);
-          s_fx[(i >> 3) * 9 + (i & 7)] = o;
+          s_fx[(i / kFewQ) * kFewS + (i % kFewQ)] = o;
         }
       }
     }
-    // the chunk's weights: s_w[(t * NJ + j) * 8 + q] = w[tap t][output j][d0 + 4q .. +3] (zero past the last channel)
-    for (int i = tid; i < taps.n * NJ * 8; i += kFewTileThreads) {
-      const int q = i & 7, tj = i >> 3;
+    // the chunk's weights: s_w[(t * NJ + j) * kFewQ + q] = w[tap t][output j][d0 + 4q .. +3] (zero past the last channel)
+    for (int i = tid; i < taps.n * NJ * kFewQ; i += kFewTileThreads) {
+      const int q = i % kFewQ, tj = i / kFewQ;
       const int t = tj / NJ, j = tj - t * NJ;
       float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (d0 + 4 * q < g.Ck && j < a.J) wv = *reinterpret_cast<const float4*>(a.w + taps.boff[t] + j * a.sJ + d0 + 4 * q);
       s_w[i] = wv;
     }
     __syncthreads();
-    // Software pipeline over half taps (four float4 = 16 channels each): the LDS reads of the next half are issued
+    // Software pipeline over half taps (kFewQ / 2 float4 each): the LDS reads of the next half are issued
     // before the FMAs of the current one, and a compiler barrier keeps them there -- left alone, the scheduler sinks
     // every read next to its use (read, wait, four FMAs), and with one wave per SIMD resident (72 KiB of LDS per
     // block) nothing else hides the LDS round trip.
     struct Half {
-      float4 d0[4], d1[4], w[NJ][4];
+      float4 d0[kFewQ / 2], d1[kFewQ / 2], w[NJ][kFewQ / 2];
     };
     auto load_half = [&](Half& h, int t, int hq) {
       const int dhw = taps.dhw[t];
       const int dh = dhw >> 16, dw = sx16(dhw);
-      const float4* src0 = s_fx + ((2 * pr2 + dh - ft.dh0) * ft.LW + (pc + dw - ft.dw0)) * 9 + 4 * hq;
-      const float4* src1 = src0 + ft.LW * 9;
-      const float4* wt = s_w + t * NJ * 8 + 4 * hq;
+      const float4* src0 = s_fx + ((2 * pr2 + dh - ft.dh0) * ft.LW + (pc + dw - ft.dw0)) * kFewS + (kFewQ / 2) * hq;
+      const float4* src1 = src0 + ft.LW * kFewS;
+      const float4* wt = s_w + t * NJ * kFewQ + (kFewQ / 2) * hq;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < kFewQ / 2; ++q) {
         h.d0[q] = src0[q];
         h.d1[q] = src1[q];
       }
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) h.w[j][q] = wt[j * 8 + q];   // the same address in every lane: LDS broadcast
+        for (int q = 0; q < kFewQ / 2; ++q) h.w[j][q] = wt[j * kFewQ + q];   // the same address in every lane: LDS broadcast
       asm volatile("" ::: "memory");
     };
     auto fma_half = [&](const Half& h) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < kFewQ / 2; ++q) {
         const f32x2 a01 = {h.d0[q].x, h.d0[q].y}, a23 = {h.d0[q].z, h.d0[q].w};
         const f32x2 b01 = {h.d1[q].x, h.d1[q].y}, b23 = {h.d1[q].z, h.d1[q].w};
 #pragma unroll
@@ -1022,7 +1024,7 @@ static bool launch_fewout_tile(const GatherA& ga, const Taps& t, const FewOutArg
   ft.lw_magic = ((1u << 20) + ft.LW - 1) / ft.LW;
   if (ft.TR % 2) return false;
   const int nj = fa.J == 3 ? 3 : 4;
-  const size_t lds = sizeof(float4) * (9 * (size_t)ft.LH * ft.LW + (size_t)t.n * nj * 8);
+  const size_t lds = sizeof(float4) * (kFewS * (size_t)ft.LH * ft.LW + (size_t)t.n * nj * kFewQ);
   if (lds > 80 * 1024) return false;
   const dim3 grid(ga.Mtot / 256);
   if (fa.J == 3) {
