@@ -1041,6 +1041,96 @@ static bool launch_fewout_tile(const GatherA& ga, const Taps& t, const FewOutArg
   return true;
 }
 
+// RGB-in forward (the first convolution of both critics: 3 input channels, no pre-activation): lanes run along
+// the OUTPUT channels.  A lane keeps the KS*KS*3 weights of its two channels (co, co + 64: one packed accumulator)
+// in registers for the whole tile, the input pixel -- identical for all lanes -- comes out of an LDS tile (with
+// halo) as one broadcast ds_read_b128 and enters the packed FMA as a broadcast operand.  Every store is 64
+// consecutive channels of one pixel (256 contiguous bytes).  The generic implicit GEMM spent its time in scalar gathers of
+// the 3-channel pixels (38 TFLOP/s); this form is bound by the packed FMAs and the 134 MB it writes.
+struct FewInArgs {
+  const float* x; int ldx;
+  const float* wT; int K;        // [Cout][K], K = KS*KS*3
+  const float* bias;
+  float* y; int ldy, coff;
+  int N, H, W, logW, ph, pw, TR;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void conv_rgbin_fwd_kernel(FewInArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float4 s_in[];   // [(TR + KS - 1)][(W + KS - 1)] pixels (r, g, b, 0)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int co = blockIdx.y * 128 + lane;          // this lane's channels: co and co + 64 (one packed accumulator)
+  const int tiles_per_img = a.H / a.TR;
+  const int n = blockIdx.x / tiles_per_img, r0 = (blockIdx.x - n * tiles_per_img) * a.TR;
+  const int LW = a.W + KS - 1, LH = a.TR + KS - 1;
+  const long img = (long)n * a.H * a.W;
+  for (int i = tid; i < LH * LW; i += 256) {
+    const int lr = i / LW, lc = i - lr * LW;
+    const int ih = r0 + lr - a.ph, iw = lc - a.pw;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W) {
+      const float* px = a.x + (img + (long)ih * a.W + iw) * a.ldx;
+      v = make_float4(px[0], px[1], px[2], 0.f);
+    }
+    s_in[i] = v;
+  }
+  f32x2 w[KS * KS * 3];
+  const float* wlo = a.wT + (long)co * a.K;
+  const float* whi = wlo + 64L * a.K;
+#pragma unroll
+  for (int i = 0; i < KS * KS * 3; ++i) w[i] = f32x2{wlo[i], whi[i]};
+  const f32x2 b = a.bias ? f32x2{a.bias[co], a.bias[co + 64]} : f32x2{0.f, 0.f};
+  __syncthreads();
+  // this wave's pixels: a quarter of the tile's rows, two horizontally adjacent pixels per iteration (they share
+  // the KS + 1 input positions of every filter row)
+  const int rows = a.TR >> 2, rbase = wave * rows, pairs = a.W >> 1;
+  for (int pi = 0; pi < rows * pairs; ++pi) {
+    const int r = rbase + pi / pairs, c0 = (pi % pairs) * 2;
+    f32x2 acc0 = b, acc1 = b;
+#pragma unroll
+    for (int kh = 0; kh < KS; ++kh) {
+      float4 xs[KS + 1];
+      const float4* src = s_in + (r + kh) * LW + c0;
+#pragma unroll
+      for (int j = 0; j < KS + 1; ++j) xs[j] = src[j];   // the same address in every lane: LDS broadcast
+#pragma unroll
+      for (int kw = 0; kw < KS; ++kw) {
+        const f32x2* wt = w + (kh * KS + kw) * 3;
+        acc0 = __builtin_elementwise_fma(wt[0], f32x2{xs[kw].x, xs[kw].x}, acc0);
+        acc0 = __builtin_elementwise_fma(wt[1], f32x2{xs[kw].y, xs[kw].y}, acc0);
+        acc0 = __builtin_elementwise_fma(wt[2], f32x2{xs[kw].z, xs[kw].z}, acc0);
+        acc1 = __builtin_elementwise_fma(wt[0], f32x2{xs[kw + 1].x, xs[kw + 1].x}, acc1);
+        acc1 = __builtin_elementwise_fma(wt[1], f32x2{xs[kw + 1].y, xs[kw + 1].y}, acc1);
+        acc1 = __builtin_elementwise_fma(wt[2], f32x2{xs[kw + 1].z, xs[kw + 1].z}, acc1);
+      }
+    }
+    float* dst = a.y + (img + (long)(r0 + r) * a.W + c0) * a.ldy + a.coff + co;
+    dst[0] = acc0[0];
+    dst[64] = acc0[1];
+    dst[a.ldy] = acc1[0];
+    dst[a.ldy + 64] = acc1[1];
+  }
+}
+
+static bool launch_rgbin_fwd(const otgan_conv_desc* d, int pad_t, int pad_l, const float* x, const float* wT,
+                             const float* bias, float* y, hipStream_t s) {
+  if (d->C != 3 || d->stride != 1 || d->upsample != 0 || d->KH != d->KW || (d->KH != 5 && d->KH != 3) ||
+      d->Cout % 128 != 0 || d->W < 16 || d->W > 64)
+    return false;
+  FewInArgs a;
+  a.x = x; a.ldx = d->ldx; a.wT = wT; a.K = d->KH * d->KW * 3; a.bias = bias;
+  a.y = y; a.ldy = d->ldy; a.coff = d->y_coff;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.logW = 0; a.ph = pad_t; a.pw = pad_l;
+  a.TR = 256 / d->W;
+  if (a.TR < 4 || a.TR > d->H || d->H % a.TR) return false;
+  const dim3 grid(d->N * (d->H / a.TR), d->Cout / 128);
+  const size_t lds = sizeof(float4) * (size_t)(a.TR + d->KH - 1) * (d->W + d->KW - 1);
+  if (d->KH == 5) hipLaunchKernelGGL(conv_rgbin_fwd_kernel<5>, grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(conv_rgbin_fwd_kernel<3>, grid, dim3(256), lds, s, a);
+  return true;
+}
+
 struct OuterArgs {
   // wide operand: value(pix, c) ; narrow operand: value(pix, j)
   const float* wide; int ldw; int wideC;      // channels of the wide side
@@ -1900,6 +1990,14 @@ static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32
   single_class(d, g, &ct);
   for (int t = 0; t < ct.taps[0].n; ++t) ct.taps[0].boff[t] = t * g.Ceff;
   const int Ktot = ct.taps[0].n * g.Ceff;
+  if (cmap == nullptr && d->preact == OTGAN_ACT_NONE) {
+    // RGB-in layer: lanes along the output channels, weights in registers
+    ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * ga.Mtot * (double)Ktot * d->Cout, 0.0, s);
+    if (launch_rgbin_fwd(d, g.pad_t, g.pad_l, x, wT, bias, y, s)) {
+      OTGAN_CHECK_LAUNCH("conv2d fwd (RGB in)");
+      return OTGAN_OK;
+    }
+  }
   if (d->Cout <= 4 && d->upsample == 0 && g.Ceff % 4 == 0 && d->ldx % 4 == 0 && aligned16(x) &&
       aligned16(wT)) {
     // RGB-out layer: vector-ALU kernel, thread = pixel (an MFMA tile would idle 29 of 32 columns)
