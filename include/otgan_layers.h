@@ -105,7 +105,10 @@ int otgan_conv2d_dgrad_f32(const otgan_conv_desc* d, const float* dy, const floa
  * once into its own buffer and pass it to the _pf variants.
  *   otgan_conv2d_filter_bytes(d, which)   which = 0 forward, 1 dgrad; 0: the layer / pass has none
  *   otgan_conv2d_prepare_filters_f32      `w` = what the pass itself takes (wT for forward, w for dgrad;
- *                                         folded layers: weffT / weff)
+ *                                         folded layers: weffT / weff).  Folded layers also accept
+ *                                         which = 2 / 3: forward / dgrad filters from the UN-folded wT / w
+ *                                         (bit-identical; the fold is then not needed by these two passes:
+ *                                         with `filters` given they do not read their weight argument)
  *   otgan_conv2d_fwd_pf_f32 / otgan_conv2d_dgrad_pf_f32: as the plain calls; `filters` may be NULL
  *                                         (then identical to them) and is ignored by the non-Winograd paths.
  * The buffer's content is tied to the descriptor and to the OTGAN_WINO_* switches of the process.

@@ -1858,9 +1858,9 @@ size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which) {
 
 size_t otgan_conv2d_filter_bytes(const otgan_conv_desc* d, int which) {
   Geo g;
-  if (make_geo(d, &g) != OTGAN_OK || (which != 0 && which != 1)) return 0;
-  if (wino_s2_ok(d, g)) return sizeof(float) * wino_s2_filter_floats(wino_s2_geo(d, g), which);
-  if (wino_ok(d, g)) return sizeof(float) * wino_filter_floats(wino_geo(d), which);
+  if (make_geo(d, &g) != OTGAN_OK || which < 0 || which > 3) return 0;
+  if (wino_s2_ok(d, g)) return which < 2 ? sizeof(float) * wino_s2_filter_floats(wino_s2_geo(d, g), which) : 0;
+  if (wino_ok(d, g)) return sizeof(float) * wino_filter_floats(wino_geo(d), which);   // 2, 3: from un-folded weights
   return 0;
 }
 

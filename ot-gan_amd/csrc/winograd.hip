@@ -503,6 +503,80 @@ __global__ __launch_bounds__(256) void wino_filter_bwd_kernel(const float* __res
     for (int j = 0; j < 4; ++j) st_operand(U, P, Cin, 4 * Cout, i * 4 + j, ci, cls * Cout + co, Uv[i][j]);
 }
 
+// The same two transforms straight from the UN-folded 5x5 weights (the fold of the 2x nearest-neighbour upsampling,
+// conv.hip fold_weights_kernel, applied in registers: tap k of output parity p lands on folded tap k/2 (p = 0) or
+// (k+1)/2 (p = 1); sums in the fold kernel's order, so the filters are bit-identical to the two-step route).
+__device__ __forceinline__ int fold5_tap(int p, int k) { return p ? (k + 1) >> 1 : k >> 1; }
+
+// U[f][cls*Cout + co][ci] from wT[co][(kh*5 + kw)*Cin + ci]
+__global__ __launch_bounds__(256) void wino_filter_fwd_unfolded_kernel(const float* __restrict__ wT, int Cin, int Cout,
+                                                                     float* __restrict__ U, u16* P) {
+  const long rows = 4L * Cout;
+  long row;
+  int k4;
+  if (!op_thread(P != nullptr, rows, Cin >> 2, row, k4)) return;
+  const int ci = k4 * 4;
+  const int cls = (int)(row / Cout), co = (int)(row % Cout);
+  const int ph = cls >> 1, pw = cls & 1;
+  const float* src = wT + (long)co * 25 * Cin + ci;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 g[3][3], Uv[4][4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) g[i][j] = zero;
+#pragma unroll
+  for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 5; ++kw) {
+      const f32x4 v = ld4(src + (long)(kh * 5 + kw) * Cin);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (fold5_tap(ph, kh) == i && fold5_tap(pw, kw) == j) g[i][j] += v;
+    }
+  tf_filter(g, Uv);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st_operand(U, P, rows, Cin, i * 4 + j, row, ci, Uv[i][j]);
+}
+
+// U'[f][ci][cls*Cout + co] (flipped taps) from w[kh*5 + kw][ci][co]
+__global__ __launch_bounds__(256) void wino_filter_bwd_unfolded_kernel(const float* __restrict__ w, int Cin, int Cout,
+                                                                     float* __restrict__ U, u16* P) {
+  const int c4n = Cout >> 2;
+  long row;
+  int k4;
+  if (!op_thread(P != nullptr, Cin, 4 * c4n, row, k4)) return;
+  const int ci = (int)row, cls = k4 / c4n, co = (k4 % c4n) * 4;
+  const int ph = cls >> 1, pw = cls & 1;
+  const float* src = w + (long)ci * Cout + co;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 g[3][3], Uv[4][4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) g[i][j] = zero;
+#pragma unroll
+  for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 5; ++kw) {
+      const f32x4 v = ld4(src + (long)(kh * 5 + kw) * Cin * Cout);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (fold5_tap(ph, kh) == 2 - i && fold5_tap(pw, kw) == 2 - j) g[i][j] += v;
+    }
+  tf_filter(g, Uv);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st_operand(U, P, Cin, 4 * Cout, i * 4 + j, ci, cls * Cout + co, Uv[i][j]);
+}
+
 // dweff[cls][tap][ci][co] = (G^T dU G)[tap],  dU[f] = sum over splits of slab[split][f][ci][cls*Cout + co]
 __global__ __launch_bounds__(256) void wino_filter_adj_kernel(const float* __restrict__ slabs, int nsplit,
                                                             long split_stride, int Cin, int Cout,
@@ -1244,10 +1318,22 @@ size_t wino_wgrad_ws_floats(const WinoGeo& g) {
 }
 
 size_t wino_filter_floats(const WinoGeo& g, int which) {
-  return which == 0 ? operand_floats(op_elems(4 * g.Cout, g.Cin)) : operand_floats(op_elems(g.Cin, 4 * g.Cout));
+  return (which == 0 || which == 2) ? operand_floats(op_elems(4 * g.Cout, g.Cin)) : operand_floats(op_elems(g.Cin, 4 * g.Cout));
 }
 int wino_prepare_filters(const WinoGeo& g, int which, const float* w, long cls_stride, float* out, hipStream_t s) {
   const int N4 = 4 * g.Cout;
+  if (which == 2) {          // forward filters from the un-folded transposed weights wT[Cout][25*Cin]
+    const bool x3 = use_x3() && g.Cin % X3_BK == 0;
+    hipLaunchKernelGGL(wino_filter_fwd_unfolded_kernel, dim3(op_grid(N4, g.Cin / 4)), dim3(256), 0, s, w, g.Cin, g.Cout, out,
+                       x3 ? reinterpret_cast<u16*>(out) : nullptr);
+    return OTGAN_OK;
+  }
+  if (which == 3) {          // dgrad filters from the un-folded HWIO weights w[25][Cin][Cout]
+    const bool x3 = use_x3() && N4 % X3_BK == 0;
+    hipLaunchKernelGGL(wino_filter_bwd_unfolded_kernel, dim3(op_grid(g.Cin, g.Cout)), dim3(256), 0, s, w, g.Cin, g.Cout, out,
+                       x3 ? reinterpret_cast<u16*>(out) : nullptr);
+    return OTGAN_OK;
+  }
   if (which == 0) {
     const bool x3 = use_x3() && g.Cin % X3_BK == 0;
     hipLaunchKernelGGL(wino_filter_fwd_kernel, dim3(op_grid(N4, g.Cin / 4)), dim3(256), 0, s, w, cls_stride, g.Cin,

@@ -228,12 +228,15 @@ class Conv2dFunction(torch.autograd.Function):
         def compute():
             w, wT, inv_norm = weightnorm_fwd(V2d, g)
             wd = w                       # operand of dgrad
-            if nfold:
+            unf = bool(nfold) and _lib.lib().otgan_conv2d_filter_bytes(ctypes.byref(desc), 2) > 0
+            if nfold and not unf:
                 # conv o upsample == four parity-class convs with pre-summed taps (otgan_layers.h)
                 wd, wT = fold_weights(desc, w)
             # Winograd-domain filters live as long as the normalised weights (the critic's survive the five
-            # generator steps between its updates); the dgrad ones are made by the first backward that needs them
-            return wd, wT, inv_norm, {"fwd": prepare_filters(desc, 0, wT), "bwd": None, "bwd_done": False}
+            # generator steps between its updates); the dgrad ones are made by the first backward that needs them.
+            # Folded Winograd layers derive them straight from the un-folded weights (no fold pass at all).
+            return wd, wT, inv_norm, {"fwd": prepare_filters(desc, 2 if unf else 0, wT), "bwd": None,
+                                      "bwd_done": False, "bwd_which": 3 if unf else 1}
 
         wd, wT, inv_norm, filt = cached_weights(V, g, compute)
         conv_fwd_raw(desc, x, cmap, wT, b, y, filt["fwd"])
@@ -254,7 +257,7 @@ class Conv2dFunction(torch.autograd.Function):
             dx = torch.empty_like(x)
             filt = ctx.filt
             if not filt["bwd_done"]:
-                filt["bwd"], filt["bwd_done"] = prepare_filters(desc, 1, w), True
+                filt["bwd"], filt["bwd_done"] = prepare_filters(desc, filt["bwd_which"], w), True
             conv_dgrad_raw(desc, dy, w, x, ctx.inv, dx, x.shape[3], False, filt["bwd"])
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw = torch.empty_like(V2d)

@@ -152,6 +152,15 @@ def test_prepared_filters_match_inline(dev):
     L = _lib.lib()
     rc = L.otgan_conv2d_prepare_filters_f32(ctypes.byref(desc), 0, wT.data_ptr(), filt.data_ptr(), 16, _lib.stream_ptr())
     assert rc == -2 and b"too small" in L.otgan_last_error()
+    # folded (upsampling) layer: filters from the un-folded weights (which = 2 / 3) == from the folded ones (0 / 1)
+    xu = torch.randn(2, 8, 8, 32, device=dev)
+    Vu = (torch.randn(5 * 5 * 32, 64, device=dev) * 0.05).contiguous()
+    wu, wuT, _ = ops.weightnorm_fwd(Vu, torch.ones(64, device=dev))
+    du = ops.make_desc(xu, 32, True, 5, 5, 1, 64, 64, 0, 0)
+    weff, weffT = ops.fold_weights(du, wu)
+    assert torch.equal(ops.prepare_filters(du, 0, weffT), ops.prepare_filters(du, 2, wuT))
+    assert torch.equal(ops.prepare_filters(du, 1, weff), ops.prepare_filters(du, 3, wu))
+    assert L.otgan_conv2d_filter_bytes(ctypes.byref(desc), 2) == 0      # strided layers have no folded form
     plain = ops.make_desc(torch.empty(2, 8, 8, 16, device=dev), 16, False, 3, 3, 1, 32, 32, 0, 0)
     assert ops.prepare_filters(plain, 0, wT) is None and L.otgan_conv2d_filter_bytes(ctypes.byref(plain), 2) == 0
 
