@@ -1275,7 +1275,8 @@ void class_views(const WinoGeo& g, P base, int ld, V (&v)[4]) {
 // K splits of the wgrad GEMM on the bf16 pipe (256 x 256 tiles: few tiles, long K)
 int x3_wgrad_splits(int M, int N, long T) {
   const int blocks = ((M + X3_BM - 1) / X3_BM) * ((N + X3_BN - 1) / X3_BN) * 16;
-  int ns = (768 + blocks - 1) / blocks;
+  static const int target = [] { const char* e = getenv("OTGAN_X3_SPLIT_TARGET"); return e ? atoi(e) : 256; }();
+  int ns = (target + blocks - 1) / blocks;
   if (ns > 16) ns = 16;
   const int nkt = (int)((T + X3_BK - 1) / X3_BK);
   while (ns > 1 && nkt / ns < 8) --ns;
