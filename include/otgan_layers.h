@@ -67,7 +67,9 @@ size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which);
  * Environment switches (debugging / A-B measurements): OTGAN_DISABLE_WINOGRAD=1,
  * OTGAN_WINO_FP32=1 (Winograd GEMMs on the fp32 engine), OTGAN_WINO_WGRAD_X3=0 (weight-gradient GEMMs on
  * the fp32 engine), OTGAN_WINO_WGRAD_TL=0 (weight-gradient operands from the transposing producers instead
- * of the forward-layout ones), OTGAN_DISABLE_DENSE16=1, OTGAN_DENSE16_V1=1.
+ * of the forward-layout ones), OTGAN_DISABLE_DENSE16=1, OTGAN_DENSE16_V1=1; tuning knobs kept for measurements:
+ * OTGAN_X3_SPLIT_TARGET (workgroups a K-split weight-gradient GEMM aims for, default 256) and OTGAN_OUTER_CHUNKS
+ * (pixel chunks of the few-channel weight gradient, default 512).
  */
 
 /*
