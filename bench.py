@@ -23,6 +23,78 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16 dense pea
 PEAK_HBM_GBPS = 8000.0
 
 
+def _time_steps(model, x, warmup, steps):
+    import torch
+    for _ in range(warmup):
+        model.step(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model.step(x)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def secondary(dev, a):
+    """Driver-timed numbers for the other BASELINE configurations, measured in this process after the headline
+    (unprofiled wall clock around whole calls, inputs resident in HBM):
+      * the matching block alone (microseconds and TFLOP/s on 36*N^2*D; two-batch, lambda 500) at
+        N = 128 / 256 (the single-GPU problems of configs[1] / [4]) and N = 1024 (the 8-GPU problem of
+        configs[2], whole and as the 256 rows one rank of eight computes);
+      * one DenseNet step (configs[3] shape: 256 img/GPU, 200 Sinkhorn iterations);
+      * one 64x64 step (configs[4] shape: 512 img/GPU = two halves of 256, D = 131072)."""
+    import torch
+    from otgan_amd.trainer import OTGAN, default_args
+    from otgan_amd.utils import matching
+    sec = {}
+    g = torch.Generator(device=dev).manual_seed(5)
+
+    def feats(n, D, shift):
+        c = torch.rand(32, D, device=dev, generator=g) + shift
+        f = (c[torch.randint(0, 32, (n,), device=dev, generator=g)] + 0.1 * torch.randn(n, D, device=dev, generator=g)).abs()
+        return torch.nn.functional.normalize(f, dim=1)
+
+    blocks = []
+    for N, D, L, rows in ((128, 32768, 100, None), (256, 131072, 100, None), (1024, 32768, 100, None),
+                          (1024, 32768, 100, 256), (1024, 7296, 200, 256)):
+        fa = list(torch.chunk(feats(2 * N, D, 0.0), 2, 0))
+        fb = list(torch.chunk(feats(2 * N, D, 0.5) ** 2, 2, 0))
+        fb = [torch.nn.functional.normalize(t, dim=1) for t in fb]
+        call = ((lambda: matching.get_matched_features(fa, fb, 500.0, L)) if rows is None else
+                (lambda: matching.get_matched_features_rows(fa, fb, 500.0, L, 0, rows)))
+        for _ in range(2):
+            call()
+        torch.cuda.synchronize()
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            call()
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / reps * 1e6
+        # algorithmic FLOP: 12 N^2 D cost + 24 N^2 D plan application (rows variant: the rank's share of the latter)
+        flop = 12.0 * N * N * D + 24.0 * N * N * D * (1.0 if rows is None else rows / (2.0 * N))
+        blocks.append({"N": N, "D": D, "iters": L, "rows": "all" if rows is None else rows, "us": round(us, 1),
+                       "tflops": round(flop / us / 1e6, 1)})
+        del fa, fb
+    sec["matching_block"] = {"unit": "microseconds per call (wall, 5 calls); TFLOP/s on 12*N^2*D + 24*N^2*D*(rows/2N)",
+                             "cases": blocks}
+    torch.cuda.empty_cache()
+    for tag, kw, size, bpg, (w, k) in (
+            ("densenet_cfg4_shape", dict(model="densenet", nr_sinkhorn_iter=200), 32, 256, (3, 6)),
+            ("dcgan_64x64_cfg5_shape", dict(model="dcgan", nr_sinkhorn_iter=100, image_size=64), 64, 512, (2, 6))):
+        args = default_args(batch_size=bpg // 2, nr_gpu=2, sinkhorn_lambda=500.0, nr_gen_per_disc=5, seed=1, **kw)
+        m = OTGAN(args, dev)
+        xs = torch.rand(m.nb, size, size, 3, device=dev) * 2 - 1
+        per = _time_steps(m, xs, w, k)
+        sec[tag] = {"images_per_sec": round(m.nb / per, 1), "ms_per_step": round(per * 1e3, 2), "img_per_gpu": bpg,
+                    "steps": k, "warmup": w, "sinkhorn_iters": args.nr_sinkhorn_iter,
+                    "note": "6 timed steps = 1 critic + 5 generator steps (the 5:1 mix), unprofiled wall clock"}
+        m.close()
+        del m, xs
+        torch.cuda.empty_cache()
+    return sec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -34,7 +106,9 @@ def main():
     ap.add_argument("--matching_scope", type=str, default="global")
     ap.add_argument("--image_size", type=int, default=32)
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--no_prof", action="store_true")
+    ap.add_argument("--no_prof", action="store_true", help="skip the second (profiled) pass that feeds `roofline`")
+    ap.add_argument("--no_secondary", action="store_true",
+                    help="skip the secondary measurements (matching block alone, DenseNet cfg4 shape, 64x64 cfg5 shape)")
     a = ap.parse_args()
 
     import torch
@@ -64,9 +138,7 @@ def main():
     for _ in range(a.warmup):
         model.step(x)
     torch.cuda.synchronize()
-    if not a.no_prof:
-        _lib.prof_reset()
-        _lib.prof_enable(True)
+    # ---- pass 1 (the headline `value`): exactly K steps, NO per-launch profiling
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -79,10 +151,21 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if torch.distributed.get_backend() == "gloo" else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    prof = None
+    # ---- pass 2 (feeds `roofline` / `kernel_classes` only): the same K steps with every library launch
+    # bracketed by HIP events on its launch stream (otgan_prof_*).  Never mixed into `value`.
+    prof, dt_prof = None, None
     if not a.no_prof:
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            model.step(x)
+        torch.cuda.synchronize()
+        dt_prof = time.perf_counter() - t1
         prof = _lib.prof_collect()
         _lib.prof_enable(False)
+    parallel.barrier()
 
     if rank != 0:
         return
@@ -102,6 +185,7 @@ def main():
                                f"{a.nr_sinkhorn_iter} Sinkhorn iters, lambda 500, 5:1 generator:critic steps, Adam",
                    "global_batch": world * a.batch_per_gpu, "parallelism": f"dp{world}",
                    "matching_scope": args.matching_scope if world > 1 else "local",
+                   **({"collectives": "forced (RCCL, world size 1)"} if (world == 1 and model.collectives) else {}),
                    "last_distance": float(last["distance"]), "last_entropy": float(last["entropy"]),
                    "precision_note": ("fp32 tensors and fp32 accumulation everywhere; the Winograd-domain GEMMs multiply "
                                       "operands stored as three bf16 pieces (hi+mid+lo = the full 24-bit significand) with six "
@@ -130,8 +214,12 @@ def main():
         try:
             if not (default_cfg or a.model == "densenet"):
                 raise LookupError("no PMC summary for this configuration")
-            with open(os.path.join(ROOT, "profiles", f"r01_pmc_summary_{a.model}.json")) as f:
-                traffic = round(json.load(f)[dom]["hbm_bytes_per_launch"])
+            for rnd in ("r02", "r01"):          # newest committed PMC summary of this configuration
+                fn = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary_{a.model}.json")
+                if os.path.exists(fn):
+                    with open(fn) as f:
+                        traffic = round(json.load(f)[dom]["hbm_bytes_per_launch"])
+                    break
         except Exception:
             pass
         kname = {"wino_gemm": "wino_gemm (wino_bgemm_kernel, fp32 MFMA)",
@@ -140,7 +228,9 @@ def main():
         out["roofline"] = {"bound": "mfma", "kernel": kname.get(dom, dom), "achieved": round(ach, 2),
                            "peak": peak, "unit": "TFLOP/s",
                            "frac": round(ach / peak, 4), "traffic": traffic,
-                           "launches": d["launches"], "avg_ms": round(d["ms"] / max(d["launches"], 1), 4)}
+                           "launches": d["launches"], "avg_ms": round(d["ms"] / max(d["launches"], 1), 4),
+                           "pass": f"second pass of {a.steps} steps with per-launch HIP events "
+                                   f"({dt_prof / a.steps * 1e3:.3f} ms/step; the headline pass ran unprofiled)"}
         if dom == "wino_gemm_bf16x3":
             # six bf16 MFMAs (hi/mid/lo pieces) evaluate one fp32-exact product
             out["roofline"]["fp32_equivalent_tflops"] = round(ach / 6.0, 2)
@@ -148,7 +238,12 @@ def main():
                                      "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flop"] > 0 else None}
                                  for k, v in prof.items() if v["launches"]}
         # wino_gemm launches are nested inside the conv classes: not added again
-        out["kernel_time_frac_of_wall"] = round(sum(v["ms"] for k, v in prof.items() if not k.startswith("wino_gemm")) / (dt * 1e3), 4)
+        out["kernel_time_frac_of_wall"] = round(sum(v["ms"] for k, v in prof.items() if not k.startswith("wino_gemm")) / (dt_prof * 1e3), 4)
+    if world == 1 and not a.no_secondary:
+        model.close()
+        del model, x
+        torch.cuda.empty_cache()
+        out["secondary"] = secondary(dev, a)
     if world == 1 and not a.no_cpu_baseline:
         from oracle import train_step_cpu
         # bounded sample: 2 shards x 16 images (~10 s of CPU work), at most 32 host threads (torch's CPU convs

@@ -130,7 +130,7 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
                            const float* dy, float* dw, void* workspace, size_t workspace_bytes,
                            void* stream);
 
-/* ---- weight normalisation (nn.py:176-181): w = g * V / max(||V||_col, 1e-12) ------------
+/* ---- weight normalisation (nn.py:176-181): w = g * V * rsqrt(max(sum_col V^2, 1e-12)) ------------
  * V, w: [K][Cout] (K = KH*KW*Cin_eff), wT: [Cout][K] (nullable), inv_norm: [Cout].        */
 int otgan_weightnorm_fwd_f32(const float* V, const float* g, int K, int Cout, float* w,
                              float* wT, float* inv_norm, void* stream);

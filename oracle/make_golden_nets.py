@@ -66,6 +66,22 @@ def run_model(mod, tag, B, opts):
     return out
 
 
+def run_critic64(mod):
+    """The reference's DCGAN critic is size-agnostic (models/dcgan.py:7-22): run it, unmodified, on one 64x64
+    image (BASELINE config 5 shape; D = 8*8*2048 = 131072).  Stored in fp32 to keep the fixture small."""
+    base.set_dtype(np.float64)
+    S.reset(seed=zlib.crc32(b"dcgan64") & 0xffff)
+    rs = np.random.RandomState(zlib.crc32(b"xdcgan64") & 0xffff)
+    x = base.T(fp32_uniform(rs, (1, 64, 64, 3)))
+    mod.discriminator(x, init=True)
+    perturb()
+    f = np.asarray(mod.discriminator(x))
+    names = sorted(k for k in S.VARS if k.startswith("discriminator/"))
+    return {"x": np.asarray(x, np.float32), "features": f.astype(np.float32),
+            "var_names": np.array(names),
+            "var_shapes": np.array([",".join(map(str, S.VARS[k].shape)) for k in names])}
+
+
 def run_optimisers(nn):
     """Three applications of each reference update rule in float32 on fixed gradients."""
     base.set_dtype(np.float32)
@@ -106,6 +122,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "nets_optimisers.npz"), **run_optimisers(nn))
     np.savez_compressed(os.path.join(OUT, "nets_dcgan.npz"), **run_model(dcgan, "dcgan", 2, {}))
     np.savez_compressed(os.path.join(OUT, "nets_densenet.npz"), **run_model(densenet, "densenet", 2, {}))
+    np.savez_compressed(os.path.join(OUT, "nets_dcgan_critic64.npz"), **run_critic64(dcgan))
     np.savez_compressed(os.path.join(OUT, "nets_densenet_small_celu.npz"),
                         **run_model(densenet, "densenet_small", 3,
                                     dict(layers_per_block=3, filters_per_layer=8, nonlinearity="celu")))

@@ -109,6 +109,52 @@ def _two_batch_core(fa1, fa2, fb1, fb2, lam, iters, cost_fn):
     return f_aa, f_bb, f_ab, f_ba, entropy, plans, costs
 
 
+def two_batch_plans(fa1, fa2, fb1, fb2, lam, iters, threads=6):
+    """The six plans / costs / mean entropy of the two-batch matching (matching.py:29-61) without the
+    twelve products -- for tests at the 8-GPU problem size (N = 1024), where only some rows of the
+    matched features are compared.  The six independent problems run on a small thread pool (NumPy
+    releases the GIL inside its ufuncs); the arithmetic is sinkhorn_plan()'s, unchanged."""
+    from concurrent.futures import ThreadPoolExecutor
+    pairs = [("a1a2", fa1, fa2), ("b2b1", fb2, fb1), ("a1b1", fa1, fb1),
+             ("a1b2", fa1, fb2), ("a2b1", fa2, fb1), ("a2b2", fa2, fb2)]
+
+    def solve(item):
+        name, x, y = item
+        C = cosine_cost(x, y)
+        M, e, _ = sinkhorn_plan(C, lam, iters)
+        return name, M, C, e
+
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        res = list(ex.map(solve, pairs))
+    plans = {n: M for n, M, _, _ in res}
+    costs = {n: C for n, _, C, _ in res}
+    entropy = sum(e for *_, e in res) / len(res)
+    return plans, costs, entropy
+
+
+def matched_rows(plans, fa1, fa2, fb1, fb2, half, r0, r1):
+    """Rows [r0, r1) of mini-batch `half` (0: a1/b1, 1: a2/b2) of f_aa, f_bb, f_ab, f_ba
+    (matching.py:64-83) from the six plans."""
+    sl = slice(r0, r1)
+    if half == 0:
+        aa = plans["a1a2"][sl] @ fa2
+        bb = plans["b2b1"].T[sl] @ fb2
+        ab = 0.5 * (plans["a1b1"][sl] @ fb1 + plans["a1b2"][sl] @ fb2)
+        ba = 0.5 * (plans["a1b1"].T[sl] @ fa1 + plans["a2b1"].T[sl] @ fa2)
+    else:
+        aa = plans["a1a2"].T[sl] @ fa1
+        bb = plans["b2b1"][sl] @ fb1
+        ab = 0.5 * (plans["a2b1"][sl] @ fb1 + plans["a2b2"][sl] @ fb2)
+        ba = 0.5 * (plans["a1b2"].T[sl] @ fa1 + plans["a2b2"].T[sl] @ fa2)
+    return aa, bb, ab, ba
+
+
+def closed_form_from(plans, costs, N):
+    """SURVEY 3.4 closed form of calc_distance from plans and costs."""
+    W = {k: np.sum(plans[k] * costs[k]) for k in plans}
+    return (W["a1b1"] + W["a1b2"] + W["a2b1"] + W["a2b2"] - 2 * W["a1a2"] - 2 * W["b2b1"]) / (4 * N)
+
+
 def get_matched_features(features_a, features_b, sinkhorn_lambda, nr_sinkhorn_iter,
                          dtype=np.float64):
     """Reference contract (utils/matching.py:11-85): lists of S shards of [B,D] in,

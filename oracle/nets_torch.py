@@ -110,8 +110,9 @@ def dcgan_disc_shapes(nonlinearity="crelu"):
             ("conv2d_2", (5, 5, 256 * m, 512)), ("conv2d_3", (5, 5, 512 * m, 1024))]
 
 
-def dcgan_gen_shapes():
-    return [("dense_0", (100, 2 * 4 * 4 * 1024)), ("conv2d_0", (5, 5, 1024, 1024)),
+def dcgan_gen_shapes(image_size=32):
+    base = image_size // 8        # image_size other than 32: the build's added option (reference hard-codes 32)
+    return [("dense_0", (100, 2 * base * base * 1024)), ("conv2d_0", (5, 5, 1024, 1024)),
             ("conv2d_1", (5, 5, 512, 512)), ("conv2d_2", (5, 5, 256, 256)),
             ("conv2d_3", (5, 5, 128, 3))]
 
@@ -171,7 +172,8 @@ def dcgan_discriminator(x, P, nonlinearity="crelu", scope="discriminator"):
 def dcgan_generator(u, P, scope="generator"):
     """models/dcgan.py:28-52; u: [B,100] uniform(-1,1) noise"""
     B = u.shape[0]
-    x = glu(dense(u, P[f"{scope}/dense_0"], None), 1).reshape(B, 4, 4, 1024)
+    base = int(round(math.sqrt(P[f"{scope}/dense_0"]["V"].shape[1] // 2048)))   # 4 for 32x32 (reference), 8 for 64x64
+    x = glu(dense(u, P[f"{scope}/dense_0"], None), 1).reshape(B, base, base, 1024)
     x = glu(conv2d(x, P[f"{scope}/conv2d_0"], None, 1, True), 3)
     x = glu(conv2d(x, P[f"{scope}/conv2d_1"], None, 1, True), 3)
     x = glu(conv2d(x, P[f"{scope}/conv2d_2"], None, 1, True), 3)

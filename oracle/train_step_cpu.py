@@ -13,12 +13,13 @@ from . import nets_torch as NT
 
 
 class CpuOTGAN:
-    def __init__(self, model="dcgan", nonlinearity="crelu", seed=1, dtype=torch.float32, use_c_matching=True):
+    def __init__(self, model="dcgan", nonlinearity="crelu", seed=1, dtype=torch.float32, use_c_matching=True,
+                 image_size=32):
         g = torch.Generator().manual_seed(seed)
         self.model, self.nl, self.dtype = model, nonlinearity, dtype
         if model == "dcgan":
             self.P = NT.init_params(NT.dcgan_disc_shapes(nonlinearity), "discriminator", g, dtype)
-            self.P.update(NT.init_params(NT.dcgan_gen_shapes(), "generator", g, dtype))
+            self.P.update(NT.init_params(NT.dcgan_gen_shapes(image_size), "generator", g, dtype))
         else:
             self.P = NT.init_params(NT.densenet_disc_shapes(nonlinearity), "discriminator", g, dtype)
             self.P.update(NT.init_params(NT.densenet_gen_shapes(nonlinearity), "generator", g, dtype))
@@ -41,9 +42,19 @@ class CpuOTGAN:
         return (NT.dcgan_discriminator(x, self.P, self.nl) if self.model == "dcgan"
                 else NT.densenet_discriminator(x, self.P, self.nl))
 
-    def gen(self, noise):
-        return (NT.dcgan_generator(noise, self.P) if self.model == "dcgan"
-                else NT.densenet_generator(noise, self.P, self.nl))
+    def gen(self, noise, P=None):
+        P = self.P if P is None else P
+        return (NT.dcgan_generator(noise, P) if self.model == "dcgan"
+                else NT.densenet_generator(noise, P, self.nl))
+
+    def ema_params(self, named_shadow):
+        """Generator parameter dict built from EMA shadows {'generator/conv2d_0/V': tensor, ...}
+        (train.py:75: `generator(ema=ema)` reads every variable through ema.average)."""
+        P = {}
+        for k, v in named_shadow.items():
+            lay, leaf = k.rsplit("/", 1)
+            P.setdefault(lay, {})[leaf] = v.detach().to(self.dtype).cpu()
+        return P
 
     def match(self, f_gen, f_dat, S, lam, iters):
         fa, fb = f_gen.detach().numpy(), f_dat.detach().numpy()
@@ -58,8 +69,10 @@ class CpuOTGAN:
         t = lambda z: torch.as_tensor(z, dtype=self.dtype)
         return t(aa) - t(ab), t(bb) - t(ba), float(dist), float(ent)
 
-    def grads(self, kind, x_data, noise, S, lam, iters):
-        """Gradient lists exactly as train.py:108-130 injects them (summed over shards)."""
+    def grads(self, kind, x_data, noise, S, lam, iters, ema_P=None):
+        """Gradient lists exactly as train.py:108-130 injects them (summed over shards).
+        `ema_P` (critic step only): --train_disc_against_ema, the generated branch comes from the
+        EMA generator (train.py:102-103,119-123)."""
         if kind == "gen":
             x_gen = self.gen(noise)
             with torch.no_grad():
@@ -69,7 +82,7 @@ class CpuOTGAN:
             gr = torch.autograd.grad(f_gen, self.params("generator"), g_gen)
         else:
             with torch.no_grad():
-                x_gen = self.gen(noise)
+                x_gen = self.gen(noise, ema_P)
             f_all = self.disc(torch.cat([x_data, x_gen], 0))
             nb = x_data.shape[0]
             g_gen, g_dat, dist, ent = self.match(f_all[nb:], f_all[:nb], S, lam, iters)

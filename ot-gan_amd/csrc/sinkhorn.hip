@@ -2,6 +2,8 @@
 //   cost Gram blocks (fp32 MFMA, split-K)  ->  log-domain Sinkhorn (potential form, exact
 //   iteration count)  ->  plan application (fp32 MFMA)  ->  distance (fp64 accumulation).
 // Replaces reference utils/matching.py:11-153 and toy_example/matching_cpu.py:4-164.
+#include <stdlib.h>
+
 #include "gemm_tile.h"
 #include "../../include/otgan.h"
 
@@ -398,17 +400,38 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
   if (!ok && t == 0) a.stats[p * 4 + 3] = __builtin_nan("");
 }
 
+// The panel kernel spin-waits across its P*R workgroups, so ALL of them must be resident at once.
+// co_resident_capacity = (workgroups of this kernel one CU can host) x (CUs of the current device),
+// from the occupancy calculator -- on a partitioned / CU-masked device it is smaller than on the
+// full MI355X and the caller falls back to the multi-launch path.  (A device shared with another
+// process can still starve the grid: the spins are bounded and the failure is reported through
+// stats[p][3] = NaN, which poisons entropy and distance -- see entropy_finalize_kernel.)
 template <int TPR>
-void launch_panel(const PanelArgs& a, int P, hipStream_t s) {
+bool launch_panel(const PanelArgs& a, int P, hipStream_t s) {
   constexpr int RPW = kPanelThreads / TPR;
   const size_t lds = sizeof(float) * ((size_t)TPR * 32 * RPW + 1024 + 2 * TPR * RPW);
-  static const bool once = [lds] {
+  static thread_local int cap_dev = -1, capacity = 0;
+  int dev = 0;
+  hipGetDevice(&dev);
+  if (dev != cap_dev) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_panel_kernel<TPR>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    return true;
-  }();
-  (void)once;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sinkhorn_panel_kernel<TPR>, kPanelThreads, lds) !=
+            hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+      (void)hipGetLastError();
+      per_cu = cus = 0;
+    }
+    capacity = per_cu * cus;
+    cap_dev = dev;
+  }
+  int cap = capacity;
+  const char* lim = getenv("OTGAN_PANEL_MAX_WG");   // tests: pretend a smaller / partitioned device
+  if (lim && atoi(lim) >= 0 && atoi(lim) < cap) cap = atoi(lim);
+  if (P * a.R > cap) return false;
   hipLaunchKernelGGL(sinkhorn_panel_kernel<TPR>, dim3(P * a.R), dim3(kPanelThreads), lds, s, a);
+  return true;
 }
 
 // ---- 2b. general sizes: K stays in HBM/L2, two kernels per sweep -------------------------
@@ -588,13 +611,24 @@ __global__ __launch_bounds__(256) void dot3_kernel(const float* __restrict__ a,
   }
 }
 
-__global__ void distance_finalize_kernel(const double* s3, double denom, double* dist) {
+// stats[p][3] is 0 for a solved problem and NaN when the persistent Sinkhorn kernel gave up (its
+// workgroups were not co-resident): adding it in makes entropy AND distance NaN, so a failed
+// matching can never pass for a valid one (the plans / matched features of that call are garbage).
+__device__ __forceinline__ double failure_poison(const double* stats, int P) {
+  double z = 0.0;
+  if (stats)
+    for (int p = 0; p < P; ++p) z += stats[p * 4 + 3];
+  return z;
+}
+
+__global__ void distance_finalize_kernel(const double* s3, double denom, double* dist, const double* stats,
+                                         int P) {
   // (nd_bb + nd_aa - 2 nd_ab) / denom          (matching.py:150,152)
-  dist[0] = (s3[1] + s3[0] - 2.0 * s3[2]) / denom;
+  dist[0] = (s3[1] + s3[0] - 2.0 * s3[2]) / denom + failure_poison(stats, P);
 }
 
 __global__ void entropy_finalize_kernel(const double* stats, int P, int n, float* entropy) {
-  double e = 0.0;
+  double e = failure_poison(stats, P);
   for (int p = 0; p < P; ++p) e += stats[p * 4 + 0] / (double)n;  // mean row entropy (matching.py:57)
   entropy[0] = (float)(e / P);                                     // mean over problems (:61)
 }
@@ -605,7 +639,7 @@ __global__ void entropy_finalize_kernel(const double* stats, int P, int n, float
 __global__ void closed_form_distance_kernel(const double* stats, int N, double* dist) {
   double T[6];
   for (int p = 0; p < 6; ++p) T[p] = stats[p * 4 + 2] - stats[p * 4 + 1];
-  dist[0] = (2.0 * T[0] + 2.0 * T[1] - (T[2] + T[3] + T[4] + T[5])) / (4.0 * N);
+  dist[0] = (2.0 * T[0] + 2.0 * T[1] - (T[2] + T[3] + T[4] + T[5])) / (4.0 * N) + failure_poison(stats, 6);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -691,7 +725,7 @@ int launch_sinkhorn(const float* K, int P, int n, int m, int iters, float lambda
   float* g = fg_ws + (size_t)P * n;
   hipMemsetAsync(stats, 0, sizeof(double) * 4 * P, s);
   if (n == m && n <= 1024) {
-    // persistent panel kernel: all P*R workgroups are co-resident (<= 192 of 256 CUs)
+    // persistent panel kernel: all P*R workgroups must be co-resident (<= 192 of 256 CUs; checked)
     const int rpw = n <= 256 ? 128 : (n <= 512 ? 64 : 32);
     PanelArgs a;
     memset(&a, 0, sizeof(a));
@@ -702,11 +736,13 @@ int launch_sinkhorn(const float* K, int P, int n, int m, int iters, float lambda
     a.fail = reinterpret_cast<unsigned*>(a.g + (size_t)P * n);
     a.plan = plan; a.planT = planT; a.stats = stats;
     hipMemsetAsync(fg_ws, 0, sizeof(unsigned long long) * 2 * (size_t)P * n + sizeof(unsigned), s);
-    if (rpw == 128) launch_panel<8>(a, P, s);
-    else if (rpw == 64) launch_panel<16>(a, P, s);
-    else launch_panel<32>(a, P, s);
-    OTGAN_CHECK_LAUNCH("sinkhorn_panel_kernel");
-    return OTGAN_OK;
+    const bool launched = rpw == 128 ? launch_panel<8>(a, P, s)
+                          : rpw == 64 ? launch_panel<16>(a, P, s) : launch_panel<32>(a, P, s);
+    if (launched) {
+      OTGAN_CHECK_LAUNCH("sinkhorn_panel_kernel");
+      return OTGAN_OK;
+    }
+    // not enough CUs to keep the whole grid resident: multi-launch path below
   }
   hipMemsetAsync(g, 0, sizeof(float) * (size_t)P * m, s);
   const dim3 grow(ceil_div(n, 4), P), gcol(ceil_div(m, 64), P);
@@ -748,14 +784,14 @@ int launch_apply(const ApplyBlock* blocks, int nblocks, int max_rows, int D, lon
 
 int launch_distance(const float* a, const float* b, const float* aa, const float* bb,
                     const float* ab, long total, double denom, double* dist, double* scratch3,
-                    hipStream_t s) {
+                    hipStream_t s, const double* stats = nullptr, int P = 0) {
   hipMemsetAsync(scratch3, 0, 3 * sizeof(double), s);
   long blocks = ceil_div_l(total, 256 * 8);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(dot3_kernel, dim3((int)blocks), dim3(256), 0, s, a, b, aa, bb, ab, total,
                      scratch3);
-  hipLaunchKernelGGL(distance_finalize_kernel, dim3(1), dim3(1), 0, s, scratch3, denom, dist);
+  hipLaunchKernelGGL(distance_finalize_kernel, dim3(1), dim3(1), 0, s, scratch3, denom, dist, stats, P);
   OTGAN_CHECK_LAUNCH("distance kernels");
   return OTGAN_OK;
 }
@@ -875,7 +911,7 @@ int otgan_matching_two_batch_f32(const float* fa, const float* fb, int N, int D,
   hipLaunchKernelGGL(entropy_finalize_kernel, dim3(1), dim3(1), 0, s, w.stats, 6, N, entropy);
   const double denom = (cost_kind == OTGAN_COST_COSINE) ? 2.0 * (2.0 * N)          // matching.py:152
                                                         : 2.0 * (2.0 * N) * (double)D;  // matching_cpu.py:158-163
-  rc = launch_distance(fa, fb, f_aa, f_bb, f_ab, (long)2 * N * D, denom, dist, w.dot3, s);
+  rc = launch_distance(fa, fb, f_aa, f_bb, f_ab, (long)2 * N * D, denom, dist, w.dot3, s, w.stats, 6);
   if (rc) return rc;
   if (stats) hipMemcpyAsync(stats, w.stats, sizeof(double) * 24, hipMemcpyDeviceToDevice, s);
   return OTGAN_OK;
@@ -984,7 +1020,7 @@ int otgan_matching_single_batch_f32(const float* fa, const float* fb, int n, int
   rc = launch_apply(blk, 4, n, D, ldf, ldo, s);
   if (rc) return rc;
   hipLaunchKernelGGL(entropy_finalize_kernel, dim3(1), dim3(1), 0, s, w.stats, 3, n, entropy);
-  rc = launch_distance(fa, fb, f_aa, f_bb, f_ab, (long)n * D, 2.0 * n, dist, w.dot3, s);
+  rc = launch_distance(fa, fb, f_aa, f_bb, f_ab, (long)n * D, 2.0 * n, dist, w.dot3, s, w.stats, 3);
   if (rc) return rc;
   if (stats) hipMemcpyAsync(stats, w.stats, sizeof(double) * 12, hipMemcpyDeviceToDevice, s);
   return OTGAN_OK;

@@ -5,6 +5,7 @@ PyTorch stream; PyTorch only owns the device memory and the backward graph.  The
 fallback: CPU tensors raise OtganError.
 """
 import ctypes
+from collections import OrderedDict
 
 import torch
 
@@ -18,8 +19,11 @@ _ws = {}
 
 
 def workspace(nbytes, device):
-    """Grow-only per-device scratch buffer (caller-provided workspace of the C ABI)."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    """Grow-only scratch buffer per (device, stream) -- the caller-provided workspace of the C ABI.
+    Kernels of one stream run in order, so one buffer per stream is race-free; two trainers driving
+    different streams get different buffers."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(max(nbytes, 1 << 20)), dtype=torch.uint8, device=device)
@@ -84,8 +88,8 @@ def out_hw(H, W, upsample, stride):
 # write parameters through raw pointers, so they bump `weights_epoch` explicitly.
 weights_epoch = 0          # global: bumped when anything may have changed (checkpoint load, tests)
 _storage_epoch = {}        # per storage: bumped by the optimiser / EMA kernels that write into it
-_wcache = {}
-_WCACHE_MAX = 512
+_wcache = OrderedDict()    # id(V) -> (V, g, token, value), least recently used first
+_WCACHE_MAX = 1024         # > 2 networks x (live + EMA) x ~160 layers (DenseNet); entries are evicted one by one
 
 
 def bump_weights_epoch(t=None):
@@ -107,11 +111,13 @@ def cached_weights(V, g, compute):
     token = (weights_epoch, _epoch_of(V), _epoch_of(g), V._version, g._version)
     hit = _wcache.get(key)
     if hit is not None and hit[0] is V and hit[1] is g and hit[2] == token:
+        _wcache.move_to_end(key)
         return hit[3]
     val = compute()
-    if len(_wcache) >= _WCACHE_MAX:
-        _wcache.clear()
     _wcache[key] = (V, g, token, val)      # holding V keeps id(V) from being reused
+    _wcache.move_to_end(key)
+    while len(_wcache) > _WCACHE_MAX:      # evict the least recently used entry only
+        _wcache.popitem(last=False)
     return val
 
 
@@ -211,7 +217,9 @@ class Conv2dFunction(torch.autograd.Function):
         _need_cuda(x, V, g, b)
         x = x.contiguous()
         N, H, W, C = x.shape
-        KH, KW, Cin_eff, Cout = V.shape
+        # a dense layer passes its [Cin_eff, Cout] variable as is (a 1x1 filter): the weight cache is keyed by
+        # the parameter OBJECT, so a fresh .view() per call would miss every time and pin a new entry
+        KH, KW, Cin_eff, Cout = V.shape if V.dim() == 4 else (1, 1) + tuple(V.shape)
         if Cin_eff != C * (2 if preact in DOUBLED else 1):
             raise ValueError(f"weight expects {Cin_eff} effective input channels, input gives "
                              f"{C * (2 if preact in DOUBLED else 1)}")
@@ -278,7 +286,7 @@ def conv2d_op(x, V, g, b, stride=1, upsample=False, preact=0, segs=None):
 def dense_op(x, V, g, b, preact=0, segs=None):
     """x: [N, Cin]; V: [Cin_eff, Cout]  (reference nn.py:314-325) -- a 1x1 conv on a 1x1 image."""
     N, C = x.shape
-    y = Conv2dFunction.apply(x.view(N, 1, 1, C), V.view(1, 1, *V.shape), g, b, 1, False,
+    y = Conv2dFunction.apply(x.view(N, 1, 1, C), V, g, b, 1, False,
                              int(preact), tuple(segs) if segs else None)
     return y.view(N, -1)
 

@@ -26,7 +26,8 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("OTGAN_FORCE_COLLECTIVES") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -44,6 +45,15 @@ def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def _skip_collectives():
+    """World size 1 needs no exchange.  OTGAN_FORCE_COLLECTIVES=1 (tests, bench.py --force_collectives) runs the
+    collective code path anyway on an initialised 1-rank group, so that the RCCL calls, their stream ordering and
+    the bucket hooks are exercised on a single-GPU box."""
+    if world_size() > 1:
+        return False
+    return not (dist.is_initialized() and os.environ.get("OTGAN_FORCE_COLLECTIVES") == "1")
+
+
 def get_rank():
     return dist.get_rank() if dist.is_initialized() else 0
 
@@ -56,7 +66,7 @@ def _staged():
 def all_gather_rows(x):
     """[n, D] per rank -> [world*n, D] in rank order (one collective)."""
     w = world_size()
-    if w == 1:
+    if _skip_collectives():
         return x
     x = x.contiguous()
     if _staged() and x.is_cuda:
@@ -84,7 +94,7 @@ class PendingGather:
 
 def all_gather_rows_async(x):
     w = world_size()
-    if w == 1:
+    if _skip_collectives():
         return PendingGather(x, None)
     x = x.contiguous()
     if _staged() and x.is_cuda:
@@ -113,7 +123,7 @@ def local_rows(flat_global, rows_per_rank):
 def allreduce_sum_(tensors):
     """SUM all-reduce of a list of tensors through ONE flat bucket; returns the reduced tensors (a single large
     collective suits xGMI's point-to-point links better than many small ones)."""
-    if world_size() == 1 or not tensors:
+    if _skip_collectives() or not tensors:
         return tensors
     flat = torch.cat([t.reshape(-1) for t in tensors])
     if _staged() and flat.is_cuda:
@@ -143,9 +153,17 @@ class GradBuckets:
     views of the flat buffer, in the order of `params`.  Hooks only act between `arm()` and
     `finish()`, so variables that are evaluated without being differentiated are unaffected."""
 
+    _live = {}      # id(first param) -> the instance whose hooks are installed on that parameter set
+
     def __init__(self, params, nbuckets=4):
         self.params = list(params)
         n = len(self.params)
+        # a second trainer over the same (module-level, shared) variables replaces the first one's
+        # hooks instead of stacking a second set on top
+        old = GradBuckets._live.get(id(self.params[0]))
+        if old is not None:
+            old.remove()
+        GradBuckets._live[id(self.params[0])] = self
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=self.params[0].dtype, device=self.params[0].device)
         self.views = [None] * n
@@ -166,8 +184,16 @@ class GradBuckets:
                 lo, cnt = off, 0
         self.armed = False
         self.left, self.works = [], []
-        for i, p in enumerate(self.params):
-            p.register_hook(lambda g, i=i: self._on_grad(i, g))
+        self.handles = [p.register_hook(lambda g, i=i: self._on_grad(i, g)) for i, p in enumerate(self.params)]
+
+    def remove(self):
+        """Uninstall the tensor hooks (the instance is dead afterwards)."""
+        for h in self.handles:
+            h.remove()
+        self.handles = []
+        self.armed = False
+        if GradBuckets._live.get(id(self.params[0])) is self:
+            del GradBuckets._live[id(self.params[0])]
 
     def arm(self):
         self.armed = True

@@ -9,7 +9,11 @@ matching problem (it must be even, train.py:34) -- and is decoupled from the num
 physical GPUs (= torch.distributed world size): every rank owns nr_gpu / world shards.
 
 Added flags (not in the reference): --synthetic (random CIFAR-shaped data instead of the
-pickled dataset), --matching_scope global|local, --max_steps, --image_size.
+pickled dataset), --synthetic_size, --matching_scope global|local, --max_steps, --image_size, --save_every.
+
+Checkpoints (`<save_dir>/med_gan_params-<epoch>`, the reference's naming, train.py:275-277) are torch pickles
+of {variable name: tensor} plus optimiser moments / step count and EMA shadows (which the reference's
+Saver omits); they are not TensorFlow checkpoints.
 """
 import argparse
 import os
@@ -47,6 +51,8 @@ def build_parser():
     p.add_argument('--matching_scope', type=str, default='global', choices=['global', 'local'])
     p.add_argument('--max_steps', type=int, default=0, help='stop after this many steps (0 = run like the reference)')
     p.add_argument('--image_size', type=int, default=32)
+    p.add_argument('--save_every', type=int, default=200, help='checkpoint every this many epochs (reference: 200, train.py:275)')
+    p.add_argument('--synthetic_size', type=int, default=50000, help='number of synthetic images with --synthetic')
     return p
 
 
@@ -105,7 +111,7 @@ def main(argv=None):
         print("model has a hidden representation with %d features" % model.num_features)   # train.py:56
 
     if args.synthetic:
-        trainx = np.random.rand(50000, args.image_size, args.image_size, 3).astype(np.float32) * 2 - 1
+        trainx = np.random.rand(args.synthetic_size, args.image_size, args.image_size, 3).astype(np.float32) * 2 - 1
     else:
         trainx = load_cifar(args.data_dir)
     per_step = args.nr_gpu * args.batch_size
@@ -140,6 +146,7 @@ def main(argv=None):
             total += 1
             if args.max_steps and total >= args.max_steps:
                 break
+        model.check_finite()        # one sync per logging interval (a failed Sinkhorn launch poisons the scalars)
         f = lambda lst: float(torch.stack([z.double() for z in lst]).mean()) if lst else float('nan')
         mean_dist_gen.append(f(dg))
         mean_dist_disc.append(f(dd))
@@ -149,7 +156,7 @@ def main(argv=None):
                                                    mean_dist_disc[-1], f(ent)))          # train.py:231
             save_tile_png(model.sample(100), os.path.join(args.save_dir, 'sample%d.png' % epoch))
             save_tile_png(model.sample(100, ema=True), os.path.join(args.save_dir, 'ema_sample%d.png' % epoch))
-            if (epoch + 1) % 200 == 0 and epoch != current_epoch:                          # train.py:275-277
+            if (epoch + 1) % args.save_every == 0 and epoch != current_epoch:                          # train.py:275-277
                 torch.save(model.state_dict(), os.path.join(args.save_dir, 'med_gan_params-%d' % epoch))
                 np.savez(os.path.join(args.save_dir, 'distances.npz'), mean_dist_gen=np.array(mean_dist_gen),
                          mean_dist_disc=np.array(mean_dist_disc))

@@ -43,6 +43,12 @@ class OTGAN:
         self.scope = getattr(args, "matching_scope", "global")
         if self.world == 1:
             self.scope = "local"
+        if self.scope == "global" and self.world % 2 != 0:
+            # a rank's rows must lie inside ONE mini-batch half (shards [0,S/2) | [S/2,S), matching.py:16-19)
+            raise ValueError(f"global matching scope needs an even number of ranks (got {self.world}): with an odd "
+                             "count one rank's shards straddle the two mini-batch halves; use --matching_scope local")
+        # world size 1 with OTGAN_FORCE_COLLECTIVES=1: run the RCCL calls anyway (single-GPU readiness test)
+        self.collectives = not parallel._skip_collectives()
         if self.scope == "local" and self.shards % 2 != 0:
             raise ValueError("local matching needs an even number of shards per rank")
         self.nb = self.shards * args.batch_size             # images per rank per step
@@ -74,7 +80,7 @@ class OTGAN:
         kw = {"mom1": 0.5} if args.optimizer == "nesterov" else {"mom1": 0.5, "mom2": 0.999}
         # more than one rank: the gradient all-reduce runs bucket by bucket underneath the backward pass
         # (OTGAN_GRAD_OVERLAP=0: one all-reduce after the backward pass instead)
-        overlap = self.world > 1 and os.environ.get("OTGAN_GRAD_OVERLAP", "1") != "0"
+        overlap = self.collectives and os.environ.get("OTGAN_GRAD_OVERLAP", "1") != "0"
         self.disc_buckets = parallel.GradBuckets(self.disc_params) if overlap else None
         self.gen_buckets = parallel.GradBuckets(self.gen_params) if overlap else None
         self.gen_optimizer = mk[args.optimizer](self.gen_params, **kw)          # train.py:142
@@ -101,6 +107,8 @@ class OTGAN:
                     fa, fb, a.sinkhorn_lambda, a.nr_sinkhorn_iter, self.rank * self.nb, self.nb, K)
                 return outs[0] - outs[2], outs[1] - outs[3], dist, ent
         else:
+            if pending_dat is not None:       # forced-collective mode at world size 1: same rows, via RCCL
+                f_dat = pending_dat.wait()
             fa = list(torch.chunk(f_gen, self.shards, 0))
             fb = list(torch.chunk(f_dat, self.shards, 0))
         if a.single_batch:
@@ -118,23 +126,9 @@ class OTGAN:
         return grad_gen, grad_dat, dist, m[4]
 
     def _sharded_log_kernels(self, f_gen, f_dat, fa, fb):
-        lam = self.args.sinkhorn_lambda
-        h = len(fa) // 2
-        a1, a2 = torch.cat(fa[:h], 0), torch.cat(fa[h:], 0)
-        b1, b2 = torch.cat(fb[:h], 0), torch.cat(fb[h:], 0)
-        N = a1.shape[0]
-        first = self.rank < self.world // 2
-        if first:   # my rows belong to a1 / b1
-            mine = [matching.cost_log_kernel(f_gen, y, lam) for y in (a2, b1, b2)]      # p0, p2, p3
-        else:       # my rows belong to a2 / b2
-            mine = [matching.cost_log_kernel(f_dat, b1, lam),                            # p1 (b2,b1)
-                    matching.cost_log_kernel(f_gen, b1, lam),                            # p4 (a2,b1)
-                    matching.cost_log_kernel(f_gen, b2, lam)]                            # p5 (a2,b2)
-        allk = parallel.all_gather_rows(torch.stack(mine, 0).unsqueeze(0))              # [W,3,nb,N]
-        W2 = self.world // 2
-        lo = allk[:W2].permute(1, 0, 2, 3).reshape(3, N, N)     # problems 0, 2, 3
-        hi = allk[W2:].permute(1, 0, 2, 3).reshape(3, N, N)     # problems 1, 4, 5
-        return torch.stack([lo[0], hi[0], lo[1], lo[2], hi[1], hi[2]], 0).contiguous()
+        mine = rank_log_kernel_slices(self.rank, self.world, f_gen, f_dat, fa, fb, self.args.sinkhorn_lambda)
+        allk = parallel.all_gather_rows(mine.unsqueeze(0))                              # [W,3,nb,N]
+        return assemble_log_kernels(allk, self.world)
 
     # ---------------------------------------------------------------- one sess.run
     def step(self, x_data, noise=None, apply_updates=True):
@@ -169,7 +163,8 @@ class OTGAN:
             # the real-data features are final here: start their all-gather now, it overlaps the
             # generator forward and the second critic pass
             pending = (parallel.all_gather_rows_async(f_dat)
-                       if (self.scope == "global" and self.world > 1) else None)
+                       if (self.scope == "global" and self.world > 1) or (self.collectives and self.world == 1)
+                       else None)
             x_gen = self.generator(batch_size=self.nb, device=self.device, **gkw)
             # only the generator's variables are differentiated in this step (train.py:112): run the critic with
             # its variables frozen, so that its layers skip their weight gradients (autograd's needs_input_grad
@@ -195,20 +190,86 @@ class OTGAN:
     def sample(self, n, ema=False):
         return self.generator(batch_size=n, ema=self.ema if ema else None, device=self.device, **self.model_opts)
 
-    def state_dict(self):
+    # ---------------------------------------------------------------- checkpoint (train.py:60,190-193,275-277)
+    def state_dict(self, full=True):
+        """Variables under the reference's names ('discriminator/conv2d_0/V', ...) + the step counter --
+        what the reference's Saver(trainable_variables) keeps (train.py:60) -- and, with `full` (default;
+        SURVEY 8f-3), what it omits: the optimisers' moments and step count and the EMA shadows, so
+        that a resumed run continues bit for bit instead of restarting Adam at t = 1 with an
+        untrained EMA generator.  Format: a torch-pickled dict of CPU tensors (not a TF checkpoint)."""
         sd = {"step_counter": self.step_counter}
         for t in (self.discriminator, self.generator):
             sd.update({k: v.detach().cpu() for k, v in t.named_variables().items()})
+        if full:
+            sd["__optim__"] = {"gen": self.gen_optimizer.state_dict(), "disc": self.disc_optimizer.state_dict()}
+            names = list(self.generator.named_variables())
+            sd["__ema__"] = {n: self.ema.average(p).detach().cpu() for n, p in zip(names, self.gen_params)}
         return sd
 
     def load_state_dict(self, sd):
+        from . import ops
         with torch.no_grad():
             for t in (self.discriminator, self.generator):
                 for k, v in t.named_variables().items():
                     v.copy_(sd[k].to(v.device))
-        from . import ops
+            names = list(self.generator.named_variables())
+            ema = sd.get("__ema__")
+            for n, p in zip(names, self.gen_params):
+                # a weights-only checkpoint (the reference's kind): the shadows restart AT the loaded
+                # weights, as tf.train.ExponentialMovingAverage initialises them -- never at the random init
+                src = ema[n].to(p.device) if ema is not None else p.detach()
+                self.ema.average(p).copy_(src)
+        opt = sd.get("__optim__")
+        if opt is not None:
+            self.gen_optimizer.load_state_dict(opt["gen"])
+            self.disc_optimizer.load_state_dict(opt["disc"])
         ops.bump_weights_epoch()
         self.step_counter = int(sd.get("step_counter", 0))
+
+    def check_finite(self):
+        """Synchronising sanity check of the last step's scalars (the persistent Sinkhorn kernel
+        reports a failed -- not co-resident -- launch by poisoning entropy and distance with NaN).
+        The hot loop never calls this; train.py does once per logging interval."""
+        for k in ("distance", "entropy"):
+            v = self.last.get(k)
+            if v is not None and not bool(torch.isfinite(v)):
+                raise FloatingPointError(f"non-finite matching {k} in step {self.step_counter - 1}: the Sinkhorn "
+                                         "kernel failed (device shared / partitioned?) or the model diverged")
+
+    def close(self):
+        """Uninstall the gradient-bucket hooks from the (module-level, shared) variables."""
+        for b in (self.disc_buckets, self.gen_buckets):
+            if b is not None:
+                b.remove()
+        self.disc_buckets = self.gen_buckets = None
+
+
+def rank_log_kernel_slices(rank, world, f_gen, f_dat, fa, fb, lam):
+    """The three [nb, N] log-kernel row slices rank `rank` of `world` computes, exactly the reference's
+    row sharding of the cost GEMMs (matching.py:29-39): a rank of the first half owns rows of a1 / b1 and
+    makes its rows of (a1,a2) (a1,b1) (a1,b2); a rank of the second half owns rows of a2 / b2 and makes
+    its rows of (b2,b1) (a2,b1) (a2,b2).  f_gen / f_dat: the rank's own [nb, D] features; fa / fb: the
+    gathered global shard lists.  Returns [3, nb, N]."""
+    h = len(fa) // 2
+    a2 = torch.cat(fa[h:], 0)
+    b1, b2 = torch.cat(fb[:h], 0), torch.cat(fb[h:], 0)
+    if rank < world // 2:   # my rows belong to a1 / b1
+        mine = [matching.cost_log_kernel(f_gen, y, lam) for y in (a2, b1, b2)]      # p0, p2, p3
+    else:                   # my rows belong to a2 / b2
+        mine = [matching.cost_log_kernel(f_dat, b1, lam),                            # p1 (b2,b1)
+                matching.cost_log_kernel(f_gen, b1, lam),                            # p4 (a2,b1)
+                matching.cost_log_kernel(f_gen, b2, lam)]                            # p5 (a2,b2)
+    return torch.stack(mine, 0)
+
+
+def assemble_log_kernels(allk, world):
+    """[world, 3, nb, N] all-gathered slices -> the six [N, N] log-kernels in the reference's problem order
+    a1a2, b2b1, a1b1, a1b2, a2b1, a2b2 (matching.py:41-43)."""
+    W2 = world // 2
+    N = allk.shape[3]
+    lo = allk[:W2].permute(1, 0, 2, 3).reshape(3, N, N)     # problems 0, 2, 3
+    hi = allk[W2:].permute(1, 0, 2, 3).reshape(3, N, N)     # problems 1, 4, 5
+    return torch.stack([lo[0], hi[0], lo[1], lo[2], hi[1], hi[2]], 0).contiguous()
 
 
 def default_args(**over):
@@ -219,7 +280,8 @@ def default_args(**over):
              nonlinearity='crelu', nr_gpu=8, nr_gen_per_disc=5, sinkhorn_lambda=500.,
              nr_sinkhorn_iter=500, single_batch=False, train_disc_against_ema=False, model='dcgan',
              load_params=False, model_name='med_gan_params-2399', no_sinkhorn=False,
-             image_size=32, matching_scope='global', synthetic=False, max_steps=0)
+             image_size=32, matching_scope='global', synthetic=False, max_steps=0, save_every=200,
+             synthetic_size=50000)
     d.update(over)
     return argparse.Namespace(**d)
 

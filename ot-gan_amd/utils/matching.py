@@ -31,7 +31,10 @@ _ws_cache = {}
 
 
 def _workspace(nbytes, device):
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    # one grow-only buffer per (device, stream): calls on one stream are ordered, calls on different
+    # streams (two trainers in one process) must not share scratch
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)

@@ -365,6 +365,21 @@ class _Updates:
                     self._step(p, g.contiguous(), st, lr)
         self.t += 1.0
 
+    # checkpointing (the reference saves no optimiser state, train.py:60; SURVEY 8f-3 asks for it)
+    def state_dict(self):
+        return {"t": self.t, "slots": [{k: (None if v is None else v.detach().cpu()) for k, v in st.items()}
+                                       for st in self.state]}
+
+    def load_state_dict(self, sd):
+        self.t = float(sd["t"])
+        targets = [self.group.flat] if self.group is not None else self.params
+        if len(sd["slots"]) != len(self.state):
+            raise ValueError("optimiser state does not match this parameter layout")
+        for st, saved, p in zip(self.state, sd["slots"], targets):
+            st.clear()
+            for k, v in saved.items():
+                st[k] = None if v is None else v.to(p.device).clone()
+
 
 class _Adam(_Updates):
     def _step(self, p, g, st, lr):

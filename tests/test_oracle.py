@@ -109,3 +109,26 @@ def test_permutation_equivariance():
     np.testing.assert_allclose(out2[0][0], out[0][0][p], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(out2[2][0], out[2][0][p], rtol=1e-9, atol=1e-12)
     assert out2[4] == pytest.approx(out[4], rel=1e-10)
+
+
+def test_row_helpers_agree_with_full_two_batch():
+    """two_batch_plans / matched_rows / closed_form_from (used by the N = 1024 rank tests) are the same
+    arithmetic as get_matched_features / calc_distance."""
+    rng = np.random.RandomState(3)
+    S, B, D = 4, 6, 40
+    ca, cb = rng.randn(4, D), rng.randn(4, D)
+    fa = [M.clustered_features(rng, B, D, ca) for _ in range(S)]
+    fb = [M.clustered_features(rng, B, D, cb) for _ in range(S)]
+    ref = M.get_matched_features(fa, fb, 200.0, 17)
+    fa1, fa2 = np.concatenate(fa[:2]), np.concatenate(fa[2:])
+    fb1, fb2 = np.concatenate(fb[:2]), np.concatenate(fb[2:])
+    plans, costs, ent = M.two_batch_plans(fa1, fa2, fb1, fb2, 200.0, 17)
+    assert ent == pytest.approx(ref[4], rel=1e-13)
+    N = 2 * B
+    for half in (0, 1):
+        rows = M.matched_rows(plans, fa1, fa2, fb1, fb2, half, 3, 9)
+        for got, full in zip(rows, ref[:4]):
+            want = np.concatenate(full)[half * N + 3: half * N + 9]
+            np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-14)
+    d = M.closed_form_from(plans, costs, N)
+    assert d == pytest.approx(M.calc_distance(fa, fb, ref), rel=1e-9)

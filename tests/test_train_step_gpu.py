@@ -184,3 +184,103 @@ def test_checkpoint_roundtrip_and_learning_signal(dev, tmp_path):
     for a, b in zip(m.gen_params + m.disc_params, m2.gen_params + m2.disc_params):
         assert torch.equal(a.detach(), b.detach())
     assert m2.step_counter == m.step_counter
+
+
+# ------------------------------------------------------------------ tighter step-level / mode parity (round 2)
+def _named(m):
+    named = {}
+    named.update(m.discriminator.named_variables())
+    named.update(m.generator.named_variables())
+    return named
+
+
+@pytest.mark.parametrize("model,size", [("dcgan", 32), ("densenet", 32), ("dcgan", 64)])
+@pytest.mark.parametrize("kind", ["disc", "gen"])
+def test_well_conditioned_step_gradients(dev, model, size, kind):
+    """Whole-step numerics in a well-conditioned setting: ELU (no CReLU sign flips), lambda = 20, 10 sweeps
+    (no lambda-amplified cancellation).  EVERY gradient tensor of the step must match the fp64 oracle step to
+    2e-4 relative L2, distance and entropy to 1e-4 (the loose CReLU / lambda = 100 case above pins wiring only).
+    size = 64 is BASELINE configs[4]'s shape (generator stem 8x8, D = 65536 with ELU)."""
+    from otgan_amd.trainer import OTGAN, default_args
+    lam, iters = 20.0, 10
+    args = default_args(model=model, batch_size=3, nr_gpu=2, sinkhorn_lambda=lam, nr_sinkhorn_iter=iters,
+                        nr_gen_per_disc=1, seed=5, nonlinearity="elu", image_size=size)
+    m = OTGAN(args, dev)
+    if kind == "gen":
+        m.step_counter = 1
+    gen = torch.Generator().manual_seed(12)
+    x = torch.rand(m.nb, size, size, 3, generator=gen) * 2 - 1
+    noise = _noise(model, m.nb, gen)
+    to_dev = lambda z: [t.to(dev) for t in z] if isinstance(z, list) else z.to(dev)
+    r = m.step(x.to(dev), noise=to_dev(noise), apply_updates=False)
+    assert r["kind"] == kind
+    o = CpuOTGAN(model, "elu", dtype=torch.float64, use_c_matching=False, image_size=size)
+    o.load(_named(m))
+    to64 = lambda z: [t.double() for t in z] if isinstance(z, list) else z.double()
+    gr, dist, ent = o.grads(kind, x.double(), to64(noise), 2, lam, iters)
+    assert float(r["distance"]) == pytest.approx(dist, rel=1e-4, abs=1e-7)
+    assert float(r["entropy"]) == pytest.approx(ent, rel=1e-4)
+    names = list((m.generator if kind == "gen" else m.discriminator).named_variables())
+    worst = max((_rel(a, b), n) for n, a, b in zip(names, r["grads"], gr))
+    assert worst[0] < 2e-4, worst
+
+
+def test_ema_critic_step_matches_oracle(dev):
+    """--train_disc_against_ema (train.py:102-103,119-123): on a critic step the generated branch is the EMA
+    generator's samples (and its own matching).  After one critic + one generator update the shadows differ
+    from the weights; the next critic step is compared with the oracle fed the same shadows."""
+    from otgan_amd.trainer import OTGAN, default_args
+    lam, iters = 20.0, 10
+    args = default_args(model="dcgan", batch_size=3, nr_gpu=2, sinkhorn_lambda=lam, nr_sinkhorn_iter=iters,
+                        nr_gen_per_disc=1, seed=8, nonlinearity="elu", train_disc_against_ema=True,
+                        learning_rate_gen=0.05)       # large step: shadows and weights clearly apart
+    m = OTGAN(args, dev)
+    gen = torch.Generator().manual_seed(13)
+    x = (torch.rand(m.nb, 32, 32, 3, generator=gen) * 2 - 1).to(dev)
+    u = (torch.rand(m.nb, 100, generator=gen) * 2 - 1).to(dev)
+    m.step(x, noise=u)        # critic update
+    m.step(x, noise=u)        # generator update + EMA
+    names_g = list(m.generator.named_variables())
+    shadow = {n: m.ema.average(p) for n, p in zip(names_g, m.gen_params)}
+    p0 = m.gen_params[0]
+    assert _rel(shadow[names_g[0]], p0) > 1e-5                       # the EMA generator is a different network
+    r = m.step(x, noise=u, apply_updates=False)
+    assert r["kind"] == "disc"
+    o = CpuOTGAN("dcgan", "elu", dtype=torch.float64, use_c_matching=False)
+    o.load(_named(m))
+    gr, dist, ent = o.grads("disc", x.double().cpu(), u.double().cpu(), 2, lam, iters, ema_P=o.ema_params(shadow))
+    assert float(r["distance"]) == pytest.approx(dist, rel=1e-4, abs=1e-7)
+    assert float(r["entropy"]) == pytest.approx(ent, rel=1e-4)
+    names = list(m.discriminator.named_variables())
+    worst = max((_rel(a, b), n) for n, a, b in zip(names, r["grads"], gr))
+    assert worst[0] < 2e-4, worst
+    # and it is NOT what the live generator would give
+    gr_live, dist_live, _ = o.grads("disc", x.double().cpu(), u.double().cpu(), 2, lam, iters)
+    assert abs(dist_live - dist) > 1e-3 * abs(dist)
+
+
+@pytest.mark.parametrize("opt", ["adamax", "nesterov"])
+def test_adamax_nesterov_through_trainer(dev, opt):
+    """--optimizer adamax / nesterov through the trainer: two critic updates on fixed inputs reproduce the
+    oracle's update rule (nn.py:29-48,75-87) applied to the trainer's own gradients; lr = -lr for the critic
+    (train.py:143); train.py:142-149 passes mom1 = 0.5 (and mom2 = 0.999 to adamax)."""
+    from otgan_amd.trainer import OTGAN, default_args
+    args = default_args(model="dcgan", batch_size=2, nr_gpu=2, sinkhorn_lambda=50.0, nr_sinkhorn_iter=5,
+                        nr_gen_per_disc=10 ** 6, seed=4, optimizer=opt, learning_rate_disc=1e-3)
+    m = OTGAN(args, dev)
+    x = torch.rand(m.nb, 32, 32, 3, device=dev) * 2 - 1
+    u = torch.rand(m.nb, 100, device=dev) * 2 - 1
+    upd = NT.adamax_update if opt == "adamax" else NT.nesterov_update
+    states = None
+    for it in range(2):
+        p_before = [p.detach().double().cpu() for p in m.disc_params]
+        m.step_counter = 0
+        grads = [g.double().cpu() for g in m.step(x, noise=u, apply_updates=False)["grads"]]
+        m.step_counter = 0
+        m.step(x, noise=u)
+        if states is None:
+            states = [{"v": torch.zeros_like(p), "mg": torch.zeros_like(p)} for p in p_before]
+        for p, p0, g, st in zip(m.disc_params, p_before, grads, states):
+            kw = dict(mom1=0.5, mom2=0.999) if opt == "adamax" else dict(mom1=0.5)
+            ref = upd(p0, g, st, -args.learning_rate_disc, **kw)
+            assert _rel(p, ref) < 1e-6, (opt, it)
