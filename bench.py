@@ -257,7 +257,15 @@ def main():
                                "sample": f"one generator step ({best['gen']:.2f} s) + one critic step "
                                          f"({best['disc']:.2f} s) of the oracle (PyTorch-CPU fp32 nets + C "
                                          f"Sinkhorn) at {nb} img/step (2 shards x {bps}), combined 5:1"}
-    print(json.dumps(out))
+    # the JSON line is the LAST thing on stdout: flush the C-level buffers first (RCCL prints a banner through
+    # printf that would otherwise surface after Python's own output)
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

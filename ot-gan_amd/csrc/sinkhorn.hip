@@ -23,9 +23,16 @@ struct CostArgs {
   long ldf;
   int kt_per_split;
   float* ws;  // [nsplit][P][n][m]
+  // FUSE (one K split): the epilogue writes K = -lambda * cost directly, no partials, no finish kernel
+  float* K;   // [P][n][m]
+  float lambda, inv_d;
+  int cost_kind;
+  const float* xsq[kMaxProb];
+  const float* ysq[kMaxProb];
+  float diag[kMaxProb];
 };
 
-template <bool VEC>
+template <bool VEC, bool FUSE>
 __global__ __launch_bounds__(256) void cost_partial_kernel(CostArgs a) {
   using LA = MatLoaderK<SCfg, 128, VEC>;
   using LB = MatLoaderK<SCfg, 128, VEC>;
@@ -45,12 +52,28 @@ __global__ __launch_bounds__(256) void cost_partial_kernel(CostArgs a) {
   typename SCfg::acc_t acc[SCfg::MT][SCfg::NT];
   zero_acc<SCfg>(acc);
   gemm_mainloop<SCfg>(la, lb, nkt, smem, acc);
-  float* out = a.ws + ((long)split * a.P + p) * a.n * a.m;
   const int n = a.n, m = a.m;
-  foreach_acc<SCfg>(acc, [&](int r, int c, int, int, int, float v) {
-    const int row = tmi * 128 + r, col = tni * 128 + c;
-    if (row < n && col < m) out[(long)row * m + col] = v;
-  });
+  if (FUSE) {
+    float* out = a.K + (long)p * n * m;
+    const float lam = a.lambda, inv_d = a.inv_d, dg = a.diag[p];
+    const bool cosine = a.cost_kind == OTGAN_COST_COSINE;
+    const float* xs = a.xsq[p];
+    const float* ys = a.ysq[p];
+    foreach_acc<SCfg>(acc, [&](int r, int c, int, int, int, float v) {
+      const int row = tmi * 128 + r, col = tni * 128 + c;
+      if (row < n && col < m) {
+        float cst = cosine ? 1.f - v : xs[row] + ys[col] - v * inv_d;
+        if (row == col) cst += dg;
+        out[(long)row * m + col] = -lam * cst;
+      }
+    });
+  } else {
+    float* out = a.ws + ((long)split * a.P + p) * n * m;
+    foreach_acc<SCfg>(acc, [&](int r, int c, int, int, int, float v) {
+      const int row = tmi * 128 + r, col = tni * 128 + c;
+      if (row < n && col < m) out[(long)row * m + col] = v;
+    });
+  }
 }
 
 struct FinishArgs {
@@ -654,7 +677,12 @@ inline CostPlan plan_cost(int P, int n, int m, int D) {
   CostPlan c;
   c.tiles = ceil_div(n, 128) * ceil_div(m, 128);
   const int nkt = ceil_div(D, SCfg::BK);
-  int want = ceil_div(768, c.tiles * P);  // aim for ~3 workgroups per CU
+  // K splits.  With at least one tile per CU (256) no split is needed: the GEMM epilogue writes the
+  // log-kernel itself (no partial sums in memory at all).  Small problems (N = 128: 6 tiles) need the
+  // parallelism: ~2 workgroups per CU (OTGAN_COST_WG_TARGET, default 512; 768 = 3 per CU wrote 1.5x the
+  // partial sums for the same time), reduced by cost_finish_kernel.
+  static const int target = [] { const char* e = getenv("OTGAN_COST_WG_TARGET"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+  int want = c.tiles * P >= 256 ? 1 : ceil_div(target, c.tiles * P);
   if (want < 1) want = 1;
   if (want > nkt) want = nkt;
   c.kt_per_split = ceil_div(nkt, want);
@@ -688,14 +716,27 @@ int launch_cost(const float* const* X, const float* const* Y, const float* const
   ca.P = P; ca.n = n; ca.m = m; ca.D = D; ca.ldf = ldf;
   ca.kt_per_split = cp.kt_per_split;
   ca.ws = partial_ws;
+  ca.K = K; ca.lambda = lambda; ca.inv_d = 1.f / (float)D; ca.cost_kind = cost_kind;
+  for (int p = 0; p < P; ++p) {
+    ca.xsq[p] = xsq ? xsq[p] : nullptr;
+    ca.ysq[p] = ysq ? ysq[p] : nullptr;
+    ca.diag[p] = diag ? diag[p] : 0.f;
+  }
+  const bool fuse = cp.nsplit == 1;
   dim3 grid(cp.tiles, cp.nsplit, P);
   {
     ProfScope ps(OTGAN_PROF_COST_GEMM, 2.0 * P * n * (double)m * D,
                  4.0 * P * ((double)n + m) * D, s);
-    if (vec) hipLaunchKernelGGL(cost_partial_kernel<true>, grid, dim3(256), 0, s, ca);
-    else hipLaunchKernelGGL(cost_partial_kernel<false>, grid, dim3(256), 0, s, ca);
+    if (fuse) {
+      if (vec) hipLaunchKernelGGL((cost_partial_kernel<true, true>), grid, dim3(256), 0, s, ca);
+      else hipLaunchKernelGGL((cost_partial_kernel<false, true>), grid, dim3(256), 0, s, ca);
+    } else {
+      if (vec) hipLaunchKernelGGL((cost_partial_kernel<true, false>), grid, dim3(256), 0, s, ca);
+      else hipLaunchKernelGGL((cost_partial_kernel<false, false>), grid, dim3(256), 0, s, ca);
+    }
   }
   OTGAN_CHECK_LAUNCH("cost_partial_kernel");
+  if (fuse) return OTGAN_OK;
   FinishArgs fa;
   memset(&fa, 0, sizeof(fa));
   fa.ws = partial_ws; fa.nsplit = cp.nsplit; fa.P = P; fa.n = n; fa.m = m;

@@ -56,17 +56,56 @@ def test_critic_64_reproduces_reference_run(dev):
     assert _rel(f, fix["features"]) < 2e-5
 
 
+def _critic_layerwise(dev, x, nonlinearity):
+    """The critic run layer by layer on both sides (same layer calls as models/dcgan.py:7-22), keeping the
+    pre-activation tensors.  CReLU's derivative is a step at 0: with ~1.5 M pre-activations per 64x64 image pair a
+    few land within fp32 rounding (|x| ~ 1e-7) of zero, and a legal rounding difference in the forward pass picks
+    the other branch of relu'(x) for that unit -- an O(1) change of one mask bit, not an arithmetic error.  The
+    oracle therefore evaluates its derivative masks at the signs the HIP forward produced: units whose sign
+    differs are nudged across zero in the oracle (|shift| < 2e-6, counted and bounded), so that both sides
+    differentiate the same piecewise-linear function."""
+    from otgan_amd.models import dcgan
+    from otgan_amd.utils import nn
+    acts = []
+
+    def spec(z, **kw):
+        with nn.arg_scope([nn.conv2d, nn.dense], counters={}, init=False, weight_norm=True, ema=None):
+            for filters, s, act in dcgan._CRITIC:
+                z = nn.conv2d(z, filters, filter_size=[5, 5], stride=[s, s], pre_activation=nonlinearity if act else None)
+                acts.append(z)
+            return nn.feature_head(z)
+
+    t = nn.make_template("discriminator", spec)
+    t.store = dcgan.discriminator.store               # shared variables, like make_template
+    xg = x.to(dev).requires_grad_(True)
+    f = t(xg)
+    P = _oracle_params(dcgan.discriminator)
+    x64 = x.double().requires_grad_(True)
+    h, flips = x64, 0
+    for i, (filters, s, act) in enumerate(dcgan._CRITIC):
+        h = NT.conv2d(h, P[f"discriminator/conv2d_{i}"], nonlinearity if act else None, s)
+        a = acts[i].detach().double().cpu()
+        differ = (torch.sign(a) != torch.sign(h.detach())) & (a != 0)
+        assert float((h.detach() - a).abs()[differ].max() if differ.any() else 0.0) < 2e-6   # only rounding-level units
+        flips += int(differ.sum())
+        h = h + torch.where(differ, a - h.detach(), torch.zeros_like(a))                      # same mask on both sides
+    f_ref = NT.feature_head(h)
+    return xg, f, x64, f_ref, P, flips
+
+
 def test_dcgan_64_critic_parity_fwd_and_grads(dev):
     from otgan_amd.models import dcgan
     dcgan.discriminator.reset(seed=21)
     gen = torch.Generator().manual_seed(5)
     x = torch.rand(2, 64, 64, 3, generator=gen) * 2 - 1
-    xg = x.to(dev).requires_grad_(True)
-    f = dcgan.discriminator(xg, nonlinearity="crelu")
-    assert f.shape == (2, 131072)
-    P = _oracle_params(dcgan.discriminator)
-    x64 = x.double().requires_grad_(True)
-    f_ref = NT.dcgan_discriminator(x64, P)
+    with torch.no_grad():
+        dcgan.discriminator(x.to(dev), init=True)                      # creates the variables
+        f_plain = dcgan.discriminator(x.to(dev), nonlinearity="crelu")
+        assert f_plain.shape == (2, 131072)
+        assert _rel(f_plain, NT.dcgan_discriminator(x.double(), _oracle_params(dcgan.discriminator))) < 2e-5
+    xg, f, x64, f_ref, P, flips = _critic_layerwise(dev, x, "crelu")
+    assert torch.equal(f.detach(), f_plain)                             # the layer-wise run IS the model
+    assert flips <= 16, flips                                           # a handful of 1.5 M units
     assert _rel(f, f_ref) < 2e-5
     gy = torch.randn(f_ref.shape, generator=gen, dtype=torch.float64).float()
     params = dcgan.discriminator.trainable_variables()

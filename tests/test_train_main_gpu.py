@@ -36,7 +36,9 @@ def test_train_main_runs_saves_and_resumes(dev, tmp_path, capsys):
     for f in ("sample0.png", "ema_sample0.png", "med_gan_params-1", "distances.npz"):
         assert os.path.exists(os.path.join(save, f)), f
     d = np.load(os.path.join(save, "distances.npz"))
-    assert np.isfinite(d["mean_dist_gen"]).all() and np.isfinite(d["mean_dist_disc"]).all()
+    # epochs 0 and 1 are complete (one critic + two generator steps each); the truncated epoch 2 holds a single
+    # critic step, so its generator mean is the mean of an empty list (nan), exactly like np.mean([]) in train.py:229
+    assert np.isfinite(d["mean_dist_gen"][:2]).all() and np.isfinite(d["mean_dist_disc"][:2]).all()
     sd = torch.load(os.path.join(save, "med_gan_params-1"), map_location="cpu")
     assert "discriminator/conv2d_0/V" in sd and "generator/dense_0/V" in sd      # the reference's variable names
     assert sd["step_counter"] == 6 and "__optim__" in sd and "__ema__" in sd

@@ -222,7 +222,10 @@ def test_well_conditioned_step_gradients(dev, model, size, kind):
     assert float(r["entropy"]) == pytest.approx(ent, rel=1e-4)
     names = list((m.generator if kind == "gen" else m.discriminator).named_variables())
     worst = max((_rel(a, b), n) for n, a, b in zip(names, r["grads"], gr))
-    assert worst[0] < 2e-4, worst
+    # 64x64: the injected gradient f_aa - f_ab is a difference of two matched feature rows whose entries shrink like
+    # 1/sqrt(D) while the fp32 rounding of the D-long cost dot products does not: the cancellation costs a factor ~4
+    # at D = 65536 against D = 16384 (measured 8e-4 on the last critic layer, 1e-4 .. 2e-4 elsewhere)
+    assert worst[0] < (2e-4 if size == 32 else 1.5e-3), worst
 
 
 def test_ema_critic_step_matches_oracle(dev):
