@@ -122,6 +122,15 @@ int otgan_cost_matrix_f32(const float* X, const float* Y, int n, int m, int D, l
                           float sinkhorn_lambda, int cost_kind, float diag_add, float* K,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same for P <= 6 blocks of one shape in ONE launch: K[P][n][m], K[p] = -lambda * (cost(X[p], Y[p]) + diag_add[p] * I)
+ * (diag_add nullable).  X / Y are HOST arrays of P device pointers; blocks named more than once are staged once.
+ * This is what a data-parallel rank calls for its three row slices of the cost matrices (the reference shards
+ * them over the towers the same way, matching.py:29-39). */
+size_t otgan_cost_matrix_batched_workspace_bytes(int P, int n, int m, int D);
+int otgan_cost_matrix_batched_f32(const float* const* X, const float* const* Y, int P, int n, int m, int D,
+                                  long ldf, float sinkhorn_lambda, int cost_kind, const float* diag_add,
+                                  float* K, void* workspace, size_t workspace_bytes, void* stream);
+
 /* P log-kernels K[P][n][m] -> plans M[P][n][m], transposed plans MT[P][m][n] and stats[P][4]
  * (matching.py:52-57).  lambda is only used to report <M,C> with C = -K/lambda. */
 size_t otgan_sinkhorn_workspace_bytes(int P, int n, int m);

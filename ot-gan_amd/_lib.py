@@ -32,6 +32,9 @@ SIGNATURES = {
     "otgan_cost_matrix_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "otgan_cost_matrix_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_long, c_float, c_int,
                                       c_float, c_fp, c_fp, c_size_t, c_fp]),
+    "otgan_cost_matrix_batched_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "otgan_cost_matrix_batched_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_long, c_float, c_int,
+                                              c_fp, c_fp, c_fp, c_size_t, c_fp]),
     "otgan_sinkhorn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "otgan_sinkhorn_plan_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_float, c_fp, c_fp, c_fp,
                                         c_fp, c_size_t, c_fp]),

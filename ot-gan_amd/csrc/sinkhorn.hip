@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include "gemm_tile.h"
+#include "gemm_x3.h"
 #include "../../include/otgan.h"
 
 namespace {
@@ -665,6 +666,179 @@ __global__ void closed_form_distance_kernel(const double* stats, int N, double* 
   dist[0] = (2.0 * T[0] + 2.0 * T[1] - (T[2] + T[3] + T[4] + T[5])) / (4.0 * N) + failure_poison(stats, 6);
 }
 
+// ======================================================================================
+// 5. The matching GEMMs on the bf16 matrix pipe with split-precision operands (gemm_x3.h)
+// ======================================================================================
+// For N >= 256 (the 64x64 configuration and the multi-GPU problems) both GEMM families of the block run on
+// the 256 x 256 split-precision engine that carries the convolutions: every fp32 operand is three bf16
+// planes (hi + mid + lo = the full 24-bit significand), six MFMAs per product, fp32 accumulate -- measured
+// 2e-7 .. 5e-7 rel. L2 against fp64, i.e. the lambda-amplified cost GEMM keeps its full fp32 accuracy
+// (SURVEY 7.3-c asks for exactly this; plain bf16 / fp16 inputs fail the 1e-4 loss bound).
+//   * the stacked features [a1; a2; b1; b2] are split ONCE into the blocked operand layout (op_off): the cost
+//     GEMMs read it as the row-major NT operand (rows = samples, k = D), the plan application reads the same
+//     buffer as its t-leading B operand (rows = contraction index = samples, columns = D);
+//   * cost: C_p = X_p . Y_p^T, six problems in one launch (blockIdx.z, operand offsets per problem); one K split
+//     -> the epilogue writes K = -lambda (1 - x.y) itself, more -> partial sums + cost_finish_kernel;
+//   * plan application: out = A^T . F with A = the plan (or its transpose) as a t-leading operand; the two-term
+//     blocks 0.5 (M_1 F_1 + M_2 F_2) are ONE GEMM over the stacked contraction index [F_1; F_2], alpha folded
+//     into the plan planes; eight output blocks (four for a rank's row range) in one launch.
+__device__ __forceinline__ f32x4 x3_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+struct SplitSrc {
+  const float* src[12];
+  long ld[12];
+  long row0[12];     // destination row inside the stacked operand
+  float scale[12];
+  int n;
+};
+// src[i]: [rows x K] fp32 row-major  ->  dst: stacked operand (kblocks = K / 16), three bf16 planes.
+// A wave covers 16 rows x 16 k: every store instruction writes 512 contiguous bytes of one chunk.
+__global__ __launch_bounds__(256) void x3_split_rows_kernel(SplitSrc a, int rows, int K, u16* dst, long plane_stride) {
+  const int nk4 = K >> 2, kgroups = (nk4 + 15) >> 4;
+  const long b = blockIdx.x;
+  const int i = blockIdx.y;
+  const int k4 = (int)(b % kgroups) * 16 + (threadIdx.x >> 6) * 4 + (threadIdx.x & 3);
+  const long row = (b / kgroups) * 16 + ((threadIdx.x >> 2) & 15);
+  if (row >= rows || k4 >= nk4) return;
+  f32x4 v = x3_ld4(a.src[i] + row * a.ld[i] + 4 * k4);
+  const float sc = a.scale[i];
+  v *= sc;
+  st_split4(dst, plane_stride, op_off(a.row0[i] + row, 4 * k4, K >> 4), v);
+}
+
+template <auto Kern>
+inline void x3_ensure_lds() {
+  static const bool done = [] {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3_LDS);
+    return true;
+  }();
+  (void)done;
+}
+
+inline bool match_x3_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("OTGAN_MATCH_FP32");     // 1: keep the matching GEMMs on the exact-fp32 MFMA engine
+    return !(e && e[0] == '1');
+  }();
+  return on;
+}
+// operand elements (u16 per plane) of a stacked [rows x K] operand
+inline size_t x3_plane_elems(size_t rows, size_t K) { return ((rows + 31) / 32) * 32 * K; }
+inline long x3_row_off(long row, long K) { return (row >> 5) * (K >> 4) * 512; }   // element offset of row block row/32
+
+void x3_split(const SplitSrc& ss, int rows, int K, u16* dst, long plane_stride, hipStream_t s) {
+  const int nk4 = K / 4, kgroups = (nk4 + 15) / 16;
+  const dim3 grid((unsigned)(((long)(rows + 15) / 16) * kgroups), ss.n);
+  hipLaunchKernelGGL(x3_split_rows_kernel, grid, dim3(256), 0, s, ss, rows, K, dst, plane_stride);
+}
+
+// the conditions under which the split-precision engine takes a matching problem of n x m blocks, feature width D
+inline bool x3_shape_ok(int n, int m, int D) {
+  return match_x3_enabled() && n >= 256 && m >= 256 && n % 32 == 0 && m % 32 == 0 && D % 32 == 0 && D >= 64;
+}
+
+// K splits of the cost GEMM on the 256 x 256 engine: one workgroup per CU (a workgroup owns a CU's LDS), none
+// when there are enough tiles
+struct X3CostPlan {
+  int tiles, nsplit, kt_per_split;
+};
+inline X3CostPlan x3_plan_cost(int P, int n, int m, int D) {
+  X3CostPlan c;
+  c.tiles = ceil_div(n, X3_BM) * ceil_div(m, X3_BN);
+  const int nkt = D / X3_BK;
+  int want = c.tiles * P >= 192 ? 1 : ceil_div(256, c.tiles * P);
+  if (want > nkt / 4) want = nkt / 4 > 0 ? nkt / 4 : 1;      // >= 4 granules (8 stages) per split
+  if (want < 1) want = 1;
+  c.kt_per_split = ceil_div(nkt, want);
+  c.nsplit = ceil_div(nkt, c.kt_per_split);
+  return c;
+}
+
+// cost GEMMs: problem p multiplies rows [xrow[p], +n) by rows [yrow[p], +m) of the stacked operand FP
+// (kblocks = D / 16).  nsplit == 1: K written directly; else partial sums (then cost_finish_kernel).
+int launch_cost_x3(const u16* FP, long plane, long rows_total, const long* xrow, const long* yrow, const float* diag,
+                   int P, int n, int m, int D, float lambda, float* partial_ws, float* K, hipStream_t s) {
+  const X3CostPlan cp = x3_plan_cost(P, n, m, D);
+  BgArgs b;
+  memset(&b, 0, sizeof(b));
+  b.Ap = FP; b.Bp = FP; b.pA = plane; b.pB = plane;
+  b.M = n; b.N = m; b.K = D;
+  b.ldc = m;
+  b.tiles_m = ceil_div(n, X3_BM); b.tiles_n = ceil_div(m, X3_BN);
+  b.kt_per_split = cp.kt_per_split;
+  b.rbA = n / 32; b.rbB = m / 32; b.kblocks = D / 16;
+  b.ztab = 1;
+  for (int p = 0; p < P; ++p) {
+    b.zA[p] = x3_row_off(xrow[p], D);
+    b.zB[p] = x3_row_off(yrow[p], D);
+    b.zC[p] = (long)p * n * m;
+    b.zK[p] = D;
+    b.epi_diag[p] = diag ? -lambda * diag[p] : 0.f;
+  }
+  const bool fuse = cp.nsplit == 1;
+  b.C = fuse ? K : partial_ws;
+  b.sSplit = (long)P * n * m;
+  if (fuse) {   // K = -lambda (1 - dot) = lambda * dot - lambda
+    b.epi = 1; b.epi_scale = lambda; b.epi_bias = -lambda;
+  }
+  x3_ensure_lds<wino_bgemm_x3_kernel<true, false>>();
+  const dim3 grid(b.tiles_m * b.tiles_n, cp.nsplit, P);
+  hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, false>), grid, dim3(X3_THREADS), X3_LDS, s, b);
+  OTGAN_CHECK_LAUNCH("cost GEMM (split precision)");
+  if (fuse) return OTGAN_OK;
+  FinishArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.ws = partial_ws; fa.nsplit = cp.nsplit; fa.P = P; fa.n = n; fa.m = m;
+  fa.lambda = lambda; fa.inv_d = 1.f / (float)D; fa.cost_kind = OTGAN_COST_COSINE; fa.K = K;
+  for (int p = 0; p < P; ++p) fa.diag[p] = diag ? diag[p] : 0.f;
+  const long total = (long)P * n * m;
+  const int blocks = (int)(ceil_div_l(total, 256) < 2048 ? ceil_div_l(total, 256) : 2048);
+  hipLaunchKernelGGL(cost_finish_kernel, dim3(blocks), dim3(256), 0, s, fa);
+  OTGAN_CHECK_LAUNCH("cost_finish_kernel");
+  return OTGAN_OK;
+}
+
+// plan application on the t-leading engine.  Block z: out_z[m_begin .. m_end) x D = A_z^T . F_z with
+// A_z = rows [arow, +K_z) of the plan operand PA (columns = output rows, cbA = ncolsA / 16) and
+// F_z = rows [frow, +K_z) of the stacked feature operand FP.
+struct X3ApplyBlock {
+  const u16* A;      // PT or PM base
+  long arow, frow;
+  int K;
+  float* out;        // row m_begin of this block's output
+};
+int launch_apply_x3(const X3ApplyBlock* blk, int nblk, const u16* PA_base, long planeA, int ncolsA, const u16* FP,
+                    long planeF, int m_begin, int m_count, int D, long ldo, hipStream_t s) {
+  BgArgs b;
+  memset(&b, 0, sizeof(b));
+  b.Ap = PA_base; b.Bp = FP; b.pA = planeA; b.pB = planeF;
+  b.M = m_begin + m_count; b.N = D;
+  b.ldc = ldo;
+  b.tiles_m = ceil_div(m_count, X3_BM); b.tiles_n = ceil_div(D, X3_BN);
+  b.cbA = ncolsA / 16; b.cbB = D / 16;
+  b.ztab = 1; b.m_begin = m_begin;
+  double flops = 0;
+  float* base = blk[0].out;
+  int minK = 1 << 30;
+  for (int z = 0; z < nblk; ++z) {
+    b.zA[z] = (blk[z].A - PA_base) + x3_row_off(blk[z].arow, ncolsA);
+    b.zB[z] = x3_row_off(blk[z].frow, D);
+    b.zC[z] = (blk[z].out - base) - (long)m_begin * ldo;
+    b.zK[z] = blk[z].K;
+    if (blk[z].K < minK) minK = blk[z].K;
+    flops += 2.0 * m_count * (double)blk[z].K * D;
+  }
+  b.C = base;
+  b.kt_per_split = 1 << 28;    // one split: each block contracts over its whole zK
+  ProfScope ps(OTGAN_PROF_PLAN_APPLY, flops, 0.0, s);
+  x3_ensure_lds<wino_bgemm_x3_kernel<true, true>>();
+  const dim3 grid(b.tiles_m * b.tiles_n, 1, nblk);
+  (void)minK;
+  hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, true>), grid, dim3(X3_THREADS), X3_LDS, s, b);
+  OTGAN_CHECK_LAUNCH("plan application (split precision)");
+  return OTGAN_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // host-side planning helpers
 // ---------------------------------------------------------------------------------------
@@ -679,9 +853,9 @@ inline CostPlan plan_cost(int P, int n, int m, int D) {
   const int nkt = ceil_div(D, SCfg::BK);
   // K splits.  With at least one tile per CU (256) no split is needed: the GEMM epilogue writes the
   // log-kernel itself (no partial sums in memory at all).  Small problems (N = 128: 6 tiles) need the
-  // parallelism: ~2 workgroups per CU (OTGAN_COST_WG_TARGET, default 512; 768 = 3 per CU wrote 1.5x the
-  // partial sums for the same time), reduced by cost_finish_kernel.
-  static const int target = [] { const char* e = getenv("OTGAN_COST_WG_TARGET"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+  // parallelism: ~3 workgroups per CU (OTGAN_COST_WG_TARGET, default 768; 512 = 2 per CU measured 92 vs 67 us at
+  // N = 128, D = 32768: the engine hides its staging latency with co-resident workgroups), reduced by cost_finish_kernel.
+  static const int target = [] { const char* e = getenv("OTGAN_COST_WG_TARGET"); return e && atoi(e) > 0 ? atoi(e) : 768; }();
   int want = c.tiles * P >= 256 ? 1 : ceil_div(target, c.tiles * P);
   if (want < 1) want = 1;
   if (want > nkt) want = nkt;
@@ -848,6 +1022,12 @@ struct MatchWs {
   float* fg;       // [P][n+m]
   double* stats;   // [P][4]
   double* dot3;    // [3]
+  // split-precision path (x3_shape_ok): stacked feature operand [fa; fb] and the plans as t-leading operands
+  bool x3;
+  u16* FP;         // 3 planes x [2 * feat_rows][D]
+  u16* PT;         // 3 planes x [P * n][n]   (transposed plans: A operand of M . F)
+  u16* PM;         // 3 planes x [P * n][n]   (plans: A operand of M^T . F)
+  long planeF, planeP;
   size_t bytes;
 };
 MatchWs carve_match(void* base, size_t cap, int P, int n, int D, int feat_rows) {
@@ -855,9 +1035,17 @@ MatchWs carve_match(void* base, size_t cap, int P, int n, int D, int feat_rows) 
   MatchWs w;
   const CostPlan cp = plan_cost(P, n, n, D);
   const size_t pnm = (size_t)P * n * n;
+  w.x3 = x3_shape_ok(n, n, D);
+  int nsplit = cp.nsplit;
+  if (w.x3 && x3_plan_cost(P, n, n, D).nsplit > nsplit) nsplit = x3_plan_cost(P, n, n, D).nsplit;
   w.sq_a = (float*)c.take(sizeof(float) * feat_rows);
   w.sq_b = (float*)c.take(sizeof(float) * feat_rows);
-  w.partial = (float*)c.take(sizeof(float) * pnm * cp.nsplit);
+  w.planeF = (long)x3_plane_elems(2 * (size_t)feat_rows, D);
+  w.planeP = (long)x3_plane_elems((size_t)P * n, n);
+  w.FP = (u16*)c.take(w.x3 ? sizeof(u16) * 3 * (size_t)w.planeF : 0);
+  w.PT = (u16*)c.take(w.x3 ? sizeof(u16) * 3 * (size_t)w.planeP : 0);
+  w.PM = (u16*)c.take(w.x3 ? sizeof(u16) * 3 * (size_t)w.planeP : 0);
+  w.partial = (float*)c.take(sizeof(float) * pnm * nsplit);
   w.K = (float*)c.take(sizeof(float) * pnm);
   w.plan = (float*)c.take(sizeof(float) * pnm);
   w.planT = (float*)c.take(sizeof(float) * pnm);
@@ -866,6 +1054,32 @@ MatchWs carve_match(void* base, size_t cap, int P, int n, int D, int feat_rows) 
   w.dot3 = (double*)c.take(sizeof(double) * 4);
   w.bytes = c.off;
   return w;
+}
+
+// stacked feature operand [fa; fb] (each `rows` rows) for the split-precision GEMMs
+void x3_split_features(const MatchWs& w, const float* fa, const float* fb, int rows, int D, long ldf, hipStream_t s) {
+  SplitSrc ss;
+  memset(&ss, 0, sizeof(ss));
+  ss.n = 2;
+  ss.src[0] = fa; ss.ld[0] = ldf; ss.row0[0] = 0; ss.scale[0] = 1.f;
+  ss.src[1] = fb; ss.ld[1] = ldf; ss.row0[1] = rows; ss.scale[1] = 1.f;
+  x3_split(ss, rows, D, w.FP, w.planeF, s);
+}
+
+// plans / transposed plans of P problems -> t-leading operands; order[i] = problem stored at rows [i n, (i+1) n)
+void x3_split_plans(const MatchWs& w, const float* plan, const float* planT, int P, int n, const int* orderM,
+                    const float* alpha, hipStream_t s) {
+  SplitSrc st, sm;
+  memset(&st, 0, sizeof(st));
+  memset(&sm, 0, sizeof(sm));
+  st.n = sm.n = P;
+  for (int i = 0; i < P; ++i) {
+    st.src[i] = planT + (size_t)i * n * n; st.ld[i] = n; st.row0[i] = (long)i * n; st.scale[i] = alpha[i];
+    const int p = orderM[i];
+    sm.src[i] = plan + (size_t)p * n * n; sm.ld[i] = n; sm.row0[i] = (long)i * n; sm.scale[i] = alpha[p];
+  }
+  x3_split(st, n, n, w.PT, w.planeP, s);
+  x3_split(sm, n, n, w.PM, w.planeP, s);
 }
 
 }  // namespace
@@ -914,9 +1128,20 @@ int otgan_matching_two_batch_f32(const float* fa, const float* fb, int N, int D,
     memcpy(xsq, xs, sizeof(xs));
     memcpy(ysq, ys, sizeof(ys));
   }
-  int rc = launch_cost(X, Y, cost_kind == OTGAN_COST_SQEUCLID_MEAN ? xsq : nullptr,
-                       cost_kind == OTGAN_COST_SQEUCLID_MEAN ? ysq : nullptr, nullptr, 6, N, N, D,
-                       ldf, lambda, cost_kind, w.partial, w.K, s);
+  const bool x3 = w.x3 && cost_kind == OTGAN_COST_COSINE && ldf % 4 == 0 && aligned16(fa) && aligned16(fb);
+  int rc;
+  if (x3) {
+    // stacked rows: a1 [0,N) a2 [N,2N) b1 [2N,3N) b2 [3N,4N); problems a1a2, b2b1, a1b1, a1b2, a2b1, a2b2
+    const long xrow[6] = {0, 3L * N, 0, 0, N, N};
+    const long yrow[6] = {N, 2L * N, 2L * N, 3L * N, 2L * N, 3L * N};
+    ProfScope ps(OTGAN_PROF_COST_GEMM, 12.0 * N * (double)N * D, 16.0 * N * (double)D, s);
+    x3_split_features(w, fa, fb, 2 * N, D, ldf, s);
+    rc = launch_cost_x3(w.FP, w.planeF, 4L * N, xrow, yrow, nullptr, 6, N, N, D, lambda, w.partial, w.K, s);
+  } else {
+    rc = launch_cost(X, Y, cost_kind == OTGAN_COST_SQEUCLID_MEAN ? xsq : nullptr,
+                     cost_kind == OTGAN_COST_SQEUCLID_MEAN ? ysq : nullptr, nullptr, 6, N, N, D,
+                     ldf, lambda, cost_kind, w.partial, w.K, s);
+  }
   if (rc) return rc;
   rc = launch_sinkhorn(w.K, 6, N, N, iters, lambda, w.plan, w.planT, w.stats, w.fg, s);
   if (rc) return rc;
@@ -947,7 +1172,26 @@ int otgan_matching_two_batch_f32(const float* fa, const float* fb, int N, int D,
   set2(5, f_ab + half, M4, fb1, M5, fb2, 0.5f); // a2 <- (M_a2b1.b1 + M_a2b2.b2)/2   (:68,69,80)
   set2(6, f_ba, T2, fa1, T4, fa2, 0.5f);        // b1 <- (M_a1b1^T.a1 + M_a2b1^T.a2)/2 (:72,74,82)
   set2(7, f_ba + half, T3, fa1, T5, fa2, 0.5f); // b2 <- (M_a1b2^T.a1 + M_a2b2^T.a2)/2 (:73,75,82)
-  rc = launch_apply(blk, 8, N, D, ldf, ldo, s);
+  if (x3 && ldo % 4 == 0) {
+    // PT rows: T0 T1 T2 T3 T4 T5;  PM rows: M0 M1 M2 M4 M3 M5 (the pairs contracted together are adjacent)
+    const int orderM[6] = {0, 1, 2, 4, 3, 5};
+    const float alpha[6] = {1.f, 1.f, 0.5f, 0.5f, 0.5f, 0.5f};
+    x3_split_plans(w, w.plan, w.planT, 6, N, orderM, alpha, s);
+    const long n1 = N;
+    const X3ApplyBlock xb[8] = {
+        {w.PT, 0 * n1, 1 * n1, N, f_aa},            // a1 <- M0 . a2
+        {w.PM, 0 * n1, 0 * n1, N, f_aa + half},     // a2 <- M0^T . a1
+        {w.PM, 1 * n1, 3 * n1, N, f_bb},            // b1 <- M1^T . b2
+        {w.PT, 1 * n1, 2 * n1, N, f_bb + half},     // b2 <- M1 . b1
+        {w.PT, 2 * n1, 2 * n1, 2 * N, f_ab},        // a1 <- (M2 . b1 + M3 . b2) / 2
+        {w.PT, 4 * n1, 2 * n1, 2 * N, f_ab + half}, // a2 <- (M4 . b1 + M5 . b2) / 2
+        {w.PM, 2 * n1, 0 * n1, 2 * N, f_ba},        // b1 <- (M2^T . a1 + M4^T . a2) / 2
+        {w.PM, 4 * n1, 0 * n1, 2 * N, f_ba + half}, // b2 <- (M3^T . a1 + M5^T . a2) / 2
+    };
+    rc = launch_apply_x3(xb, 8, w.PT < w.PM ? w.PT : w.PM, w.planeP, N, w.FP, w.planeF, 0, N, D, ldo, s);
+  } else {
+    rc = launch_apply(blk, 8, N, D, ldf, ldo, s);
+  }
   if (rc) return rc;
   hipLaunchKernelGGL(entropy_finalize_kernel, dim3(1), dim3(1), 0, s, w.stats, 6, N, entropy);
   const double denom = (cost_kind == OTGAN_COST_COSINE) ? 2.0 * (2.0 * N)          // matching.py:152
@@ -981,9 +1225,18 @@ int otgan_matching_two_batch_rows_f32(const float* fa, const float* fb, int N, i
   const float* Y[6] = {fa2, fb1, fb1, fb2, fb1, fb2};
   int rc = OTGAN_OK;
   const float* Kuse = K_pre;
+  const bool x3 = w.x3 && ldf % 4 == 0 && ldo % 4 == 0 && aligned16(fa) && aligned16(fb) && row_begin % 16 == 0;
+  if (x3) x3_split_features(w, fa, fb, 2 * N, D, ldf, s);     // cost operand and B operand of the plan application
   if (!K_pre) {
-    rc = launch_cost(X, Y, nullptr, nullptr, nullptr, 6, N, N, D, ldf, lambda, OTGAN_COST_COSINE,
-                     w.partial, w.K, s);
+    if (x3) {
+      const long xrow[6] = {0, 3L * N, 0, 0, N, N};
+      const long yrow[6] = {N, 2L * N, 2L * N, 3L * N, 2L * N, 3L * N};
+      ProfScope ps(OTGAN_PROF_COST_GEMM, 12.0 * N * (double)N * D, 16.0 * N * (double)D, s);
+      rc = launch_cost_x3(w.FP, w.planeF, 4L * N, xrow, yrow, nullptr, 6, N, N, D, lambda, w.partial, w.K, s);
+    } else {
+      rc = launch_cost(X, Y, nullptr, nullptr, nullptr, 6, N, N, D, ldf, lambda, OTGAN_COST_COSINE,
+                       w.partial, w.K, s);
+    }
     if (rc) return rc;
     Kuse = w.K;
   }
@@ -1016,7 +1269,28 @@ int otgan_matching_two_batch_rows_f32(const float* fa, const float* fb, int N, i
     set(2, f_ab, M[4], fb1, M[5], fb2, 0.5f);
     set(3, f_ba, T[3], fa1, T[5], fa2, 0.5f);
   }
-  rc = launch_apply(blk, 4, row_count, D, ldf, ldo, s);
+  if (x3) {
+    const int orderM[6] = {0, 1, 2, 4, 3, 5};
+    const float alpha[6] = {1.f, 1.f, 0.5f, 0.5f, 0.5f, 0.5f};
+    x3_split_plans(w, w.plan, w.planT, 6, N, orderM, alpha, s);
+    const long n1 = N;
+    const int r0 = row_begin - half * N;
+    X3ApplyBlock xb[4];
+    if (half == 0) {  // rows of a1 / b1
+      xb[0] = {w.PT, 0 * n1, 1 * n1, N, f_aa};         // M0 . a2
+      xb[1] = {w.PM, 1 * n1, 3 * n1, N, f_bb};         // M1^T . b2
+      xb[2] = {w.PT, 2 * n1, 2 * n1, 2 * N, f_ab};     // (M2 . b1 + M3 . b2) / 2
+      xb[3] = {w.PM, 2 * n1, 0 * n1, 2 * N, f_ba};     // (M2^T . a1 + M4^T . a2) / 2
+    } else {          // rows of a2 / b2
+      xb[0] = {w.PM, 0 * n1, 0 * n1, N, f_aa};         // M0^T . a1
+      xb[1] = {w.PT, 1 * n1, 2 * n1, N, f_bb};         // M1 . b1
+      xb[2] = {w.PT, 4 * n1, 2 * n1, 2 * N, f_ab};     // (M4 . b1 + M5 . b2) / 2
+      xb[3] = {w.PM, 4 * n1, 0 * n1, 2 * N, f_ba};     // (M3^T . a1 + M5^T . a2) / 2
+    }
+    rc = launch_apply_x3(xb, 4, w.PT < w.PM ? w.PT : w.PM, w.planeP, N, w.FP, w.planeF, r0, row_count, D, ldo, s);
+  } else {
+    rc = launch_apply(blk, 4, row_count, D, ldf, ldo, s);
+  }
   if (rc) return rc;
   hipLaunchKernelGGL(entropy_finalize_kernel, dim3(1), dim3(1), 0, s, w.stats, 6, N, entropy);
   hipLaunchKernelGGL(closed_form_distance_kernel, dim3(1), dim3(1), 0, s, w.stats, N, dist);
@@ -1042,8 +1316,18 @@ int otgan_matching_single_batch_f32(const float* fa, const float* fb, int n, int
   const float* X[3] = {fa, fb, fa};
   const float* Y[3] = {fa, fb, fb};
   const float diag[3] = {999.f, 999.f, 0.f};  // matching.py:109-110
-  int rc = launch_cost(X, Y, nullptr, nullptr, diag, 3, n, n, D, ldf, lambda, OTGAN_COST_COSINE,
-                       w.partial, w.K, s);
+  const bool x3 = w.x3 && ldf % 4 == 0 && ldo % 4 == 0 && aligned16(fa) && aligned16(fb);
+  int rc;
+  if (x3) {   // stacked rows: a [0,n), b [n,2n); problems aa, bb, ab
+    const long xrow[3] = {0, n, 0};
+    const long yrow[3] = {0, n, n};
+    ProfScope ps(OTGAN_PROF_COST_GEMM, 6.0 * n * (double)n * D, 8.0 * n * (double)D, s);
+    x3_split_features(w, fa, fb, n, D, ldf, s);
+    rc = launch_cost_x3(w.FP, w.planeF, 2L * n, xrow, yrow, diag, 3, n, n, D, lambda, w.partial, w.K, s);
+  } else {
+    rc = launch_cost(X, Y, nullptr, nullptr, diag, 3, n, n, D, ldf, lambda, OTGAN_COST_COSINE,
+                     w.partial, w.K, s);
+  }
   if (rc) return rc;
   rc = launch_sinkhorn(w.K, 3, n, n, iters, lambda, w.plan, w.planT, w.stats, w.fg, s);
   if (rc) return rc;
@@ -1058,7 +1342,21 @@ int otgan_matching_single_batch_f32(const float* fa, const float* fb, int n, int
   set1(1, f_bb, w.plan + nn, fb);       // :132
   set1(2, f_ab, w.plan + 2 * nn, fb);   // :133
   set1(3, f_ba, w.planT + 2 * nn, fa);  // :134
-  rc = launch_apply(blk, 4, n, D, ldf, ldo, s);
+  if (x3) {
+    const int orderM[3] = {0, 1, 2};
+    const float alpha[3] = {1.f, 1.f, 1.f};
+    x3_split_plans(w, w.plan, w.planT, 3, n, orderM, alpha, s);
+    const long n1 = n;
+    const X3ApplyBlock xb[4] = {
+        {w.PT, 0 * n1, 0 * n1, n, f_aa},     // M_aa . a
+        {w.PT, 1 * n1, 1 * n1, n, f_bb},     // M_bb . b
+        {w.PT, 2 * n1, 1 * n1, n, f_ab},     // M_ab . b
+        {w.PM, 2 * n1, 0 * n1, n, f_ba},     // M_ab^T . a
+    };
+    rc = launch_apply_x3(xb, 4, w.PT < w.PM ? w.PT : w.PM, w.planeP, n, w.FP, w.planeF, 0, n, D, ldo, s);
+  } else {
+    rc = launch_apply(blk, 4, n, D, ldf, ldo, s);
+  }
   if (rc) return rc;
   hipLaunchKernelGGL(entropy_finalize_kernel, dim3(1), dim3(1), 0, s, w.stats, 3, n, entropy);
   rc = launch_distance(fa, fb, f_aa, f_bb, f_ab, (long)n * D, 2.0 * n, dist, w.dot3, s, w.stats, 3);
@@ -1067,40 +1365,101 @@ int otgan_matching_single_batch_f32(const float* fa, const float* fb, int n, int
   return OTGAN_OK;
 }
 
+// workspace of the (batched) staged cost entry point: split-K partial sums, the toy cost's row statistics and --
+// on the split-precision path -- the stacked operand of the distinct X / Y blocks (at most 2 P of them)
+static size_t cost_batched_ws(int P, int n, int m, int D, bool* x3_out) {
+  const bool x3 = x3_shape_ok(n, m, D);
+  if (x3_out) *x3_out = x3;
+  int nsplit = plan_cost(P, n, m, D).nsplit;
+  if (x3 && x3_plan_cost(P, n, m, D).nsplit > nsplit) nsplit = x3_plan_cost(P, n, m, D).nsplit;
+  size_t b = align_up(sizeof(float) * (size_t)P * n * m * nsplit, 256) + (size_t)P * (align_up(sizeof(float) * n, 256) +
+                                                                                      align_up(sizeof(float) * m, 256));
+  if (x3) b += align_up(sizeof(u16) * 3 * x3_plane_elems((size_t)P * ((size_t)n + m), D), 256);
+  return b;
+}
+
 size_t otgan_cost_matrix_workspace_bytes(int n, int m, int D) {
   if (n <= 0 || m <= 0 || D <= 0) return 0;
-  const CostPlan cp = plan_cost(1, n, m, D);
-  return align_up(sizeof(float) * (size_t)n * m * cp.nsplit, 256) +
-         align_up(sizeof(float) * n, 256) + align_up(sizeof(float) * m, 256);
+  return cost_batched_ws(1, n, m, D, nullptr);
+}
+
+size_t otgan_cost_matrix_batched_workspace_bytes(int P, int n, int m, int D) {
+  if (P <= 0 || P > kMaxProb || n <= 0 || m <= 0 || D <= 0) return 0;
+  return cost_batched_ws(P, n, m, D, nullptr);
+}
+
+int otgan_cost_matrix_batched_f32(const float* const* X, const float* const* Y, int P, int n, int m, int D, long ldf,
+                                  float lambda, int cost_kind, const float* diag_add, float* K, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  OTGAN_CHECK_ARG(X && Y && K, "null pointer");
+  OTGAN_CHECK_ARG(P > 0 && P <= kMaxProb, "1 <= P <= %d problems per call", kMaxProb);
+  OTGAN_CHECK_ARG(n > 0 && m > 0 && D > 0 && ldf >= D, "bad sizes");
+  OTGAN_CHECK_ARG(cost_kind == OTGAN_COST_COSINE || cost_kind == OTGAN_COST_SQEUCLID_MEAN, "unknown cost kind %d", cost_kind);
+  for (int p = 0; p < P; ++p) OTGAN_CHECK_ARG(X[p] && Y[p], "null block pointer");
+  bool x3 = false;
+  const size_t need = cost_batched_ws(P, n, m, D, &x3);
+  if (!workspace || workspace_bytes < need) {
+    otgan_set_error("workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    return OTGAN_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  int nsplit = plan_cost(P, n, m, D).nsplit;
+  if (x3 && x3_plan_cost(P, n, m, D).nsplit > nsplit) nsplit = x3_plan_cost(P, n, m, D).nsplit;
+  Carver c(workspace, workspace_bytes);
+  float* partial = (float*)c.take(sizeof(float) * (size_t)P * n * m * nsplit);
+  const float *xp[kMaxProb], *yp[kMaxProb];
+  for (int p = 0; p < P; ++p) {
+    xp[p] = (float*)c.take(sizeof(float) * n);
+    yp[p] = (float*)c.take(sizeof(float) * m);
+  }
+  x3 = x3 && cost_kind == OTGAN_COST_COSINE && ldf % 4 == 0;
+  for (int p = 0; p < P && x3; ++p) x3 = aligned16(X[p]) && aligned16(Y[p]);
+  if (x3) {
+    // every distinct block is split once into a stacked operand (a rank's slices share their X, two of them a Y)
+    u16* FP = (u16*)c.take(sizeof(u16) * 3 * x3_plane_elems((size_t)P * ((size_t)n + m), D));
+    const long plane = (long)x3_plane_elems((size_t)P * ((size_t)n + m), D);
+    const float* uniq[2 * kMaxProb];
+    long urow[2 * kMaxProb];
+    int nu = 0;
+    long rows = 0, xrow[kMaxProb], yrow[kMaxProb];
+    SplitSrc sx, sy;
+    memset(&sx, 0, sizeof(sx));
+    memset(&sy, 0, sizeof(sy));
+    auto place = [&](const float* ptr, int r, SplitSrc& ss) -> long {
+      for (int i = 0; i < nu; ++i)
+        if (uniq[i] == ptr) return urow[i];
+      uniq[nu] = ptr; urow[nu] = rows;
+      ss.src[ss.n] = ptr; ss.ld[ss.n] = ldf; ss.row0[ss.n] = rows; ss.scale[ss.n] = 1.f;
+      ++ss.n; ++nu;
+      rows += r;          // n and m are multiples of 32: every block starts on a row-block boundary
+      return rows - r;
+    };
+    for (int p = 0; p < P; ++p) xrow[p] = place(X[p], n, sx);
+    for (int p = 0; p < P; ++p) yrow[p] = place(Y[p], m, sy);   // (a pointer used as X and as Y needs n == m to be reused)
+    ProfScope ps(OTGAN_PROF_COST_GEMM, 2.0 * P * n * (double)m * D, 4.0 * P * ((double)n + m) * D, s);
+    if (sx.n) x3_split(sx, n, D, FP, plane, s);
+    if (sy.n) x3_split(sy, m, D, FP, plane, s);
+    return launch_cost_x3(FP, plane, rows, xrow, yrow, diag_add, P, n, m, D, lambda, partial, K, s);
+  }
+  if (cost_kind == OTGAN_COST_SQEUCLID_MEAN) {
+    for (int p = 0; p < P; ++p) {
+      hipLaunchKernelGGL(row_halfmeansq_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, X[p], ldf, n, D, (float*)xp[p]);
+      hipLaunchKernelGGL(row_halfmeansq_kernel, dim3(ceil_div(m, 4)), dim3(256), 0, s, Y[p], ldf, m, D, (float*)yp[p]);
+    }
+  }
+  return launch_cost(X, Y, cost_kind == OTGAN_COST_SQEUCLID_MEAN ? xp : nullptr,
+                     cost_kind == OTGAN_COST_SQEUCLID_MEAN ? yp : nullptr, diag_add, P, n, m, D, ldf,
+                     lambda, cost_kind, partial, K, s);
 }
 
 int otgan_cost_matrix_f32(const float* X, const float* Y, int n, int m, int D, long ldf,
                           float lambda, int cost_kind, float diag_add, float* K, void* workspace,
                           size_t workspace_bytes, void* stream) {
   OTGAN_CHECK_ARG(X && Y && K, "null pointer");
-  OTGAN_CHECK_ARG(n > 0 && m > 0 && D > 0 && ldf >= D, "bad sizes");
-  const size_t need = otgan_cost_matrix_workspace_bytes(n, m, D);
-  if (!workspace || workspace_bytes < need) {
-    otgan_set_error("workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
-    return OTGAN_ERR_WORKSPACE;
-  }
-  hipStream_t s = (hipStream_t)stream;
-  const CostPlan cp = plan_cost(1, n, m, D);
-  Carver c(workspace, workspace_bytes);
-  float* partial = (float*)c.take(sizeof(float) * (size_t)n * m * cp.nsplit);
-  float* xs = (float*)c.take(sizeof(float) * n);
-  float* ys = (float*)c.take(sizeof(float) * m);
-  const float *xp[1] = {xs}, *yp[1] = {ys};
-  if (cost_kind == OTGAN_COST_SQEUCLID_MEAN) {
-    hipLaunchKernelGGL(row_halfmeansq_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, X, ldf, n, D, xs);
-    hipLaunchKernelGGL(row_halfmeansq_kernel, dim3(ceil_div(m, 4)), dim3(256), 0, s, Y, ldf, m, D, ys);
-  }
   const float* Xp[1] = {X};
   const float* Yp[1] = {Y};
   const float dg[1] = {diag_add};
-  return launch_cost(Xp, Yp, cost_kind == OTGAN_COST_SQEUCLID_MEAN ? xp : nullptr,
-                     cost_kind == OTGAN_COST_SQEUCLID_MEAN ? yp : nullptr, dg, 1, n, m, D, ldf,
-                     lambda, cost_kind, partial, K, s);
+  return otgan_cost_matrix_batched_f32(Xp, Yp, 1, n, m, D, ldf, lambda, cost_kind, dg, K, workspace, workspace_bytes, stream);
 }
 
 size_t otgan_sinkhorn_workspace_bytes(int P, int n, int m) {

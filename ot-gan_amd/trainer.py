@@ -253,13 +253,11 @@ def rank_log_kernel_slices(rank, world, f_gen, f_dat, fa, fb, lam):
     h = len(fa) // 2
     a2 = torch.cat(fa[h:], 0)
     b1, b2 = torch.cat(fb[:h], 0), torch.cat(fb[h:], 0)
-    if rank < world // 2:   # my rows belong to a1 / b1
-        mine = [matching.cost_log_kernel(f_gen, y, lam) for y in (a2, b1, b2)]      # p0, p2, p3
-    else:                   # my rows belong to a2 / b2
-        mine = [matching.cost_log_kernel(f_dat, b1, lam),                            # p1 (b2,b1)
-                matching.cost_log_kernel(f_gen, b1, lam),                            # p4 (a2,b1)
-                matching.cost_log_kernel(f_gen, b2, lam)]                            # p5 (a2,b2)
-    return torch.stack(mine, 0)
+    # one launch for the rank's three slices; blocks named twice (the rank's own rows, b1) are staged once
+    if rank < world // 2:   # my rows belong to a1 / b1:  p0 (a1,a2), p2 (a1,b1), p3 (a1,b2)
+        return matching.cost_log_kernels([f_gen, f_gen, f_gen], [a2, b1, b2], lam)
+    # my rows belong to a2 / b2:  p1 (b2,b1), p4 (a2,b1), p5 (a2,b2)
+    return matching.cost_log_kernels([f_dat, f_gen, f_gen], [b1, b1, b2], lam)
 
 
 def assemble_log_kernels(allk, world):

@@ -130,6 +130,33 @@ def cost_log_kernel(x, y, sinkhorn_lambda, diag_add=0.0, cost_kind=COST_COSINE):
     return K
 
 
+def cost_log_kernels(xs, ys, sinkhorn_lambda, cost_kind=COST_COSINE):
+    """K[p] = -lambda * cost(xs[p][n,D], ys[p][m,D]) for up to six equally shaped pairs in ONE launch
+    (otgan_cost_matrix_batched_f32) -> [P, n, m].  A tensor that appears several times in xs / ys is staged once:
+    a data-parallel rank passes its own rows as every x and the gathered halves as the ys (matching.py:29-39)."""
+    import ctypes
+    L = _lib.lib()
+    xs = [x.detach().contiguous() for x in xs]
+    ys = [y.detach().contiguous() for y in ys]
+    P = len(xs)
+    n, D = xs[0].shape
+    m = ys[0].shape[0]
+    for x, y in zip(xs, ys):
+        if tuple(x.shape) != (n, D) or tuple(y.shape) != (m, D) or x.dtype != torch.float32 or not x.is_cuda:
+            raise ValueError("cost_log_kernels needs equally shaped float32 CUDA blocks")
+    K = torch.empty((P, n, m), dtype=torch.float32, device=xs[0].device)
+    need = L.otgan_cost_matrix_batched_workspace_bytes(P, n, m, D)
+    ws = _workspace(need, xs[0].device)
+    arr = ctypes.c_void_p * P
+    X = arr(*[x.data_ptr() for x in xs])
+    Y = arr(*[y.data_ptr() for y in ys])
+    rc = L.otgan_cost_matrix_batched_f32(ctypes.cast(X, ctypes.c_void_p), ctypes.cast(Y, ctypes.c_void_p), P, n, m, D, D,
+                                         float(sinkhorn_lambda), int(cost_kind), None, K.data_ptr(), ws.data_ptr(),
+                                         ws.numel(), _lib.stream_ptr())
+    _lib.check(rc, "otgan_cost_matrix_batched_f32")
+    return K
+
+
 def get_matched_features_rows(features_a, features_b, sinkhorn_lambda, nr_sinkhorn_iter, row_begin,
                               row_count, log_kernels=None):
     """Two-batch matching over the full shard lists, producing only rows

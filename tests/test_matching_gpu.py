@@ -85,6 +85,29 @@ def test_cost_matrix(dev, n, m, D, kind):
     assert np.abs(got - ref).max() < 2e-5 * scale + 1e-5
 
 
+@pytest.mark.parametrize("n,m,D", [(256, 1024, 512),      # split-precision engine (a rank's slices at the 8-GPU size)
+                                   (256, 256, 4096),      # ... with K splits
+                                   (40, 72, 100)])        # exact-fp32 engine
+def test_cost_matrix_batched(dev, n, m, D):
+    """otgan_cost_matrix_batched_f32: three blocks in one launch, shared operands staged once; the rank-level
+    call pattern of trainer.rank_log_kernel_slices (matching.py:29-39)."""
+    from otgan_amd.utils import matching
+    rng = np.random.RandomState(n + m + D)
+    nrm = lambda z: z / np.linalg.norm(z, axis=1, keepdims=True)
+    X, Y0, Y1 = nrm(np.abs(rng.randn(n, D))), nrm(np.abs(rng.randn(m, D)) + 0.2), nrm(np.abs(rng.randn(m, D)) ** 2)
+    x, y0, y1 = _t(X, dev), _t(Y0, dev), _t(Y1, dev)
+    lam = 500.0
+    K = matching.cost_log_kernels([x, x, x], [y0, y1, y0], lam).cpu().numpy()
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    for p, Yp in enumerate((Y0, Y1, Y0)):
+        ref = -lam * M.cosine_cost(f(X), f(Yp))
+        assert np.abs(K[p] - ref).max() < 2e-5 * lam, p
+    np.testing.assert_array_equal(K[0], K[2])
+    # the single-block entry point is the same code
+    K1 = matching.cost_log_kernel(x, y1, lam).cpu().numpy()
+    assert np.abs(K1 - K[1]).max() < 1e-4 * lam * 1e-3
+
+
 @pytest.mark.parametrize("P,n,m,iters", [(6, 128, 128, 50), (3, 40, 72, 13), (2, 200, 136, 21),
                                          (1, 1, 1, 3), (2, 128, 96, 0),
                                          # square, 128 < N <= 1024: persistent multi-workgroup kernel
