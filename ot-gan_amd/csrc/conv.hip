@@ -36,6 +36,11 @@ using CfgSmall = GemmCfg<2, 2, 1, 2, 32>;   // 64 x 128 x 32
 using CfgMain16 = GemmCfg<2, 2, 2, 2, 16>;  // 128 x 128 x 16
 using CfgNarrow = GemmCfg<4, 1, 2, 1, 16>;  // 256 x 32 x 16 (Cout / Cin <= 32)
 using CfgN16 = GemmCfg<4, 1, 4, 1, 16, 16>;  // 256 x 16 x 16 on v_mfma_f32_16x16x4_f32 (Cout <= 16: DenseNet)
+// One column tile for outputs just above a multiple of 128 (the DenseNet transition layers: Cout = 144, 200, 208):
+// two 128-wide tiles would compute 256 columns for 144 (44 % of the matrix work wasted).  Four waves stacked along
+// M, each 32 rows x all columns.
+using CfgW160 = GemmCfg<4, 1, 1, 5, 32>;     // 128 x 160 x 32  (74 KB LDS: two workgroups per CU)
+using CfgW224 = GemmCfg<4, 1, 1, 7, 16>;     // 128 x 224 x 16  (46 KB LDS)
 
 // Kernels use dynamic LDS (the 128x128x32 tile needs 66 KB > the 64 KB static limit).
 template <auto Kern>
@@ -1552,6 +1557,7 @@ struct WgPlan {
   int outer;       // 0 no, 1 few outputs (Cout <= 4), 2 few inputs (Cin_eff <= 4)
   int chunk, nchunks;
   bool vec, fold, narrow, n16;
+  int wide;   // 0, or 160 / 224: one exact column tile for Cout just above 128 / 192 (CfgW160 / CfgW224)
   bool dense16;    // DenseNet growth layer: dense16.hip kernel, nsplit slabs
   int bk;
   int tiles_m, tiles_n, nsplit, kt_per_split, nz;
@@ -1560,6 +1566,7 @@ struct WgPlan {
 };
 WgPlan plan_wgrad(const otgan_conv_desc* d, const Geo& g) {
   WgPlan p;
+  p.wide = 0;
   const int taps = d->KH * d->KW;
   p.dense16 = false;
   if (d->Cout == 16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->upsample == 0 && d->C % 4 == 0 &&
@@ -1608,8 +1615,12 @@ WgPlan plan_wgrad(const otgan_conv_desc* d, const Geo& g) {
   p.narrow = d->Cout <= 32;
   p.n16 = d->Cout <= 16;
   // vector path: 128x128x32 (256x32x16 / 256x16x16 when narrow); scalar path: BK = 16 tiles
-  const int BM = p.narrow ? CfgNarrow::BM : 128, BN = p.n16 ? CfgN16::BN : (p.narrow ? CfgNarrow::BN : 128);
-  p.bk = (p.vec && !p.narrow) ? CfgMain::BK : 16;
+  p.wide = 0;
+  if (p.vec && d->Cout > 128 && d->Cout <= 160) p.wide = 160;
+  if (p.vec && d->Cout > 192 && d->Cout <= 224) p.wide = 224;
+  const int BM = p.narrow ? CfgNarrow::BM : 128,
+            BN = p.wide ? p.wide : (p.n16 ? CfgN16::BN : (p.narrow ? CfgNarrow::BN : 128));
+  p.bk = p.wide == 224 ? CfgW224::BK : ((p.vec && !p.narrow) ? CfgMain::BK : 16);
   if (p.fold) {
     const FoldTab f = make_fold(d, g);
     p.slab_elems = f.total;
@@ -1740,6 +1751,19 @@ void launch_igemm(bool vec_ok, int Ck, int rows, int ncols, bool paired, int ncl
       }
     }
     return;
+  }
+  if constexpr (EPI == EPI_FWD) {
+    // forward of the wide-but-not-256 outputs: one exact column tile instead of two 128-wide ones
+    if (!paired && vec_ok && Ck % 32 == 0 && ncols > 128 && ncols <= 160 && (long)ceil_div(rows, 128) * ncls >= 256) {
+      dim3 grid(ceil_div(rows, CfgW160::BM), 1, ncls);
+      launch_igemm3<CfgW160, true, EPI, ACT>(grid, s, ga, ct, wb, e);
+      return;
+    }
+    if (!paired && vec_ok && Ck % 16 == 0 && ncols > 192 && ncols <= 224 && (long)ceil_div(rows, 128) * ncls >= 256) {
+      dim3 grid(ceil_div(rows, CfgW224::BM), 1, ncls);
+      launch_igemm3<CfgW224, true, EPI, ACT>(grid, s, ga, ct, wb, e);
+      return;
+    }
   }
   if (vec_ok && Ck % 32 == 0) {
     const long tiles128 = (long)ceil_div(rows, 128) * ntiles * ncls;
@@ -2433,6 +2457,8 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
     if (p.vec) {
       if (p.n16) launch_wgrad<CfgN16, true>(act, grid, s, ga, ct, a);
       else if (p.narrow) launch_wgrad<CfgNarrow, true>(act, grid, s, ga, ct, a);
+      else if (p.wide == 160) launch_wgrad<CfgW160, true>(act, grid, s, ga, ct, a);
+      else if (p.wide == 224) launch_wgrad<CfgW224, true>(act, grid, s, ga, ct, a);
       else launch_wgrad<CfgMain, true>(act, grid, s, ga, ct, a);
     } else {
       if (p.n16) launch_wgrad<CfgN16, false>(act, grid, s, ga, ct, a);

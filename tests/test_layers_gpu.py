@@ -79,6 +79,10 @@ CONV_CASES = [
     ("rgb_in_many", 72, 32, 32, (3,), 32, 5, 1, False, None),
     ("few_out_small_crelu", 2, 4, 4, (16,), 2, 5, 1, False, "crelu"),
     ("few_out_list", 2, 8, 8, (16, 8), 3, 3, 1, False, "crelu"),
+    # DenseNet transition shapes: outputs just above 128 / 192 columns take one exact column tile (128x160, 128x224)
+    ("wide160_s2_list", 128, 32, 32, (32, 16, 16), 144, 3, 2, False, "crelu"),
+    ("wide224_up_list", 32, 16, 16, (32, 16, 16), 208, 3, 1, True, "crelu"),
+    ("wide160_up_celu", 32, 16, 16, (32,), 144, 3, 1, True, "celu"),
 ]
 
 
