@@ -167,18 +167,20 @@ struct ConvALoader {
   __device__ __forceinline__ void load(int kt) {
     const int c4 = threadIdx.x % CPR;
     if (VEC) {
-      // Ck % BK == 0: the whole K tile lies inside one tap
+      // every K tile lies inside one tap: a tap contributes ceil(Ck / BK) tiles, the last one zero-filled past
+      // Ck (Ck % 4 == 0; the DenseNet transitions have Ck = 200, 228)
       const int t = __builtin_amdgcn_readfirstlane(nt);
       const int d = __builtin_amdgcn_readfirstlane(nd) + 4 * c4;
       int sc;
       decode_map(g, d, cm_next, sc, sgn);
       const int dhw = taps.dhw[t];
       const int dh = dhw >> 16, dw = sx16(dhw);
+      const bool kin = d < g.Ck;
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {
         const int ih = ia[p] + dh, iw = ib[p] + dw;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)ih < (unsigned)vH && (unsigned)iw < (unsigned)vW) {
+        if (kin && (unsigned)ih < (unsigned)vH && (unsigned)iw < (unsigned)vW) {
           const long pix = (long)pixbase[p] + (long)(ih >> g.logUp) * g.W + (iw >> g.logUp);
           v = *reinterpret_cast<const float4*>(g.x + pix * g.ldx + sc);
         }
@@ -193,7 +195,7 @@ struct ConvALoader {
         nt = 0;
         nd += BK;
       }
-      if (g.cmap && nd < g.Ck) cm_next = g.cmap[nd + 4 * c4];  // consumed one tile later
+      if (g.cmap && nd + 4 * c4 < g.Ck) cm_next = g.cmap[nd + 4 * c4];  // consumed one tile later
     } else {
       const int k = kt * BK + 4 * c4;
 #pragma unroll
@@ -312,10 +314,11 @@ struct ConvBLoader {
       const int t = __builtin_amdgcn_readfirstlane(nt);
       const int d = __builtin_amdgcn_readfirstlane(nd) + 4 * c4;
       const float* base = wbase + taps.boff[t] + d;
+      const bool kin = d < b.Ck;
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rowoff[p] >= 0) v = *reinterpret_cast<const float4*>(base + rowoff[p]);
+        if (kin && rowoff[p] >= 0) v = *reinterpret_cast<const float4*>(base + rowoff[p]);
         reg[p] = v;
       }
       nt += 1;  // taps fastest, channel slices slowest (same order as the A loader)
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Cla
   lb.init(nblk);
   typename Cfg::acc_t acc[Cfg::MT][Cfg::NT];
   zero_acc<Cfg>(acc);
-  const int nkt = (taps.n * g.Ck + Cfg::BK - 1) / Cfg::BK;
+  const int nkt = VEC ? taps.n * ((g.Ck + Cfg::BK - 1) / Cfg::BK) : (taps.n * g.Ck + Cfg::BK - 1) / Cfg::BK;
   gemm_mainloop<Cfg>(la, lb, nkt, smem, acc);
 
   const int oa = ct.oa[cls], ob = ct.ob[cls];
@@ -1777,7 +1780,7 @@ void launch_igemm(bool vec_ok, int Ck, int rows, int ncols, bool paired, int ncl
     return;
   }
   dim3 grid(ceil_div(rows, CfgMain16::BM), ntiles, ncls);
-  if (vec_ok && Ck % 16 == 0) launch_igemm3<CfgMain16, true, EPI, ACT>(grid, s, ga, ct, wb, e);
+  if (vec_ok && Ck % 4 == 0) launch_igemm3<CfgMain16, true, EPI, ACT>(grid, s, ga, ct, wb, e);
   else launch_igemm3<CfgMain16, false, EPI, ACT>(grid, s, ga, ct, wb, e);
 }
 
@@ -2117,7 +2120,8 @@ static int conv2d_dgrad_impl(const otgan_conv_desc* d, const float* dy, const fl
   e.ncols = d->C;
   e.xsrc = x; e.ldxs = d->ldx; e.xH = d->H; e.xW = d->W;
   e.act = kind;
-  const bool vec = (d->Cout % 16 == 0) && (d->ldy % 4 == 0) && (d->y_coff % 4 == 0) &&
+  // float4 gathers of dy / w along the output channels; a tap's last K tile is zero-filled past Cout
+  const bool vec = (d->Cout % 4 == 0) && (d->ldy % 4 == 0) && (d->y_coff % 4 == 0) &&
                    aligned16(dy) && aligned16(w);
   ClassTab ct;
   memset(&ct, 0, sizeof(ct));

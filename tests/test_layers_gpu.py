@@ -83,6 +83,10 @@ CONV_CASES = [
     ("wide160_s2_list", 128, 32, 32, (32, 16, 16), 144, 3, 2, False, "crelu"),
     ("wide224_up_list", 32, 16, 16, (32, 16, 16), 208, 3, 1, True, "crelu"),
     ("wide160_up_celu", 32, 16, 16, (32,), 144, 3, 1, True, "celu"),
+    # Cout % 16 != 0 (DenseNet transitions 200, 228): float4 dgrad gathers with a zero-filled last K tile per tap
+    ("cout200_s2_list", 4, 16, 16, (32, 16, 16), 200, 3, 2, False, "crelu"),
+    ("cout228_s2", 3, 8, 8, (24,), 228, 3, 2, False, "crelu"),
+    ("cout20_plain", 2, 8, 8, (16,), 20, 3, 1, False, None),
 ]
 
 
