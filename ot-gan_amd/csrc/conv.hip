@@ -1532,7 +1532,7 @@ FoldTab make_fold(const otgan_conv_desc* d, const Geo& g) {
 // Winograd F(2x2,3x3) applies to folded 5x5 upsampling layers without pre-activation.
 inline bool wino_ok(const otgan_conv_desc* d, const Geo& g) {
   return g.fold && d->KH == 5 && d->KW == 5 && d->preact == OTGAN_ACT_NONE && d->C % 32 == 0 &&
-         d->Cout % 4 == 0 && d->H % 2 == 0 && d->W % 2 == 0 && d->H >= 2 && d->W >= 2 && winograd_enabled();
+         d->Cout % 4 == 0 && d->H % kWinoM == 0 && d->W % kWinoM == 0 && d->H >= kWinoM && d->W >= kWinoM && winograd_enabled();
 }
 inline WinoGeo wino_geo(const otgan_conv_desc* d) {
   WinoGeo w;
@@ -1544,7 +1544,7 @@ inline WinoGeo wino_geo(const otgan_conv_desc* d) {
 // 5x5 stride-2 layers (single-tensor input): four 3x3 sub-convolutions in Winograd form.
 inline bool wino_s2_ok(const otgan_conv_desc* d, const Geo& g) {
   return d->stride == 2 && d->upsample == 0 && d->KH == 5 && d->KW == 5 && d->C % 4 == 0 && g.Ceff % 32 == 0 &&
-         d->Cout % 4 == 0 && d->H % 4 == 0 && d->W % 4 == 0 && d->ldx % 4 == 0 && d->ldy % 4 == 0 &&
+         d->Cout % 4 == 0 && d->H % (2 * kWinoM) == 0 && d->W % (2 * kWinoM) == 0 && d->ldx % 4 == 0 && d->ldy % 4 == 0 &&
          d->y_coff % 4 == 0 && winograd_enabled();
 }
 inline WinoS2Geo wino_s2_geo(const otgan_conv_desc* d, const Geo& g) {
@@ -1956,7 +1956,7 @@ static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32
   if (wino_s2_ok(d, g) && cmap == nullptr && aligned16(x) && aligned16(wT) && aligned16(y) && aligned16(bias) &&
       aligned16(workspace) && workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 0)) {
     const WinoS2Geo w = wino_s2_geo(d, g);
-    ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * 49.0 * (double)wino_s2_tiles(w) * g.Ceff * d->Cout, 0.0, s);
+    ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * kWinoS2Blocks * (double)wino_s2_tiles(w) * g.Ceff * d->Cout, 0.0, s);
     rc = wino_s2_fwd(w, x, wT, bias, y, (float*)workspace, s, filters);
     OTGAN_CHECK_LAUNCH("conv2d fwd (winograd, stride 2)");
     return rc;
@@ -1972,7 +1972,7 @@ static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32
     const FoldTab f = make_fold(d, g);
     const WinoGeo w = wino_geo(d);
     // executed FLOP: 16 GEMMs of tiles x 4*Cout x Cin
-    ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * 16.0 * (double)wino_tiles(w) * 4.0 * d->Cout * d->C, 0.0, s);
+    ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * kWinoFreq * (double)wino_tiles(w) * 4.0 * d->Cout * d->C, 0.0, s);
     rc = wino_fwd(w, x, wT, f.woff[1] - f.woff[0], bias, y, (float*)workspace, s, filters);
     OTGAN_CHECK_LAUNCH("conv2d fwd (winograd)");
     return rc;
@@ -2170,7 +2170,7 @@ static int conv2d_dgrad_impl(const otgan_conv_desc* d, const float* dy, const fl
   if (wino_s2_ok(d, g) && inv == nullptr && lddx % 4 == 0 && aligned16(dy) && aligned16(w) && aligned16(dx) &&
       aligned16(x) && aligned16(workspace) && workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 1)) {
     const WinoS2Geo wg = wino_s2_geo(d, g);
-    ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * 49.0 * (double)wino_s2_tiles(wg) * g.Ceff * d->Cout, 0.0, s);
+    ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * kWinoS2Blocks * (double)wino_s2_tiles(wg) * g.Ceff * d->Cout, 0.0, s);
     rc = wino_s2_dgrad(wg, dy, w, x, dx, lddx, accumulate, (float*)workspace, s, filters);
     OTGAN_CHECK_LAUNCH("conv2d dgrad (winograd, stride 2)");
     return rc;
@@ -2185,7 +2185,7 @@ static int conv2d_dgrad_impl(const otgan_conv_desc* d, const float* dy, const fl
     }
     const FoldTab f = make_fold(d, g);
     const WinoGeo wg = wino_geo(d);
-    ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * 16.0 * (double)wino_tiles(wg) * 4.0 * d->Cout * d->C, 0.0, s);
+    ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * kWinoFreq * (double)wino_tiles(wg) * 4.0 * d->Cout * d->C, 0.0, s);
     rc = wino_dgrad(wg, dy, w, f.woff[1] - f.woff[0], dx, lddx, accumulate, (float*)workspace, s, filters);
     OTGAN_CHECK_LAUNCH("conv2d dgrad (winograd)");
     return rc;
@@ -2305,7 +2305,7 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
   if (wino_s2_ok(d, g) && cmap == nullptr && aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace) &&
       workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 2)) {
     const WinoS2Geo wg = wino_s2_geo(d, g);
-    ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * 49.0 * (double)wino_s2_tiles(wg) * g.Ceff * d->Cout, 0.0, s);
+    ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * kWinoS2Blocks * (double)wino_s2_tiles(wg) * g.Ceff * d->Cout, 0.0, s);
     rc = wino_s2_wgrad(wg, x, dy, dw, (float*)workspace, s);
     OTGAN_CHECK_LAUNCH("conv2d wgrad (winograd, stride 2)");
     return rc;
@@ -2323,7 +2323,7 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
     float* ws = (float*)workspace;
     float* dweff = ws + wino_wgrad_ws_floats(wg);
     {
-      ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * 16.0 * (double)wino_tiles(wg) * 4.0 * d->Cout * d->C, 0.0, s);
+      ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * kWinoFreq * (double)wino_tiles(wg) * 4.0 * d->Cout * d->C, 0.0, s);
       rc = wino_wgrad(wg, x, dy, dweff, f.woff[1] - f.woff[0], ws, s);
       if (rc) return rc;
     }

@@ -10,8 +10,18 @@
 
 namespace {
 
+// Winograd F(m x m, 3 x 3): transformed tile edge kWA = m + 2, kWF = kWA^2 frequencies (batched GEMMs).
+#ifndef OTGAN_WINO_ALPHA
+#define OTGAN_WINO_ALPHA 6
+#endif
+constexpr int kWA = OTGAN_WINO_ALPHA;
+constexpr int kWF = kWA * kWA;
+
+// Strided 5x5 layers: is the (parity class, frequency) block structurally non-zero?  The even-parity classes have
+// a zero outer tap, which empties frequency index `skip` (0: forward orientation, kWA - 1: flipped filters) in
+// that dimension.
 __host__ __device__ __forceinline__ bool s2_present(int cls, int f, int skip) {
-  const int pi = cls >> 1, pj = cls & 1, fi = f >> 2, fj = f & 3;
+  const int pi = cls >> 1, pj = cls & 1, fi = f / kWA, fj = f % kWA;
   return (pi || fi != skip) && (pj || fj != skip);
 }
 
@@ -105,13 +115,17 @@ struct BgArgs {
 };
 
 
-// Forward pass of a strided layer (seg_mode 1): the contraction length depends on the frequency -- 9 of the 16 have
-// all four classes (full K), 6 have two (K / 2), frequency 0 has one (K / 4).  Workgroups are dispatched in
-// blockIdx order, z slowest; in the natural order the LAST frequencies are full-length and the launch ends with
-// a long tail.  Longest-processing-time-first order instead: full, half, quarter.
+// Forward pass of a strided layer (seg_mode 1): the contraction length depends on the frequency -- those with both
+// indices non-zero have all four classes (full K), one zero index two classes (K / 2), frequency 0 one (K / 4).
+// Workgroups are dispatched in blockIdx order, z slowest; in the natural order the LAST frequencies are
+// full-length and the launch ends with a long tail.  Longest-processing-time-first order instead.
 __device__ __forceinline__ int lpt_frequency(int seg_mode, int z) {
-  // 4-bit entries, z = 0 first: 5 6 7 9 10 11 13 14 15 | 1 2 3 4 8 12 | 0
-  return seg_mode == 1 ? (int)((0x0C84321FEDBA9765ull >> (4 * z)) & 15) : z;
+  if (seg_mode != 1) return z;
+  constexpr int n = kWA - 1, full = n * n;
+  if (z < full) return (1 + z / n) * kWA + 1 + z % n;          // both indices non-zero
+  if (z < full + n) return 1 + (z - full);                       // row index 0
+  if (z < full + 2 * n) return (1 + (z - full - n)) * kWA;       // column index 0
+  return 0;
 }
 // ---- the NT GEMM on the bf16 pipe (split-precision operands) --------------------------------
 // 256 x 256 block tile, FOUR waves (2 x 2) = one wave per SIMD with a 128 x 128 wave tile: 16 accumulator

@@ -1,12 +1,15 @@
-// winograd.h -- Winograd F(2x2, 3x3) path of the folded 5x5 upsampling convolutions
-// (reference models/dcgan.py:33-46: resize_nearest_neighbor + 5x5 conv, three times).
+// winograd.h -- Winograd F(4x4, 3x3) path of the folded 5x5 upsampling convolutions
+// (reference models/dcgan.py:33-46: resize_nearest_neighbor + 5x5 conv, three times) and of the 5x5 stride-2
+// convolutions of the critic (models/dcgan.py:12-14).
 // Internal interface between conv.hip (dispatch, fold/unfold) and winograd.hip (kernels).
 //
 // After upsample folding each of the four output-parity classes is an ordinary 3x3 'SAME'
-// convolution on the SMALL image, so the minimal-filtering form applies: per 2x2 output tile
-// 16 multiplies instead of 36 (2.25x fewer MFMA FLOP), exact up to fp32 rounding of the
-// +-1, +-1/2 transform coefficients (measured 5e-7 relative L2 against fp64, the same class
-// as the direct fp32 chain; the F(4x4,3x3) variant measured 3.4e-6 and was rejected).
+// convolution on the SMALL image, so the minimal-filtering form applies: per 4x4 output tile
+// 36 multiplies instead of 144 (4x fewer MFMA FLOP than the folded direct form; F(2x2,3x3), the
+// round-1 choice, needs 64).  Interpolation points {0, 1, -1, 1/2, -2, inf}: dyadic data / output
+// transforms; measured 6.8e-7 relative L2 against fp64 on the split-precision GEMM -- between
+// F(2x2,3x3) (2.2e-7) and a plain fp32 MFMA chain of the direct convolution (1.3e-6).  (Round 1
+// rejected F(4x4,3x3) at 3.4e-6: textbook points {0,+-1,+-2}, fp32 filter transform, fp32 MFMA.)
 #pragma once
 #include "common.h"
 
@@ -18,8 +21,11 @@ struct WinoGeo {
 };
 
 bool winograd_enabled();
-// tiles = N * (H/2) * (W/2)
-inline long wino_tiles(const WinoGeo& g) { return (long)g.N * (g.H / 2) * (g.W / 2); }
+constexpr int kWinoM = 4;          // output tile edge of F(4x4, 3x3)
+constexpr int kWinoFreq = 36;      // (kWinoM + 2)^2 batched GEMMs
+constexpr int kWinoS2Blocks = 121; // non-zero (class, frequency) blocks of a strided layer, of 4 * 36
+// tiles = N * (H/4) * (W/4)
+inline long wino_tiles(const WinoGeo& g) { return (long)g.N * (g.H / kWinoM) * (g.W / kWinoM); }
 // scratch floats of each pass
 size_t wino_fwd_ws_floats(const WinoGeo& g);
 size_t wino_dgrad_ws_floats(const WinoGeo& g);
@@ -41,13 +47,13 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
 
 // ---- 5x5 stride-2 layers (DCGAN critic, models/dcgan.py:12-14) --------------------------------
 struct WinoS2Geo {
-  int N, H, W;             // input image (H, W multiples of 4); output is H/2 x W/2
+  int N, H, W;             // input image (H, W multiples of 8); output is H/2 x W/2
   int C, Ceff;             // real / effective input channels
   int doubled, act;        // CReLU/CELU doubling; 0 none, 1 relu-type, 2 elu-type
   int ldx;
   int Cout, ldy, y_coff;
 };
-inline long wino_s2_tiles(const WinoS2Geo& g) { return (long)g.N * (g.H / 4) * (g.W / 4); }
+inline long wino_s2_tiles(const WinoS2Geo& g) { return (long)g.N * (g.H / (2 * kWinoM)) * (g.W / (2 * kWinoM)); }
 size_t wino_s2_fwd_ws_floats(const WinoS2Geo& g);
 size_t wino_s2_dgrad_ws_floats(const WinoS2Geo& g);
 size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g);

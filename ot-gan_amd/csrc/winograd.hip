@@ -1,9 +1,9 @@
 // winograd.hip -- Winograd F(2x2,3x3) for the folded 5x5 upsampling convolutions (see winograd.h).
 //
 // Pipeline of one pass (all in the NHWC / channel-contiguous layouts of the rest of the library):
-//   forward : V = B^T d B  (x, 4x4 patches)          [16][T][Cin]
+//   forward : V = B^T d B  (x, 4x4 patches)          [WF][T][Cin]
 //             U = G g G^T  (four class filters)      [16][4*Cout][Cin]
-//             M[f] = V[f] . U[f]^T   16 GEMMs        [16][T][4*Cout]      <- all the MFMA work
+//             M[f] = V[f] . U[f]^T   16 GEMMs        [WF][T][4*Cout]      <- all the MFMA work
 //             y = A^T M A + bias, scattered to the class's output parity
 //   dgrad   : the same with d = dy sampled per class, flipped filters, K = 4*Cout, N = Cin
 //   wgrad   : dU[f] = V[f]^T . (A dY A^T)[f]  (K = tiles), then dweff = G^T dU G
@@ -33,15 +33,39 @@ inline void ensure_lds(size_t bytes) {
 }
 
 
+// ---- F(4x4, 3x3) -------------------------------------------------------------------------------
+// Minimal filtering with a 4x4 output tile: a 6x6 transformed tile, 36 products per tile and channel pair =
+// 2.25 multiplies per output (direct: 9; F(2x2,3x3): 4).  Interpolation points {0, 1, -1, 1/2, -2, inf}: the data
+// and output transforms have dyadic coefficients only (exact in fp32) and this asymmetric set is markedly better
+// conditioned than the textbook {0, +-1, +-2}.  Measured against fp64 (exact products, fp32 accumulation -- what the
+// split-precision GEMM delivers -- K = 256 .. 1024): 6.8e-7 relative L2, between F(2x2,3x3) on the same GEMM
+// (2.2e-7) and a plain fp32 MFMA chain over the direct convolution (1.3e-6); {0, +-1, +-2}: 1.3e-6.
+// The filter transform (thirds and fifteenths) is evaluated in fp64.
+//   B^T (6x6)                       G (6x3)                   A^T (4x6)
+//   1 -3/2   -2  3/2   1  0         1      0      0          1  1  1   1   1  0
+//   0   -1  1/2  5/2   1  0         1/3    1/3    1/3        0  1 -1  1/2 -2  0
+//   0    1 -5/2  1/2   1  0        -1/3    1/3   -1/3        0  1  1  1/4  4  0
+//   0   -2   -1    2   1  0       -16/15  -8/15  -4/15       0  1 -1  1/8 -8  1
+//   0  1/2   -1 -1/2   1  0        1/15   -2/15   4/15
+//   0    1 -3/2   -2 3/2  1         0      0      1
+// Row 0 of G picks tap 0 and row 5 tap 2 alone: a zero outer tap (the even-parity classes of the strided layers)
+// makes the filter transform vanish at that index (structural zeros, see s2_present in gemm_x3.h).
+constexpr int WA = kWA;        // transformed tile edge (6)
+constexpr int WM = kWA - 2;    // output tile edge (4)
+constexpr int WF = kWF;        // frequencies (36)
+static_assert(WA == 6, "the transforms below are written for F(4x4, 3x3)");
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
-// store k .. k+3 of row `row`, frequency f, of a [16][rows][ld] operand: fp32 row-major in F, or (P non-null)
+// store k .. k+3 of row `row`, frequency f, of a [WF][rows][ld] operand: fp32 row-major in F, or (P non-null)
 // as three bf16 planes in the blocked layout
 __device__ __forceinline__ void st_operand(float* F, u16* P, long rows, int ld, int f, long row, int k, f32x4 v) {
   if (P) {
     const long fs = op_fstride(rows, ld);
-    st_split4(P, 16 * fs, f * fs + op_off(row, k, ld >> 4), v);
+    st_split4(P, WF * fs, f * fs + op_off(row, k, ld >> 4), v);
   } else {
     st4(F + ((long)f * rows + row) * ld + k, v);
   }
@@ -66,89 +90,90 @@ __device__ __forceinline__ bool op_thread(bool blocked, long rows, int nk4, long
 }
 inline int op_grid(long rows, long nk4) { return (int)(((rows + 15) / 16) * ((nk4 + 15) / 16)); }
 
-// ---- the four small transforms, on float4 = four channels at once -------------------------
-// V = B^T d B
-__device__ __forceinline__ void tf_input(const f32x4 (&d)[4][4], f32x4 (&V)[4][4]) {
-  f32x4 t[4][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    t[0][j] = d[0][j] - d[2][j];
-    t[1][j] = d[1][j] + d[2][j];
-    t[2][j] = d[2][j] - d[1][j];
-    t[3][j] = d[1][j] - d[3][j];
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    V[i][0] = t[i][0] - t[i][2];
-    V[i][1] = t[i][1] + t[i][2];
-    V[i][2] = t[i][2] - t[i][1];
-    V[i][3] = t[i][1] - t[i][3];
-  }
+// ---- the one-dimensional transforms (a 2-D transform = columns, then rows), on float4 = four channels ------
+// y = B^T x
+__device__ __forceinline__ void bt1(const f32x4 (&x)[WA], f32x4 (&y)[WA]) {
+  y[0] = x[0] - 1.5f * x[1] - 2.f * x[2] + 1.5f * x[3] + x[4];
+  y[1] = 0.5f * x[2] - x[1] + 2.5f * x[3] + x[4];
+  y[2] = x[1] - 2.5f * x[2] + 0.5f * x[3] + x[4];
+  y[3] = 2.f * (x[3] - x[1]) - x[2] + x[4];
+  y[4] = 0.5f * (x[1] - x[3]) - x[2] + x[4];
+  y[5] = x[1] - 1.5f * x[2] - 2.f * x[3] + 1.5f * x[4] + x[5];
 }
-// U = G g G^T
-__device__ __forceinline__ void tf_filter(const f32x4 (&g)[3][3], f32x4 (&U)[4][4]) {
-  f32x4 t[4][3];
+// y = A^T x
+__device__ __forceinline__ void at1(const f32x4 (&x)[WA], f32x4 (&y)[WM]) {
+  const f32x4 s = x[1] + x[2], d = x[1] - x[2];
+  y[0] = x[0] + s + x[3] + x[4];
+  y[1] = d + 0.5f * x[3] - 2.f * x[4];
+  y[2] = s + 0.25f * x[3] + 4.f * x[4];
+  y[3] = d + 0.125f * x[3] - 8.f * x[4] + x[5];
+}
+// x = A y   (adjoint of at1)
+__device__ __forceinline__ void a1(const f32x4 (&y)[WM], f32x4 (&x)[WA]) {
+  x[0] = y[0];
+  x[1] = y[0] + y[1] + y[2] + y[3];
+  x[2] = y[0] - y[1] + y[2] - y[3];
+  x[3] = y[0] + 0.5f * y[1] + 0.25f * y[2] + 0.125f * y[3];
+  x[4] = y[0] - 2.f * y[1] + 4.f * y[2] - 8.f * y[3];
+  x[5] = y[3];
+}
+// u = G g   (fp64)
+__device__ __forceinline__ void g1(const f64x4 (&g)[3], f64x4 (&u)[WA]) {
+  u[0] = g[0];
+  u[1] = (g[0] + g[1] + g[2]) * (1.0 / 3.0);
+  u[2] = (g[1] - g[0] - g[2]) * (1.0 / 3.0);
+  u[3] = (4.0 * g[0] + 2.0 * g[1] + g[2]) * (-4.0 / 15.0);
+  u[4] = (g[0] - 2.0 * g[1] + 4.0 * g[2]) * (1.0 / 15.0);
+  u[5] = g[2];
+}
+// g = G^T u   (adjoint of g1, fp64)
+__device__ __forceinline__ void gt1(const f64x4 (&u)[WA], f64x4 (&g)[3]) {
+  const f64x4 a = u[1] * (1.0 / 3.0), b = u[2] * (1.0 / 3.0), c = u[3] * (-4.0 / 15.0), d = u[4] * (1.0 / 15.0);
+  g[0] = u[0] + a - b + 4.0 * c + d;
+  g[1] = a + b + 2.0 * c - 2.0 * d;
+  g[2] = a - b + c + 4.0 * d + u[5];
+}
+__device__ __forceinline__ f64x4 to_d(f32x4 v) { return __builtin_convertvector(v, f64x4); }
+__device__ __forceinline__ f32x4 to_f(f64x4 v) { return __builtin_convertvector(v, f32x4); }
+
+// U = G g G^T of a 3x3 filter (four channels), emitted frequency by frequency through `emit(f, value)`
+template <class Emit>
+__device__ __forceinline__ void tf_filter(const f32x4 (&g)[3][3], Emit&& emit) {
+  f64x4 t[WA][3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    t[0][j] = g[0][j];
-    t[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
-    t[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
-    t[3][j] = g[2][j];
+    const f64x4 col[3] = {to_d(g[0][j]), to_d(g[1][j]), to_d(g[2][j])};
+    f64x4 u[WA];
+    g1(col, u);
+#pragma unroll
+    for (int i = 0; i < WA; ++i) t[i][j] = u[i];
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    U[i][0] = t[i][0];
-    U[i][1] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
-    U[i][2] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
-    U[i][3] = t[i][2];
-  }
-}
-// Y = A^T M A
-__device__ __forceinline__ void tf_output(const f32x4 (&M)[4][4], f32x4 (&Y)[2][2]) {
-  f32x4 s[2][4];
+  for (int i = 0; i < WA; ++i) {
+    f64x4 u[WA];
+    g1(t[i], u);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    s[0][j] = M[0][j] + M[1][j] + M[2][j];
-    s[1][j] = M[1][j] - M[2][j] - M[3][j];
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    Y[i][0] = s[i][0] + s[i][1] + s[i][2];
-    Y[i][1] = s[i][1] - s[i][2] - s[i][3];
+    for (int j = 0; j < WA; ++j) emit(i * WA + j, to_f(u[j]));
   }
 }
-// dM = A dY A^T  (adjoint of tf_output)
-__device__ __forceinline__ void tf_output_adj(const f32x4 (&dY)[2][2], f32x4 (&dM)[4][4]) {
-  f32x4 u[4][2];
+// dg = G^T dU G; the columns of dU are pulled through `col(j, out[WA])`
+template <class Col>
+__device__ __forceinline__ void tf_filter_adj(Col&& col, f32x4 (&dg)[3][3]) {
+  f64x4 p[3][WA];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    u[0][j] = dY[0][j];
-    u[1][j] = dY[0][j] + dY[1][j];
-    u[2][j] = dY[0][j] - dY[1][j];
-    u[3][j] = -dY[1][j];
-  }
+  for (int j = 0; j < WA; ++j) {
+    f64x4 u[WA], g[3];
+    col(j, u);
+    gt1(u, g);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    dM[i][0] = u[i][0];
-    dM[i][1] = u[i][0] + u[i][1];
-    dM[i][2] = u[i][0] - u[i][1];
-    dM[i][3] = -u[i][1];
-  }
-}
-// dg = G^T dU G  (adjoint of tf_filter)
-__device__ __forceinline__ void tf_filter_adj(const f32x4 (&dU)[4][4], f32x4 (&dg)[3][3]) {
-  f32x4 p[3][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    p[0][j] = dU[0][j] + 0.5f * (dU[1][j] + dU[2][j]);
-    p[1][j] = 0.5f * (dU[1][j] - dU[2][j]);
-    p[2][j] = 0.5f * (dU[1][j] + dU[2][j]) + dU[3][j];
+    for (int i = 0; i < 3; ++i) p[i][j] = g[i];
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    dg[i][0] = p[i][0] + 0.5f * (p[i][1] + p[i][2]);
-    dg[i][1] = 0.5f * (p[i][1] - p[i][2]);
-    dg[i][2] = 0.5f * (p[i][1] + p[i][2]) + p[i][3];
+    f64x4 g[3];
+    gt1(p[i], g);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dg[i][j] = to_f(g[j]);
   }
 }
 
@@ -163,7 +188,7 @@ struct WView {
   long sn, sh, sw;
 };
 
-// V[f][t][coff + c] = (B^T d B)[f];  d = 4x4 patch at (2ta-1, 2tb-1), zero outside [0,H)x[0,W).
+// V[f][t][coff + c] = (B^T d B)[f];  d = 6x6 patch at (4ta-1, 4tb-1), zero outside [0,H)x[0,W).
 // blockIdx.z selects one of up to four views (dgrad: the four output-parity classes of dy).
 struct InArgs {
   View v[4];
@@ -184,8 +209,10 @@ __device__ __forceinline__ f32x4 wino_act(f32x4 v) {
   }
   return v;
 }
-// ACT / DOUBLED: the pre-activation of the strided layers is applied to the patch before the
-// transform; CReLU / CELU emit two transformed patches (channels c and Creal + c of the view's slot).
+// ACT / DOUBLED: the pre-activation of the strided layers is applied to the patch before the transform; CReLU /
+// CELU emit two transformed patches (channels c and Creal + c of the view's slot): blockIdx.y = 0 transforms
+// act(x), 1 act(-x).  The patch is consumed column by column (B^T d), the rows of (B^T d) B are stored as they
+// are produced: 36 float4 of state per thread.
 template <int ACT, bool DOUBLED>
 __global__ __launch_bounds__(256) void wino_input_kernel(InArgs a) {
   long t;
@@ -194,56 +221,39 @@ __global__ __launch_bounds__(256) void wino_input_kernel(InArgs a) {
   const int c = k4 * 4;
   const int tb = (int)(t % a.TW), ta = (int)((t / a.TW) % a.TH);
   const long n = t / ((long)a.TW * a.TH);
-  const View v = a.v[blockIdx.z];
+  const int cls = blockIdx.z;
+  const View v = a.v[cls];
+  const int pass = DOUBLED ? (int)blockIdx.y : 0;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  f32x4 d[4][4], V[4][4];
+  f32x4 T[WA][WA];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = 2 * ta - 1 + i;
+  for (int j = 0; j < WA; ++j) {
+    const int q = WM * tb - 1 + j;
+    f32x4 col[WA], o[WA];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int q = 2 * tb - 1 + j;
+    for (int i = 0; i < WA; ++i) {
+      const int r = WM * ta - 1 + i;
       const bool ok = (unsigned)r < (unsigned)a.H && (unsigned)q < (unsigned)a.W;
-      d[i][j] = ok ? ld4(v.p + n * v.sn + r * v.sh + q * v.sw + c) : zero;
+      f32x4 e = ok ? ld4(v.p + n * v.sn + r * v.sh + q * v.sw + c) : zero;
+      if (ACT != 0 || DOUBLED) e = wino_act<ACT>(pass ? -e : e);
+      col[i] = e;
     }
+    bt1(col, o);
+#pragma unroll
+    for (int i = 0; i < WA; ++i) T[i][j] = o[i];
   }
-  const int k0 = a.coff[blockIdx.z] + c;
-  if (ACT == 0 && !DOUBLED) {
-    tf_input(d, V);
+  const int k0 = a.coff[cls] + c + (pass ? a.C : 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < WA; ++i) {
+    f32x4 o[WA];
+    bt1(T[i], o);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (a.s2_skip < 0 || s2_present(blockIdx.z, i * 4 + j, a.s2_skip)) st_operand(a.V, a.P, a.T, a.ldv, i * 4 + j, t, k0, V[i][j]);
-  } else {
-    f32x4 e[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) e[i][j] = wino_act<ACT>(d[i][j]);
-    const int cls = blockIdx.z;
-    tf_input(e, V);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (a.s2_skip < 0 || s2_present(cls, i * 4 + j, a.s2_skip)) st_operand(a.V, a.P, a.T, a.ldv, i * 4 + j, t, k0, V[i][j]);
-    if (DOUBLED) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) e[i][j] = wino_act<ACT>(-d[i][j]);
-      tf_input(e, V);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (a.s2_skip < 0 || s2_present(cls, i * 4 + j, a.s2_skip)) st_operand(a.V, a.P, a.T, a.ldv, i * 4 + j, t, k0 + a.C, V[i][j]);
-    }
+    for (int j = 0; j < WA; ++j)
+      if (a.s2_skip < 0 || s2_present(cls, i * WA + j, a.s2_skip)) st_operand(a.V, a.P, a.T, a.ldv, i * WA + j, t, k0, o[j]);
   }
 }
 
-// dst(n, 2ta+i, 2tb+j, c) (+)= (A^T M A)[i][j] + bias[c],  M[f] = Mh[f][t][coff + c]
+// dst(n, 4ta+i, 4tb+j, c) (+)= (A^T M A)[i][j] + bias[c],  M[f] = Mh[f][t][coff + c]
 struct OutArgs {
   WView v[4];
   int coff[4];
@@ -265,26 +275,33 @@ __global__ __launch_bounds__(256) void wino_output_kernel(OutArgs a) {
   const WView v = a.v[blockIdx.z];
   const float* in = a.Mh + t * a.ldm + a.coff[blockIdx.z] + c;
   const long fs = a.T * a.ldm;
-  f32x4 M[4][4], Y[2][2];
+  f32x4 S[WM][WA];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int j = 0; j < WA; ++j) {
+    f32x4 col[WA], o[WM];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) M[i][j] = ld4(in + (i * 4 + j) * fs);
-  tf_output(M, Y);
+    for (int i = 0; i < WA; ++i) col[i] = ld4(in + (i * WA + j) * fs);
+    at1(col, o);
+#pragma unroll
+    for (int i = 0; i < WM; ++i) S[i][j] = o[i];
+  }
   f32x4 b = {0.f, 0.f, 0.f, 0.f};
   if (a.bias) b = ld4(a.bias + c);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WM; ++i) {
+    f32x4 y[WM];
+    at1(S[i], y);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      float* dst = v.p + n * v.sn + (2 * ta + i) * v.sh + (2 * tb + j) * v.sw + c;
-      f32x4 o = Y[i][j] + b;
+    for (int j = 0; j < WM; ++j) {
+      float* dst = v.p + n * v.sn + (WM * ta + i) * v.sh + (WM * tb + j) * v.sw + c;
+      f32x4 o = y[j] + b;
       if (a.accumulate) o += ld4(dst);
       st4(dst, o);
     }
+  }
 }
 
-// dM[f][t][coff + c] = (A dY A^T)[f],  dY = the 2x2 tile of the view at (2ta, 2tb)
+// dM[f][t][coff + c] = (A dY A^T)[f],  dY = the 4x4 tile of the view at (4ta, 4tb)
 __global__ __launch_bounds__(256) void wino_outadj_kernel(InArgs a) {
   long t;
   int k4;
@@ -293,117 +310,22 @@ __global__ __launch_bounds__(256) void wino_outadj_kernel(InArgs a) {
   const int tb = (int)(t % a.TW), ta = (int)((t / a.TW) % a.TH);
   const long n = t / ((long)a.TW * a.TH);
   const View v = a.v[blockIdx.z];
-  f32x4 dY[2][2], dM[4][4];
+  f32x4 u[WA][WM];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < WM; ++j) {
+    f32x4 col[WM], o[WA];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) dY[i][j] = ld4(v.p + n * v.sn + (2 * ta + i) * v.sh + (2 * tb + j) * v.sw + c);
-  tf_output_adj(dY, dM);
+    for (int i = 0; i < WM; ++i) col[i] = ld4(v.p + n * v.sn + (WM * ta + i) * v.sh + (WM * tb + j) * v.sw + c);
+    a1(col, o);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) st_operand(a.V, a.P, a.T, a.ldv, i * 4 + j, t, a.coff[blockIdx.z] + c, dM[i][j]);
-}
-
-
-// ---- transposed operand producers (wgrad on the bf16 pipe) ------------------------------------
-// The wgrad GEMM contracts over the tiles, so its operands must be tile-contiguous:
-// P[piece][f] = the [row][t] matrix in the blocked operand layout.  These kernels compute the same transforms as wino_input_kernel /
-// wino_outadj_kernel for a block of 64 tiles x 16 channels and transpose through LDS (four
-// frequencies at a time), so that every global store is a full 128-byte row segment of 64 tiles.
-// Tiles >= T (padding up to a multiple of 64) are written as zeros.
-struct ProdTArgs {
-  View v[4];
-  int coff[4];
-  int H, W, TH, TW, C;   // C = channels of the view (multiple of 16)
-  long T, Tpad;
-  int rows;              // rows of the transposed operand per frequency
-  u16* P;                // [3][16] x blocked [rows][Tpad] (op_off)
-};
-
-template <int KIND, int ACT, bool DOUBLED>   // KIND 0: B^T d B of the 4x4 patch, 1: A dY A^T of the 2x2 tile
-__global__ __launch_bounds__(256) void wino_prodT_kernel(ProdTArgs a) {
-  __shared__ __attribute__((aligned(16))) u16 lds[3][4][16][72];
-  const int tid = threadIdx.x, cq = tid & 3, tl = tid >> 2;
-  const long t = (long)blockIdx.x * 64 + tl;
-  const int c = blockIdx.y * 16 + 4 * cq;
-  const View v = a.v[blockIdx.z];
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  f32x4 d[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) d[i][j] = zero;
-  if (t < a.T) {
-    const int tb = (int)(t % a.TW), ta = (int)((t / a.TW) % a.TH);
-    const long n = t / ((long)a.TW * a.TH);
-    if (KIND == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = 2 * ta - 1 + i;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int q = 2 * tb - 1 + j;
-          if ((unsigned)r < (unsigned)a.H && (unsigned)q < (unsigned)a.W) d[i][j] = ld4(v.p + n * v.sn + r * v.sh + q * v.sw + c);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) d[i][j] = ld4(v.p + n * v.sn + (2 * ta + i) * v.sh + (2 * tb + j) * v.sw + c);
-    }
+    for (int i = 0; i < WA; ++i) u[i][j] = o[i];
   }
-  const int kblocks = (int)(a.Tpad >> 4);
-  const long fsP = op_fstride(a.rows, a.Tpad), ps = 16 * fsP;
 #pragma unroll
-  for (int pass = 0; pass < (DOUBLED ? 2 : 1); ++pass) {
-    f32x4 V[4][4];
-    if (KIND == 0) {
-      f32x4 e[4][4];
+  for (int i = 0; i < WA; ++i) {
+    f32x4 o[WA];
+    a1(u[i], o);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) e[i][j] = wino_act<ACT>(pass ? -d[i][j] : d[i][j]);
-      tf_input(e, V);
-    } else {
-      f32x4 y[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) y[i][j] = d[i][j];
-      tf_output_adj(y, V);
-    }
-    const int rowbase = a.coff[blockIdx.z] + blockIdx.y * 16 + (pass ? a.C : 0);
-#pragma unroll
-    for (int round = 0; round < 4; ++round) {
-#pragma unroll
-      for (int fl = 0; fl < 4; ++fl)
-#pragma unroll
-        for (int k = 0; k < 4; k += 2) {
-          unsigned h, m, l;
-          split2(V[round][fl][k], V[round][fl][k + 1], h, m, l);
-          lds[0][fl][4 * cq + k][tl] = (u16)h;
-          lds[0][fl][4 * cq + k + 1][tl] = (u16)(h >> 16);
-          lds[1][fl][4 * cq + k][tl] = (u16)m;
-          lds[1][fl][4 * cq + k + 1][tl] = (u16)(m >> 16);
-          lds[2][fl][4 * cq + k][tl] = (u16)l;
-          lds[2][fl][4 * cq + k + 1][tl] = (u16)(l >> 16);
-        }
-      __syncthreads();
-#pragma unroll
-      for (int it = 0; it < 6; ++it) {
-        // 32 consecutive lanes = 16 channel rows x 2 chunks = 512 contiguous bytes of one operand chunk
-        const int id = it * 256 + tid;
-        const int ch = ((id >> 5) & 3) * 2 + (id & 1), cc = (id >> 1) & 15, pf = id >> 7;
-        const int piece = pf >> 2, fl = pf & 3;
-        const u32x4 val = *reinterpret_cast<const u32x4*>(&lds[piece][fl][cc][8 * ch]);
-        const long f = 4 * round + fl;
-        u16* dst = a.P + piece * ps + f * fsP + op_off(rowbase + cc, blockIdx.x * 64 + 8 * ch, kblocks);
-        *reinterpret_cast<u32x4*>(dst) = val;
-      }
-      __syncthreads();
-    }
+    for (int j = 0; j < WA; ++j) st_operand(a.V, a.P, a.T, a.ldv, i * WA + j, t, a.coff[blockIdx.z] + c, o[j]);
   }
 }
 
@@ -417,16 +339,12 @@ __global__ __launch_bounds__(256) void wino_filter_fwd_kernel(const float* __res
   const int ci = k4 * 4;
   const int cls = (int)(row / Cout), co = (int)(row % Cout);
   const float* src = weffT + cls * cls_stride + (long)co * 9 * Cin + ci;
-  f32x4 g[3][3], Uv[4][4];
+  f32x4 g[3][3];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) g[i][j] = ld4(src + (long)(i * 3 + j) * Cin);
-  tf_filter(g, Uv);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) st_operand(U, P, rows, Cin, i * 4 + j, row, ci, Uv[i][j]);
+  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, rows, Cin, f, row, ci, v); });
 }
 
 // backward filters (flipped taps): U'[f][ci][cls*Cout + co] from weff[cls][tap][ci][co]
@@ -438,16 +356,12 @@ __global__ __launch_bounds__(256) void wino_filter_bwd_kernel(const float* __res
   if (!op_thread(P != nullptr, Cin, 4 * c4n, row, k4)) return;
   const int ci = (int)row, cls = k4 / c4n, co = (k4 % c4n) * 4;
   const float* src = weff + cls * cls_stride + (long)ci * Cout + co;
-  f32x4 g[3][3], Uv[4][4];
+  f32x4 g[3][3];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) g[i][j] = ld4(src + (long)((2 - i) * 3 + (2 - j)) * Cin * Cout);
-  tf_filter(g, Uv);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) st_operand(U, P, Cin, 4 * Cout, i * 4 + j, ci, cls * Cout + co, Uv[i][j]);
+  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, Cin, 4 * Cout, f, ci, cls * Cout + co, v); });
 }
 
 // The same two transforms straight from the UN-folded 5x5 weights (the fold of the 2x nearest-neighbour upsampling,
@@ -467,7 +381,7 @@ __global__ __launch_bounds__(256) void wino_filter_fwd_unfolded_kernel(const flo
   const int ph = cls >> 1, pw = cls & 1;
   const float* src = wT + (long)co * 25 * Cin + ci;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  f32x4 g[3][3], Uv[4][4];
+  f32x4 g[3][3];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -483,11 +397,7 @@ __global__ __launch_bounds__(256) void wino_filter_fwd_unfolded_kernel(const flo
         for (int j = 0; j < 3; ++j)
           if (fold5_tap(ph, kh) == i && fold5_tap(pw, kw) == j) g[i][j] += v;
     }
-  tf_filter(g, Uv);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) st_operand(U, P, rows, Cin, i * 4 + j, row, ci, Uv[i][j]);
+  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, rows, Cin, f, row, ci, v); });
 }
 
 // U'[f][ci][cls*Cout + co] (flipped taps) from w[kh*5 + kw][ci][co]
@@ -501,7 +411,7 @@ __global__ __launch_bounds__(256) void wino_filter_bwd_unfolded_kernel(const flo
   const int ph = cls >> 1, pw = cls & 1;
   const float* src = w + (long)ci * Cout + co;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  f32x4 g[3][3], Uv[4][4];
+  f32x4 g[3][3];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -517,11 +427,7 @@ __global__ __launch_bounds__(256) void wino_filter_bwd_unfolded_kernel(const flo
         for (int j = 0; j < 3; ++j)
           if (fold5_tap(ph, kh) == 2 - i && fold5_tap(pw, kw) == 2 - j) g[i][j] += v;
     }
-  tf_filter(g, Uv);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) st_operand(U, P, Cin, 4 * Cout, i * 4 + j, ci, cls * Cout + co, Uv[i][j]);
+  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, Cin, 4 * Cout, f, ci, cls * Cout + co, v); });
 }
 
 // dweff[cls][tap][ci][co] = (G^T dU G)[tap],  dU[f] = sum over splits of slab[split][f][ci][cls*Cout + co]
@@ -536,16 +442,17 @@ __global__ __launch_bounds__(256) void wino_filter_adj_kernel(const float* __res
   const int ci = (int)(r % Cin), cls = (int)(r / Cin);
   const long ldu = 4L * Cout, fs = (long)Cin * ldu;
   const float* src = slabs + (long)ci * ldu + (long)cls * Cout + co;
-  f32x4 dU[4][4], dg[3][3];
+  f32x4 dg[3][3];
+  tf_filter_adj(
+      [&](int j, f64x4(&u)[WA]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 s = ld4(src + (i * 4 + j) * fs);
-      for (int k = 1; k < nsplit; ++k) s += ld4(src + k * split_stride + (i * 4 + j) * fs);
-      dU[i][j] = s;
-    }
-  tf_filter_adj(dU, dg);
+        for (int i = 0; i < WA; ++i) {
+          f64x4 s = to_d(ld4(src + (i * WA + j) * fs));
+          for (int k = 1; k < nsplit; ++k) s += to_d(ld4(src + k * split_stride + (i * WA + j) * fs));
+          u[i] = s;
+        }
+      },
+      dg);
   float* dst = dweff + cls * cls_stride + (long)ci * Cout + co;
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -559,8 +466,9 @@ __global__ __launch_bounds__(256) void wino_filter_adj_kernel(const float* __res
 // -1,0,+1, kh = 1,3 the EVEN rows at offsets 0,+1.  With the 2-tap windows zero-padded to three
 // taps every (row parity, column parity) class is a 3x3 'SAME' correlation of the class's
 // sub-image X[r][c] = act(x)[2r+pi][2c+pj] on the OUTPUT grid, and the sum over the four classes
-// folds into the contraction index: 16 GEMMs with K = 4*Ceff (64 products per 2x2 output tile
-// and channel pair instead of 100).
+// folds into the contraction index: 36 GEMMs with K = 4*Ceff.  The zero tap empties one frequency index per
+// dimension of the even-parity classes: 25 + 30 + 30 + 36 = 121 of the 144 (class, frequency) blocks remain --
+// 121 products per 4x4 output tile and channel pair instead of 400 (F(2x2,3x3): 49 per 2x2 tile = 196).
 __device__ __forceinline__ int s2_tap(int parity, int i) {   // filter tap of window slot i, or -1
   return parity ? 2 * i : (i == 0 ? -1 : 2 * i - 1);
 }
@@ -575,7 +483,7 @@ __global__ __launch_bounds__(256) void wino_s2_filter_fwd_kernel(const float* __
   const int co = (int)row, cls = k4 / c4n, ce = (k4 % c4n) * 4;
   const int pi = cls >> 1, pj = cls & 1;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  f32x4 g[3][3], Uv[4][4];
+  f32x4 g[3][3];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -583,13 +491,10 @@ __global__ __launch_bounds__(256) void wino_s2_filter_fwd_kernel(const float* __
       const int kh = s2_tap(pi, i), kw = s2_tap(pj, j);
       g[i][j] = (kh >= 0 && kw >= 0) ? ld4(wT + ((long)co * 25 + kh * 5 + kw) * Ceff + ce) : zero;
     }
-  tf_filter(g, Uv);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (s2_present(cls, i * 4 + j, 0))   // absent blocks are never read by the GEMM
-        st_operand(U, P, Cout, 4 * Ceff, i * 4 + j, co, cls * Ceff + ce, Uv[i][j]);
+  tf_filter(g, [&](int f, f32x4 v) {
+    if (s2_present(cls, f, 0))   // absent blocks are never read by the GEMM
+      st_operand(U, P, Cout, 4 * Ceff, f, co, cls * Ceff + ce, v);
+  });
 }
 
 // backward filters (flipped): U'[f][cls*Ceff + ce][co] from w[kh*5+kw][ce][co]
@@ -602,7 +507,7 @@ __global__ __launch_bounds__(256) void wino_s2_filter_bwd_kernel(const float* __
   const int ce = (int)(r % Ceff), cls = (int)(r / Ceff);
   const int pi = cls >> 1, pj = cls & 1;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  f32x4 g[3][3], Uv[4][4];
+  f32x4 g[3][3];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -610,11 +515,7 @@ __global__ __launch_bounds__(256) void wino_s2_filter_bwd_kernel(const float* __
       const int kh = s2_tap(pi, 2 - i), kw = s2_tap(pj, 2 - j);
       g[i][j] = (kh >= 0 && kw >= 0) ? ld4(w + ((long)(kh * 5 + kw) * Ceff + ce) * Cout + co) : zero;
     }
-  tf_filter(g, Uv);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) st_operand(U, P, 4L * Ceff, Cout, i * 4 + j, r, co, Uv[i][j]);
+  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, 4L * Ceff, Cout, f, r, co, v); });
 }
 
 // dw[kh*5+kw][ce][co] = (G^T dU G)[i][j] of the tap's class; dU[f] = sum of slab[split][f][cls*Ceff+ce][co]
@@ -630,19 +531,20 @@ __global__ __launch_bounds__(256) void wino_s2_filter_adj_kernel(const float* __
   const int pi = cls >> 1, pj = cls & 1;
   const long fs = 4L * Ceff * Cout;
   const float* src = slabs + r * Cout + co;
-  f32x4 dU[4][4], dg[3][3];
+  f32x4 dg[3][3];
+  tf_filter_adj(
+      [&](int j, f64x4(&u)[WA]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
-      if (s2_present(cls, i * 4 + j, 0)) {
-        sacc = ld4(src + (i * 4 + j) * fs);
-        for (int k = 1; k < nsplit; ++k) sacc += ld4(src + k * split_stride + (i * 4 + j) * fs);
-      }
-      dU[i][j] = sacc;
-    }
-  tf_filter_adj(dU, dg);
+        for (int i = 0; i < WA; ++i) {
+          f64x4 sacc = {0.0, 0.0, 0.0, 0.0};
+          if (s2_present(cls, i * WA + j, 0)) {
+            sacc = to_d(ld4(src + (i * WA + j) * fs));
+            for (int k = 1; k < nsplit; ++k) sacc += to_d(ld4(src + k * split_stride + (i * WA + j) * fs));
+          }
+          u[i] = sacc;
+        }
+      },
+      dg);
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -652,7 +554,7 @@ __global__ __launch_bounds__(256) void wino_s2_filter_adj_kernel(const float* __
     }
 }
 
-// input gradient of a strided layer: per class the 2x2 tile of d/d(act(+-x)) at the class's
+// input gradient of a strided layer: per class the 4x4 tile of d/d(act(+-x)) at the class's
 // sub-image positions, combined through the activation derivative:
 //   dx = act'(x) * G[c] - act'(-x) * G[C + c]        (DOUBLED),   dx = act'(x) * G[c]  otherwise
 struct OutS2Args {
@@ -664,6 +566,7 @@ struct OutS2Args {
   const float* Xh;
   int accumulate;
 };
+// (A^T M A) of the class's M, rows i0 .. i0+1 only (two output rows at a time keep the register count down)
 template <int ACT, bool DOUBLED>
 __global__ __launch_bounds__(256) void wino_s2_output_kernel(OutS2Args a) {
   const int c4n = a.C >> 2;
@@ -679,41 +582,49 @@ __global__ __launch_bounds__(256) void wino_s2_output_kernel(OutS2Args a) {
   const float* in = a.Xh + t * a.ldm + (long)cls * a.Ceff + c;
   const long fs = a.T * a.ldm;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  f32x4 M[4][4], Yp[2][2], Yn[2][2];
+  f32x4 Sp[WM][WA], Sn[DOUBLED ? WM : 1][WA];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int j = 0; j < WA; ++j) {
+    f32x4 col[WA], o[WM];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) M[i][j] = s2_present(cls, i * 4 + j, 3) ? ld4(in + (i * 4 + j) * fs) : zero;
-  tf_output(M, Yp);
-  if (DOUBLED) {
+    for (int i = 0; i < WA; ++i) col[i] = s2_present(cls, i * WA + j, WA - 1) ? ld4(in + (i * WA + j) * fs) : zero;
+    at1(col, o);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WM; ++i) Sp[i][j] = o[i];
+    if (DOUBLED) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) M[i][j] = s2_present(cls, i * 4 + j, 3) ? ld4(in + a.C + (i * 4 + j) * fs) : zero;
-    tf_output(M, Yn);
+      for (int i = 0; i < WA; ++i) col[i] = s2_present(cls, i * WA + j, WA - 1) ? ld4(in + a.C + (i * WA + j) * fs) : zero;
+      at1(col, o);
+#pragma unroll
+      for (int i = 0; i < WM; ++i) Sn[DOUBLED ? i : 0][j] = o[i];
+    }
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WM; ++i) {
+    f32x4 yp[WM], yn[WM];
+    at1(Sp[i], yp);
+    if (DOUBLED) at1(Sn[DOUBLED ? i : 0], yn);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const long off = n * dv.sn + (2 * ta + i) * dv.sh + (2 * tb + j) * dv.sw + c;
-      f32x4 o = Yp[i][j];
+    for (int j = 0; j < WM; ++j) {
+      const long off = n * dv.sn + (WM * ta + i) * dv.sh + (WM * tb + j) * dv.sw + c;
+      f32x4 o = yp[j];
       if (ACT != 0 || DOUBLED) {
-        const f32x4 x4 = ld4(xv.p + n * xv.sn + (2 * ta + i) * xv.sh + (2 * tb + j) * xv.sw + c);
+        const f32x4 x4 = ld4(xv.p + n * xv.sn + (WM * ta + i) * xv.sh + (WM * tb + j) * xv.sw + c);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float xq = x4[q];
           float dp = 1.f, dn = 1.f;
           if (ACT == 1) { dp = xq > 0.f ? 1.f : 0.f; dn = -xq > 0.f ? 1.f : 0.f; }
           if (ACT == 2) { dp = xq > 0.f ? 1.f : expf(xq); dn = -xq > 0.f ? 1.f : expf(-xq); }
-          o[q] = dp * Yp[i][j][q];
-          if (DOUBLED) o[q] -= dn * Yn[i][j][q];
+          o[q] = dp * yp[j][q];
+          if (DOUBLED) o[q] -= dn * yn[j][q];
         }
       }
       float* dst = dv.p + off;
       if (a.accumulate) o += ld4(dst);
       st4(dst, o);
     }
+  }
 }
 
 
@@ -808,9 +719,9 @@ void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
   size_t lds;
   if (TN) lds = sizeof(float) * 2 * (MatLoaderR<Cfg, Cfg::BM, true>::FLOATS + MatLoaderR<Cfg, Cfg::BN, true>::FLOATS);
   else lds = sizeof(float) * 2 * (MatLoaderK<Cfg, Cfg::BM, true>::FLOATS + MatLoaderK<Cfg, Cfg::BN, true>::FLOATS);
-  // executed fp32-equivalent FLOP: 16 GEMMs, minus the skipped (class, frequency) blocks of the strided layers
-  double flop = 2.0 * 16.0 * (double)a.M * a.N * a.K;
-  if (a.seg_mode) flop *= 49.0 / 64.0;
+  // executed fp32-equivalent FLOP: WF GEMMs, minus the skipped (class, frequency) blocks of the strided layers
+  double flop = 2.0 * WF * (double)a.M * a.N * a.K;
+  if (a.seg_mode) flop *= 121.0 / 144.0;
   const bool x3 = !TN && a.Ap != nullptr;
   ProfScope ps(x3 ? OTGAN_PROF_WINO_GEMM_X3 : OTGAN_PROF_WINO_GEMM, x3 ? 6.0 * flop : flop, 0.0, s);
   if (x3) {
@@ -824,14 +735,14 @@ void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
     else b.xmap = n_ok ? 2 : m_ok ? 1 : 0;
     if (nsplit == 1) b.kt_per_split = a.K / X3_BK;
     b.sAp = op_fstride(a.M, a.K); b.sBp = op_fstride(a.N, a.K);
-    b.pA = 16 * b.sAp; b.pB = 16 * b.sBp;
+    b.pA = WF * b.sAp; b.pB = WF * b.sBp;
     b.rbA = (a.M + 31) / 32; b.rbB = (a.N + 31) / 32; b.kblocks = a.K / 16;
     // the pipelined kernel needs >= 4 stages of 16 in every block: the shortest K run of a strided forward is one
     // class (seg_len), the shortest K split is the last one
     int min_k = a.K;
     if (a.seg_mode == 1) min_k = a.seg_len;
     else if (nsplit > 1) min_k = a.K - (nsplit - 1) * b.kt_per_split * X3_BK;
-    const dim3 grid(b.tiles_m * b.tiles_n, nsplit, 16);
+    const dim3 grid(b.tiles_m * b.tiles_n, nsplit, WF);
     if (min_k >= 4 * X3_SK) hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, false>), grid, dim3(X3_THREADS), X3_LDS, s, b);
     else hipLaunchKernelGGL((wino_bgemm_x3_kernel<false, false>), grid, dim3(X3_THREADS), X3_LDS, s, b);
     return;
@@ -843,15 +754,15 @@ void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
   const bool m_ok = a.tiles_m % 8 == 0, n_ok = a.tiles_n % 8 == 0;
   if (a.M >= a.N) b.xmap = m_ok ? 1 : n_ok ? 2 : 0;
   else b.xmap = n_ok ? 2 : m_ok ? 1 : 0;
-  const dim3 grid(a.tiles_m * a.tiles_n, nsplit, 16);
+  const dim3 grid(a.tiles_m * a.tiles_n, nsplit, WF);
   hipLaunchKernelGGL((wino_bgemm_kernel<TN>), grid, dim3(Cfg::THREADS), lds, s, b);
 }
 
 // C[f][M][N] (slabs per K split) = sum_k A[f][k][m] B[f][k][n] with t-leading split-precision operands
 // (Ap: blocked [K rows][M cols], Bp: blocked [K rows][N cols]); K % 32 == 0, M % 32 == 0, N % 32 == 0.
 void launch_bgemm_tl(const BgArgs& a, int nsplit, hipStream_t s) {
-  double flop = 2.0 * 16.0 * (double)a.M * a.N * a.K;
-  if (a.seg_mode) flop *= 49.0 / 64.0;
+  double flop = 2.0 * WF * (double)a.M * a.N * a.K;
+  if (a.seg_mode) flop *= 121.0 / 144.0;
   ProfScope ps(OTGAN_PROF_WINO_GEMM_X3, 6.0 * flop, 0.0, s);
   ensure_lds<wino_bgemm_x3_kernel<true, true>>(X3_LDS);
   ensure_lds<wino_bgemm_x3_kernel<false, true>>(X3_LDS);
@@ -863,10 +774,10 @@ void launch_bgemm_tl(const BgArgs& a, int nsplit, hipStream_t s) {
   else b.xmap = n_ok ? 2 : m_ok ? 1 : 0;
   if (nsplit == 1) b.kt_per_split = a.K / X3_BK;
   b.sAp = op_fstride(a.K, a.M); b.sBp = op_fstride(a.K, a.N);
-  b.pA = 16 * b.sAp; b.pB = 16 * b.sBp;
+  b.pA = WF * b.sAp; b.pB = WF * b.sBp;
   b.cbA = a.M / 16; b.cbB = a.N / 16;
   const int min_k = nsplit > 1 ? a.K - (nsplit - 1) * b.kt_per_split * X3_BK : a.K;
-  const dim3 grid(b.tiles_m * b.tiles_n, nsplit, 16);
+  const dim3 grid(b.tiles_m * b.tiles_n, nsplit, WF);
   if (min_k >= 4 * X3_SK) hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, true>), grid, dim3(X3_THREADS), X3_LDS, s, b);
   else hipLaunchKernelGGL((wino_bgemm_x3_kernel<false, true>), grid, dim3(X3_THREADS), X3_LDS, s, b);
 }
@@ -901,8 +812,8 @@ bool use_x3_wgrad_tl() {
 }
 // floats of workspace that hold n operand elements (three bf16 planes = 6 bytes per element)
 inline size_t operand_floats(size_t n) { return (3 * n + 1) / 2; }
-// elements of a [16][rows][K] operand in either layout (rows padded to 32, K to 16)
-inline size_t op_elems(size_t rows, size_t K) { return 16 * ((rows + 31) / 32 * 32) * ((K + 15) / 16 * 16); }
+// elements of a [WF][rows][K] operand in either layout (rows padded to 32, K to 16)
+inline size_t op_elems(size_t rows, size_t K) { return WF * ((rows + 31) / 32 * 32) * ((K + 15) / 16 * 16); }
 
 // the four output-parity classes of a [N, 2H, 2W, ld] buffer as small-grid views
 template <class V, class P>
@@ -919,7 +830,7 @@ void class_views(const WinoGeo& g, P base, int ld, V (&v)[4]) {
 
 // K splits of the wgrad GEMM on the bf16 pipe (256 x 256 tiles: few tiles, long K)
 int x3_wgrad_splits(int M, int N, long T) {
-  const int blocks = ((M + X3_BM - 1) / X3_BM) * ((N + X3_BN - 1) / X3_BN) * 16;
+  const int blocks = ((M + X3_BM - 1) / X3_BM) * ((N + X3_BN - 1) / X3_BN) * WF;
   static const int target = [] { const char* e = getenv("OTGAN_X3_SPLIT_TARGET"); return e ? atoi(e) : 256; }();
   int ns = (target + blocks - 1) / blocks;
   if (ns > 16) ns = 16;
@@ -930,7 +841,7 @@ int x3_wgrad_splits(int M, int N, long T) {
 
 int wgrad_splits(const WinoGeo& g) {
   const long T = wino_tiles(g);
-  const int blocks = ((g.Cin + 127) / 128) * ((4 * g.Cout + 127) / 128) * 16;
+  const int blocks = ((g.Cin + 127) / 128) * ((4 * g.Cout + 127) / 128) * WF;
   int ns = (1024 + blocks - 1) / blocks;
   if (ns > 8) ns = 8;
   const int nkt = (int)((T + Cfg::BK - 1) / Cfg::BK);
@@ -952,7 +863,7 @@ size_t wino_fwd_ws_floats(const WinoGeo& g) {
   const size_t T = (size_t)wino_tiles(g);
   return operand_floats(op_elems(T, g.Cin)) + operand_floats(op_elems(T, 4 * g.Cout)) +
          operand_floats(std::max(op_elems(4 * g.Cout, g.Cin), op_elems(g.Cin, 4 * g.Cout))) +
-         16 * T * (size_t)(4 * g.Cout > g.Cin ? 4 * g.Cout : g.Cin);
+         WF * T * (size_t)(4 * g.Cout > g.Cin ? 4 * g.Cout : g.Cin);
 }
 size_t wino_dgrad_ws_floats(const WinoGeo& g) { return wino_fwd_ws_floats(g); }
 size_t wino_wgrad_ws_floats(const WinoGeo& g) {
@@ -960,7 +871,7 @@ size_t wino_wgrad_ws_floats(const WinoGeo& g) {
   const size_t Tp = (T + 63) / 64 * 64;
   const int ns = std::max(wgrad_splits(g), x3_wgrad_splits(g.Cin, 4 * g.Cout, (long)Tp));
   return operand_floats(std::max(op_elems(g.Cin, Tp), op_elems(Tp, g.Cin))) +
-         operand_floats(std::max(op_elems(4 * g.Cout, Tp), op_elems(Tp, 4 * g.Cout))) + (size_t)ns * 16 * 4 * g.Cout * g.Cin;
+         operand_floats(std::max(op_elems(4 * g.Cout, Tp), op_elems(Tp, 4 * g.Cout))) + (size_t)ns * WF * 4 * g.Cout * g.Cin;
 }
 
 size_t wino_filter_floats(const WinoGeo& g, int which) {
@@ -1009,7 +920,7 @@ int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stri
   memset(&ia, 0, sizeof(ia));
   ia.s2_skip = -1;
   ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
-  ia.H = g.H; ia.W = g.W; ia.TH = g.H / 2; ia.TW = g.W / 2; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.V = V;
+  ia.H = g.H; ia.W = g.W; ia.TH = g.H / WM; ia.TW = g.W / WM; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.V = V;
   ia.P = VP;
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cin / 4), 1, 1), dim3(256), 0, s, ia);
   BgArgs b;
@@ -1025,7 +936,7 @@ int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stri
   memset(&oa, 0, sizeof(oa));
   class_views(g, y + g.y_coff, g.ldy, oa.v);
   for (int cls = 0; cls < 4; ++cls) oa.coff[cls] = cls * g.Cout;
-  oa.TH = g.H / 2; oa.TW = g.W / 2; oa.C = g.Cout; oa.T = T; oa.ldm = N4; oa.Mh = Mh; oa.bias = bias;
+  oa.TH = g.H / WM; oa.TW = g.W / WM; oa.C = g.Cout; oa.T = T; oa.ldm = N4; oa.Mh = Mh; oa.bias = bias;
   hipLaunchKernelGGL(wino_output_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 4), dim3(256), 0, s, oa);
   return OTGAN_OK;
 }
@@ -1036,9 +947,9 @@ int wino_dgrad(const WinoGeo& g, const float* dy, const float* weff, long cls_st
   const int K4 = 4 * g.Cout;
   const bool x3 = use_x3() && K4 % X3_BK == 0;
   const size_t nV = op_elems(T, K4), nU = op_elems(g.Cin, K4);
-  float* DV = ws;                            // [16][T][4*Cout]
-  float* Uws = DV + operand_floats(nV);      // [16][Cin][4*Cout]
-  float* Xh = Uws + operand_floats(nU);      // [16][T][Cin]
+  float* DV = ws;                            // [WF][T][4*Cout]
+  float* Uws = DV + operand_floats(nV);      // [WF][Cin][4*Cout]
+  float* Xh = Uws + operand_floats(nU);      // [WF][T][Cin]
   float* U = prep ? const_cast<float*>(prep) : Uws;
   u16* VP = x3 ? reinterpret_cast<u16*>(DV) : nullptr;
   u16* UP = x3 ? reinterpret_cast<u16*>(U) : nullptr;
@@ -1048,7 +959,7 @@ int wino_dgrad(const WinoGeo& g, const float* dy, const float* weff, long cls_st
   ia.s2_skip = -1;
   class_views(g, dy + g.y_coff, g.ldy, ia.v);
   for (int cls = 0; cls < 4; ++cls) ia.coff[cls] = cls * g.Cout;
-  ia.H = g.H; ia.W = g.W; ia.TH = g.H / 2; ia.TW = g.W / 2; ia.C = g.Cout; ia.T = T; ia.ldv = K4; ia.V = DV;
+  ia.H = g.H; ia.W = g.W; ia.TH = g.H / WM; ia.TW = g.W / WM; ia.C = g.Cout; ia.T = T; ia.ldv = K4; ia.V = DV;
   ia.P = VP;
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cout / 4), 1, 4), dim3(256), 0, s, ia);
   BgArgs b;
@@ -1063,7 +974,7 @@ int wino_dgrad(const WinoGeo& g, const float* dy, const float* weff, long cls_st
   OutArgs oa;
   memset(&oa, 0, sizeof(oa));
   oa.v[0].p = dx; oa.v[0].sn = (long)g.H * g.W * lddx; oa.v[0].sh = (long)g.W * lddx; oa.v[0].sw = lddx;
-  oa.TH = g.H / 2; oa.TW = g.W / 2; oa.C = g.Cin; oa.T = T; oa.ldm = g.Cin; oa.Mh = Xh; oa.bias = nullptr;
+  oa.TH = g.H / WM; oa.TW = g.W / WM; oa.C = g.Cin; oa.T = T; oa.ldm = g.Cin; oa.Mh = Xh; oa.bias = nullptr;
   oa.accumulate = accumulate;
   hipLaunchKernelGGL(wino_output_kernel, dim3(grid1(T * (g.Cin / 4)), 1, 1), dim3(256), 0, s, oa);
   return OTGAN_OK;
@@ -1084,88 +995,55 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
     memset(&ia, 0, sizeof(ia));
     ia.s2_skip = -1;
     ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
-    ia.H = g.H; ia.W = g.W; ia.TH = g.H / 2; ia.TW = g.W / 2; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.P = VP;
+    ia.H = g.H; ia.W = g.W; ia.TH = g.H / WM; ia.TW = g.W / WM; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.P = VP;
     hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cin / 4), 1, 1), dim3(256), 0, s, ia);
     InArgs da;
     memset(&da, 0, sizeof(da));
     da.s2_skip = -1;
     class_views(g, dy + g.y_coff, g.ldy, da.v);
     for (int cls = 0; cls < 4; ++cls) da.coff[cls] = cls * g.Cout;
-    da.H = g.H; da.W = g.W; da.TH = g.H / 2; da.TW = g.W / 2; da.C = g.Cout; da.T = T; da.ldv = N4; da.P = MP;
+    da.H = g.H; da.W = g.W; da.TH = g.H / WM; da.TW = g.W / WM; da.C = g.Cout; da.T = T; da.ldv = N4; da.P = MP;
     hipLaunchKernelGGL(wino_outadj_kernel, dim3(op_grid(T, g.Cout / 4), 1, 4), dim3(256), 0, s, da);
     BgArgs b;
     memset(&b, 0, sizeof(b));
     b.Ap = VP; b.Bp = MP;
     b.C = slabs; b.M = g.Cin; b.N = N4; b.K = (int)T;
-    b.ldc = N4; b.sC = (long)g.Cin * N4; b.sSplit = 16L * g.Cin * N4;
+    b.ldc = N4; b.sC = (long)g.Cin * N4; b.sSplit = (long)WF * g.Cin * N4;
     b.kt_per_split = (int)((T / X3_BK + ns - 1) / ns);
     launch_bgemm_tl(b, ns, s);
     hipLaunchKernelGGL(wino_filter_adj_kernel, dim3(grid1(4L * g.Cin * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
-                       16L * g.Cin * N4, g.Cin, g.Cout, dweff, cls_stride);
-    return OTGAN_OK;
-  }
-  if (use_x3_wgrad() && g.Cin % 16 == 0 && g.Cout % 16 == 0) {
-    // operands tile-contiguous (transposing producers), NT GEMM on the bf16 pipe with K = tiles
-    const long Tp = (T + 63) / 64 * 64;
-    const int ns = x3_wgrad_splits(g.Cin, N4, Tp);
-    const size_t nV = op_elems(g.Cin, Tp), nM = op_elems(N4, Tp);
-    u16* VP = reinterpret_cast<u16*>(ws);
-    u16* MP = reinterpret_cast<u16*>(ws + operand_floats(nV));
-    float* slabs = ws + operand_floats(nV) + operand_floats(nM);
-    ProdTArgs pa;
-    memset(&pa, 0, sizeof(pa));
-    pa.v[0].p = x; pa.v[0].sn = (long)g.H * g.W * g.ldx; pa.v[0].sh = (long)g.W * g.ldx; pa.v[0].sw = g.ldx;
-    pa.H = g.H; pa.W = g.W; pa.TH = g.H / 2; pa.TW = g.W / 2; pa.C = g.Cin; pa.T = T; pa.Tpad = Tp; pa.rows = g.Cin;
-    pa.P = VP;
-    hipLaunchKernelGGL((wino_prodT_kernel<0, 0, false>), dim3((int)(Tp / 64), g.Cin / 16, 1), dim3(256), 0, s, pa);
-    ProdTArgs pd;
-    memset(&pd, 0, sizeof(pd));
-    class_views(g, dy + g.y_coff, g.ldy, pd.v);
-    for (int cls = 0; cls < 4; ++cls) pd.coff[cls] = cls * g.Cout;
-    pd.H = g.H; pd.W = g.W; pd.TH = g.H / 2; pd.TW = g.W / 2; pd.C = g.Cout; pd.T = T; pd.Tpad = Tp; pd.rows = N4;
-    pd.P = MP;
-    hipLaunchKernelGGL((wino_prodT_kernel<1, 0, false>), dim3((int)(Tp / 64), g.Cout / 16, 4), dim3(256), 0, s, pd);
-    BgArgs b;
-    memset(&b, 0, sizeof(b));
-    b.Ap = VP; b.Bp = MP; b.pA = (long)nV; b.pB = (long)nM;
-    b.C = slabs; b.M = g.Cin; b.N = N4; b.K = (int)Tp;
-    b.lda = Tp; b.ldb = Tp; b.ldc = N4;
-    b.sA = (long)g.Cin * Tp; b.sB = (long)N4 * Tp; b.sC = (long)g.Cin * N4; b.sSplit = 16L * g.Cin * N4;
-    b.kt_per_split = (int)((Tp / X3_BK + ns - 1) / ns);
-    launch_bgemm<false>(b, ns, s);
-    hipLaunchKernelGGL(wino_filter_adj_kernel, dim3(grid1(4L * g.Cin * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
-                       16L * g.Cin * N4, g.Cin, g.Cout, dweff, cls_stride);
+                       (long)WF * g.Cin * N4, g.Cin, g.Cout, dweff, cls_stride);
     return OTGAN_OK;
   }
   const int ns = wgrad_splits(g);
-  const size_t nV = 16 * (size_t)T * g.Cin, nM = 16 * (size_t)T * N4;
-  float* V = ws;                              // [16][T][Cin]
-  float* dM = V + operand_floats(nV);         // [16][T][4*Cout]
-  float* slabs = dM + operand_floats(nM);     // [ns][16][Cin][4*Cout]
+  const size_t nV = WF * (size_t)T * g.Cin, nM = WF * (size_t)T * N4;
+  float* V = ws;                              // [WF][T][Cin]
+  float* dM = V + operand_floats(nV);         // [WF][T][4*Cout]
+  float* slabs = dM + operand_floats(nM);     // [ns][WF][Cin][4*Cout]
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
   ia.s2_skip = -1;
   ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
-  ia.H = g.H; ia.W = g.W; ia.TH = g.H / 2; ia.TW = g.W / 2; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.V = V;
+  ia.H = g.H; ia.W = g.W; ia.TH = g.H / WM; ia.TW = g.W / WM; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.V = V;
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cin / 4), 1, 1), dim3(256), 0, s, ia);
   InArgs da;
   memset(&da, 0, sizeof(da));
   da.s2_skip = -1;
   class_views(g, dy + g.y_coff, g.ldy, da.v);
   for (int cls = 0; cls < 4; ++cls) da.coff[cls] = cls * g.Cout;
-  da.H = g.H; da.W = g.W; da.TH = g.H / 2; da.TW = g.W / 2; da.C = g.Cout; da.T = T; da.ldv = N4; da.V = dM;
+  da.H = g.H; da.W = g.W; da.TH = g.H / WM; da.TW = g.W / WM; da.C = g.Cout; da.T = T; da.ldv = N4; da.V = dM;
   hipLaunchKernelGGL(wino_outadj_kernel, dim3(op_grid(T, g.Cout / 4), 1, 4), dim3(256), 0, s, da);
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.A = V; b.B = dM; b.C = slabs; b.M = g.Cin; b.N = N4; b.K = (int)T;
   b.lda = g.Cin; b.ldb = N4; b.ldc = N4;
-  b.sA = T * g.Cin; b.sB = T * N4; b.sC = (long)g.Cin * N4; b.sSplit = 16L * g.Cin * N4;
+  b.sA = T * g.Cin; b.sB = T * N4; b.sC = (long)g.Cin * N4; b.sSplit = (long)WF * g.Cin * N4;
   b.tiles_m = (g.Cin + Cfg::BM - 1) / Cfg::BM; b.tiles_n = (N4 + Cfg::BN - 1) / Cfg::BN;
   const int nkt = (int)((T + Cfg::BK - 1) / Cfg::BK);
   b.kt_per_split = (nkt + ns - 1) / ns;
   launch_bgemm<true>(b, ns, s);
   hipLaunchKernelGGL(wino_filter_adj_kernel, dim3(grid1(4L * g.Cin * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
-                     16L * g.Cin * N4, g.Cin, g.Cout, dweff, cls_stride);
+                     (long)WF * g.Cin * N4, g.Cin, g.Cout, dweff, cls_stride);
   return OTGAN_OK;
 }
 
@@ -1188,7 +1066,7 @@ void parity_views(int H, int W, P base, int ld, V (&v)[4]) {
 
 int s2_wgrad_splits(const WinoS2Geo& g) {
   const long T = wino_s2_tiles(g);
-  const int blocks = ((4 * g.Ceff + 127) / 128) * ((g.Cout + 127) / 128) * 16;
+  const int blocks = ((4 * g.Ceff + 127) / 128) * ((g.Cout + 127) / 128) * WF;
   int ns = (1024 + blocks - 1) / blocks;
   if (ns > 8) ns = 8;
   const int nkt = (int)((T + Cfg::BK - 1) / Cfg::BK);
@@ -1203,11 +1081,11 @@ void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, u16* VP, h
   ia.s2_skip = -1;
   parity_views(g.H, g.W, x, g.ldx, ia.v);
   for (int cls = 0; cls < 4; ++cls) ia.coff[cls] = cls * g.Ceff;
-  ia.H = g.H / 2; ia.W = g.W / 2; ia.TH = g.H / 4; ia.TW = g.W / 4; ia.C = g.C; ia.T = T; ia.ldv = 4 * g.Ceff;
+  ia.H = g.H / 2; ia.W = g.W / 2; ia.TH = g.H / (2 * WM); ia.TW = g.W / (2 * WM); ia.C = g.C; ia.T = T; ia.ldv = 4 * g.Ceff;
   ia.V = V;
   ia.P = VP;
   ia.s2_skip = 0;
-  const dim3 grid(op_grid(T, g.C / 4), 1, 4), blk(256);
+  const dim3 grid(op_grid(T, g.C / 4), g.doubled ? 2 : 1, 4), blk(256);
   if (g.doubled) {
     if (g.act == 2) hipLaunchKernelGGL((wino_input_kernel<2, true>), grid, blk, 0, s, ia);
     else hipLaunchKernelGGL((wino_input_kernel<1, true>), grid, blk, 0, s, ia);
@@ -1221,7 +1099,7 @@ void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, u16* VP, h
 size_t wino_s2_fwd_ws_floats(const WinoS2Geo& g) {
   const size_t T = (size_t)wino_s2_tiles(g), K4 = 4 * (size_t)g.Ceff;
   return operand_floats(op_elems(T, K4)) + operand_floats(op_elems(T, g.Cout)) +
-         operand_floats(std::max(op_elems(g.Cout, K4), op_elems(K4, g.Cout))) + 16 * T * K4;
+         operand_floats(std::max(op_elems(g.Cout, K4), op_elems(K4, g.Cout))) + WF * T * K4;
 }
 size_t wino_s2_dgrad_ws_floats(const WinoS2Geo& g) { return wino_s2_fwd_ws_floats(g); }
 size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g) {
@@ -1229,7 +1107,7 @@ size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g) {
   const size_t Tp = (T + 63) / 64 * 64;
   const int ns = std::max(s2_wgrad_splits(g), x3_wgrad_splits((int)K4, g.Cout, (long)Tp));
   return operand_floats(std::max(op_elems(K4, Tp), op_elems(Tp, K4))) + operand_floats(std::max(op_elems(g.Cout, Tp), op_elems(Tp, g.Cout))) +
-         (size_t)ns * 16 * K4 * g.Cout;
+         (size_t)ns * WF * K4 * g.Cout;
 }
 
 size_t wino_s2_filter_floats(const WinoS2Geo& g, int which) {
@@ -1254,9 +1132,9 @@ int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float
   const int K4 = 4 * g.Ceff;
   const bool x3 = use_x3() && g.Ceff % X3_BK == 0;
   const size_t nV = op_elems(T, K4), nU = op_elems(g.Cout, K4);
-  float* V = ws;                              // [16][T][4*Ceff]
-  float* Uws = V + operand_floats(nV);        // [16][Cout][4*Ceff]
-  float* Mh = Uws + operand_floats(nU);       // [16][T][Cout]
+  float* V = ws;                              // [WF][T][4*Ceff]
+  float* Uws = V + operand_floats(nV);        // [WF][Cout][4*Ceff]
+  float* Mh = Uws + operand_floats(nU);       // [WF][T][Cout]
   float* U = prep ? const_cast<float*>(prep) : Uws;
   u16* VP = x3 ? reinterpret_cast<u16*>(V) : nullptr;
   u16* UP = x3 ? reinterpret_cast<u16*>(U) : nullptr;
@@ -1276,7 +1154,7 @@ int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float
   memset(&oa, 0, sizeof(oa));
   const int OH = g.H / 2, OW = g.W / 2;
   oa.v[0].p = y + g.y_coff; oa.v[0].sn = (long)OH * OW * g.ldy; oa.v[0].sh = (long)OW * g.ldy; oa.v[0].sw = g.ldy;
-  oa.TH = OH / 2; oa.TW = OW / 2; oa.C = g.Cout; oa.T = T; oa.ldm = g.Cout; oa.Mh = Mh; oa.bias = bias;
+  oa.TH = OH / WM; oa.TW = OW / WM; oa.C = g.Cout; oa.T = T; oa.ldm = g.Cout; oa.Mh = Mh; oa.bias = bias;
   hipLaunchKernelGGL(wino_output_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 1), dim3(256), 0, s, oa);
   return OTGAN_OK;
 }
@@ -1288,9 +1166,9 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   const int OH = g.H / 2, OW = g.W / 2;
   const bool x3 = use_x3() && g.Cout % X3_BK == 0;
   const size_t nV = op_elems(T, g.Cout), nU = op_elems(K4, g.Cout);
-  float* DV = ws;                             // [16][T][Cout]
-  float* Uws = DV + operand_floats(nV);       // [16][4*Ceff][Cout]
-  float* Xh = Uws + operand_floats(nU);       // [16][T][4*Ceff]
+  float* DV = ws;                             // [WF][T][Cout]
+  float* Uws = DV + operand_floats(nV);       // [WF][4*Ceff][Cout]
+  float* Xh = Uws + operand_floats(nU);       // [WF][T][4*Ceff]
   float* U = prep ? const_cast<float*>(prep) : Uws;
   u16* VP = x3 ? reinterpret_cast<u16*>(DV) : nullptr;
   u16* UP = x3 ? reinterpret_cast<u16*>(U) : nullptr;
@@ -1299,7 +1177,7 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   memset(&ia, 0, sizeof(ia));
   ia.s2_skip = -1;
   ia.v[0].p = dy + g.y_coff; ia.v[0].sn = (long)OH * OW * g.ldy; ia.v[0].sh = (long)OW * g.ldy; ia.v[0].sw = g.ldy;
-  ia.H = OH; ia.W = OW; ia.TH = OH / 2; ia.TW = OW / 2; ia.C = g.Cout; ia.T = T; ia.ldv = g.Cout; ia.V = DV;
+  ia.H = OH; ia.W = OW; ia.TH = OH / WM; ia.TW = OW / WM; ia.C = g.Cout; ia.T = T; ia.ldv = g.Cout; ia.V = DV;
   ia.P = VP;
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cout / 4), 1, 1), dim3(256), 0, s, ia);
   BgArgs b;
@@ -1310,13 +1188,13 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   b.sA = T * g.Cout; b.sB = (long)K4 * g.Cout; b.sC = T * K4;
   b.tiles_m = (int)((T + Cfg::BM - 1) / Cfg::BM); b.tiles_n = (K4 + Cfg::BN - 1) / Cfg::BN;
   b.kt_per_split = (g.Cout + Cfg::BK - 1) / Cfg::BK;
-  b.seg_mode = 2; b.seg_len = g.Ceff; b.seg_skip = 3;
+  b.seg_mode = 2; b.seg_len = g.Ceff; b.seg_skip = WA - 1;
   launch_bgemm<false>(b, 1, s);
   OutS2Args oa;
   memset(&oa, 0, sizeof(oa));
   parity_views(g.H, g.W, dx, lddx, oa.dx);
   parity_views(g.H, g.W, x, g.ldx, oa.x);
-  oa.TH = OH / 2; oa.TW = OW / 2; oa.C = g.C; oa.Ceff = g.Ceff; oa.T = T; oa.ldm = K4; oa.Xh = Xh;
+  oa.TH = OH / WM; oa.TW = OW / WM; oa.C = g.C; oa.Ceff = g.Ceff; oa.T = T; oa.ldm = K4; oa.Xh = Xh;
   oa.accumulate = accumulate;
   const dim3 grid(grid1(T * (g.C / 4)), 1, 4), blk(256);
   if (g.doubled) {
@@ -1345,81 +1223,43 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
     memset(&da, 0, sizeof(da));
     da.s2_skip = -1;
     da.v[0].p = dy + g.y_coff; da.v[0].sn = (long)OH * OW * g.ldy; da.v[0].sh = (long)OW * g.ldy; da.v[0].sw = g.ldy;
-    da.H = OH; da.W = OW; da.TH = OH / 2; da.TW = OW / 2; da.C = g.Cout; da.T = T; da.ldv = g.Cout; da.P = MP;
+    da.H = OH; da.W = OW; da.TH = OH / WM; da.TW = OW / WM; da.C = g.Cout; da.T = T; da.ldv = g.Cout; da.P = MP;
     hipLaunchKernelGGL(wino_outadj_kernel, dim3(op_grid(T, g.Cout / 4), 1, 1), dim3(256), 0, s, da);
     BgArgs b;
     memset(&b, 0, sizeof(b));
     b.Ap = VP; b.Bp = MP;
     b.C = slabs; b.M = K4; b.N = g.Cout; b.K = (int)T;
-    b.ldc = g.Cout; b.sC = (long)K4 * g.Cout; b.sSplit = 16L * K4 * g.Cout;
+    b.ldc = g.Cout; b.sC = (long)K4 * g.Cout; b.sSplit = (long)WF * K4 * g.Cout;
     b.kt_per_split = (int)((T / X3_BK + ns - 1) / ns);
     b.seg_mode = 3; b.seg_len = g.Ceff; b.seg_skip = 0;
     launch_bgemm_tl(b, ns, s);
     hipLaunchKernelGGL(wino_s2_filter_adj_kernel, dim3(grid1(4L * g.Ceff * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
-                       16L * K4 * g.Cout, g.Ceff, g.Cout, dw);
-    return OTGAN_OK;
-  }
-  if (use_x3_wgrad() && g.C % 16 == 0 && g.Cout % 16 == 0) {
-    const long Tp = (T + 63) / 64 * 64;
-    const int ns = x3_wgrad_splits(K4, g.Cout, Tp);
-    const size_t nV = op_elems(K4, Tp), nM = op_elems(g.Cout, Tp);
-    u16* VP = reinterpret_cast<u16*>(ws);
-    u16* MP = reinterpret_cast<u16*>(ws + operand_floats(nV));
-    float* slabs = ws + operand_floats(nV) + operand_floats(nM);
-    ProdTArgs pa;
-    memset(&pa, 0, sizeof(pa));
-    parity_views(g.H, g.W, x, g.ldx, pa.v);
-    for (int cls = 0; cls < 4; ++cls) pa.coff[cls] = cls * g.Ceff;
-    pa.H = OH; pa.W = OW; pa.TH = OH / 2; pa.TW = OW / 2; pa.C = g.C; pa.T = T; pa.Tpad = Tp; pa.rows = K4; pa.P = VP;
-    const dim3 grid((int)(Tp / 64), g.C / 16, 4), blk(256);
-    if (g.doubled) {
-      if (g.act == 2) hipLaunchKernelGGL((wino_prodT_kernel<0, 2, true>), grid, blk, 0, s, pa);
-      else hipLaunchKernelGGL((wino_prodT_kernel<0, 1, true>), grid, blk, 0, s, pa);
-    } else if (g.act == 1) hipLaunchKernelGGL((wino_prodT_kernel<0, 1, false>), grid, blk, 0, s, pa);
-    else if (g.act == 2) hipLaunchKernelGGL((wino_prodT_kernel<0, 2, false>), grid, blk, 0, s, pa);
-    else hipLaunchKernelGGL((wino_prodT_kernel<0, 0, false>), grid, blk, 0, s, pa);
-    ProdTArgs pd;
-    memset(&pd, 0, sizeof(pd));
-    pd.v[0].p = dy + g.y_coff; pd.v[0].sn = (long)OH * OW * g.ldy; pd.v[0].sh = (long)OW * g.ldy; pd.v[0].sw = g.ldy;
-    pd.H = OH; pd.W = OW; pd.TH = OH / 2; pd.TW = OW / 2; pd.C = g.Cout; pd.T = T; pd.Tpad = Tp; pd.rows = g.Cout;
-    pd.P = MP;
-    hipLaunchKernelGGL((wino_prodT_kernel<1, 0, false>), dim3((int)(Tp / 64), g.Cout / 16, 1), dim3(256), 0, s, pd);
-    BgArgs b;
-    memset(&b, 0, sizeof(b));
-    b.Ap = VP; b.Bp = MP; b.pA = (long)nV; b.pB = (long)nM;
-    b.C = slabs; b.M = K4; b.N = g.Cout; b.K = (int)Tp;
-    b.lda = Tp; b.ldb = Tp; b.ldc = g.Cout;
-    b.sA = (long)K4 * Tp; b.sB = (long)g.Cout * Tp; b.sC = (long)K4 * g.Cout; b.sSplit = 16L * K4 * g.Cout;
-    b.kt_per_split = (int)((Tp / X3_BK + ns - 1) / ns);
-    b.seg_mode = 3; b.seg_len = g.Ceff; b.seg_skip = 0;
-    launch_bgemm<false>(b, ns, s);
-    hipLaunchKernelGGL(wino_s2_filter_adj_kernel, dim3(grid1(4L * g.Ceff * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
-                       16L * K4 * g.Cout, g.Ceff, g.Cout, dw);
+                       (long)WF * K4 * g.Cout, g.Ceff, g.Cout, dw);
     return OTGAN_OK;
   }
   const int ns = s2_wgrad_splits(g);
-  const size_t nV = 16 * (size_t)T * K4, nM = 16 * (size_t)T * g.Cout;
-  float* V = ws;                              // [16][T][4*Ceff]
-  float* dM = V + operand_floats(nV);         // [16][T][Cout]
-  float* slabs = dM + operand_floats(nM);     // [ns][16][4*Ceff][Cout]
+  const size_t nV = WF * (size_t)T * K4, nM = WF * (size_t)T * g.Cout;
+  float* V = ws;                              // [WF][T][4*Ceff]
+  float* dM = V + operand_floats(nV);         // [WF][T][Cout]
+  float* slabs = dM + operand_floats(nM);     // [ns][WF][4*Ceff][Cout]
   s2_input_transform(g, x, V, nullptr, s);
   InArgs da;
   memset(&da, 0, sizeof(da));
   da.s2_skip = -1;
   da.v[0].p = dy + g.y_coff; da.v[0].sn = (long)OH * OW * g.ldy; da.v[0].sh = (long)OW * g.ldy; da.v[0].sw = g.ldy;
-  da.H = OH; da.W = OW; da.TH = OH / 2; da.TW = OW / 2; da.C = g.Cout; da.T = T; da.ldv = g.Cout; da.V = dM;
+  da.H = OH; da.W = OW; da.TH = OH / WM; da.TW = OW / WM; da.C = g.Cout; da.T = T; da.ldv = g.Cout; da.V = dM;
   hipLaunchKernelGGL(wino_outadj_kernel, dim3(op_grid(T, g.Cout / 4), 1, 1), dim3(256), 0, s, da);
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.A = V; b.B = dM; b.C = slabs; b.M = K4; b.N = g.Cout; b.K = (int)T;
   b.lda = K4; b.ldb = g.Cout; b.ldc = g.Cout;
-  b.sA = T * K4; b.sB = T * g.Cout; b.sC = (long)K4 * g.Cout; b.sSplit = 16L * K4 * g.Cout;
+  b.sA = T * K4; b.sB = T * g.Cout; b.sC = (long)K4 * g.Cout; b.sSplit = (long)WF * K4 * g.Cout;
   b.tiles_m = (K4 + Cfg::BM - 1) / Cfg::BM; b.tiles_n = (g.Cout + Cfg::BN - 1) / Cfg::BN;
   const int nkt = (int)((T + Cfg::BK - 1) / Cfg::BK);
   b.kt_per_split = (nkt + ns - 1) / ns;
   b.seg_mode = 3; b.seg_len = g.Ceff; b.seg_skip = 0;
   launch_bgemm<true>(b, ns, s);
   hipLaunchKernelGGL(wino_s2_filter_adj_kernel, dim3(grid1(4L * g.Ceff * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
-                     16L * K4 * g.Cout, g.Ceff, g.Cout, dw);
+                     (long)WF * K4 * g.Cout, g.Ceff, g.Cout, dw);
   return OTGAN_OK;
 }

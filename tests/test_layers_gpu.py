@@ -362,4 +362,5 @@ def test_full_size_adjoint_identities(dev, case):
     ysum = fwd(w + w2, (w + w2).t().contiguous())
     y2 = fwd(w2, w2T)
     err = float((ysum - y - y2).norm() / ysum.norm())
-    assert err < 5e-6, ("additivity", err)
+    # three independent fp32 evaluations: each carries the F(4x4,3x3) rounding (~7e-7 .. 2e-6 relative at K ~ 10^4)
+    assert err < 1e-5, ("additivity", err)
