@@ -101,8 +101,9 @@ __device__ __forceinline__ void bt1(const f32x4 (&x)[WA], f32x4 (&y)[WA]) {
   y[5] = x[1] - 1.5f * x[2] - 2.f * x[3] + 1.5f * x[4] + x[5];
 }
 // y = A^T x
-__device__ __forceinline__ void at1(const f32x4 (&x)[WA], f32x4 (&y)[WM]) {
-  const f32x4 s = x[1] + x[2], d = x[1] - x[2];
+template <class V>
+__device__ __forceinline__ void at1(const V (&x)[WA], V (&y)[WM]) {
+  const V s = x[1] + x[2], d = x[1] - x[2];
   y[0] = x[0] + s + x[3] + x[4];
   y[1] = d + 0.5f * x[3] - 2.f * x[4];
   y[2] = s + 0.25f * x[3] + 4.f * x[4];
@@ -126,12 +127,13 @@ __device__ __forceinline__ void g1(const f64x4 (&g)[3], f64x4 (&u)[WA]) {
   u[4] = (g[0] - 2.0 * g[1] + 4.0 * g[2]) * (1.0 / 15.0);
   u[5] = g[2];
 }
-// g = G^T u   (adjoint of g1, fp64)
-__device__ __forceinline__ void gt1(const f64x4 (&u)[WA], f64x4 (&g)[3]) {
-  const f64x4 a = u[1] * (1.0 / 3.0), b = u[2] * (1.0 / 3.0), c = u[3] * (-4.0 / 15.0), d = u[4] * (1.0 / 15.0);
-  g[0] = u[0] + a - b + 4.0 * c + d;
-  g[1] = a + b + 2.0 * c - 2.0 * d;
-  g[2] = a - b + c + 4.0 * d + u[5];
+// g = G^T u   (adjoint of g1; fp32: a weight GRADIENT, measured 5e-7 .. 9e-7 from fp64 either way, and the fp64
+// version needed 256 + 66 registers -- one wave per SIMD -- for 2.1 TB/s)
+__device__ __forceinline__ void gt1(const f32x4 (&u)[WA], f32x4 (&g)[3]) {
+  const f32x4 a = u[1] * (1.f / 3.f), b = u[2] * (1.f / 3.f), c = u[3] * (-4.f / 15.f), d = u[4] * (1.f / 15.f);
+  g[0] = u[0] + a - b + 4.f * c + d;
+  g[1] = a + b + 2.f * c - 2.f * d;
+  g[2] = a - b + c + 4.f * d + u[5];
 }
 __device__ __forceinline__ f64x4 to_d(f32x4 v) { return __builtin_convertvector(v, f64x4); }
 __device__ __forceinline__ f32x4 to_f(f64x4 v) { return __builtin_convertvector(v, f32x4); }
@@ -159,22 +161,17 @@ __device__ __forceinline__ void tf_filter(const f32x4 (&g)[3][3], Emit&& emit) {
 // dg = G^T dU G; the columns of dU are pulled through `col(j, out[WA])`
 template <class Col>
 __device__ __forceinline__ void tf_filter_adj(Col&& col, f32x4 (&dg)[3][3]) {
-  f64x4 p[3][WA];
+  f32x4 p[3][WA];
 #pragma unroll
   for (int j = 0; j < WA; ++j) {
-    f64x4 u[WA], g[3];
+    f32x4 u[WA], g[3];
     col(j, u);
     gt1(u, g);
 #pragma unroll
     for (int i = 0; i < 3; ++i) p[i][j] = g[i];
   }
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    f64x4 g[3];
-    gt1(p[i], g);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) dg[i][j] = to_f(g[j]);
-  }
+  for (int i = 0; i < 3; ++i) gt1(p[i], dg[i]);
 }
 
 // ---- streaming kernels --------------------------------------------------------------------
@@ -444,11 +441,11 @@ __global__ __launch_bounds__(256) void wino_filter_adj_kernel(const float* __res
   const float* src = slabs + (long)ci * ldu + (long)cls * Cout + co;
   f32x4 dg[3][3];
   tf_filter_adj(
-      [&](int j, f64x4(&u)[WA]) {
+      [&](int j, f32x4(&u)[WA]) {
 #pragma unroll
         for (int i = 0; i < WA; ++i) {
-          f64x4 s = to_d(ld4(src + (i * WA + j) * fs));
-          for (int k = 1; k < nsplit; ++k) s += to_d(ld4(src + k * split_stride + (i * WA + j) * fs));
+          f32x4 s = ld4(src + (i * WA + j) * fs);
+          for (int k = 1; k < nsplit; ++k) s += ld4(src + k * split_stride + (i * WA + j) * fs);
           u[i] = s;
         }
       },
@@ -533,13 +530,13 @@ __global__ __launch_bounds__(256) void wino_s2_filter_adj_kernel(const float* __
   const float* src = slabs + r * Cout + co;
   f32x4 dg[3][3];
   tf_filter_adj(
-      [&](int j, f64x4(&u)[WA]) {
+      [&](int j, f32x4(&u)[WA]) {
 #pragma unroll
         for (int i = 0; i < WA; ++i) {
-          f64x4 sacc = {0.0, 0.0, 0.0, 0.0};
+          f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
           if (s2_present(cls, i * WA + j, 0)) {
-            sacc = to_d(ld4(src + (i * WA + j) * fs));
-            for (int k = 1; k < nsplit; ++k) sacc += to_d(ld4(src + k * split_stride + (i * WA + j) * fs));
+            sacc = ld4(src + (i * WA + j) * fs);
+            for (int k = 1; k < nsplit; ++k) sacc += ld4(src + k * split_stride + (i * WA + j) * fs);
           }
           u[i] = sacc;
         }
@@ -567,13 +564,18 @@ struct OutS2Args {
   int accumulate;
 };
 // (A^T M A) of the class's M, rows i0 .. i0+1 only (two output rows at a time keep the register count down)
+// DOUBLED (CReLU / CELU): a thread owns TWO channels (both halves of each): the two 36-value column passes of four
+// channels needed 256 VGPRs plus 160 AGPR copies -- one wave per SIMD.  Otherwise four channels.
 template <int ACT, bool DOUBLED>
 __global__ __launch_bounds__(256) void wino_s2_output_kernel(OutS2Args a) {
-  const int c4n = a.C >> 2;
+  constexpr int VW = DOUBLED ? 2 : 4;
+  typedef float VT __attribute__((ext_vector_type(VW)));
+  auto ldv = [](const float* p) { return *reinterpret_cast<const VT*>(p); };
+  const int cvn = a.C / VW;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= a.T * c4n) return;
-  const int c = (int)(idx % c4n) * 4;
-  const long t = idx / c4n;
+  if (idx >= a.T * cvn) return;
+  const int c = (int)(idx % cvn) * VW;
+  const long t = idx / cvn;
   const int tb = (int)(t % a.TW), ta = (int)((t / a.TW) % a.TH);
   const long n = t / ((long)a.TW * a.TH);
   const int cls = blockIdx.z;
@@ -581,19 +583,21 @@ __global__ __launch_bounds__(256) void wino_s2_output_kernel(OutS2Args a) {
   const View xv = a.x[cls];
   const float* in = a.Xh + t * a.ldm + (long)cls * a.Ceff + c;
   const long fs = a.T * a.ldm;
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  f32x4 Sp[WM][WA], Sn[DOUBLED ? WM : 1][WA];
+  VT zero;
+#pragma unroll
+  for (int q = 0; q < VW; ++q) zero[q] = 0.f;
+  VT Sp[WM][WA], Sn[DOUBLED ? WM : 1][WA];
 #pragma unroll
   for (int j = 0; j < WA; ++j) {
-    f32x4 col[WA], o[WM];
+    VT col[WA], o[WM];
 #pragma unroll
-    for (int i = 0; i < WA; ++i) col[i] = s2_present(cls, i * WA + j, WA - 1) ? ld4(in + (i * WA + j) * fs) : zero;
+    for (int i = 0; i < WA; ++i) col[i] = s2_present(cls, i * WA + j, WA - 1) ? ldv(in + (i * WA + j) * fs) : zero;
     at1(col, o);
 #pragma unroll
     for (int i = 0; i < WM; ++i) Sp[i][j] = o[i];
     if (DOUBLED) {
 #pragma unroll
-      for (int i = 0; i < WA; ++i) col[i] = s2_present(cls, i * WA + j, WA - 1) ? ld4(in + a.C + (i * WA + j) * fs) : zero;
+      for (int i = 0; i < WA; ++i) col[i] = s2_present(cls, i * WA + j, WA - 1) ? ldv(in + a.C + (i * WA + j) * fs) : zero;
       at1(col, o);
 #pragma unroll
       for (int i = 0; i < WM; ++i) Sn[DOUBLED ? i : 0][j] = o[i];
@@ -601,17 +605,17 @@ __global__ __launch_bounds__(256) void wino_s2_output_kernel(OutS2Args a) {
   }
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
-    f32x4 yp[WM], yn[WM];
+    VT yp[WM], yn[WM];
     at1(Sp[i], yp);
     if (DOUBLED) at1(Sn[DOUBLED ? i : 0], yn);
 #pragma unroll
     for (int j = 0; j < WM; ++j) {
       const long off = n * dv.sn + (WM * ta + i) * dv.sh + (WM * tb + j) * dv.sw + c;
-      f32x4 o = yp[j];
+      VT o = yp[j];
       if (ACT != 0 || DOUBLED) {
-        const f32x4 x4 = ld4(xv.p + n * xv.sn + (WM * ta + i) * xv.sh + (WM * tb + j) * xv.sw + c);
+        const VT x4 = ldv(xv.p + n * xv.sn + (WM * ta + i) * xv.sh + (WM * tb + j) * xv.sw + c);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < VW; ++q) {
           const float xq = x4[q];
           float dp = 1.f, dn = 1.f;
           if (ACT == 1) { dp = xq > 0.f ? 1.f : 0.f; dn = -xq > 0.f ? 1.f : 0.f; }
@@ -621,8 +625,8 @@ __global__ __launch_bounds__(256) void wino_s2_output_kernel(OutS2Args a) {
         }
       }
       float* dst = dv.p + off;
-      if (a.accumulate) o += ld4(dst);
-      st4(dst, o);
+      if (a.accumulate) o += ldv(dst);
+      *reinterpret_cast<VT*>(dst) = o;
     }
   }
 }
@@ -1155,6 +1159,7 @@ int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float
   const int OH = g.H / 2, OW = g.W / 2;
   oa.v[0].p = y + g.y_coff; oa.v[0].sn = (long)OH * OW * g.ldy; oa.v[0].sh = (long)OW * g.ldy; oa.v[0].sw = g.ldy;
   oa.TH = OH / WM; oa.TW = OW / WM; oa.C = g.Cout; oa.T = T; oa.ldm = g.Cout; oa.Mh = Mh; oa.bias = bias;
+
   hipLaunchKernelGGL(wino_output_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 1), dim3(256), 0, s, oa);
   return OTGAN_OK;
 }
@@ -1196,7 +1201,7 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   parity_views(g.H, g.W, x, g.ldx, oa.x);
   oa.TH = OH / WM; oa.TW = OW / WM; oa.C = g.C; oa.Ceff = g.Ceff; oa.T = T; oa.ldm = K4; oa.Xh = Xh;
   oa.accumulate = accumulate;
-  const dim3 grid(grid1(T * (g.C / 4)), 1, 4), blk(256);
+  const dim3 grid(grid1(T * (g.C / (g.doubled ? 2 : 4))), 1, 4), blk(256);
   if (g.doubled) {
     if (g.act == 2) hipLaunchKernelGGL((wino_s2_output_kernel<2, true>), grid, blk, 0, s, oa);
     else hipLaunchKernelGGL((wino_s2_output_kernel<1, true>), grid, blk, 0, s, oa);
