@@ -30,7 +30,7 @@ __host__ __device__ __forceinline__ bool s2_present(int cls, int f, int skip) {
 // fp32-exact products: every fp32 operand is stored as three bf16 planes x = hi + mid + lo
 // (8 + 8 + 8 mantissa bits) by the kernel that produces it, and the GEMM issues the six MFMAs
 // hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid per k slab, accumulating in fp32.  Measured
-// 2.3e-7 .. 5e-7 relative L2 against fp64 at K = 256 .. 1024 (the fp32 MFMA chain: 1.3e-6).
+// 2.3e-7 .. 5e-7 relative L2 against fp64 at K = 256 .. 1024 on plain GEMMs (the fp32 MFMA chain: 1.3e-6).
 typedef unsigned short u16;
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -92,7 +92,7 @@ struct BgArgs {
   int xmap;   // 1: XCD = row-tile residue, 2: XCD = column-tile residue, 0: linear
   // Strided layers: the zero-padded 2-tap windows make the filter transform of an even-parity
   // class vanish at one frequency index per dimension (G row 0 picks the zero tap in the forward
-  // orientation, row 3 in the flipped one), so 15 of the 64 (class, frequency) blocks are
+  // orientation, the last row in the flipped one), so 23 of the 144 (class, frequency) blocks are
   // structurally zero and are skipped: seg_mode 1 = classes along K (forward), 2 = along N
   // (dgrad), 3 = along M (wgrad); seg_len = channels per class; seg_skip = vanishing index.
   int seg_mode, seg_len, seg_skip;
