@@ -89,7 +89,15 @@ struct BgArgs {
   long lda, ldb, ldc;
   long sA, sB, sC, sSplit;
   int tiles_m, tiles_n, kt_per_split;
-  int xmap;   // 1: XCD = row-tile residue, 2: XCD = column-tile residue, 0: linear
+  int xmap;   // 1: XCD = row-tile residue, 2: XCD = column-tile residue, 0: linear, 4: frequency-major (fmap)
+  // xmap 4 (x3 kernel, one-dimensional grid in x): workgroup x runs on XCD x % 8 (round-robin placement) and takes
+  // entry x / 8 of that XCD's queue = all tiles of frequency fmap[xcd][0], then of fmap[xcd][1], ...  Every tile of
+  // a frequency then shares ONE L2: V[f] and U[f] are fetched from HBM once instead of once per XCD that
+  // happens to hold one of the frequency's tiles (measured 2.3 - 3x the unique bytes with the tile-residue maps
+  // on the F(4x4,3x3) shapes, where the GEMMs run at 2.7 - 4.2 TB/s of HBM traffic).
+  signed char fmap[8][8];   // frequency per (XCD, slot), -1 = none; + 64: first half of the tiles only, + 128 (as
+                            // unsigned): second half (36 frequencies do not divide by 8: the last four are shared
+                            // by two XCDs each so that every XCD carries 4.5 frequencies)
   // Strided layers: the zero-padded 2-tap windows make the filter transform of an even-parity
   // class vanish at one frequency index per dimension (G row 0 picks the zero tap in the forward
   // orientation, the last row in the flipped one), so 23 of the 144 (class, frequency) blocks are
@@ -161,8 +169,21 @@ template <bool PIPE, bool TL>
 __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_bgemm_x3_kernel(BgArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
   const int x = blockIdx.x;
-  int tm, tn;
-  if (a.xmap == 1) {
+  int tm, tn, fsel = -1;
+  if (a.xmap == 4) {
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int xcd = x & 7, idx = x >> 3;
+    const int slot = idx / tiles, tile = idx - slot * tiles;
+    const int code = (unsigned char)a.fmap[xcd][slot];
+    if (code == 255) return;
+    const int half = (tiles + 1) >> 1;
+    if ((code & 64) && tile >= half) return;
+    if ((code & 128) && tile < half) return;
+    // (the division runs on the vector ALU: the operand addresses of the global_load_lds stream must be scalar)
+    fsel = __builtin_amdgcn_readfirstlane(code & 63);
+    tn = __builtin_amdgcn_readfirstlane(tile % a.tiles_n);
+    tm = __builtin_amdgcn_readfirstlane(tile / a.tiles_n);
+  } else if (a.xmap == 1) {
     const int xcd = x & 7, idx = x >> 3;
     tn = idx % a.tiles_n;
     tm = (idx / a.tiles_n) * 8 + xcd;
@@ -174,7 +195,7 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     tn = x % a.tiles_n;
     tm = x / a.tiles_n;
   }
-  const int f = lpt_frequency(a.seg_mode, blockIdx.z);
+  const int f = fsel >= 0 ? fsel : lpt_frequency(a.seg_mode, blockIdx.z);
   const int m0 = a.m_begin + tm * X3_BM, n0 = tn * X3_BN;
   const int Kz = a.ztab ? a.zK[f] : a.K;
   if (a.seg_mode == 2 || a.seg_mode == 3) {

@@ -718,6 +718,55 @@ __global__ __launch_bounds__(Cfg::THREADS) void wino_bgemm_kernel(BgArgs a) {
 
 
 
+// Frequency-major grid of the split-precision GEMMs (BgArgs::fmap): the 36 frequencies are dealt to the 8 XCDs by
+// longest-processing-time-first on their work (strided layers: 4, 2 or 1 parity classes are present at a
+// frequency -- contraction runs in the forward pass, surviving tiles in dgrad / wgrad), each XCD's queue longest
+// first.  Returns the grid size in x.  OTGAN_X3_FMAP=0 keeps the tile-residue maps of round 1.
+bool use_fmap() {
+  static const bool on = [] {
+    const char* e = getenv("OTGAN_X3_FMAP");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+unsigned build_fmap(BgArgs& b) {
+  int load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  memset(b.fmap, -1, sizeof(b.fmap));
+  auto weight = [&](int f) {
+    if (!b.seg_mode) return 4;
+    int w = 0;
+    for (int c = 0; c < 4; ++c) w += s2_present(c, f, b.seg_skip) ? 1 : 0;
+    return w;
+  };
+  if (!b.seg_mode) {
+    // equal work per frequency: four whole frequencies per XCD, the last four as halves (4.5 each)
+    for (int f = 0; f < WF; ++f) {
+      if (f < 32) {
+        b.fmap[f & 7][cnt[f & 7]++] = (signed char)f;
+      } else {
+        const int x0 = 2 * (f - 32);
+        b.fmap[x0][cnt[x0]++] = (signed char)(f | 64);
+        b.fmap[x0 + 1][cnt[x0 + 1]++] = (signed char)(f | 128);
+      }
+    }
+    b.xmap = 4;
+    return 8u * 5u * (unsigned)(b.tiles_m * b.tiles_n);
+  }
+  for (int w = 4; w >= 1; --w)
+    for (int f = 0; f < WF; ++f) {
+      if (weight(f) != w) continue;
+      int best = 0;
+      for (int x = 1; x < 8; ++x)
+        if (load[x] < load[best]) best = x;
+      b.fmap[best][cnt[best]++] = (signed char)f;
+      load[best] += w;
+    }
+  int slots = 0;
+  for (int x = 0; x < 8; ++x) slots = cnt[x] > slots ? cnt[x] : slots;
+  b.xmap = 4;
+  return 8u * (unsigned)slots * (unsigned)(b.tiles_m * b.tiles_n);
+}
+
 template <bool TN>
 void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
   size_t lds;
@@ -746,7 +795,8 @@ void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
     int min_k = a.K;
     if (a.seg_mode == 1) min_k = a.seg_len;
     else if (nsplit > 1) min_k = a.K - (nsplit - 1) * b.kt_per_split * X3_BK;
-    const dim3 grid(b.tiles_m * b.tiles_n, nsplit, WF);
+    dim3 grid(b.tiles_m * b.tiles_n, nsplit, WF);
+    if (use_fmap()) grid = dim3(build_fmap(b), nsplit, 1);
     if (min_k >= 4 * X3_SK) hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, false>), grid, dim3(X3_THREADS), X3_LDS, s, b);
     else hipLaunchKernelGGL((wino_bgemm_x3_kernel<false, false>), grid, dim3(X3_THREADS), X3_LDS, s, b);
     return;
@@ -781,7 +831,8 @@ void launch_bgemm_tl(const BgArgs& a, int nsplit, hipStream_t s) {
   b.pA = WF * b.sAp; b.pB = WF * b.sBp;
   b.cbA = a.M / 16; b.cbB = a.N / 16;
   const int min_k = nsplit > 1 ? a.K - (nsplit - 1) * b.kt_per_split * X3_BK : a.K;
-  const dim3 grid(b.tiles_m * b.tiles_n, nsplit, WF);
+  dim3 grid(b.tiles_m * b.tiles_n, nsplit, WF);
+  if (use_fmap()) grid = dim3(build_fmap(b), nsplit, 1);
   if (min_k >= 4 * X3_SK) hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, true>), grid, dim3(X3_THREADS), X3_LDS, s, b);
   else hipLaunchKernelGGL((wino_bgemm_x3_kernel<false, true>), grid, dim3(X3_THREADS), X3_LDS, s, b);
 }
