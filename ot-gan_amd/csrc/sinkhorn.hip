@@ -129,6 +129,11 @@ __global__ void row_halfmeansq_kernel(const float* x, long ld, int rows, int D, 
 // Thread (idx = t & 127, q = t >> 7) holds row-role values K[idx][32q..32q+31] and
 // column-role values K[32q..32q+31][idx]; potentials live in LDS.  Per half-sweep: each
 // thread reduces its 32 values, the four quarter-partials are combined through LDS.
+// (Round 2 tried the four partials of a line in adjacent lanes, combined with two DPP exchanges and ONE barrier
+// per half-sweep instead of two: 1.12 us per half-sweep against 1.07 us for this form at N = 128 -- the
+// half-sweep is bound by the CU's transcendental rate, 16384 v_exp_f32 per problem at 16 per clock = 0.5 us, plus
+// ~140 other VALU instructions per thread on two waves per SIMD, not by the barriers.  Kept this form: its plan
+// stores are fully coalesced.)
 __device__ __forceinline__ void small_half_step(const float (&kv)[32], const float* s_in,
                                                 float* s_out, float (*s_pm)[128],
                                                 float (*s_ps)[128], int idx, int q, int limit) {
