@@ -26,6 +26,6 @@ for k in sorted(f, key=lambda k: -f[k][1]):
     rd = f[k][0] * 1024 * 2 / n / 1e6
     wr = w[k][0] * 1024 / max(w[k][2], 1) / 1e6 if k in w else 0
     us = f[k][1] / n / 1e3
-    print(f"{k} n={n} avg={us:7.1f}us rd={rd:8.1f}MB wr={wr:8.1f}MB {(rd+wr)/us*1e-3:6.2f} TB/s")
+    print(f"{k} n={n} avg={us:7.1f}us rd={rd:8.1f}MB wr={wr:8.1f}MB {(rd+wr)/us:6.2f} TB/s")
 PY
 rm -rf $R/gpurun_out/lyf $R/gpurun_out/lyw
