@@ -82,6 +82,36 @@ def run_critic64(mod):
             "var_shapes": np.array([",".join(map(str, S.VARS[k].shape)) for k in names])}
 
 
+def run_data_init(mod, tag, B, opts):
+    """The reference's INTENDED data-dependent initialisation (utils/nn.py:133-162; built by train.py:52-54 but never
+    fetched there): the init=True pass with its g / b assigns executed (eagerly, layer by layer, so that
+    every layer sees the normalised output of the previous one).  Stored: input, noise, the g and b of every layer
+    after the pass and the pass's outputs (fp32).  V follows the name-seeded recipe."""
+    base.set_dtype(np.float64)
+    S.reset(seed=zlib.crc32(("init" + tag).encode()) & 0xffff)
+    rs = np.random.RandomState(zlib.crc32(("xinit" + tag).encode()) & 0xffff)
+    x = base.T(fp32_uniform(rs, (B, 32, 32, 3)))
+    S.EAGER_ASSIGN[0] = True
+    n0 = len(S.DRAWS)
+    f = np.asarray(mod.discriminator(x, init=True, **opts))
+    img = np.asarray(mod.generator(B, init=True, **opts))
+    S.EAGER_ASSIGN[0] = False
+    noise = S.DRAWS[n0:]
+    names = sorted(S.VARS.keys())
+    out = {"x": np.asarray(x, np.float32), "features_init": f.astype(np.float32), "image_init": img.astype(np.float32),
+           "var_names": np.array(names),
+           "var_shapes": np.array([",".join(map(str, S.VARS[k].shape)) for k in names])}
+    for k in names:
+        if k.endswith("/g") or k.endswith("/b"):
+            out["val:" + k] = np.asarray(S.VARS[k], np.float64)
+    for i, u in enumerate(noise):
+        out[f"noise{i}"] = u
+    # after the pass a plain forward reproduces the init-pass output (same g, b)
+    f2 = np.asarray(mod.discriminator(x, **opts))
+    assert np.allclose(f2, f, rtol=1e-10, atol=1e-12)
+    return out
+
+
 def run_optimisers(nn):
     """Three applications of each reference update rule in float32 on fixed gradients."""
     base.set_dtype(np.float32)
@@ -123,6 +153,8 @@ def main():
     np.savez_compressed(os.path.join(OUT, "nets_dcgan.npz"), **run_model(dcgan, "dcgan", 2, {}))
     np.savez_compressed(os.path.join(OUT, "nets_densenet.npz"), **run_model(densenet, "densenet", 2, {}))
     np.savez_compressed(os.path.join(OUT, "nets_dcgan_critic64.npz"), **run_critic64(dcgan))
+    np.savez_compressed(os.path.join(OUT, "nets_dcgan_datainit.npz"), **run_data_init(dcgan, "dcgan", 4, {}))
+    np.savez_compressed(os.path.join(OUT, "nets_densenet_datainit.npz"), **run_data_init(densenet, "densenet", 4, {}))
     np.savez_compressed(os.path.join(OUT, "nets_densenet_small_celu.npz"),
                         **run_model(densenet, "densenet_small", 3,
                                     dict(layers_per_block=3, filters_per_layer=8, nonlinearity="celu")))

@@ -70,20 +70,38 @@ def upsample2(x):
     return x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
 
 
-def conv2d(xs, p, pre=None, stride=1, upsample=False):
-    """nn.py:327-338 with weight norm.  p = {'V','g','b'}"""
+def _data_init(y0, p, init_scale):
+    """nn.py:137-161 (the init=True branch of get_params): y0 = f(x, l2_normalize(V)); moments over all axes but the
+    last; g <- init_scale / sqrt(var), b <- -mean * g  (assigned in place)."""
+    axes = tuple(range(y0.dim() - 1))
+    m = y0.mean(axes)
+    v = y0.var(axes, unbiased=False)
+    with torch.no_grad():
+        g = init_scale / torch.sqrt(v)
+        p["g"].copy_(g)
+        p["b"].copy_(-m * g)
+
+
+def conv2d(xs, p, pre=None, stride=1, upsample=False, init=False, init_scale=1.0):
+    """nn.py:327-338 with weight norm.  p = {'V','g','b'}; init: the data-dependent initialisation pass"""
     if not isinstance(xs, (list, tuple)):
         xs = [xs]
     if upsample:
         xs = [upsample2(torch.cat(list(xs), 3))]
     x = apply_pre_activation(xs, pre, 3)
+    if init:
+        with torch.no_grad():
+            _data_init(conv2d_nhwc(x, weight_norm(p["V"], torch.ones_like(p["g"])), stride), p, init_scale)
     y = conv2d_nhwc(x, weight_norm(p["V"], p["g"]), stride)
     return y + p["b"]
 
 
-def dense(x, p, pre=None):
+def dense(x, p, pre=None, init=False, init_scale=1.0):
     """nn.py:314-325"""
     x = apply_pre_activation(x, pre, 1)
+    if init:
+        with torch.no_grad():
+            _data_init(x @ weight_norm(p["V"], torch.ones_like(p["g"])), p, init_scale)
     return x @ weight_norm(p["V"], p["g"]) + p["b"]
 
 
@@ -160,28 +178,28 @@ def init_params(shapes, scope, gen, dtype=torch.float32, device="cpu"):
 
 
 # ----------------------------------------------------------------------------- DCGAN
-def dcgan_discriminator(x, P, nonlinearity="crelu", scope="discriminator"):
+def dcgan_discriminator(x, P, nonlinearity="crelu", scope="discriminator", init=False):
     """models/dcgan.py:7-22"""
-    x = conv2d(x, P[f"{scope}/conv2d_0"], None)
-    x = conv2d(x, P[f"{scope}/conv2d_1"], nonlinearity, 2)
-    x = conv2d(x, P[f"{scope}/conv2d_2"], nonlinearity, 2)
-    x = conv2d(x, P[f"{scope}/conv2d_3"], nonlinearity, 2)
+    x = conv2d(x, P[f"{scope}/conv2d_0"], None, init=init)
+    x = conv2d(x, P[f"{scope}/conv2d_1"], nonlinearity, 2, init=init)
+    x = conv2d(x, P[f"{scope}/conv2d_2"], nonlinearity, 2, init=init)
+    x = conv2d(x, P[f"{scope}/conv2d_3"], nonlinearity, 2, init=init)
     return feature_head(x)
 
 
-def dcgan_generator(u, P, scope="generator"):
+def dcgan_generator(u, P, scope="generator", init=False):
     """models/dcgan.py:28-52; u: [B,100] uniform(-1,1) noise"""
     B = u.shape[0]
     base = int(round(math.sqrt(P[f"{scope}/dense_0"]["V"].shape[1] // 2048)))   # 4 for 32x32 (reference), 8 for 64x64
-    x = glu(dense(u, P[f"{scope}/dense_0"], None), 1).reshape(B, base, base, 1024)
-    x = glu(conv2d(x, P[f"{scope}/conv2d_0"], None, 1, True), 3)
-    x = glu(conv2d(x, P[f"{scope}/conv2d_1"], None, 1, True), 3)
-    x = glu(conv2d(x, P[f"{scope}/conv2d_2"], None, 1, True), 3)
-    return torch.tanh(conv2d(x, P[f"{scope}/conv2d_3"], None))
+    x = glu(dense(u, P[f"{scope}/dense_0"], None, init=init), 1).reshape(B, base, base, 1024)
+    x = glu(conv2d(x, P[f"{scope}/conv2d_0"], None, 1, True, init=init), 3)
+    x = glu(conv2d(x, P[f"{scope}/conv2d_1"], None, 1, True, init=init), 3)
+    x = glu(conv2d(x, P[f"{scope}/conv2d_2"], None, 1, True, init=init), 3)
+    return torch.tanh(conv2d(x, P[f"{scope}/conv2d_3"], None, init=init, init_scale=0.1))     # models/dcgan.py:50
 
 
 # ----------------------------------------------------------------------------- DenseNet
-def densenet_discriminator(x, P, nonlinearity="crelu", L=16, scope="discriminator"):
+def densenet_discriminator(x, P, nonlinearity="crelu", L=16, scope="discriminator", init=False):
     """models/densenet.py:7-45"""
     k = [0]
 
@@ -190,16 +208,16 @@ def densenet_discriminator(x, P, nonlinearity="crelu", L=16, scope="discriminato
         k[0] += 1
         return p
 
-    x = conv2d(x, nxt(), None)
+    x = conv2d(x, nxt(), None, init=init)
     for _ in range(3):
         xs = [x]
         for _r in range(L):
-            xs.append(conv2d(xs, nxt(), nonlinearity))
-        x = conv2d(xs, nxt(), nonlinearity, 2)
+            xs.append(conv2d(xs, nxt(), nonlinearity, init=init))
+        x = conv2d(xs, nxt(), nonlinearity, 2, init=init)
     return feature_head(x)
 
 
-def densenet_generator(us, P, nonlinearity="crelu", L=16, Fg=16, scope="generator"):
+def densenet_generator(us, P, nonlinearity="crelu", L=16, Fg=16, scope="generator", init=False):
     """models/densenet.py:51-88; us = [u0 [B,100], u1 [B,8,8,F], u2 [B,16,16,F], u3 [B,32,32,F]]"""
     B = us[0].shape[0]
     k = [0]
@@ -209,15 +227,15 @@ def densenet_generator(us, P, nonlinearity="crelu", L=16, Fg=16, scope="generato
         k[0] += 1
         return p
 
-    x = dense(us[0], P[f"{scope}/dense_0"], None).reshape(B, 8, 8, Fg)
+    x = dense(us[0], P[f"{scope}/dense_0"], None, init=init).reshape(B, 8, 8, Fg)
     xs = [x, us[1]]
     for blk in range(3):
         for _r in range(L):
-            xs.append(conv2d(xs, nxt(), nonlinearity))
+            xs.append(conv2d(xs, nxt(), nonlinearity, init=init))
         if blk < 2:
-            x = conv2d(xs, nxt(), nonlinearity, 1, True)
+            x = conv2d(xs, nxt(), nonlinearity, 1, True, init=init)
             xs = [x, us[blk + 2]]
-    return torch.tanh(conv2d(xs, nxt(), nonlinearity))
+    return torch.tanh(conv2d(xs, nxt(), nonlinearity, init=init, init_scale=0.1))     # models/densenet.py:86
 
 
 # ----------------------------------------------------------------------------- optimisers

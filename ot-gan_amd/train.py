@@ -9,7 +9,8 @@ matching problem (it must be even, train.py:34) -- and is decoupled from the num
 physical GPUs (= torch.distributed world size): every rank owns nr_gpu / world shards.
 
 Added flags (not in the reference): --synthetic (random CIFAR-shaped data instead of the
-pickled dataset), --synthetic_size, --matching_scope global|local, --max_steps, --image_size, --save_every.
+pickled dataset), --synthetic_size, --matching_scope global|local, --max_steps, --image_size, --save_every,
+--data_dependent_init.
 
 Checkpoints (`<save_dir>/med_gan_params-<epoch>`, the reference's naming, train.py:275-277) are torch pickles
 of {variable name: tensor} plus optimiser moments / step count and EMA shadows (which the reference's
@@ -53,6 +54,9 @@ def build_parser():
     p.add_argument('--image_size', type=int, default=32)
     p.add_argument('--save_every', type=int, default=200, help='checkpoint every this many epochs (reference: 200, train.py:275)')
     p.add_argument('--synthetic_size', type=int, default=50000, help='number of synthetic images with --synthetic')
+    p.add_argument('--data_dependent_init', action='store_true',
+                   help="run the reference's intended (never executed, SURVEY F7) data-dependent initialisation pass "
+                        "on the first batch: g <- init_scale / std, b <- -mean * g per layer (utils/nn.py:133-162)")
     return p
 
 
@@ -106,14 +110,15 @@ def main(argv=None):
         print(args)
     np.random.seed(args.seed)                                      # train.py:48
     torch.manual_seed(args.seed + rank)
-    model = OTGAN(args, dev)
-    if rank == 0:
-        print("model has a hidden representation with %d features" % model.num_features)   # train.py:56
-
     if args.synthetic:
         trainx = np.random.rand(args.synthetic_size, args.image_size, args.image_size, 3).astype(np.float32) * 2 - 1
     else:
         trainx = load_cifar(args.data_dir)
+    init_batch = torch.from_numpy(trainx[:args.batch_size]) if args.data_dependent_init else None
+    model = OTGAN(args, dev, init_batch=init_batch)
+    if rank == 0:
+        print("model has a hidden representation with %d features" % model.num_features)   # train.py:56
+
     per_step = args.nr_gpu * args.batch_size
     nr_batches = trainx.shape[0] // per_step                        # train.py:159
     if rank == 0:

@@ -31,7 +31,9 @@ class OTGAN:
     plus: image_size, matching_scope ('global' = one OT problem set over all ranks, the
     reference's semantics; 'local' = an independent problem set per rank)."""
 
-    def __init__(self, args, device):
+    def __init__(self, args, device, init_batch=None):
+        """init_batch: [n, H, W, 3] data for the reference's intended data-dependent initialisation pass
+        (only with args.data_dependent_init; nn.py:133-162, train.py:52-54)."""
         self.args = args
         self.device = device
         self.rank, self.world = parallel.get_rank(), parallel.world_size()
@@ -62,10 +64,19 @@ class OTGAN:
             if args.model != "dcgan":
                 raise ValueError("--image_size other than 32 is only available for --model dcgan")
             self.model_opts["image_size"] = size
-        # parameter creation pass (train.py:52-56; the data-dependent init it builds is never run)
-        with torch.no_grad():
-            f = self.discriminator(torch.zeros(2, size, size, 3, device=device), init=True, **self.model_opts)
-            self.generator(batch_size=2, init=True, device=device, **self.model_opts)
+        # parameter creation pass (train.py:52-56; the data-dependent init it builds is never run by the reference:
+        # default g = 1, b = 0; --data_dependent_init executes it on `init_batch`)
+        ddi = bool(getattr(args, "data_dependent_init", False))
+        if ddi and init_batch is None:
+            raise ValueError("--data_dependent_init needs an initial data batch (OTGAN(args, device, init_batch=...))")
+        nn.data_dependent_init(ddi)
+        try:
+            with torch.no_grad():
+                x0 = init_batch.to(device) if ddi else torch.zeros(2, size, size, 3, device=device)
+                f = self.discriminator(x0, init=True, **self.model_opts)
+                self.generator(batch_size=x0.shape[0], init=True, device=device, **self.model_opts)
+        finally:
+            nn.data_dependent_init(False)
         self.num_features = f.shape[-1]
         # one flat buffer per network: optimiser / EMA / gradient all-reduce act on it in one go
         self.discriminator.flatten()
@@ -279,7 +290,7 @@ def default_args(**over):
              nr_sinkhorn_iter=500, single_batch=False, train_disc_against_ema=False, model='dcgan',
              load_params=False, model_name='med_gan_params-2399', no_sinkhorn=False,
              image_size=32, matching_scope='global', synthetic=False, max_steps=0, save_every=200,
-             synthetic_size=50000)
+             synthetic_size=50000, data_dependent_init=False)
     d.update(over)
     return argparse.Namespace(**d)
 

@@ -245,6 +245,30 @@ def _channels_eff(xs, pre_activation):
     return c * (2 if pre_activation in ("celu", "crelu") else 1), c
 
 
+# --------------------------------------------------------------------------------- data-dependent init
+# The reference builds a data-dependent initialisation pass (nn.py:133-162: g <- init_scale / std, b <- -mean * g of
+# every layer's output on an initial batch, layer by layer) but its train.py never runs it, so the
+# default here is the EFFECTIVE behaviour g = 1, b = 0.  `data_dependent_init(True)` (train.py --data_dependent_init)
+# makes an `init=True` call execute that pass: the statistics are taken from the HIP forward of the layer.
+_DATA_INIT = [False]
+
+
+def data_dependent_init(on=True):
+    _DATA_INIT[0] = bool(on)
+
+
+def _run_data_init(y0, g, b, init_scale):
+    """nn.py:137-161: moments over all axes but the last of y0 = f(x, l2_normalize(V)); assigns g and b in place."""
+    with torch.no_grad():
+        flat = y0.reshape(-1, y0.shape[-1]).double()
+        m = flat.mean(0)
+        v = flat.var(0, unbiased=False)
+        gi = init_scale / torch.sqrt(v)
+        g.copy_(gi.to(g.dtype))
+        b.copy_((-m * gi).to(b.dtype))
+    ops.bump_weights_epoch()
+
+
 # --------------------------------------------------------------------------------- layers
 @_scoped
 def dense(x, num_units, pre_activation='celu', init_scale=1., counters={}, init=False, ema=None,
@@ -261,6 +285,11 @@ def dense(x, num_units, pre_activation='celu', init_scale=1., counters={}, init=
     g = get_var_maybe_avg(f"{name}/g", (num_units,), "ones", ema, dev)
     b = get_var_maybe_avg(f"{name}/b", (num_units,), "zeros", ema, dev)
     xin = xs[0] if len(xs) == 1 else torch.cat(xs, 1)
+    if init and _DATA_INIT[0] and ema is None:
+        with torch.no_grad():
+            y0 = ops.dense_op(xin, V, torch.ones_like(g), torch.zeros_like(b), preact=ops.ACT[pre_activation],
+                              segs=[int(t.shape[-1]) for t in xs])
+        _run_data_init(y0, g, b, init_scale)
     return ops.dense_op(xin, V, g, b, preact=ops.ACT[pre_activation], segs=[int(t.shape[-1]) for t in xs])
 
 
@@ -289,6 +318,11 @@ def conv2d(x, num_filters, pre_activation='celu', filter_size=[3, 3], stride=[1,
         xin = xs.buffer
     else:
         xin = xs[0] if len(xs) == 1 else torch.cat(xs, 3)
+    if init and _DATA_INIT[0] and ema is None:
+        with torch.no_grad():
+            y0 = ops.conv2d_op(xin, V, torch.ones_like(g), torch.zeros_like(b), stride=stride[0], upsample=upsample,
+                               preact=ops.ACT[pre_activation], segs=[int(t.shape[-1]) for t in xs])
+        _run_data_init(y0, g, b, init_scale)
     return ops.conv2d_op(xin, V, g, b, stride=stride[0], upsample=upsample,
                          preact=ops.ACT[pre_activation], segs=[int(t.shape[-1]) for t in xs])
 
@@ -308,6 +342,14 @@ def dense_block(x, layers_per_block, filters_per_layer, pre_activation='celu', f
     (models/densenet.py:11-16, 60-65) as one in-place growing block.  Layer names / variables
     are the same `conv2d_<k>/{V,g,b}` the loop would have created."""
     xs = _as_list(x)
+    if init and _DATA_INIT[0] and ema is None:
+        # data-dependent init: every layer's statistics depend on the initialised layers before it -- the plain loop
+        # of the reference (models/densenet.py:11-16), one conv2d per layer (initialisation only)
+        feats = list(xs)
+        for _ in range(layers_per_block):
+            feats.append(conv2d(feats, filters_per_layer, pre_activation=pre_activation, filter_size=filter_size,
+                                counters=counters, init=True, ema=None, weight_norm=weight_norm))
+        return feats
     dev = xs[0].device
     segs0 = [int(t.shape[-1]) for t in xs]
     x0 = xs.buffer if isinstance(xs, ConcatList) and xs.buffer is not None else (

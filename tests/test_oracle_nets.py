@@ -84,3 +84,34 @@ def test_optimisers_match_reference_run(tag):
             ref = fix[f"{tag}_step{k + 1}_{i}"]
             assert ps[i].dtype == torch.float32
             assert np.max(np.abs(ps[i].numpy() - ref)) <= 2e-7 * max(1.0, float(np.max(np.abs(ref)))), (tag, k, i)
+
+
+@pytest.mark.parametrize("fname,kind", [("nets_dcgan_datainit.npz", "dcgan"), ("nets_densenet_datainit.npz", "densenet")])
+def test_data_dependent_init_matches_reference_run(fname, kind):
+    """The reference's intended data-dependent initialisation (utils/nn.py:133-162, executed eagerly over the stand-in
+    by oracle/make_golden_nets.py::run_data_init): g and b of every layer after the pass, and the pass's outputs."""
+    fix = GN.load(fname)
+    P = {}
+    for n, sh in zip(fix["var_names"], fix["var_shapes"]):
+        n = str(n)
+        shape = [int(v) for v in str(sh).split(",")]
+        layer, leaf = n.rsplit("/", 1)
+        # before the pass: V from the recipe, g = 1, b = 0 (the reference's initialisers, nn.py:124,143,160)
+        t = _t64(GN.variable(n, shape)) if leaf == "V" else (torch.ones(shape, dtype=torch.float64) if leaf == "g"
+                                                              else torch.zeros(shape, dtype=torch.float64))
+        P.setdefault(layer, {})[leaf] = t
+    x = _t64(fix["x"])
+    us = [_t64(u) for u in GN.noise(fix)]
+    if kind == "dcgan":
+        f = NT.dcgan_discriminator(x, P, init=True)
+        img = NT.dcgan_generator(us[0], P, init=True)
+    else:
+        f = NT.densenet_discriminator(x, P, init=True)
+        img = NT.densenet_generator(us, P, init=True)
+    assert _rel(f, fix["features_init"]) < 1e-6 and _rel(img, fix["image_init"]) < 1e-6       # stored as fp32
+    for key in fix:
+        if key.startswith("val:"):
+            layer, leaf = key[4:].rsplit("/", 1)
+            assert _rel(P[layer][leaf], fix[key]) < 1e-10, key
+    # the initialised layers are normalised: unit variance / zero mean pre-activations -> g is not all ones any more
+    assert not np.allclose(P["discriminator/conv2d_1"]["g"].numpy(), 1.0)
