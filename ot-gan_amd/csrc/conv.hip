@@ -1349,14 +1349,38 @@ __global__ __launch_bounds__(320) void conv_outer2_kernel(Outer2Args a) {
   }
 }
 
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, int nsplit, long n,
-                                   float* __restrict__ out) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += slab[(long)k * n + i];
-    out[i] = s;
+// out[i] = sum_k slab[k][i], deterministic.  A 256-thread block owns 64 groups of VW consecutive elements; its four
+// waves take the splits k = w, w + 4, ... (four independent loads in flight each) and are combined through LDS in
+// wave order.  (One thread per element summing all splits in sequence: 33 us for 100 slabs of 72 K floats, 0.85 TB/s,
+// 51 launches per DenseNet step.)
+template <int VW>
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int nsplit, long n,
+                                                          float* __restrict__ out) {
+  typedef float VT __attribute__((ext_vector_type(VW)));
+  __shared__ VT part[4][64];
+  const int e = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long i = ((long)blockIdx.x * 64 + e) * VW;
+  VT acc[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int q = 0; q < VW; ++q) acc[u][q] = 0.f;
+  if (i < n) {
+    int k = w;
+    for (; k + 12 < nsplit; k += 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] += *reinterpret_cast<const VT*>(slab + (long)(k + 4 * u) * n + i);
+    }
+    for (; k < nsplit; k += 4) acc[0] += *reinterpret_cast<const VT*>(slab + (long)k * n + i);
   }
+  part[w][e] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  __syncthreads();
+  if (w == 0 && i < n) *reinterpret_cast<VT*>(out + i) = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+}
+static void launch_slab_reduce(const float* slab, int nsplit, long n, float* out, hipStream_t s) {
+  const bool v4 = n % 4 == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  if (v4) hipLaunchKernelGGL(slab_reduce_kernel<4>, dim3((unsigned)ceil_div_l(n, 256)), dim3(256), 0, s, slab, nsplit, n, out);
+  else hipLaunchKernelGGL(slab_reduce_kernel<1>, dim3((unsigned)ceil_div_l(n, 64)), dim3(256), 0, s, slab, nsplit, n, out);
 }
 
 // dx[n,h,w,c] (+)= sum over the 2x2 replicas of dxv[n,2h+i,2w+j,c]  (legacy upsample dgrad)
@@ -2350,10 +2374,7 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
     }
     OTGAN_CHECK_LAUNCH("conv2d wgrad (dense16)");
     if (p.nsplit > 1) {
-      long blocks = ceil_div_l(p.slab_elems, 256);
-      if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)blocks), dim3(256), 0, s, (const float*)slabs, p.nsplit,
-                         p.slab_elems, dw);
+      launch_slab_reduce((const float*)slabs, p.nsplit, p.slab_elems, dw, s);
       OTGAN_CHECK_LAUNCH("slab_reduce");
     }
     return OTGAN_OK;
@@ -2421,10 +2442,7 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
       else hipLaunchKernelGGL(conv_outer_kernel<0>, grid, dim3(256), 0, s, oa, ct.taps[0]);
       OTGAN_CHECK_LAUNCH("conv2d wgrad (few channels)");
     }
-    long blocks = ceil_div_l(p.slab_elems, 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)blocks), dim3(256), 0, s, (const float*)workspace,
-                       p.nchunks, p.slab_elems, dw);
+    launch_slab_reduce((const float*)workspace, p.nchunks, p.slab_elems, dw, s);
     OTGAN_CHECK_LAUNCH("slab_reduce");
     return OTGAN_OK;
   }
@@ -2472,10 +2490,7 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
   }
   OTGAN_CHECK_LAUNCH("conv2d wgrad");
   if (p.nsplit > 1) {
-    long blocks = ceil_div_l(p.slab_elems, 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((int)blocks), dim3(256), 0, s, (const float*)slabs,
-                       p.nsplit, p.slab_elems, p.fold ? dweff : dw);
+    launch_slab_reduce((const float*)slabs, p.nsplit, p.slab_elems, p.fold ? dweff : dw, s);
     OTGAN_CHECK_LAUNCH("slab_reduce");
   }
   if (p.fold) {
