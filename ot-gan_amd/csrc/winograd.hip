@@ -15,6 +15,10 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <array>
+#include <atomic>
+#include <map>
+#include <mutex>
 
 #include "gemm_tile.h"
 
@@ -729,42 +733,87 @@ bool use_fmap() {
   }();
   return on;
 }
-unsigned build_fmap(BgArgs& b) {
-  int load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  memset(b.fmap, -1, sizeof(b.fmap));
-  auto weight = [&](int f) {
-    if (!b.seg_mode) return 4;
-    int w = 0;
-    for (int c = 0; c < 4; ++c) w += s2_present(c, f, b.seg_skip) ? 1 : 0;
-    return w;
-  };
-  if (!b.seg_mode) {
-    // equal work per frequency: four whole frequencies per XCD, the last four as halves (4.5 each)
-    for (int f = 0; f < WF; ++f) {
-      if (f < 32) {
-        b.fmap[f & 7][cnt[f & 7]++] = (signed char)f;
-      } else {
-        const int x0 = 2 * (f - 32);
-        b.fmap[x0][cnt[x0]++] = (signed char)(f | 64);
-        b.fmap[x0 + 1][cnt[x0 + 1]++] = (signed char)(f | 128);
-      }
+unsigned build_fmap(BgArgs& b) { return x3_build_fmap(b); }
+
+// Persistent "stream" GEMM (gemm_x3.h): workgroups per XCD = compute units / 8; OTGAN_X3_STREAM=0 keeps the
+// one-tile-per-workgroup kernel.  The parked-tile area is the tail of every Winograd workspace.
+int x3_stream_mode() {   // 0: off, 1: where it pays (few tiles per compute unit), 2: every launch
+  static const int m = [] {
+    const char* e = getenv("OTGAN_X3_STREAM");
+    return e ? atoi(e) : 1;
+  }();
+  return use_fmap() ? m : 0;
+}
+int x3_stream_nw() {
+  static const int nw = [] {
+    if (!x3_stream_mode()) return 0;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+      cus = 256;
+    (void)hipGetLastError();
+    int n = cus / 8;
+    return n > X3_SK_MAXW ? X3_SK_MAXW : n;
+  }();
+  return nw;
+}
+size_t x3_stream_floats() { return x3_stream_nw() ? x3_stream_ws_floats(8 * x3_stream_nw()) + 4 : 0; }
+// the area inside a workspace of `total` floats (16-byte aligned start)
+float* x3_stream_area(float* ws, size_t total) {
+  if (!x3_stream_nw()) return nullptr;
+  float* p = ws + (total - x3_stream_floats());
+  return reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(p) + 15) & ~(uintptr_t)15);
+}
+unsigned long long x3_next_epoch() {
+  // multiples of 16 (the low four bits of a flag carry the writer's XCD), never 0 (= "consumed")
+  static std::atomic<unsigned long long> e{(0x9e3779b97f4a7c15ull ^ ((unsigned long long)(uintptr_t)&e << 17)) & ~15ull};
+  unsigned long long v = e.fetch_add(0x632be59bd9b4e010ull) + 0x632be59bd9b4e010ull;
+  return v ? v : 16;
+}
+// plans are a function of the shape only: planned once per shape (a DCGAN step launches ~50 of these GEMMs)
+struct StreamPlan {
+  bool ok;
+  unsigned bound[8][41];
+  unsigned long long inv_tn;
+  unsigned char cmask[64];
+};
+bool cached_stream_plan(BgArgs& b, int nw) {
+  static std::mutex mu;
+  static std::map<std::array<int, 7>, StreamPlan> cache;
+  const std::array<int, 7> key = {b.M, b.N, b.K, b.seg_mode, b.seg_len, b.seg_skip, nw};
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(key);
+  if (it == cache.end()) {
+    StreamPlan p;
+    memset(&p, 0, sizeof(p));
+    p.ok = x3_plan_stream(b, nw);
+    if (p.ok) {
+      memcpy(p.bound, b.sk_bound, sizeof(p.bound));
+      p.inv_tn = b.sk_inv_tn;
+      memcpy(p.cmask, b.sk_cmask, sizeof(p.cmask));
     }
-    b.xmap = 4;
-    return 8u * 5u * (unsigned)(b.tiles_m * b.tiles_n);
+    it = cache.emplace(key, p).first;
   }
-  for (int w = 4; w >= 1; --w)
-    for (int f = 0; f < WF; ++f) {
-      if (weight(f) != w) continue;
-      int best = 0;
-      for (int x = 1; x < 8; ++x)
-        if (load[x] < load[best]) best = x;
-      b.fmap[best][cnt[best]++] = (signed char)f;
-      load[best] += w;
-    }
-  int slots = 0;
-  for (int x = 0; x < 8; ++x) slots = cnt[x] > slots ? cnt[x] : slots;
-  b.xmap = 4;
-  return 8u * (unsigned)slots * (unsigned)(b.tiles_m * b.tiles_n);
+  const StreamPlan& p = it->second;
+  if (!p.ok) return false;
+  memcpy(b.sk_bound, p.bound, sizeof(p.bound));
+  b.sk_inv_tn = p.inv_tn;
+  memcpy(b.sk_cmask, p.cmask, sizeof(p.cmask));
+  b.sk_nw = nw;
+  return true;
+}
+template <bool TL>
+bool launch_stream(BgArgs& b, hipStream_t s) {
+  if (!b.sk_partial || !x3_stream_nw() || b.xmap != 4) return false;
+  // Measured (tools/ablate/x3_phase.hip, random operands): with 4.5 and 9 tiles per compute unit the one-tile grid
+  // is 5 % faster (its rounds are full and nothing is parked); with 0.56 .. 2.25 the stream kernel is 1.05 - 1.33 x
+  // faster (no partly empty last round).
+  if (x3_stream_mode() == 1 && (long)b.tiles_m * b.tiles_n * 9 > 2L * 3 * x3_stream_nw()) return false;
+  if (!cached_stream_plan(b, x3_stream_nw())) return false;
+  ensure_lds<wino_bgemm_x3_stream_kernel<TL>>(X3_SK_LDS);
+  b.sk_epoch = x3_next_epoch();
+  hipLaunchKernelGGL((wino_bgemm_x3_stream_kernel<TL>), dim3(8 * b.sk_nw), dim3(X3_THREADS), X3_SK_LDS, s, b);
+  return true;
 }
 
 template <bool TN>
@@ -797,6 +846,7 @@ void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
     else if (nsplit > 1) min_k = a.K - (nsplit - 1) * b.kt_per_split * X3_BK;
     dim3 grid(b.tiles_m * b.tiles_n, nsplit, WF);
     if (use_fmap()) grid = dim3(build_fmap(b), nsplit, 1);
+    if (nsplit == 1 && launch_stream<false>(b, s)) return;
     if (min_k >= 4 * X3_SK) hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, false>), grid, dim3(X3_THREADS), X3_LDS, s, b);
     else hipLaunchKernelGGL((wino_bgemm_x3_kernel<false, false>), grid, dim3(X3_THREADS), X3_LDS, s, b);
     return;
@@ -833,6 +883,7 @@ void launch_bgemm_tl(const BgArgs& a, int nsplit, hipStream_t s) {
   const int min_k = nsplit > 1 ? a.K - (nsplit - 1) * b.kt_per_split * X3_BK : a.K;
   dim3 grid(b.tiles_m * b.tiles_n, nsplit, WF);
   if (use_fmap()) grid = dim3(build_fmap(b), nsplit, 1);
+  if (nsplit == 1 && launch_stream<true>(b, s)) return;
   if (min_k >= 4 * X3_SK) hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, true>), grid, dim3(X3_THREADS), X3_LDS, s, b);
   else hipLaunchKernelGGL((wino_bgemm_x3_kernel<false, true>), grid, dim3(X3_THREADS), X3_LDS, s, b);
 }
@@ -885,6 +936,7 @@ void class_views(const WinoGeo& g, P base, int ld, V (&v)[4]) {
 
 // K splits of the wgrad GEMM on the bf16 pipe (256 x 256 tiles: few tiles, long K)
 int x3_wgrad_splits(int M, int N, long T) {
+  if (x3_stream_nw()) return 1;   // the stream kernel balances the contraction over the compute units itself
   const int blocks = ((M + X3_BM - 1) / X3_BM) * ((N + X3_BN - 1) / X3_BN) * WF;
   static const int target = [] { const char* e = getenv("OTGAN_X3_SPLIT_TARGET"); return e ? atoi(e) : 256; }();
   int ns = (target + blocks - 1) / blocks;
@@ -918,7 +970,7 @@ size_t wino_fwd_ws_floats(const WinoGeo& g) {
   const size_t T = (size_t)wino_tiles(g);
   return operand_floats(op_elems(T, g.Cin)) + operand_floats(op_elems(T, 4 * g.Cout)) +
          operand_floats(std::max(op_elems(4 * g.Cout, g.Cin), op_elems(g.Cin, 4 * g.Cout))) +
-         WF * T * (size_t)(4 * g.Cout > g.Cin ? 4 * g.Cout : g.Cin);
+         WF * T * (size_t)(4 * g.Cout > g.Cin ? 4 * g.Cout : g.Cin) + x3_stream_floats();
 }
 size_t wino_dgrad_ws_floats(const WinoGeo& g) { return wino_fwd_ws_floats(g); }
 size_t wino_wgrad_ws_floats(const WinoGeo& g) {
@@ -926,7 +978,8 @@ size_t wino_wgrad_ws_floats(const WinoGeo& g) {
   const size_t Tp = (T + 63) / 64 * 64;
   const int ns = std::max(wgrad_splits(g), x3_wgrad_splits(g.Cin, 4 * g.Cout, (long)Tp));
   return operand_floats(std::max(op_elems(g.Cin, Tp), op_elems(Tp, g.Cin))) +
-         operand_floats(std::max(op_elems(4 * g.Cout, Tp), op_elems(Tp, 4 * g.Cout))) + (size_t)ns * WF * 4 * g.Cout * g.Cin;
+         operand_floats(std::max(op_elems(4 * g.Cout, Tp), op_elems(Tp, 4 * g.Cout))) + (size_t)ns * WF * 4 * g.Cout * g.Cin +
+         x3_stream_floats();
 }
 
 size_t wino_filter_floats(const WinoGeo& g, int which) {
@@ -986,6 +1039,7 @@ int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stri
   b.sA = T * g.Cin; b.sB = (long)N4 * g.Cin; b.sC = T * N4;
   b.tiles_m = (int)((T + Cfg::BM - 1) / Cfg::BM); b.tiles_n = (N4 + Cfg::BN - 1) / Cfg::BN;
   b.kt_per_split = (g.Cin + Cfg::BK - 1) / Cfg::BK;
+  b.sk_partial = x3_stream_area(ws, wino_fwd_ws_floats(g));
   launch_bgemm<false>(b, 1, s);
   OutArgs oa;
   memset(&oa, 0, sizeof(oa));
@@ -1025,6 +1079,7 @@ int wino_dgrad(const WinoGeo& g, const float* dy, const float* weff, long cls_st
   b.sA = T * K4; b.sB = (long)g.Cin * K4; b.sC = T * g.Cin;
   b.tiles_m = (int)((T + Cfg::BM - 1) / Cfg::BM); b.tiles_n = (g.Cin + Cfg::BN - 1) / Cfg::BN;
   b.kt_per_split = (K4 + Cfg::BK - 1) / Cfg::BK;
+  b.sk_partial = x3_stream_area(ws, wino_dgrad_ws_floats(g));
   launch_bgemm<false>(b, 1, s);
   OutArgs oa;
   memset(&oa, 0, sizeof(oa));
@@ -1065,6 +1120,7 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
     b.C = slabs; b.M = g.Cin; b.N = N4; b.K = (int)T;
     b.ldc = N4; b.sC = (long)g.Cin * N4; b.sSplit = (long)WF * g.Cin * N4;
     b.kt_per_split = (int)((T / X3_BK + ns - 1) / ns);
+    b.sk_partial = x3_stream_area(ws, wino_wgrad_ws_floats(g));
     launch_bgemm_tl(b, ns, s);
     hipLaunchKernelGGL(wino_filter_adj_kernel, dim3(grid1(4L * g.Cin * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
                        (long)WF * g.Cin * N4, g.Cin, g.Cout, dweff, cls_stride);
@@ -1154,7 +1210,7 @@ void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, u16* VP, h
 size_t wino_s2_fwd_ws_floats(const WinoS2Geo& g) {
   const size_t T = (size_t)wino_s2_tiles(g), K4 = 4 * (size_t)g.Ceff;
   return operand_floats(op_elems(T, K4)) + operand_floats(op_elems(T, g.Cout)) +
-         operand_floats(std::max(op_elems(g.Cout, K4), op_elems(K4, g.Cout))) + WF * T * K4;
+         operand_floats(std::max(op_elems(g.Cout, K4), op_elems(K4, g.Cout))) + WF * T * K4 + x3_stream_floats();
 }
 size_t wino_s2_dgrad_ws_floats(const WinoS2Geo& g) { return wino_s2_fwd_ws_floats(g); }
 size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g) {
@@ -1162,7 +1218,7 @@ size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g) {
   const size_t Tp = (T + 63) / 64 * 64;
   const int ns = std::max(s2_wgrad_splits(g), x3_wgrad_splits((int)K4, g.Cout, (long)Tp));
   return operand_floats(std::max(op_elems(K4, Tp), op_elems(Tp, K4))) + operand_floats(std::max(op_elems(g.Cout, Tp), op_elems(Tp, g.Cout))) +
-         (size_t)ns * WF * K4 * g.Cout;
+         (size_t)ns * WF * K4 * g.Cout + x3_stream_floats();
 }
 
 size_t wino_s2_filter_floats(const WinoS2Geo& g, int which) {
@@ -1204,6 +1260,7 @@ int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float
   b.tiles_m = (int)((T + Cfg::BM - 1) / Cfg::BM); b.tiles_n = (g.Cout + Cfg::BN - 1) / Cfg::BN;
   b.kt_per_split = (K4 + Cfg::BK - 1) / Cfg::BK;
   b.seg_mode = 1; b.seg_len = g.Ceff; b.seg_skip = 0;
+  b.sk_partial = x3_stream_area(ws, wino_s2_fwd_ws_floats(g));
   launch_bgemm<false>(b, 1, s);
   OutArgs oa;
   memset(&oa, 0, sizeof(oa));
@@ -1245,6 +1302,7 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   b.tiles_m = (int)((T + Cfg::BM - 1) / Cfg::BM); b.tiles_n = (K4 + Cfg::BN - 1) / Cfg::BN;
   b.kt_per_split = (g.Cout + Cfg::BK - 1) / Cfg::BK;
   b.seg_mode = 2; b.seg_len = g.Ceff; b.seg_skip = WA - 1;
+  b.sk_partial = x3_stream_area(ws, wino_s2_dgrad_ws_floats(g));
   launch_bgemm<false>(b, 1, s);
   OutS2Args oa;
   memset(&oa, 0, sizeof(oa));
@@ -1288,6 +1346,7 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
     b.ldc = g.Cout; b.sC = (long)K4 * g.Cout; b.sSplit = (long)WF * K4 * g.Cout;
     b.kt_per_split = (int)((T / X3_BK + ns - 1) / ns);
     b.seg_mode = 3; b.seg_len = g.Ceff; b.seg_skip = 0;
+    b.sk_partial = x3_stream_area(ws, wino_s2_wgrad_ws_floats(g));
     launch_bgemm_tl(b, ns, s);
     hipLaunchKernelGGL(wino_s2_filter_adj_kernel, dim3(grid1(4L * g.Ceff * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
                        (long)WF * K4 * g.Cout, g.Ceff, g.Cout, dw);
