@@ -805,10 +805,16 @@ bool cached_stream_plan(BgArgs& b, int nw) {
 template <bool TL>
 bool launch_stream(BgArgs& b, hipStream_t s) {
   if (!b.sk_partial || !x3_stream_nw() || b.xmap != 4) return false;
-  // Measured (tools/ablate/x3_phase.hip, random operands): with 4.5 and 9 tiles per compute unit the one-tile grid
-  // is 5 % faster (its rounds are full and nothing is parked); with 0.56 .. 2.25 the stream kernel is 1.05 - 1.33 x
-  // faster (no partly empty last round).
-  if (x3_stream_mode() == 1 && (long)b.tiles_m * b.tiles_n * 9 > 2L * 3 * x3_stream_nw()) return false;
+  // Where it pays (tools/ablate/x3_phase.hip, tools/bench_layers.py with OTGAN_X3_STREAM=0/1/2): up to 1.5 tiles per
+  // compute unit the one-tile grid leaves its last round half empty and the stream kernel is 1.1 - 1.33 x faster;
+  // around 2.25 it is a wash (+-5 %); from 4.5 on the one-tile grid wins by ~5 % (full rounds, nothing parked).
+  // Forward passes of the strided layers already balance their three K lengths longest-first: stream only below
+  // one tile per compute unit.
+  if (x3_stream_mode() == 1) {
+    const long per_xcd2 = (long)b.tiles_m * b.tiles_n * 9;   // 2 x tiles per XCD (4.5 frequencies each)
+    static const long half_rounds = [] { const char* e = getenv("OTGAN_X3_STREAM_HALF_ROUNDS"); return e ? atol(e) : 3L; }();
+    if (per_xcd2 > (b.seg_mode == 1 ? 2L : half_rounds) * x3_stream_nw()) return false;
+  }
   if (!cached_stream_plan(b, x3_stream_nw())) return false;
   ensure_lds<wino_bgemm_x3_stream_kernel<TL>>(X3_SK_LDS);
   b.sk_epoch = x3_next_epoch();

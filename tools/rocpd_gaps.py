@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """Idle gaps between consecutive kernels of a rocprofv3 (rocpd sqlite) kernel trace: total idle time, the
 distribution of gaps, and which kernel pairs the idle time sits between.  (dev tool)
-usage: tools/rocpd_gaps.py <results.db> [top]"""
+usage: tools/rocpd_gaps.py <results.db> [top] [window_ms: only the last window_ms of the trace]"""
 import sqlite3, sys, re, collections
 db = sqlite3.connect(sys.argv[1])
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 rows = db.execute("select name, start, end from kernels order by start").fetchall()
+if len(sys.argv) > 3:
+    t0 = rows[-1][2] - float(sys.argv[3]) * 1e6
+    rows = [r for r in rows if r[1] >= t0]
 short = lambda n: re.sub(r"\(anonymous namespace\)::", "", n).split("(")[0][:48]
 busy = sum(e - s for _, s, e in rows)
 span = rows[-1][2] - rows[0][1]
