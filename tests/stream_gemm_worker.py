@@ -1,0 +1,42 @@
+"""Worker of tests/test_stream_gemm_gpu.py: runs three Winograd layers (forward, dgrad, wgrad) whose batched GEMMs
+have few tiles per compute unit, under whatever OTGAN_X3_STREAM the parent set, twice, and writes the results."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from otgan_amd import _lib, ops  # noqa: E402
+
+CASES = [  # name, N, H, C, Cout, k, stride, upsample, preact
+    ("up_8x8", 64, 8, 256, 256, 5, 1, True, None),        # 256 tiles x (4 x 256) outputs: 4 GEMM tiles
+    ("up_4x4", 128, 4, 512, 512, 5, 1, True, None),       # 128 tiles: one row tile, 8 column tiles
+    ("s2_16x16", 64, 16, 128, 256, 5, 2, False, "crelu"),  # strided: absent (class, frequency) blocks, K runs
+]
+
+
+def main(out):
+    dev = torch.device("cuda:0")
+    _lib.lib()
+    res = {}
+    for name, N, H, C, Cout, k, s, up, pre in CASES:
+        gen = torch.Generator().manual_seed(sum(map(ord, name)))
+        mult = 2 if pre == "crelu" else 1
+        x0 = torch.randn(N, H, H, C, generator=gen)
+        V0 = torch.randn(k, k, C * mult, Cout, generator=gen) * 0.05
+        for rep in range(2):
+            x = x0.to(dev).requires_grad_(True)
+            V = V0.to(dev).requires_grad_(True)
+            g = torch.ones(Cout, device=dev, requires_grad=True)
+            b = torch.zeros(Cout, device=dev, requires_grad=True)
+            y = ops.conv2d_op(x, V, g, b, stride=s, upsample=up, preact=ops.ACT[pre])
+            dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7)).to(dev)
+            dx, dV = torch.autograd.grad(y, [x, V], dy)
+            for tag, t in (("y", y), ("dx", dx), ("dV", dV)):
+                res[f"{name}.{tag}.{rep}"] = t.detach().cpu().numpy()
+    np.savez(out, **res)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
