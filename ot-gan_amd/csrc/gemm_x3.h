@@ -40,6 +40,42 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+// Pieces per operand element (per translation unit): 3 = bf16 hi + mid + lo, 24 significand bits, six MFMAs per
+// product; 2 = fp16 hi + lo of the power-of-two SCALED value, 22 bits, three MFMAs (hi*hi, hi*lo, lo*hi).
+#ifndef X3_PIECES
+#define X3_PIECES 3
+#endif
+constexpr int X3_NP = X3_PIECES;
+constexpr int X3_NTERM = X3_NP == 3 ? 6 : 3;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#if X3_PIECES == 3
+typedef bf16x8 x3frag_t;
+#define X3_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+constexpr int X3_PA[6] = {2, 0, 1, 1, 0, 0}, X3_PB[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+#else
+typedef f16x8 x3frag_t;
+#define X3_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+constexpr int X3_PA[3] = {1, 0, 0}, X3_PB[3] = {0, 1, 0};
+#endif
+
+// R fragment reads spread over the 16 MFMAs of a term group (scheduling hint; the builtin wants literals)
+template <int DS, int R, int Q = 0>
+__device__ __forceinline__ void x3_sched_group() {
+  if constexpr (Q < R) {
+    __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);                                  // the DS reads of one fragment
+    __builtin_amdgcn_sched_group_barrier(0x008, (Q + 1) * 16 / R - Q * 16 / R, 0);       // its share of the MFMAs
+    x3_sched_group<DS, R, Q + 1>();
+  }
+}
+// calls f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void x3_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    x3_static_for<N, I + 1>(f);
+  }
+}
+
 // (hi, mid, lo) bf16 pieces of two floats, each packed in one dword (round-to-nearest-even through
 // v_cvt_pk_bf16_f32; the residuals are exact in fp32)
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
@@ -61,6 +97,39 @@ __device__ __forceinline__ void st_split4(u16* planes, long plane_stride, long i
   *reinterpret_cast<u32x2*>(planes + idx) = u32x2{h0, h1};
   *reinterpret_cast<u32x2*>(planes + plane_stride + idx) = u32x2{m0, m1};
   *reinterpret_cast<u32x2*>(planes + 2 * plane_stride + idx) = u32x2{l0, l1};
+}
+// ---- two scaled fp16 pieces (X3_PIECES == 2) ---------------------------------------------------------------
+// x * 2^s = hi + lo with hi = fp16(x 2^s), lo = fp16(x 2^s - hi): 22 significand bits, and hi*hi + hi*lo + lo*hi is
+// the product to 2^-22 -- measured 7.5e-8 relative L2 on dot products before fp32 accumulation (bf16 x 3: 6e-9; the
+// accumulation itself: 3e-7), heavy-tailed and outlier-ridden operands included (oracle/split_precision_np.py).
+// fp16 has 5 exponent bits, so every operand carries ONE power-of-two scale per frequency, derived from the largest
+// magnitude of the tensor it is a transform of (amax, a device scalar in the operand's header) and the transform's
+// gain bound (product of the absolute row sums of the two 1-D transform matrices): |value| <= gain * amax < 2^e,
+// scale 2^(14 - e): the largest piece stays below 2^14, typical values 4 - 8 binades lower, their lo pieces normal
+// down to 2^-3.  The GEMM multiplies the sums by 2^(eA + eB - 28) on the way out (exact).  The scales are computed
+// once per operand (winograd.hip: absmax_kernel's last block) into a header of X3_HDR floats in front of the planes.
+constexpr int X3_HDR = 128;
+__host__ __device__ __forceinline__ int x3_scale_exp(float amax, float gi, float gj) {
+  const float bound = amax * (gi * gj);
+  if (!(bound > 0.f)) return 0;            // all-zero tensor (NaN falls through to the arithmetic and stays loud)
+  int e;
+#if defined(__HIP_DEVICE_COMPILE__)
+  e = __builtin_amdgcn_frexp_expf(bound);  // bound = m 2^e, 0.5 <= m < 1
+#else
+  frexpf(bound, &e);
+#endif
+  return e;
+}
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+// planes[p][idx .. idx+3] = p-th fp16 piece of v (already scaled)
+__device__ __forceinline__ void st_split4h(u16* planes, long plane_stride, long idx, f32x4 v) {
+  f32x2_t a = {v[0], v[1]}, b = {v[2], v[3]};
+  const f16x2_t ha = __builtin_convertvector(a, f16x2_t), hb = __builtin_convertvector(b, f16x2_t);
+  a -= __builtin_convertvector(ha, f32x2_t);
+  b -= __builtin_convertvector(hb, f32x2_t);
+  const f16x2_t la = __builtin_convertvector(a, f16x2_t), lb = __builtin_convertvector(b, f16x2_t);
+  *reinterpret_cast<u32x2*>(planes + idx) = u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+  *reinterpret_cast<u32x2*>(planes + plane_stride + idx) = u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
 }
 // Layout of a split-precision operand: per (piece, frequency) the [rows][K] matrix is stored as
 // [row block of 32][k block of 16] chunks of 1 KiB, and a chunk is exactly the LDS image that one
@@ -120,6 +189,11 @@ struct BgArgs {
   long zA[8], zB[8], zC[8];
   int zK[8];
   float epi_scale, epi_bias, epi_diag[8];
+  // Scaled two-piece operands (X3_PIECES == 2): the operands' headers (X3_HDR floats in front of the planes:
+  // [0] largest magnitude of the source tensor, [16 + f] scale 2^(14 - e_f), [64 + f] its inverse);
+  // C = hdrA[64 + f] * hdrB[64 + f] * sum (null: unscaled operands)
+  const float* hdrA;
+  const float* hdrB;
   // Stream kernel (wino_bgemm_x3_stream_kernel): one persistent workgroup per compute unit; workgroup c of XCD x
   // owns the positions [sk_bound[x][c], sk_bound[x][c + 1]) of that XCD's queue (x3_plan_stream).
   unsigned sk_bound[8][41];
@@ -132,6 +206,8 @@ struct BgArgs {
   unsigned long long* dbg;   // tools/ablate/x3_phase.hip: s_memtime stamps of workgroup x at dbg[64 x ..]
 #endif
 };
+// 2^(eA + eB - 28) of frequency f (scaled two-piece operands): a product of two powers of two, exact
+__device__ __forceinline__ float x3_out_scale(const BgArgs& a, int f) { return a.hdrA[64 + f] * a.hdrB[64 + f]; }
 #ifdef X3_TIMING
 // (stamps go to LDS past the stage buffers: a global store would count in the vmcnt waits of the pipeline)
 #define X3_STAMP(i) do { if (threadIdx.x == 0 && (i) < 64) reinterpret_cast<unsigned long long*>(smem3 + X3_LDS)[i] = __builtin_readcyclecounter(); } while (0)
@@ -164,13 +240,13 @@ __device__ __forceinline__ int lpt_frequency(int seg_mode, int z) {
 constexpr int X3_BM = 256, X3_BN = 256, X3_BK = 32;     // X3_BK: granularity of K (two stages)
 constexpr int X3_SK = 16, X3_MT = 4, X3_NT = 4, X3_THREADS = 256, X3_NSTAGE = 3;
 constexpr int X3_TA = X3_BM * X3_SK * 2, X3_TB = X3_BN * X3_SK * 2;   // bytes per (operand, piece, stage)
-constexpr int X3_STAGE = 3 * (X3_TA + X3_TB);
+constexpr int X3_STAGE = X3_NP * (X3_TA + X3_TB);
 constexpr size_t X3_LDS = (size_t)X3_NSTAGE * X3_STAGE;
-constexpr int X3_PER_WAVE = 3 * (X3_BM + X3_BN) / 32 / 4;              // global_load_lds per wave per stage
+constexpr int X3_PER_WAVE = X3_NP * (X3_BM + X3_BN) / 32 / 4;              // global_load_lds per wave per stage
 
 struct X3Frags {
-  bf16x8 a[X3_MT][3];
-  bf16x8 b[X3_NT][3];
+  x3frag_t a[X3_MT][X3_NP];
+  x3frag_t b[X3_NT][X3_NP];
 };
 
 // s_waitcnt vmcnt(n) only (expcnt / lgkmcnt untouched): gfx9 encoding vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14
@@ -293,7 +369,7 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         if (rb > rbmax) rb = rbmax;
         src = opb + piece * plane + (((long)rb * a.kblocks + kb) << 9);
       }
-      const unsigned dst = lds_base + buf * X3_STAGE + (isA ? 0 : 3 * X3_TA) + piece * X3_TA + rg * 1024;
+      const unsigned dst = lds_base + buf * X3_STAGE + (isA ? 0 : X3_NP * X3_TA) + piece * X3_TA + rg * 1024;
       // scalar base + per-lane 32-bit offset (the builtin expands to 64-bit per-lane addresses inside the loop);
       // M0 = LDS address of the chunk.  Nothing else in this kernel uses M0.
       asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst) : "memory");
@@ -314,16 +390,15 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
   const int g4 = lane >> 4, l16 = lane & 15;
   const int ftl = (g4 & 1) * 512 + (8 * (g4 >> 1) + (l16 >> 2)) * 32 + ((((l16 >> 1) & 1) ^ (g4 >> 1)) * 16) + (l16 & 1) * 8;
   const int fa = TL ? wm * 4096 + ftl : (wm * X3_MT * 32 + r) * 32 + 16 * (g ^ sw);
-  const int fb = 3 * X3_TA + (TL ? wn * 4096 + ftl : (wn * X3_NT * 32 + r) * 32 + 16 * (g ^ sw));
-  auto read_frag = [&](const unsigned char* p) -> bf16x8 {
+  const int fb = X3_NP * X3_TA + (TL ? wn * 4096 + ftl : (wn * X3_NT * 32 + r) * 32 + 16 * (g ^ sw));
+  auto read_frag = [&](const unsigned char* p) -> x3frag_t {
     if (TL) {
       typedef short s16x4 __attribute__((ext_vector_type(4)));
-      typedef short s16x8 __attribute__((ext_vector_type(8)));
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
       const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 128));
-      return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      return __builtin_bit_cast(x3frag_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     } else {
-      return *reinterpret_cast<const bf16x8*>(p);
+      return *reinterpret_cast<const x3frag_t*>(p);
     }
   };
   auto load_frags = [&](X3Frags& F, int buf) {
@@ -332,22 +407,20 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
     for (int t = 0; t < X3_MT; ++t)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) F.a[t][p] = read_frag(pa + p * X3_TA + t * 1024);
+      for (int p = 0; p < X3_NP; ++p) F.a[t][p] = read_frag(pa + p * X3_TA + t * 1024);
 #pragma unroll
     for (int t = 0; t < X3_NT; ++t)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) F.b[t][p] = read_frag(pb + p * X3_TB + t * 1024);
+      for (int p = 0; p < X3_NP; ++p) F.b[t][p] = read_frag(pb + p * X3_TB + t * 1024);
   };
   // six products per fp32-exact product, smallest terms first; consecutive MFMAs hit different accumulators
   auto mfmas = [&](const X3Frags& F) {
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+    for (int t = 0; t < X3_NTERM; ++t)
 #pragma unroll
       for (int i = 0; i < X3_MT; ++i)
 #pragma unroll
-        for (int j = 0; j < X3_NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][PA[t]], F.b[j][PB[t]], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < X3_NT; ++j) acc[i][j] = X3_MFMA(F.a[i][X3_PA[t]], F.b[j][X3_PB[t]], acc[i][j]);
   };
   if (PIPE) {
     // nst is even and >= 4 (host contract).  One stage: stage st+1 has landed (barrier), the buffer stage st
@@ -362,34 +435,30 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
       // six term groups of 16 MFMAs; in front of each: two of the twelve refill loads (all twelve at once keep the
       // wave in its VMEM issue queue for several hundred cycles while the matrix pipe drains) and four of the 24
       // fragment reads of the next stage
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
       const int rbuf = bufn == 0 ? X3_NSTAGE - 1 : bufn - 1;
       const unsigned char* pa = smem3 + bufn * X3_STAGE + fa;
       const unsigned char* pb = smem3 + bufn * X3_STAGE + fb;
-#pragma unroll
-      for (int t = 0; t < 6; ++t) {
-        if (ISSUE) issue(st + 3, rbuf, 2 * t, 2);
+      constexpr int NR = 8 * X3_NP;   // fragment reads of a stage
+      x3_static_for<X3_NTERM>([&](auto tc) {
+        // term group t: its share of the refill loads and of the next stage's fragment reads in front of 16 MFMAs
+        constexpr int t = decltype(tc)::value;
+        constexpr int l0 = t * X3_PER_WAVE / X3_NTERM, l1 = (t + 1) * X3_PER_WAVE / X3_NTERM;
+        constexpr int q0 = t * NR / X3_NTERM, q1 = (t + 1) * NR / X3_NTERM;
+        if (ISSUE) issue(st + 3, rbuf, l0, l1 - l0);
         if (LOAD) {
 #pragma unroll
-          for (int q = 4 * t; q < 4 * t + 4; ++q) {
-            const int tt = (q % 12) / 3, p = q % 3;   // q < 12: A fragments, else B
-            if (q < 12) G.a[tt][p] = read_frag(pa + p * X3_TA + tt * 1024);
+          for (int q = q0; q < q1; ++q) {
+            const int qq = q % (4 * X3_NP), tt = qq / X3_NP, p = qq % X3_NP;   // q < 4 NP: A fragments, else B
+            if (q < 4 * X3_NP) G.a[tt][p] = read_frag(pa + p * X3_TA + tt * 1024);
             else G.b[tt][p] = read_frag(pb + p * X3_TB + tt * 1024);
           }
         }
 #pragma unroll
         for (int i = 0; i < X3_MT; ++i)
 #pragma unroll
-          for (int j = 0; j < X3_NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][PA[t]], F.b[j][PB[t]], acc[i][j], 0, 0, 0);
-        if (LOAD) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x100, TL ? 2 : 1, 0);   // the DS reads of one fragment
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);            // four MFMAs
-          }
-        }
-      }
+          for (int j = 0; j < X3_NT; ++j) acc[i][j] = X3_MFMA(F.a[i][X3_PA[t]], F.b[j][X3_PB[t]], acc[i][j]);
+        if (LOAD) x3_sched_group<TL ? 2 : 1, q1 - q0>();
+      });
     };
     using Y = std::true_type;
     using N = std::false_type;
@@ -431,7 +500,9 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     }
   }
   float* C = a.C + (a.ztab ? a.zC[f] : f * a.sC) + blockIdx.y * a.sSplit;
-  const float es = a.epi ? a.epi_scale : 1.f, eb = a.epi ? a.epi_bias : 0.f, ed = a.epi ? a.epi_diag[f & 7] : 0.f;
+  float es = a.epi ? a.epi_scale : 1.f;
+  const float eb = a.epi ? a.epi_bias : 0.f, ed = a.epi ? a.epi_diag[f & 7] : 0.f;
+  if (a.hdrA) es *= x3_out_scale(a, f);
   if (m0 + X3_BM <= a.M && n0 + X3_BN <= a.N && ed == 0.f) {
     // whole tile inside C: one running row pointer per lane, the four column tiles of a row at immediate offsets
     // (with a bounds test, an address multiply and the epilogue select per element this loop took 26.8 k cycles per
@@ -466,7 +537,7 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
           const int n = n0 + (wn * X3_NT + j) * 32 + r;
           if (m < a.M && n < a.N) {
             float v = acc[i][j][q];
-            if (a.epi) v = fmaf(es, v, eb) + (m == n ? ed : 0.f);
+            if (a.epi || a.hdrA) v = fmaf(es, v, eb) + (m == n ? ed : 0.f);
             C[(long)m * a.ldc + n] = v;
           }
         }
@@ -747,7 +818,7 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
       const int li = half * X3_PER_WAVE + i;
       const int piece = li >> 3, rg = li & 7;
       const u16* src = c.base[i] + koff;
-      const unsigned dst = lds_base + buf * X3_STAGE + (isA ? 0 : 3 * X3_TA) + piece * X3_TA + rg * 1024;
+      const unsigned dst = lds_base + buf * X3_STAGE + (isA ? 0 : X3_NP * X3_TA) + piece * X3_TA + rg * 1024;
       asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst) : "memory");
     }
   };
@@ -773,15 +844,15 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
   const int g4 = lane >> 4, l16 = lane & 15;
   const int ftl = (g4 & 1) * 512 + (8 * (g4 >> 1) + (l16 >> 2)) * 32 + ((((l16 >> 1) & 1) ^ (g4 >> 1)) * 16) + (l16 & 1) * 8;
   const int fa = TL ? wm * 4096 + ftl : (wm * X3_MT * 32 + r) * 32 + 16 * (g ^ sw);
-  const int fb = 3 * X3_TA + (TL ? wn * 4096 + ftl : (wn * X3_NT * 32 + r) * 32 + 16 * (g ^ sw));
-  auto read_frag = [&](const unsigned char* p) -> bf16x8 {
+  const int fb = X3_NP * X3_TA + (TL ? wn * 4096 + ftl : (wn * X3_NT * 32 + r) * 32 + 16 * (g ^ sw));
+  auto read_frag = [&](const unsigned char* p) -> x3frag_t {
     if (TL) {
       typedef short s16x4 __attribute__((ext_vector_type(4)));
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
       const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 128));
-      return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      return __builtin_bit_cast(x3frag_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     } else {
-      return *reinterpret_cast<const bf16x8*>(p);
+      return *reinterpret_cast<const x3frag_t*>(p);
     }
   };
   // one stage (see the one-tile kernel): the stage after this one has landed (vmcnt + barrier; `landed`: known
@@ -790,30 +861,27 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
   auto stage = [&](Cur& c, int bufn, const X3Frags& F, X3Frags& G, bool landed) {
     if (!landed) X3_WAIT_VM(X3_PER_WAVE);
     __builtin_amdgcn_s_barrier();
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
     const int rbuf = bufn == 0 ? X3_NSTAGE - 1 : bufn - 1;
     const unsigned char* pa = smem3 + bufn * X3_STAGE + fa;
     const unsigned char* pb = smem3 + bufn * X3_STAGE + fb;
+    constexpr int NR = 8 * X3_NP;
+    x3_static_for<X3_NTERM>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      constexpr int l0 = t * X3_PER_WAVE / X3_NTERM, l1 = (t + 1) * X3_PER_WAVE / X3_NTERM;
+      constexpr int q0 = t * NR / X3_NTERM, q1 = (t + 1) * NR / X3_NTERM;
+      issue(c, rbuf, l0, l1 - l0);
 #pragma unroll
-    for (int t = 0; t < 6; ++t) {
-      issue(c, rbuf, 2 * t, 2);
-#pragma unroll
-      for (int q = 4 * t; q < 4 * t + 4; ++q) {
-        const int tt = (q % 12) / 3, p = q % 3;
-        if (q < 12) G.a[tt][p] = read_frag(pa + p * X3_TA + tt * 1024);
+      for (int q = q0; q < q1; ++q) {
+        const int qq = q % (4 * X3_NP), tt = qq / X3_NP, p = qq % X3_NP;
+        if (q < 4 * X3_NP) G.a[tt][p] = read_frag(pa + p * X3_TA + tt * 1024);
         else G.b[tt][p] = read_frag(pb + p * X3_TB + tt * 1024);
       }
 #pragma unroll
       for (int i = 0; i < X3_MT; ++i)
 #pragma unroll
-        for (int j = 0; j < X3_NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][PA[t]], F.b[j][PB[t]], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x100, TL ? 2 : 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-      }
-    }
+        for (int j = 0; j < X3_NT; ++j) acc[i][j] = X3_MFMA(F.a[i][X3_PA[t]], F.b[j][X3_PB[t]], acc[i][j]);
+      x3_sched_group<TL ? 2 : 1, q1 - q0>();
+    });
     advance(c);
   };
 
@@ -878,6 +946,7 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     const int tm = x3_tile_row(a, p_tile), tn = p_tile - tm * a.tiles_n;
     const int m0 = tm * X3_BM, n0 = tn * X3_BN;
     float* C = a.C + (long)p_f * a.sC;
+    const float es = a.hdrA ? x3_out_scale(a, p_f) : 1.f;   // a power of two: exact
     if (m0 + X3_BM <= a.M && n0 + X3_BN <= a.N) {
       const long ld = a.ldc;
       float* row = C + (long)(m0 + wm * X3_MT * 32 + 4 * g) * ld + (n0 + wn * X3_NT * 32 + r);
@@ -896,7 +965,7 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
           for (int ql = 0; ql < 4; ++ql) {
 #pragma unroll
-            for (int j = 0; j < X3_NT; ++j) q[j * 32] = acc[i][j][4 * qh + ql] + pv[j][ql];
+            for (int j = 0; j < X3_NT; ++j) q[j * 32] = (acc[i][j][4 * qh + ql] + pv[j][ql]) * es;
             q += ld;
           }
         }
@@ -914,7 +983,7 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             for (int ql = 0; ql < 4; ++ql) {
               const int m = m0 + (wm * X3_MT + i) * 32 + ql + 8 * qh + 4 * g;
               const int n = n0 + (wn * X3_NT + j) * 32 + r;
-              if (m < a.M && n < a.N) C[(long)m * a.ldc + n] = acc[i][j][4 * qh + ql] + pv[ql];
+              if (m < a.M && n < a.N) C[(long)m * a.ldc + n] = (acc[i][j][4 * qh + ql] + pv[ql]) * es;
             }
           }
       X3_WAIT_VM(0);   // (a wave may have issued fewer than 64 stores here)
@@ -942,11 +1011,11 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
     for (int t = 0; t < X3_MT; ++t)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) F.a[t][p] = read_frag(pa + p * X3_TA + t * 1024);
+      for (int p = 0; p < X3_NP; ++p) F.a[t][p] = read_frag(pa + p * X3_TA + t * 1024);
 #pragma unroll
     for (int t = 0; t < X3_NT; ++t)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) F.b[t][p] = read_frag(pb + p * X3_TB + t * 1024);
+      for (int p = 0; p < X3_NP; ++p) F.b[t][p] = read_frag(pb + p * X3_TB + t * 1024);
   };
   int bufn = 1;           // buffer of the stage after the one about to be computed
   bool landed = false;

@@ -9,6 +9,8 @@
 //   wgrad   : dU[f] = V[f]^T . (A dY A^T)[f]  (K = tiles), then dweff = G^T dU G
 // The transforms are streaming float4 kernels; the GEMMs use the shared block-GEMM engine.
 #include "winograd.h"
+// the Winograd-domain GEMMs of the convolution layers: two scaled fp16 pieces per operand element (gemm_x3.h)
+#define X3_PIECES 2
 #include "gemm_x3.h"
 #include <type_traits>
 
@@ -65,11 +67,13 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 // store k .. k+3 of row `row`, frequency f, of a [WF][rows][ld] operand: fp32 row-major in F, or (P non-null)
-// as three bf16 planes in the blocked layout
+// as two fp16 planes of the SCALED value in the blocked layout; the scale of frequency f sits in the operand's
+// header, X3_HDR floats in front of the planes (written by absmax_kernel before the producer runs)
 __device__ __forceinline__ void st_operand(float* F, u16* P, long rows, int ld, int f, long row, int k, f32x4 v) {
   if (P) {
     const long fs = op_fstride(rows, ld);
-    st_split4(P, WF * fs, f * fs + op_off(row, k, ld >> 4), v);
+    const float sc = (reinterpret_cast<const float*>(P) - X3_HDR)[16 + f];
+    st_split4h(P, WF * fs, f * fs + op_off(row, k, ld >> 4), v * sc);
   } else {
     st4(F + ((long)f * rows + row) * ld + k, v);
   }
@@ -176,6 +180,100 @@ __device__ __forceinline__ void tf_filter_adj(Col&& col, f32x4 (&dg)[3][3]) {
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) gt1(p[i], dg[i]);
+}
+
+// ---- operand scales --------------------------------------------------------------------------------------
+// Largest magnitude of the tensor an operand is a transform of, and from it the 36 per-frequency scales
+// 2^(14 - e_f), |transform_f| <= gain_i gain_j fold amax < 2^(e_f) (gemm_x3.h), into the operand's header.  One
+// launch: every block leaves its maximum in a scratch slot, the last one to finish (a counter that it resets)
+// reduces the slots and writes the header.  max is order-independent: deterministic.  A NaN anywhere makes every
+// scale NaN (fmaxf would drop it), an infinity too: the layer's output is then NaN, as the fp32 engine's would be.
+struct AmaxArgs {
+  const float* x;
+  long rows, ld;        // rows of C floats, row stride ld
+  int C;
+  float* hdr;
+  float gain[WA];       // absolute row sums of the 1-D transform matrix
+  float fold;           // taps summed into one filter tap before the transform (1, or 4 for un-folded upsampling filters)
+  int floor_one;        // ELU / CELU applied inside the transform: |act(x)| <= max(|x|, 1)
+  float* scratch;
+  unsigned* counter;
+};
+constexpr float kGainBt[WA] = {7.f, 5.f, 5.f, 6.f, 3.f, 7.f};                         // B^T (data / dgrad-data transform)
+constexpr float kGainG[WA] = {1.f, 1.f, 1.f, 28.f / 15.f, 7.f / 15.f, 1.f};           // G (filter transform)
+constexpr float kGainA[WA] = {1.f, 4.f, 4.f, 1.875f, 15.f, 1.f};                      // A (output-adjoint transform)
+constexpr int kAmaxBlocks = 1024, kAmaxSlots = 64;
+
+__global__ __launch_bounds__(256) void absmax_kernel(AmaxArgs a) {
+  __shared__ float red[4];
+  __shared__ int last;
+  const int tid = threadIdx.x, c4 = a.C >> 2;
+  const long n4 = a.rows * c4;
+  float m = 0.f;
+  bool bad = false;
+  for (long i = (long)blockIdx.x * 256 + tid; i < n4; i += (long)gridDim.x * 256) {
+    const long row = i / c4;
+    const int q = (int)(i - row * c4);
+    const f32x4 v = ld4(a.x + row * a.ld + 4 * q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bad = bad || !(v[j] == v[j]);
+      m = fmaxf(m, fabsf(v[j]));
+    }
+  }
+  if (bad) m = __builtin_nanf("");
+  auto wave_max = [&](float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float w = __shfl_xor(v, o);
+      v = (v == v && w == w) ? fmaxf(v, w) : __builtin_nanf("");
+    }
+    return v;
+  };
+  auto block_max = [&](float v) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) r = (r == r && red[w] == red[w]) ? fmaxf(r, red[w]) : __builtin_nanf("");
+    return r;
+  };
+  m = block_max(m);
+  if (tid == 0) {
+    __hip_atomic_store(&a.scratch[blockIdx.x], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    last = atomicAdd(a.counter, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float r = 0.f;
+  for (int i = tid; i < (int)gridDim.x; i += 256) {
+    const float w = __hip_atomic_load(&a.scratch[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r = (r == r && w == w) ? fmaxf(r, w) : __builtin_nanf("");
+  }
+  float amax = block_max(r);
+  if (a.floor_one && amax == amax) amax = fmaxf(amax, 1.f);
+  if (tid < WF) {
+    const int i = tid / WA, j = tid - i * WA;
+    const float bound = amax * a.fold * (a.gain[i] * a.gain[j]);
+    float sc = 1.f, inv = 1.f;
+    if (!(bound <= 3.0e38f)) {          // NaN or infinite
+      sc = inv = __builtin_nanf("");
+    } else if (bound > 0.f) {
+      const int e = x3_scale_exp(amax * a.fold, a.gain[i], a.gain[j]);
+      sc = __builtin_ldexpf(1.f, 14 - e);
+      inv = __builtin_ldexpf(1.f, e - 14);
+    }
+    a.hdr[16 + tid] = sc;
+    a.hdr[64 + tid] = inv;
+  }
+  if (tid == 0) {
+    a.hdr[0] = amax;
+    *a.counter = 0;
+  }
 }
 
 // ---- streaming kernels --------------------------------------------------------------------
@@ -738,15 +836,13 @@ unsigned build_fmap(BgArgs& b) { return x3_build_fmap(b); }
 // Persistent "stream" GEMM (gemm_x3.h): workgroups per XCD = compute units / 8; OTGAN_X3_STREAM=0 keeps the
 // one-tile-per-workgroup kernel.  The parked-tile area is the tail of every Winograd workspace.
 int x3_stream_mode() {   // 0: off, 1: where it pays (few tiles per compute unit), 2: every launch
-  static const int m = [] {
-    const char* e = getenv("OTGAN_X3_STREAM");
-    return e ? atoi(e) : 1;
-  }();
-  return use_fmap() ? m : 0;
+  // (read per launch, so that a debugging session can switch kernels inside one process: tools/debug/stream_step_diff.py)
+  const char* e = getenv("OTGAN_X3_STREAM");
+  return use_fmap() ? (e ? atoi(e) : 1) : 0;
 }
 int x3_stream_nw() {
   static const int nw = [] {
-    if (!x3_stream_mode()) return 0;
+    if (!use_fmap()) return 0;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
@@ -804,7 +900,7 @@ bool cached_stream_plan(BgArgs& b, int nw) {
 }
 template <bool TL>
 bool launch_stream(BgArgs& b, hipStream_t s) {
-  if (!b.sk_partial || !x3_stream_nw() || b.xmap != 4) return false;
+  if (!b.sk_partial || !x3_stream_nw() || !x3_stream_mode() || b.xmap != 4) return false;
   // Where it pays (tools/ablate/x3_phase.hip, tools/bench_layers.py with OTGAN_X3_STREAM=0/1/2): up to 1.5 tiles per
   // compute unit the one-tile grid leaves its last round half empty and the stream kernel is 1.1 - 1.33 x faster;
   // around 2.25 it is a wash (+-5 %); from 4.5 on the one-tile grid wins by ~5 % (full rounds, nothing parked).
@@ -923,7 +1019,53 @@ bool use_x3_wgrad_tl() {
   return on && use_x3_wgrad();
 }
 // floats of workspace that hold n operand elements (three bf16 planes = 6 bytes per element)
-inline size_t operand_floats(size_t n) { return (3 * n + 1) / 2; }
+inline size_t operand_floats(size_t n) { return X3_HDR + (X3_NP * n + 1) / 2; }
+// the planes of a split operand follow its header
+inline u16* op_planes(float* base) { return reinterpret_cast<u16*>(base + X3_HDR); }
+
+// scratch slots and completion counters of absmax_kernel: owned by the library, one set per process (one process
+// per GPU), 64 launches may be in flight at once
+struct AmaxScratch {
+  float* slots = nullptr;
+  unsigned* counters = nullptr;
+  int device = -1;
+};
+AmaxScratch& amax_scratch() {
+  static AmaxScratch sc;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (sc.device != dev) {
+    void* p = nullptr;
+    const size_t bytes = (size_t)kAmaxSlots * kAmaxBlocks * sizeof(float) + kAmaxSlots * sizeof(unsigned);
+    if (hipMalloc(&p, bytes) == hipSuccess) {
+      (void)hipMemset(p, 0, bytes);
+      sc.slots = static_cast<float*>(p);
+      sc.counters = reinterpret_cast<unsigned*>(sc.slots + (size_t)kAmaxSlots * kAmaxBlocks);
+      sc.device = dev;
+    }
+  }
+  return sc;
+}
+// scales of the operand at `base` (header) for a transform with row gains `gain` of the tensor x[rows][C] (row stride ld)
+void op_scales(const float* x, long rows, int C, long ld, float* base, const float (&gain)[WA], float fold, bool floor_one,
+               hipStream_t s) {
+  static std::atomic<unsigned> seq{0};
+  AmaxScratch& sc = amax_scratch();
+  const unsigned slot = seq.fetch_add(1) % kAmaxSlots;
+  AmaxArgs a;
+  a.x = x; a.rows = rows; a.ld = ld; a.C = C; a.hdr = base;
+  for (int i = 0; i < WA; ++i) a.gain[i] = gain[i];
+  a.fold = fold; a.floor_one = floor_one ? 1 : 0;
+  a.scratch = sc.slots + (size_t)slot * kAmaxBlocks;
+  a.counter = sc.counters + slot;
+  const long n4 = rows * (C / 4);
+  long blocks = (n4 + 256 * 8 - 1) / (256 * 8);
+  if (blocks > kAmaxBlocks) blocks = kAmaxBlocks;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+}
 // elements of a [WF][rows][K] operand in either layout (rows padded to 32, K to 16)
 inline size_t op_elems(size_t rows, size_t K) { return WF * ((rows + 31) / 32 * 32) * ((K + 15) / 16 * 16); }
 
@@ -995,24 +1137,28 @@ int wino_prepare_filters(const WinoGeo& g, int which, const float* w, long cls_s
   const int N4 = 4 * g.Cout;
   if (which == 2) {          // forward filters from the un-folded transposed weights wT[Cout][25*Cin]
     const bool x3 = use_x3() && g.Cin % X3_BK == 0;
+    if (x3) op_scales(w, 1, 25 * g.Cin * g.Cout, 0, out, kGainG, 4.f, false, s);   // a class tap = up to 2 x 2 of the 25
     hipLaunchKernelGGL(wino_filter_fwd_unfolded_kernel, dim3(op_grid(N4, g.Cin / 4)), dim3(256), 0, s, w, g.Cin, g.Cout, out,
-                       x3 ? reinterpret_cast<u16*>(out) : nullptr);
+                       x3 ? op_planes(out) : nullptr);
     return OTGAN_OK;
   }
   if (which == 3) {          // dgrad filters from the un-folded HWIO weights w[25][Cin][Cout]
     const bool x3 = use_x3() && N4 % X3_BK == 0;
+    if (x3) op_scales(w, 1, 25 * g.Cin * g.Cout, 0, out, kGainG, 4.f, false, s);
     hipLaunchKernelGGL(wino_filter_bwd_unfolded_kernel, dim3(op_grid(g.Cin, g.Cout)), dim3(256), 0, s, w, g.Cin, g.Cout, out,
-                       x3 ? reinterpret_cast<u16*>(out) : nullptr);
+                       x3 ? op_planes(out) : nullptr);
     return OTGAN_OK;
   }
   if (which == 0) {
     const bool x3 = use_x3() && g.Cin % X3_BK == 0;
+    if (x3) op_scales(w, 4, 9 * g.Cin * g.Cout, cls_stride, out, kGainG, 1.f, false, s);
     hipLaunchKernelGGL(wino_filter_fwd_kernel, dim3(op_grid(N4, g.Cin / 4)), dim3(256), 0, s, w, cls_stride, g.Cin,
-                       g.Cout, out, x3 ? reinterpret_cast<u16*>(out) : nullptr);
+                       g.Cout, out, x3 ? op_planes(out) : nullptr);
   } else {
     const bool x3 = use_x3() && N4 % X3_BK == 0;
+    if (x3) op_scales(w, 4, 9 * g.Cin * g.Cout, cls_stride, out, kGainG, 1.f, false, s);
     hipLaunchKernelGGL(wino_filter_bwd_kernel, dim3(op_grid(g.Cin, g.Cout)), dim3(256), 0, s, w, cls_stride, g.Cin,
-                       g.Cout, out, x3 ? reinterpret_cast<u16*>(out) : nullptr);
+                       g.Cout, out, x3 ? op_planes(out) : nullptr);
   }
   return OTGAN_OK;
 }
@@ -1027,8 +1173,8 @@ int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stri
   float* Uws = V + operand_floats(nV);
   float* Mh = Uws + operand_floats(nU);
   float* U = prep ? const_cast<float*>(prep) : Uws;
-  u16* VP = x3 ? reinterpret_cast<u16*>(V) : nullptr;
-  u16* UP = x3 ? reinterpret_cast<u16*>(U) : nullptr;
+  u16* VP = x3 ? op_planes(V) : nullptr;
+  u16* UP = x3 ? op_planes(U) : nullptr;
   if (!prep) wino_prepare_filters(g, 0, weffT, cls_stride, U, s);
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
@@ -1036,10 +1182,12 @@ int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stri
   ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
   ia.H = g.H; ia.W = g.W; ia.TH = g.H / WM; ia.TW = g.W / WM; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.V = V;
   ia.P = VP;
+  if (x3) op_scales(x, (long)g.N * g.H * g.W, g.Cin, g.ldx, V, kGainBt, 1.f, false, s);
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cin / 4), 1, 1), dim3(256), 0, s, ia);
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.Ap = VP; b.Bp = UP; b.pA = (long)nV; b.pB = (long)nU;
+  if (x3) { b.hdrA = V; b.hdrB = U; }
   b.A = V; b.B = U; b.C = Mh; b.M = (int)T; b.N = N4; b.K = g.Cin;
   b.lda = g.Cin; b.ldb = g.Cin; b.ldc = N4;
   b.sA = T * g.Cin; b.sB = (long)N4 * g.Cin; b.sC = T * N4;
@@ -1066,8 +1214,8 @@ int wino_dgrad(const WinoGeo& g, const float* dy, const float* weff, long cls_st
   float* Uws = DV + operand_floats(nV);      // [WF][Cin][4*Cout]
   float* Xh = Uws + operand_floats(nU);      // [WF][T][Cin]
   float* U = prep ? const_cast<float*>(prep) : Uws;
-  u16* VP = x3 ? reinterpret_cast<u16*>(DV) : nullptr;
-  u16* UP = x3 ? reinterpret_cast<u16*>(U) : nullptr;
+  u16* VP = x3 ? op_planes(DV) : nullptr;
+  u16* UP = x3 ? op_planes(U) : nullptr;
   if (!prep) wino_prepare_filters(g, 1, weff, cls_stride, U, s);
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
@@ -1076,10 +1224,12 @@ int wino_dgrad(const WinoGeo& g, const float* dy, const float* weff, long cls_st
   for (int cls = 0; cls < 4; ++cls) ia.coff[cls] = cls * g.Cout;
   ia.H = g.H; ia.W = g.W; ia.TH = g.H / WM; ia.TW = g.W / WM; ia.C = g.Cout; ia.T = T; ia.ldv = K4; ia.V = DV;
   ia.P = VP;
+  if (x3) op_scales(dy + g.y_coff, (long)g.N * 4 * g.H * g.W, g.Cout, g.ldy, DV, kGainBt, 1.f, false, s);
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cout / 4), 1, 4), dim3(256), 0, s, ia);
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.Ap = VP; b.Bp = UP; b.pA = (long)nV; b.pB = (long)nU;
+  if (x3) { b.hdrA = DV; b.hdrB = U; }
   b.A = DV; b.B = U; b.C = Xh; b.M = (int)T; b.N = g.Cin; b.K = K4;
   b.lda = K4; b.ldb = K4; b.ldc = g.Cin;
   b.sA = T * K4; b.sB = (long)g.Cin * K4; b.sC = T * g.Cin;
@@ -1104,14 +1254,17 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
     // the operands of forward (V[tile][Cin]) and dgrad (dM[tile][4 Cout]) as they are: t-leading GEMM over the tiles
     const int ns = x3_wgrad_splits(g.Cin, N4, T);
     const size_t nV = op_elems(T, g.Cin), nM = op_elems(T, N4);
-    u16* VP = reinterpret_cast<u16*>(ws);
-    u16* MP = reinterpret_cast<u16*>(ws + operand_floats(nV));
+    float* Vb = ws;
+    u16* VP = op_planes(Vb);
+    float* Mb = ws + operand_floats(nV);
+    u16* MP = op_planes(Mb);
     float* slabs = ws + operand_floats(nV) + operand_floats(nM);
     InArgs ia;
     memset(&ia, 0, sizeof(ia));
     ia.s2_skip = -1;
     ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
     ia.H = g.H; ia.W = g.W; ia.TH = g.H / WM; ia.TW = g.W / WM; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.P = VP;
+    op_scales(x, (long)g.N * g.H * g.W, g.Cin, g.ldx, Vb, kGainBt, 1.f, false, s);
     hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cin / 4), 1, 1), dim3(256), 0, s, ia);
     InArgs da;
     memset(&da, 0, sizeof(da));
@@ -1119,10 +1272,11 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
     class_views(g, dy + g.y_coff, g.ldy, da.v);
     for (int cls = 0; cls < 4; ++cls) da.coff[cls] = cls * g.Cout;
     da.H = g.H; da.W = g.W; da.TH = g.H / WM; da.TW = g.W / WM; da.C = g.Cout; da.T = T; da.ldv = N4; da.P = MP;
+    op_scales(dy + g.y_coff, (long)g.N * 4 * g.H * g.W, g.Cout, g.ldy, Mb, kGainA, 1.f, false, s);
     hipLaunchKernelGGL(wino_outadj_kernel, dim3(op_grid(T, g.Cout / 4), 1, 4), dim3(256), 0, s, da);
     BgArgs b;
     memset(&b, 0, sizeof(b));
-    b.Ap = VP; b.Bp = MP;
+    b.Ap = VP; b.Bp = MP; b.hdrA = Vb; b.hdrB = Mb;
     b.C = slabs; b.M = g.Cin; b.N = N4; b.K = (int)T;
     b.ldc = N4; b.sC = (long)g.Cin * N4; b.sSplit = (long)WF * g.Cin * N4;
     b.kt_per_split = (int)((T / X3_BK + ns - 1) / ns);
@@ -1193,6 +1347,8 @@ int s2_wgrad_splits(const WinoS2Geo& g) {
 
 void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, u16* VP, hipStream_t s) {
   const long T = wino_s2_tiles(g);
+  // (the activation is applied inside the transform: |relu(+-x)| <= |x|, |elu(x)| <= max(|x|, 1))
+  if (VP) op_scales(x, (long)g.N * g.H * g.W, g.C, g.ldx, reinterpret_cast<float*>(VP) - X3_HDR, kGainBt, 1.f, g.act == 2, s);
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
   ia.s2_skip = -1;
@@ -1233,12 +1389,14 @@ size_t wino_s2_filter_floats(const WinoS2Geo& g, int which) {
 int wino_s2_prepare_filters(const WinoS2Geo& g, int which, const float* w, float* out, hipStream_t s) {
   if (which == 0) {
     const bool x3 = use_x3() && g.Ceff % X3_BK == 0;
+    if (x3) op_scales(w, 1, 25 * g.Ceff * g.Cout, 0, out, kGainG, 1.f, false, s);
     hipLaunchKernelGGL(wino_s2_filter_fwd_kernel, dim3(op_grid(g.Cout, g.Ceff)), dim3(256), 0, s, w, g.Ceff, g.Cout, out,
-                       x3 ? reinterpret_cast<u16*>(out) : nullptr);
+                       x3 ? op_planes(out) : nullptr);
   } else {
     const bool x3 = use_x3() && g.Cout % X3_BK == 0;
+    if (x3) op_scales(w, 1, 25 * g.Ceff * g.Cout, 0, out, kGainG, 1.f, false, s);
     hipLaunchKernelGGL(wino_s2_filter_bwd_kernel, dim3(op_grid(4L * g.Ceff, g.Cout / 4)), dim3(256), 0, s, w, g.Ceff,
-                       g.Cout, out, x3 ? reinterpret_cast<u16*>(out) : nullptr);
+                       g.Cout, out, x3 ? op_planes(out) : nullptr);
   }
   return OTGAN_OK;
 }
@@ -1253,13 +1411,14 @@ int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float
   float* Uws = V + operand_floats(nV);        // [WF][Cout][4*Ceff]
   float* Mh = Uws + operand_floats(nU);       // [WF][T][Cout]
   float* U = prep ? const_cast<float*>(prep) : Uws;
-  u16* VP = x3 ? reinterpret_cast<u16*>(V) : nullptr;
-  u16* UP = x3 ? reinterpret_cast<u16*>(U) : nullptr;
+  u16* VP = x3 ? op_planes(V) : nullptr;
+  u16* UP = x3 ? op_planes(U) : nullptr;
   if (!prep) wino_s2_prepare_filters(g, 0, wT, U, s);
   s2_input_transform(g, x, V, VP, s);
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.Ap = VP; b.Bp = UP; b.pA = (long)nV; b.pB = (long)nU;
+  if (x3) { b.hdrA = V; b.hdrB = U; }
   b.A = V; b.B = U; b.C = Mh; b.M = (int)T; b.N = g.Cout; b.K = K4;
   b.lda = K4; b.ldb = K4; b.ldc = g.Cout;
   b.sA = T * K4; b.sB = (long)g.Cout * K4; b.sC = T * g.Cout;
@@ -1289,8 +1448,8 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   float* Uws = DV + operand_floats(nV);       // [WF][4*Ceff][Cout]
   float* Xh = Uws + operand_floats(nU);       // [WF][T][4*Ceff]
   float* U = prep ? const_cast<float*>(prep) : Uws;
-  u16* VP = x3 ? reinterpret_cast<u16*>(DV) : nullptr;
-  u16* UP = x3 ? reinterpret_cast<u16*>(U) : nullptr;
+  u16* VP = x3 ? op_planes(DV) : nullptr;
+  u16* UP = x3 ? op_planes(U) : nullptr;
   if (!prep) wino_s2_prepare_filters(g, 1, w, U, s);
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
@@ -1298,10 +1457,12 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   ia.v[0].p = dy + g.y_coff; ia.v[0].sn = (long)OH * OW * g.ldy; ia.v[0].sh = (long)OW * g.ldy; ia.v[0].sw = g.ldy;
   ia.H = OH; ia.W = OW; ia.TH = OH / WM; ia.TW = OW / WM; ia.C = g.Cout; ia.T = T; ia.ldv = g.Cout; ia.V = DV;
   ia.P = VP;
+  if (x3) op_scales(dy + g.y_coff, (long)g.N * OH * OW, g.Cout, g.ldy, DV, kGainBt, 1.f, false, s);
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cout / 4), 1, 1), dim3(256), 0, s, ia);
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.Ap = VP; b.Bp = UP; b.pA = (long)nV; b.pB = (long)nU;
+  if (x3) { b.hdrA = DV; b.hdrB = U; }
   b.A = DV; b.B = U; b.C = Xh; b.M = (int)T; b.N = K4; b.K = g.Cout;
   b.lda = g.Cout; b.ldb = g.Cout; b.ldc = K4;
   b.sA = T * g.Cout; b.sB = (long)K4 * g.Cout; b.sC = T * K4;
@@ -1335,8 +1496,10 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
     // masked by the adjoint filter transform) and the dgrad operand dM[tile][Cout]: t-leading GEMM over the tiles
     const int ns = x3_wgrad_splits(K4, g.Cout, T);
     const size_t nV = op_elems(T, K4), nM = op_elems(T, g.Cout);
-    u16* VP = reinterpret_cast<u16*>(ws);
-    u16* MP = reinterpret_cast<u16*>(ws + operand_floats(nV));
+    float* Vb = ws;
+    u16* VP = op_planes(Vb);
+    float* Mb = ws + operand_floats(nV);
+    u16* MP = op_planes(Mb);
     float* slabs = ws + operand_floats(nV) + operand_floats(nM);
     s2_input_transform(g, x, nullptr, VP, s);
     InArgs da;
@@ -1344,10 +1507,11 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
     da.s2_skip = -1;
     da.v[0].p = dy + g.y_coff; da.v[0].sn = (long)OH * OW * g.ldy; da.v[0].sh = (long)OW * g.ldy; da.v[0].sw = g.ldy;
     da.H = OH; da.W = OW; da.TH = OH / WM; da.TW = OW / WM; da.C = g.Cout; da.T = T; da.ldv = g.Cout; da.P = MP;
+    op_scales(dy + g.y_coff, (long)g.N * OH * OW, g.Cout, g.ldy, Mb, kGainA, 1.f, false, s);
     hipLaunchKernelGGL(wino_outadj_kernel, dim3(op_grid(T, g.Cout / 4), 1, 1), dim3(256), 0, s, da);
     BgArgs b;
     memset(&b, 0, sizeof(b));
-    b.Ap = VP; b.Bp = MP;
+    b.Ap = VP; b.Bp = MP; b.hdrA = Vb; b.hdrB = Mb;
     b.C = slabs; b.M = K4; b.N = g.Cout; b.K = (int)T;
     b.ldc = g.Cout; b.sC = (long)K4 * g.Cout; b.sSplit = (long)WF * K4 * g.Cout;
     b.kt_per_split = (int)((T / X3_BK + ns - 1) / ns);

@@ -166,8 +166,17 @@ def test_prepared_filters_match_inline(dev):
     wu, wuT, _ = ops.weightnorm_fwd(Vu, torch.ones(64, device=dev))
     du = ops.make_desc(xu, 32, True, 5, 5, 1, 64, 64, 0, 0)
     weff, weffT = ops.fold_weights(du, wu)
-    assert torch.equal(ops.prepare_filters(du, 0, weffT), ops.prepare_filters(du, 2, wuT))
-    assert torch.equal(ops.prepare_filters(du, 1, weff), ops.prepare_filters(du, 3, wu))
+    # (the two carry different power-of-two scales -- the folded tensor's own largest magnitude against four times the
+    # un-folded one's bound -- so the buffers differ; what they produce agrees to the rounding of the 22-bit pieces)
+    yf, yu = torch.empty(2, 16, 16, 64, device=dev), torch.empty(2, 16, 16, 64, device=dev)
+    ops.conv_fwd_raw(du, xu, None, weffT, None, yf, ops.prepare_filters(du, 0, weffT))
+    ops.conv_fwd_raw(du, xu, None, wuT, None, yu, ops.prepare_filters(du, 2, wuT))
+    assert _rel(yu, yf) < 1e-6
+    dyu = torch.randn_like(yf)
+    dxf, dxu = torch.empty_like(xu), torch.empty_like(xu)
+    ops.conv_dgrad_raw(du, dyu, weff, xu, None, dxf, 32, False, ops.prepare_filters(du, 1, weff))
+    ops.conv_dgrad_raw(du, dyu, wu, xu, None, dxu, 32, False, ops.prepare_filters(du, 3, wu))
+    assert _rel(dxu, dxf) < 1e-6
     assert L.otgan_conv2d_filter_bytes(ctypes.byref(desc), 2) == 0      # strided layers have no folded form
     plain = ops.make_desc(torch.empty(2, 8, 8, 16, device=dev), 16, False, 3, 3, 1, 32, 32, 0, 0)
     assert ops.prepare_filters(plain, 0, wT) is None and L.otgan_conv2d_filter_bytes(ctypes.byref(plain), 2) == 0

@@ -264,8 +264,17 @@ def test_ema_critic_step_matches_oracle(dev):
     assert float(r["distance"]) == pytest.approx(dist, rel=1e-4, abs=1e-7)
     assert float(r["entropy"]) == pytest.approx(ent, rel=1e-4)
     names = list(m.discriminator.named_variables())
-    worst = max((_rel(a, b), n) for n, a, b in zip(names, r["grads"], gr))
-    assert worst[0] < 2e-4, worst
+    # The two updates above are Adam steps of size lr = 0.05: where a gradient entry is ~0 its sign, and with it the
+    # weight, depends on the last bit of the gradient, so WHICH weights this comparison happens at depends on the
+    # kernels' summation orders.  Some of those points are ill-conditioned (features nearly collapsed: the distance
+    # is a small difference of large terms); the oracle itself in fp32 is the yardstick there, as in
+    # test_step_gradients_match_oracle.  At well-conditioned points both sit at ~5e-6.
+    o32 = CpuOTGAN("dcgan", "elu", dtype=torch.float32, use_c_matching=False)
+    o32.load(_named(m))
+    gr32, _, _ = o32.grads("disc", x.float().cpu(), u.float().cpu(), 2, lam, iters, ema_P=o32.ema_params(shadow))
+    for n, a, b, c in zip(names, r["grads"], gr, gr32):
+        e_hip, e_32 = _rel(a, b), _rel(c, b)
+        assert e_hip < max(2e-4, 3 * e_32), (n, e_hip, e_32)
     # and it is NOT what the live generator would give
     gr_live, dist_live, _ = o.grads("disc", x.double().cpu(), u.double().cpu(), 2, lam, iters)
     assert abs(dist_live - dist) > 1e-3 * abs(dist)

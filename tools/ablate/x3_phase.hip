@@ -48,13 +48,14 @@ int main(int argc, char** argv) {
   b.sAp = op_fstride(M, K); b.sBp = op_fstride(N, K);
   b.pA = kWF * b.sAp; b.pB = kWF * b.sBp;
   b.rbA = (M + 31) / 32; b.rbB = (N + 31) / 32; b.kblocks = K / 16;
-  const size_t na = (size_t)3 * b.pA, nb = (size_t)3 * b.pB, nc = (size_t)kWF * M * N;
+  const size_t na = (size_t)X3_NP * b.pA, nb = (size_t)X3_NP * b.pB, nc = (size_t)kWF * M * N;
   std::vector<u16> h(std::max(na, nb));
   unsigned lcg = 12345u;
   const bool zeros = getenv("X3_ZEROS") != nullptr;   // all-zero operands: the same instruction stream at low power
   for (auto& v : h) {
     lcg = lcg * 1664525u + 1013904223u;
-    v = zeros ? (u16)0 : (u16)(0x3c00u | ((lcg >> 16) & 0x83ffu));   // +-[0.0078, 0.0156): finite, all mantissa bits toggling
+    // finite, all mantissa bits toggling: bf16 +-[0.0078, 0.0156); fp16 (two-piece build) +-[0.125, 1)
+    v = zeros ? (u16)0 : X3_NP == 3 ? (u16)(0x3c00u | ((lcg >> 16) & 0x83ffu)) : (u16)((0x3000u + ((lcg >> 16) & 0x0bffu)) | ((lcg >> 16) & 0x8000u));
   }
   u16 *dA, *dB;
   float* dC;
@@ -82,7 +83,7 @@ int main(int argc, char** argv) {
     CK(hipEventElapsedTime(&ms, e0, e1));
     if (r >= 2) { best = std::min(best, ms); sum += ms; }
   }
-  const double flop = 6.0 * 2.0 * kWF * (double)M * N * K;
+  const double flop = (double)X3_NTERM * 2.0 * kWF * (double)M * N * K;
   printf("M=%d N=%d K=%d grid=%u tiles/XCD=%.1f: avg %.1f us best %.1f us  %.0f TFLOP/s (%.3f of 2500)\n", M, N, K, grid,
          b.tiles_m * b.tiles_n * 4.5, sum / reps * 1e3, best * 1e3, flop / (sum / reps * 1e-3) / 1e12,
          flop / (sum / reps * 1e-3) / 2.5e15);
