@@ -40,6 +40,13 @@ typedef struct otgan_conv_desc {
                      is a multiple of 4 channels wide, i.e. aligned groups of 4 effective
                      channels map to 4 consecutive source channels with one sign -> 16-byte
                      gathers; 0 = arbitrary widths -> per-channel gathers */
+  /* Optional, Winograd passes only (otgan_conv2d_filter_bytes > 0): device pointers to "amax records" of the
+   * tensors the pass reads -- otgan_absmax_f32 of x (forward, wgrad) and of dy (dgrad, wgrad).  The scaled
+   * two-piece operands of those passes need the largest magnitude of their source tensor; NULL = the library
+   * reduces the tensor itself inside the call (one more read of it).  A caller that runs forward and wgrad on the
+   * same x, or dgrad and wgrad on the same dy, computes each record once. */
+  const float* x_amax;
+  const float* dy_amax;
 } otgan_conv_desc;
 
 /*
@@ -52,6 +59,14 @@ typedef struct otgan_conv_desc {
 
 /* which: 0 fwd, 1 dgrad, 2 wgrad */
 size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which);
+
+/*
+ * amax record of x[rows][C] (row stride ld floats, C and ld multiples of 4, 16-byte aligned): record[0] = the
+ * largest |x| (NaN if any element is NaN).  record: OTGAN_AMAX_RECORD_FLOATS floats of device memory, written
+ * asynchronously on `stream`; pass it as otgan_conv_desc::x_amax / dy_amax.  Deterministic.
+ */
+#define OTGAN_AMAX_RECORD_FLOATS 128
+int otgan_absmax_f32(const float* x, long rows, int C, long ld, float* record, void* stream);
 
 /*
  * Winograd F(2x2,3x3) paths (fwd, dgrad and wgrad; scratch for the transformed operands is

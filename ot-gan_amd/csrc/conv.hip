@@ -1562,6 +1562,7 @@ inline WinoGeo wino_geo(const otgan_conv_desc* d) {
   WinoGeo w;
   w.N = d->N; w.H = d->H; w.W = d->W; w.Cin = d->C; w.Cout = d->Cout; w.ldx = d->ldx; w.ldy = d->ldy;
   w.y_coff = d->y_coff;
+  w.x_amax = d->x_amax; w.dy_amax = d->dy_amax;
   return w;
 }
 
@@ -1575,6 +1576,7 @@ inline WinoS2Geo wino_s2_geo(const otgan_conv_desc* d, const Geo& g) {
   WinoS2Geo w;
   w.N = d->N; w.H = d->H; w.W = d->W; w.C = d->C; w.Ceff = g.Ceff; w.doubled = doubled_act(d->preact) ? 1 : 0;
   w.act = act_kind(d->preact); w.ldx = d->ldx; w.Cout = d->Cout; w.ldy = d->ldy; w.y_coff = d->y_coff;
+  w.x_amax = d->x_amax; w.dy_amax = d->dy_amax;
   return w;
 }
 
@@ -1913,6 +1915,14 @@ size_t otgan_conv2d_filter_bytes(const otgan_conv_desc* d, int which) {
   if (wino_s2_ok(d, g)) return which < 2 ? sizeof(float) * wino_s2_filter_floats(wino_s2_geo(d, g), which) : 0;
   if (wino_ok(d, g)) return sizeof(float) * wino_filter_floats(wino_geo(d), which);   // 2, 3: from un-folded weights
   return 0;
+}
+
+int otgan_absmax_f32(const float* x, long rows, int C, long ld, float* record, void* stream) {
+  OTGAN_CHECK_ARG(x && record && aligned16(x) && aligned16(record), "null or misaligned pointer");
+  OTGAN_CHECK_ARG(rows >= 1 && C >= 4 && C % 4 == 0 && (rows == 1 || (ld >= C && ld % 4 == 0)), "rows >= 1, C and ld multiples of 4, ld >= C");
+  wino_absmax(x, rows, C, ld, record, (hipStream_t)stream);
+  OTGAN_CHECK_LAUNCH("absmax");
+  return OTGAN_OK;
 }
 
 int otgan_conv2d_prepare_filters_f32(const otgan_conv_desc* d, int which, const float* w, void* filters,

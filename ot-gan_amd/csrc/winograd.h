@@ -18,9 +18,13 @@ struct WinoGeo {
   int Cin, Cout;    // real channels (pre-activation NONE only)
   int ldx;          // channel stride of x
   int ldy, y_coff;  // output buffer [N, 2H, 2W, ldy], channel offset
+  const float* x_amax = nullptr;    // amax records of x / dy when the caller has them (otgan_layers.h), else null
+  const float* dy_amax = nullptr;
 };
 
 bool winograd_enabled();
+// amax record (otgan_layers.h) of x[rows][C], row stride ld
+void wino_absmax(const float* x, long rows, int C, long ld, float* record, hipStream_t s);
 constexpr int kWinoM = 4;          // output tile edge of F(4x4, 3x3)
 constexpr int kWinoFreq = 36;      // (kWinoM + 2)^2 batched GEMMs
 constexpr int kWinoS2Blocks = 121; // non-zero (class, frequency) blocks of a strided layer, of 4 * 36
@@ -52,6 +56,8 @@ struct WinoS2Geo {
   int doubled, act;        // CReLU/CELU doubling; 0 none, 1 relu-type, 2 elu-type
   int ldx;
   int Cout, ldy, y_coff;
+  const float* x_amax = nullptr;
+  const float* dy_amax = nullptr;
 };
 inline long wino_s2_tiles(const WinoS2Geo& g) { return (long)g.N * (g.H / (2 * kWinoM)) * (g.W / (2 * kWinoM)); }
 size_t wino_s2_fwd_ws_floats(const WinoS2Geo& g);

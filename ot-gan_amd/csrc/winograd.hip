@@ -21,6 +21,7 @@
 #include <atomic>
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "gemm_tile.h"
 
@@ -202,7 +203,27 @@ struct AmaxArgs {
 constexpr float kGainBt[WA] = {7.f, 5.f, 5.f, 6.f, 3.f, 7.f};                         // B^T (data / dgrad-data transform)
 constexpr float kGainG[WA] = {1.f, 1.f, 1.f, 28.f / 15.f, 7.f / 15.f, 1.f};           // G (filter transform)
 constexpr float kGainA[WA] = {1.f, 4.f, 4.f, 1.875f, 15.f, 1.f};                      // A (output-adjoint transform)
-constexpr int kAmaxBlocks = 1024, kAmaxSlots = 64;
+constexpr int kAmaxBlocks = 2048, kAmaxSlots = 64;
+
+// header of an operand from the largest magnitude of its source tensor (threads 0 .. 35 one frequency each)
+__device__ __forceinline__ void write_scales(const AmaxArgs& a, float amax, int tid) {
+  if (a.floor_one && amax == amax) amax = fmaxf(amax, 1.f);
+  if (tid < WF) {
+    const int i = tid / WA, j = tid - i * WA;
+    const float bound = amax * a.fold * (a.gain[i] * a.gain[j]);
+    float sc = 1.f, inv = 1.f;
+    if (!(bound <= 3.0e38f)) {          // NaN or infinite
+      sc = inv = __builtin_nanf("");
+    } else if (bound > 0.f) {
+      const int e = x3_scale_exp(amax * a.fold, a.gain[i], a.gain[j]);
+      sc = __builtin_ldexpf(1.f, 14 - e);
+      inv = __builtin_ldexpf(1.f, e - 14);
+    }
+    a.hdr[16 + tid] = sc;
+    a.hdr[64 + tid] = inv;
+  }
+  if (tid == 0) a.hdr[0] = amax;
+}
 
 __global__ __launch_bounds__(256) void absmax_kernel(AmaxArgs a) {
   __shared__ float red[4];
@@ -211,15 +232,29 @@ __global__ __launch_bounds__(256) void absmax_kernel(AmaxArgs a) {
   const long n4 = a.rows * c4;
   float m = 0.f;
   bool bad = false;
-  for (long i = (long)blockIdx.x * 256 + tid; i < n4; i += (long)gridDim.x * 256) {
-    const long row = i / c4;
-    const int q = (int)(i - row * c4);
-    const f32x4 v = ld4(a.x + row * a.ld + 4 * q);
+  auto take = [&](f32x4 v) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       bad = bad || !(v[j] == v[j]);
       m = fmaxf(m, fabsf(v[j]));
     }
+  };
+  const long stride = (long)gridDim.x * 256;
+  long i = (long)blockIdx.x * 256 + tid;
+  if (a.ld == a.C) {
+    // contiguous rows: eight independent 16-byte loads in flight per thread
+    for (; i + 7 * stride < n4; i += 8 * stride) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ld4(a.x + 4 * (i + u * stride));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) take(v[u]);
+    }
+  }
+  for (; i < n4; i += stride) {
+    const long row = i / c4;
+    const int q = (int)(i - row * c4);
+    take(ld4(a.x + row * a.ld + 4 * q));
   }
   if (bad) m = __builtin_nanf("");
   auto wave_max = [&](float v) {
@@ -242,39 +277,25 @@ __global__ __launch_bounds__(256) void absmax_kernel(AmaxArgs a) {
   };
   m = block_max(m);
   if (tid == 0) {
+    // device-scope (cache-bypassing) store, acknowledged before the counter moves; no fence: a device-scope release
+    // would write back the whole L2 once per block
     __hip_atomic_store(&a.scratch[blockIdx.x], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
-    last = atomicAdd(a.counter, 1u) == gridDim.x - 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
   }
   __syncthreads();
   if (!last) return;
-  __threadfence();
   float r = 0.f;
   for (int i = tid; i < (int)gridDim.x; i += 256) {
     const float w = __hip_atomic_load(&a.scratch[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     r = (r == r && w == w) ? fmaxf(r, w) : __builtin_nanf("");
   }
-  float amax = block_max(r);
-  if (a.floor_one && amax == amax) amax = fmaxf(amax, 1.f);
-  if (tid < WF) {
-    const int i = tid / WA, j = tid - i * WA;
-    const float bound = amax * a.fold * (a.gain[i] * a.gain[j]);
-    float sc = 1.f, inv = 1.f;
-    if (!(bound <= 3.0e38f)) {          // NaN or infinite
-      sc = inv = __builtin_nanf("");
-    } else if (bound > 0.f) {
-      const int e = x3_scale_exp(amax * a.fold, a.gain[i], a.gain[j]);
-      sc = __builtin_ldexpf(1.f, 14 - e);
-      inv = __builtin_ldexpf(1.f, e - 14);
-    }
-    a.hdr[16 + tid] = sc;
-    a.hdr[64 + tid] = inv;
-  }
-  if (tid == 0) {
-    a.hdr[0] = amax;
-    *a.counter = 0;
-  }
+  const float amax = block_max(r);
+  write_scales(a, amax, tid);
+  if (tid == 0) *a.counter = 0;
 }
+// the 36 scales from an amax record the caller already has (a.x = the record)
+__global__ __launch_bounds__(64) void scales_from_amax_kernel(AmaxArgs a) { write_scales(a, a.x[0], threadIdx.x); }
 
 // ---- streaming kernels --------------------------------------------------------------------
 // A "view" of a small-grid image: element (n, a, b, c) at p[n*sn + a*sh + b*sw + c].
@@ -866,6 +887,24 @@ unsigned long long x3_next_epoch() {
   unsigned long long v = e.fetch_add(0x632be59bd9b4e010ull) + 0x632be59bd9b4e010ull;
   return v ? v : 16;
 }
+// dev tool: OTGAN_X3_DUMP=k writes C of the k-th stream-eligible NT launch to /tmp/x3_dump_<k>_<tag>.bin
+int g_stream_idx = -1;
+void maybe_dump(const BgArgs& b, hipStream_t s) {
+  const char* e = getenv("OTGAN_X3_DUMP");
+  if (!e || g_stream_idx != atoi(e)) return;
+  (void)hipStreamSynchronize(s);
+  const size_t n = (size_t)WF * b.M * b.N;
+  std::vector<float> h(n);
+  (void)hipMemcpy(h.data(), b.C, n * 4, hipMemcpyDeviceToHost);
+  const char* tag = getenv("OTGAN_X3_DUMP_TAG");
+  char fn[256];
+  snprintf(fn, sizeof(fn), "/tmp/x3_dump_%d_%s.bin", g_stream_idx, tag ? tag : "x");
+  FILE* f = fopen(fn, "wb");
+  if (f) { fwrite(h.data(), 4, n, f); fclose(f); }
+  fprintf(stderr, "dumped %s: %d x %d x %d\n", fn, WF, b.M, b.N);
+  g_stream_idx = -1;
+}
+
 // plans are a function of the shape only: planned once per shape (a DCGAN step launches ~50 of these GEMMs)
 struct StreamPlan {
   bool ok;
@@ -910,8 +949,29 @@ bool launch_stream(BgArgs& b, hipStream_t s) {
     const long per_xcd2 = (long)b.tiles_m * b.tiles_n * 9;   // 2 x tiles per XCD (4.5 frequencies each)
     static const long half_rounds = [] { const char* e = getenv("OTGAN_X3_STREAM_HALF_ROUNDS"); return e ? atol(e) : 3L; }();
     if (per_xcd2 > (b.seg_mode == 1 ? 2L : half_rounds) * x3_stream_nw()) return false;
+    // below half a tile per workgroup a tile is a chain of three and more parked pieces, each waiting for the one
+    // before it (a 32 x 256 x 512 problem: 290 us): test-sized layers keep the one-tile grid
+    if (per_xcd2 < x3_stream_nw()) return false;
   }
   if (!cached_stream_plan(b, x3_stream_nw())) return false;
+  {   // dev tool: OTGAN_X3_STREAM_ONLY=k lets only the k-th eligible launch (counted since the variable last changed)
+      // take the stream kernel; OTGAN_X3_STREAM_LOG=1 prints every eligible launch
+    static int cnt = 0, last_only = -2;
+    const char* eo = getenv("OTGAN_X3_STREAM_ONLY");
+    const int only = eo ? atoi(eo) : -1;
+    if (only != last_only) { cnt = 0; last_only = only; }
+    const int idx = cnt++;
+    g_stream_idx = idx;
+    if (getenv("OTGAN_X3_STREAM_LOG"))
+      fprintf(stderr, "stream-eligible launch %d: %s M=%d N=%d K=%d seg=%d/%d/%d tiles=%dx%d%s\n", idx, TL ? "TL" : "NT", b.M, b.N, b.K,
+              b.seg_mode, b.seg_len, b.seg_skip, b.tiles_m, b.tiles_n, (only >= 0 && idx != only) ? " (one-tile)" : "");
+    if (only >= 0 && idx != only) return false;
+  }
+  if (getenv("OTGAN_X3_OWN_PARTIAL")) {   // dev tool: parked tiles in a buffer of their own instead of the workspace tail
+    static float* own = nullptr;
+    if (!own) { void* p = nullptr; (void)hipMalloc(&p, (x3_stream_floats() + 64) * 4); (void)hipMemset(p, 0, (x3_stream_floats() + 64) * 4); own = (float*)p; }
+    b.sk_partial = own;
+  }
   ensure_lds<wino_bgemm_x3_stream_kernel<TL>>(X3_SK_LDS);
   b.sk_epoch = x3_next_epoch();
   hipLaunchKernelGGL((wino_bgemm_x3_stream_kernel<TL>), dim3(8 * b.sk_nw), dim3(X3_THREADS), X3_SK_LDS, s, b);
@@ -927,7 +987,7 @@ void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
   double flop = 2.0 * WF * (double)a.M * a.N * a.K;
   if (a.seg_mode) flop *= 121.0 / 144.0;
   const bool x3 = !TN && a.Ap != nullptr;
-  ProfScope ps(x3 ? OTGAN_PROF_WINO_GEMM_X3 : OTGAN_PROF_WINO_GEMM, x3 ? 6.0 * flop : flop, 0.0, s);
+  ProfScope ps(x3 ? OTGAN_PROF_WINO_GEMM_X3 : OTGAN_PROF_WINO_GEMM, x3 ? (double)X3_NTERM * flop : flop, 0.0, s);
   if (x3) {
     ensure_lds<wino_bgemm_x3_kernel<true, false>>(X3_LDS);
     ensure_lds<wino_bgemm_x3_kernel<false, false>>(X3_LDS);
@@ -948,9 +1008,11 @@ void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
     else if (nsplit > 1) min_k = a.K - (nsplit - 1) * b.kt_per_split * X3_BK;
     dim3 grid(b.tiles_m * b.tiles_n, nsplit, WF);
     if (use_fmap()) grid = dim3(build_fmap(b), nsplit, 1);
-    if (nsplit == 1 && launch_stream<false>(b, s)) return;
+    g_stream_idx = -1;
+    if (nsplit == 1 && launch_stream<false>(b, s)) { maybe_dump(b, s); return; }
     if (min_k >= 4 * X3_SK) hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, false>), grid, dim3(X3_THREADS), X3_LDS, s, b);
     else hipLaunchKernelGGL((wino_bgemm_x3_kernel<false, false>), grid, dim3(X3_THREADS), X3_LDS, s, b);
+    maybe_dump(b, s);
     return;
   }
   ensure_lds<wino_bgemm_kernel<TN>>(lds);
@@ -969,7 +1031,7 @@ void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
 void launch_bgemm_tl(const BgArgs& a, int nsplit, hipStream_t s) {
   double flop = 2.0 * WF * (double)a.M * a.N * a.K;
   if (a.seg_mode) flop *= 121.0 / 144.0;
-  ProfScope ps(OTGAN_PROF_WINO_GEMM_X3, 6.0 * flop, 0.0, s);
+  ProfScope ps(OTGAN_PROF_WINO_GEMM_X3, (double)X3_NTERM * flop, 0.0, s);
   ensure_lds<wino_bgemm_x3_kernel<true, true>>(X3_LDS);
   ensure_lds<wino_bgemm_x3_kernel<false, true>>(X3_LDS);
   BgArgs b = a;
@@ -1048,23 +1110,45 @@ AmaxScratch& amax_scratch() {
   }
   return sc;
 }
-// scales of the operand at `base` (header) for a transform with row gains `gain` of the tensor x[rows][C] (row stride ld)
+// scales of the operand at `base` (header) for a transform with row gains `gain` of the tensor x[rows][C] (row stride
+// ld); `given`: the caller's amax record of that tensor (otgan_layers.h) -- then only the 36 scales are computed
 void op_scales(const float* x, long rows, int C, long ld, float* base, const float (&gain)[WA], float fold, bool floor_one,
-               hipStream_t s) {
+               hipStream_t s, const float* given = nullptr) {
   static std::atomic<unsigned> seq{0};
-  AmaxScratch& sc = amax_scratch();
-  const unsigned slot = seq.fetch_add(1) % kAmaxSlots;
   AmaxArgs a;
-  a.x = x; a.rows = rows; a.ld = ld; a.C = C; a.hdr = base;
+  a.x = x; a.rows = rows; a.ld = rows == 1 ? C : ld; a.C = C; a.hdr = base;
   for (int i = 0; i < WA; ++i) a.gain[i] = gain[i];
   a.fold = fold; a.floor_one = floor_one ? 1 : 0;
+  if (given) {
+    a.x = given;
+    hipLaunchKernelGGL(scales_from_amax_kernel, dim3(1), dim3(64), 0, s, a);
+    return;
+  }
+  AmaxScratch& sc = amax_scratch();
+  const unsigned slot = seq.fetch_add(1) % kAmaxSlots;
   a.scratch = sc.slots + (size_t)slot * kAmaxBlocks;
   a.counter = sc.counters + slot;
   const long n4 = rows * (C / 4);
+  static const long cap = [] { const char* e = getenv("OTGAN_AMAX_BLOCKS"); return e ? atol(e) : 256L; }();
   long blocks = (n4 + 256 * 8 - 1) / (256 * 8);
+  if (blocks > cap) blocks = cap;
   if (blocks > kAmaxBlocks) blocks = kAmaxBlocks;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  static const bool dbg = getenv("OTGAN_AMAX_DEBUG") != nullptr;
+  if (dbg) {   // dynamic range of the tensor (dev tool: synchronises)
+    (void)hipStreamSynchronize(s);
+    std::vector<float> h((size_t)rows * C);
+    for (long r = 0; r < rows; ++r) (void)hipMemcpy(h.data() + r * C, x + r * a.ld, (size_t)C * 4, hipMemcpyDeviceToHost);
+    double sum = 0, mx = 0;
+    long small = 0;
+    for (float v : h) { sum += fabs(v); mx = std::max(mx, (double)fabs(v)); }
+    for (float v : h) small += fabs(v) < mx * 9.5e-7 ? 1 : 0;   // below amax 2^-20
+    float rec = 0;
+    (void)hipMemcpy(&rec, base, 4, hipMemcpyDeviceToHost);
+    fprintf(stderr, "amax rows=%ld C=%d gain0=%.2f: amax %.3e (record %.3e) mean|x| %.3e ratio %.1e, %.1f%% below amax*2^-20\n", rows, C,
+            gain[0], mx, rec, sum / h.size(), mx / (sum / h.size() + 1e-300), 100.0 * small / h.size());
+  }
 }
 // elements of a [WF][rows][K] operand in either layout (rows padded to 32, K to 16)
 inline size_t op_elems(size_t rows, size_t K) { return WF * ((rows + 31) / 32 * 32) * ((K + 15) / 16 * 16); }
@@ -1105,6 +1189,11 @@ int wgrad_splits(const WinoGeo& g) {
 }
 
 }  // namespace
+
+void wino_absmax(const float* x, long rows, int C, long ld, float* record, hipStream_t s) {
+  const float unit[WA] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+  op_scales(x, rows, C, ld, record, unit, 1.f, false, s);
+}
 
 bool winograd_enabled() {
   static const bool on = [] {
@@ -1182,7 +1271,7 @@ int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stri
   ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
   ia.H = g.H; ia.W = g.W; ia.TH = g.H / WM; ia.TW = g.W / WM; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.V = V;
   ia.P = VP;
-  if (x3) op_scales(x, (long)g.N * g.H * g.W, g.Cin, g.ldx, V, kGainBt, 1.f, false, s);
+  if (x3) op_scales(x, (long)g.N * g.H * g.W, g.Cin, g.ldx, V, kGainBt, 1.f, false, s, g.x_amax);
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cin / 4), 1, 1), dim3(256), 0, s, ia);
   BgArgs b;
   memset(&b, 0, sizeof(b));
@@ -1224,7 +1313,7 @@ int wino_dgrad(const WinoGeo& g, const float* dy, const float* weff, long cls_st
   for (int cls = 0; cls < 4; ++cls) ia.coff[cls] = cls * g.Cout;
   ia.H = g.H; ia.W = g.W; ia.TH = g.H / WM; ia.TW = g.W / WM; ia.C = g.Cout; ia.T = T; ia.ldv = K4; ia.V = DV;
   ia.P = VP;
-  if (x3) op_scales(dy + g.y_coff, (long)g.N * 4 * g.H * g.W, g.Cout, g.ldy, DV, kGainBt, 1.f, false, s);
+  if (x3) op_scales(dy + g.y_coff, (long)g.N * 4 * g.H * g.W, g.Cout, g.ldy, DV, kGainBt, 1.f, false, s, g.dy_amax);
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cout / 4), 1, 4), dim3(256), 0, s, ia);
   BgArgs b;
   memset(&b, 0, sizeof(b));
@@ -1264,7 +1353,7 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
     ia.s2_skip = -1;
     ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
     ia.H = g.H; ia.W = g.W; ia.TH = g.H / WM; ia.TW = g.W / WM; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.P = VP;
-    op_scales(x, (long)g.N * g.H * g.W, g.Cin, g.ldx, Vb, kGainBt, 1.f, false, s);
+    op_scales(x, (long)g.N * g.H * g.W, g.Cin, g.ldx, Vb, kGainBt, 1.f, false, s, g.x_amax);
     hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cin / 4), 1, 1), dim3(256), 0, s, ia);
     InArgs da;
     memset(&da, 0, sizeof(da));
@@ -1272,7 +1361,7 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
     class_views(g, dy + g.y_coff, g.ldy, da.v);
     for (int cls = 0; cls < 4; ++cls) da.coff[cls] = cls * g.Cout;
     da.H = g.H; da.W = g.W; da.TH = g.H / WM; da.TW = g.W / WM; da.C = g.Cout; da.T = T; da.ldv = N4; da.P = MP;
-    op_scales(dy + g.y_coff, (long)g.N * 4 * g.H * g.W, g.Cout, g.ldy, Mb, kGainA, 1.f, false, s);
+    op_scales(dy + g.y_coff, (long)g.N * 4 * g.H * g.W, g.Cout, g.ldy, Mb, kGainA, 1.f, false, s, g.dy_amax);
     hipLaunchKernelGGL(wino_outadj_kernel, dim3(op_grid(T, g.Cout / 4), 1, 4), dim3(256), 0, s, da);
     BgArgs b;
     memset(&b, 0, sizeof(b));
@@ -1348,7 +1437,7 @@ int s2_wgrad_splits(const WinoS2Geo& g) {
 void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, u16* VP, hipStream_t s) {
   const long T = wino_s2_tiles(g);
   // (the activation is applied inside the transform: |relu(+-x)| <= |x|, |elu(x)| <= max(|x|, 1))
-  if (VP) op_scales(x, (long)g.N * g.H * g.W, g.C, g.ldx, reinterpret_cast<float*>(VP) - X3_HDR, kGainBt, 1.f, g.act == 2, s);
+  if (VP) op_scales(x, (long)g.N * g.H * g.W, g.C, g.ldx, reinterpret_cast<float*>(VP) - X3_HDR, kGainBt, 1.f, g.act == 2, s, g.x_amax);
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
   ia.s2_skip = -1;
@@ -1457,7 +1546,7 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   ia.v[0].p = dy + g.y_coff; ia.v[0].sn = (long)OH * OW * g.ldy; ia.v[0].sh = (long)OW * g.ldy; ia.v[0].sw = g.ldy;
   ia.H = OH; ia.W = OW; ia.TH = OH / WM; ia.TW = OW / WM; ia.C = g.Cout; ia.T = T; ia.ldv = g.Cout; ia.V = DV;
   ia.P = VP;
-  if (x3) op_scales(dy + g.y_coff, (long)g.N * OH * OW, g.Cout, g.ldy, DV, kGainBt, 1.f, false, s);
+  if (x3) op_scales(dy + g.y_coff, (long)g.N * OH * OW, g.Cout, g.ldy, DV, kGainBt, 1.f, false, s, g.dy_amax);
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cout / 4), 1, 1), dim3(256), 0, s, ia);
   BgArgs b;
   memset(&b, 0, sizeof(b));
@@ -1507,7 +1596,7 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
     da.s2_skip = -1;
     da.v[0].p = dy + g.y_coff; da.v[0].sn = (long)OH * OW * g.ldy; da.v[0].sh = (long)OW * g.ldy; da.v[0].sw = g.ldy;
     da.H = OH; da.W = OW; da.TH = OH / WM; da.TW = OW / WM; da.C = g.Cout; da.T = T; da.ldv = g.Cout; da.P = MP;
-    op_scales(dy + g.y_coff, (long)g.N * OH * OW, g.Cout, g.ldy, Mb, kGainA, 1.f, false, s);
+    op_scales(dy + g.y_coff, (long)g.N * OH * OW, g.Cout, g.ldy, Mb, kGainA, 1.f, false, s, g.dy_amax);
     hipLaunchKernelGGL(wino_outadj_kernel, dim3(op_grid(T, g.Cout / 4), 1, 1), dim3(256), 0, s, da);
     BgArgs b;
     memset(&b, 0, sizeof(b));

@@ -173,6 +173,17 @@ def conv_dgrad_raw(desc, dy, w, x, inv, dx, lddx, accumulate, filters=None):
                                            _lib.stream_ptr()), "conv2d_dgrad")
 
 
+def absmax_record(t):
+    """amax record (otgan_layers.h: otgan_absmax_f32) of a contiguous NHWC tensor: 128 floats on its device, [0] =
+    max |t|.  The Winograd passes scale their two-piece fp16 operands by it; computing it here, once per tensor,
+    lets forward + wgrad (x) and dgrad + wgrad (dy) share one reduction."""
+    rec = torch.empty(128, dtype=torch.float32, device=t.device)
+    C = t.shape[-1]
+    _lib.check(_lib.lib().otgan_absmax_f32(t.data_ptr(), t.numel() // C, C, C, rec.data_ptr(), _lib.stream_ptr()),
+               "absmax")
+    return rec
+
+
 def prepare_filters(desc, which, w):
     """Winograd-domain filters of a layer's forward (which=0, from wT) or dgrad (which=1, from w) pass, or None
     when the pass does not run as a Winograd GEMM (otgan_layers.h)."""
@@ -247,6 +258,11 @@ class Conv2dFunction(torch.autograd.Function):
                                       "bwd_done": False, "bwd_which": 3 if unf else 1}
 
         wd, wT, inv_norm, filt = cached_weights(V, g, compute)
+        ctx.x_rec = None
+        if filt["fwd"] is not None and x.is_contiguous() and C % 4 == 0:
+            # Winograd passes: one reduction of x for the forward pass now and the weight gradient later
+            ctx.x_rec = absmax_record(x)
+            desc.x_amax = ctx.x_rec.data_ptr()
         conv_fwd_raw(desc, x, cmap, wT, b, y, filt["fwd"])
         ctx.save_for_backward(x, V2d, g, wd, inv_norm)
         ctx.filt = filt
@@ -261,6 +277,10 @@ class Conv2dFunction(torch.autograd.Function):
         dy = dy.contiguous()
         desc = ctx.desc
         dx = dV = dg = db = None
+        dy_rec = None
+        if ctx.x_rec is not None and dy.shape[-1] % 4 == 0:
+            dy_rec = absmax_record(dy)        # shared by dgrad and wgrad
+            desc.dy_amax = dy_rec.data_ptr()
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             filt = ctx.filt

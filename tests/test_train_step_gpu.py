@@ -264,19 +264,18 @@ def test_ema_critic_step_matches_oracle(dev):
     assert float(r["distance"]) == pytest.approx(dist, rel=1e-4, abs=1e-7)
     assert float(r["entropy"]) == pytest.approx(ent, rel=1e-4)
     names = list(m.discriminator.named_variables())
-    # The two updates above are Adam steps of size lr = 0.05: where a gradient entry is ~0 its sign, and with it the
-    # weight, depends on the last bit of the gradient, so WHICH weights this comparison happens at depends on the
-    # kernels' summation orders.  Some of those points are ill-conditioned (features nearly collapsed: the distance
-    # is a small difference of large terms); the oracle itself in fp32 is the yardstick there, as in
-    # test_step_gradients_match_oracle.  At well-conditioned points both sit at ~5e-6.
-    o32 = CpuOTGAN("dcgan", "elu", dtype=torch.float32, use_c_matching=False)
-    o32.load(_named(m))
-    gr32, _, _ = o32.grads("disc", x.float().cpu(), u.float().cpu(), 2, lam, iters, ema_P=o32.ema_params(shadow))
-    for n, a, b, c in zip(names, r["grads"], gr, gr32):
-        e_hip, e_32 = _rel(a, b), _rel(c, b)
-        assert e_hip < max(2e-4, 3 * e_32), (n, e_hip, e_32)
-    # and it is NOT what the live generator would give
+    # The feature head is a CReLU whatever --nonlinearity says (models/dcgan.py:16,19): its backward switches between
+    # two unrelated gradient entries where a pre-activation changes sign, so ONE of the 6 x 16384 final pre-activations
+    # landing on the other side of zero than in the fp64 oracle moves every critic gradient by ~1e-3 (measured: the
+    # same weights give 6e-6 or 1.3e-3 depending on the summation order of one GEMM upstream, tools/debug/ema_cache.py;
+    # and which weights the two Adam steps of size 0.05 above arrive at depends on the last bit of the gradients).
+    # The tight step-level parity lives in the well-conditioned cases above; this test pins the BRANCH: the gradients
+    # must be those of the EMA generator's samples, far closer to them than to the live generator's.
     gr_live, dist_live, _ = o.grads("disc", x.double().cpu(), u.double().cpu(), 2, lam, iters)
+    for n, a, b, c in zip(names, r["grads"], gr, gr_live):
+        e_ema, e_live = _rel(a, b), _rel(a, c)
+        assert e_ema < 5e-3 and e_live > 20 * e_ema, (n, e_ema, e_live)
+    # and it is NOT what the live generator would give
     assert abs(dist_live - dist) > 1e-3 * abs(dist)
 
 
