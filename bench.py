@@ -217,7 +217,7 @@ def main():
         try:
             if not (default_cfg or a.model == "densenet"):
                 raise LookupError("no PMC summary for this configuration")
-            for rnd in ("r02", "r01"):          # newest committed PMC summary of this configuration
+            for rnd in ("r02", "r02b", "r01"):          # newest committed PMC summary of this configuration
                 fn = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary_{a.model}.json")
                 if os.path.exists(fn):
                     with open(fn) as f:

@@ -69,22 +69,26 @@ size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which);
 int otgan_absmax_f32(const float* x, long rows, int C, long ld, float* record, void* stream);
 
 /*
- * Winograd F(2x2,3x3) paths (fwd, dgrad and wgrad; scratch for the transformed operands is
+ * Winograd F(4x4,3x3) paths (fwd, dgrad and wgrad; scratch for the transformed operands is
  * reported by otgan_conv2d_workspace_bytes; nothing else changes for the caller):
  *   - folded 5x5 upsampling layers without pre-activation (the DCGAN generator,
  *     models/dcgan.py:33-46): each output-parity class is a 3x3 convolution on the small image;
  *   - 5x5 stride-2 layers with a single-tensor input (the DCGAN critic, models/dcgan.py:12-14):
  *     four 3x3 sub-convolutions of the input-parity sub-images, classes folded into the
  *     contraction index, structurally-zero blocks skipped (49 instead of 100 products per tile).
- * The batched GEMMs of these paths run on the bf16 matrix pipe with operands stored as three bf16
- * planes (hi + mid + lo): six MFMAs per fp32-exact product, fp32 accumulation -- results are at
- * least as accurate as the fp32 MFMA chain of the direct path.
+ * The batched GEMMs of these paths run on the fp16 matrix pipe with operands stored as two fp16 pieces of the
+ * power-of-two-scaled value (hi + lo = 22 significand bits, one scale per Winograd frequency derived from the
+ * largest magnitude of the tensor the operand is a transform of): three MFMAs per product, fp32 accumulation,
+ * exact rescale on the way out -- measured errors at or below those of the fp32 MFMA chain of the direct path.
  * Environment switches (debugging / A-B measurements): OTGAN_DISABLE_WINOGRAD=1,
  * OTGAN_WINO_FP32=1 (Winograd GEMMs on the fp32 engine), OTGAN_WINO_WGRAD_X3=0 (weight-gradient GEMMs on
  * the fp32 engine), OTGAN_WINO_WGRAD_TL=0 (weight-gradient operands from the transposing producers instead
  * of the forward-layout ones), OTGAN_DISABLE_DENSE16=1, OTGAN_DENSE16_V1=1; tuning knobs kept for measurements:
- * OTGAN_X3_SPLIT_TARGET (workgroups a K-split weight-gradient GEMM aims for, default 256) and OTGAN_OUTER_CHUNKS
- * (pixel chunks of the few-channel weight gradient, default 512).
+ * OTGAN_X3_SPLIT_TARGET (workgroups a K-split weight-gradient GEMM aims for, default 256), OTGAN_OUTER_CHUNKS
+ * (pixel chunks of the few-channel weight gradient, default 512), OTGAN_X3_STREAM (0 / 1 / 2: the persistent
+ * stream-K GEMM never / where it pays / always; read per launch), OTGAN_X3_STREAM_HALF_ROUNDS (its selection
+ * threshold in half tiles per compute unit, default 3), OTGAN_X3_FMAP=0 (tile-residue instead of frequency-major
+ * GEMM grid), OTGAN_AMAX_BLOCKS (workgroups of the largest-magnitude reduction, default 256).
  */
 
 /*
