@@ -373,3 +373,60 @@ def test_full_size_adjoint_identities(dev, case):
     err = float((ysum - y - y2).norm() / ysum.norm())
     # three independent fp32 evaluations: each carries the F(4x4,3x3) rounding (~7e-7 .. 2e-6 relative at K ~ 10^4)
     assert err < 1e-5, ("additivity", err)
+
+
+# ---- scaled two-piece fp16 operands of the Winograd GEMMs: the scale follows the data ----------------------
+def _wino_layer(dev, x, V, dy, stride, up, pre):
+    from otgan_amd import ops
+    x = x.to(dev).requires_grad_(True)
+    V = V.to(dev).requires_grad_(True)
+    Cout = V.shape[-1]
+    g = torch.ones(Cout, device=dev, requires_grad=True)
+    b = torch.zeros(Cout, device=dev, requires_grad=True)
+    y = ops.conv2d_op(x, V, g, b, stride=stride, upsample=up, preact=ops.ACT[pre])
+    dx, dV = torch.autograd.grad(y, [x, V], dy.to(dev))
+    return y, dx, dV
+
+
+@pytest.mark.parametrize("kind", ["up", "s2_crelu"])
+@pytest.mark.parametrize("mag", [1e-12, 1.0, 1e12])
+def test_wino_scale_invariance(dev, kind, mag):
+    """Magnitudes far outside the fp16 range on both sides (activations AND gradients scaled by `mag`): the
+    per-tensor power-of-two scales make the result exactly covariant when `mag` is a power of two, and the
+    accuracy against fp64 independent of it."""
+    up, stride, pre = (True, 1, None) if kind == "up" else (False, 2, "crelu")
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 8, 8, 64, generator=gen)
+    V = torch.randn(5, 5, 64 * (2 if pre else 1), 32, generator=gen) * 0.05
+    y0, dx0, dV0 = _wino_layer(dev, x, V, torch.randn(4, 16 if up else 4, 16 if up else 4, 32, generator=torch.Generator().manual_seed(3)), stride, up, pre)
+    p2 = float(2.0 ** round(float(torch.log2(torch.tensor(mag)))))           # the power of two next to mag
+    dy = torch.randn(4, 16 if up else 4, 16 if up else 4, 32, generator=torch.Generator().manual_seed(3))
+    y1, dx1, dV1 = _wino_layer(dev, x * p2, V, dy * p2, stride, up, pre)
+    assert torch.equal(y1, y0 * p2)                  # exact: every scale moved by the same power of two
+    assert torch.equal(dx1, dx0 * p2)
+    assert _rel(dV1, dV0 * (p2 * p2)) < 1e-6         # (weight-norm backward renormalises: not bitwise)
+    assert torch.isfinite(y1).all() and torch.isfinite(dx1).all() and torch.isfinite(dV1).all()
+
+
+def test_wino_outlier_zero_and_nan(dev):
+    """One element 1e4 times the rest sets the scale of its tensor: the other outputs keep their accuracy; an
+    all-zero input gives an exactly zero output (scale 1 for amax = 0); a NaN in the input makes the output NaN."""
+    from otgan_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 8, 8, 64, generator=gen)
+    V = (torch.randn(5, 5, 64, 32, generator=gen) * 0.05)
+    x_out = x.clone()
+    x_out[0, 0, 0, 0] = 1.0e4
+    g, b = torch.ones(32), torch.zeros(32)
+    ref = NT.conv2d([x_out.double()], {"V": V.double(), "g": g.double(), "b": b.double()}, None, 1, True)
+    y = ops.conv2d_op(x_out.to(dev), V.to(dev), g.to(dev), b.to(dev), stride=1, upsample=True, preact=0)
+    assert _rel(y[1], ref[1]) < TOL                  # the image without the outlier: unaffected
+    far = ref[0, 8:, 8:]                              # outputs of the outlier's image its 5x5 window does not reach
+    assert _rel(y[0, 8:, 8:], far) < TOL
+    assert _rel(y, ref) < TOL
+    yz = ops.conv2d_op(torch.zeros_like(x).to(dev), V.to(dev), g.to(dev), b.to(dev), stride=1, upsample=True, preact=0)
+    assert torch.count_nonzero(yz) == 0
+    x_nan = x.clone()
+    x_nan[1, 3, 3, 5] = float("nan")
+    yn = ops.conv2d_op(x_nan.to(dev), V.to(dev), g.to(dev), b.to(dev), stride=1, upsample=True, preact=0)
+    assert torch.isnan(yn).any()
