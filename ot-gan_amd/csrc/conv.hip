@@ -1580,6 +1580,20 @@ inline WinoS2Geo wino_s2_geo(const otgan_conv_desc* d, const Geo& g) {
   return w;
 }
 
+// 3x3 on a 2x upsampled image with CReLU (DenseNet generator transitions): forward through Winograd when the caller
+// hands over filters prepared from the UN-folded weights (otgan_conv2d_filter_bytes(d, 2) > 0)
+inline bool wino_up3_ok(const otgan_conv_desc* d, const Geo& g) {
+  return d->upsample == 1 && d->stride == 1 && d->KH == 3 && d->KW == 3 && d->preact == OTGAN_ACT_CRELU && d->C % 4 == 0 &&
+         g.Ceff == 2 * d->C && g.Ceff % 32 == 0 && d->Cout % 4 == 0 && (2 * d->H) % kWinoM == 0 && (2 * d->W) % kWinoM == 0 &&
+         d->ldx % 4 == 0 && d->ldy % 4 == 0 && d->y_coff % 4 == 0 && winograd_enabled() && getenv("OTGAN_DISABLE_WINO_UP3") == nullptr;
+}
+inline WinoUp3Geo wino_up3_geo(const otgan_conv_desc* d, const Geo& g) {
+  WinoUp3Geo w;
+  w.N = d->N; w.H = d->H; w.W = d->W; w.C = d->C; w.Ceff = g.Ceff; w.ldx = d->ldx; w.Cout = d->Cout; w.ldy = d->ldy;
+  w.y_coff = d->y_coff; w.x_amax = d->x_amax;
+  return w;
+}
+
 inline int outer_unit_rows(int H) { return H >= 8 ? 8 : H; }
 
 struct WgPlan {
@@ -1886,6 +1900,7 @@ size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which) {
     return align_up(sizeof(float) * fl, 256) + 256;
   }
   size_t s2 = 0;   // the strided Winograd path falls back to the generic one for list inputs: max of both
+  if (which == 0 && wino_up3_ok(d, g)) s2 = align_up(sizeof(float) * wino_up3_fwd_ws_floats(wino_up3_geo(d, g)), 256) + 256;
   if (wino_s2_ok(d, g)) {
     const WinoS2Geo w = wino_s2_geo(d, g);
     const size_t fl = which == 0 ? wino_s2_fwd_ws_floats(w) : which == 1 ? wino_s2_dgrad_ws_floats(w)
@@ -1914,6 +1929,7 @@ size_t otgan_conv2d_filter_bytes(const otgan_conv_desc* d, int which) {
   if (make_geo(d, &g) != OTGAN_OK || which < 0 || which > 3) return 0;
   if (wino_s2_ok(d, g)) return which < 2 ? sizeof(float) * wino_s2_filter_floats(wino_s2_geo(d, g), which) : 0;
   if (wino_ok(d, g)) return sizeof(float) * wino_filter_floats(wino_geo(d), which);   // 2, 3: from un-folded weights
+  if (wino_up3_ok(d, g)) return which == 2 ? sizeof(float) * wino_up3_filter_floats(wino_up3_geo(d, g)) : 0;   // forward only
   return 0;
 }
 
@@ -1940,6 +1956,8 @@ int otgan_conv2d_prepare_filters_f32(const otgan_conv_desc* d, int which, const 
   hipStream_t s = (hipStream_t)stream;
   if (wino_s2_ok(d, g)) {
     rc = wino_s2_prepare_filters(wino_s2_geo(d, g), which, w, (float*)filters, s);
+  } else if (!wino_ok(d, g) && wino_up3_ok(d, g)) {
+    rc = wino_up3_prepare_filters(wino_up3_geo(d, g), w, (float*)filters, s);
   } else {
     const FoldTab f = make_fold(d, g);
     rc = wino_prepare_filters(wino_geo(d), which, w, f.woff[1] - f.woff[0], (float*)filters, s);
@@ -1993,6 +2011,14 @@ static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32
     ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * kWinoS2Blocks * (double)wino_s2_tiles(w) * g.Ceff * d->Cout, 0.0, s);
     rc = wino_s2_fwd(w, x, wT, bias, y, (float*)workspace, s, filters);
     OTGAN_CHECK_LAUNCH("conv2d fwd (winograd, stride 2)");
+    return rc;
+  }
+  if (filters && wino_up3_ok(d, g) && !wino_ok(d, g) && cmap == nullptr && aligned16(x) && aligned16(y) && aligned16(bias) &&
+      aligned16(workspace) && workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 0)) {
+    const WinoUp3Geo w = wino_up3_geo(d, g);
+    ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * kWinoFreq * (double)wino_up3_tiles(w) * g.Ceff * d->Cout, 0.0, s);
+    rc = wino_up3_fwd(w, x, bias, y, (float*)workspace, s, filters);
+    OTGAN_CHECK_LAUNCH("conv2d fwd (winograd, 3x3 on upsampled input)");
     return rc;
   }
   if (wino_ok(d, g)) {

@@ -71,3 +71,23 @@ int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float
 int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const float* x, float* dx, int lddx,
                   int accumulate, float* ws, hipStream_t s, const float* prep = nullptr);
 int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw, float* ws, hipStream_t s);
+
+// ---- 3x3 convolution of a 2x nearest-neighbour upsampled image with a doubled ReLU pre-activation ([relu(x),
+// relu(-x)], the reference concatenates a list input BEFORE the activation here): the DenseNet generator's
+// transition layers.  Forward only: F(4x4,3x3) on the UPSAMPLED grid (2.25 products per output; the folded
+// implicit GEMM: 4) with the un-folded filters, on the split-precision engine.  dgrad / wgrad keep the folded path.
+struct WinoUp3Geo {
+  int N, H, W;        // small (stored) image; output is 2H x 2W
+  int C, Ceff;        // real / effective (2 C) input channels
+  int ldx;
+  int Cout, ldy, y_coff;
+  const float* x_amax = nullptr;
+};
+inline long wino_up3_tiles(const WinoUp3Geo& g) { return (long)g.N * (2 * g.H / kWinoM) * (2 * g.W / kWinoM); }
+size_t wino_up3_fwd_ws_floats(const WinoUp3Geo& g);
+size_t wino_up3_filter_floats(const WinoUp3Geo& g);
+// wT: un-folded [Cout][9 * Ceff]
+int wino_up3_prepare_filters(const WinoUp3Geo& g, const float* wT, float* out, hipStream_t s);
+int wino_up3_fwd(const WinoUp3Geo& g, const float* x, const float* bias, float* y, float* ws, hipStream_t s,
+                 const float* prep);
+

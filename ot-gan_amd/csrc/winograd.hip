@@ -318,7 +318,8 @@ struct InArgs {
   int ldv;               // row length of V
   float* V;
   int s2_skip;           // >= 0: strided layer, the (class = blockIdx.z, f) blocks absent under this index are not stored
-  u16* P;                // non-null: write the operand as three bf16 planes (blocked layout, op_off) instead of V
+  u16* P;                // non-null: write the operand as split planes (blocked layout, op_off) instead of V
+  int up;                // 1: the view is a stored small image read through a 2x nearest-neighbour upsample (H, W = upsampled)
 };
 template <int ACT>
 __device__ __forceinline__ f32x4 wino_act(f32x4 v) {
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(InArgs a) {
     for (int i = 0; i < WA; ++i) {
       const int r = WM * ta - 1 + i;
       const bool ok = (unsigned)r < (unsigned)a.H && (unsigned)q < (unsigned)a.W;
-      f32x4 e = ok ? ld4(v.p + n * v.sn + r * v.sh + q * v.sw + c) : zero;
+      f32x4 e = ok ? ld4(v.p + n * v.sn + (r >> a.up) * v.sh + (q >> a.up) * v.sw + c) : zero;
       if (ACT != 0 || DOUBLED) e = wino_act<ACT>(pass ? -e : e);
       col[i] = e;
     }
@@ -1635,5 +1636,72 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
   launch_bgemm<true>(b, ns, s);
   hipLaunchKernelGGL(wino_s2_filter_adj_kernel, dim3(grid1(4L * g.Ceff * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
                      (long)WF * K4 * g.Cout, g.Ceff, g.Cout, dw);
+  return OTGAN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 on a 2x upsampled image with a doubled ReLU (DenseNet generator transitions): forward
+// ---------------------------------------------------------------------------------------------
+namespace {
+// U[f][co][ce] from the un-folded wT[co][(i*3 + j)*Ceff + ce]
+__global__ __launch_bounds__(256) void wino_up3_filter_fwd_kernel(const float* __restrict__ wT, int Ceff, int Cout,
+                                                                float* __restrict__ U, u16* P) {
+  long row;
+  int k4;
+  if (!op_thread(P != nullptr, Cout, Ceff >> 2, row, k4)) return;
+  const int co = (int)row, ce = k4 * 4;
+  f32x4 g[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) g[i][j] = ld4(wT + ((long)co * 9 + i * 3 + j) * Ceff + ce);
+  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, Cout, Ceff, f, co, ce, v); });
+}
+}  // namespace
+
+size_t wino_up3_filter_floats(const WinoUp3Geo& g) { return operand_floats(op_elems(g.Cout, g.Ceff)); }
+size_t wino_up3_fwd_ws_floats(const WinoUp3Geo& g) {
+  const size_t T = (size_t)wino_up3_tiles(g);
+  return operand_floats(op_elems(T, g.Ceff)) + WF * T * (size_t)g.Cout + x3_stream_floats();
+}
+int wino_up3_prepare_filters(const WinoUp3Geo& g, const float* wT, float* out, hipStream_t s) {
+  op_scales(wT, 1, 9 * g.Ceff * g.Cout, 0, out, kGainG, 1.f, false, s);
+  hipLaunchKernelGGL(wino_up3_filter_fwd_kernel, dim3(op_grid(g.Cout, g.Ceff / 4)), dim3(256), 0, s, wT, g.Ceff, g.Cout, out,
+                     op_planes(out));
+  return OTGAN_OK;
+}
+int wino_up3_fwd(const WinoUp3Geo& g, const float* x, const float* bias, float* y, float* ws, hipStream_t s,
+                 const float* prep) {
+  const long T = wino_up3_tiles(g);
+  const int OH = 2 * g.H, OW = 2 * g.W;
+  const size_t nV = op_elems(T, g.Ceff), nU = op_elems(g.Cout, g.Ceff);
+  float* V = ws;
+  float* Mh = V + operand_floats(nV);
+  float* U = const_cast<float*>(prep);
+  op_scales(x, (long)g.N * g.H * g.W, g.C, g.ldx, V, kGainBt, 1.f, false, s, g.x_amax);   // |relu(+-x)| <= |x|
+  InArgs ia;
+  memset(&ia, 0, sizeof(ia));
+  ia.s2_skip = -1;
+  ia.up = 1;
+  ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
+  ia.H = OH; ia.W = OW; ia.TH = OH / WM; ia.TW = OW / WM; ia.C = g.C; ia.T = T; ia.ldv = g.Ceff; ia.V = V;
+  ia.P = op_planes(V);
+  hipLaunchKernelGGL((wino_input_kernel<1, true>), dim3(op_grid(T, g.C / 4), 2, 1), dim3(256), 0, s, ia);
+  BgArgs b;
+  memset(&b, 0, sizeof(b));
+  b.Ap = op_planes(V); b.Bp = op_planes(U); b.pA = (long)nV; b.pB = (long)nU;
+  b.hdrA = V; b.hdrB = U;
+  b.A = V; b.B = U; b.C = Mh; b.M = (int)T; b.N = g.Cout; b.K = g.Ceff;
+  b.lda = g.Ceff; b.ldb = g.Ceff; b.ldc = g.Cout;
+  b.sA = T * g.Ceff; b.sB = (long)g.Cout * g.Ceff; b.sC = T * g.Cout;
+  b.tiles_m = (int)((T + Cfg::BM - 1) / Cfg::BM); b.tiles_n = (g.Cout + Cfg::BN - 1) / Cfg::BN;
+  b.kt_per_split = (g.Ceff + Cfg::BK - 1) / Cfg::BK;
+  b.sk_partial = x3_stream_area(ws, wino_up3_fwd_ws_floats(g));
+  launch_bgemm<false>(b, 1, s);
+  OutArgs oa;
+  memset(&oa, 0, sizeof(oa));
+  oa.v[0].p = y + g.y_coff; oa.v[0].sn = (long)OH * OW * g.ldy; oa.v[0].sh = (long)OW * g.ldy; oa.v[0].sw = g.ldy;
+  oa.TH = OH / WM; oa.TW = OW / WM; oa.C = g.Cout; oa.T = T; oa.ldm = g.Cout; oa.Mh = Mh; oa.bias = bias;
+  hipLaunchKernelGGL(wino_output_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 1), dim3(256), 0, s, oa);
   return OTGAN_OK;
 }

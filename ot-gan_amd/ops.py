@@ -247,15 +247,21 @@ class Conv2dFunction(torch.autograd.Function):
         def compute():
             w, wT, inv_norm = weightnorm_fwd(V2d, g)
             wd = w                       # operand of dgrad
-            unf = bool(nfold) and _lib.lib().otgan_conv2d_filter_bytes(ctypes.byref(desc), 2) > 0
-            if nfold and not unf:
+            # Winograd passes of a folded layer take filters made from the UN-folded weights (which = 2 forward,
+            # 3 dgrad: no fold pass at all); a layer may have only the forward one (3x3 on an upsampled input)
+            unf_f = bool(nfold) and _lib.lib().otgan_conv2d_filter_bytes(ctypes.byref(desc), 2) > 0
+            unf_b = bool(nfold) and _lib.lib().otgan_conv2d_filter_bytes(ctypes.byref(desc), 3) > 0
+            if nfold and not (unf_f and unf_b):
                 # conv o upsample == four parity-class convs with pre-summed taps (otgan_layers.h)
-                wd, wT = fold_weights(desc, w)
+                wd_f, wT_f = fold_weights(desc, w)
+                if not unf_b:
+                    wd = wd_f
+                if not unf_f:
+                    wT = wT_f
             # Winograd-domain filters live as long as the normalised weights (the critic's survive the five
             # generator steps between its updates); the dgrad ones are made by the first backward that needs them.
-            # Folded Winograd layers derive them straight from the un-folded weights (no fold pass at all).
-            return wd, wT, inv_norm, {"fwd": prepare_filters(desc, 2 if unf else 0, wT), "bwd": None,
-                                      "bwd_done": False, "bwd_which": 3 if unf else 1}
+            return wd, wT, inv_norm, {"fwd": prepare_filters(desc, 2 if unf_f else 0, wT), "bwd": None,
+                                      "bwd_done": False, "bwd_which": 3 if unf_b else 1}
 
         wd, wT, inv_norm, filt = cached_weights(V, g, compute)
         ctx.x_rec = None
