@@ -4,7 +4,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libotgan_hip.so")
+# (OTGAN_LIB_PATH: a differently built library for A/B timing experiments -- dev only)
+LIB_PATH = os.environ.get("OTGAN_LIB_PATH") or os.path.join(_HERE, "csrc", "libotgan_hip.so")
 _lock = threading.Lock()
 _lib = None
 
