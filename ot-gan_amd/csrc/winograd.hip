@@ -938,22 +938,27 @@ bool cached_stream_plan(BgArgs& b, int nw) {
   b.sk_nw = nw;
   return true;
 }
+// does the selection rule send a GEMM with this many 256 x 256 tiles per frequency to the stream kernel?
+bool stream_wanted(long tiles, int seg_mode) {
+  const int mode = x3_stream_mode();
+  if (!mode || !x3_stream_nw()) return false;
+  if (mode != 1) return true;
+  const long per_xcd2 = tiles * 9;   // 2 x tiles per XCD (4.5 frequencies each)
+  static const long half_rounds = [] { const char* e = getenv("OTGAN_X3_STREAM_HALF_ROUNDS"); return e ? atol(e) : 3L; }();
+  return seg_mode != 1 && per_xcd2 > 2L * x3_stream_nw() && per_xcd2 <= half_rounds * x3_stream_nw();
+}
 template <bool TL>
 bool launch_stream(BgArgs& b, hipStream_t s) {
   if (!b.sk_partial || !x3_stream_nw() || !x3_stream_mode() || b.xmap != 4) return false;
-  // Where it pays (tools/ablate/x3_phase.hip, tools/bench_layers.py with OTGAN_X3_STREAM=0/1/2): up to 1.5 tiles per
-  // compute unit the one-tile grid leaves its last round half empty and the stream kernel is 1.1 - 1.33 x faster;
-  // around 2.25 it is a wash (+-5 %); from 4.5 on the one-tile grid wins by ~5 % (full rounds, nothing parked).
-  // Forward passes of the strided layers already balance their three K lengths longest-first: stream only below
-  // one tile per compute unit.
-  if (x3_stream_mode() == 1) {
-    const long per_xcd2 = (long)b.tiles_m * b.tiles_n * 9;   // 2 x tiles per XCD (4.5 frequencies each)
-    static const long half_rounds = [] { const char* e = getenv("OTGAN_X3_STREAM_HALF_ROUNDS"); return e ? atol(e) : 3L; }();
-    if (per_xcd2 > (b.seg_mode == 1 ? 2L : half_rounds) * x3_stream_nw()) return false;
-    // below half a tile per workgroup a tile is a chain of three and more parked pieces, each waiting for the one
-    // before it (a 32 x 256 x 512 problem: 290 us): test-sized layers keep the one-tile grid
-    if (per_xcd2 < x3_stream_nw()) return false;
-  }
+  // Where it pays.  With six MFMAs per product (three bf16 pieces) the stream kernel won 1.1 - 1.33 x up to 1.5 tiles per
+  // compute unit, was a wash around 2.25 and lost 5 % from 4.5 on (full rounds, nothing parked).  With three MFMAs per
+  // product a K stage is half as long and the kernel's per-stage bookkeeping and per-tile table weigh twice as much
+  // (tools/ablate/x3_phase.hip, -DX3_PIECES=2; us one-tile -> stream): 0.56 tiles per CU 258 -> 276, 1.125 269 -> 225,
+  // 2.25 234 -> 245, 4.5 233 -> 289, 9 270 -> 334; whole DCGAN step, same box: never 10.97 ms, <= 1.5 tiles 11.12,
+  // <= 2.5 tiles 11.30.  What is left is the one case where the one-tile grid wastes most of a round: just above
+  // one tile per compute unit (the second round 1/8 .. 1/2 full).  Forward passes of the strided layers balance their
+  // three K lengths longest-first already.
+  if (!stream_wanted((long)b.tiles_m * b.tiles_n, b.seg_mode)) return false;
   if (!cached_stream_plan(b, x3_stream_nw())) return false;
   {   // dev tool: OTGAN_X3_STREAM_ONLY=k lets only the k-th eligible launch (counted since the variable last changed)
       // take the stream kernel; OTGAN_X3_STREAM_LOG=1 prints every eligible launch
@@ -1169,7 +1174,8 @@ void class_views(const WinoGeo& g, P base, int ld, V (&v)[4]) {
 
 // K splits of the wgrad GEMM on the bf16 pipe (256 x 256 tiles: few tiles, long K)
 int x3_wgrad_splits(int M, int N, long T) {
-  if (x3_stream_nw()) return 1;   // the stream kernel balances the contraction over the compute units itself
+  // the stream kernel balances the contraction over the compute units itself
+  if (stream_wanted((long)((M + X3_BM - 1) / X3_BM) * ((N + X3_BN - 1) / X3_BN), 0)) return 1;
   const int blocks = ((M + X3_BM - 1) / X3_BM) * ((N + X3_BN - 1) / X3_BN) * WF;
   static const int target = [] { const char* e = getenv("OTGAN_X3_SPLIT_TARGET"); return e ? atoi(e) : 256; }();
   int ns = (target + blocks - 1) / blocks;
