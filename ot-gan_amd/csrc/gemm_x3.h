@@ -519,7 +519,7 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
           for (int j = 0; j < X3_NT; ++j) {
             const float v = acc[i][j][4 * qh + ql];
-            p[j * 32] = fmaf(es, v, eb);   // es = 1, eb = 0 without an epilogue: exact
+            p[j * 32] = fmaf(es, v, eb);   // es = 1, eb = 0 without an epilogue: exact (nontemporal stores: no change)
           }
           p += ld;
         }
@@ -950,23 +950,41 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     if (m0 + X3_BM <= a.M && n0 + X3_BN <= a.N) {
       const long ld = a.ldc;
       float* row = C + (long)(m0 + wm * X3_MT * 32 + 4 * g) * ld + (n0 + wn * X3_NT * 32 + r);
+      if (!has_prev) {
+        // the common case, kept as lean as the one-tile kernel's write-out: one running row pointer, immediate offsets
 #pragma unroll
-      for (int i = 0; i < X3_MT; ++i) {
+        for (int i = 0; i < X3_MT; ++i) {
 #pragma unroll
-        for (int qh = 0; qh < 4; ++qh) {
-          f32x4v pv[X3_NT];
+          for (int qh = 0; qh < 4; ++qh) {
+            // (a fence for the scheduler: left alone it copies the whole accumulator tile to vector registers first,
+            // spills a third of the copies to scratch and then waits on the reloads with the stores in flight)
+            __builtin_amdgcn_sched_barrier(0);
+            float* q = row + (long)(i * 32 + 8 * qh) * ld;
 #pragma unroll
-          for (int j = 0; j < X3_NT; ++j) pv[j] = f32x4v{poison ? __builtin_nanf("") : 0.f, 0.f, 0.f, 0.f};
-          if (has_prev) {
+            for (int ql = 0; ql < 4; ++ql) {
+#pragma unroll
+              for (int j = 0; j < X3_NT; ++j) q[j * 32] = acc[i][j][4 * qh + ql] * es;
+              q += ld;
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < X3_MT; ++i) {
+#pragma unroll
+          for (int qh = 0; qh < 4; ++qh) {
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4v pv[X3_NT];
 #pragma unroll
             for (int j = 0; j < X3_NT; ++j) pv[j] = Pp[((i * X3_NT + j) * 4 + qh) * 64];
-          }
-          float* q = row + (long)(i * 32 + 8 * qh) * ld;
+            if (poison) pv[0][0] = __builtin_nanf("");
+            float* q = row + (long)(i * 32 + 8 * qh) * ld;
 #pragma unroll
-          for (int ql = 0; ql < 4; ++ql) {
+            for (int ql = 0; ql < 4; ++ql) {
 #pragma unroll
-            for (int j = 0; j < X3_NT; ++j) q[j * 32] = (acc[i][j][4 * qh + ql] + pv[j][ql]) * es;
-            q += ld;
+              for (int j = 0; j < X3_NT; ++j) q[j * 32] = (acc[i][j][4 * qh + ql] + pv[j][ql]) * es;
+              q += ld;
+            }
           }
         }
       }
