@@ -10,7 +10,8 @@ physical GPUs (= torch.distributed world size): every rank owns nr_gpu / world s
 
 Added flags (not in the reference): --synthetic (random CIFAR-shaped data instead of the
 pickled dataset), --synthetic_size, --matching_scope global|local, --max_steps, --image_size, --save_every,
---data_dependent_init.
+--data_dependent_init, --eval_every / --eval_samples / --inception_model (the reference's Inception-score hook,
+train.py:245-272, with the classifier as an input: there is no network to download the 2015 graph).
 
 Checkpoints (`<save_dir>/med_gan_params-<epoch>`, the reference's naming, train.py:275-277) are torch pickles
 of {variable name: tensor} plus optimiser moments / step count and EMA shadows (which the reference's
@@ -57,7 +58,30 @@ def build_parser():
     p.add_argument('--data_dependent_init', action='store_true',
                    help="run the reference's intended (never executed, SURVEY F7) data-dependent initialisation pass "
                         "on the first batch: g <- init_scale / std, b <- -mean * g per layer (utils/nn.py:133-162)")
+    p.add_argument('--eval_every', type=int, default=100, help='Inception score every this many epochs (reference: 100, train.py:245)')
+    p.add_argument('--eval_samples', type=int, default=50000, help='samples per score (reference: 50000, train.py:262)')
+    p.add_argument('--inception_model', type=str, default='',
+                   help='TorchScript classifier (float32 images [n,H,W,3] in 0..255 -> class probabilities); without it the '
+                        'Inception-score hook is skipped (the reference downloads the 2015 Inception graph)')
     return p
+
+
+def inception_hook(model, args, classifier, state):
+    """train.py:245-272: scores of `eval_samples` samples of the generator and of its EMA copy, running maximum."""
+    from .utils.inception import get_inception_score
+    out = {}
+    for tag, ema in (("", False), ("EMA ", True)):
+        imgs = []
+        while sum(x.shape[0] for x in imgs) < args.eval_samples:
+            imgs.append(model.sample(min(1000, args.eval_samples), ema=ema).float().cpu().numpy())
+        x = np.concatenate(imgs)[:args.eval_samples]
+        score = get_inception_score([127.5 * (im + 1.) for im in x], splits=10, classifier=classifier)   # train.py:260-262
+        print('%sinception score was %.6f, std was %.3f' % (tag, score[0], score[1]))
+        if score[0] > state["max"]:
+            state["max"], state["iter"] = score[0], state["epoch"]
+        out[tag.strip() or "live"] = score
+    print('max inception score was %.6f, iter was %d' % (state["max"], state["iter"]))
+    return out
 
 
 def load_cifar(data_dir, subset='train'):
@@ -131,6 +155,12 @@ def main(argv=None):
     if rank == 0:
         print('starting training')
     mean_dist_gen, mean_dist_disc = [], []
+    classifier, score_state = None, {"max": 0.0, "iter": 0, "epoch": 0}
+    if args.inception_model and rank == 0:
+        from .utils.inception import load_classifier
+        classifier = load_classifier(args.inception_model, dev)
+    elif rank == 0:
+        print('no --inception_model: the Inception-score hook (reference train.py:245-272) is skipped')
     start_time = time.time()
     total = 0
     for epoch in range(current_epoch, 1000000):
@@ -161,6 +191,9 @@ def main(argv=None):
                                                    mean_dist_disc[-1], f(ent)))          # train.py:231
             save_tile_png(model.sample(100), os.path.join(args.save_dir, 'sample%d.png' % epoch))
             save_tile_png(model.sample(100, ema=True), os.path.join(args.save_dir, 'ema_sample%d.png' % epoch))
+            if classifier is not None and (epoch + 1) % args.eval_every == 0 and epoch != current_epoch:   # train.py:245
+                score_state["epoch"] = epoch
+                inception_hook(model, args, classifier, score_state)
             if (epoch + 1) % args.save_every == 0 and epoch != current_epoch:                          # train.py:275-277
                 torch.save(model.state_dict(), os.path.join(args.save_dir, 'med_gan_params-%d' % epoch))
                 np.savez(os.path.join(args.save_dir, 'distances.npz'), mean_dist_gen=np.array(mean_dist_gen),

@@ -290,7 +290,8 @@ def default_args(**over):
              nr_sinkhorn_iter=500, single_batch=False, train_disc_against_ema=False, model='dcgan',
              load_params=False, model_name='med_gan_params-2399', no_sinkhorn=False,
              image_size=32, matching_scope='global', synthetic=False, max_steps=0, save_every=200,
-             synthetic_size=50000, data_dependent_init=False)
+             synthetic_size=50000, data_dependent_init=False, eval_every=100, eval_samples=50000,
+             inception_model='')
     d.update(over)
     return argparse.Namespace(**d)
 
