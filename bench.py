@@ -250,6 +250,23 @@ def main():
         del model, x
         torch.cuda.empty_cache()
         out["secondary"] = secondary(dev, a)
+        if default_cfg:
+            # the headline configuration with the convolution GEMMs on three bf16 pieces per operand element (24
+            # significand bits, six MFMAs per product: the scheme before the two-piece fp16 operands) -- a fresh process
+            # (OTGAN_WINO_PIECES=3), the same unprofiled timing; not the headline, a reference point for the trade
+            import subprocess
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(a.steps), "--warmup", str(a.warmup),
+                                    "--no_secondary", "--no_cpu_baseline", "--no_prof"], capture_output=True, text=True,
+                                   timeout=300, env=dict(os.environ, OTGAN_WINO_PIECES="3"))
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+                d3 = json.loads(line)
+                out["secondary"]["three_bf16_pieces_24bit"] = {
+                    "images_per_sec": d3["value"], "ms_per_step": d3["ms_per_step"],
+                    "note": "OTGAN_WINO_PIECES=3: conv GEMM operands as three bf16 pieces (hi+mid+lo = 24 significand bits), six "
+                            "MFMAs per product; everything else identical; own process, unprofiled"}
+            except Exception as e:      # never lose the headline line over the reference point
+                out["secondary"]["three_bf16_pieces_24bit"] = {"error": repr(e)[:200]}
     if world == 1 and not a.no_cpu_baseline:
         from oracle import train_step_cpu
         # bounded sample: 2 shards x 16 images (~10 s of CPU work), at most 32 host threads (torch's CPU convs

@@ -23,6 +23,15 @@
 #include "gemm_tile.h"
 #include "dense16.h"
 #include "winograd.h"
+
+// winograd.hip exists twice in the library (winograd_api.inc): two scaled fp16 pieces per operand element (wino_p2,
+// default) or three bf16 pieces (wino_p3: 24 significand bits, six MFMAs per product) -- OTGAN_WINO_PIECES=3, read per
+// call so that one process can measure both (prepared filters belong to the mode they were made in)
+static inline int wino_pieces() {
+  const char* e = getenv("OTGAN_WINO_PIECES");
+  return (e && e[0] == '3') ? 3 : 2;
+}
+#define WINO(fn) (wino_pieces() == 3 ? wino_p3::fn : wino_p2::fn)
 #include "../../include/otgan.h"
 
 namespace {
@@ -1556,7 +1565,7 @@ FoldTab make_fold(const otgan_conv_desc* d, const Geo& g) {
 // Winograd F(2x2,3x3) applies to folded 5x5 upsampling layers without pre-activation.
 inline bool wino_ok(const otgan_conv_desc* d, const Geo& g) {
   return g.fold && d->KH == 5 && d->KW == 5 && d->preact == OTGAN_ACT_NONE && d->C % 32 == 0 &&
-         d->Cout % 4 == 0 && d->H % kWinoM == 0 && d->W % kWinoM == 0 && d->H >= kWinoM && d->W >= kWinoM && winograd_enabled();
+         d->Cout % 4 == 0 && d->H % kWinoM == 0 && d->W % kWinoM == 0 && d->H >= kWinoM && d->W >= kWinoM && WINO(winograd_enabled)();
 }
 inline WinoGeo wino_geo(const otgan_conv_desc* d) {
   WinoGeo w;
@@ -1570,7 +1579,7 @@ inline WinoGeo wino_geo(const otgan_conv_desc* d) {
 inline bool wino_s2_ok(const otgan_conv_desc* d, const Geo& g) {
   return d->stride == 2 && d->upsample == 0 && d->KH == 5 && d->KW == 5 && d->C % 4 == 0 && g.Ceff % 32 == 0 &&
          d->Cout % 4 == 0 && d->H % (2 * kWinoM) == 0 && d->W % (2 * kWinoM) == 0 && d->ldx % 4 == 0 && d->ldy % 4 == 0 &&
-         d->y_coff % 4 == 0 && winograd_enabled();
+         d->y_coff % 4 == 0 && WINO(winograd_enabled)();
 }
 inline WinoS2Geo wino_s2_geo(const otgan_conv_desc* d, const Geo& g) {
   WinoS2Geo w;
@@ -1585,7 +1594,7 @@ inline WinoS2Geo wino_s2_geo(const otgan_conv_desc* d, const Geo& g) {
 inline bool wino_up3_ok(const otgan_conv_desc* d, const Geo& g) {
   return d->upsample == 1 && d->stride == 1 && d->KH == 3 && d->KW == 3 && d->preact == OTGAN_ACT_CRELU && d->C % 4 == 0 &&
          g.Ceff == 2 * d->C && g.Ceff % 32 == 0 && d->Cout % 4 == 0 && (2 * d->H) % kWinoM == 0 && (2 * d->W) % kWinoM == 0 &&
-         d->ldx % 4 == 0 && d->ldy % 4 == 0 && d->y_coff % 4 == 0 && winograd_enabled() && getenv("OTGAN_DISABLE_WINO_UP3") == nullptr;
+         d->ldx % 4 == 0 && d->ldy % 4 == 0 && d->y_coff % 4 == 0 && WINO(winograd_enabled)() && getenv("OTGAN_DISABLE_WINO_UP3") == nullptr;
 }
 inline WinoUp3Geo wino_up3_geo(const otgan_conv_desc* d, const Geo& g) {
   WinoUp3Geo w;
@@ -1895,16 +1904,16 @@ size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which) {
   if (make_geo(d, &g) != OTGAN_OK) return 0;
   if (wino_ok(d, g)) {
     const WinoGeo w = wino_geo(d);
-    const size_t fl = which == 0 ? wino_fwd_ws_floats(w) : which == 1 ? wino_dgrad_ws_floats(w)
-                                                                      : wino_wgrad_ws_floats(w) + make_fold(d, g).total;
+    const size_t fl = which == 0 ? WINO(wino_fwd_ws_floats)(w) : which == 1 ? WINO(wino_dgrad_ws_floats)(w)
+                                                                      : WINO(wino_wgrad_ws_floats)(w) + make_fold(d, g).total;
     return align_up(sizeof(float) * fl, 256) + 256;
   }
   size_t s2 = 0;   // the strided Winograd path falls back to the generic one for list inputs: max of both
-  if (which == 0 && wino_up3_ok(d, g)) s2 = align_up(sizeof(float) * wino_up3_fwd_ws_floats(wino_up3_geo(d, g)), 256) + 256;
+  if (which == 0 && wino_up3_ok(d, g)) s2 = align_up(sizeof(float) * WINO(wino_up3_fwd_ws_floats)(wino_up3_geo(d, g)), 256) + 256;
   if (wino_s2_ok(d, g)) {
     const WinoS2Geo w = wino_s2_geo(d, g);
-    const size_t fl = which == 0 ? wino_s2_fwd_ws_floats(w) : which == 1 ? wino_s2_dgrad_ws_floats(w)
-                                                                         : wino_s2_wgrad_ws_floats(w);
+    const size_t fl = which == 0 ? WINO(wino_s2_fwd_ws_floats)(w) : which == 1 ? WINO(wino_s2_dgrad_ws_floats)(w)
+                                                                         : WINO(wino_s2_wgrad_ws_floats)(w);
     s2 = align_up(sizeof(float) * fl, 256) + 256;
   }
   if (which == 1) {
@@ -1927,16 +1936,16 @@ size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which) {
 size_t otgan_conv2d_filter_bytes(const otgan_conv_desc* d, int which) {
   Geo g;
   if (make_geo(d, &g) != OTGAN_OK || which < 0 || which > 3) return 0;
-  if (wino_s2_ok(d, g)) return which < 2 ? sizeof(float) * wino_s2_filter_floats(wino_s2_geo(d, g), which) : 0;
-  if (wino_ok(d, g)) return sizeof(float) * wino_filter_floats(wino_geo(d), which);   // 2, 3: from un-folded weights
-  if (wino_up3_ok(d, g)) return which == 2 ? sizeof(float) * wino_up3_filter_floats(wino_up3_geo(d, g)) : 0;   // forward only
+  if (wino_s2_ok(d, g)) return which < 2 ? sizeof(float) * WINO(wino_s2_filter_floats)(wino_s2_geo(d, g), which) : 0;
+  if (wino_ok(d, g)) return sizeof(float) * WINO(wino_filter_floats)(wino_geo(d), which);   // 2, 3: from un-folded weights
+  if (wino_up3_ok(d, g)) return which == 2 ? sizeof(float) * WINO(wino_up3_filter_floats)(wino_up3_geo(d, g)) : 0;   // forward only
   return 0;
 }
 
 int otgan_absmax_f32(const float* x, long rows, int C, long ld, float* record, void* stream) {
   OTGAN_CHECK_ARG(x && record && aligned16(x) && aligned16(record), "null or misaligned pointer");
   OTGAN_CHECK_ARG(rows >= 1 && C >= 4 && C % 4 == 0 && (rows == 1 || (ld >= C && ld % 4 == 0)), "rows >= 1, C and ld multiples of 4, ld >= C");
-  wino_absmax(x, rows, C, ld, record, (hipStream_t)stream);
+  WINO(wino_absmax)(x, rows, C, ld, record, (hipStream_t)stream);
   OTGAN_CHECK_LAUNCH("absmax");
   return OTGAN_OK;
 }
@@ -1955,12 +1964,12 @@ int otgan_conv2d_prepare_filters_f32(const otgan_conv_desc* d, int which, const 
   }
   hipStream_t s = (hipStream_t)stream;
   if (wino_s2_ok(d, g)) {
-    rc = wino_s2_prepare_filters(wino_s2_geo(d, g), which, w, (float*)filters, s);
+    rc = WINO(wino_s2_prepare_filters)(wino_s2_geo(d, g), which, w, (float*)filters, s);
   } else if (!wino_ok(d, g) && wino_up3_ok(d, g)) {
-    rc = wino_up3_prepare_filters(wino_up3_geo(d, g), w, (float*)filters, s);
+    rc = WINO(wino_up3_prepare_filters)(wino_up3_geo(d, g), w, (float*)filters, s);
   } else {
     const FoldTab f = make_fold(d, g);
-    rc = wino_prepare_filters(wino_geo(d), which, w, f.woff[1] - f.woff[0], (float*)filters, s);
+    rc = WINO(wino_prepare_filters)(wino_geo(d), which, w, f.woff[1] - f.woff[0], (float*)filters, s);
   }
   OTGAN_CHECK_LAUNCH("conv2d prepare filters");
   return rc;
@@ -2009,7 +2018,7 @@ static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32
       aligned16(workspace) && workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 0)) {
     const WinoS2Geo w = wino_s2_geo(d, g);
     ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * kWinoS2Blocks * (double)wino_s2_tiles(w) * g.Ceff * d->Cout, 0.0, s);
-    rc = wino_s2_fwd(w, x, wT, bias, y, (float*)workspace, s, filters);
+    rc = WINO(wino_s2_fwd)(w, x, wT, bias, y, (float*)workspace, s, filters);
     OTGAN_CHECK_LAUNCH("conv2d fwd (winograd, stride 2)");
     return rc;
   }
@@ -2017,7 +2026,7 @@ static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32
       aligned16(workspace) && workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 0)) {
     const WinoUp3Geo w = wino_up3_geo(d, g);
     ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * kWinoFreq * (double)wino_up3_tiles(w) * g.Ceff * d->Cout, 0.0, s);
-    rc = wino_up3_fwd(w, x, bias, y, (float*)workspace, s, filters);
+    rc = WINO(wino_up3_fwd)(w, x, bias, y, (float*)workspace, s, filters);
     OTGAN_CHECK_LAUNCH("conv2d fwd (winograd, 3x3 on upsampled input)");
     return rc;
   }
@@ -2033,7 +2042,7 @@ static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32
     const WinoGeo w = wino_geo(d);
     // executed FLOP: 16 GEMMs of tiles x 4*Cout x Cin
     ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * kWinoFreq * (double)wino_tiles(w) * 4.0 * d->Cout * d->C, 0.0, s);
-    rc = wino_fwd(w, x, wT, f.woff[1] - f.woff[0], bias, y, (float*)workspace, s, filters);
+    rc = WINO(wino_fwd)(w, x, wT, f.woff[1] - f.woff[0], bias, y, (float*)workspace, s, filters);
     OTGAN_CHECK_LAUNCH("conv2d fwd (winograd)");
     return rc;
   }
@@ -2231,7 +2240,7 @@ static int conv2d_dgrad_impl(const otgan_conv_desc* d, const float* dy, const fl
       aligned16(x) && aligned16(workspace) && workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 1)) {
     const WinoS2Geo wg = wino_s2_geo(d, g);
     ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * kWinoS2Blocks * (double)wino_s2_tiles(wg) * g.Ceff * d->Cout, 0.0, s);
-    rc = wino_s2_dgrad(wg, dy, w, x, dx, lddx, accumulate, (float*)workspace, s, filters);
+    rc = WINO(wino_s2_dgrad)(wg, dy, w, x, dx, lddx, accumulate, (float*)workspace, s, filters);
     OTGAN_CHECK_LAUNCH("conv2d dgrad (winograd, stride 2)");
     return rc;
   }
@@ -2246,7 +2255,7 @@ static int conv2d_dgrad_impl(const otgan_conv_desc* d, const float* dy, const fl
     const FoldTab f = make_fold(d, g);
     const WinoGeo wg = wino_geo(d);
     ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * kWinoFreq * (double)wino_tiles(wg) * 4.0 * d->Cout * d->C, 0.0, s);
-    rc = wino_dgrad(wg, dy, w, f.woff[1] - f.woff[0], dx, lddx, accumulate, (float*)workspace, s, filters);
+    rc = WINO(wino_dgrad)(wg, dy, w, f.woff[1] - f.woff[0], dx, lddx, accumulate, (float*)workspace, s, filters);
     OTGAN_CHECK_LAUNCH("conv2d dgrad (winograd)");
     return rc;
   }
@@ -2366,7 +2375,7 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
       workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 2)) {
     const WinoS2Geo wg = wino_s2_geo(d, g);
     ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * kWinoS2Blocks * (double)wino_s2_tiles(wg) * g.Ceff * d->Cout, 0.0, s);
-    rc = wino_s2_wgrad(wg, x, dy, dw, (float*)workspace, s);
+    rc = WINO(wino_s2_wgrad)(wg, x, dy, dw, (float*)workspace, s);
     OTGAN_CHECK_LAUNCH("conv2d wgrad (winograd, stride 2)");
     return rc;
   }
@@ -2381,10 +2390,10 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
     const FoldTab f = make_fold(d, g);
     const WinoGeo wg = wino_geo(d);
     float* ws = (float*)workspace;
-    float* dweff = ws + wino_wgrad_ws_floats(wg);
+    float* dweff = ws + WINO(wino_wgrad_ws_floats)(wg);
     {
       ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * kWinoFreq * (double)wino_tiles(wg) * 4.0 * d->Cout * d->C, 0.0, s);
-      rc = wino_wgrad(wg, x, dy, dweff, f.woff[1] - f.woff[0], ws, s);
+      rc = WINO(wino_wgrad)(wg, x, dy, dweff, f.woff[1] - f.woff[0], ws, s);
       if (rc) return rc;
     }
     OTGAN_CHECK_LAUNCH("conv2d wgrad (winograd)");

@@ -22,32 +22,19 @@ struct WinoGeo {
   const float* dy_amax = nullptr;
 };
 
-bool winograd_enabled();
 // amax record (otgan_layers.h) of x[rows][C], row stride ld
-void wino_absmax(const float* x, long rows, int C, long ld, float* record, hipStream_t s);
 constexpr int kWinoM = 4;          // output tile edge of F(4x4, 3x3)
 constexpr int kWinoFreq = 36;      // (kWinoM + 2)^2 batched GEMMs
 constexpr int kWinoS2Blocks = 121; // non-zero (class, frequency) blocks of a strided layer, of 4 * 36
 // tiles = N * (H/4) * (W/4)
 inline long wino_tiles(const WinoGeo& g) { return (long)g.N * (g.H / kWinoM) * (g.W / kWinoM); }
 // scratch floats of each pass
-size_t wino_fwd_ws_floats(const WinoGeo& g);
-size_t wino_dgrad_ws_floats(const WinoGeo& g);
-size_t wino_wgrad_ws_floats(const WinoGeo& g);
 
 // y = folded conv of x with the class weights given as weffT[cls][Cout][9*Cin] (class stride cls_stride)
 // `prep` (optional): the Winograd-domain filters of this pass, made once by wino_prepare_filters() and reused while
 // the weights do not change (wino_filter_floats() floats); null: derived from the weights into the workspace
-size_t wino_filter_floats(const WinoGeo& g, int which);   // which: 0 forward (from weffT), 1 dgrad (from weff)
-int wino_prepare_filters(const WinoGeo& g, int which, const float* w, long cls_stride, float* out, hipStream_t s);
-int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stride, const float* bias, float* y,
-             float* ws, hipStream_t s, const float* prep = nullptr);
 // dx[N,H,W,lddx] (+)= gradient w.r.t. the small input; weff[cls][9][Cin][Cout]
-int wino_dgrad(const WinoGeo& g, const float* dy, const float* weff, long cls_stride, float* dx, int lddx,
-               int accumulate, float* ws, hipStream_t s, const float* prep = nullptr);
 // dweff[cls][9][Cin][Cout] (class stride cls_stride) = folded weight gradient
-int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, long cls_stride, float* ws,
-               hipStream_t s);
 
 // ---- 5x5 stride-2 layers (DCGAN critic, models/dcgan.py:12-14) --------------------------------
 struct WinoS2Geo {
@@ -60,17 +47,7 @@ struct WinoS2Geo {
   const float* dy_amax = nullptr;
 };
 inline long wino_s2_tiles(const WinoS2Geo& g) { return (long)g.N * (g.H / (2 * kWinoM)) * (g.W / (2 * kWinoM)); }
-size_t wino_s2_fwd_ws_floats(const WinoS2Geo& g);
-size_t wino_s2_dgrad_ws_floats(const WinoS2Geo& g);
-size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g);
 // wT: [Cout][25*Ceff];  w: HWIO [25][Ceff][Cout];  single-tensor inputs only (default channel map)
-size_t wino_s2_filter_floats(const WinoS2Geo& g, int which);   // which: 0 forward (from wT), 1 dgrad (from w)
-int wino_s2_prepare_filters(const WinoS2Geo& g, int which, const float* w, float* out, hipStream_t s);
-int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float* bias, float* y, float* ws,
-                hipStream_t s, const float* prep = nullptr);
-int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const float* x, float* dx, int lddx,
-                  int accumulate, float* ws, hipStream_t s, const float* prep = nullptr);
-int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw, float* ws, hipStream_t s);
 
 // ---- 3x3 convolution of a 2x nearest-neighbour upsampled image with a doubled ReLU pre-activation ([relu(x),
 // relu(-x)], the reference concatenates a list input BEFORE the activation here): the DenseNet generator's
@@ -84,10 +61,16 @@ struct WinoUp3Geo {
   const float* x_amax = nullptr;
 };
 inline long wino_up3_tiles(const WinoUp3Geo& g) { return (long)g.N * (2 * g.H / kWinoM) * (2 * g.W / kWinoM); }
-size_t wino_up3_fwd_ws_floats(const WinoUp3Geo& g);
-size_t wino_up3_filter_floats(const WinoUp3Geo& g);
 // wT: un-folded [Cout][9 * Ceff]
-int wino_up3_prepare_filters(const WinoUp3Geo& g, const float* wT, float* out, hipStream_t s);
-int wino_up3_fwd(const WinoUp3Geo& g, const float* x, const float* bias, float* y, float* ws, hipStream_t s,
-                 const float* prep);
 
+// the functions of winograd.hip: one namespace per piece count (winograd_api.inc)
+#ifdef WINO_NS
+#include "winograd_api.inc"
+#else
+#define WINO_NS wino_p2
+#include "winograd_api.inc"
+#undef WINO_NS
+#define WINO_NS wino_p3
+#include "winograd_api.inc"
+#undef WINO_NS
+#endif

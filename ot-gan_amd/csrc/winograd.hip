@@ -8,9 +8,16 @@
 //   dgrad   : the same with d = dy sampled per class, flipped filters, K = 4*Cout, N = Cin
 //   wgrad   : dU[f] = V[f]^T . (A dY A^T)[f]  (K = tiles), then dweff = G^T dU G
 // The transforms are streaming float4 kernels; the GEMMs use the shared block-GEMM engine.
-#include "winograd.h"
-// the Winograd-domain GEMMs of the convolution layers: two scaled fp16 pieces per operand element (gemm_x3.h)
+// The Winograd-domain GEMMs of the convolution layers.  This file is compiled twice (Makefile): X3_PIECES = 2,
+// WINO_NS = wino_p2 -- two scaled fp16 pieces per operand element, three MFMAs per product (default) -- and
+// X3_PIECES = 3, WINO_NS = wino_p3 -- three bf16 pieces, 24 significand bits, six MFMAs (OTGAN_WINO_PIECES=3).
+#ifndef X3_PIECES
 #define X3_PIECES 2
+#endif
+#ifndef WINO_NS
+#define WINO_NS wino_p2
+#endif
+#include "winograd.h"
 #include "gemm_x3.h"
 #include <type_traits>
 
@@ -24,6 +31,8 @@
 #include <vector>
 
 #include "gemm_tile.h"
+
+namespace WINO_NS {
 
 namespace {
 
@@ -73,8 +82,12 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 __device__ __forceinline__ void st_operand(float* F, u16* P, long rows, int ld, int f, long row, int k, f32x4 v) {
   if (P) {
     const long fs = op_fstride(rows, ld);
+#if X3_PIECES == 2
     const float sc = (reinterpret_cast<const float*>(P) - X3_HDR)[16 + f];
     st_split4h(P, WF * fs, f * fs + op_off(row, k, ld >> 4), v * sc);
+#else
+    st_split4(P, WF * fs, f * fs + op_off(row, k, ld >> 4), v);   // three bf16 pieces: no scale
+#endif
   } else {
     st4(F + ((long)f * rows + row) * ld + k, v);
   }
@@ -1090,6 +1103,8 @@ bool use_x3_wgrad_tl() {
 inline size_t operand_floats(size_t n) { return X3_HDR + (X3_NP * n + 1) / 2; }
 // the planes of a split operand follow its header
 inline u16* op_planes(float* base) { return reinterpret_cast<u16*>(base + X3_HDR); }
+// ... and the GEMM reads its output scale from the headers of both operands (two-piece build only)
+inline const float* op_hdr(const float* base) { return X3_NP == 2 ? base : nullptr; }
 
 // scratch slots and completion counters of absmax_kernel: owned by the library, one set per process (one process
 // per GPU), 64 launches may be in flight at once
@@ -1120,6 +1135,7 @@ AmaxScratch& amax_scratch() {
 // ld); `given`: the caller's amax record of that tensor (otgan_layers.h) -- then only the 36 scales are computed
 void op_scales(const float* x, long rows, int C, long ld, float* base, const float (&gain)[WA], float fold, bool floor_one,
                hipStream_t s, const float* given = nullptr) {
+  if (X3_NP != 2) return;   // three bf16 pieces carry the full exponent range: no scales
   static std::atomic<unsigned> seq{0};
   AmaxArgs a;
   a.x = x; a.rows = rows; a.ld = rows == 1 ? C : ld; a.C = C; a.hdr = base;
@@ -1283,7 +1299,7 @@ int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stri
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.Ap = VP; b.Bp = UP; b.pA = (long)nV; b.pB = (long)nU;
-  if (x3) { b.hdrA = V; b.hdrB = U; }
+  if (x3) { b.hdrA = op_hdr(V); b.hdrB = op_hdr(U); }
   b.A = V; b.B = U; b.C = Mh; b.M = (int)T; b.N = N4; b.K = g.Cin;
   b.lda = g.Cin; b.ldb = g.Cin; b.ldc = N4;
   b.sA = T * g.Cin; b.sB = (long)N4 * g.Cin; b.sC = T * N4;
@@ -1325,7 +1341,7 @@ int wino_dgrad(const WinoGeo& g, const float* dy, const float* weff, long cls_st
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.Ap = VP; b.Bp = UP; b.pA = (long)nV; b.pB = (long)nU;
-  if (x3) { b.hdrA = DV; b.hdrB = U; }
+  if (x3) { b.hdrA = op_hdr(DV); b.hdrB = op_hdr(U); }
   b.A = DV; b.B = U; b.C = Xh; b.M = (int)T; b.N = g.Cin; b.K = K4;
   b.lda = K4; b.ldb = K4; b.ldc = g.Cin;
   b.sA = T * K4; b.sB = (long)g.Cin * K4; b.sC = T * g.Cin;
@@ -1372,7 +1388,7 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
     hipLaunchKernelGGL(wino_outadj_kernel, dim3(op_grid(T, g.Cout / 4), 1, 4), dim3(256), 0, s, da);
     BgArgs b;
     memset(&b, 0, sizeof(b));
-    b.Ap = VP; b.Bp = MP; b.hdrA = Vb; b.hdrB = Mb;
+    b.Ap = VP; b.Bp = MP; b.hdrA = op_hdr(Vb); b.hdrB = op_hdr(Mb);
     b.C = slabs; b.M = g.Cin; b.N = N4; b.K = (int)T;
     b.ldc = N4; b.sC = (long)g.Cin * N4; b.sSplit = (long)WF * g.Cin * N4;
     b.kt_per_split = (int)((T / X3_BK + ns - 1) / ns);
@@ -1514,7 +1530,7 @@ int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.Ap = VP; b.Bp = UP; b.pA = (long)nV; b.pB = (long)nU;
-  if (x3) { b.hdrA = V; b.hdrB = U; }
+  if (x3) { b.hdrA = op_hdr(V); b.hdrB = op_hdr(U); }
   b.A = V; b.B = U; b.C = Mh; b.M = (int)T; b.N = g.Cout; b.K = K4;
   b.lda = K4; b.ldb = K4; b.ldc = g.Cout;
   b.sA = T * K4; b.sB = (long)g.Cout * K4; b.sC = T * g.Cout;
@@ -1558,7 +1574,7 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.Ap = VP; b.Bp = UP; b.pA = (long)nV; b.pB = (long)nU;
-  if (x3) { b.hdrA = DV; b.hdrB = U; }
+  if (x3) { b.hdrA = op_hdr(DV); b.hdrB = op_hdr(U); }
   b.A = DV; b.B = U; b.C = Xh; b.M = (int)T; b.N = K4; b.K = g.Cout;
   b.lda = g.Cout; b.ldb = g.Cout; b.ldc = K4;
   b.sA = T * g.Cout; b.sB = (long)K4 * g.Cout; b.sC = T * K4;
@@ -1607,7 +1623,7 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
     hipLaunchKernelGGL(wino_outadj_kernel, dim3(op_grid(T, g.Cout / 4), 1, 1), dim3(256), 0, s, da);
     BgArgs b;
     memset(&b, 0, sizeof(b));
-    b.Ap = VP; b.Bp = MP; b.hdrA = Vb; b.hdrB = Mb;
+    b.Ap = VP; b.Bp = MP; b.hdrA = op_hdr(Vb); b.hdrB = op_hdr(Mb);
     b.C = slabs; b.M = K4; b.N = g.Cout; b.K = (int)T;
     b.ldc = g.Cout; b.sC = (long)K4 * g.Cout; b.sSplit = (long)WF * K4 * g.Cout;
     b.kt_per_split = (int)((T / X3_BK + ns - 1) / ns);
@@ -1696,7 +1712,7 @@ int wino_up3_fwd(const WinoUp3Geo& g, const float* x, const float* bias, float* 
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.Ap = op_planes(V); b.Bp = op_planes(U); b.pA = (long)nV; b.pB = (long)nU;
-  b.hdrA = V; b.hdrB = U;
+  b.hdrA = op_hdr(V); b.hdrB = op_hdr(U);
   b.A = V; b.B = U; b.C = Mh; b.M = (int)T; b.N = g.Cout; b.K = g.Ceff;
   b.lda = g.Ceff; b.ldb = g.Ceff; b.ldc = g.Cout;
   b.sA = T * g.Ceff; b.sB = (long)g.Cout * g.Ceff; b.sC = T * g.Cout;
@@ -1711,3 +1727,5 @@ int wino_up3_fwd(const WinoUp3Geo& g, const float* x, const float* bias, float* 
   hipLaunchKernelGGL(wino_output_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 1), dim3(256), 0, s, oa);
   return OTGAN_OK;
 }
+
+}  // namespace WINO_NS

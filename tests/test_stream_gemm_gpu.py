@@ -12,8 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 pytestmark = pytest.mark.gpu
 
 
-def _run(mode, path):
-    env = dict(os.environ, OTGAN_X3_STREAM=str(mode))
+def _run(mode, path, **extra):
+    env = dict(os.environ, OTGAN_X3_STREAM=str(mode), **extra)
     subprocess.run([sys.executable, os.path.join(HERE, "stream_gemm_worker.py"), str(path)], check=True, env=env,
                    timeout=600)
     return dict(np.load(path))
@@ -33,3 +33,46 @@ def test_stream_vs_one_tile(tmp_path):
         # a re-associated fp32 sum over K, amplified by the F(4x4,3x3) output transform: 1e-7 .. 3e-6 measured
         # (both variants are asserted against the fp64 oracle at 2e-5 in test_layers_gpu.py)
         assert rel < 1e-5, f"{n}: stream vs one-tile {rel:.2e}"
+
+
+def test_three_bf16_pieces_build(tmp_path):
+    """OTGAN_WINO_PIECES=3 runs the same layers on the second build of winograd.hip (three bf16 pieces per operand
+    element, 24 significand bits, six MFMAs per product, no scales): deterministic, and within the rounding of the
+    default two-piece fp16 operands (22 bits) of it."""
+    p2 = _run(1, tmp_path / "p2.npz")
+    p3 = _run(1, tmp_path / "p3.npz", OTGAN_WINO_PIECES="3")
+    for n in sorted({k.rsplit(".", 1)[0] for k in p3}):
+        assert np.array_equal(p3[n + ".0"], p3[n + ".1"]), n
+        a, b = p2[n + ".0"].astype(np.float64), p3[n + ".0"].astype(np.float64)
+        assert np.isfinite(b).all()
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-5, n
+
+
+def test_split_engines_are_no_worse_than_the_fp32_mfma_engine(tmp_path):
+    """The precision claim of the convolution GEMMs, measured: against an fp64 evaluation of the same layers the
+    default engine (two scaled fp16 pieces, 22 significand bits, three MFMAs per product) and the three-piece bf16
+    engine (24 bits, six MFMAs) are at least as close as the SAME Winograd GEMMs executed with fp32 operands on the
+    fp32 MFMA pipe (OTGAN_WINO_FP32=1) -- their fp32 accumulation, not the operand split, sets the error."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+    import nets_torch as NT
+    from stream_gemm_worker import CASES
+    runs = {"fp16x2": _run(1, tmp_path / "a.npz"), "bf16x3": _run(1, tmp_path / "b.npz", OTGAN_WINO_PIECES="3"),
+            "fp32": _run(1, tmp_path / "c.npz", OTGAN_WINO_FP32="1")}
+    for name, N, H, C, Cout, k, s, up, pre in CASES:
+        gen = torch.Generator().manual_seed(sum(map(ord, name)))
+        mult = 2 if pre == "crelu" else 1
+        x = torch.randn(N, H, H, C, generator=gen).double().requires_grad_(True)
+        V = (torch.randn(k, k, C * mult, Cout, generator=gen) * 0.05).double().requires_grad_(True)
+        g = torch.ones(Cout, dtype=torch.float64)
+        b = torch.zeros(Cout, dtype=torch.float64)
+        y = NT.conv2d([x], {"V": V, "g": g, "b": b}, pre, s, up)
+        dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7)).double()
+        dx, dV = torch.autograd.grad(y, [x, V], dy)
+        for tag, ref in (("y", y), ("dx", dx), ("dV", dV)):
+            ref = ref.detach().numpy()
+            err = {e: float(np.linalg.norm(r[f"{name}.{tag}.0"] - ref) / np.linalg.norm(ref)) for e, r in runs.items()}
+            assert err["fp16x2"] < 2e-5 and err["bf16x3"] < 2e-5, (name, tag, err)
+            assert err["fp16x2"] <= 1.25 * err["fp32"] + 1e-7, (name, tag, err)
+            assert err["bf16x3"] <= 1.25 * err["fp32"] + 1e-7, (name, tag, err)
