@@ -80,6 +80,8 @@ int otgan_absmax_f32(const float* x, long rows, int C, long ld, float* record, v
  * power-of-two-scaled value (hi + lo = 22 significand bits, one scale per Winograd frequency derived from the
  * largest magnitude of the tensor the operand is a transform of): three MFMAs per product, fp32 accumulation,
  * exact rescale on the way out -- measured errors at or below those of the fp32 MFMA chain of the direct path.
+ * OTGAN_WINO_PIECES=3 selects the other build of the same source: three bf16 pieces (24 significand bits), six
+ * MFMAs per product, no scales (read per call; a prepared filter buffer belongs to the mode it was made in).
  * Environment switches (debugging / A-B measurements): OTGAN_DISABLE_WINOGRAD=1,
  * OTGAN_WINO_FP32=1 (Winograd GEMMs on the fp32 engine), OTGAN_WINO_WGRAD_X3=0 (weight-gradient GEMMs on
  * the fp32 engine), OTGAN_WINO_WGRAD_TL=0 (weight-gradient operands from the transposing producers instead
