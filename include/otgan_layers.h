@@ -47,6 +47,10 @@ typedef struct otgan_conv_desc {
    * same x, or dgrad and wgrad on the same dy, computes each record once. */
   const float* x_amax;
   const float* dy_amax;
+  /* forward only: 1 = y += conv(x) + bias instead of y = ...  Implemented for the 3x3 / stride-1 / 16-output growth
+   * layers (dense16 kernels), which is what a dense block split into "block-input convolution + growth chain" needs
+   * (ops.py DenseBlockFunction); any other layer with this flag set is rejected with OTGAN_ERR_ARG. */
+  int y_accumulate;
 } otgan_conv_desc;
 
 /*

@@ -11,7 +11,8 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [("N", c_int), ("H", c_int), ("W", c_int), ("C", c_int), ("ldx", c_int),
                 ("upsample", c_int), ("KH", c_int), ("KW", c_int), ("stride", c_int),
                 ("Cout", c_int), ("ldy", c_int), ("y_coff", c_int), ("preact", c_int),
-                ("list_quads", c_int), ("x_amax", ctypes.c_void_p), ("dy_amax", ctypes.c_void_p)]
+                ("list_quads", c_int), ("x_amax", ctypes.c_void_p), ("dy_amax", ctypes.c_void_p),
+                ("y_accumulate", c_int)]
 
 
 P_DESC = ctypes.POINTER(ConvDesc)

@@ -1576,7 +1576,16 @@ inline WinoGeo wino_geo(const otgan_conv_desc* d) {
 }
 
 // 5x5 stride-2 layers (single-tensor input): four 3x3 sub-convolutions in Winograd form.
+// Wide 3x3 stride-1 layers (the block-input convolution of a DenseNet block: ops.py DenseBlockFunction) take the same
+// three passes with ONE class ("plain", winograd.h): 2.25 instead of 9 products per output.  Narrow ones do not pay
+// (the Winograd-domain result is 2.25 x Cout floats per pixel, written and read once): Cout >= 128.
+inline bool wino_plain3_ok(const otgan_conv_desc* d, const Geo& g) {
+  return d->stride == 1 && d->upsample == 0 && d->KH == 3 && d->KW == 3 && d->C % 4 == 0 && g.Ceff % 32 == 0 &&
+         g.Ceff >= 64 && d->Cout % 32 == 0 && d->Cout >= 128 && d->H % kWinoM == 0 && d->W % kWinoM == 0 && d->ldx % 4 == 0 &&
+         d->ldy % 4 == 0 && d->y_coff % 4 == 0 && WINO(winograd_enabled)() && getenv("OTGAN_DISABLE_WINO_PLAIN3") == nullptr;
+}
 inline bool wino_s2_ok(const otgan_conv_desc* d, const Geo& g) {
+  if (wino_plain3_ok(d, g)) return true;
   return d->stride == 2 && d->upsample == 0 && d->KH == 5 && d->KW == 5 && d->C % 4 == 0 && g.Ceff % 32 == 0 &&
          d->Cout % 4 == 0 && d->H % (2 * kWinoM) == 0 && d->W % (2 * kWinoM) == 0 && d->ldx % 4 == 0 && d->ldy % 4 == 0 &&
          d->y_coff % 4 == 0 && WINO(winograd_enabled)();
@@ -1586,8 +1595,10 @@ inline WinoS2Geo wino_s2_geo(const otgan_conv_desc* d, const Geo& g) {
   w.N = d->N; w.H = d->H; w.W = d->W; w.C = d->C; w.Ceff = g.Ceff; w.doubled = doubled_act(d->preact) ? 1 : 0;
   w.act = act_kind(d->preact); w.ldx = d->ldx; w.Cout = d->Cout; w.ldy = d->ldy; w.y_coff = d->y_coff;
   w.x_amax = d->x_amax; w.dy_amax = d->dy_amax;
+  w.plain = d->stride == 1 ? 1 : 0;
   return w;
 }
+inline double wino_s2_blocks(const WinoS2Geo& w) { return w.plain ? kWinoFreq : kWinoS2Blocks; }
 
 // 3x3 on a 2x upsampled image with CReLU (DenseNet generator transitions): forward through Winograd when the caller
 // hands over filters prepared from the UN-folded weights (otgan_conv2d_filter_bytes(d, 2) > 0)
@@ -2000,6 +2011,9 @@ static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32
   if (rc) return rc;
   OTGAN_CHECK_ARG(x && wT && y, "null pointer");
   hipStream_t s = (hipStream_t)stream;
+  const bool growth16 = d->Cout == 16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->upsample == 0 && d->C % 8 == 0 &&
+                        d->ldx % 4 == 0 && aligned16(x) && aligned16(wT) && aligned16(cmap) && dense16_enabled();
+  OTGAN_CHECK_ARG(!d->y_accumulate || growth16, "y_accumulate: only the 3x3 stride-1 16-output growth layers accumulate");
   GatherA ga;
   ClassTab ct;
   WeightB wb;
@@ -2017,7 +2031,7 @@ static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32
   if (wino_s2_ok(d, g) && cmap == nullptr && aligned16(x) && aligned16(wT) && aligned16(y) && aligned16(bias) &&
       aligned16(workspace) && workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 0)) {
     const WinoS2Geo w = wino_s2_geo(d, g);
-    ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * kWinoS2Blocks * (double)wino_s2_tiles(w) * g.Ceff * d->Cout, 0.0, s);
+    ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * wino_s2_blocks(w) * (double)wino_s2_tiles(w) * g.Ceff * d->Cout, 0.0, s);
     rc = WINO(wino_s2_fwd)(w, x, wT, bias, y, (float*)workspace, s, filters);
     OTGAN_CHECK_LAUNCH("conv2d fwd (winograd, stride 2)");
     return rc;
@@ -2115,15 +2129,14 @@ static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32
     OTGAN_CHECK_LAUNCH("conv2d fwd (few outputs)");
     return OTGAN_OK;
   }
-  if (d->Cout == 16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->upsample == 0 && d->C % 8 == 0 &&
-      d->ldx % 4 == 0 && aligned16(x) && aligned16(wT) && aligned16(cmap) && dense16_enabled()) {
+  if (growth16) {
     // DenseNet growth layer: LDS-free streaming MFMA kernel (dense16.hip)
     Dense16Geo dg;
     dg.N = d->N; dg.H = d->H; dg.W = d->W; dg.logH = ilog2_exact(d->H); dg.logW = ilog2_exact(d->W);
     dg.C = d->C; dg.Ceff = g.Ceff; dg.doubled = doubled_act(d->preact) ? 1 : 0;
     dg.act = act_kind(d->preact); dg.ldx = d->ldx; dg.cmap = cmap;
     ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * ga.Mtot * (double)Ktot * d->Cout, 0.0, s);
-    rc = dense16_fwd(dg, x, wT, bias, y, d->ldy, d->y_coff, s);
+    rc = dense16_fwd(dg, x, wT, bias, y, d->ldy, d->y_coff, d->y_accumulate, s);
     OTGAN_CHECK_LAUNCH("conv2d fwd (dense16)");
     return rc;
   }
@@ -2239,7 +2252,7 @@ static int conv2d_dgrad_impl(const otgan_conv_desc* d, const float* dy, const fl
   if (wino_s2_ok(d, g) && inv == nullptr && lddx % 4 == 0 && aligned16(dy) && aligned16(w) && aligned16(dx) &&
       aligned16(x) && aligned16(workspace) && workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 1)) {
     const WinoS2Geo wg = wino_s2_geo(d, g);
-    ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * kWinoS2Blocks * (double)wino_s2_tiles(wg) * g.Ceff * d->Cout, 0.0, s);
+    ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * wino_s2_blocks(wg) * (double)wino_s2_tiles(wg) * g.Ceff * d->Cout, 0.0, s);
     rc = WINO(wino_s2_dgrad)(wg, dy, w, x, dx, lddx, accumulate, (float*)workspace, s, filters);
     OTGAN_CHECK_LAUNCH("conv2d dgrad (winograd, stride 2)");
     return rc;
@@ -2374,7 +2387,7 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
   if (wino_s2_ok(d, g) && cmap == nullptr && aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace) &&
       workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 2)) {
     const WinoS2Geo wg = wino_s2_geo(d, g);
-    ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * kWinoS2Blocks * (double)wino_s2_tiles(wg) * g.Ceff * d->Cout, 0.0, s);
+    ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * wino_s2_blocks(wg) * (double)wino_s2_tiles(wg) * g.Ceff * d->Cout, 0.0, s);
     rc = WINO(wino_s2_wgrad)(wg, x, dy, dw, (float*)workspace, s);
     OTGAN_CHECK_LAUNCH("conv2d wgrad (winograd, stride 2)");
     return rc;

@@ -31,6 +31,7 @@ struct FwdArgs {
   const float* bias;
   float* y;
   int M, H, W, logW, ldx, C, Ceff, doubled, K, ldy, coff;
+  int accumulate;   // y += instead of y = (the growth layers of a split dense block add onto the block-input convolution's result)
 };
 
 template <int ACT>
@@ -187,7 +188,10 @@ __global__ __launch_bounds__(256) void dense16_fwd_kernel(FwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const long m = (long)(tile0 + t) * 16 + 4 * g + r;
-      if (m < a.M) a.y[m * a.ldy + a.coff + p] = acc[t][r] + b;
+      if (m < a.M) {
+        float* yp = a.y + m * a.ldy + a.coff + p;
+        *yp = acc[t][r] + b + (a.accumulate ? *yp : 0.f);
+      }
     }
 }
 
@@ -217,6 +221,7 @@ struct FwdLdsArgs {
   float* y;
   int N, H, W, logW, ldx, C, Ceff, doubled, K, ldy, coff;
   int TR, RS;  // tile rows, LDS row stride in pixels
+  int accumulate;
 };
 
 constexpr int kPixQuads = 10;  // LDS quads (16 B) per pixel
@@ -390,7 +395,8 @@ __global__ __launch_bounds__(256, 2) void dense16_fwd_lds_kernel(FwdLdsArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const long m = m0 + (wave * PT + t) * 16 + 4 * g + r;
-      a.y[m * a.ldy + a.coff + p] = acc[t][r] + b;
+      float* yp = a.y + m * a.ldy + a.coff + p;
+      *yp = acc[t][r] + b + (a.accumulate ? *yp : 0.f);
     }
 }
 
@@ -588,7 +594,8 @@ __global__ __launch_bounds__(256, 2) void dense16_fwd_x3_kernel(FwdLdsArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const long m = m0 + (wave * PT + t) * 16 + 4 * g + r;
-      a.y[m * a.ldy + a.coff + p] = acc[t][r] + b;
+      float* yp = a.y + m * a.ldy + a.coff + p;
+      *yp = acc[t][r] + b + (a.accumulate ? *yp : 0.f);
     }
 }
 
@@ -935,8 +942,9 @@ bool dense16_enabled() {
 }
 
 int dense16_fwd(const Dense16Geo& g, const float* x, const float* wT, const float* bias, float* y,
-                int ldy, int coff, hipStream_t s) {
+                int ldy, int coff, int accumulate, hipStream_t s) {
   FwdArgs a;
+  a.accumulate = accumulate;
   a.x = x; a.cmap = g.cmap; a.wT = wT; a.bias = bias; a.y = y;
   a.M = g.N * g.H * g.W;
   a.H = g.H; a.W = g.W; a.logW = ilog2i(g.W);
@@ -951,6 +959,7 @@ int dense16_fwd(const Dense16Geo& g, const float* x, const float* wT, const floa
     int PT = g.H * g.W >= 256 ? 4 : g.H * g.W / 64;
     while (PT > 1 && (long)g.N * g.H * g.W / (64 * PT) < 512) PT >>= 1;
     FwdLdsArgs l;
+    l.accumulate = accumulate;
     l.x = x; l.cmap = g.cmap; l.wT = wT; l.bias = bias; l.y = y;
     l.N = g.N; l.H = g.H; l.W = g.W; l.logW = ilog2i(g.W); l.ldx = g.ldx; l.C = g.C; l.Ceff = g.Ceff;
     l.doubled = g.doubled; l.K = 9 * g.Ceff; l.ldy = ldy; l.coff = coff;

@@ -45,9 +45,16 @@ struct WinoS2Geo {
   int Cout, ldy, y_coff;
   const float* x_amax = nullptr;
   const float* dy_amax = nullptr;
+  // 1: a 3x3 stride-1 layer instead (the block-input convolution of a DenseNet block, ops.py DenseBlockFunction):
+  // ONE class on the full H x W grid (multiples of 4), taps taken as they are, nothing structurally zero;
+  // wT: [Cout][9*Ceff], w: [9][Ceff][Cout].  Same kernels, same three passes.
+  int plain = 0;
 };
-inline long wino_s2_tiles(const WinoS2Geo& g) { return (long)g.N * (g.H / (2 * kWinoM)) * (g.W / (2 * kWinoM)); }
-// wT: [Cout][25*Ceff];  w: HWIO [25][Ceff][Cout];  single-tensor inputs only (default channel map)
+inline int wino_s2_classes(const WinoS2Geo& g) { return g.plain ? 1 : 4; }
+inline int wino_s2_out_h(const WinoS2Geo& g) { return g.plain ? g.H : g.H / 2; }
+inline int wino_s2_out_w(const WinoS2Geo& g) { return g.plain ? g.W : g.W / 2; }
+inline long wino_s2_tiles(const WinoS2Geo& g) { return (long)g.N * (wino_s2_out_h(g) / kWinoM) * (wino_s2_out_w(g) / kWinoM); }
+// wT: [Cout][25*Ceff];  w: HWIO [25][Ceff][Cout];  single-tensor inputs only (default channel map: [act(x), act(-x)])
 
 // ---- 3x3 convolution of a 2x nearest-neighbour upsampled image with a doubled ReLU pre-activation ([relu(x),
 // relu(-x)], the reference concatenates a list input BEFORE the activation here): the DenseNet generator's

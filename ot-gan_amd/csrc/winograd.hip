@@ -608,12 +608,13 @@ __device__ __forceinline__ int s2_tap(int parity, int i) {   // filter tap of wi
 }
 
 // forward filters: U[f][co][cls*Ceff + ce] from wT[co][(kh*5+kw)*Ceff + ce]
+// (plain: a 3x3 stride-1 layer -- one class, wT[co][(i*3+j)*Ceff + ce], every block present)
 __global__ __launch_bounds__(256) void wino_s2_filter_fwd_kernel(const float* __restrict__ wT, int Ceff, int Cout,
-                                                               float* __restrict__ U, u16* P) {
-  const int c4n = Ceff >> 2;
+                                                               float* __restrict__ U, u16* P, int plain) {
+  const int c4n = Ceff >> 2, ncls = plain ? 1 : 4, kk = plain ? 3 : 5;
   long row;
   int k4;
-  if (!op_thread(P != nullptr, Cout, 4 * c4n, row, k4)) return;
+  if (!op_thread(P != nullptr, Cout, ncls * c4n, row, k4)) return;
   const int co = (int)row, cls = k4 / c4n, ce = (k4 % c4n) * 4;
   const int pi = cls >> 1, pj = cls & 1;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -622,21 +623,23 @@ __global__ __launch_bounds__(256) void wino_s2_filter_fwd_kernel(const float* __
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int kh = s2_tap(pi, i), kw = s2_tap(pj, j);
-      g[i][j] = (kh >= 0 && kw >= 0) ? ld4(wT + ((long)co * 25 + kh * 5 + kw) * Ceff + ce) : zero;
+      const int kh = plain ? i : s2_tap(pi, i), kw = plain ? j : s2_tap(pj, j);
+      g[i][j] = (kh >= 0 && kw >= 0) ? ld4(wT + ((long)co * kk * kk + kh * kk + kw) * Ceff + ce) : zero;
     }
   tf_filter(g, [&](int f, f32x4 v) {
-    if (s2_present(cls, f, 0))   // absent blocks are never read by the GEMM
-      st_operand(U, P, Cout, 4 * Ceff, f, co, cls * Ceff + ce, v);
+    if (plain || s2_present(cls, f, 0))   // absent blocks are never read by the GEMM
+      st_operand(U, P, Cout, ncls * Ceff, f, co, cls * Ceff + ce, v);
   });
 }
 
 // backward filters (flipped): U'[f][cls*Ceff + ce][co] from w[kh*5+kw][ce][co]
 __global__ __launch_bounds__(256) void wino_s2_filter_bwd_kernel(const float* __restrict__ w, int Ceff, int Cout,
-                                                               float* __restrict__ U, u16* P) {
+                                                               float* __restrict__ U, u16* P, int plain) {
   long r;                               // cls*Ceff + ce
   int k4;
-  if (!op_thread(P != nullptr, 4L * Ceff, Cout >> 2, r, k4)) return;
+  const long rows = (plain ? 1L : 4L) * Ceff;
+  const int kk = plain ? 3 : 5;
+  if (!op_thread(P != nullptr, rows, Cout >> 2, r, k4)) return;
   const int co = k4 * 4;
   const int ce = (int)(r % Ceff), cls = (int)(r / Ceff);
   const int pi = cls >> 1, pj = cls & 1;
@@ -646,24 +649,26 @@ __global__ __launch_bounds__(256) void wino_s2_filter_bwd_kernel(const float* __
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int kh = s2_tap(pi, 2 - i), kw = s2_tap(pj, 2 - j);
-      g[i][j] = (kh >= 0 && kw >= 0) ? ld4(w + ((long)(kh * 5 + kw) * Ceff + ce) * Cout + co) : zero;
+      const int kh = plain ? 2 - i : s2_tap(pi, 2 - i), kw = plain ? 2 - j : s2_tap(pj, 2 - j);
+      g[i][j] = (kh >= 0 && kw >= 0) ? ld4(w + ((long)(kh * kk + kw) * Ceff + ce) * Cout + co) : zero;
     }
-  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, 4L * Ceff, Cout, f, r, co, v); });
+  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, rows, Cout, f, r, co, v); });
 }
 
 // dw[kh*5+kw][ce][co] = (G^T dU G)[i][j] of the tap's class; dU[f] = sum of slab[split][f][cls*Ceff+ce][co]
 __global__ __launch_bounds__(256) void wino_s2_filter_adj_kernel(const float* __restrict__ slabs, int nsplit,
                                                                long split_stride, int Ceff, int Cout,
-                                                               float* __restrict__ dw) {
+                                                               float* __restrict__ dw, int plain) {
   const int c4n = Cout >> 2;
+  const long rows = (plain ? 1L : 4L) * Ceff;
+  const int kk = plain ? 3 : 5;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= 4L * Ceff * c4n) return;
+  if (idx >= rows * c4n) return;
   const int co = (int)(idx % c4n) * 4;
   const long r = idx / c4n;
   const int ce = (int)(r % Ceff), cls = (int)(r / Ceff);
   const int pi = cls >> 1, pj = cls & 1;
-  const long fs = 4L * Ceff * Cout;
+  const long fs = rows * Cout;
   const float* src = slabs + r * Cout + co;
   f32x4 dg[3][3];
   tf_filter_adj(
@@ -671,7 +676,7 @@ __global__ __launch_bounds__(256) void wino_s2_filter_adj_kernel(const float* __
 #pragma unroll
         for (int i = 0; i < WA; ++i) {
           f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
-          if (s2_present(cls, i * WA + j, 0)) {
+          if (plain || s2_present(cls, i * WA + j, 0)) {
             sacc = ld4(src + (i * WA + j) * fs);
             for (int k = 1; k < nsplit; ++k) sacc += ld4(src + k * split_stride + (i * WA + j) * fs);
           }
@@ -683,8 +688,8 @@ __global__ __launch_bounds__(256) void wino_s2_filter_adj_kernel(const float* __
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int kh = s2_tap(pi, i), kw = s2_tap(pj, j);
-      if (kh >= 0 && kw >= 0) st4(dw + ((long)(kh * 5 + kw) * Ceff + ce) * Cout + co, dg[i][j]);
+      const int kh = plain ? i : s2_tap(pi, i), kw = plain ? j : s2_tap(pj, j);
+      if (kh >= 0 && kw >= 0) st4(dw + ((long)(kh * kk + kw) * Ceff + ce) * Cout + co, dg[i][j]);
     }
 }
 
@@ -699,6 +704,7 @@ struct OutS2Args {
   int ldm;              // 4*Ceff
   const float* Xh;
   int accumulate;
+  int plain;            // one class, nothing structurally zero (a 3x3 stride-1 layer)
 };
 // (A^T M A) of the class's M, rows i0 .. i0+1 only (two output rows at a time keep the register count down)
 // DOUBLED (CReLU / CELU): a thread owns TWO channels (both halves of each): the two 36-value column passes of four
@@ -716,6 +722,7 @@ __global__ __launch_bounds__(256) void wino_s2_output_kernel(OutS2Args a) {
   const int tb = (int)(t % a.TW), ta = (int)((t / a.TW) % a.TH);
   const long n = t / ((long)a.TW * a.TH);
   const int cls = blockIdx.z;
+  const int pcls = a.plain ? 3 : cls;   // class 3 has no absent frequencies
   const WView dv = a.dx[cls];
   const View xv = a.x[cls];
   const float* in = a.Xh + t * a.ldm + (long)cls * a.Ceff + c;
@@ -728,13 +735,13 @@ __global__ __launch_bounds__(256) void wino_s2_output_kernel(OutS2Args a) {
   for (int j = 0; j < WA; ++j) {
     VT col[WA], o[WM];
 #pragma unroll
-    for (int i = 0; i < WA; ++i) col[i] = s2_present(cls, i * WA + j, WA - 1) ? ldv(in + (i * WA + j) * fs) : zero;
+    for (int i = 0; i < WA; ++i) col[i] = s2_present(pcls, i * WA + j, WA - 1) ? ldv(in + (i * WA + j) * fs) : zero;
     at1(col, o);
 #pragma unroll
     for (int i = 0; i < WM; ++i) Sp[i][j] = o[i];
     if (DOUBLED) {
 #pragma unroll
-      for (int i = 0; i < WA; ++i) col[i] = s2_present(cls, i * WA + j, WA - 1) ? ldv(in + a.C + (i * WA + j) * fs) : zero;
+      for (int i = 0; i < WA; ++i) col[i] = s2_present(pcls, i * WA + j, WA - 1) ? ldv(in + a.C + (i * WA + j) * fs) : zero;
       at1(col, o);
 #pragma unroll
       for (int i = 0; i < WM; ++i) Sn[DOUBLED ? i : 0][j] = o[i];
@@ -1447,9 +1454,21 @@ void parity_views(int H, int W, P base, int ld, V (&v)[4]) {
   }
 }
 
+// the views a layer's passes transform: the four parity sub-images of a strided layer, the image itself of a plain one
+template <class V, class P>
+void s2_views(const WinoS2Geo& g, P base, int ld, V (&v)[4]) {
+  if (!g.plain) return parity_views(g.H, g.W, base, ld, v);
+  v[0].p = base;
+  v[0].sn = (long)g.H * g.W * ld;
+  v[0].sh = (long)g.W * ld;
+  v[0].sw = ld;
+}
+inline int s2_k(const WinoS2Geo& g) { return wino_s2_classes(g) * g.Ceff; }
+inline int s2_taps(const WinoS2Geo& g) { return g.plain ? 9 : 25; }
+
 int s2_wgrad_splits(const WinoS2Geo& g) {
   const long T = wino_s2_tiles(g);
-  const int blocks = ((4 * g.Ceff + 127) / 128) * ((g.Cout + 127) / 128) * WF;
+  const int blocks = ((s2_k(g) + 127) / 128) * ((g.Cout + 127) / 128) * WF;
   int ns = (1024 + blocks - 1) / blocks;
   if (ns > 8) ns = 8;
   const int nkt = (int)((T + Cfg::BK - 1) / Cfg::BK);
@@ -1464,13 +1483,13 @@ void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, u16* VP, h
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
   ia.s2_skip = -1;
-  parity_views(g.H, g.W, x, g.ldx, ia.v);
+  s2_views(g, x, g.ldx, ia.v);
   for (int cls = 0; cls < 4; ++cls) ia.coff[cls] = cls * g.Ceff;
-  ia.H = g.H / 2; ia.W = g.W / 2; ia.TH = g.H / (2 * WM); ia.TW = g.W / (2 * WM); ia.C = g.C; ia.T = T; ia.ldv = 4 * g.Ceff;
+  ia.H = wino_s2_out_h(g); ia.W = wino_s2_out_w(g); ia.TH = ia.H / WM; ia.TW = ia.W / WM; ia.C = g.C; ia.T = T; ia.ldv = s2_k(g);
   ia.V = V;
   ia.P = VP;
-  ia.s2_skip = 0;
-  const dim3 grid(op_grid(T, g.C / 4), g.doubled ? 2 : 1, 4), blk(256);
+  ia.s2_skip = g.plain ? -1 : 0;
+  const dim3 grid(op_grid(T, g.C / 4), g.doubled ? 2 : 1, wino_s2_classes(g)), blk(256);
   if (g.doubled) {
     if (g.act == 2) hipLaunchKernelGGL((wino_input_kernel<2, true>), grid, blk, 0, s, ia);
     else hipLaunchKernelGGL((wino_input_kernel<1, true>), grid, blk, 0, s, ia);
@@ -1482,13 +1501,13 @@ void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, u16* VP, h
 }  // namespace
 
 size_t wino_s2_fwd_ws_floats(const WinoS2Geo& g) {
-  const size_t T = (size_t)wino_s2_tiles(g), K4 = 4 * (size_t)g.Ceff;
+  const size_t T = (size_t)wino_s2_tiles(g), K4 = (size_t)s2_k(g);
   return operand_floats(op_elems(T, K4)) + operand_floats(op_elems(T, g.Cout)) +
          operand_floats(std::max(op_elems(g.Cout, K4), op_elems(K4, g.Cout))) + WF * T * K4 + x3_stream_floats();
 }
 size_t wino_s2_dgrad_ws_floats(const WinoS2Geo& g) { return wino_s2_fwd_ws_floats(g); }
 size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g) {
-  const size_t T = (size_t)wino_s2_tiles(g), K4 = 4 * (size_t)g.Ceff;
+  const size_t T = (size_t)wino_s2_tiles(g), K4 = (size_t)s2_k(g);
   const size_t Tp = (T + 63) / 64 * 64;
   const int ns = std::max(s2_wgrad_splits(g), x3_wgrad_splits((int)K4, g.Cout, (long)Tp));
   return operand_floats(std::max(op_elems(K4, Tp), op_elems(Tp, K4))) + operand_floats(std::max(op_elems(g.Cout, Tp), op_elems(Tp, g.Cout))) +
@@ -1496,19 +1515,19 @@ size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g) {
 }
 
 size_t wino_s2_filter_floats(const WinoS2Geo& g, int which) {
-  return which == 0 ? operand_floats(op_elems(g.Cout, 4 * g.Ceff)) : operand_floats(op_elems(4 * g.Ceff, g.Cout));
+  return which == 0 ? operand_floats(op_elems(g.Cout, s2_k(g))) : operand_floats(op_elems(s2_k(g), g.Cout));
 }
 int wino_s2_prepare_filters(const WinoS2Geo& g, int which, const float* w, float* out, hipStream_t s) {
   if (which == 0) {
     const bool x3 = use_x3() && g.Ceff % X3_BK == 0;
-    if (x3) op_scales(w, 1, 25 * g.Ceff * g.Cout, 0, out, kGainG, 1.f, false, s);
-    hipLaunchKernelGGL(wino_s2_filter_fwd_kernel, dim3(op_grid(g.Cout, g.Ceff)), dim3(256), 0, s, w, g.Ceff, g.Cout, out,
-                       x3 ? op_planes(out) : nullptr);
+    if (x3) op_scales(w, 1, s2_taps(g) * g.Ceff * g.Cout, 0, out, kGainG, 1.f, false, s);
+    hipLaunchKernelGGL(wino_s2_filter_fwd_kernel, dim3(op_grid(g.Cout, s2_k(g) / 4)), dim3(256), 0, s, w, g.Ceff, g.Cout, out,
+                       x3 ? op_planes(out) : nullptr, g.plain);
   } else {
     const bool x3 = use_x3() && g.Cout % X3_BK == 0;
-    if (x3) op_scales(w, 1, 25 * g.Ceff * g.Cout, 0, out, kGainG, 1.f, false, s);
-    hipLaunchKernelGGL(wino_s2_filter_bwd_kernel, dim3(op_grid(4L * g.Ceff, g.Cout / 4)), dim3(256), 0, s, w, g.Ceff,
-                       g.Cout, out, x3 ? op_planes(out) : nullptr);
+    if (x3) op_scales(w, 1, s2_taps(g) * g.Ceff * g.Cout, 0, out, kGainG, 1.f, false, s);
+    hipLaunchKernelGGL(wino_s2_filter_bwd_kernel, dim3(op_grid(s2_k(g), g.Cout / 4)), dim3(256), 0, s, w, g.Ceff,
+                       g.Cout, out, x3 ? op_planes(out) : nullptr, g.plain);
   }
   return OTGAN_OK;
 }
@@ -1516,7 +1535,7 @@ int wino_s2_prepare_filters(const WinoS2Geo& g, int which, const float* w, float
 int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float* bias, float* y, float* ws,
                 hipStream_t s, const float* prep) {
   const long T = wino_s2_tiles(g);
-  const int K4 = 4 * g.Ceff;
+  const int K4 = s2_k(g);
   const bool x3 = use_x3() && g.Ceff % X3_BK == 0;
   const size_t nV = op_elems(T, K4), nU = op_elems(g.Cout, K4);
   float* V = ws;                              // [WF][T][4*Ceff]
@@ -1536,12 +1555,12 @@ int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float
   b.sA = T * K4; b.sB = (long)g.Cout * K4; b.sC = T * g.Cout;
   b.tiles_m = (int)((T + Cfg::BM - 1) / Cfg::BM); b.tiles_n = (g.Cout + Cfg::BN - 1) / Cfg::BN;
   b.kt_per_split = (K4 + Cfg::BK - 1) / Cfg::BK;
-  b.seg_mode = 1; b.seg_len = g.Ceff; b.seg_skip = 0;
+  b.seg_mode = g.plain ? 0 : 1; b.seg_len = g.Ceff; b.seg_skip = 0;
   b.sk_partial = x3_stream_area(ws, wino_s2_fwd_ws_floats(g));
   launch_bgemm<false>(b, 1, s);
   OutArgs oa;
   memset(&oa, 0, sizeof(oa));
-  const int OH = g.H / 2, OW = g.W / 2;
+  const int OH = wino_s2_out_h(g), OW = wino_s2_out_w(g);
   oa.v[0].p = y + g.y_coff; oa.v[0].sn = (long)OH * OW * g.ldy; oa.v[0].sh = (long)OW * g.ldy; oa.v[0].sw = g.ldy;
   oa.TH = OH / WM; oa.TW = OW / WM; oa.C = g.Cout; oa.T = T; oa.ldm = g.Cout; oa.Mh = Mh; oa.bias = bias;
 
@@ -1552,8 +1571,8 @@ int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float
 int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const float* x, float* dx, int lddx,
                   int accumulate, float* ws, hipStream_t s, const float* prep) {
   const long T = wino_s2_tiles(g);
-  const int K4 = 4 * g.Ceff;
-  const int OH = g.H / 2, OW = g.W / 2;
+  const int K4 = s2_k(g);
+  const int OH = wino_s2_out_h(g), OW = wino_s2_out_w(g);
   const bool x3 = use_x3() && g.Cout % X3_BK == 0;
   const size_t nV = op_elems(T, g.Cout), nU = op_elems(K4, g.Cout);
   float* DV = ws;                             // [WF][T][Cout]
@@ -1580,16 +1599,17 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   b.sA = T * g.Cout; b.sB = (long)K4 * g.Cout; b.sC = T * K4;
   b.tiles_m = (int)((T + Cfg::BM - 1) / Cfg::BM); b.tiles_n = (K4 + Cfg::BN - 1) / Cfg::BN;
   b.kt_per_split = (g.Cout + Cfg::BK - 1) / Cfg::BK;
-  b.seg_mode = 2; b.seg_len = g.Ceff; b.seg_skip = WA - 1;
+  b.seg_mode = g.plain ? 0 : 2; b.seg_len = g.Ceff; b.seg_skip = WA - 1;
   b.sk_partial = x3_stream_area(ws, wino_s2_dgrad_ws_floats(g));
   launch_bgemm<false>(b, 1, s);
   OutS2Args oa;
   memset(&oa, 0, sizeof(oa));
-  parity_views(g.H, g.W, dx, lddx, oa.dx);
-  parity_views(g.H, g.W, x, g.ldx, oa.x);
+  s2_views(g, dx, lddx, oa.dx);
+  s2_views(g, x, g.ldx, oa.x);
+  oa.plain = g.plain;
   oa.TH = OH / WM; oa.TW = OW / WM; oa.C = g.C; oa.Ceff = g.Ceff; oa.T = T; oa.ldm = K4; oa.Xh = Xh;
   oa.accumulate = accumulate;
-  const dim3 grid(grid1(T * (g.C / (g.doubled ? 2 : 4))), 1, 4), blk(256);
+  const dim3 grid(grid1(T * (g.C / (g.doubled ? 2 : 4))), 1, wino_s2_classes(g)), blk(256);
   if (g.doubled) {
     if (g.act == 2) hipLaunchKernelGGL((wino_s2_output_kernel<2, true>), grid, blk, 0, s, oa);
     else hipLaunchKernelGGL((wino_s2_output_kernel<1, true>), grid, blk, 0, s, oa);
@@ -1601,8 +1621,8 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
 
 int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw, float* ws, hipStream_t s) {
   const long T = wino_s2_tiles(g);
-  const int K4 = 4 * g.Ceff;
-  const int OH = g.H / 2, OW = g.W / 2;
+  const int K4 = s2_k(g);
+  const int OH = wino_s2_out_h(g), OW = wino_s2_out_w(g);
   if (use_x3_wgrad_tl() && T % 32 == 0 && g.Ceff % 32 == 0 && g.Cout % 32 == 0) {
     // the forward operand V[tile][4 Ceff] (absent (class, frequency) blocks unwritten: their rows of the result are
     // masked by the adjoint filter transform) and the dgrad operand dM[tile][Cout]: t-leading GEMM over the tiles
@@ -1627,11 +1647,11 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
     b.C = slabs; b.M = K4; b.N = g.Cout; b.K = (int)T;
     b.ldc = g.Cout; b.sC = (long)K4 * g.Cout; b.sSplit = (long)WF * K4 * g.Cout;
     b.kt_per_split = (int)((T / X3_BK + ns - 1) / ns);
-    b.seg_mode = 3; b.seg_len = g.Ceff; b.seg_skip = 0;
+    b.seg_mode = g.plain ? 0 : 3; b.seg_len = g.Ceff; b.seg_skip = 0;
     b.sk_partial = x3_stream_area(ws, wino_s2_wgrad_ws_floats(g));
     launch_bgemm_tl(b, ns, s);
-    hipLaunchKernelGGL(wino_s2_filter_adj_kernel, dim3(grid1(4L * g.Ceff * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
-                       (long)WF * K4 * g.Cout, g.Ceff, g.Cout, dw);
+    hipLaunchKernelGGL(wino_s2_filter_adj_kernel, dim3(grid1((long)K4 * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
+                       (long)WF * K4 * g.Cout, g.Ceff, g.Cout, dw, g.plain);
     return OTGAN_OK;
   }
   const int ns = s2_wgrad_splits(g);
@@ -1654,10 +1674,10 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
   b.tiles_m = (K4 + Cfg::BM - 1) / Cfg::BM; b.tiles_n = (g.Cout + Cfg::BN - 1) / Cfg::BN;
   const int nkt = (int)((T + Cfg::BK - 1) / Cfg::BK);
   b.kt_per_split = (nkt + ns - 1) / ns;
-  b.seg_mode = 3; b.seg_len = g.Ceff; b.seg_skip = 0;
+  b.seg_mode = g.plain ? 0 : 3; b.seg_len = g.Ceff; b.seg_skip = 0;
   launch_bgemm<true>(b, ns, s);
-  hipLaunchKernelGGL(wino_s2_filter_adj_kernel, dim3(grid1(4L * g.Ceff * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
-                     (long)WF * K4 * g.Cout, g.Ceff, g.Cout, dw);
+  hipLaunchKernelGGL(wino_s2_filter_adj_kernel, dim3(grid1((long)K4 * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
+                     (long)WF * K4 * g.Cout, g.Ceff, g.Cout, dw, g.plain);
   return OTGAN_OK;
 }
 

@@ -317,6 +317,70 @@ def dense_op(x, V, g, b, preact=0, segs=None):
     return y.view(N, -1)
 
 
+def absmax_record_strided(t_ptr, rows, C, ld, device):
+    """amax record of a channel slice [rows][C] (row stride ld floats) of a larger NHWC buffer."""
+    rec = torch.empty(128, dtype=torch.float32, device=device)
+    _lib.check(_lib.lib().otgan_absmax_f32(t_ptr, rows, C, ld, rec.data_ptr(), _lib.stream_ptr()), "absmax")
+    return rec
+
+
+def _input_row_order(segs0, preact, device):
+    """Effective-channel rows of the block input inside a growth layer's weight tensor, in the order the
+    single-tensor convolution kernels use ([act(x_all), act(-x_all)]): the reference interleaves per list element
+    ([x0, -x0, x1, -x1, ...], nn.py:198-200).  None = already in that order."""
+    segs0 = tuple(int(c) for c in segs0)
+    if preact not in DOUBLED or len(segs0) <= 1:
+        return None
+    key = ("rows", segs0, device)
+    hit = _map_cache.get(key)
+    if hit is None:
+        pos, neg, off = [], [], 0
+        for c in segs0:
+            pos += [2 * off + i for i in range(c)]
+            neg += [2 * off + c + i for i in range(c)]
+            off += c
+        hit = torch.tensor(pos + neg, dtype=torch.int64, device=device)
+        _map_cache[key] = hit
+    return hit
+
+
+_block_cache = OrderedDict()   # id(V of layer 0) -> (per-layer normalised weights it was made from, value)
+
+
+def _split_block_weights(Vs, per_layer, Ceff0, F, rows, desc_in):
+    """Operands of a dense block computed as "block-input convolution + growth chain": the rows of every layer's
+    normalised weights that multiply the block input, gathered into ONE 3x3 convolution C0 -> L*F (wT_in
+    [L*F][9*Ceff0], w_in [9*Ceff0][L*F], Winograd-domain filters), and per layer the remaining rows (the earlier
+    growth layers' outputs) as contiguous tensors.  Cached for as long as the per-layer normalised weights are."""
+    key = id(Vs[0])
+    ws = [pl[0] for pl in per_layer]
+    hit = _block_cache.get(key)
+    if hit is not None and len(hit[0]) == len(ws) and all(a is b for a, b in zip(hit[0], ws)):
+        _block_cache.move_to_end(key)
+        return hit[1]
+    L = len(per_layer)
+    w_in = torch.cat([pl[0].view(9, -1, F)[:, :Ceff0, :] for pl in per_layer], dim=2)        # [9][Ceff0][L*F]
+    wT_in = torch.cat([pl[1].view(F, 9, -1)[:, :, :Ceff0] for pl in per_layer], dim=0)       # [L*F][9][Ceff0]
+    if rows is not None:
+        w_in = w_in.index_select(1, rows)
+        wT_in = wT_in.index_select(2, rows)
+    w_in = w_in.contiguous().view(9 * Ceff0, L * F)
+    wT_in = wT_in.contiguous().view(L * F, 9 * Ceff0)
+    w_g = [None] + [per_layer[k][0].view(9, -1, F)[:, Ceff0:, :].contiguous().view(-1, F) for k in range(1, L)]
+    wT_g = [None] + [per_layer[k][1].view(F, 9, -1)[:, :, Ceff0:].contiguous().view(F, -1) for k in range(1, L)]
+    val = {"w_in": w_in, "wT_in": wT_in, "w_g": w_g, "wT_g": wT_g,
+           "fwd": prepare_filters(desc_in, 0, wT_in), "bwd": None, "bwd_done": False}
+    _block_cache[key] = (ws, val)
+    while len(_block_cache) > 64:
+        _block_cache.popitem(last=False)
+    return val
+
+
+def _split_block_enabled():
+    import os
+    return os.environ.get("OTGAN_DENSE_SPLIT", "1") != "0"
+
+
 class DenseBlockFunction(torch.autograd.Function):
     """L weight-normalised convolutions that each read the concatenation of everything before
     them and append `F` channels (reference models/densenet.py:11-16: `x.append(conv2d(x, F))`).
@@ -326,6 +390,15 @@ class DenseBlockFunction(torch.autograd.Function):
     the conv ABI).  The backward pass walks the layers in reverse over one gradient buffer:
     layer k's dy is a channel slice of it and its dgrad accumulates into channels [0, Ck).
     No concatenation copies, no per-layer activation tensors.
+
+    Wide block inputs (C0 of 144 ... 224 against 16 new channels per layer) are taken out of the chain: every layer's
+    pre-activation is linear in act(block input), so the block input's share of ALL L layers is one 3x3 convolution
+    C0 -> L*F written straight into channels [C0, Ctot) of the buffer (a GEMM wide enough for the Winograd
+    F(4x4,3x3) passes: 2.25 instead of 9 products per output, on the split-precision engine), after which layer k
+    only adds the convolution of the k earlier growth outputs onto its slice (`y_accumulate`).  Backward mirrors it:
+    the growth layers' dgrad / wgrad see channels [C0, Ck) only, the block input takes one dgrad and one wgrad of
+    the wide convolution against the finished gradient of channels [C0, Ctot).  Same sums in a different order;
+    chosen when the library routes the wide convolution to its Winograd path (OTGAN_DENSE_SPLIT=0: never).
 
     args: x0 [N,H,W,C0] (concatenated initial list), then V_k, g_k, b_k for every layer."""
 
@@ -339,25 +412,58 @@ class DenseBlockFunction(torch.autograd.Function):
         buf = torch.empty((N, H, W, Ctot), dtype=x0.dtype, device=x0.device)
         buf[..., :C0].copy_(x0)
         mult = 2 if preact in DOUBLED else 1
-        saved, descs, maps = [], [], []
+        saved, descs, maps, per_layer = [], [], [], []
         segs = list(segs0)
         for k in range(L):
             V, g, b = params[3 * k:3 * k + 3]
             Ck = C0 + k * F
             assert tuple(V.shape) == (ksize, ksize, Ck * mult, F), (V.shape, Ck, mult)
             V2d = V.contiguous().view(-1, F)
-            w, wT, inv_norm = cached_weights(V, g, lambda V2d=V2d, g=g: weightnorm_fwd(V2d, g))
+            per_layer.append(cached_weights(V, g, lambda V2d=V2d, g=g: weightnorm_fwd(V2d, g)))
+            saved += [V2d, g, per_layer[k][0], per_layer[k][2]]
+        ctx.vshapes = [p.shape for p in params[0::3]]
+        ctx.L, ctx.C0, ctx.F = L, C0, F
+
+        # ---- block-input convolution + growth chain
+        quads0 = 1 if all(int(c) % 4 == 0 for c in segs0) else 0
+        desc_in = ConvDesc(N, H, W, C0, Ctot, 0, ksize, ksize, 1, L * F, Ctot, C0, preact, 1)
+        ctx.split = (_split_block_enabled() and ksize == 3 and L >= 2 and quads0 == 1 and F == 16 and
+                     all(p is not None for p in params[2::3]) and
+                     _lib.lib().otgan_conv2d_filter_bytes(ctypes.byref(desc_in), 0) > 0)
+        if ctx.split:
+            ctx.row_order = _input_row_order(segs0, preact, x0.device)
+            sw = _split_block_weights(params[0::3], per_layer, C0 * mult, F, ctx.row_order, desc_in)
+            x0c = x0.contiguous()
+            ctx.x_rec = absmax_record(x0c)
+            desc_in.x_amax = ctx.x_rec.data_ptr()
+            bias_all = torch.cat([b for b in params[2::3]])
+            conv_fwd_raw(desc_in, buf, None, sw["wT_in"], bias_all, buf, sw["fwd"])
+            grown = buf[..., C0:]                  # channel slice: same rows, pointer advanced by C0 floats
+            for k in range(1, L):
+                desc = ConvDesc(N, H, W, k * F, Ctot, 0, ksize, ksize, 1, F, Ctot, C0 + k * F, preact, 1)
+                desc.y_accumulate = 1
+                cmap, inv = channel_maps((F,) * k, preact, x0.device)
+                conv_fwd_raw(desc, grown, cmap, sw["wT_g"][k], None, buf)
+                desc.y_accumulate = 0
+                descs.append(desc)
+                maps.append((cmap, inv))
+            ctx.desc_in, ctx.sw = desc_in, sw
+            ctx.save_for_backward(buf, *saved)
+            ctx.descs, ctx.maps = descs, maps
+            return buf
+
+        for k in range(L):
+            b = params[3 * k + 2]
+            Ck = C0 + k * F
             desc = ConvDesc(N, H, W, Ck, Ctot, 0, ksize, ksize, 1, F, Ctot, Ck, preact,
                             1 if all(s % 4 == 0 for s in segs) else 0)
             cmap, inv = channel_maps(tuple(segs), preact, x0.device)
-            conv_fwd_raw(desc, buf, cmap, wT, b, buf)
-            saved += [V2d, g, w, inv_norm]
+            conv_fwd_raw(desc, buf, cmap, per_layer[k][1], b, buf)
             descs.append(desc)
             maps.append((cmap, inv))
             segs.append(F)
         ctx.save_for_backward(buf, *saved)
-        ctx.descs, ctx.maps, ctx.L, ctx.C0, ctx.F = descs, maps, L, C0, F
-        ctx.vshapes = [p.shape for p in params[0::3]]
+        ctx.descs, ctx.maps = descs, maps
         return buf
 
     @staticmethod
@@ -369,18 +475,54 @@ class DenseBlockFunction(torch.autograd.Function):
         need_w = any(ctx.needs_input_grad[4:])
         grads = [None] * (3 * L)
         rows = N * H * W
-        for k in reversed(range(L)):
-            V2d, g, w, inv_norm = saved[4 * k:4 * k + 4]
-            desc = ctx.descs[k]
-            cmap, inv = ctx.maps[k]
-            Ck = C0 + k * F
+        if ctx.split:
+            sw, desc_in = ctx.sw, ctx.desc_in
+            grown, Ggrown = buf[..., C0:], G[..., C0:]
+            dw_g = [None] * L
+            for k in reversed(range(1, L)):
+                desc = ctx.descs[k - 1]
+                cmap, inv = ctx.maps[k - 1]
+                if need_w:
+                    dw_g[k] = torch.empty_like(sw["w_g"][k])
+                    conv_wgrad_raw(desc, grown, cmap, G, dw_g[k])
+                # d/d(growth outputs 0 .. k-1) accumulates into channels [C0, Ck) of G
+                conv_dgrad_raw(desc, G, sw["w_g"][k], grown, inv, Ggrown, Ctot, True)
+            # channels [C0, Ctot) of G are final: the block input sees them through the wide convolution
+            dy_rec = absmax_record_strided(Ggrown.data_ptr(), rows, L * F, Ctot, G.device)
+            desc_in.dy_amax = dy_rec.data_ptr()
+            Ceff0 = sw["w_in"].shape[0] // 9
             if need_w:
-                dw = torch.empty_like(V2d)
-                conv_wgrad_raw(desc, buf, cmap, G, dw)
-                dV2d, dg = weightnorm_bwd(V2d, g, inv_norm, dw)
-                grads[3 * k:3 * k + 2] = [dV2d.view(ctx.vshapes[k]), dg]
-            # d/d(inputs of layer k) accumulates into the first Ck channels of G
-            conv_dgrad_raw(desc, G, w, buf, inv, G, Ctot, True)
+                dw_in = torch.empty_like(sw["w_in"])
+                conv_wgrad_raw(desc_in, buf, None, G, dw_in)
+                dw_in = dw_in.view(9, Ceff0, L, F)
+                order = ctx.row_order
+                if order is not None:
+                    back = torch.empty_like(order)
+                    back[order] = torch.arange(order.numel(), device=order.device)
+                    dw_in = dw_in.index_select(1, back)
+                for k in range(L):
+                    V2d, g, w, inv_norm = saved[4 * k:4 * k + 4]
+                    part = dw_in[:, :, k, :]
+                    dw = torch.cat([part, dw_g[k].view(9, -1, F)], dim=1) if k else part.contiguous()
+                    dV2d, dg = weightnorm_bwd(V2d, g, inv_norm, dw.view(-1, F))
+                    grads[3 * k:3 * k + 2] = [dV2d.view(ctx.vshapes[k]), dg]
+            if ctx.needs_input_grad[0]:
+                if not sw["bwd_done"]:
+                    sw["bwd"], sw["bwd_done"] = prepare_filters(desc_in, 1, sw["w_in"]), True
+                conv_dgrad_raw(desc_in, G, sw["w_in"], buf, None, G, Ctot, True, sw["bwd"])
+            desc_in.dy_amax = None
+        else:
+            for k in reversed(range(L)):
+                V2d, g, w, inv_norm = saved[4 * k:4 * k + 4]
+                desc = ctx.descs[k]
+                cmap, inv = ctx.maps[k]
+                if need_w:
+                    dw = torch.empty_like(V2d)
+                    conv_wgrad_raw(desc, buf, cmap, G, dw)
+                    dV2d, dg = weightnorm_bwd(V2d, g, inv_norm, dw)
+                    grads[3 * k:3 * k + 2] = [dV2d.view(ctx.vshapes[k]), dg]
+                # d/d(inputs of layer k) accumulates into the first Ck channels of G
+                conv_dgrad_raw(desc, G, w, buf, inv, G, Ctot, True)
         if need_w:
             # Layer k's output gradient G[..., Ck:Ck+F] is final once the layers after it have been
             # processed, and no earlier layer writes there: all L bias gradients are the column sums

@@ -87,6 +87,11 @@ CONV_CASES = [
     ("cout200_s2_list", 4, 16, 16, (32, 16, 16), 200, 3, 2, False, "crelu"),
     ("cout228_s2", 3, 8, 8, (24,), 228, 3, 2, False, "crelu"),
     ("cout20_plain", 2, 8, 8, (16,), 20, 3, 1, False, None),
+    # wide 3x3 stride-1 layers: Winograd F(4x4,3x3) with one class (the block-input convolution of a dense block)
+    ("wino_plain3_crelu", 6, 16, 16, (48,), 128, 3, 1, False, "crelu"),
+    ("wino_plain3_none", 3, 8, 8, (64,), 160, 3, 1, False, None),
+    ("wino_plain3_celu_rect", 5, 8, 16, (32,), 256, 3, 1, False, "celu"),
+    ("wino_plain3_list_generic", 2, 8, 8, (32, 16), 128, 3, 1, False, "crelu"),
 ]
 
 
@@ -430,3 +435,53 @@ def test_wino_outlier_zero_and_nan(dev):
     x_nan[1, 3, 3, 5] = float("nan")
     yn = ops.conv2d_op(x_nan.to(dev), V.to(dev), g.to(dev), b.to(dev), stride=1, upsample=True, preact=0)
     assert torch.isnan(yn).any()
+
+
+@pytest.mark.parametrize("case", [
+    ("crelu_list", 3, 16, 16, (32, 16), 8, "crelu"),
+    ("crelu_single", 2, 8, 8, (64,), 9, "crelu"),
+    ("celu_list", 2, 8, 16, (16, 8, 8), 8, "celu"),
+    ("elu_single", 2, 8, 8, (64,), 8, "elu"),
+], ids=lambda c: c[0])
+def test_dense_block_split_matches_chain(dev, case, monkeypatch):
+    """A dense block computed as "block-input convolution (Winograd) + growth chain" (ops.DenseBlockFunction) against
+    the fp64 oracle's plain chain of convolutions over the growing concatenation (reference nn.py:243-262), and
+    against the same op with the split switched off."""
+    from otgan_amd import ops
+    name, N, H, W, segs0, L, pre = case
+    F = 16
+    gen = torch.Generator().manual_seed(sum(map(ord, name)))
+    mult = 2 if pre in ("crelu", "celu") else 1
+    C0 = sum(segs0)
+    xs64 = [torch.randn(N, H, W, c, generator=gen, dtype=torch.float64).float().double().requires_grad_(True) for c in segs0]
+    P64 = []
+    for k in range(L):
+        V = (torch.randn(3, 3, (C0 + k * F) * mult, F, generator=gen, dtype=torch.float64) * 0.05).float().double()
+        g = (torch.rand(F, generator=gen, dtype=torch.float64) + 0.5).float().double()
+        b = (torch.randn(F, generator=gen, dtype=torch.float64) * 0.1).float().double()
+        P64.append([t.requires_grad_(True) for t in (V, g, b)])
+    feats = list(xs64)
+    for V, g, b in P64:
+        feats.append(NT.conv2d(feats, {"V": V, "g": g, "b": b}, pre, 1, False))
+    y_ref = torch.cat(feats, 3)
+    dy64 = torch.randn(y_ref.shape, generator=gen, dtype=torch.float64).float().double()
+    flat64 = [t for p in P64 for t in p]
+    grads_ref = torch.autograd.grad(y_ref, xs64 + flat64, dy64)
+
+    def run(split):
+        monkeypatch.setenv("OTGAN_DENSE_SPLIT", "1" if split else "0")
+        ops.bump_weights_epoch()
+        x0 = torch.cat([t.detach().float() for t in xs64], 3).to(dev).requires_grad_(True)
+        params = [[t.detach().float().to(dev).requires_grad_(True) for t in p] for p in P64]
+        y = ops.dense_block_op(x0, segs0, params, 3, ops.ACT[pre])
+        grads = torch.autograd.grad(y, [x0] + [t for p in params for t in p], dy64.float().to(dev))
+        return y, grads
+
+    y_s, g_s = run(True)
+    y_c, g_c = run(False)
+    assert _rel(y_s, y_ref) < TOL and _rel(y_c, y_ref) < TOL
+    dx_ref = torch.cat(grads_ref[:len(segs0)], 3)
+    assert _rel(g_s[0], dx_ref) < TOL and _rel(g_c[0], dx_ref) < TOL
+    for i, (a, c, r) in enumerate(zip(g_s[1:], g_c[1:], grads_ref[len(segs0):])):
+        assert _rel(a, r) < TOL, f"split: gradient of parameter {i}"
+        assert _rel(c, r) < TOL, f"chain: gradient of parameter {i}"
