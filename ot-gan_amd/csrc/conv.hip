@@ -1579,9 +1579,16 @@ inline WinoGeo wino_geo(const otgan_conv_desc* d) {
 // Wide 3x3 stride-1 layers (the block-input convolution of a DenseNet block: ops.py DenseBlockFunction) take the same
 // three passes with ONE class ("plain", winograd.h): 2.25 instead of 9 products per output.  Narrow ones do not pay
 // (the Winograd-domain result is 2.25 x Cout floats per pixel, written and read once): Cout >= 128.
+inline int wino_plain3_min_ceff() {
+  static const int v = [] {
+    const char* e = getenv("OTGAN_PLAIN3_MIN_CEFF");
+    return e ? atoi(e) : 64;
+  }();
+  return v;
+}
 inline bool wino_plain3_ok(const otgan_conv_desc* d, const Geo& g) {
   return d->stride == 1 && d->upsample == 0 && d->KH == 3 && d->KW == 3 && d->C % 4 == 0 && g.Ceff % 32 == 0 &&
-         g.Ceff >= 64 && d->Cout % 32 == 0 && d->Cout >= 128 && d->H % kWinoM == 0 && d->W % kWinoM == 0 && d->ldx % 4 == 0 &&
+         g.Ceff >= wino_plain3_min_ceff() && d->Cout % 32 == 0 && d->Cout >= 128 && d->H % kWinoM == 0 && d->W % kWinoM == 0 && d->ldx % 4 == 0 &&
          d->ldy % 4 == 0 && d->y_coff % 4 == 0 && WINO(winograd_enabled)() && getenv("OTGAN_DISABLE_WINO_PLAIN3") == nullptr;
 }
 inline bool wino_s2_ok(const otgan_conv_desc* d, const Geo& g) {
@@ -1611,6 +1618,20 @@ inline WinoUp3Geo wino_up3_geo(const otgan_conv_desc* d, const Geo& g) {
   WinoUp3Geo w;
   w.N = d->N; w.H = d->H; w.W = d->W; w.C = d->C; w.Ceff = g.Ceff; w.ldx = d->ldx; w.Cout = d->Cout; w.ldy = d->ldy;
   w.y_coff = d->y_coff; w.x_amax = d->x_amax;
+  return w;
+}
+
+// ... and their weight gradient: the one-class ("plain") passes of the strided-layer code on the upsampled grid, x read
+// through the upsample by the input transform; un-folded dw directly (no dweff, no unfold pass)
+inline bool wino_up3_wgrad_ok(const otgan_conv_desc* d, const Geo& g) {
+  return wino_up3_ok(d, g) && d->Cout % 16 == 0 && ((long)d->N * (2 * d->H / kWinoM) * (2 * d->W / kWinoM)) % 32 == 0 &&
+         getenv("OTGAN_DISABLE_WINO_UP3_WGRAD") == nullptr;
+}
+inline WinoS2Geo wino_up3_wgrad_geo(const otgan_conv_desc* d, const Geo& g) {
+  WinoS2Geo w;
+  w.N = d->N; w.H = 2 * d->H; w.W = 2 * d->W; w.C = d->C; w.Ceff = g.Ceff; w.doubled = 1; w.act = 1; w.ldx = d->ldx;
+  w.Cout = d->Cout; w.ldy = d->ldy; w.y_coff = d->y_coff; w.x_amax = d->x_amax; w.dy_amax = d->dy_amax;
+  w.plain = 1; w.up = 1;
   return w;
 }
 
@@ -1921,6 +1942,7 @@ size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which) {
   }
   size_t s2 = 0;   // the strided Winograd path falls back to the generic one for list inputs: max of both
   if (which == 0 && wino_up3_ok(d, g)) s2 = align_up(sizeof(float) * WINO(wino_up3_fwd_ws_floats)(wino_up3_geo(d, g)), 256) + 256;
+  if (which == 2 && wino_up3_wgrad_ok(d, g)) s2 = align_up(sizeof(float) * WINO(wino_s2_wgrad_ws_floats)(wino_up3_wgrad_geo(d, g)), 256) + 256;
   if (wino_s2_ok(d, g)) {
     const WinoS2Geo w = wino_s2_geo(d, g);
     const size_t fl = which == 0 ? WINO(wino_s2_fwd_ws_floats)(w) : which == 1 ? WINO(wino_s2_dgrad_ws_floats)(w)
@@ -2383,6 +2405,14 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
   if ((p.nsplit > 1 || p.fold) && (!workspace || workspace_bytes < need)) {
     otgan_set_error("conv2d wgrad workspace too small: need %zu, got %zu", need, workspace_bytes);
     return OTGAN_ERR_WORKSPACE;
+  }
+  if (wino_up3_wgrad_ok(d, g) && cmap == nullptr && aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace) &&
+      workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 2)) {
+    const WinoS2Geo wg = wino_up3_wgrad_geo(d, g);
+    ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * kWinoFreq * (double)wino_s2_tiles(wg) * g.Ceff * d->Cout, 0.0, s);
+    rc = WINO(wino_s2_wgrad)(wg, x, dy, dw, (float*)workspace, s);
+    OTGAN_CHECK_LAUNCH("conv2d wgrad (winograd, 3x3 on upsampled input)");
+    return rc;
   }
   if (wino_s2_ok(d, g) && cmap == nullptr && aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace) &&
       workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 2)) {

@@ -362,7 +362,10 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
       const u16* src;
       if (TL) {
         int cb = cb0 + 2 * rg;
-        if (cb > cbn - 2) cb = cbn - 2;   // past the operand's last column: duplicates feed C rows / columns never stored
+        // past the operand's last column: duplicates feed C rows / columns never stored.  An odd block count (columns a
+        // multiple of 16 only) pairs the last block with the 1 KiB after it (the next row group's first block, or the
+        // operand that follows in the workspace): read, multiplied into columns that are never stored
+        if (cb > ((cbn - 1) & ~1)) cb = (cbn - 1) & ~1;
         src = opb + piece * plane + ((((long)(kb >> 1) * cbn + cb) << 9) + ((kb & 1) << 8));
       } else {
         int rb = rb0 + rg;
@@ -795,7 +798,7 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
       const int piece = li >> 3, rg = li & 7;
       if (TL) {
         int cb = o0 + 2 * rg;
-        if (cb > cbn - 2) cb = cbn - 2;
+        if (cb > ((cbn - 1) & ~1)) cb = (cbn - 1) & ~1;
         c.base[i] = opb + piece * plane + ((long)cb << 9);
       } else {
         int rb = o0 + rg;

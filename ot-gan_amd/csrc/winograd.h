@@ -49,6 +49,10 @@ struct WinoS2Geo {
   // ONE class on the full H x W grid (multiples of 4), taps taken as they are, nothing structurally zero;
   // wT: [Cout][9*Ceff], w: [9][Ceff][Cout].  Same kernels, same three passes.
   int plain = 0;
+  // plain only, 1: x is stored at half resolution ([N, H/2, W/2, ldx]) and read through a 2x nearest-neighbour
+  // upsample (the DenseNet generator's transition layers); H, W stay the grid the convolution runs on.  Input
+  // transform and weight gradient only (dgrad keeps the folded path).
+  int up = 0;
 };
 inline int wino_s2_classes(const WinoS2Geo& g) { return g.plain ? 1 : 4; }
 inline int wino_s2_out_h(const WinoS2Geo& g) { return g.plain ? g.H : g.H / 2; }

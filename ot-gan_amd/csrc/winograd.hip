@@ -1479,11 +1479,16 @@ int s2_wgrad_splits(const WinoS2Geo& g) {
 void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, u16* VP, hipStream_t s) {
   const long T = wino_s2_tiles(g);
   // (the activation is applied inside the transform: |relu(+-x)| <= |x|, |elu(x)| <= max(|x|, 1))
-  if (VP) op_scales(x, (long)g.N * g.H * g.W, g.C, g.ldx, reinterpret_cast<float*>(VP) - X3_HDR, kGainBt, 1.f, g.act == 2, s, g.x_amax);
+  if (VP) op_scales(x, (long)g.N * (g.H >> g.up) * (g.W >> g.up), g.C, g.ldx, reinterpret_cast<float*>(VP) - X3_HDR, kGainBt, 1.f, g.act == 2, s, g.x_amax);
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
   ia.s2_skip = -1;
   s2_views(g, x, g.ldx, ia.v);
+  if (g.up) {   // the stored image is half the grid (plain layers only)
+    ia.up = 1;
+    ia.v[0].sn = (long)(g.H / 2) * (g.W / 2) * g.ldx;
+    ia.v[0].sh = (long)(g.W / 2) * g.ldx;
+  }
   for (int cls = 0; cls < 4; ++cls) ia.coff[cls] = cls * g.Ceff;
   ia.H = wino_s2_out_h(g); ia.W = wino_s2_out_w(g); ia.TH = ia.H / WM; ia.TW = ia.W / WM; ia.C = g.C; ia.T = T; ia.ldv = s2_k(g);
   ia.V = V;
@@ -1623,7 +1628,7 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
   const long T = wino_s2_tiles(g);
   const int K4 = s2_k(g);
   const int OH = wino_s2_out_h(g), OW = wino_s2_out_w(g);
-  if (use_x3_wgrad_tl() && T % 32 == 0 && g.Ceff % 32 == 0 && g.Cout % 32 == 0) {
+  if (use_x3_wgrad_tl() && T % 32 == 0 && g.Ceff % 32 == 0 && g.Cout % 16 == 0) {
     // the forward operand V[tile][4 Ceff] (absent (class, frequency) blocks unwritten: their rows of the result are
     // masked by the adjoint filter transform) and the dgrad operand dM[tile][Cout]: t-leading GEMM over the tiles
     const int ns = x3_wgrad_splits(K4, g.Cout, T);
