@@ -48,8 +48,9 @@ typedef struct otgan_conv_desc {
   const float* x_amax;
   const float* dy_amax;
   /* forward only: 1 = y += conv(x) + bias instead of y = ...  Implemented for the 3x3 / stride-1 / 16-output growth
-   * layers (dense16 kernels), which is what a dense block split into "block-input convolution + growth chain" needs
-   * (ops.py DenseBlockFunction); any other layer with this flag set is rejected with OTGAN_ERR_ARG. */
+   * layers (dense16 kernels) and for the wide 3x3 / stride-1 layers that take the Winograd path, which is what a dense
+   * block split into "wide convolutions of finished channel groups + short growth chains" needs (ops.py
+   * DenseBlockFunction); any other layer with this flag set is rejected with OTGAN_ERR_ARG. */
   int y_accumulate;
 } otgan_conv_desc;
 

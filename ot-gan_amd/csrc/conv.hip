@@ -2035,7 +2035,12 @@ static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32
   hipStream_t s = (hipStream_t)stream;
   const bool growth16 = d->Cout == 16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->upsample == 0 && d->C % 8 == 0 &&
                         d->ldx % 4 == 0 && aligned16(x) && aligned16(wT) && aligned16(cmap) && dense16_enabled();
-  OTGAN_CHECK_ARG(!d->y_accumulate || growth16, "y_accumulate: only the 3x3 stride-1 16-output growth layers accumulate");
+  const bool wino_s2_fwd_taken = wino_s2_ok(d, g) && cmap == nullptr && aligned16(x) && aligned16(wT) && aligned16(y) &&
+                                 aligned16(bias) && aligned16(workspace) && workspace &&
+                                 workspace_bytes >= otgan_conv2d_workspace_bytes(d, 0);
+  OTGAN_CHECK_ARG(!d->y_accumulate || growth16 || (wino_s2_fwd_taken && wino_plain3_ok(d, g)),
+                  "y_accumulate: only the 3x3 stride-1 growth layers (16 outputs) and the wide 3x3 stride-1 layers on the "
+                  "Winograd path accumulate");
   GatherA ga;
   ClassTab ct;
   WeightB wb;
@@ -2050,9 +2055,9 @@ static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32
   e.bias = bias; e.ncols = d->Cout;
   double flops;
   bool vec;
-  if (wino_s2_ok(d, g) && cmap == nullptr && aligned16(x) && aligned16(wT) && aligned16(y) && aligned16(bias) &&
-      aligned16(workspace) && workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 0)) {
-    const WinoS2Geo w = wino_s2_geo(d, g);
+  if (wino_s2_fwd_taken) {
+    WinoS2Geo w = wino_s2_geo(d, g);
+    w.y_accumulate = d->y_accumulate;
     ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * wino_s2_blocks(w) * (double)wino_s2_tiles(w) * g.Ceff * d->Cout, 0.0, s);
     rc = WINO(wino_s2_fwd)(w, x, wT, bias, y, (float*)workspace, s, filters);
     OTGAN_CHECK_LAUNCH("conv2d fwd (winograd, stride 2)");

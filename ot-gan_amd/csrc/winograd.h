@@ -53,6 +53,7 @@ struct WinoS2Geo {
   // upsample (the DenseNet generator's transition layers); H, W stay the grid the convolution runs on.  Input
   // transform and weight gradient only (dgrad keeps the folded path).
   int up = 0;
+  int y_accumulate = 0;   // forward: y += result + bias (otgan_conv_desc::y_accumulate)
 };
 inline int wino_s2_classes(const WinoS2Geo& g) { return g.plain ? 1 : 4; }
 inline int wino_s2_out_h(const WinoS2Geo& g) { return g.plain ? g.H : g.H / 2; }

@@ -1568,7 +1568,7 @@ int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float
   const int OH = wino_s2_out_h(g), OW = wino_s2_out_w(g);
   oa.v[0].p = y + g.y_coff; oa.v[0].sn = (long)OH * OW * g.ldy; oa.v[0].sh = (long)OW * g.ldy; oa.v[0].sw = g.ldy;
   oa.TH = OH / WM; oa.TW = OW / WM; oa.C = g.Cout; oa.T = T; oa.ldm = g.Cout; oa.Mh = Mh; oa.bias = bias;
-
+  oa.accumulate = g.y_accumulate;
   hipLaunchKernelGGL(wino_output_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 1), dim3(256), 0, s, oa);
   return OTGAN_OK;
 }

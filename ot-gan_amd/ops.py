@@ -347,38 +347,75 @@ def _input_row_order(segs0, preact, device):
 _block_cache = OrderedDict()   # id(V of layer 0) -> (per-layer normalised weights it was made from, value)
 
 
-def _split_block_weights(Vs, per_layer, Ceff0, F, rows, desc_in):
-    """Operands of a dense block computed as "block-input convolution + growth chain": the rows of every layer's
-    normalised weights that multiply the block input, gathered into ONE 3x3 convolution C0 -> L*F (wT_in
-    [L*F][9*Ceff0], w_in [9*Ceff0][L*F], Winograd-domain filters), and per layer the remaining rows (the earlier
-    growth layers' outputs) as contiguous tensors.  Cached for as long as the per-layer normalised weights are."""
+def _wide_operands(per_layer, layers, row0, nrows, order, F, desc):
+    """One wide 3x3 convolution gathered from a dense block: rows [row0, row0 + nrows) of the normalised weights of
+    `layers` (the effective channels of one finished channel group), side by side.  w [9*nrows][len(layers)*F],
+    wT [len(layers)*F][9*nrows], rows re-ordered to the single-tensor order when `order` is given."""
+    w = torch.cat([per_layer[k][0].view(9, -1, F)[:, row0:row0 + nrows, :] for k in layers], dim=2)
+    wT = torch.cat([per_layer[k][1].view(F, 9, -1)[:, :, row0:row0 + nrows] for k in layers], dim=0)
+    if order is not None:
+        w = w.index_select(1, order)
+        wT = wT.index_select(2, order)
+    n = len(layers) * F
+    w, wT = w.contiguous().view(9 * nrows, n), wT.contiguous().view(n, 9 * nrows)
+    return {"w": w, "wT": wT, "fwd": prepare_filters(desc, 0, wT), "bwd": None, "bwd_done": False}
+
+
+def _split_block_weights(Vs, per_layer, plan, F):
+    """Operands of a dense block computed as "wide convolutions of finished channel groups + short growth chains"
+    (DenseBlockFunction): per wide convolution the gathered weights and their Winograd-domain filters, per layer the
+    rows of its own chain as contiguous tensors.  Cached for as long as the per-layer normalised weights are."""
     key = id(Vs[0])
     ws = [pl[0] for pl in per_layer]
     hit = _block_cache.get(key)
-    if hit is not None and len(hit[0]) == len(ws) and all(a is b for a, b in zip(hit[0], ws)):
+    if hit is not None and len(hit[0]) == len(ws) and all(a is b for a, b in zip(hit[0], ws)) and hit[2] == plan["key"]:
         _block_cache.move_to_end(key)
         return hit[1]
     L = len(per_layer)
-    w_in = torch.cat([pl[0].view(9, -1, F)[:, :Ceff0, :] for pl in per_layer], dim=2)        # [9][Ceff0][L*F]
-    wT_in = torch.cat([pl[1].view(F, 9, -1)[:, :, :Ceff0] for pl in per_layer], dim=0)       # [L*F][9][Ceff0]
-    if rows is not None:
-        w_in = w_in.index_select(1, rows)
-        wT_in = wT_in.index_select(2, rows)
-    w_in = w_in.contiguous().view(9 * Ceff0, L * F)
-    wT_in = wT_in.contiguous().view(L * F, 9 * Ceff0)
-    w_g = [None] + [per_layer[k][0].view(9, -1, F)[:, Ceff0:, :].contiguous().view(-1, F) for k in range(1, L)]
-    wT_g = [None] + [per_layer[k][1].view(F, 9, -1)[:, :, Ceff0:].contiguous().view(F, -1) for k in range(1, L)]
-    val = {"w_in": w_in, "wT_in": wT_in, "w_g": w_g, "wT_g": wT_g,
-           "fwd": prepare_filters(desc_in, 0, wT_in), "bwd": None, "bwd_done": False}
-    _block_cache[key] = (ws, val)
+    val = {"wide": [_wide_operands(per_layer, range(wd["d0"], L), wd["row0"], wd["nrows"], wd["order"], F, wd["desc"])
+                    for wd in plan["wide"]],
+           "w_g": [None] * L, "wT_g": [None] * L}
+    for k in range(L):
+        r0 = plan["own_row0"][k]
+        if plan["own_len"][k]:
+            val["w_g"][k] = per_layer[k][0].view(9, -1, F)[:, r0:, :].contiguous().view(-1, F)
+            val["wT_g"][k] = per_layer[k][1].view(F, 9, -1)[:, :, r0:].contiguous().view(F, -1)
+    _block_cache[key] = (ws, val, plan["key"])
     while len(_block_cache) > 64:
         _block_cache.popitem(last=False)
     return val
 
 
-def _split_block_enabled():
+def _split_block_plan(N, H, W, C0, L, F, segs0, preact, device):
+    """How a dense block is cut (None: not at all).  The pre-activation of layer k is linear in act(every earlier
+    channel), so the share of a FINISHED channel group in all later layers is one 3x3 convolution group -> (later
+    layers) * F, wide enough for the Winograd F(4x4,3x3) passes:
+      * the block input (C0 channels) into all L layers, before the chain starts;
+      * the first half of the growth outputs into the second half of the layers, once layer L/2 - 1 is done.
+    What stays on the 16-output growth kernels is each layer's chain inside its own half."""
     import os
-    return os.environ.get("OTGAN_DENSE_SPLIT", "1") != "0"
+    if os.environ.get("OTGAN_DENSE_SPLIT", "1") == "0" or F != 16 or L < 2 or any(int(c) % 4 for c in segs0):
+        return None
+    mult = 2 if preact in DOUBLED else 1
+    Ctot = C0 + L * F
+    lib = _lib.lib()
+    desc_in = ConvDesc(N, H, W, C0, Ctot, 0, 3, 3, 1, L * F, Ctot, C0, preact, 1)
+    if not lib.otgan_conv2d_filter_bytes(ctypes.byref(desc_in), 0):
+        return None
+    wide = [{"desc": desc_in, "x_off": 0, "C": C0, "d0": 0, "row0": 0, "nrows": C0 * mult,
+             "order": _input_row_order(segs0, preact, device), "accumulate": 0}]
+    h = L // 2
+    desc_mid = ConvDesc(N, H, W, h * F, Ctot, 0, 3, 3, 1, (L - h) * F, Ctot, C0 + h * F, preact, 1)
+    if os.environ.get("OTGAN_DENSE_SPLIT_HALVES", "1") != "0" and h >= 1 and \
+            lib.otgan_conv2d_filter_bytes(ctypes.byref(desc_mid), 0):
+        wide.append({"desc": desc_mid, "x_off": C0, "C": h * F, "d0": h, "row0": C0 * mult, "nrows": h * F * mult,
+                     "order": _input_row_order((F,) * h, preact, device), "accumulate": 1})
+    else:
+        h = None
+    g0 = [0 if (h is None or k < h) else h for k in range(L)]
+    return {"wide": wide, "h": h, "g0": g0, "own_len": [k - g0[k] for k in range(L)],
+            "own_row0": [(C0 + g0[k] * F) * mult for k in range(L)],
+            "key": (H, W, C0, L, F, tuple(segs0), preact, h)}
 
 
 class DenseBlockFunction(torch.autograd.Function):
@@ -391,14 +428,16 @@ class DenseBlockFunction(torch.autograd.Function):
     layer k's dy is a channel slice of it and its dgrad accumulates into channels [0, Ck).
     No concatenation copies, no per-layer activation tensors.
 
-    Wide block inputs (C0 of 144 ... 224 against 16 new channels per layer) are taken out of the chain: every layer's
-    pre-activation is linear in act(block input), so the block input's share of ALL L layers is one 3x3 convolution
-    C0 -> L*F written straight into channels [C0, Ctot) of the buffer (a GEMM wide enough for the Winograd
-    F(4x4,3x3) passes: 2.25 instead of 9 products per output, on the split-precision engine), after which layer k
-    only adds the convolution of the k earlier growth outputs onto its slice (`y_accumulate`).  Backward mirrors it:
-    the growth layers' dgrad / wgrad see channels [C0, Ck) only, the block input takes one dgrad and one wgrad of
-    the wide convolution against the finished gradient of channels [C0, Ctot).  Same sums in a different order;
-    chosen when the library routes the wide convolution to its Winograd path (OTGAN_DENSE_SPLIT=0: never).
+    Finished channel groups are taken out of the chain (`_split_block_plan`): every layer's pre-activation is linear
+    in act(earlier channels), so the block input's share of ALL L layers is one 3x3 convolution C0 -> L*F written
+    straight into channels [C0, Ctot) of the buffer, and the first half of the growth outputs enters the second half
+    of the layers through one more (L/2)*F -> (L/2)*F convolution added onto them -- GEMMs wide enough for the
+    Winograd F(4x4,3x3) passes on the split-precision engine (2.25 instead of 9 products per output); layer k then
+    only adds the convolution of the growth outputs of its own half (`y_accumulate`).  Backward mirrors it: the
+    growth layers' dgrad / wgrad see their own half only, each wide convolution takes one dgrad and one wgrad
+    against the finished gradient of the channels it wrote.  Same sums in a different order; chosen when the
+    library routes the wide convolutions to its Winograd path (OTGAN_DENSE_SPLIT=0: never, OTGAN_DENSE_SPLIT_HALVES=0:
+    the block input only).
 
     args: x0 [N,H,W,C0] (concatenated initial list), then V_k, g_k, b_k for every layer."""
 
@@ -424,30 +463,43 @@ class DenseBlockFunction(torch.autograd.Function):
         ctx.vshapes = [p.shape for p in params[0::3]]
         ctx.L, ctx.C0, ctx.F = L, C0, F
 
-        # ---- block-input convolution + growth chain
-        quads0 = 1 if all(int(c) % 4 == 0 for c in segs0) else 0
-        desc_in = ConvDesc(N, H, W, C0, Ctot, 0, ksize, ksize, 1, L * F, Ctot, C0, preact, 1)
-        ctx.split = (_split_block_enabled() and ksize == 3 and L >= 2 and quads0 == 1 and F == 16 and
-                     all(p is not None for p in params[2::3]) and
-                     _lib.lib().otgan_conv2d_filter_bytes(ctypes.byref(desc_in), 0) > 0)
-        if ctx.split:
-            ctx.row_order = _input_row_order(segs0, preact, x0.device)
-            sw = _split_block_weights(params[0::3], per_layer, C0 * mult, F, ctx.row_order, desc_in)
-            x0c = x0.contiguous()
-            ctx.x_rec = absmax_record(x0c)
-            desc_in.x_amax = ctx.x_rec.data_ptr()
+        plan = None
+        if ksize == 3 and all(p is not None for p in params[2::3]):
+            plan = _split_block_plan(N, H, W, C0, L, F, segs0, preact, x0.device)
+        ctx.plan = plan
+        if plan is not None:
+            sw = _split_block_weights(params[0::3], per_layer, plan, F)
             bias_all = torch.cat([b for b in params[2::3]])
-            conv_fwd_raw(desc_in, buf, None, sw["wT_in"], bias_all, buf, sw["fwd"])
-            grown = buf[..., C0:]                  # channel slice: same rows, pointer advanced by C0 floats
-            for k in range(1, L):
-                desc = ConvDesc(N, H, W, k * F, Ctot, 0, ksize, ksize, 1, F, Ctot, C0 + k * F, preact, 1)
-                desc.y_accumulate = 1
-                cmap, inv = channel_maps((F,) * k, preact, x0.device)
-                conv_fwd_raw(desc, grown, cmap, sw["wT_g"][k], None, buf)
+            rows = N * H * W
+            ctx.x_recs = []
+
+            def wide_fwd(i):
+                wd, ops_ = plan["wide"][i], sw["wide"][i]
+                desc = wd["desc"]
+                src = buf[..., wd["x_off"]:]       # channel slice: same rows, pointer advanced by x_off floats
+                rec = absmax_record_strided(src.data_ptr(), rows, wd["C"], Ctot, buf.device)
+                ctx.x_recs.append(rec)
+                desc.x_amax = rec.data_ptr()
+                desc.y_accumulate = wd["accumulate"]
+                conv_fwd_raw(desc, src, None, ops_["wT"], None if wd["accumulate"] else bias_all, buf, ops_["fwd"])
                 desc.y_accumulate = 0
+
+            wide_fwd(0)
+            for k in range(L):
+                if plan["h"] is not None and k == plan["h"]:
+                    wide_fwd(1)
+                n_own = plan["own_len"][k]
+                desc = cmap = inv = None
+                if n_own:
+                    g0 = plan["g0"][k]
+                    desc = ConvDesc(N, H, W, n_own * F, Ctot, 0, ksize, ksize, 1, F, Ctot, C0 + k * F, preact, 1)
+                    desc.y_accumulate = 1
+                    cmap, inv = channel_maps((F,) * n_own, preact, x0.device)
+                    conv_fwd_raw(desc, buf[..., C0 + g0 * F:], cmap, sw["wT_g"][k], None, buf)
+                    desc.y_accumulate = 0
                 descs.append(desc)
                 maps.append((cmap, inv))
-            ctx.desc_in, ctx.sw = desc_in, sw
+            ctx.sw = sw
             ctx.save_for_backward(buf, *saved)
             ctx.descs, ctx.maps = descs, maps
             return buf
@@ -475,42 +527,61 @@ class DenseBlockFunction(torch.autograd.Function):
         need_w = any(ctx.needs_input_grad[4:])
         grads = [None] * (3 * L)
         rows = N * H * W
-        if ctx.split:
-            sw, desc_in = ctx.sw, ctx.desc_in
-            grown, Ggrown = buf[..., C0:], G[..., C0:]
+        plan = ctx.plan
+        if plan is not None:
+            sw = ctx.sw
             dw_g = [None] * L
-            for k in reversed(range(1, L)):
-                desc = ctx.descs[k - 1]
-                cmap, inv = ctx.maps[k - 1]
+            dw_wide = [None] * len(plan["wide"])
+
+            def wide_bwd(i, need_dx):
+                # channels [C0 + d0*F, Ctot) of G are final here: the group sees them through its wide convolution
+                wd, ops_ = plan["wide"][i], sw["wide"][i]
+                desc = wd["desc"]
+                src, gsrc = buf[..., wd["x_off"]:], G[..., wd["x_off"]:]
+                n_out = (L - wd["d0"]) * F
+                dy_rec = absmax_record_strided(G.data_ptr() + 4 * (C0 + wd["d0"] * F), rows, n_out, Ctot, G.device)
+                desc.x_amax = ctx.x_recs[i].data_ptr()
+                desc.dy_amax = dy_rec.data_ptr()
                 if need_w:
-                    dw_g[k] = torch.empty_like(sw["w_g"][k])
-                    conv_wgrad_raw(desc, grown, cmap, G, dw_g[k])
-                # d/d(growth outputs 0 .. k-1) accumulates into channels [C0, Ck) of G
-                conv_dgrad_raw(desc, G, sw["w_g"][k], grown, inv, Ggrown, Ctot, True)
-            # channels [C0, Ctot) of G are final: the block input sees them through the wide convolution
-            dy_rec = absmax_record_strided(Ggrown.data_ptr(), rows, L * F, Ctot, G.device)
-            desc_in.dy_amax = dy_rec.data_ptr()
-            Ceff0 = sw["w_in"].shape[0] // 9
+                    dw = torch.empty_like(ops_["w"])
+                    conv_wgrad_raw(desc, src, None, G, dw)
+                    dw = dw.view(9, wd["nrows"], L - wd["d0"], F)
+                    order = wd["order"]
+                    if order is not None:
+                        back = torch.empty_like(order)
+                        back[order] = torch.arange(order.numel(), device=order.device)
+                        dw = dw.index_select(1, back)
+                    dw_wide[i] = dw
+                if need_dx:
+                    if not ops_["bwd_done"]:
+                        ops_["bwd"], ops_["bwd_done"] = prepare_filters(desc, 1, ops_["w"]), True
+                    conv_dgrad_raw(desc, G, ops_["w"], src, None, gsrc, Ctot, True, ops_["bwd"])
+                desc.dy_amax = None
+
+            for k in reversed(range(L)):
+                if plan["own_len"][k]:
+                    desc = ctx.descs[k]
+                    cmap, inv = ctx.maps[k]
+                    off = C0 + plan["g0"][k] * F
+                    if need_w:
+                        dw_g[k] = torch.empty_like(sw["w_g"][k])
+                        conv_wgrad_raw(desc, buf[..., off:], cmap, G, dw_g[k])
+                    # d/d(growth outputs of the layer's own half) accumulates into their channels of G
+                    conv_dgrad_raw(desc, G, sw["w_g"][k], buf[..., off:], inv, G[..., off:], Ctot, True)
+                if plan["h"] is not None and k == plan["h"]:
+                    wide_bwd(1, True)
+            wide_bwd(0, ctx.needs_input_grad[0])
             if need_w:
-                dw_in = torch.empty_like(sw["w_in"])
-                conv_wgrad_raw(desc_in, buf, None, G, dw_in)
-                dw_in = dw_in.view(9, Ceff0, L, F)
-                order = ctx.row_order
-                if order is not None:
-                    back = torch.empty_like(order)
-                    back[order] = torch.arange(order.numel(), device=order.device)
-                    dw_in = dw_in.index_select(1, back)
                 for k in range(L):
                     V2d, g, w, inv_norm = saved[4 * k:4 * k + 4]
-                    part = dw_in[:, :, k, :]
-                    dw = torch.cat([part, dw_g[k].view(9, -1, F)], dim=1) if k else part.contiguous()
+                    parts = [dw_wide[0][:, :, k, :]]
+                    if plan["h"] is not None and k >= plan["h"]:
+                        parts.append(dw_wide[1][:, :, k - plan["h"], :])
+                    if dw_g[k] is not None:
+                        parts.append(dw_g[k].view(9, -1, F))
+                    dw = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0].contiguous()
                     dV2d, dg = weightnorm_bwd(V2d, g, inv_norm, dw.view(-1, F))
                     grads[3 * k:3 * k + 2] = [dV2d.view(ctx.vshapes[k]), dg]
-            if ctx.needs_input_grad[0]:
-                if not sw["bwd_done"]:
-                    sw["bwd"], sw["bwd_done"] = prepare_filters(desc_in, 1, sw["w_in"]), True
-                conv_dgrad_raw(desc_in, G, sw["w_in"], buf, None, G, Ctot, True, sw["bwd"])
-            desc_in.dy_amax = None
         else:
             for k in reversed(range(L)):
                 V2d, g, w, inv_norm = saved[4 * k:4 * k + 4]

@@ -442,6 +442,8 @@ def test_wino_outlier_zero_and_nan(dev):
     ("crelu_single", 2, 8, 8, (64,), 9, "crelu"),
     ("celu_list", 2, 8, 16, (16, 8, 8), 8, "celu"),
     ("elu_single", 2, 8, 8, (64,), 8, "elu"),
+    ("crelu_halves", 2, 8, 8, (32, 16), 16, "crelu"),     # 16 layers: the first 8 outputs enter the last 8 layers as one 128 -> 128 convolution
+    ("elu_halves", 1, 8, 8, (64,), 16, "elu"),
 ], ids=lambda c: c[0])
 def test_dense_block_split_matches_chain(dev, case, monkeypatch):
     """A dense block computed as "block-input convolution (Winograd) + growth chain" (ops.DenseBlockFunction) against
