@@ -391,8 +391,10 @@ def _split_block_plan(N, H, W, C0, L, F, segs0, preact, device):
     channel), so the share of a FINISHED channel group in all later layers is one 3x3 convolution group -> (later
     layers) * F, wide enough for the Winograd F(4x4,3x3) passes:
       * the block input (C0 channels) into all L layers, before the chain starts;
-      * the first half of the growth outputs into the second half of the layers, once layer L/2 - 1 is done.
-    What stays on the 16-output growth kernels is each layer's chain inside its own half."""
+      * every group of `OTGAN_DENSE_GROUP` (default L/2: the first half into the second half) consecutive growth outputs
+        into all layers after the group, once its last layer is done -- as long as the library takes that convolution
+        on its Winograd path.
+    What stays on the 16-output growth kernels is each layer's chain inside its own group."""
     import os
     if os.environ.get("OTGAN_DENSE_SPLIT", "1") == "0" or F != 16 or L < 2 or any(int(c) % 4 for c in segs0):
         return None
@@ -403,19 +405,27 @@ def _split_block_plan(N, H, W, C0, L, F, segs0, preact, device):
     if not lib.otgan_conv2d_filter_bytes(ctypes.byref(desc_in), 0):
         return None
     wide = [{"desc": desc_in, "x_off": 0, "C": C0, "d0": 0, "row0": 0, "nrows": C0 * mult,
-             "order": _input_row_order(segs0, preact, device), "accumulate": 0}]
-    h = L // 2
-    desc_mid = ConvDesc(N, H, W, h * F, Ctot, 0, 3, 3, 1, (L - h) * F, Ctot, C0 + h * F, preact, 1)
-    if os.environ.get("OTGAN_DENSE_SPLIT_HALVES", "1") != "0" and h >= 1 and \
-            lib.otgan_conv2d_filter_bytes(ctypes.byref(desc_mid), 0):
-        wide.append({"desc": desc_mid, "x_off": C0, "C": h * F, "d0": h, "row0": C0 * mult, "nrows": h * F * mult,
-                     "order": _input_row_order((F,) * h, preact, device), "accumulate": 1})
-    else:
-        h = None
-    g0 = [0 if (h is None or k < h) else h for k in range(L)]
-    return {"wide": wide, "h": h, "g0": g0, "own_len": [k - g0[k] for k in range(L)],
+             "order": _input_row_order(segs0, preact, device), "accumulate": 0, "after": -1}]
+    # measured on the DenseNet step (L = 16): halves 51.9 ms, groups of four 52.9 (with 64-column convolutions allowed
+    # 53.5), pairs 60.7, block input only 58.2 -- a wide convolution with K = 128 is bound by its transforms
+    group = int(os.environ.get("OTGAN_DENSE_GROUP", str((L + 1) // 2)))
+    g0 = [0] * L          # growth outputs [0, g0[k]) reach layer k through wide convolutions
+    for s0 in range(0, L, group) if group > 0 else ():
+        s1 = min(s0 + group, L)
+        if s1 >= L:
+            break
+        n = s1 - s0
+        desc = ConvDesc(N, H, W, n * F, Ctot, 0, 3, 3, 1, (L - s1) * F, Ctot, C0 + s1 * F, preact, 1)
+        if not lib.otgan_conv2d_filter_bytes(ctypes.byref(desc), 0):
+            break         # later groups feed fewer layers still
+        wide.append({"desc": desc, "x_off": C0 + s0 * F, "C": n * F, "d0": s1, "row0": (C0 + s0 * F) * mult,
+                     "nrows": n * F * mult, "order": _input_row_order((F,) * n, preact, device), "accumulate": 1,
+                     "after": s1 - 1})
+        for k in range(s1, L):
+            g0[k] = s1
+    return {"wide": wide, "g0": g0, "own_len": [k - g0[k] for k in range(L)],
             "own_row0": [(C0 + g0[k] * F) * mult for k in range(L)],
-            "key": (H, W, C0, L, F, tuple(segs0), preact, h)}
+            "key": (H, W, C0, L, F, tuple(segs0), preact, tuple(g0))}
 
 
 class DenseBlockFunction(torch.autograd.Function):
@@ -430,14 +440,14 @@ class DenseBlockFunction(torch.autograd.Function):
 
     Finished channel groups are taken out of the chain (`_split_block_plan`): every layer's pre-activation is linear
     in act(earlier channels), so the block input's share of ALL L layers is one 3x3 convolution C0 -> L*F written
-    straight into channels [C0, Ctot) of the buffer, and the first half of the growth outputs enters the second half
-    of the layers through one more (L/2)*F -> (L/2)*F convolution added onto them -- GEMMs wide enough for the
+    straight into channels [C0, Ctot) of the buffer, and the finished first half of the growth outputs enters the second
+    half of the layers through one more (L/2)*F -> (L/2)*F convolution added onto them -- GEMMs wide enough for the
     Winograd F(4x4,3x3) passes on the split-precision engine (2.25 instead of 9 products per output); layer k then
-    only adds the convolution of the growth outputs of its own half (`y_accumulate`).  Backward mirrors it: the
-    growth layers' dgrad / wgrad see their own half only, each wide convolution takes one dgrad and one wgrad
+    only adds the convolution of the growth outputs of its own group (`y_accumulate`).  Backward mirrors it: the
+    growth layers' dgrad / wgrad see their own group only, each wide convolution takes one dgrad and one wgrad
     against the finished gradient of the channels it wrote.  Same sums in a different order; chosen when the
-    library routes the wide convolutions to its Winograd path (OTGAN_DENSE_SPLIT=0: never, OTGAN_DENSE_SPLIT_HALVES=0:
-    the block input only).
+    library routes the wide convolutions to its Winograd path (OTGAN_DENSE_SPLIT=0: never, OTGAN_DENSE_GROUP=n:
+    groups of n, 0: the block input only).
 
     args: x0 [N,H,W,C0] (concatenated initial list), then V_k, g_k, b_k for every layer."""
 
@@ -486,8 +496,6 @@ class DenseBlockFunction(torch.autograd.Function):
 
             wide_fwd(0)
             for k in range(L):
-                if plan["h"] is not None and k == plan["h"]:
-                    wide_fwd(1)
                 n_own = plan["own_len"][k]
                 desc = cmap = inv = None
                 if n_own:
@@ -499,6 +507,9 @@ class DenseBlockFunction(torch.autograd.Function):
                     desc.y_accumulate = 0
                 descs.append(desc)
                 maps.append((cmap, inv))
+                for i, wd in enumerate(plan["wide"]):
+                    if wd["after"] == k:       # the group that ends with layer k is finished
+                        wide_fwd(i)
             ctx.sw = sw
             ctx.save_for_backward(buf, *saved)
             ctx.descs, ctx.maps = descs, maps
@@ -559,6 +570,9 @@ class DenseBlockFunction(torch.autograd.Function):
                 desc.dy_amax = None
 
             for k in reversed(range(L)):
+                for i in reversed(range(1, len(plan["wide"]))):
+                    if plan["wide"][i]["after"] == k:
+                        wide_bwd(i, True)
                 if plan["own_len"][k]:
                     desc = ctx.descs[k]
                     cmap, inv = ctx.maps[k]
@@ -568,15 +582,11 @@ class DenseBlockFunction(torch.autograd.Function):
                         conv_wgrad_raw(desc, buf[..., off:], cmap, G, dw_g[k])
                     # d/d(growth outputs of the layer's own half) accumulates into their channels of G
                     conv_dgrad_raw(desc, G, sw["w_g"][k], buf[..., off:], inv, G[..., off:], Ctot, True)
-                if plan["h"] is not None and k == plan["h"]:
-                    wide_bwd(1, True)
             wide_bwd(0, ctx.needs_input_grad[0])
             if need_w:
                 for k in range(L):
                     V2d, g, w, inv_norm = saved[4 * k:4 * k + 4]
-                    parts = [dw_wide[0][:, :, k, :]]
-                    if plan["h"] is not None and k >= plan["h"]:
-                        parts.append(dw_wide[1][:, :, k - plan["h"], :])
+                    parts = [dw_wide[i][:, :, k - wd["d0"], :] for i, wd in enumerate(plan["wide"]) if wd["d0"] <= k]
                     if dw_g[k] is not None:
                         parts.append(dw_g[k].view(9, -1, F))
                     dw = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0].contiguous()
