@@ -1642,6 +1642,11 @@ inline WinoS2Geo wino_up3_wgrad_geo(const otgan_conv_desc* d, const Geo& g) {
   return w;
 }
 
+// ... and their input gradient, when the caller hands over filters prepared from the UN-folded weights (which = 3)
+inline bool wino_up3_dgrad_ok(const otgan_conv_desc* d, const Geo& g) {
+  return wino_up3_ok(d, g) && d->Cout % 4 == 0 && getenv("OTGAN_DISABLE_WINO_UP3_DGRAD") == nullptr;
+}
+
 inline int outer_unit_rows(int H) { return H >= 8 ? 8 : H; }
 
 struct WgPlan {
@@ -1949,6 +1954,7 @@ size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which) {
   }
   size_t s2 = 0;   // the strided Winograd path falls back to the generic one for list inputs: max of both
   if (which == 0 && wino_up3_ok(d, g)) s2 = align_up(sizeof(float) * WINO(wino_up3_fwd_ws_floats)(wino_up3_geo(d, g)), 256) + 256;
+  if (which == 1 && wino_up3_dgrad_ok(d, g)) s2 = align_up(sizeof(float) * WINO(wino_s2_dgrad_ws_floats)(wino_up3_wgrad_geo(d, g)), 256) + 256;
   if (which == 2 && wino_up3_wgrad_ok(d, g)) s2 = align_up(sizeof(float) * WINO(wino_s2_wgrad_ws_floats)(wino_up3_wgrad_geo(d, g)), 256) + 256;
   if (wino_s2_ok(d, g)) {
     const WinoS2Geo w = wino_s2_geo(d, g);
@@ -1978,7 +1984,11 @@ size_t otgan_conv2d_filter_bytes(const otgan_conv_desc* d, int which) {
   if (make_geo(d, &g) != OTGAN_OK || which < 0 || which > 3) return 0;
   if (wino_s2_ok(d, g)) return which < 2 ? sizeof(float) * WINO(wino_s2_filter_floats)(wino_s2_geo(d, g), which) : 0;
   if (wino_ok(d, g)) return sizeof(float) * WINO(wino_filter_floats)(wino_geo(d), which);   // 2, 3: from un-folded weights
-  if (wino_up3_ok(d, g)) return which == 2 ? sizeof(float) * WINO(wino_up3_filter_floats)(wino_up3_geo(d, g)) : 0;   // forward only
+  if (wino_up3_ok(d, g)) {   // from the un-folded weights: forward (2), input gradient (3)
+    if (which == 2) return sizeof(float) * WINO(wino_up3_filter_floats)(wino_up3_geo(d, g));
+    if (which == 3 && wino_up3_dgrad_ok(d, g)) return sizeof(float) * WINO(wino_s2_filter_floats)(wino_up3_wgrad_geo(d, g), 1);
+    return 0;
+  }
   return 0;
 }
 
@@ -2006,7 +2016,8 @@ int otgan_conv2d_prepare_filters_f32(const otgan_conv_desc* d, int which, const 
   if (wino_s2_ok(d, g)) {
     rc = WINO(wino_s2_prepare_filters)(wino_s2_geo(d, g), which, w, (float*)filters, s);
   } else if (!wino_ok(d, g) && wino_up3_ok(d, g)) {
-    rc = WINO(wino_up3_prepare_filters)(wino_up3_geo(d, g), w, (float*)filters, s);
+    if (which == 3) rc = WINO(wino_s2_prepare_filters)(wino_up3_wgrad_geo(d, g), 1, w, (float*)filters, s);
+    else rc = WINO(wino_up3_prepare_filters)(wino_up3_geo(d, g), w, (float*)filters, s);
   } else {
     const FoldTab f = make_fold(d, g);
     rc = WINO(wino_prepare_filters)(wino_geo(d), which, w, f.woff[1] - f.woff[0], (float*)filters, s);
@@ -2281,6 +2292,18 @@ static int conv2d_dgrad_impl(const otgan_conv_desc* d, const float* dy, const fl
     ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * (double)d->N * d->H * d->W * 9.0 * d->Cout * g.Ceff, 0.0, s);
     rc = dense16_dgrad(dg, dy, d->ldy, d->y_coff, w, x, inv, dx, lddx, accumulate, s);
     OTGAN_CHECK_LAUNCH("conv2d dgrad (dense16)");
+    return rc;
+  }
+  if (filters && !wino_ok(d, g) && wino_up3_dgrad_ok(d, g)) {
+    // prepared filters of a 3x3 upsampling layer exist only for the Winograd input gradient, and they (and `w`) are
+    // made from the UN-folded weights: nothing else below may run with them
+    OTGAN_CHECK_ARG(inv == nullptr && lddx % 4 == 0 && aligned16(dy) && aligned16(dx) && aligned16(x) && aligned16(workspace) &&
+                        workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 1),
+                    "winograd dgrad of a 3x3 upsampling layer: single-tensor input, 16-byte aligned operands, workspace");
+    const WinoS2Geo wg = wino_up3_wgrad_geo(d, g);
+    ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * kWinoFreq * (double)wino_s2_tiles(wg) * g.Ceff * d->Cout, 0.0, s);
+    rc = WINO(wino_s2_dgrad)(wg, dy, w, x, dx, lddx, accumulate, (float*)workspace, s, filters);
+    OTGAN_CHECK_LAUNCH("conv2d dgrad (winograd, 3x3 on upsampled input)");
     return rc;
   }
   if (wino_s2_ok(d, g) && inv == nullptr && lddx % 4 == 0 && aligned16(dy) && aligned16(w) && aligned16(dx) &&

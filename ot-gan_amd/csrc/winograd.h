@@ -50,8 +50,9 @@ struct WinoS2Geo {
   // wT: [Cout][9*Ceff], w: [9][Ceff][Cout].  Same kernels, same three passes.
   int plain = 0;
   // plain only, 1: x is stored at half resolution ([N, H/2, W/2, ldx]) and read through a 2x nearest-neighbour
-  // upsample (the DenseNet generator's transition layers); H, W stay the grid the convolution runs on.  Input
-  // transform and weight gradient only (dgrad keeps the folded path).
+  // upsample (the DenseNet generator's transition layers); H, W stay the grid the convolution runs on.  Weight
+  // gradient (the input transform reads through the upsample) and input gradient (the output transform sums the
+  // 2x2 groups of its 4x4 tile onto the stored pixel).
   int up = 0;
   int y_accumulate = 0;   // forward: y += result + bias (otgan_conv_desc::y_accumulate)
 };

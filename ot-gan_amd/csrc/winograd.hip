@@ -333,6 +333,7 @@ struct InArgs {
   int s2_skip;           // >= 0: strided layer, the (class = blockIdx.z, f) blocks absent under this index are not stored
   u16* P;                // non-null: write the operand as split planes (blocked layout, op_off) instead of V
   int up;                // 1: the view is a stored small image read through a 2x nearest-neighbour upsample (H, W = upsampled)
+  int Cpad;              // > C: k columns [C, Cpad) of the operand are written as zeros (K padded to the GEMM's granule)
 };
 template <int ACT>
 __device__ __forceinline__ f32x4 wino_act(f32x4 v) {
@@ -351,7 +352,7 @@ template <int ACT, bool DOUBLED>
 __global__ __launch_bounds__(256) void wino_input_kernel(InArgs a) {
   long t;
   int k4;
-  if (!op_thread(a.P != nullptr, a.T, a.C >> 2, t, k4)) return;
+  if (!op_thread(a.P != nullptr, a.T, (a.Cpad > a.C ? a.Cpad : a.C) >> 2, t, k4)) return;
   const int c = k4 * 4;
   const int tb = (int)(t % a.TW), ta = (int)((t / a.TW) % a.TH);
   const long n = t / ((long)a.TW * a.TH);
@@ -359,6 +360,10 @@ __global__ __launch_bounds__(256) void wino_input_kernel(InArgs a) {
   const View v = a.v[cls];
   const int pass = DOUBLED ? (int)blockIdx.y : 0;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  if (c >= a.C) {   // K padding (single-view, non-doubled callers only)
+    for (int f = 0; f < WF; ++f) st_operand(a.V, a.P, a.T, a.ldv, f, t, c, zero);
+    return;
+  }
   f32x4 T[WA][WA];
 #pragma unroll
   for (int j = 0; j < WA; ++j) {
@@ -634,13 +639,18 @@ __global__ __launch_bounds__(256) void wino_s2_filter_fwd_kernel(const float* __
 
 // backward filters (flipped): U'[f][cls*Ceff + ce][co] from w[kh*5+kw][ce][co]
 __global__ __launch_bounds__(256) void wino_s2_filter_bwd_kernel(const float* __restrict__ w, int Ceff, int Cout,
-                                                               float* __restrict__ U, u16* P, int plain) {
+                                                               float* __restrict__ U, u16* P, int plain, int Kp) {
   long r;                               // cls*Ceff + ce
   int k4;
   const long rows = (plain ? 1L : 4L) * Ceff;
   const int kk = plain ? 3 : 5;
-  if (!op_thread(P != nullptr, rows, Cout >> 2, r, k4)) return;
+  if (!op_thread(P != nullptr, rows, Kp >> 2, r, k4)) return;
   const int co = k4 * 4;
+  if (co >= Cout) {   // K padding: zero columns [Cout, Kp)
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < WF; ++f) st_operand(U, P, rows, Kp, f, r, co, z);
+    return;
+  }
   const int ce = (int)(r % Ceff), cls = (int)(r / Ceff);
   const int pi = cls >> 1, pj = cls & 1;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -652,7 +662,7 @@ __global__ __launch_bounds__(256) void wino_s2_filter_bwd_kernel(const float* __
       const int kh = plain ? 2 - i : s2_tap(pi, 2 - i), kw = plain ? 2 - j : s2_tap(pj, 2 - j);
       g[i][j] = (kh >= 0 && kw >= 0) ? ld4(w + ((long)(kh * kk + kw) * Ceff + ce) * Cout + co) : zero;
     }
-  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, rows, Cout, f, r, co, v); });
+  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, rows, Kp, f, r, co, v); });
 }
 
 // dw[kh*5+kw][ce][co] = (G^T dU G)[i][j] of the tap's class; dU[f] = sum of slab[split][f][cls*Ceff+ce][co]
@@ -705,6 +715,8 @@ struct OutS2Args {
   const float* Xh;
   int accumulate;
   int plain;            // one class, nothing structurally zero (a 3x3 stride-1 layer)
+  int up;               // plain only: x / dx are half-resolution images behind a 2x nearest-neighbour upsample --
+                        // the 4x4 tile of gradients is summed over its 2x2 groups
 };
 // (A^T M A) of the class's M, rows i0 .. i0+1 only (two output rows at a time keep the register count down)
 // DOUBLED (CReLU / CELU): a thread owns TWO channels (both halves of each): the two 36-value column passes of four
@@ -746,6 +758,46 @@ __global__ __launch_bounds__(256) void wino_s2_output_kernel(OutS2Args a) {
 #pragma unroll
       for (int i = 0; i < WM; ++i) Sn[DOUBLED ? i : 0][j] = o[i];
     }
+  }
+  if (a.up) {
+    VT pp[2][2], pn[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) pp[i][j] = pn[i][j] = zero;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      VT yp[WM], yn[WM];
+      at1(Sp[i], yp);
+      if (DOUBLED) at1(Sn[DOUBLED ? i : 0], yn);
+#pragma unroll
+      for (int j = 0; j < WM; ++j) {
+        pp[i >> 1][j >> 1] += yp[j];
+        if (DOUBLED) pn[i >> 1][j >> 1] += yn[j];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        VT o = pp[i][j];
+        if (ACT != 0 || DOUBLED) {
+          const VT x4 = ldv(xv.p + n * xv.sn + (2 * ta + i) * xv.sh + (2 * tb + j) * xv.sw + c);
+#pragma unroll
+          for (int q = 0; q < VW; ++q) {
+            const float xq = x4[q];
+            float dp = 1.f, dn = 1.f;
+            if (ACT == 1) { dp = xq > 0.f ? 1.f : 0.f; dn = -xq > 0.f ? 1.f : 0.f; }
+            if (ACT == 2) { dp = xq > 0.f ? 1.f : expf(xq); dn = -xq > 0.f ? 1.f : expf(-xq); }
+            o[q] = dp * pp[i][j][q];
+            if (DOUBLED) o[q] -= dn * pn[i][j][q];
+          }
+        }
+        float* dst = dv.p + n * dv.sn + (2 * ta + i) * dv.sh + (2 * tb + j) * dv.sw + c;
+        if (a.accumulate) o += ldv(dst);
+        *reinterpret_cast<VT*>(dst) = o;
+      }
+    return;
   }
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
@@ -1464,6 +1516,9 @@ void s2_views(const WinoS2Geo& g, P base, int ld, V (&v)[4]) {
   v[0].sw = ld;
 }
 inline int s2_k(const WinoS2Geo& g) { return wino_s2_classes(g) * g.Ceff; }
+// contraction length of the input-gradient GEMM: Cout, padded (zero columns in both operands) to the split-precision
+// GEMM's K granule for the plain layers (208, 144 outputs of the DenseNet transitions)
+inline int s2_kp(const WinoS2Geo& g) { return (g.plain && use_x3()) ? (g.Cout + X3_BK - 1) / X3_BK * X3_BK : g.Cout; }
 inline int s2_taps(const WinoS2Geo& g) { return g.plain ? 9 : 25; }
 
 int s2_wgrad_splits(const WinoS2Geo& g) {
@@ -1507,8 +1562,9 @@ void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, u16* VP, h
 
 size_t wino_s2_fwd_ws_floats(const WinoS2Geo& g) {
   const size_t T = (size_t)wino_s2_tiles(g), K4 = (size_t)s2_k(g);
-  return operand_floats(op_elems(T, K4)) + operand_floats(op_elems(T, g.Cout)) +
-         operand_floats(std::max(op_elems(g.Cout, K4), op_elems(K4, g.Cout))) + WF * T * K4 + x3_stream_floats();
+  const size_t Kp = (size_t)s2_kp(g);
+  return operand_floats(op_elems(T, K4)) + operand_floats(op_elems(T, Kp)) +
+         operand_floats(std::max(op_elems(g.Cout, K4), op_elems(K4, Kp))) + WF * T * K4 + x3_stream_floats();
 }
 size_t wino_s2_dgrad_ws_floats(const WinoS2Geo& g) { return wino_s2_fwd_ws_floats(g); }
 size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g) {
@@ -1520,7 +1576,7 @@ size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g) {
 }
 
 size_t wino_s2_filter_floats(const WinoS2Geo& g, int which) {
-  return which == 0 ? operand_floats(op_elems(g.Cout, s2_k(g))) : operand_floats(op_elems(s2_k(g), g.Cout));
+  return which == 0 ? operand_floats(op_elems(g.Cout, s2_k(g))) : operand_floats(op_elems(s2_k(g), s2_kp(g)));
 }
 int wino_s2_prepare_filters(const WinoS2Geo& g, int which, const float* w, float* out, hipStream_t s) {
   if (which == 0) {
@@ -1529,10 +1585,11 @@ int wino_s2_prepare_filters(const WinoS2Geo& g, int which, const float* w, float
     hipLaunchKernelGGL(wino_s2_filter_fwd_kernel, dim3(op_grid(g.Cout, s2_k(g) / 4)), dim3(256), 0, s, w, g.Ceff, g.Cout, out,
                        x3 ? op_planes(out) : nullptr, g.plain);
   } else {
-    const bool x3 = use_x3() && g.Cout % X3_BK == 0;
+    const int Kp = s2_kp(g);
+    const bool x3 = use_x3() && Kp % X3_BK == 0;
     if (x3) op_scales(w, 1, s2_taps(g) * g.Ceff * g.Cout, 0, out, kGainG, 1.f, false, s);
-    hipLaunchKernelGGL(wino_s2_filter_bwd_kernel, dim3(op_grid(s2_k(g), g.Cout / 4)), dim3(256), 0, s, w, g.Ceff,
-                       g.Cout, out, x3 ? op_planes(out) : nullptr, g.plain);
+    hipLaunchKernelGGL(wino_s2_filter_bwd_kernel, dim3(op_grid(s2_k(g), Kp / 4)), dim3(256), 0, s, w, g.Ceff,
+                       g.Cout, out, x3 ? op_planes(out) : nullptr, g.plain, Kp);
   }
   return OTGAN_OK;
 }
@@ -1578,10 +1635,11 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   const long T = wino_s2_tiles(g);
   const int K4 = s2_k(g);
   const int OH = wino_s2_out_h(g), OW = wino_s2_out_w(g);
-  const bool x3 = use_x3() && g.Cout % X3_BK == 0;
-  const size_t nV = op_elems(T, g.Cout), nU = op_elems(K4, g.Cout);
-  float* DV = ws;                             // [WF][T][Cout]
-  float* Uws = DV + operand_floats(nV);       // [WF][4*Ceff][Cout]
+  const int Kp = s2_kp(g);                    // Cout, or Cout padded with zero columns (plain layers)
+  const bool x3 = use_x3() && Kp % X3_BK == 0;
+  const size_t nV = op_elems(T, Kp), nU = op_elems(K4, Kp);
+  float* DV = ws;                             // [WF][T][Kp]
+  float* Uws = DV + operand_floats(nV);       // [WF][4*Ceff][Kp]
   float* Xh = Uws + operand_floats(nU);       // [WF][T][4*Ceff]
   float* U = prep ? const_cast<float*>(prep) : Uws;
   u16* VP = x3 ? op_planes(DV) : nullptr;
@@ -1591,19 +1649,20 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   memset(&ia, 0, sizeof(ia));
   ia.s2_skip = -1;
   ia.v[0].p = dy + g.y_coff; ia.v[0].sn = (long)OH * OW * g.ldy; ia.v[0].sh = (long)OW * g.ldy; ia.v[0].sw = g.ldy;
-  ia.H = OH; ia.W = OW; ia.TH = OH / WM; ia.TW = OW / WM; ia.C = g.Cout; ia.T = T; ia.ldv = g.Cout; ia.V = DV;
+  ia.H = OH; ia.W = OW; ia.TH = OH / WM; ia.TW = OW / WM; ia.C = g.Cout; ia.T = T; ia.ldv = Kp; ia.V = DV;
   ia.P = VP;
+  ia.Cpad = Kp;
   if (x3) op_scales(dy + g.y_coff, (long)g.N * OH * OW, g.Cout, g.ldy, DV, kGainBt, 1.f, false, s, g.dy_amax);
-  hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cout / 4), 1, 1), dim3(256), 0, s, ia);
+  hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, Kp / 4), 1, 1), dim3(256), 0, s, ia);
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.Ap = VP; b.Bp = UP; b.pA = (long)nV; b.pB = (long)nU;
   if (x3) { b.hdrA = op_hdr(DV); b.hdrB = op_hdr(U); }
-  b.A = DV; b.B = U; b.C = Xh; b.M = (int)T; b.N = K4; b.K = g.Cout;
-  b.lda = g.Cout; b.ldb = g.Cout; b.ldc = K4;
-  b.sA = T * g.Cout; b.sB = (long)K4 * g.Cout; b.sC = T * K4;
+  b.A = DV; b.B = U; b.C = Xh; b.M = (int)T; b.N = K4; b.K = Kp;
+  b.lda = Kp; b.ldb = Kp; b.ldc = K4;
+  b.sA = T * Kp; b.sB = (long)K4 * Kp; b.sC = T * K4;
   b.tiles_m = (int)((T + Cfg::BM - 1) / Cfg::BM); b.tiles_n = (K4 + Cfg::BN - 1) / Cfg::BN;
-  b.kt_per_split = (g.Cout + Cfg::BK - 1) / Cfg::BK;
+  b.kt_per_split = (Kp + Cfg::BK - 1) / Cfg::BK;
   b.seg_mode = g.plain ? 0 : 2; b.seg_len = g.Ceff; b.seg_skip = WA - 1;
   b.sk_partial = x3_stream_area(ws, wino_s2_dgrad_ws_floats(g));
   launch_bgemm<false>(b, 1, s);
@@ -1612,6 +1671,11 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   s2_views(g, dx, lddx, oa.dx);
   s2_views(g, x, g.ldx, oa.x);
   oa.plain = g.plain;
+  if (g.up) {   // x and dx live on the half-resolution grid
+    oa.up = 1;
+    oa.dx[0].sn = (long)(g.H / 2) * (g.W / 2) * lddx; oa.dx[0].sh = (long)(g.W / 2) * lddx;
+    oa.x[0].sn = (long)(g.H / 2) * (g.W / 2) * g.ldx; oa.x[0].sh = (long)(g.W / 2) * g.ldx;
+  }
   oa.TH = OH / WM; oa.TW = OW / WM; oa.C = g.C; oa.Ceff = g.Ceff; oa.T = T; oa.ldm = K4; oa.Xh = Xh;
   oa.accumulate = accumulate;
   const dim3 grid(grid1(T * (g.C / (g.doubled ? 2 : 4))), 1, wino_s2_classes(g)), blk(256);
