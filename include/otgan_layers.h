@@ -165,6 +165,44 @@ int otgan_weightnorm_bwd_f32(const float* V, const float* g, const float* inv_no
                              const float* dw, int K, int Cout, float* dV, float* dg,
                              float* scratch, void* stream);
 
+/*
+ * The same two passes for MANY layers with 16 outputs each (the growth layers of a dense block,
+ * models/densenet.py:11-16) in one launch per OTGAN_WN_MAX_LAYERS layers: `layers` is a HOST array, the pointers in it
+ * are device pointers (16-byte aligned).  Deterministic.
+ *   forward: w[K][16], wT[16][K] (nullable), inv[16] from V[K][16], g[16].
+ *   backward: dV[taps*Ceff][16], dg[16] from the weight gradient given as up to three PARTS per layer, each holding
+ *     nrows consecutive effective-channel rows of every tap: row (tap, e) of part i is the 16 floats at
+ *     p + ((tap * nrows + perm[e]) * rstride)   (perm: device int32 array or NULL = identity; unused parts: nrows 0)
+ *     -- the layout in which a dense block computed as wide convolutions + growth chains (ops.py DenseBlockFunction)
+ *     leaves its weight gradients: a column slice of each wide convolution's dw, then the layer's own chain.
+ */
+#define OTGAN_WN_MAX_LAYERS 16
+typedef struct otgan_wn_fwd_layer {
+  const float* V;
+  const float* g;
+  float* w;
+  float* wT;
+  float* inv;
+  int K;
+} otgan_wn_fwd_layer;
+typedef struct otgan_wn_part {
+  const float* p;
+  const int32_t* perm;
+  int nrows;
+  int rstride;
+} otgan_wn_part;
+typedef struct otgan_wn_bwd_layer {
+  const float* V;
+  const float* g;
+  const float* inv;
+  float* dV;
+  float* dg;
+  int Ceff, taps;
+  otgan_wn_part part[3];
+} otgan_wn_bwd_layer;
+int otgan_weightnorm_fwd_batched16_f32(const otgan_wn_fwd_layer* layers, int n_layers, void* stream);
+int otgan_weightnorm_bwd_batched16_f32(const otgan_wn_bwd_layer* layers, int n_layers, void* stream);
+
 /* out[c] = sum_r a[r*lda + c]   (bias gradients; rows = pixels).  scratch: 256*cols floats */
 int otgan_colsum_f32(const float* a, long rows, int cols, long lda, float* out, float* scratch,
                      void* stream);

@@ -17,6 +17,23 @@ class ConvDesc(ctypes.Structure):
 
 P_DESC = ctypes.POINTER(ConvDesc)
 
+
+class WnFwdLayer(ctypes.Structure):
+    """Mirror of `otgan_wn_fwd_layer`."""
+    _fields_ = [("V", c_fp), ("g", c_fp), ("w", c_fp), ("wT", c_fp), ("inv", c_fp), ("K", c_int)]
+
+
+class WnPart(ctypes.Structure):
+    """Mirror of `otgan_wn_part`."""
+    _fields_ = [("p", c_fp), ("perm", c_fp), ("nrows", c_int), ("rstride", c_int)]
+
+
+class WnBwdLayer(ctypes.Structure):
+    """Mirror of `otgan_wn_bwd_layer`."""
+    _fields_ = [("V", c_fp), ("g", c_fp), ("inv", c_fp), ("dV", c_fp), ("dg", c_fp), ("Ceff", c_int), ("taps", c_int),
+                ("part", WnPart * 3)]
+
+
 SIGNATURES = {
     "otgan_conv2d_workspace_bytes": (c_size_t, [P_DESC, c_int]),
     "otgan_absmax_f32": (c_int, [c_fp, c_long, c_int, c_long, c_fp, c_fp]),
@@ -33,6 +50,8 @@ SIGNATURES = {
                                           c_size_t, c_fp]),
     "otgan_weightnorm_fwd_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp]),
     "otgan_weightnorm_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp]),
+    "otgan_weightnorm_fwd_batched16_f32": (c_int, [ctypes.POINTER(WnFwdLayer), c_int, c_fp]),
+    "otgan_weightnorm_bwd_batched16_f32": (c_int, [ctypes.POINTER(WnBwdLayer), c_int, c_fp]),
     "otgan_colsum_f32": (c_int, [c_fp, c_long, c_int, c_long, c_fp, c_fp, c_fp]),
     "otgan_glu_fwd_f32": (c_int, [c_fp, c_long, c_int, c_fp, c_fp]),
     "otgan_glu_bwd_f32": (c_int, [c_fp, c_fp, c_long, c_int, c_fp, c_fp]),

@@ -179,6 +179,99 @@ __global__ void weightnorm_dg_kernel(const float* __restrict__ dot, const float*
   if (c < Cout) dg[c] = dot[c] * inv[c];
 }
 
+// ---- weight norm of the 16-output growth layers of a dense block, all layers in one launch ---------------
+// (DenseNet: 96 such layers per network; per layer the three / five launches above are a few microseconds of work
+// each and the step's Python + launch overhead between them left the GPU idle.)  One workgroup per layer: thread
+// (row lane, column quad) walks the rows K of [K][16] matrices with float4 loads, fixed-order LDS tree over the 128
+// row lanes (deterministic), second walk writes the results.
+constexpr int kWnThreads = 512, kWnRowLanes = kWnThreads / 4;
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+struct WnFwdArgs {
+  otgan_wn_fwd_layer l[OTGAN_WN_MAX_LAYERS];
+};
+struct WnBwdArgs {
+  otgan_wn_bwd_layer l[OTGAN_WN_MAX_LAYERS];
+};
+__device__ __forceinline__ float4 wn_tree(float4 v, float4 (*red)[4], int rl, int cq) {
+  red[rl][cq] = v;
+  __syncthreads();
+#pragma unroll
+  for (int h = kWnRowLanes / 2; h > 0; h >>= 1) {
+    if (rl < h) {
+      const float4 a = red[rl][cq], b = red[rl + h][cq];
+      red[rl][cq] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+    __syncthreads();
+  }
+  const float4 r = red[0][cq];
+  __syncthreads();
+  return r;
+}
+__global__ __launch_bounds__(kWnThreads) void wn_fwd_batched_kernel(WnFwdArgs a) {
+  __shared__ float4 red[kWnRowLanes][4];
+  const otgan_wn_fwd_layer& L = a.l[blockIdx.x];
+  const int cq = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = rl; r < L.K; r += kWnRowLanes) {
+    const float4 v = *reinterpret_cast<const float4*>(L.V + (long)r * 16 + 4 * cq);
+    s.x += v.x * v.x; s.y += v.y * v.y; s.z += v.z * v.z; s.w += v.w * v.w;
+  }
+  s = wn_tree(s, red, rl, cq);
+  const float4 g = *reinterpret_cast<const float4*>(L.g + 4 * cq);
+  const float4 iv = make_float4(rsqrtf(fmaxf(s.x, 1e-12f)), rsqrtf(fmaxf(s.y, 1e-12f)), rsqrtf(fmaxf(s.z, 1e-12f)),
+                                rsqrtf(fmaxf(s.w, 1e-12f)));
+  if (rl == 0) *reinterpret_cast<float4*>(L.inv + 4 * cq) = iv;
+  const float4 sc = make_float4(g.x * iv.x, g.y * iv.y, g.z * iv.z, g.w * iv.w);
+  for (int r = rl; r < L.K; r += kWnRowLanes) {
+    const float4 v = *reinterpret_cast<const float4*>(L.V + (long)r * 16 + 4 * cq);
+    const float4 w = make_float4(v.x * sc.x, v.y * sc.y, v.z * sc.z, v.w * sc.w);
+    *reinterpret_cast<float4*>(L.w + (long)r * 16 + 4 * cq) = w;
+    if (L.wT) {
+      float* t = L.wT + (long)(4 * cq) * L.K + r;
+      t[0] = w.x; t[L.K] = w.y; t[2L * L.K] = w.z; t[3L * L.K] = w.w;
+    }
+  }
+}
+// dw row (tap, e) of a layer = row e - (rows of the parts before) of the part it falls into
+__device__ __forceinline__ const float* wn_dw_row(const otgan_wn_bwd_layer& L, int tap, int e) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const otgan_wn_part& p = L.part[i];
+    if (e < p.nrows || i == 2) {
+      const int ee = p.perm ? p.perm[e] : e;
+      return p.p + ((long)tap * p.nrows + ee) * p.rstride;
+    }
+    e -= p.nrows;
+  }
+  return nullptr;
+}
+__global__ __launch_bounds__(kWnThreads) void wn_bwd_batched_kernel(WnBwdArgs a) {
+  __shared__ float4 red[kWnRowLanes][4];
+  const otgan_wn_bwd_layer& L = a.l[blockIdx.x];
+  const int cq = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int K = L.taps * L.Ceff;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = rl; r < K; r += kWnRowLanes) {
+    const int tap = r / L.Ceff, e = r - tap * L.Ceff;
+    const float4 d = *reinterpret_cast<const float4*>(wn_dw_row(L, tap, e) + 4 * cq);
+    const float4 v = *reinterpret_cast<const float4*>(L.V + (long)r * 16 + 4 * cq);
+    s.x += d.x * v.x; s.y += d.y * v.y; s.z += d.z * v.z; s.w += d.w * v.w;
+  }
+  s = wn_tree(s, red, rl, cq);
+  const float4 g = *reinterpret_cast<const float4*>(L.g + 4 * cq);
+  const float4 iv = *reinterpret_cast<const float4*>(L.inv + 4 * cq);
+  if (rl == 0) *reinterpret_cast<float4*>(L.dg + 4 * cq) = make_float4(s.x * iv.x, s.y * iv.y, s.z * iv.z, s.w * iv.w);
+  const float4 sc = make_float4(g.x * iv.x, g.y * iv.y, g.z * iv.z, g.w * iv.w);
+  const float4 pr = make_float4(s.x * iv.x * iv.x, s.y * iv.y * iv.y, s.z * iv.z * iv.z, s.w * iv.w * iv.w);
+  for (int r = rl; r < K; r += kWnRowLanes) {
+    const int tap = r / L.Ceff, e = r - tap * L.Ceff;
+    const float4 d = *reinterpret_cast<const float4*>(wn_dw_row(L, tap, e) + 4 * cq);
+    const float4 v = *reinterpret_cast<const float4*>(L.V + (long)r * 16 + 4 * cq);
+    *reinterpret_cast<float4*>(L.dV + (long)r * 16 + 4 * cq) =
+        make_float4(sc.x * (d.x - v.x * pr.x), sc.y * (d.y - v.y * pr.y), sc.z * (d.z - v.z * pr.z), sc.w * (d.w - v.w * pr.w));
+  }
+}
+
 // ---- GLU / tanh --------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
@@ -366,6 +459,58 @@ int otgan_weightnorm_bwd_f32(const float* V, const float* g, const float* inv_no
   hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, V, g, inv_norm, dw,
                      scratch, total, Cout, dV);
   OTGAN_CHECK_LAUNCH("weightnorm bwd");
+  return OTGAN_OK;
+}
+
+int otgan_weightnorm_fwd_batched16_f32(const otgan_wn_fwd_layer* layers, int n_layers, void* stream) {
+  OTGAN_CHECK_ARG(layers && n_layers > 0, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  double bytes = 0.0;
+  for (int i = 0; i < n_layers; ++i) {
+    const otgan_wn_fwd_layer& l = layers[i];
+    OTGAN_CHECK_ARG(l.V && l.g && l.w && l.inv && l.K > 0, "layer %d: null pointer or empty", i);
+    OTGAN_CHECK_ARG(aligned16(l.V) && aligned16(l.g) && aligned16(l.w) && aligned16(l.inv), "layer %d: 16-byte alignment", i);
+    bytes += 4.0 * 4 * (double)l.K * 16;
+  }
+  ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, bytes, s);
+  for (int i0 = 0; i0 < n_layers; i0 += OTGAN_WN_MAX_LAYERS) {
+    const int n = n_layers - i0 < OTGAN_WN_MAX_LAYERS ? n_layers - i0 : OTGAN_WN_MAX_LAYERS;
+    WnFwdArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int i = 0; i < n; ++i) a.l[i] = layers[i0 + i];
+    hipLaunchKernelGGL(wn_fwd_batched_kernel, dim3(n), dim3(kWnThreads), 0, s, a);
+  }
+  OTGAN_CHECK_LAUNCH("weightnorm fwd (batched)");
+  return OTGAN_OK;
+}
+
+int otgan_weightnorm_bwd_batched16_f32(const otgan_wn_bwd_layer* layers, int n_layers, void* stream) {
+  OTGAN_CHECK_ARG(layers && n_layers > 0, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  double bytes = 0.0;
+  for (int i = 0; i < n_layers; ++i) {
+    const otgan_wn_bwd_layer& l = layers[i];
+    OTGAN_CHECK_ARG(l.V && l.g && l.inv && l.dV && l.dg && l.Ceff > 0 && l.taps > 0, "layer %d: null pointer or empty", i);
+    OTGAN_CHECK_ARG(aligned16(l.V) && aligned16(l.g) && aligned16(l.inv) && aligned16(l.dV) && aligned16(l.dg), "layer %d: 16-byte alignment", i);
+    int rows = 0;
+    for (int p = 0; p < 3; ++p) {
+      const otgan_wn_part& q = l.part[p];
+      OTGAN_CHECK_ARG(q.nrows >= 0 && (q.nrows == 0 || (q.p && aligned16(q.p) && q.rstride >= 16 && q.rstride % 4 == 0)),
+                      "layer %d part %d: pointer / stride", i, p);
+      rows += q.nrows;
+    }
+    OTGAN_CHECK_ARG(rows == l.Ceff, "layer %d: the parts hold %d rows per tap, Ceff is %d", i, rows, l.Ceff);
+    bytes += 4.0 * 5 * (double)l.taps * l.Ceff * 16;
+  }
+  ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, bytes, s);
+  for (int i0 = 0; i0 < n_layers; i0 += OTGAN_WN_MAX_LAYERS) {
+    const int n = n_layers - i0 < OTGAN_WN_MAX_LAYERS ? n_layers - i0 : OTGAN_WN_MAX_LAYERS;
+    WnBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int i = 0; i < n; ++i) a.l[i] = layers[i0 + i];
+    hipLaunchKernelGGL(wn_bwd_batched_kernel, dim3(n), dim3(kWnThreads), 0, s, a);
+  }
+  OTGAN_CHECK_LAUNCH("weightnorm bwd (batched)");
   return OTGAN_OK;
 }
 

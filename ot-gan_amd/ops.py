@@ -5,12 +5,13 @@ PyTorch stream; PyTorch only owns the device memory and the backward graph.  The
 fallback: CPU tensors raise OtganError.
 """
 import ctypes
+import os
 from collections import OrderedDict
 
 import torch
 
 from . import _lib
-from ._lib_layers import ConvDesc
+from ._lib_layers import ConvDesc, WnBwdLayer, WnFwdLayer
 
 ACT = {None: 0, "none": 0, "crelu": 1, "celu": 2, "elu": 3, "relu": 4}
 DOUBLED = (1, 2)
@@ -344,6 +345,77 @@ def _input_row_order(segs0, preact, device):
     return hit
 
 
+def _aligned16(*ts):
+    return all(t is None or t.data_ptr() % 16 == 0 for t in ts)
+
+
+def weightnorm_fwd_block(V2ds, gs):
+    """weightnorm_fwd of every 16-output layer of a dense block in ONE launch (otgan_weightnorm_fwd_batched16_f32);
+    the results are views of three block-wide buffers.  Returns [(w, wT, inv_norm)] per layer."""
+    L = len(V2ds)
+    Ks = [int(v.shape[0]) for v in V2ds]
+    dev, dt = V2ds[0].device, V2ds[0].dtype
+    w_all = torch.empty(sum(Ks) * 16, dtype=dt, device=dev)
+    wT_all = torch.empty(sum(Ks) * 16, dtype=dt, device=dev)
+    inv_all = torch.empty(L * 16, dtype=dt, device=dev)
+    arr = (WnFwdLayer * L)()
+    out, off = [], 0
+    wp, tp, ip = w_all.data_ptr(), wT_all.data_ptr(), inv_all.data_ptr()
+    for k in range(L):
+        n = Ks[k] * 16
+        a = arr[k]
+        a.V, a.g, a.K = V2ds[k].data_ptr(), gs[k].data_ptr(), Ks[k]
+        a.w, a.wT, a.inv = wp + 4 * off, tp + 4 * off, ip + 64 * k
+        out.append((w_all[off:off + n].view(Ks[k], 16), wT_all[off:off + n].view(16, Ks[k]), inv_all[16 * k:16 * k + 16]))
+        off += n
+    _lib.check(_lib.lib().otgan_weightnorm_fwd_batched16_f32(arr, L, _lib.stream_ptr()), "weightnorm_fwd_batched")
+    return out
+
+
+def weightnorm_bwd_block(V2ds, gs, invs, parts):
+    """weightnorm_bwd of every 16-output layer of a dense block in ONE launch.  parts[k]: up to three
+    (tensor_or_pointer, perm, nrows, rstride) pieces of layer k's weight gradient (otgan_layers.h: otgan_wn_part).
+    Returns ([dV2d_k], [dg_k])."""
+    L = len(V2ds)
+    Ks = [int(v.shape[0]) for v in V2ds]
+    dev, dt = V2ds[0].device, V2ds[0].dtype
+    dV_all = torch.empty(sum(Ks) * 16, dtype=dt, device=dev)
+    dg_all = torch.empty(L * 16, dtype=dt, device=dev)
+    arr = (WnBwdLayer * L)()
+    dVs, dgs, off = [], [], 0
+    vp, gp = dV_all.data_ptr(), dg_all.data_ptr()
+    for k in range(L):
+        n = Ks[k] * 16
+        a = arr[k]
+        a.V, a.g, a.inv = V2ds[k].data_ptr(), gs[k].data_ptr(), invs[k].data_ptr()
+        a.dV, a.dg = vp + 4 * off, gp + 64 * k
+        a.taps = 9
+        a.Ceff = Ks[k] // 9
+        for i, (ptr, perm, nrows, rstride) in enumerate(parts[k]):
+            q = a.part[i]
+            q.p, q.perm, q.nrows, q.rstride = ptr, (perm.data_ptr() if perm is not None else None), nrows, rstride
+        dVs.append(dV_all[off:off + n].view(Ks[k], 16))
+        dgs.append(dg_all[16 * k:16 * k + 16])
+        off += n
+    _lib.check(_lib.lib().otgan_weightnorm_bwd_batched16_f32(arr, L, _lib.stream_ptr()), "weightnorm_bwd_batched")
+    return dVs, dgs
+
+
+def _row_order_back(order):
+    """int32 inverse of `_input_row_order`: position, in the single-tensor order, of every row of the reference's
+    per-element order (None stays None)."""
+    if order is None:
+        return None
+    key = ("back", order.data_ptr())
+    hit = _map_cache.get(key)
+    if hit is None:
+        back = torch.empty_like(order)
+        back[order] = torch.arange(order.numel(), device=order.device)
+        hit = (order, back.to(torch.int32))      # holding `order` keeps its data_ptr from being reused
+        _map_cache[key] = hit
+    return hit[1]
+
+
 _block_cache = OrderedDict()   # id(V of layer 0) -> (per-layer normalised weights it was made from, value)
 
 
@@ -423,6 +495,8 @@ def _split_block_plan(N, H, W, C0, L, F, segs0, preact, device):
                      "after": s1 - 1})
         for k in range(s1, L):
             g0[k] = s1
+    for wd in wide:
+        wd["back"] = _row_order_back(wd["order"])
     return {"wide": wide, "g0": g0, "own_len": [k - g0[k] for k in range(L)],
             "own_row0": [(C0 + g0[k] * F) * mult for k in range(L)],
             "key": (H, W, C0, L, F, tuple(segs0), preact, tuple(g0))}
@@ -463,13 +537,26 @@ class DenseBlockFunction(torch.autograd.Function):
         mult = 2 if preact in DOUBLED else 1
         saved, descs, maps, per_layer = [], [], [], []
         segs = list(segs0)
+        V2ds = []
         for k in range(L):
-            V, g, b = params[3 * k:3 * k + 3]
-            Ck = C0 + k * F
-            assert tuple(V.shape) == (ksize, ksize, Ck * mult, F), (V.shape, Ck, mult)
-            V2d = V.contiguous().view(-1, F)
-            per_layer.append(cached_weights(V, g, lambda V2d=V2d, g=g: weightnorm_fwd(V2d, g)))
-            saved += [V2d, g, per_layer[k][0], per_layer[k][2]]
+            V = params[3 * k]
+            assert tuple(V.shape) == (ksize, ksize, (C0 + k * F) * mult, F), (V.shape, C0 + k * F, mult)
+            V2ds.append(V.contiguous().view(-1, F))
+        gs = list(params[1::3])
+        ctx.batched = F == 16 and ksize == 3 and _aligned16(*V2ds, *gs) and os.environ.get("OTGAN_WN_BATCHED", "1") != "0"
+        batch = []
+
+        def normalised(k):
+            # all layers of the block in one launch the first time any of them misses the cache
+            if ctx.batched:
+                if not batch:
+                    batch.extend(weightnorm_fwd_block(V2ds, gs))
+                return batch[k]
+            return weightnorm_fwd(V2ds[k], gs[k])
+
+        for k in range(L):
+            per_layer.append(cached_weights(params[3 * k], gs[k], lambda k=k: normalised(k)))
+            saved += [V2ds[k], gs[k], per_layer[k][0], per_layer[k][2]]
         ctx.vshapes = [p.shape for p in params[0::3]]
         ctx.L, ctx.C0, ctx.F = L, C0, F
 
@@ -556,13 +643,7 @@ class DenseBlockFunction(torch.autograd.Function):
                 if need_w:
                     dw = torch.empty_like(ops_["w"])
                     conv_wgrad_raw(desc, src, None, G, dw)
-                    dw = dw.view(9, wd["nrows"], L - wd["d0"], F)
-                    order = wd["order"]
-                    if order is not None:
-                        back = torch.empty_like(order)
-                        back[order] = torch.arange(order.numel(), device=order.device)
-                        dw = dw.index_select(1, back)
-                    dw_wide[i] = dw
+                    dw_wide[i] = dw          # [9][nrows][layers d0 ..][F], rows in the convolution's own order
                 if need_dx:
                     if not ops_["bwd_done"]:
                         ops_["bwd"], ops_["bwd_done"] = prepare_filters(desc, 1, ops_["w"]), True
@@ -583,27 +664,56 @@ class DenseBlockFunction(torch.autograd.Function):
                     # d/d(growth outputs of the layer's own half) accumulates into their channels of G
                     conv_dgrad_raw(desc, G, sw["w_g"][k], buf[..., off:], inv, G[..., off:], Ctot, True)
             wide_bwd(0, ctx.needs_input_grad[0])
-            if need_w:
+            if need_w and ctx.batched and len(plan["wide"]) <= 2:
+                # the pieces of every layer's weight gradient where the passes left them (a column slice of each wide
+                # convolution's dw, in that convolution's row order, then the layer's own chain): one launch
+                parts = []
+                for k in range(L):
+                    pk = []
+                    for i, wd in enumerate(plan["wide"]):
+                        if wd["d0"] <= k:
+                            nl = L - wd["d0"]
+                            pk.append((dw_wide[i].data_ptr() + 4 * (k - wd["d0"]) * F, wd["back"], wd["nrows"], nl * F))
+                    if dw_g[k] is not None:
+                        pk.append((dw_g[k].data_ptr(), None, dw_g[k].shape[0] // 9, F))
+                    parts.append(pk)
+                dVs, dgs = weightnorm_bwd_block(saved[0::4], saved[1::4], saved[3::4], parts)
+                for k in range(L):
+                    grads[3 * k:3 * k + 2] = [dVs[k].view(ctx.vshapes[k]), dgs[k]]
+            elif need_w:
                 for k in range(L):
                     V2d, g, w, inv_norm = saved[4 * k:4 * k + 4]
-                    parts = [dw_wide[i][:, :, k - wd["d0"], :] for i, wd in enumerate(plan["wide"]) if wd["d0"] <= k]
+                    parts = []
+                    for i, wd in enumerate(plan["wide"]):
+                        if wd["d0"] <= k:
+                            dwi = dw_wide[i].view(9, wd["nrows"], L - wd["d0"], F)
+                            if wd["back"] is not None:
+                                dwi = dwi.index_select(1, wd["back"].long())
+                            parts.append(dwi[:, :, k - wd["d0"], :])
                     if dw_g[k] is not None:
                         parts.append(dw_g[k].view(9, -1, F))
                     dw = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0].contiguous()
                     dV2d, dg = weightnorm_bwd(V2d, g, inv_norm, dw.view(-1, F))
                     grads[3 * k:3 * k + 2] = [dV2d.view(ctx.vshapes[k]), dg]
         else:
+            dws = [None] * L
             for k in reversed(range(L)):
                 V2d, g, w, inv_norm = saved[4 * k:4 * k + 4]
                 desc = ctx.descs[k]
                 cmap, inv = ctx.maps[k]
                 if need_w:
-                    dw = torch.empty_like(V2d)
-                    conv_wgrad_raw(desc, buf, cmap, G, dw)
-                    dV2d, dg = weightnorm_bwd(V2d, g, inv_norm, dw)
-                    grads[3 * k:3 * k + 2] = [dV2d.view(ctx.vshapes[k]), dg]
+                    dws[k] = torch.empty_like(V2d)
+                    conv_wgrad_raw(desc, buf, cmap, G, dws[k])
+                    if not ctx.batched:
+                        dV2d, dg = weightnorm_bwd(V2d, g, inv_norm, dws[k])
+                        grads[3 * k:3 * k + 2] = [dV2d.view(ctx.vshapes[k]), dg]
                 # d/d(inputs of layer k) accumulates into the first Ck channels of G
                 conv_dgrad_raw(desc, G, w, buf, inv, G, Ctot, True)
+            if need_w and ctx.batched:
+                parts = [[(dws[k].data_ptr(), None, dws[k].shape[0] // 9, F)] for k in range(L)]
+                dVs, dgs = weightnorm_bwd_block(saved[0::4], saved[1::4], saved[3::4], parts)
+                for k in range(L):
+                    grads[3 * k:3 * k + 2] = [dVs[k].view(ctx.vshapes[k]), dgs[k]]
         if need_w:
             # Layer k's output gradient G[..., Ck:Ck+F] is final once the layers after it have been
             # processed, and no earlier layer writes there: all L bias gradients are the column sums
