@@ -69,10 +69,17 @@ def test_step_gradients_match_oracle(dev, model, kind):
     o32.load(named)
     to32 = lambda z: [t.float() for t in z] if isinstance(z, list) else z.float()
     gr32, _, _ = o32.grads(kind, x.float(), to32(noise), 2, lam, iters)
+    # A pre-activation that is zero to rounding flips its CReLU unit between two fp32 evaluation orders; one flip
+    # moves the small tensors near it by up to ~1.3e-2 and the median tensor to ~2e-3 (tools/debug/step_seeds.py:
+    # over five seeds the per-layer and the batched weight norm -- same values to 1 ulp -- each land on either
+    # side).  Hence a per-tensor bound of 3e-2 and a median bound, not 1e-2 everywhere.
     names = list((m.generator if kind == "gen" else m.discriminator).named_variables())
+    errs = []
     for n, a, b, c in zip(names, r["grads"], gr, gr32):
         e_hip, e_32 = _rel(a, b), _rel(c, b)
-        assert e_hip < max(1e-2, 3 * e_32), (n, e_hip, e_32)
+        errs.append(e_hip)
+        assert e_hip < max(3e-2, 3 * e_32), (n, e_hip, e_32)
+    assert sorted(errs)[len(errs) // 2] < 5e-3, sorted(errs)[len(errs) // 2]
 
 
 def test_updates_and_ema(dev):
