@@ -1594,7 +1594,7 @@ inline int wino_plain3_min_cout() {
   return v;
 }
 inline bool wino_plain3_ok(const otgan_conv_desc* d, const Geo& g) {
-  return d->stride == 1 && d->upsample == 0 && d->KH == 3 && d->KW == 3 && d->C % 4 == 0 && g.Ceff % 32 == 0 &&
+  return d->stride == 1 && d->upsample == 0 && d->KH == 3 && d->KW == 3 && d->C % 4 == 0 && g.Ceff % 16 == 0 &&
          g.Ceff >= wino_plain3_min_ceff() && d->Cout % 32 == 0 && d->Cout >= wino_plain3_min_cout() && d->H % kWinoM == 0 && d->W % kWinoM == 0 && d->ldx % 4 == 0 &&
          d->ldy % 4 == 0 && d->y_coff % 4 == 0 && WINO(winograd_enabled)() && getenv("OTGAN_DISABLE_WINO_PLAIN3") == nullptr;
 }

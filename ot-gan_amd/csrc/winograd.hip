@@ -440,6 +440,15 @@ __global__ __launch_bounds__(256) void wino_output_kernel(OutArgs a) {
   }
 }
 
+// zero columns [k0, k1) of every row and frequency of a blocked operand (K padded to the GEMM's granule)
+__global__ __launch_bounds__(256) void op_zero_cols_kernel(u16* P, long rows, int ld, int k0, int k1) {
+  long row;
+  int k4;
+  if (!op_thread(true, rows, (k1 - k0) >> 2, row, k4)) return;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (int f = 0; f < WF; ++f) st_operand(nullptr, P, rows, ld, f, row, k0 + 4 * k4, z);
+}
+
 // dM[f][t][coff + c] = (A dY A^T)[f],  dY = the 4x4 tile of the view at (4ta, 4tb)
 __global__ __launch_bounds__(256) void wino_outadj_kernel(InArgs a) {
   long t;
@@ -615,7 +624,7 @@ __device__ __forceinline__ int s2_tap(int parity, int i) {   // filter tap of wi
 // forward filters: U[f][co][cls*Ceff + ce] from wT[co][(kh*5+kw)*Ceff + ce]
 // (plain: a 3x3 stride-1 layer -- one class, wT[co][(i*3+j)*Ceff + ce], every block present)
 __global__ __launch_bounds__(256) void wino_s2_filter_fwd_kernel(const float* __restrict__ wT, int Ceff, int Cout,
-                                                               float* __restrict__ U, u16* P, int plain) {
+                                                               float* __restrict__ U, u16* P, int plain, int ld) {
   const int c4n = Ceff >> 2, ncls = plain ? 1 : 4, kk = plain ? 3 : 5;
   long row;
   int k4;
@@ -633,7 +642,7 @@ __global__ __launch_bounds__(256) void wino_s2_filter_fwd_kernel(const float* __
     }
   tf_filter(g, [&](int f, f32x4 v) {
     if (plain || s2_present(cls, f, 0))   // absent blocks are never read by the GEMM
-      st_operand(U, P, Cout, ncls * Ceff, f, co, cls * Ceff + ce, v);
+      st_operand(U, P, Cout, ld, f, co, cls * Ceff + ce, v);
   });
 }
 
@@ -1518,6 +1527,9 @@ void s2_views(const WinoS2Geo& g, P base, int ld, V (&v)[4]) {
 inline int s2_k(const WinoS2Geo& g) { return wino_s2_classes(g) * g.Ceff; }
 // contraction length of the input-gradient GEMM: Cout, padded (zero columns in both operands) to the split-precision
 // GEMM's K granule for the plain layers (208, 144 outputs of the DenseNet transitions)
+// contraction length of the forward GEMM: the effective channels, padded the same way for the plain layers (400
+// effective channels of the 8x8 critic block)
+inline int s2_kf(const WinoS2Geo& g) { return (g.plain && use_x3()) ? (s2_k(g) + X3_BK - 1) / X3_BK * X3_BK : s2_k(g); }
 inline int s2_kp(const WinoS2Geo& g) { return (g.plain && use_x3()) ? (g.Cout + X3_BK - 1) / X3_BK * X3_BK : g.Cout; }
 inline int s2_taps(const WinoS2Geo& g) { return g.plain ? 9 : 25; }
 
@@ -1531,8 +1543,9 @@ int s2_wgrad_splits(const WinoS2Geo& g) {
   return ns < 1 ? 1 : ns;
 }
 
-void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, u16* VP, hipStream_t s) {
+void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, u16* VP, hipStream_t s, int ld = 0) {
   const long T = wino_s2_tiles(g);
+  if (ld == 0) ld = s2_k(g);
   // (the activation is applied inside the transform: |relu(+-x)| <= |x|, |elu(x)| <= max(|x|, 1))
   if (VP) op_scales(x, (long)g.N * (g.H >> g.up) * (g.W >> g.up), g.C, g.ldx, reinterpret_cast<float*>(VP) - X3_HDR, kGainBt, 1.f, g.act == 2, s, g.x_amax);
   InArgs ia;
@@ -1545,10 +1558,12 @@ void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, u16* VP, h
     ia.v[0].sh = (long)(g.W / 2) * g.ldx;
   }
   for (int cls = 0; cls < 4; ++cls) ia.coff[cls] = cls * g.Ceff;
-  ia.H = wino_s2_out_h(g); ia.W = wino_s2_out_w(g); ia.TH = ia.H / WM; ia.TW = ia.W / WM; ia.C = g.C; ia.T = T; ia.ldv = s2_k(g);
+  ia.H = wino_s2_out_h(g); ia.W = wino_s2_out_w(g); ia.TH = ia.H / WM; ia.TW = ia.W / WM; ia.C = g.C; ia.T = T; ia.ldv = ld;
   ia.V = V;
   ia.P = VP;
   ia.s2_skip = g.plain ? -1 : 0;
+  if (VP && ld > s2_k(g))   // zero columns up to the GEMM's K granule
+    hipLaunchKernelGGL(op_zero_cols_kernel, dim3(op_grid(T, (ld - s2_k(g)) / 4)), dim3(256), 0, s, VP, T, ld, s2_k(g), ld);
   const dim3 grid(op_grid(T, g.C / 4), g.doubled ? 2 : 1, wino_s2_classes(g)), blk(256);
   if (g.doubled) {
     if (g.act == 2) hipLaunchKernelGGL((wino_input_kernel<2, true>), grid, blk, 0, s, ia);
@@ -1562,9 +1577,9 @@ void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, u16* VP, h
 
 size_t wino_s2_fwd_ws_floats(const WinoS2Geo& g) {
   const size_t T = (size_t)wino_s2_tiles(g), K4 = (size_t)s2_k(g);
-  const size_t Kp = (size_t)s2_kp(g);
-  return operand_floats(op_elems(T, K4)) + operand_floats(op_elems(T, Kp)) +
-         operand_floats(std::max(op_elems(g.Cout, K4), op_elems(K4, Kp))) + WF * T * K4 + x3_stream_floats();
+  const size_t Kp = (size_t)s2_kp(g), Kf = (size_t)s2_kf(g);
+  return operand_floats(op_elems(T, Kf)) + operand_floats(op_elems(T, Kp)) +
+         operand_floats(std::max(op_elems(g.Cout, Kf), op_elems(K4, Kp))) + WF * T * K4 + x3_stream_floats();
 }
 size_t wino_s2_dgrad_ws_floats(const WinoS2Geo& g) { return wino_s2_fwd_ws_floats(g); }
 size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g) {
@@ -1576,14 +1591,18 @@ size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g) {
 }
 
 size_t wino_s2_filter_floats(const WinoS2Geo& g, int which) {
-  return which == 0 ? operand_floats(op_elems(g.Cout, s2_k(g))) : operand_floats(op_elems(s2_k(g), s2_kp(g)));
+  return which == 0 ? operand_floats(op_elems(g.Cout, s2_kf(g))) : operand_floats(op_elems(s2_k(g), s2_kp(g)));
 }
 int wino_s2_prepare_filters(const WinoS2Geo& g, int which, const float* w, float* out, hipStream_t s) {
   if (which == 0) {
-    const bool x3 = use_x3() && g.Ceff % X3_BK == 0;
+    const int Kf = s2_kf(g);
+    const bool x3 = use_x3() && Kf % X3_BK == 0 && (g.plain || g.Ceff % X3_BK == 0);
     if (x3) op_scales(w, 1, s2_taps(g) * g.Ceff * g.Cout, 0, out, kGainG, 1.f, false, s);
     hipLaunchKernelGGL(wino_s2_filter_fwd_kernel, dim3(op_grid(g.Cout, s2_k(g) / 4)), dim3(256), 0, s, w, g.Ceff, g.Cout, out,
-                       x3 ? op_planes(out) : nullptr, g.plain);
+                       x3 ? op_planes(out) : nullptr, g.plain, x3 ? Kf : s2_k(g));
+    if (x3 && Kf > s2_k(g))
+      hipLaunchKernelGGL(op_zero_cols_kernel, dim3(op_grid(g.Cout, (Kf - s2_k(g)) / 4)), dim3(256), 0, s, op_planes(out),
+                         (long)g.Cout, Kf, s2_k(g), Kf);
   } else {
     const int Kp = s2_kp(g);
     const bool x3 = use_x3() && Kp % X3_BK == 0;
@@ -1597,8 +1616,8 @@ int wino_s2_prepare_filters(const WinoS2Geo& g, int which, const float* w, float
 int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float* bias, float* y, float* ws,
                 hipStream_t s, const float* prep) {
   const long T = wino_s2_tiles(g);
-  const int K4 = s2_k(g);
-  const bool x3 = use_x3() && g.Ceff % X3_BK == 0;
+  const int K4 = s2_kf(g);                    // classes x effective channels (+ zero columns up to the K granule: plain layers)
+  const bool x3 = use_x3() && K4 % X3_BK == 0 && (g.plain || g.Ceff % X3_BK == 0);
   const size_t nV = op_elems(T, K4), nU = op_elems(g.Cout, K4);
   float* V = ws;                              // [WF][T][4*Ceff]
   float* Uws = V + operand_floats(nV);        // [WF][Cout][4*Ceff]
@@ -1607,7 +1626,7 @@ int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float
   u16* VP = x3 ? op_planes(V) : nullptr;
   u16* UP = x3 ? op_planes(U) : nullptr;
   if (!prep) wino_s2_prepare_filters(g, 0, wT, U, s);
-  s2_input_transform(g, x, V, VP, s);
+  s2_input_transform(g, x, V, VP, s, K4);
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.Ap = VP; b.Bp = UP; b.pA = (long)nV; b.pB = (long)nU;
@@ -1692,7 +1711,7 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
   const long T = wino_s2_tiles(g);
   const int K4 = s2_k(g);
   const int OH = wino_s2_out_h(g), OW = wino_s2_out_w(g);
-  if (use_x3_wgrad_tl() && T % 32 == 0 && g.Ceff % 32 == 0 && g.Cout % 16 == 0) {
+  if (use_x3_wgrad_tl() && T % 32 == 0 && g.Ceff % (g.plain ? 16 : 32) == 0 && g.Cout % 16 == 0) {
     // the forward operand V[tile][4 Ceff] (absent (class, frequency) blocks unwritten: their rows of the result are
     // masked by the adjoint filter transform) and the dgrad operand dM[tile][Cout]: t-leading GEMM over the tiles
     const int ns = x3_wgrad_splits(K4, g.Cout, T);

@@ -92,6 +92,8 @@ CONV_CASES = [
     ("wino_plain3_none", 3, 8, 8, (64,), 160, 3, 1, False, None),
     ("wino_plain3_celu_rect", 5, 8, 16, (32,), 256, 3, 1, False, "celu"),
     ("wino_plain3_list_generic", 2, 8, 8, (32, 16), 128, 3, 1, False, "crelu"),
+    ("wino_plain3_k_pad", 4, 8, 8, (40,), 128, 3, 1, False, "crelu"),          # 80 effective channels: K padded to 96
+    ("wino_plain3_k_pad_none", 2, 16, 16, (48,), 160, 3, 1, False, None),       # 48 -> 64
 ]
 
 
@@ -444,6 +446,7 @@ def test_wino_outlier_zero_and_nan(dev):
     ("elu_single", 2, 8, 8, (64,), 8, "elu"),
     ("crelu_halves", 2, 8, 8, (32, 16), 16, "crelu"),     # 16 layers: the first 8 outputs enter the last 8 layers as one 128 -> 128 convolution
     ("elu_halves", 1, 8, 8, (64,), 16, "elu"),
+    ("crelu_k_pad", 2, 8, 8, (24, 16), 16, "crelu"),       # 80 effective input channels (the 8x8 critic block has 400)
 ], ids=lambda c: c[0])
 def test_dense_block_split_matches_chain(dev, case, monkeypatch):
     """A dense block computed as "block-input convolution (Winograd) + growth chain" (ops.DenseBlockFunction) against
