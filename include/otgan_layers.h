@@ -81,6 +81,9 @@ int otgan_absmax_f32(const float* x, long rows, int C, long ld, float* record, v
  *   - 5x5 stride-2 layers with a single-tensor input (the DCGAN critic, models/dcgan.py:12-14):
  *     four 3x3 sub-convolutions of the input-parity sub-images, classes folded into the
  *     contraction index, structurally-zero blocks skipped (49 instead of 100 products per tile).
+ *   - 3x3 stride-1 layers with >= 128 outputs and a single-tensor input (the wide convolutions a dense block is cut
+ *     into, ops.py DenseBlockFunction) and 3x3 layers on a 2x upsampled input with CReLU (the DenseNet generator's
+ *     transitions, models/densenet.py:67-73): the same passes with one class on the (upsampled) grid.
  * The batched GEMMs of these paths run on the fp16 matrix pipe with operands stored as two fp16 pieces of the
  * power-of-two-scaled value (hi + lo = 22 significand bits, one scale per Winograd frequency derived from the
  * largest magnitude of the tensor the operand is a transform of): three MFMAs per product, fp32 accumulation,
@@ -95,7 +98,11 @@ int otgan_absmax_f32(const float* x, long rows, int C, long ld, float* record, v
  * (pixel chunks of the few-channel weight gradient, default 512), OTGAN_X3_STREAM (0 / 1 / 2: the persistent
  * stream-K GEMM never / where it pays / always; read per launch), OTGAN_X3_STREAM_HALF_ROUNDS (its selection
  * threshold in half tiles per compute unit, default 3), OTGAN_X3_FMAP=0 (tile-residue instead of frequency-major
- * GEMM grid), OTGAN_AMAX_BLOCKS (workgroups of the largest-magnitude reduction, default 256).
+ * GEMM grid), OTGAN_AMAX_BLOCKS (workgroups of the largest-magnitude reduction, default 256);
+ * OTGAN_DISABLE_WINO_PLAIN3=1 (wide 3x3 stride-1 layers back on the implicit GEMM), OTGAN_PLAIN3_MIN_CEFF / _MIN_COUT
+ * (their eligibility thresholds, 64 / 128), OTGAN_DISABLE_WINO_UP3=1, OTGAN_DISABLE_WINO_UP3_WGRAD=1,
+ * OTGAN_DISABLE_WINO_UP3_DGRAD=1 (3x3 upsampling layers: all passes / weight gradient / input gradient back on the
+ * folded implicit GEMM).
  */
 
 /*
@@ -136,7 +143,11 @@ int otgan_conv2d_dgrad_f32(const otgan_conv_desc* d, const float* dy, const floa
  *                                         folded layers: weffT / weff).  Folded layers also accept
  *                                         which = 2 / 3: forward / dgrad filters from the UN-folded wT / w
  *                                         (bit-identical; the fold is then not needed by these two passes:
- *                                         with `filters` given they do not read their weight argument)
+ *                                         with `filters` given they do not read their weight argument).
+ *                                         3x3 layers on an upsampled CReLU input have ONLY these two (their
+ *                                         forward / dgrad run as Winograd GEMMs exactly when `filters` is given;
+ *                                         a dgrad call with `filters` must then satisfy that path's alignment /
+ *                                         workspace requirements -- it is rejected otherwise, never rerouted)
  *   otgan_conv2d_fwd_pf_f32 / otgan_conv2d_dgrad_pf_f32: as the plain calls; `filters` may be NULL
  *                                         (then identical to them) and is ignored by the non-Winograd paths.
  * The buffer's content is tied to the descriptor and to the OTGAN_WINO_* switches of the process.

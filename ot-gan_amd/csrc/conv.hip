@@ -43,6 +43,7 @@ namespace {
 using CfgMain = GemmCfg<2, 2, 2, 2, 32>;    // 128 x 128 x 32
 using CfgSmall = GemmCfg<2, 2, 1, 2, 32>;   // 64 x 128 x 32
 using CfgMain16 = GemmCfg<2, 2, 2, 2, 16>;  // 128 x 128 x 16
+using CfgSmall16 = GemmCfg<2, 2, 1, 2, 16>; // 64 x 128 x 16
 using CfgNarrow = GemmCfg<4, 1, 2, 1, 16>;  // 256 x 32 x 16 (Cout / Cin <= 32)
 using CfgN16 = GemmCfg<4, 1, 4, 1, 16, 16>;  // 256 x 16 x 16 on v_mfma_f32_16x16x4_f32 (Cout <= 16: DenseNet)
 // One column tile for outputs just above a multiple of 128 (the DenseNet transition layers: Cout = 144, 200, 208):
@@ -1870,6 +1871,12 @@ void launch_igemm(bool vec_ok, int Ck, int rows, int ncols, bool paired, int ncl
       dim3 grid(ceil_div(rows, CfgMain::BM), ntiles, ncls);
       launch_igemm3<CfgMain, true, EPI, ACT>(grid, s, ga, ct, wb, e);
     }
+    return;
+  }
+  if (vec_ok && Ck % 16 == 0 && (long)ceil_div(rows, 128) * ntiles * ncls < 512) {
+    // few tiles (the 8x8 -> 4x4 DenseNet transition: 64 of the 128 x 128 ones for 256 CUs): half-height tiles
+    dim3 grid(ceil_div(rows, CfgSmall16::BM), ntiles, ncls);
+    launch_igemm3<CfgSmall16, true, EPI, ACT>(grid, s, ga, ct, wb, e);
     return;
   }
   dim3 grid(ceil_div(rows, CfgMain16::BM), ntiles, ncls);
