@@ -195,8 +195,11 @@ def main():
                                       "layer parity vs fp64 unchanged at 2e-5; the matching GEMMs (lambda-amplified) keep three "
                                       "bf16 pieces / six MFMAs; OTGAN_WINO_FP32=1 runs the conv GEMMs on the fp32 MFMA engine")
                                      if a.model == "dcgan" and os.environ.get("OTGAN_WINO_FP32") != "1"
-                                     else "fp32 MFMA" + ("; the forward of the 32x32 growth layers uses the same three-way bf16 "
-                                                         "split (fp32-exact products)" if a.model == "densenet" else "")},
+                                     else "fp32 MFMA" + ("; dense blocks are cut into wide 3x3 convolutions of finished channel "
+                                                         "groups (Winograd F(4x4,3x3) GEMMs on two scaled fp16 pieces, as in the "
+                                                         "DCGAN configuration) + short 16-output growth chains whose 32x32 forward "
+                                                         "uses a three-way bf16 split (fp32-exact products); the stride-2 "
+                                                         "transitions run on the fp32 MFMA engine" if a.model == "densenet" else "")},
     }
     if prof:
         conv = {k: prof[k] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")}
