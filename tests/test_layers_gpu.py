@@ -490,3 +490,34 @@ def test_dense_block_split_matches_chain(dev, case, monkeypatch):
     for i, (a, c, r) in enumerate(zip(g_s[1:], g_c[1:], grads_ref[len(segs0):])):
         assert _rel(a, r) < TOL, f"split: gradient of parameter {i}"
         assert _rel(c, r) < TOL, f"chain: gradient of parameter {i}"
+
+
+def test_y_accumulate_contract(dev):
+    """otgan_conv_desc::y_accumulate: honoured by the 16-output growth layers and the wide 3x3 layers on the Winograd
+    path (y += conv + bias, bit-for-bit the separate sum up to one fp32 addition), rejected everywhere else."""
+    import ctypes
+    from otgan_amd import _lib, ops
+    from otgan_amd._lib_layers import ConvDesc
+    gen = torch.Generator().manual_seed(5)
+    for C, Cout in ((32, 16), (64, 128)):
+        x = torch.randn(4, 8, 8, C, generator=gen).to(dev)
+        wT = (torch.randn(Cout, 9 * 2 * C, generator=gen) * 0.05).to(dev)
+        b = torch.randn(Cout, generator=gen).to(dev)
+        y0 = torch.randn(4, 8, 8, Cout, generator=gen).to(dev)
+        desc = ConvDesc(4, 8, 8, C, C, 0, 3, 3, 1, Cout, Cout, 0, ops.ACT["crelu"], 1)
+        plain = torch.empty_like(y0)
+        ops.conv_fwd_raw(desc, x, None, wT, b, plain)
+        acc = y0.clone()
+        desc.y_accumulate = 1
+        ops.conv_fwd_raw(desc, x, None, wT, b, acc)
+        assert _rel(acc, (y0 + plain).double()) < 1e-6
+    # a 5x5 layer, and a 3x3 layer too narrow for the Winograd path: rejected, output untouched
+    for C, Cout, k in ((32, 64, 5), (16, 32, 3)):
+        x = torch.randn(2, 8, 8, C, generator=gen).to(dev)
+        wT = torch.randn(Cout, k * k * C, generator=gen).to(dev)
+        y = torch.zeros(2, 8, 8, Cout, device=dev)
+        desc = ConvDesc(2, 8, 8, C, C, 0, k, k, 1, Cout, Cout, 0, 0, 1)
+        desc.y_accumulate = 1
+        with pytest.raises(_lib.OtganError):
+            ops.conv_fwd_raw(desc, x, None, wT, None, y)
+        assert float(y.abs().max()) == 0.0
