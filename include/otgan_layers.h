@@ -52,6 +52,14 @@ typedef struct otgan_conv_desc {
    * block split into "wide convolutions of finished channel groups + short growth chains" needs (ops.py
    * DenseBlockFunction); any other layer with this flag set is rejected with OTGAN_ERR_ARG. */
   int y_accumulate;
+  /* Optional: device buffer of otgan_conv2d_operand_bytes(d) bytes (16-byte aligned) shared by the forward call and the
+   * weight-gradient call on the SAME x.  Both passes of a Winograd layer start with the same transform of x into the
+   * GEMM's operand format; with this buffer the forward call leaves that operand here instead of in its workspace
+   * and the weight-gradient call reads it instead of transforming x again (the buffer must stay untouched in
+   * between; x_amax is then not needed by the weight gradient).  Ignored when otgan_conv2d_operand_bytes(d) == 0;
+   * when it is > 0 and a call cannot take the Winograd path (list input, misaligned operands, short workspace) the
+   * call fails with OTGAN_ERR_ARG instead of silently writing / reading nothing.  NULL = each pass transforms x. */
+  void* x_operand;
 } otgan_conv_desc;
 
 /*
@@ -64,6 +72,8 @@ typedef struct otgan_conv_desc {
 
 /* which: 0 fwd, 1 dgrad, 2 wgrad */
 size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which);
+/* size of otgan_conv_desc::x_operand for this layer; 0 = forward and weight gradient do not share an operand */
+size_t otgan_conv2d_operand_bytes(const otgan_conv_desc* d);
 
 /*
  * amax record of x[rows][C] (row stride ld floats, C and ld multiples of 4, 16-byte aligned): record[0] = the

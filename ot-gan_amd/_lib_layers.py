@@ -12,7 +12,7 @@ class ConvDesc(ctypes.Structure):
                 ("upsample", c_int), ("KH", c_int), ("KW", c_int), ("stride", c_int),
                 ("Cout", c_int), ("ldy", c_int), ("y_coff", c_int), ("preact", c_int),
                 ("list_quads", c_int), ("x_amax", ctypes.c_void_p), ("dy_amax", ctypes.c_void_p),
-                ("y_accumulate", c_int)]
+                ("y_accumulate", c_int), ("x_operand", ctypes.c_void_p)]
 
 
 P_DESC = ctypes.POINTER(ConvDesc)
@@ -36,6 +36,7 @@ class WnBwdLayer(ctypes.Structure):
 
 SIGNATURES = {
     "otgan_conv2d_workspace_bytes": (c_size_t, [P_DESC, c_int]),
+    "otgan_conv2d_operand_bytes": (c_size_t, [P_DESC]),
     "otgan_absmax_f32": (c_int, [c_fp, c_long, c_int, c_long, c_fp, c_fp]),
     "otgan_conv2d_folded_weight_elems": (c_size_t, [P_DESC]),
     "otgan_conv2d_fold_weights_f32": (c_int, [P_DESC, c_fp, c_fp, c_fp, c_fp]),

@@ -1999,6 +1999,20 @@ size_t otgan_conv2d_filter_bytes(const otgan_conv_desc* d, int which) {
   return 0;
 }
 
+size_t otgan_conv2d_operand_bytes(const otgan_conv_desc* d) {
+  Geo g;
+  if (make_geo(d, &g) != OTGAN_OK) return 0;
+  if (getenv("OTGAN_DISABLE_X_OPERAND")) return 0;
+  if (wino_s2_ok(d, g)) return sizeof(float) * WINO(wino_s2_x_operand_floats)(wino_s2_geo(d, g));
+  if (wino_ok(d, g)) return sizeof(float) * WINO(wino_x_operand_floats)(wino_geo(d));
+  if (wino_up3_ok(d, g) && wino_up3_wgrad_ok(d, g)) return sizeof(float) * WINO(wino_s2_x_operand_floats)(wino_up3_wgrad_geo(d, g));
+  return 0;
+}
+// the caller's operand buffer, when this layer's forward and weight gradient share one
+static inline float* shared_x_operand(const otgan_conv_desc* d) {
+  return (d->x_operand && otgan_conv2d_operand_bytes(d) > 0) ? (float*)d->x_operand : nullptr;
+}
+
 int otgan_absmax_f32(const float* x, long rows, int C, long ld, float* record, void* stream) {
   OTGAN_CHECK_ARG(x && record && aligned16(x) && aligned16(record), "null or misaligned pointer");
   OTGAN_CHECK_ARG(rows >= 1 && C >= 4 && C % 4 == 0 && (rows == 1 || (ld >= C && ld % 4 == 0)), "rows >= 1, C and ld multiples of 4, ld >= C");
@@ -2083,6 +2097,7 @@ static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32
   if (wino_s2_fwd_taken) {
     WinoS2Geo w = wino_s2_geo(d, g);
     w.y_accumulate = d->y_accumulate;
+    w.x_op = shared_x_operand(d);
     ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * wino_s2_blocks(w) * (double)wino_s2_tiles(w) * g.Ceff * d->Cout, 0.0, s);
     rc = WINO(wino_s2_fwd)(w, x, wT, bias, y, (float*)workspace, s, filters);
     OTGAN_CHECK_LAUNCH("conv2d fwd (winograd, stride 2)");
@@ -2090,12 +2105,16 @@ static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32
   }
   if (filters && wino_up3_ok(d, g) && !wino_ok(d, g) && cmap == nullptr && aligned16(x) && aligned16(y) && aligned16(bias) &&
       aligned16(workspace) && workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 0)) {
-    const WinoUp3Geo w = wino_up3_geo(d, g);
+    WinoUp3Geo w = wino_up3_geo(d, g);
+    w.x_op = shared_x_operand(d);
     ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * kWinoFreq * (double)wino_up3_tiles(w) * g.Ceff * d->Cout, 0.0, s);
     rc = WINO(wino_up3_fwd)(w, x, bias, y, (float*)workspace, s, filters);
     OTGAN_CHECK_LAUNCH("conv2d fwd (winograd, 3x3 on upsampled input)");
     return rc;
   }
+  OTGAN_CHECK_ARG(wino_ok(d, g) || shared_x_operand(d) == nullptr,
+                  "x_operand given, but this forward call cannot take the Winograd path that writes it (list input, alignment, "
+                  "workspace, or no prepared filters for a 3x3 upsampling layer)");
   if (wino_ok(d, g)) {
     OTGAN_CHECK_ARG(aligned16(x) && aligned16(wT) && aligned16(y) && aligned16(bias) && aligned16(workspace),
                     "winograd conv needs 16-byte aligned operands");
@@ -2105,7 +2124,8 @@ static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32
       return OTGAN_ERR_WORKSPACE;
     }
     const FoldTab f = make_fold(d, g);
-    const WinoGeo w = wino_geo(d);
+    WinoGeo w = wino_geo(d);
+    w.x_op = shared_x_operand(d);
     // executed FLOP: 16 GEMMs of tiles x 4*Cout x Cin
     ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * kWinoFreq * (double)wino_tiles(w) * 4.0 * d->Cout * d->C, 0.0, s);
     rc = WINO(wino_fwd)(w, x, wT, f.woff[1] - f.woff[0], bias, y, (float*)workspace, s, filters);
@@ -2450,7 +2470,8 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
   }
   if (wino_up3_wgrad_ok(d, g) && cmap == nullptr && aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace) &&
       workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 2)) {
-    const WinoS2Geo wg = wino_up3_wgrad_geo(d, g);
+    WinoS2Geo wg = wino_up3_wgrad_geo(d, g);
+    wg.x_op = shared_x_operand(d);
     ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * kWinoFreq * (double)wino_s2_tiles(wg) * g.Ceff * d->Cout, 0.0, s);
     rc = WINO(wino_s2_wgrad)(wg, x, dy, dw, (float*)workspace, s);
     OTGAN_CHECK_LAUNCH("conv2d wgrad (winograd, 3x3 on upsampled input)");
@@ -2458,12 +2479,16 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
   }
   if (wino_s2_ok(d, g) && cmap == nullptr && aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace) &&
       workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 2)) {
-    const WinoS2Geo wg = wino_s2_geo(d, g);
+    WinoS2Geo wg = wino_s2_geo(d, g);
+    wg.x_op = shared_x_operand(d);
     ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * wino_s2_blocks(wg) * (double)wino_s2_tiles(wg) * g.Ceff * d->Cout, 0.0, s);
     rc = WINO(wino_s2_wgrad)(wg, x, dy, dw, (float*)workspace, s);
     OTGAN_CHECK_LAUNCH("conv2d wgrad (winograd, stride 2)");
     return rc;
   }
+  OTGAN_CHECK_ARG(wino_ok(d, g) || shared_x_operand(d) == nullptr,
+                  "x_operand given, but this weight-gradient call cannot take the Winograd path that reads it (list input, "
+                  "alignment, workspace)");
   if (wino_ok(d, g)) {
     OTGAN_CHECK_ARG(aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(workspace),
                     "winograd wgrad needs 16-byte aligned operands");
@@ -2473,7 +2498,8 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
       return OTGAN_ERR_WORKSPACE;
     }
     const FoldTab f = make_fold(d, g);
-    const WinoGeo wg = wino_geo(d);
+    WinoGeo wg = wino_geo(d);
+    wg.x_op = shared_x_operand(d);
     float* ws = (float*)workspace;
     float* dweff = ws + WINO(wino_wgrad_ws_floats)(wg);
     {

@@ -20,6 +20,9 @@ struct WinoGeo {
   int ldy, y_coff;  // output buffer [N, 2H, 2W, ldy], channel offset
   const float* x_amax = nullptr;    // amax records of x / dy when the caller has them (otgan_layers.h), else null
   const float* dy_amax = nullptr;
+  // otgan_conv_desc::x_operand: the forward pass leaves its transformed input here (instead of in the workspace) and
+  // the weight gradient of the same x reads it instead of transforming x again; null = each pass transforms
+  float* x_op = nullptr;
 };
 
 // amax record (otgan_layers.h) of x[rows][C], row stride ld
@@ -55,6 +58,7 @@ struct WinoS2Geo {
   // 2x2 groups of its 4x4 tile onto the stored pixel).
   int up = 0;
   int y_accumulate = 0;   // forward: y += result + bias (otgan_conv_desc::y_accumulate)
+  float* x_op = nullptr;  // as in WinoGeo
 };
 inline int wino_s2_classes(const WinoS2Geo& g) { return g.plain ? 1 : 4; }
 inline int wino_s2_out_h(const WinoS2Geo& g) { return g.plain ? g.H : g.H / 2; }
@@ -72,6 +76,7 @@ struct WinoUp3Geo {
   int ldx;
   int Cout, ldy, y_coff;
   const float* x_amax = nullptr;
+  float* x_op = nullptr;  // as in WinoGeo (read back by the one-class weight gradient, WinoS2Geo plain + up)
 };
 inline long wino_up3_tiles(const WinoUp3Geo& g) { return (long)g.N * (2 * g.H / kWinoM) * (2 * g.W / kWinoM); }
 // wT: un-folded [Cout][9 * Ceff]

@@ -1294,6 +1294,14 @@ bool winograd_enabled() {
   return on;
 }
 
+// forward and weight gradient build the SAME transformed-input operand (same kernel, same layout, same scales) when
+// both run on the split-precision engine with the t-leading weight-gradient GEMM: its size, else 0
+size_t wino_x_operand_floats(const WinoGeo& g) {
+  const long T = wino_tiles(g);
+  const bool ok = use_x3() && g.Cin % X3_BK == 0 && use_x3_wgrad_tl() && T % 32 == 0 && (4 * g.Cout) % 32 == 0;
+  return ok ? operand_floats(op_elems(T, g.Cin)) : 0;
+}
+
 size_t wino_fwd_ws_floats(const WinoGeo& g) {
   const size_t T = (size_t)wino_tiles(g);
   return operand_floats(op_elems(T, g.Cin)) + operand_floats(op_elems(T, 4 * g.Cout)) +
@@ -1349,8 +1357,8 @@ int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stri
   const int N4 = 4 * g.Cout;
   const bool x3 = use_x3() && g.Cin % X3_BK == 0;
   const size_t nV = op_elems(T, g.Cin), nU = op_elems(N4, g.Cin);
-  float* V = ws;
-  float* Uws = V + operand_floats(nV);
+  float* V = (g.x_op && x3) ? g.x_op : ws;
+  float* Uws = ws + operand_floats(nV);
   float* Mh = Uws + operand_floats(nU);
   float* U = prep ? const_cast<float*>(prep) : Uws;
   u16* VP = x3 ? op_planes(V) : nullptr;
@@ -1434,18 +1442,20 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
     // the operands of forward (V[tile][Cin]) and dgrad (dM[tile][4 Cout]) as they are: t-leading GEMM over the tiles
     const int ns = x3_wgrad_splits(g.Cin, N4, T);
     const size_t nV = op_elems(T, g.Cin), nM = op_elems(T, N4);
-    float* Vb = ws;
+    float* Vb = g.x_op ? g.x_op : ws;    // the forward pass of this x left its operand there
     u16* VP = op_planes(Vb);
     float* Mb = ws + operand_floats(nV);
     u16* MP = op_planes(Mb);
     float* slabs = ws + operand_floats(nV) + operand_floats(nM);
-    InArgs ia;
-    memset(&ia, 0, sizeof(ia));
-    ia.s2_skip = -1;
-    ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
-    ia.H = g.H; ia.W = g.W; ia.TH = g.H / WM; ia.TW = g.W / WM; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.P = VP;
-    op_scales(x, (long)g.N * g.H * g.W, g.Cin, g.ldx, Vb, kGainBt, 1.f, false, s, g.x_amax);
-    hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cin / 4), 1, 1), dim3(256), 0, s, ia);
+    if (!g.x_op) {
+      InArgs ia;
+      memset(&ia, 0, sizeof(ia));
+      ia.s2_skip = -1;
+      ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
+      ia.H = g.H; ia.W = g.W; ia.TH = g.H / WM; ia.TW = g.W / WM; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.P = VP;
+      op_scales(x, (long)g.N * g.H * g.W, g.Cin, g.ldx, Vb, kGainBt, 1.f, false, s, g.x_amax);
+      hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cin / 4), 1, 1), dim3(256), 0, s, ia);
+    }
     InArgs da;
     memset(&da, 0, sizeof(da));
     da.s2_skip = -1;
@@ -1575,6 +1585,14 @@ void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, u16* VP, h
 
 }  // namespace
 
+size_t wino_s2_x_operand_floats(const WinoS2Geo& g) {
+  const long T = wino_s2_tiles(g);
+  const int K4 = s2_k(g);
+  const bool fwd_x3 = use_x3() && s2_kf(g) == K4 && K4 % X3_BK == 0 && (g.plain || g.Ceff % X3_BK == 0);
+  const bool tl = use_x3_wgrad_tl() && T % 32 == 0 && g.Ceff % (g.plain ? 16 : 32) == 0 && g.Cout % 16 == 0;
+  return (fwd_x3 && tl) ? operand_floats(op_elems(T, K4)) : 0;
+}
+
 size_t wino_s2_fwd_ws_floats(const WinoS2Geo& g) {
   const size_t T = (size_t)wino_s2_tiles(g), K4 = (size_t)s2_k(g);
   const size_t Kp = (size_t)s2_kp(g), Kf = (size_t)s2_kf(g);
@@ -1619,8 +1637,8 @@ int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float
   const int K4 = s2_kf(g);                    // classes x effective channels (+ zero columns up to the K granule: plain layers)
   const bool x3 = use_x3() && K4 % X3_BK == 0 && (g.plain || g.Ceff % X3_BK == 0);
   const size_t nV = op_elems(T, K4), nU = op_elems(g.Cout, K4);
-  float* V = ws;                              // [WF][T][4*Ceff]
-  float* Uws = V + operand_floats(nV);        // [WF][Cout][4*Ceff]
+  float* V = (g.x_op && x3) ? g.x_op : ws;    // [WF][T][4*Ceff]
+  float* Uws = ws + operand_floats(nV);       // [WF][Cout][4*Ceff]
   float* Mh = Uws + operand_floats(nU);       // [WF][T][Cout]
   float* U = prep ? const_cast<float*>(prep) : Uws;
   u16* VP = x3 ? op_planes(V) : nullptr;
@@ -1716,12 +1734,12 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
     // masked by the adjoint filter transform) and the dgrad operand dM[tile][Cout]: t-leading GEMM over the tiles
     const int ns = x3_wgrad_splits(K4, g.Cout, T);
     const size_t nV = op_elems(T, K4), nM = op_elems(T, g.Cout);
-    float* Vb = ws;
+    float* Vb = g.x_op ? g.x_op : ws;    // the forward pass of this x left its operand there
     u16* VP = op_planes(Vb);
     float* Mb = ws + operand_floats(nV);
     u16* MP = op_planes(Mb);
     float* slabs = ws + operand_floats(nV) + operand_floats(nM);
-    s2_input_transform(g, x, nullptr, VP, s);
+    if (!g.x_op) s2_input_transform(g, x, nullptr, VP, s);
     InArgs da;
     memset(&da, 0, sizeof(da));
     da.s2_skip = -1;
@@ -1805,8 +1823,8 @@ int wino_up3_fwd(const WinoUp3Geo& g, const float* x, const float* bias, float* 
   const long T = wino_up3_tiles(g);
   const int OH = 2 * g.H, OW = 2 * g.W;
   const size_t nV = op_elems(T, g.Ceff), nU = op_elems(g.Cout, g.Ceff);
-  float* V = ws;
-  float* Mh = V + operand_floats(nV);
+  float* V = g.x_op ? g.x_op : ws;
+  float* Mh = ws + operand_floats(nV);
   float* U = const_cast<float*>(prep);
   op_scales(x, (long)g.N * g.H * g.W, g.C, g.ldx, V, kGainBt, 1.f, false, s, g.x_amax);   // |relu(+-x)| <= |x|
   InArgs ia;

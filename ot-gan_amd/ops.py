@@ -185,6 +185,18 @@ def absmax_record(t):
     return rec
 
 
+def shared_x_operand(desc, device):
+    """Buffer for `otgan_conv_desc::x_operand` (the forward pass leaves its transformed input there, the weight
+    gradient of the same x reads it back instead of transforming x again), or None when the layer's two passes do not
+    share an operand.  Sets the descriptor field."""
+    nbytes = _lib.lib().otgan_conv2d_operand_bytes(ctypes.byref(desc))
+    if not nbytes:
+        return None
+    buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+    desc.x_operand = buf.data_ptr()
+    return buf
+
+
 def prepare_filters(desc, which, w):
     """Winograd-domain filters of a layer's forward (which=0, from wT) or dgrad (which=1, from w) pass, or None
     when the pass does not run as a Winograd GEMM (otgan_layers.h)."""
@@ -270,6 +282,10 @@ class Conv2dFunction(torch.autograd.Function):
             # Winograd passes: one reduction of x for the forward pass now and the weight gradient later
             ctx.x_rec = absmax_record(x)
             desc.x_amax = ctx.x_rec.data_ptr()
+        # 288 GB of HBM: keep the transformed input of the Winograd passes for the weight gradient (0.15-0.6 GB a layer)
+        ctx.x_op = None
+        if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and cmap is None and filt["fwd"] is not None:
+            ctx.x_op = shared_x_operand(desc, x.device)
         conv_fwd_raw(desc, x, cmap, wT, b, y, filt["fwd"])
         ctx.save_for_backward(x, V2d, g, wd, inv_norm)
         ctx.filt = filt
@@ -572,7 +588,7 @@ class DenseBlockFunction(torch.autograd.Function):
             sw = _split_block_weights(params[0::3], per_layer, plan, F)
             bias_all = torch.cat([b for b in params[2::3]])
             rows = N * H * W
-            ctx.x_recs = []
+            ctx.x_recs, ctx.x_ops = [], []
 
             def wide_fwd(i):
                 wd, ops_ = plan["wide"][i], sw["wide"][i]
@@ -581,6 +597,8 @@ class DenseBlockFunction(torch.autograd.Function):
                 rec = absmax_record_strided(src.data_ptr(), rows, wd["C"], Ctot, buf.device)
                 ctx.x_recs.append(rec)
                 desc.x_amax = rec.data_ptr()
+                if any(ctx.needs_input_grad[4:]):
+                    ctx.x_ops.append(shared_x_operand(desc, buf.device))    # read back by this convolution's wgrad
                 desc.y_accumulate = wd["accumulate"]
                 conv_fwd_raw(desc, src, None, ops_["wT"], None if wd["accumulate"] else bias_all, buf, ops_["fwd"])
                 desc.y_accumulate = 0
