@@ -521,3 +521,53 @@ def test_y_accumulate_contract(dev):
         with pytest.raises(_lib.OtganError):
             ops.conv_fwd_raw(desc, x, None, wT, None, y)
         assert float(y.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("case", [
+    ("folded_up", 8, 8, 8, 64, 64, 5, 1, True, None),
+    ("strided_crelu", 8, 16, 16, 32, 64, 5, 2, False, "crelu"),
+    ("plain3_crelu", 8, 8, 8, 64, 128, 3, 1, False, "crelu"),
+    ("up3_crelu", 8, 8, 8, 32, 32, 3, 1, True, "crelu"),
+], ids=lambda c: c[0])
+def test_shared_x_operand(dev, case):
+    """otgan_conv_desc::x_operand: the weight gradient that reads the forward pass's transformed input back is
+    bit-identical to the one that transforms x itself; the forward result does not depend on where the operand lives."""
+    import ctypes
+    from otgan_amd import _lib, ops
+    from otgan_amd._lib_layers import ConvDesc
+    name, N, H, W, C, Cout, k, stride, up, pre = case
+    gen = torch.Generator().manual_seed(sum(map(ord, name)))
+    mult = 2 if pre == "crelu" else 1
+    x = torch.randn(N, H, W, C, generator=gen).to(dev)
+    V = (torch.randn(k * k * C * mult, Cout, generator=gen) * 0.05).to(dev)
+    g = (torch.rand(Cout, generator=gen) + 0.5).to(dev)
+    b = torch.randn(Cout, generator=gen).to(dev)
+    w, wT, _ = ops.weightnorm_fwd(V, g)
+    OH, OW = ops.out_hw(H, W, up, stride)
+    dy = torch.randn(N, OH, OW, Cout, generator=gen).to(dev)
+
+    def run(shared):
+        desc = ConvDesc(N, H, W, C, C, 1 if up else 0, k, k, stride, Cout, Cout, 0, ops.ACT[pre], 1)
+        unfolded = _lib.lib().otgan_conv2d_filter_bytes(ctypes.byref(desc), 2) > 0
+        wT_use = wT
+        if up and not unfolded:
+            _, wT_use = ops.fold_weights(desc, w)
+        filt = ops.prepare_filters(desc, 2 if unfolded else 0, wT if unfolded else wT_use)
+        buf = ops.shared_x_operand(desc, dev) if shared else None
+        assert (buf is not None) == shared, "this layer's passes were expected to share their operand"
+        y = torch.empty(N, OH, OW, Cout, device=dev)
+        ops.conv_fwd_raw(desc, x, None, wT_use, b, y, filt)
+        dw = torch.empty_like(V)
+        ops.conv_wgrad_raw(desc, x, None, dy, dw)
+        return y, dw
+
+    y0, dw0 = run(False)
+    y1, dw1 = run(True)
+    assert torch.equal(y0, y1) and torch.equal(dw0, dw1)
+    # a list input (channel map) cannot take the Winograd path: with x_operand given the call is refused
+    if pre == "crelu" and not up:
+        desc = ConvDesc(N, H, W, C, C, 0, k, k, stride, Cout, Cout, 0, ops.ACT[pre], 1)
+        buf = ops.shared_x_operand(desc, dev)
+        cmap, _ = ops.channel_maps((C // 2, C // 2), ops.ACT[pre], dev)
+        with pytest.raises(_lib.OtganError):
+            ops.conv_fwd_raw(desc, x, cmap, wT, b, torch.empty(N, OH, OW, Cout, device=dev))
