@@ -138,6 +138,10 @@ def test_densenet_critic_parity(dev, L):
     names = list(densenet.discriminator.named_variables())
     leaves = [x64] + [P[n.rsplit("/", 1)[0]][n.rsplit("/", 1)[1]] for n in names]
     ref = torch.autograd.grad(f_ref, leaves, gy.double())
+    # (This parameter seed has no pre-activation within fp32 rounding of zero on the default engine: every tensor sits
+    # at <= 1e-5.  Other seeds -- and this one under OTGAN_WINO_PIECES=3 -- flip one CReLU unit between two fp32
+    # evaluation orders and land at 1e-3 ... 7e-2 on the tensors next to it, with or without the dense-block split:
+    # tools/debug/dn_critic_err.py.  The blocks themselves are pinned at 2e-5 in test_layers_gpu.py.)
     for n, a, r in zip(["dx"] + names, got, ref):
         assert _rel(a, r) < 2e-4, n
 
