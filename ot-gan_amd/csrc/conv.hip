@@ -44,6 +44,7 @@ using CfgMain = GemmCfg<2, 2, 2, 2, 32>;    // 128 x 128 x 32
 using CfgSmall = GemmCfg<2, 2, 1, 2, 32>;   // 64 x 128 x 32
 using CfgMain16 = GemmCfg<2, 2, 2, 2, 16>;  // 128 x 128 x 16
 using CfgSmall16 = GemmCfg<2, 2, 1, 2, 16>; // 64 x 128 x 16
+using CfgW160k16 = GemmCfg<4, 1, 1, 5, 16>;  // 128 x 160 x 16 (split-precision main loop)
 using CfgNarrow = GemmCfg<4, 1, 2, 1, 16>;  // 256 x 32 x 16 (Cout / Cin <= 32)
 using CfgN16 = GemmCfg<4, 1, 4, 1, 16, 16>;  // 256 x 16 x 16 on v_mfma_f32_16x16x4_f32 (Cout <= 16: DenseNet)
 // One column tile for outputs just above a multiple of 128 (the DenseNet transition layers: Cout = 144, 200, 208):
@@ -259,6 +260,20 @@ struct ConvALoader {
       }
     }
   }
+  // the same tile as three k-contiguous bf16 planes (gemm_mainloop_x3s; vector path, BK = 16)
+  __device__ __forceinline__ void store3(unsigned char* t) const {
+    const int c4 = threadIdx.x % CPR, r0 = threadIdx.x / CPR;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int r = r0 + p * RPP;
+      if (r < BR) {
+        float4 v = reg[p];
+        v.x = act_apply<ACT>(v.x * sgn); v.y = act_apply<ACT>(v.y * sgn);
+        v.z = act_apply<ACT>(v.z * sgn); v.w = act_apply<ACT>(v.w * sgn);
+        x3s_store4(t, BR * kX3sRowBytes, r, 4 * c4, v);
+      }
+    }
+  }
 };
 
 // Weight ("B") operand: element (n, k=(tap, c)) at w[boff[tap] + row(n)*ldbn + c].
@@ -371,6 +386,14 @@ struct ConvBLoader {
       }
     }
   }
+  __device__ __forceinline__ void store3(unsigned char* t) const {
+    const int c4 = threadIdx.x % CPR, r0 = threadIdx.x / CPR;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int r = r0 + p * RPP;
+      if (r < BR) x3s_store4(t, BR * kX3sRowBytes, r, 4 * c4, reg[p]);
+    }
+  }
 };
 
 // ---------------------------------------------------------------------------------------
@@ -391,7 +414,7 @@ struct EpiArgs {
   int act;               // 1 relu-type, 2 elu-type
 };
 
-template <class Cfg, bool VEC, int EPI, int ACT>
+template <class Cfg, bool VEC, int EPI, int ACT, bool X3S = false>
 __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, ClassTab ct,
                                                                  WeightB wb, EpiArgs e) {
   using LA = ConvALoader<Cfg, Cfg::BM, VEC, ACT>;
@@ -408,7 +431,8 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Cla
   typename Cfg::acc_t acc[Cfg::MT][Cfg::NT];
   zero_acc<Cfg>(acc);
   const int nkt = VEC ? taps.n * ((g.Ck + Cfg::BK - 1) / Cfg::BK) : (taps.n * g.Ck + Cfg::BK - 1) / Cfg::BK;
-  gemm_mainloop<Cfg>(la, lb, nkt, smem, acc);
+  if constexpr (X3S) gemm_mainloop_x3s<Cfg>(la, lb, nkt, reinterpret_cast<unsigned char*>(smem), acc);   // bf16 pipe, three pieces
+  else gemm_mainloop<Cfg>(la, lb, nkt, smem, acc);
 
   const int oa = ct.oa[cls], ob = ct.ob[cls];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1827,6 +1851,22 @@ void launch_igemm3(dim3 grid, hipStream_t s, const GatherA& ga, const ClassTab& 
   ensure_lds<conv_igemm_kernel<Cfg, VEC, EPI, ACT>>(lds);
   hipLaunchKernelGGL((conv_igemm_kernel<Cfg, VEC, EPI, ACT>), grid, dim3(Cfg::THREADS), lds, s, ga, ct, wb, e);
 }
+// the same launch on the split-precision main loop (vector gathers, BK = 16 configurations)
+template <class Cfg, int EPI, int ACT>
+void launch_igemm3_x3s(dim3 grid, hipStream_t s, const GatherA& ga, const ClassTab& ct, const WeightB& wb,
+                       const EpiArgs& e) {
+  static_assert(Cfg::BK == 16 && Cfg::TS == 32, "");
+  constexpr size_t lds = X3sLds<Cfg>::BYTES;
+  ensure_lds<conv_igemm_kernel<Cfg, true, EPI, ACT, true>>(lds);
+  hipLaunchKernelGGL((conv_igemm_kernel<Cfg, true, EPI, ACT, true>), grid, dim3(Cfg::THREADS), lds, s, ga, ct, wb, e);
+}
+inline bool igemm_x3s() {
+  static const bool on = [] {
+    const char* v = getenv("OTGAN_IGEMM_X3");
+    return !(v && v[0] == '0');
+  }();
+  return on;
+}
 
 // Picks the tile configuration for an implicit GEMM with `rows` x `cols_tiles128` output
 // (cols_tiles = number of 128-wide N tiles, i.e. 64 real channels when paired) and launches.
@@ -1853,14 +1893,27 @@ void launch_igemm(bool vec_ok, int Ck, int rows, int ncols, bool paired, int ncl
     // forward of the wide-but-not-256 outputs: one exact column tile instead of two 128-wide ones
     if (!paired && vec_ok && Ck % 32 == 0 && ncols > 128 && ncols <= 160 && (long)ceil_div(rows, 128) * ncls >= 256) {
       dim3 grid(ceil_div(rows, CfgW160::BM), 1, ncls);
-      launch_igemm3<CfgW160, true, EPI, ACT>(grid, s, ga, ct, wb, e);
+      if (igemm_x3s()) launch_igemm3_x3s<CfgW160k16, EPI, ACT>(grid, s, ga, ct, wb, e);
+      else launch_igemm3<CfgW160, true, EPI, ACT>(grid, s, ga, ct, wb, e);
       return;
     }
     if (!paired && vec_ok && Ck % 16 == 0 && ncols > 192 && ncols <= 224 && (long)ceil_div(rows, 128) * ncls >= 256) {
       dim3 grid(ceil_div(rows, CfgW224::BM), 1, ncls);
-      launch_igemm3<CfgW224, true, EPI, ACT>(grid, s, ga, ct, wb, e);
+      if (igemm_x3s()) launch_igemm3_x3s<CfgW224, EPI, ACT>(grid, s, ga, ct, wb, e);
+      else launch_igemm3<CfgW224, true, EPI, ACT>(grid, s, ga, ct, wb, e);
       return;
     }
+  }
+  if (vec_ok && Ck % 4 == 0 && igemm_x3s()) {   // (a tap's last K tile is zero-filled past Ck)
+    const long tiles128 = (long)ceil_div(rows, 128) * ntiles * ncls;
+    if (tiles128 < 512) {
+      dim3 grid(ceil_div(rows, CfgSmall16::BM), ntiles, ncls);
+      launch_igemm3_x3s<CfgSmall16, EPI, ACT>(grid, s, ga, ct, wb, e);
+    } else {
+      dim3 grid(ceil_div(rows, CfgMain16::BM), ntiles, ncls);
+      launch_igemm3_x3s<CfgMain16, EPI, ACT>(grid, s, ga, ct, wb, e);
+    }
+    return;
   }
   if (vec_ok && Ck % 32 == 0) {
     const long tiles128 = (long)ceil_div(rows, 128) * ntiles * ncls;

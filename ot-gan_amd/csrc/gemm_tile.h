@@ -111,6 +111,107 @@ __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int nkt, float* sm
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Split-precision variant of the main loop (32x32 tiles, BK = 16): the loaders split every element ONCE, while
+// staging it, into three bf16 pieces x = hi + mid + lo (8 + 8 + 8 significand bits: exact) and write three
+// k-contiguous LDS planes [rows][16 k] (32 bytes a row); a fragment (row = lane % 32, k = 8 * (lane / 32) .. +7) is
+// one ds_read_b128 per plane, and a 16-wide k slab costs six v_mfma_f32_32x32x16_bf16 (the products of weight
+// >= 2^-16; gemm_x3.h) = 192 matrix-pipe cycles per tile instead of 8 x 64 = 512 on the fp32 instructions.
+// The two 16-byte halves of a row are swapped on every other group of four rows, which makes both the b128
+// fragment reads (8 lanes per phase) and the 8-byte staging writes conflict-free without padding:
+// LDS = 2 buffers x 3 planes x (BM + BN) x 32 B = 48 KB for a 128 x 128 tile (three workgroups per CU).
+// A loader provides store3(unsigned char* tile) next to store().
+// ---------------------------------------------------------------------------------------
+typedef __bf16 gt_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gt_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float gt_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int gt_u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kX3sRowBytes = 32;
+// byte offset of k (a multiple of 4) of row r inside a plane
+__device__ __forceinline__ int x3s_off(int r, int k) {
+  return r * kX3sRowBytes + ((((k >> 3) ^ (r >> 2)) & 1) << 4) + ((k & 4) << 1);
+}
+// four consecutive k of one row -> the three planes (plane stride `plane` bytes)
+__device__ __forceinline__ void x3s_store4(unsigned char* tile, int plane, int r, int k, float4 v) {
+  gt_f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+  const gt_bf16x2 ha = __builtin_convertvector(a, gt_bf16x2), hb = __builtin_convertvector(b, gt_bf16x2);
+  a -= __builtin_convertvector(ha, gt_f32x2);
+  b -= __builtin_convertvector(hb, gt_f32x2);
+  const gt_bf16x2 ma = __builtin_convertvector(a, gt_bf16x2), mb = __builtin_convertvector(b, gt_bf16x2);
+  a -= __builtin_convertvector(ma, gt_f32x2);
+  b -= __builtin_convertvector(mb, gt_f32x2);
+  const gt_bf16x2 la = __builtin_convertvector(a, gt_bf16x2), lb = __builtin_convertvector(b, gt_bf16x2);
+  unsigned char* d = tile + x3s_off(r, k);
+  *reinterpret_cast<gt_u32x2*>(d) = gt_u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+  *reinterpret_cast<gt_u32x2*>(d + plane) = gt_u32x2{__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb)};
+  *reinterpret_cast<gt_u32x2*>(d + 2 * plane) = gt_u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
+}
+
+template <class Cfg>
+struct X3sLds {
+  static constexpr int PA = Cfg::BM * kX3sRowBytes, PB = Cfg::BN * kX3sRowBytes;   // plane bytes
+  static constexpr int TA = 3 * PA, TB = 3 * PB;                                   // one buffer of an operand
+  static constexpr int BYTES = 2 * (TA + TB);
+};
+
+template <class Cfg, class LA, class LB>
+__device__ __forceinline__ void gemm_mainloop_x3s(LA& la, LB& lb, int nkt, unsigned char* smem,
+                                                  typename Cfg::acc_t (&acc)[Cfg::MT][Cfg::NT]) {
+  constexpr int MT = Cfg::MT, NT = Cfg::NT, TS = Cfg::TS;
+  static_assert(TS == 32 && Cfg::BK == 16, "split-precision main loop: 32x32 tiles, BK = 16");
+  using L = X3sLds<Cfg>;
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + 2 * L::TA;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int li = lane & 31, lh = lane >> 5;
+  int a_off[MT], b_off[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) a_off[mt] = x3s_off((wm * MT + mt) * TS + li, 8 * lh);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) b_off[nt] = x3s_off((wn * NT + nt) * TS + li, 8 * lh);
+  if (nkt <= 0) return;
+  la.load(0);
+  lb.load(0);
+  la.store3(sA);
+  lb.store3(sB);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    const bool more = (kt + 1 < nkt);
+    if (more) {
+      la.load(kt + 1);
+      lb.load(kt + 1);
+    }
+    const unsigned char* pa = sA + cur * L::TA;
+    const unsigned char* pb = sB + cur * L::TB;
+    gt_bf16x8 fa[3][MT], fb[3][NT];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) fa[p][mt] = *reinterpret_cast<const gt_bf16x8*>(pa + p * L::PA + a_off[mt]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) fb[p][nt] = *reinterpret_cast<const gt_bf16x8*>(pb + p * L::PB + b_off[nt]);
+    }
+    // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi (smallest first); term-major: consecutive MFMAs never share an accumulator
+#pragma unroll
+    for (int term = 0; term < 6; ++term) {
+      constexpr int pa_of[6] = {2, 0, 1, 1, 0, 0}, pb_of[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa_of[term]][mt], fb[pb_of[term]][nt], acc[mt][nt], 0, 0, 0);
+    }
+    if (more) {
+      la.store3(sA + (cur ^ 1) * L::TA);
+      lb.store3(sB + (cur ^ 1) * L::TB);
+    }
+    __syncthreads();
+  }
+}
+
 template <class Cfg>
 __device__ __forceinline__ void zero_acc(typename Cfg::acc_t (&acc)[Cfg::MT][Cfg::NT]) {
 #pragma unroll
