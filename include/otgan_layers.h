@@ -112,7 +112,8 @@ int otgan_absmax_f32(const float* x, long rows, int C, long ld, float* record, v
  * OTGAN_DISABLE_WINO_PLAIN3=1 (wide 3x3 stride-1 layers back on the implicit GEMM), OTGAN_PLAIN3_MIN_CEFF / _MIN_COUT
  * (their eligibility thresholds, 64 / 128), OTGAN_DISABLE_WINO_UP3=1, OTGAN_DISABLE_WINO_UP3_WGRAD=1,
  * OTGAN_DISABLE_WINO_UP3_DGRAD=1 (3x3 upsampling layers: all passes / weight gradient / input gradient back on the
- * folded implicit GEMM), OTGAN_DISABLE_X_OPERAND=1 (otgan_conv2d_operand_bytes reports 0: no operand sharing).
+ * folded implicit GEMM), OTGAN_DISABLE_X_OPERAND=1 (otgan_conv2d_operand_bytes reports 0: no operand sharing),
+ * OTGAN_IGEMM_X3=0 (implicit-GEMM forward / input gradient back on the fp32 MFMA loop instead of three bf16 pieces).
  */
 
 /*
