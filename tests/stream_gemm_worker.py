@@ -16,11 +16,19 @@ CASES = [  # name, N, H, C, Cout, k, stride, upsample, preact
 ]
 
 
+# layers on the implicit-GEMM engine (3x3 stride 2: no Winograd path), selected with OTGAN_WORKER_CASES=igemm
+IGEMM_CASES = [
+    ("s2_k3_144", 16, 32, 288, 144, 3, 2, False, "crelu"),   # the 128 x 160 forward tile, paired input gradient
+    ("s2_k3_200", 16, 16, 200, 200, 3, 2, False, "crelu"),   # channel counts that are multiples of 4 only
+    ("s2_k3_none", 8, 16, 64, 96, 3, 2, False, None),
+]
+
+
 def main(out):
     dev = torch.device("cuda:0")
     _lib.lib()
     res = {}
-    for name, N, H, C, Cout, k, s, up, pre in CASES:
+    for name, N, H, C, Cout, k, s, up, pre in (IGEMM_CASES if os.environ.get("OTGAN_WORKER_CASES") == "igemm" else CASES):
         gen = torch.Generator().manual_seed(sum(map(ord, name)))
         mult = 2 if pre == "crelu" else 1
         x0 = torch.randn(N, H, H, C, generator=gen)

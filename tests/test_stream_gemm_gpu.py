@@ -76,3 +76,31 @@ def test_split_engines_are_no_worse_than_the_fp32_mfma_engine(tmp_path):
             assert err["fp16x2"] < 2e-5 and err["bf16x3"] < 2e-5, (name, tag, err)
             assert err["fp16x2"] <= 1.25 * err["fp32"] + 1e-7, (name, tag, err)
             assert err["bf16x3"] <= 1.25 * err["fp32"] + 1e-7, (name, tag, err)
+
+
+def test_igemm_split_loop_is_no_worse_than_the_fp32_loop(tmp_path):
+    """The implicit-GEMM engine's split-precision main loop (three bf16 pieces split while staging, six MFMAs per 16 k)
+    against its fp32 MFMA loop (OTGAN_IGEMM_X3=0) on stride-2 3x3 layers, both measured against fp64: the products are
+    fp32-exact in both, so the errors agree to the accumulation order."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+    import nets_torch as NT
+    from stream_gemm_worker import IGEMM_CASES
+    runs = {"x3": _run(1, tmp_path / "a.npz", OTGAN_WORKER_CASES="igemm"),
+            "fp32": _run(1, tmp_path / "b.npz", OTGAN_WORKER_CASES="igemm", OTGAN_IGEMM_X3="0")}
+    for name, N, H, C, Cout, k, s, up, pre in IGEMM_CASES:
+        gen = torch.Generator().manual_seed(sum(map(ord, name)))
+        mult = 2 if pre == "crelu" else 1
+        x = torch.randn(N, H, H, C, generator=gen).double().requires_grad_(True)
+        V = (torch.randn(k, k, C * mult, Cout, generator=gen) * 0.05).double().requires_grad_(True)
+        y = NT.conv2d([x], {"V": V, "g": torch.ones(Cout, dtype=torch.float64), "b": torch.zeros(Cout, dtype=torch.float64)},
+                      pre, s, up)
+        dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7)).double()
+        dx, dV = torch.autograd.grad(y, [x, V], dy)
+        for tag, ref in (("y", y), ("dx", dx)):        # (the weight gradient runs the same kernel in both modes)
+            ref = ref.detach().numpy()
+            err = {e: float(np.linalg.norm(r[f"{name}.{tag}.0"] - ref) / np.linalg.norm(ref)) for e, r in runs.items()}
+            assert err["x3"] < 2e-5, (name, tag, err)
+            assert err["x3"] <= 1.25 * err["fp32"] + 1e-7, (name, tag, err)
+        assert not np.array_equal(runs["x3"][f"{name}.y.0"], runs["fp32"][f"{name}.y.0"]), "both runs took the same loop"
