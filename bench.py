@@ -115,11 +115,24 @@ def main():
     from otgan_amd import _lib, parallel
     from otgan_amd.trainer import OTGAN, default_args
 
+    if a.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if a.gpus > 1 and not parallel.launched():
+        # started plainly (the way the reference starts all its towers from one command, train.py:72-85): become
+        # the launcher of one process per GPU and hand back the ranks' exit code
+        try:
+            sys.exit(parallel.self_launch(os.path.abspath(__file__), sys.argv[1:], a.gpus))
+        except parallel.LaunchError as e:
+            sys.exit(f"bench.py --gpus {a.gpus}: {e}")
+    try:
+        parallel.check_devices(a.gpus)
+    except parallel.LaunchError as e:
+        sys.exit(f"bench.py --gpus {a.gpus}: {e}")
     rank, world, local = parallel.init_from_env()
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    if os.environ.get("OTGAN_SINGLE_DEVICE"):   # test mode: all ranks on cuda:0 (with gloo)
-        local = 0
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks; start it as "
+                 f"`python bench.py --gpus {a.gpus}` (self-launching) or `python -m torch.distributed.run "
+                 f"--nproc-per-node {a.gpus} bench.py --gpus {a.gpus}`")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.lib()
@@ -138,15 +151,27 @@ def main():
     for _ in range(a.warmup):
         model.step(x)
     torch.cuda.synchronize()
-    # ---- pass 1 (the headline `value`): exactly K steps, NO per-launch profiling
+    # the timed window starts on a critic step whatever W was (the reference's schedule, train.py:214: a critic step
+    # when step % 6 == 0): K steps then hold ceil(K/6) critic steps; the mix is reported in `config`
+    period = args.nr_gen_per_disc + 1
+    model.step_counter = 0
+    n_disc = -(-a.steps // period)
+    # ---- pass 1 (the headline `value`): exactly K steps, NO per-launch profiling (one event per step boundary on the
+    # compute stream -- no synchronisation -- gives the per-kind step times reported next to the wall-clock value)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(a.steps):
         last = model.step(x)
+        marks[i + 1].record()
     torch.cuda.synchronize()
     parallel.barrier()
     dt = time.perf_counter() - t0
+    per_kind = {"disc": [], "gen": []}
+    for i in range(a.steps):
+        per_kind["disc" if i % period == 0 else "gen"].append(marks[i].elapsed_time(marks[i + 1]))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if torch.distributed.get_backend() == "gloo" else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -157,6 +182,7 @@ def main():
     if not a.no_prof:
         _lib.prof_reset()
         _lib.prof_enable(True)
+        model.step_counter = 0
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(a.steps):
@@ -184,7 +210,17 @@ def main():
                                f"{a.batch_per_gpu // 2} (Sinkhorn rows N={world * a.batch_per_gpu // 2 if a.matching_scope == 'global' else a.batch_per_gpu // 2}), "
                                f"{a.nr_sinkhorn_iter} Sinkhorn iters, lambda 500, 5:1 generator:critic steps, Adam",
                    "global_batch": world * a.batch_per_gpu, "parallelism": f"dp{world}",
-                   "matching_scope": args.matching_scope if world > 1 else "local",
+                   "ranks": parallel.world_size(),
+                   "backend": (torch.distributed.get_backend() + (" (RCCL)" if torch.distributed.get_backend() == "nccl" else
+                                                                  " (all ranks on cuda:0, logic test)" if parallel.single_device_mode() else "")
+                               if torch.distributed.is_initialized() else "none (single process)"),
+                   "sinkhorn_rows": model.sinkhorn_rows(),
+                   "matching_scope": model.scope,
+                   "step_mix": {"critic_steps": n_disc, "generator_steps": a.steps - n_disc,
+                                "critic_ms": round(sum(per_kind["disc"]) / max(1, len(per_kind["disc"])), 3),
+                                "generator_ms": (round(sum(per_kind["gen"]) / len(per_kind["gen"]), 3) if per_kind["gen"] else None),
+                                "note": "timed window starts on a critic step; the reference's schedule is 1 critic : "
+                                        f"{args.nr_gen_per_disc} generator steps (train.py:24,214)"},
                    **({"collectives": "forced (RCCL, world size 1)"} if (world == 1 and model.collectives) else {}),
                    "last_distance": float(last["distance"]), "last_entropy": float(last["entropy"]),
                    "precision_note": ("fp32 tensors and fp32 accumulation everywhere; the Winograd-domain GEMMs multiply "
@@ -216,15 +252,17 @@ def main():
         ach = d["flop"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
         # HBM traffic per launch of that kernel class: from the committed rocprofv3 PMC passes
         # (tools/pmc_bench.sh -> profiles/r01_pmc_summary.json), not measurable in-process.
-        traffic = None
+        traffic, traffic_src = None, None
         try:
             if not (default_cfg or a.model == "densenet"):
                 raise LookupError("no PMC summary for this configuration")
-            for rnd in ("r02", "r02b", "r01"):          # newest committed PMC summary of this configuration
+            for rnd in ("r03", "r02", "r02b", "r01"):          # newest committed PMC summary of this configuration
                 fn = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary_{a.model}.json")
                 if os.path.exists(fn):
                     with open(fn) as f:
                         traffic = round(json.load(f)[dom]["hbm_bytes_per_launch"])
+                    traffic_src = (f"profiles/{rnd}_pmc_summary_{a.model}.json: rocprofv3 --pmc passes of this command, "
+                                   "committed (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); looked up, not measured in this run")
                     break
         except Exception:
             pass
@@ -233,7 +271,7 @@ def main():
         peak = PEAK_BF16_MFMA_TFLOPS if dom == "wino_gemm_bf16x3" else PEAK_F32_MFMA_TFLOPS
         out["roofline"] = {"bound": "mfma", "kernel": kname.get(dom, dom), "achieved": round(ach, 2),
                            "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(ach / peak, 4), "traffic": traffic,
+                           "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                            "launches": d["launches"], "avg_ms": round(d["ms"] / max(d["launches"], 1), 4),
                            "pass": f"second pass of {a.steps} steps with per-launch HIP events "
                                    f"({dt_prof / a.steps * 1e3:.3f} ms/step; the headline pass ran unprofiled)"}

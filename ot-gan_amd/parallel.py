@@ -26,6 +26,9 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if single_device_mode():      # every rank on cuda:0, gloo transport (RCCL refuses two ranks on one device)
+        local = 0
+        os.environ.setdefault("OTGAN_DIST_BACKEND", "gloo")
     force = os.environ.get("OTGAN_FORCE_COLLECTIVES") == "1"
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -39,6 +42,56 @@ def init_from_env(backend=None):
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+class LaunchError(RuntimeError):
+    """A multi-rank run was asked for that this node cannot start."""
+
+
+def launched():
+    """True inside a rank started by torchrun / torch.distributed.run (or by `self_launch`)."""
+    return "WORLD_SIZE" in os.environ and "RANK" in os.environ
+
+
+def single_device_mode():
+    """OTGAN_SINGLE_DEVICE=1 (tests of the multi-rank logic on a 1-GPU box): every rank uses cuda:0 and the
+    transport is gloo, because RCCL refuses two ranks on one device."""
+    return os.environ.get("OTGAN_SINGLE_DEVICE", "") not in ("", "0")
+
+
+def check_devices(nranks):
+    """Raise LaunchError unless `nranks` one-GPU ranks can run on this node."""
+    if not torch.cuda.is_available():
+        raise LaunchError("no MI355X visible (torch.cuda.is_available() is False): there is no CPU fallback")
+    have = torch.cuda.device_count()
+    if nranks > have and not single_device_mode():
+        raise LaunchError(f"{nranks} ranks requested but this node exposes {have} GPU(s); one process per GPU is the "
+                          f"only layout (set OTGAN_SINGLE_DEVICE=1 to run all ranks on cuda:0 over gloo -- a logic "
+                          f"test, not a measurement)")
+
+
+def self_launch(script, argv, nranks):
+    """The reference drives every device from ONE command (`for i in range(args.nr_gpu): with
+    tf.device('/gpu:%d' % i)`, train.py:72-85).  Here a rank is a process: when `script` is started plainly
+    (no WORLD_SIZE in the environment) and more than one rank is wanted, re-execute it under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node nranks` on the loopback address and return the
+    children's exit code.  The caller exits with it."""
+    import socket
+    import subprocess
+    import sys
+    check_devices(nranks)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    if single_device_mode():
+        env.setdefault("OTGAN_DIST_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    return subprocess.call(cmd, env=env)
 
 
 def world_size():
@@ -226,6 +279,19 @@ class GradBuckets:
         self.works = []
         self.armed = False
         return list(self.views)
+
+
+def broadcast_(t, src=0):
+    """In-place broadcast of rank `src`'s tensor (replica synchronisation after a data-dependent pass)."""
+    if world_size() == 1:
+        return t
+    if _staged() and t.is_cuda:
+        host = t.detach().cpu()
+        dist.broadcast(host, src=src)
+        t.detach().copy_(host)
+    else:
+        dist.broadcast(t.detach(), src=src)
+    return t
 
 
 def barrier():

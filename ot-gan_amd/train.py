@@ -58,6 +58,9 @@ def build_parser():
     p.add_argument('--data_dependent_init', action='store_true',
                    help="run the reference's intended (never executed, SURVEY F7) data-dependent initialisation pass "
                         "on the first batch: g <- init_scale / std, b <- -mean * g per layer (utils/nn.py:133-162)")
+    p.add_argument('--ranks', type=int, default=0,
+                   help='processes (= GPUs) to run on when started plainly, without torchrun; 0 = as many of the visible '
+                        'GPUs as divide --nr_gpu (the reference drives nr_gpu devices from one command, train.py:72-85)')
     p.add_argument('--eval_every', type=int, default=100, help='Inception score every this many epochs (reference: 100, train.py:245)')
     p.add_argument('--eval_samples', type=int, default=50000, help='samples per score (reference: 50000, train.py:262)')
     p.add_argument('--inception_model', type=str, default='',
@@ -120,11 +123,31 @@ def save_tile_png(x, path, n=100):
     Image.fromarray(sheet).save(path)
 
 
+def auto_ranks(nr_gpu, devices, scope='global'):
+    """Largest rank count <= devices that divides the nr_gpu logical shards (and is even or 1 in the global matching
+    scope, where a rank's rows must lie inside one mini-batch half; an even shard count per rank in the local one)."""
+    for r in range(min(devices, nr_gpu), 0, -1):
+        if nr_gpu % r == 0 and ((r == 1 or r % 2 == 0) if scope == 'global' else (nr_gpu // r) % 2 == 0):
+            return r
+    return 1
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     assert args.nr_gpu % 2 == 0                                   # train.py:34
     from . import parallel
     from .trainer import OTGAN
+    if not parallel.launched():
+        # one command drives every device, like the reference's tower loop (train.py:72-85): a rank is a process
+        # here, so the plain invocation re-executes itself under torch.distributed.run
+        want = args.ranks or auto_ranks(args.nr_gpu, torch.cuda.device_count() if torch.cuda.is_available() else 0,
+                                        args.matching_scope)
+        if want > 1:
+            script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'train.py')
+            try:
+                sys.exit(parallel.self_launch(script, sys.argv[1:] if argv is None else list(argv), want))
+            except parallel.LaunchError as e:
+                sys.exit('train.py --ranks %d: %s' % (want, e))
     rank, world, local = parallel.init_from_env()
     if not torch.cuda.is_available():
         raise RuntimeError("training needs MI355X GPUs: there is no CPU fallback")

@@ -79,8 +79,15 @@ class OTGAN:
             nn.data_dependent_init(False)
         self.num_features = f.shape[-1]
         # one flat buffer per network: optimiser / EMA / gradient all-reduce act on it in one go
-        self.discriminator.flatten()
-        self.generator.flatten()
+        groups = (self.discriminator.flatten(), self.generator.flatten())
+        if ddi and self.world > 1:
+            # the data-dependent pass draws the generator's latent from the per-rank RNG stream (train.py seeds
+            # seed + rank), so every rank computed its own g / b statistics: the replicas would start different and
+            # never meet (only gradients are exchanged).  Rank 0's initialisation is the run's.
+            from . import ops
+            for grp in groups:
+                parallel.broadcast_(grp.flat, src=0)
+            ops.bump_weights_epoch()
         self.disc_params = self.discriminator.trainable_variables()     # train.py:61
         self.gen_params = self.generator.trainable_variables()          # train.py:62
         self.ema = nn.ExponentialMovingAverage(decay=0.999)             # train.py:63
@@ -98,6 +105,12 @@ class OTGAN:
         self.disc_optimizer = mk[args.optimizer](self.disc_params, **kw)        # train.py:143
         self.step_counter = 0
         self.last = {}
+
+    def sinkhorn_rows(self):
+        """Rows N of one Sinkhorn problem of this run (matching.py:16-19: the shards of the matching scope form two
+        halves; --single_batch solves over all of them, matching.py:91-93)."""
+        S = self.args.nr_gpu if (self.scope == "global" and self.world > 1) else self.shards
+        return S * self.args.batch_size if self.args.single_batch else (S // 2) * self.args.batch_size
 
     # ---------------------------------------------------------------- matching (train.py:88-98)
     def _match(self, f_gen, f_dat, pending_dat=None):

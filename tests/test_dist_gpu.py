@@ -92,3 +92,49 @@ def test_two_ranks_equal_single_process():
         for a, b in zip(got[kind], ref[kind]):
             err = float((a - b).norm() / b.norm().clamp_min(1e-30))
             assert err < 2e-3, (kind, err)
+
+
+def _ddi_worker(rank, world, port, path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from otgan_amd import parallel
+    from otgan_amd.trainer import OTGAN, default_args
+    parallel.init_from_env(backend="gloo")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    torch.manual_seed(11 + rank)            # train.py seeds seed + rank: the generator's init latent differs per rank
+    args = default_args(model="dcgan", batch_size=B, nr_gpu=2, sinkhorn_lambda=LAM, nr_sinkhorn_iter=ITERS,
+                        nr_gen_per_disc=1, seed=5, matching_scope="global", data_dependent_init=True)
+    x, _ = _data()
+    m = OTGAN(args, dev, init_batch=x[:B])
+    sd = {k: v.detach().cpu() for t in (m.discriminator, m.generator) for k, v in t.named_variables().items()}
+    sd["__ema__"] = [m.ema.average(p).detach().cpu() for p in m.gen_params]
+    torch.save(sd, path + str(rank))
+    parallel.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_data_dependent_init_gives_identical_replicas():
+    """with --data_dependent_init every rank ran the init pass on its own latent draw and nothing
+    synchronised the result.  Rank 0's initialisation is broadcast before the EMA shadows are cloned."""
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "sd")
+        port = _free_port()
+        ctx = mp.get_context("spawn")
+        procs = [ctx.Process(target=_ddi_worker, args=(r, 2, port, path)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(600)
+            assert p.exitcode == 0
+        a, b = torch.load(path + "0"), torch.load(path + "1")
+    moved = 0
+    for k in a:
+        if k == "__ema__":
+            for u, v in zip(a[k], b[k]):
+                assert torch.equal(u, v)
+            continue
+        assert torch.equal(a[k], b[k]), k
+        if k.endswith("/g") and "generator" in k:
+            moved += int(not torch.all(a[k] == 1.0))
+    assert moved > 0                        # the pass really ran (g left its default of 1)
