@@ -304,7 +304,7 @@ def default_args(**over):
              load_params=False, model_name='med_gan_params-2399', no_sinkhorn=False,
              image_size=32, matching_scope='global', synthetic=False, max_steps=0, save_every=200,
              synthetic_size=50000, data_dependent_init=False, eval_every=100, eval_samples=50000,
-             inception_model='')
+             inception_model='', ranks=0)
     d.update(over)
     return argparse.Namespace(**d)
 
