@@ -554,6 +554,303 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 }
 
 
+#if X3_PIECES == 2
+// ---- the same GEMM on a 256 x 128 tile, TWO workgroups per compute unit (round 3) ------------------------------
+// Where a 256 x 256 tile's time goes with three MFMAs per product (tools/ablate/x3_phase.hip, cycles, K = 256):
+// 6 k until the first fragments are in registers (every compute unit's first 96 KB arrive in one HBM burst), 32 k in
+// the K loop (24.6 k of MFMA issue), 12 k writing C (256 KB per compute unit at the ~21 B/clk a compute unit gets
+// out of its L2 write path -- request-bound, not store-issue bound: 16-byte stores of 32-byte row segments took
+// 22 k), and the next workgroup reaches the compute unit a few thousand cycles later.  A one-wave-per-SIMD
+// workgroup owns the compute unit (512 registers, 144 KB of LDS), so nothing runs under its prologue and write-out:
+// 40 % of a K = 256 tile, 25 % at K = 512.  Here the tile is 256 x 128 with the same four waves (wave tile
+// 128 x 64: eight accumulator tiles = 128 registers, both fragment sets double-buffered = 96, 256 in all) and three
+// stages of 24 KB: two workgroups fit a compute unit and two waves share a SIMD, so one workgroup's write-out,
+// prologue, barrier waits and global_load_lds issue stalls (100 - 185 cycles each next to fragment reads:
+// MI355X_MICROARCH.md) are covered by the other's MFMAs.  Price: 1.5 x the operand bytes (L2 -> LDS, fragment reads)
+// per product.  Same operand layout, pipeline (three stages ahead, one barrier per stage, counted vmcnt), grid maps
+// and strided-layer handling as wino_bgemm_x3_kernel<true, TL>; host contract: nst even and >= 4.
+constexpr int X3N_NT = 2, X3N_BN = X3N_NT * 64;
+constexpr int X3N_TB = X3N_BN * X3_SK * 2;
+constexpr int X3N_STAGE = X3_NP * (X3_TA + X3N_TB);
+constexpr size_t X3N_LDS = (size_t)X3_NSTAGE * X3N_STAGE;
+constexpr int X3N_CHA = X3_NP * X3_BM / 32, X3N_CHB = X3_NP * X3N_BN / 32;   // 1 KiB chunks per stage: A 16, B 8
+constexpr int X3N_PER_WAVE = (X3N_CHA + X3N_CHB) / 4;
+static_assert(X3N_PER_WAVE * 4 == X3N_CHA + X3N_CHB, "chunks divide over four waves");
+
+struct X3NFrags {
+  x3frag_t a[X3_MT][X3_NP];
+  x3frag_t b[X3N_NT][X3_NP];
+};
+// R fragment reads spread over the NM MFMAs of a term group
+template <int DS, int R, int NM, int Q = 0>
+__device__ __forceinline__ void x3n_sched_group() {
+  if constexpr (Q < R) {
+    __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, (Q + 1) * NM / R - Q * NM / R, 0);
+    x3n_sched_group<DS, R, NM, Q + 1>();
+  }
+}
+
+#ifdef X3_TIMING
+#define X3N_STAMP(i) do { if (threadIdx.x == 0 && (i) < 64) reinterpret_cast<unsigned long long*>(smem3 + X3N_LDS)[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define X3N_STAMP(i) do { } while (0)
+#endif
+template <bool TL>
+__global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_bgemm_x3n_kernel(BgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  const int x = blockIdx.x;
+  X3N_STAMP(0);
+  int tm, tn, fsel = -1;
+  if (a.xmap == 4) {
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int xcd = x & 7, idx = x >> 3;
+    const int slot = idx / tiles, tile = idx - slot * tiles;
+    const int code = (unsigned char)a.fmap[xcd][slot];
+    if (code == 255) return;
+    const int half = (tiles + 1) >> 1;
+    if ((code & 64) && tile >= half) return;
+    if ((code & 128) && tile < half) return;
+    fsel = __builtin_amdgcn_readfirstlane(code & 63);
+    tn = __builtin_amdgcn_readfirstlane(tile % a.tiles_n);
+    tm = __builtin_amdgcn_readfirstlane(tile / a.tiles_n);
+  } else {
+    tn = x % a.tiles_n;
+    tm = x / a.tiles_n;
+  }
+  const int f = fsel >= 0 ? fsel : lpt_frequency(a.seg_mode, blockIdx.z);
+  const int m0 = a.m_begin + tm * X3_BM, n0 = tn * X3N_BN;
+  const int Kz = a.ztab ? a.zK[f] : a.K;
+  if (a.seg_mode == 2 || a.seg_mode == 3) {
+    const int lo = a.seg_mode == 2 ? n0 : m0, ext = a.seg_mode == 2 ? a.N : a.M;
+    int hi = lo + (a.seg_mode == 2 ? X3N_BN : X3_BM) - 1;
+    if (hi >= ext) hi = ext - 1;
+    bool any = false;
+    for (int c = lo / a.seg_len; c <= hi / a.seg_len; ++c) any = any || s2_present(c, f, a.seg_skip);
+    if (!any) return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, g = lane >> 5;
+
+  int lo0 = 0, len0 = 0, lo1 = 0, len1 = 0;
+  if (a.seg_mode == 1) {
+    int c = 0, nrun = 0;
+    while (c < 4) {
+      if (!s2_present(c, f, a.seg_skip)) {
+        ++c;
+        continue;
+      }
+      int e = c + 1;
+      while (e < 4 && s2_present(e, f, a.seg_skip)) ++e;
+      if (nrun == 0) {
+        lo0 = c * a.seg_len;
+        len0 = (e - c) * a.seg_len;
+      } else {
+        lo1 = c * a.seg_len;
+        len1 = (e - c) * a.seg_len;
+      }
+      ++nrun;
+      c = e;
+    }
+  } else {
+    const int nkt_all = Kz / X3_BK;
+    const int kt0 = blockIdx.y * a.kt_per_split;
+    int nkt = nkt_all - kt0;
+    if (nkt > a.kt_per_split) nkt = a.kt_per_split;
+    if (nkt < 0) nkt = 0;
+    lo0 = kt0 * X3_BK;
+    len0 = nkt * X3_BK;
+  }
+  const int steps0 = len0 / X3_SK;
+  const int nst = steps0 + len1 / X3_SK;
+  const int kb0 = lo0 / X3_SK, kb1 = lo1 / X3_SK - steps0;
+  auto kb_of = [&](int st) { return st < steps0 ? kb0 + st : kb1 + st; };
+
+  // this wave's six chunk streams out of the stage's 24 (A: piece x eight row groups of 32, then B: piece x four):
+  // scalar base address at k block 0, LDS offset inside a stage, and (TL) the operand's column-block count
+  const u16* opA = a.Ap + (a.ztab ? a.zA[f] : f * a.sAp);
+  const u16* opB = a.Bp + (a.ztab ? a.zB[f] : f * a.sBp);
+  const unsigned voff = TL ? (unsigned)(lane >> 5) * 1024u + (unsigned)(lane & 31) * 16u : (unsigned)lane * 16u;
+  const unsigned lds_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smem3;
+  const u16* cbase[X3N_PER_WAVE];
+  unsigned cdst[X3N_PER_WAVE];
+  int ccbn[X3N_PER_WAVE];
+#pragma unroll
+  for (int i = 0; i < X3N_PER_WAVE; ++i) {
+    const int li = wave * X3N_PER_WAVE + i;
+    const bool isA = li < X3N_CHA;
+    const int l2 = isA ? li : li - X3N_CHA;
+    const int piece = isA ? l2 >> 3 : l2 >> 2, rg = isA ? l2 & 7 : l2 & 3;
+    const u16* opb = (isA ? opA : opB) + piece * (isA ? a.pA : a.pB);
+    if (TL) {
+      const int cbn = isA ? a.cbA : a.cbB;
+      int cb = ((isA ? m0 : n0) >> 4) + 2 * rg;
+      if (cb > ((cbn - 1) & ~1)) cb = (cbn - 1) & ~1;   // (see the 256 x 256 kernel: duplicates feed columns never stored)
+      cbase[i] = opb + ((long)cb << 9);
+      ccbn[i] = cbn;
+    } else {
+      int rb = ((isA ? m0 : n0) >> 5) + rg;
+      const int rbmax = (isA ? a.rbA : a.rbB) - 1;
+      if (rb > rbmax) rb = rbmax;
+      cbase[i] = opb + (((long)rb * a.kblocks) << 9);
+      ccbn[i] = 0;
+    }
+    cdst[i] = lds_base + (isA ? piece * X3_TA + rg * 1024 : X3_NP * X3_TA + piece * X3N_TB + rg * 1024);
+  }
+  auto issue = [&](int st, int buf, int i0 = 0, int n = X3N_PER_WAVE) {
+    const long kb = kb_of(st);
+#pragma unroll
+    for (int i = i0; i < i0 + n; ++i) {
+      const u16* src = cbase[i] + (TL ? ((((kb >> 1) * ccbn[i]) << 9) + ((kb & 1) << 8)) : (kb << 9));
+      const unsigned dst = cdst[i] + buf * X3N_STAGE;
+      asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst) : "memory");
+    }
+  };
+  f32x16 acc[X3_MT][X3N_NT];
+#pragma unroll
+  for (int i = 0; i < X3_MT; ++i)
+#pragma unroll
+    for (int j = 0; j < X3N_NT; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  const int sw = (r >> 3) & 1;
+  const int g4 = lane >> 4, l16 = lane & 15;
+  const int ftl = (g4 & 1) * 512 + (8 * (g4 >> 1) + (l16 >> 2)) * 32 + ((((l16 >> 1) & 1) ^ (g4 >> 1)) * 16) + (l16 & 1) * 8;
+  const int fa = TL ? wm * 4096 + ftl : (wm * X3_MT * 32 + r) * 32 + 16 * (g ^ sw);
+  const int fb = X3_NP * X3_TA + (TL ? wn * 2048 + ftl : (wn * X3N_NT * 32 + r) * 32 + 16 * (g ^ sw));
+  auto read_frag = [&](const unsigned char* p) -> x3frag_t {
+    if (TL) {
+      typedef short s16x4 __attribute__((ext_vector_type(4)));
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 128));
+      return __builtin_bit_cast(x3frag_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    } else {
+      return *reinterpret_cast<const x3frag_t*>(p);
+    }
+  };
+  auto load_frags = [&](X3NFrags& F, int buf) {
+    const unsigned char* pa = smem3 + buf * X3N_STAGE + fa;
+    const unsigned char* pb = smem3 + buf * X3N_STAGE + fb;
+#pragma unroll
+    for (int t = 0; t < X3_MT; ++t)
+#pragma unroll
+      for (int p = 0; p < X3_NP; ++p) F.a[t][p] = read_frag(pa + p * X3_TA + t * 1024);
+#pragma unroll
+    for (int t = 0; t < X3N_NT; ++t)
+#pragma unroll
+      for (int p = 0; p < X3_NP; ++p) F.b[t][p] = read_frag(pb + p * X3N_TB + t * 1024);
+  };
+  // one stage: stage st+1 has landed (counted vmcnt + barrier), the buffer stage st was read from is refilled with
+  // stage st+3, then the 24 MFMAs of stage st on F in three term groups of eight, each with two of the six refill
+  // loads and four of the twelve fragment reads of stage st+1 (into G) in front
+  auto stage = [&](int st, int bufn, const X3NFrags& F, X3NFrags& G, auto issue_c, auto pend_c, auto load_c) {
+    constexpr bool ISSUE = decltype(issue_c)::value, PEND = decltype(pend_c)::value, LOAD = decltype(load_c)::value;
+    // vmcnt: this wave's share of stage st+1 has landed; lgkmcnt(0): its fragment reads of stage st (issued during
+    // stage st-1, the last ones just before this point) have RETURNED -- after the barrier the buffer they came from is
+    // refilled, and with eight waves on the compute unit a read still queued in the LDS can be overtaken by the
+    // first refill (seen: one wave's last B fragment of a stage stale, a few launches in ten; the MFMAs behind the
+    // barrier need these fragments at once anyway)
+    if (PEND) __builtin_amdgcn_s_waitcnt(0x0070 | (X3N_PER_WAVE & 15) | ((X3N_PER_WAVE >> 4) << 14));
+    else __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    const int rbuf = bufn == 0 ? X3_NSTAGE - 1 : bufn - 1;
+    const unsigned char* pa = smem3 + bufn * X3N_STAGE + fa;
+    const unsigned char* pb = smem3 + bufn * X3N_STAGE + fb;
+    constexpr int NRA = X3_MT * X3_NP, NR = (X3_MT + X3N_NT) * X3_NP;   // fragment reads of a stage: A first
+    x3_static_for<X3_NTERM>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      constexpr int l0 = t * X3N_PER_WAVE / X3_NTERM, l1 = (t + 1) * X3N_PER_WAVE / X3_NTERM;
+      constexpr int q0 = t * NR / X3_NTERM, q1 = (t + 1) * NR / X3_NTERM;
+      if (ISSUE) issue(st + 3, rbuf, l0, l1 - l0);
+      if (LOAD) {
+#pragma unroll
+        for (int q = q0; q < q1; ++q) {
+          if (q < NRA) G.a[q / X3_NP][q % X3_NP] = read_frag(pa + (q % X3_NP) * X3_TA + (q / X3_NP) * 1024);
+          else G.b[(q - NRA) / X3_NP][(q - NRA) % X3_NP] = read_frag(pb + ((q - NRA) % X3_NP) * X3N_TB + ((q - NRA) / X3_NP) * 1024);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < X3_MT; ++i)
+#pragma unroll
+        for (int j = 0; j < X3N_NT; ++j) acc[i][j] = X3_MFMA(F.a[i][X3_PA[t]], F.b[j][X3_PB[t]], acc[i][j]);
+      if (LOAD) x3n_sched_group<TL ? 2 : 1, q1 - q0, X3_MT * X3N_NT>();
+    });
+  };
+  using Y = std::true_type;
+  using N = std::false_type;
+  X3NFrags F0, F1;
+  issue(0, 0);
+  issue(1, 1);
+  issue(2, 2);
+  X3_WAIT_VM(2 * X3N_PER_WAVE);
+  __builtin_amdgcn_s_barrier();
+  load_frags(F0, 0);
+  X3N_STAMP(1);
+  int st = 0, bufn = 1;
+  auto next = [&]() { bufn = bufn == X3_NSTAGE - 1 ? 0 : bufn + 1; };
+  for (; st + 6 <= nst; st += 2) {
+    stage(st, bufn, F0, F1, Y{}, Y{}, Y{});
+    next();
+    stage(st + 1, bufn, F1, F0, Y{}, Y{}, Y{});
+    next();
+    X3N_STAMP(4 + (st >> 1));
+  }
+  stage(st, bufn, F0, F1, Y{}, Y{}, Y{});
+  next();
+  stage(st + 1, bufn, F1, F0, N{}, Y{}, Y{});
+  next();
+  stage(st + 2, bufn, F0, F1, N{}, N{}, Y{});
+  next();
+  stage(st + 3, bufn, F1, F0, N{}, N{}, N{});
+  X3N_STAMP(2);
+
+  float* C = a.C + (a.ztab ? a.zC[f] : f * a.sC) + blockIdx.y * a.sSplit;
+  float es = a.epi ? a.epi_scale : 1.f;
+  const float eb = a.epi ? a.epi_bias : 0.f, ed = a.epi ? a.epi_diag[f & 7] : 0.f;
+  if (a.hdrA) es *= x3_out_scale(a, f);
+  if (m0 + X3_BM <= a.M && n0 + X3N_BN <= a.N && ed == 0.f) {
+    const long ld = a.ldc;
+    float* row = C + (long)(m0 + wm * X3_MT * 32 + 4 * g) * ld + (n0 + wn * X3N_NT * 32 + r);
+#pragma unroll
+    for (int i = 0; i < X3_MT; ++i) {
+#pragma unroll
+      for (int qh = 0; qh < 4; ++qh) {
+        float* p = row + (long)(i * 32 + 8 * qh) * ld;
+#pragma unroll
+        for (int ql = 0; ql < 4; ++ql) {
+#pragma unroll
+          for (int j = 0; j < X3N_NT; ++j) p[j * 32] = fmaf(es, acc[i][j][4 * qh + ql], eb);
+          p += ld;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < X3_MT; ++i)
+#pragma unroll
+      for (int j = 0; j < X3N_NT; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int rr = (q & 3) + 8 * (q >> 2) + 4 * g;
+          const int m = m0 + (wm * X3_MT + i) * 32 + rr;
+          const int n = n0 + (wn * X3N_NT + j) * 32 + r;
+          if (m < a.M && n < a.N) {
+            float v = acc[i][j][q];
+            if (a.epi || a.hdrA) v = fmaf(es, v, eb) + (m == n ? ed : 0.f);
+            C[(long)m * a.ldc + n] = v;
+          }
+        }
+  }
+#ifdef X3_TIMING
+  X3N_STAMP(3);
+  __builtin_amdgcn_s_waitcnt(0);
+  X3N_STAMP(63);
+  if (threadIdx.x < 64) a.dbg[(long)blockIdx.x * 64 + threadIdx.x] = reinterpret_cast<unsigned long long*>(smem3 + X3N_LDS)[threadIdx.x];
+#endif
+}
+#endif   // X3_PIECES == 2
+
 // Frequency-major grid (BgArgs::fmap): the 36 frequencies are dealt to the 8 XCDs -- equal work: four whole
 // frequencies per XCD and the last four as halves on XCD pairs; strided layers: longest-processing-time-first on the
 // number of parity classes present at a frequency.  Returns the grid size in x of the one-tile kernel.

@@ -1065,6 +1065,35 @@ bool launch_stream(BgArgs& b, hipStream_t s) {
   return true;
 }
 
+#if X3_PIECES == 2
+// The 256 x 128 tile kernel (two workgroups per compute unit; gemm_x3.h): OTGAN_X3_NARROW=0 keeps every launch on the
+// 256 x 256 tile, 1 (default) = every launch the kernel can take, 2 = only launches with at most `OTGAN_X3_NARROW_MAXT`
+// 256 x 256 tiles per frequency.
+int x3_narrow_mode() {
+  const char* e = getenv("OTGAN_X3_NARROW");
+  return use_fmap() ? (e ? atoi(e) : 1) : 0;
+}
+template <bool TL>
+bool launch_narrow(const BgArgs& b0, int nsplit, int min_k, hipStream_t s) {
+  const int mode = x3_narrow_mode();
+  if (!mode || b0.ztab || b0.N < X3N_BN || min_k < 4 * X3_SK || (min_k / X3_SK) % 2) return false;
+  if (b0.seg_mode == 1 && (b0.seg_len / X3_SK) % 2) return false;
+  if (mode == 2) {
+    static const long maxt = [] { const char* e = getenv("OTGAN_X3_NARROW_MAXT"); return e ? atol(e) : 32L; }();
+    if ((long)b0.tiles_m * b0.tiles_n > maxt) return false;
+  }
+  BgArgs b = b0;
+  b.tiles_n = (b.N + X3N_BN - 1) / X3N_BN;
+  const unsigned gx = build_fmap(b);
+  ensure_lds<wino_bgemm_x3n_kernel<TL>>(X3N_LDS);
+  hipLaunchKernelGGL((wino_bgemm_x3n_kernel<TL>), dim3(gx, nsplit, 1), dim3(X3_THREADS), X3N_LDS, s, b);
+  return true;
+}
+#else
+template <bool TL>
+bool launch_narrow(const BgArgs&, int, int, hipStream_t) { return false; }
+#endif
+
 template <bool TN>
 void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
   size_t lds;
@@ -1096,6 +1125,10 @@ void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
     dim3 grid(b.tiles_m * b.tiles_n, nsplit, WF);
     if (use_fmap()) grid = dim3(build_fmap(b), nsplit, 1);
     g_stream_idx = -1;
+    // the 256 x 128 tile kernel first (measured best on every DCGAN shape, also where the stream kernel used to win);
+    // OTGAN_X3_STREAM=2 forces the stream kernel, OTGAN_X3_NARROW=0 restores the round-2 selection
+    if (nsplit == 1 && x3_stream_mode() == 2 && launch_stream<false>(b, s)) { maybe_dump(b, s); return; }
+    if (launch_narrow<false>(b, nsplit, min_k, s)) { maybe_dump(b, s); return; }
     if (nsplit == 1 && launch_stream<false>(b, s)) { maybe_dump(b, s); return; }
     if (min_k >= 4 * X3_SK) hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, false>), grid, dim3(X3_THREADS), X3_LDS, s, b);
     else hipLaunchKernelGGL((wino_bgemm_x3_kernel<false, false>), grid, dim3(X3_THREADS), X3_LDS, s, b);
@@ -1134,6 +1167,8 @@ void launch_bgemm_tl(const BgArgs& a, int nsplit, hipStream_t s) {
   const int min_k = nsplit > 1 ? a.K - (nsplit - 1) * b.kt_per_split * X3_BK : a.K;
   dim3 grid(b.tiles_m * b.tiles_n, nsplit, WF);
   if (use_fmap()) grid = dim3(build_fmap(b), nsplit, 1);
+  if (nsplit == 1 && x3_stream_mode() == 2 && launch_stream<true>(b, s)) return;
+  if (launch_narrow<true>(b, nsplit, min_k, s)) return;
   if (nsplit == 1 && launch_stream<true>(b, s)) return;
   if (min_k >= 4 * X3_SK) hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, true>), grid, dim3(X3_THREADS), X3_LDS, s, b);
   else hipLaunchKernelGGL((wino_bgemm_x3_kernel<false, true>), grid, dim3(X3_THREADS), X3_LDS, s, b);

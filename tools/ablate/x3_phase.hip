@@ -152,6 +152,72 @@ int main(int argc, char** argv) {
       printf(" total %llu\n", w[1] - w[0]);
     }
   }
+#if X3_PIECES == 2
+  // ---- the 256 x 128 tile kernel (two workgroups per compute unit) on the same problem ----
+  {
+    std::vector<float> ref(nc), got(nc);
+    hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, false>), dim3(grid, 1, 1), dim3(X3_THREADS), lds, 0, b);   // exact reference
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(ref.data(), dC, nc * 4, hipMemcpyDeviceToHost));
+    CK(hipMemset(dC, 0xff, nc * 4));
+    BgArgs c = b;
+    c.tiles_n = (N + X3N_BN - 1) / X3N_BN;
+    const unsigned ngrid = build_fmap_plain(c);
+    unsigned long long* ndbg;
+    CK(hipMalloc(&ndbg, (size_t)ngrid * 64 * 8));
+    CK(hipMemset(ndbg, 0, (size_t)ngrid * 64 * 8));
+    c.dbg = ndbg;
+    const size_t nlds = X3N_LDS + 512;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_bgemm_x3n_kernel<false>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)nlds));
+    int occ = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, wino_bgemm_x3n_kernel<false>, X3_THREADS, nlds));
+    float nbest = 1e9f, nsum = 0.f;
+    for (int r = 0; r < reps + 2; ++r) {
+      CK(hipEventRecord(e0, 0));
+      hipLaunchKernelGGL((wino_bgemm_x3n_kernel<false>), dim3(ngrid, 1, 1), dim3(X3_THREADS), nlds, 0, c);
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (r >= 2) { nbest = std::min(nbest, ms); nsum += ms; }
+    }
+    CK(hipMemcpy(got.data(), dC, nc * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0;
+    double maxd = 0;
+    for (size_t i = 0; i < nc; ++i) {
+      const double d = fabs((double)got[i] - ref[i]);
+      if (!(d == 0)) {
+        if (bad < 12 || (bad % 100003) == 0) {
+          const size_t fm = i / N;
+          printf("    differ at f=%zu m=%zu n=%zu: got %g ref %g\n", fm / M, fm % M, i % N, got[i], ref[i]);
+        }
+        ++bad;
+      }
+      maxd = std::max(maxd, d);
+    }
+    printf("narrow 256x128 (grid %u, %d workgroups/CU): avg %.1f us best %.1f us  %.0f TFLOP/s (%.3f)  max|diff| %.3g, %zu differ\n",
+           ngrid, occ, nsum / reps * 1e3, nbest * 1e3, flop / (nsum / reps * 1e-3) / 1e12, flop / (nsum / reps * 1e-3) / 2.5e15, maxd, bad);
+    std::vector<unsigned long long> t((size_t)ngrid * 64);
+    CK(hipMemcpy(t.data(), ndbg, t.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> pro, loop, epi, total;
+    for (unsigned x = 0; x < ngrid; ++x) {
+      const unsigned long long* w = &t[(size_t)x * 64];
+      if (!w[0] || !w[63]) continue;
+      pro.push_back((double)(w[1] - w[0])); loop.push_back((double)(w[2] - w[1])); epi.push_back((double)(w[3] - w[2]));
+      total.push_back((double)(w[63] - w[0]));
+    }
+    auto stat = [](std::vector<double> v, const char* name) {
+      std::sort(v.begin(), v.end());
+      double s = 0;
+      for (double x : v) s += x;
+      printf("  narrow %-10s mean %8.0f  p10 %8.0f  p50 %8.0f  p90 %8.0f  max %8.0f\n", name, s / v.size(), v[v.size() / 10],
+             v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+    };
+    stat(pro, "prologue"); stat(loop, "main loop"); stat(epi, "epi issue"); stat(total, "total");
+    CK(hipMemcpy(dC, ref.data(), nc * 4, hipMemcpyHostToDevice));
+  }
+#endif
   std::vector<unsigned long long> t((size_t)grid * 64);
   CK(hipMemcpy(t.data(), dbg, t.size() * 8, hipMemcpyDeviceToHost));
   // per workgroup: prologue (entry -> first fragments), main loop, epilogue issue, store drain; cycles of s_memtime
