@@ -60,6 +60,16 @@ typedef struct otgan_conv_desc {
    * when it is > 0 and a call cannot take the Winograd path (list input, misaligned operands, short workspace) the
    * call fails with OTGAN_ERR_ARG instead of silently writing / reading nothing.  NULL = each pass transforms x. */
   void* x_operand;
+  /* Optional OUTPUT amax records (round 3): the kernel that WRITES y (forward) / dx (input gradient) also leaves the
+   * largest |value| it wrote in record[0] -- atomically max-accumulated as the float's bit pattern, so the caller must
+   * have zeroed record[0] before the call; NaN / infinity propagate as in otgan_absmax_f32.  The next Winograd layer
+   * takes the record as its x_amax / dy_amax and the separate reduction pass over the tensor (otgan_absmax_f32: one
+   * more read of it) disappears.  otgan_conv2d_amax_fused(d, which) tells whether the pass does this inside its own
+   * output kernel; otherwise a given record is filled by a separate reduction launch (same result).  Requires
+   * Cout % 4 == 0 (forward) / C % 4 == 0 (input gradient), 4-aligned channel strides; not with y_accumulate /
+   * accumulate (the record describes the values this call produced, not the sums in memory). */
+  float* y_amax_out;
+  float* dx_amax_out;
 } otgan_conv_desc;
 
 /*
@@ -82,6 +92,9 @@ size_t otgan_conv2d_operand_bytes(const otgan_conv_desc* d);
  */
 #define OTGAN_AMAX_RECORD_FLOATS 128
 int otgan_absmax_f32(const float* x, long rows, int C, long ld, float* record, void* stream);
+/* which: 0 forward (y_amax_out), 1 input gradient (dx_amax_out): 1 = the pass fills the record in its own output
+ * kernel (no extra launch, no extra read), 0 = it would take a separate reduction. */
+int otgan_conv2d_amax_fused(const otgan_conv_desc* d, int which);
 
 /*
  * Winograd F(4x4,3x3) paths (fwd, dgrad and wgrad; scratch for the transformed operands is
@@ -233,6 +246,10 @@ int otgan_colsum_f32(const float* a, long rows, int cols, long lda, float* out, 
 /* GLU (models/dcgan.py:35-36): y[r, c] = x[r, c] * sigmoid(x[r, C + c]), x: [rows, 2C].    */
 int otgan_glu_fwd_f32(const float* x, long rows, int C, float* y, void* stream);
 int otgan_glu_bwd_f32(const float* x, const float* dy, long rows, int C, float* dx, void* stream);
+/* the same, also max-accumulating |y| / |dx| into an amax record (otgan_conv_desc::y_amax_out; NULL = none;
+ * needs C % 4 == 0 and 16-byte aligned tensors) */
+int otgan_glu_fwd_amax_f32(const float* x, long rows, int C, float* y, float* y_amax, void* stream);
+int otgan_glu_bwd_amax_f32(const float* x, const float* dy, long rows, int C, float* dx, float* dx_amax, void* stream);
 /* tanh output (models/dcgan.py:50) */
 int otgan_tanh_fwd_f32(const float* x, long n, float* y, void* stream);
 int otgan_tanh_bwd_f32(const float* y, const float* dy, long n, float* dx, void* stream);
@@ -243,6 +260,9 @@ int otgan_feature_head_fwd_f32(const float* x, int N, int HW, int C, float* f, f
                                void* stream);
 int otgan_feature_head_bwd_f32(const float* x, const float* f, const float* norm,
                                const float* df, int N, int HW, int C, float* dx, void* stream);
+/* the same, also max-accumulating |dx| into an amax record (NULL = none) */
+int otgan_feature_head_bwd_amax_f32(const float* x, const float* f, const float* norm, const float* df, int N, int HW,
+                                    int C, float* dx, float* dx_amax, void* stream);
 
 /* ---- optimiser / EMA (utils/nn.py:50-73, train.py:63-64) --------------------------------
  * Adam with the reference's epsilon placement:  p -= lr * vhat / sqrt(mghat + 1e-8),

@@ -12,7 +12,8 @@ class ConvDesc(ctypes.Structure):
                 ("upsample", c_int), ("KH", c_int), ("KW", c_int), ("stride", c_int),
                 ("Cout", c_int), ("ldy", c_int), ("y_coff", c_int), ("preact", c_int),
                 ("list_quads", c_int), ("x_amax", ctypes.c_void_p), ("dy_amax", ctypes.c_void_p),
-                ("y_accumulate", c_int), ("x_operand", ctypes.c_void_p)]
+                ("y_accumulate", c_int), ("x_operand", ctypes.c_void_p),
+                ("y_amax_out", ctypes.c_void_p), ("dx_amax_out", ctypes.c_void_p)]
 
 
 P_DESC = ctypes.POINTER(ConvDesc)
@@ -38,6 +39,7 @@ SIGNATURES = {
     "otgan_conv2d_workspace_bytes": (c_size_t, [P_DESC, c_int]),
     "otgan_conv2d_operand_bytes": (c_size_t, [P_DESC]),
     "otgan_absmax_f32": (c_int, [c_fp, c_long, c_int, c_long, c_fp, c_fp]),
+    "otgan_conv2d_amax_fused": (c_int, [P_DESC, c_int]),
     "otgan_conv2d_folded_weight_elems": (c_size_t, [P_DESC]),
     "otgan_conv2d_fold_weights_f32": (c_int, [P_DESC, c_fp, c_fp, c_fp, c_fp]),
     "otgan_conv2d_fwd_f32": (c_int, [P_DESC, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_size_t, c_fp]),
@@ -56,6 +58,9 @@ SIGNATURES = {
     "otgan_colsum_f32": (c_int, [c_fp, c_long, c_int, c_long, c_fp, c_fp, c_fp]),
     "otgan_glu_fwd_f32": (c_int, [c_fp, c_long, c_int, c_fp, c_fp]),
     "otgan_glu_bwd_f32": (c_int, [c_fp, c_fp, c_long, c_int, c_fp, c_fp]),
+    "otgan_glu_fwd_amax_f32": (c_int, [c_fp, c_long, c_int, c_fp, c_fp, c_fp]),
+    "otgan_glu_bwd_amax_f32": (c_int, [c_fp, c_fp, c_long, c_int, c_fp, c_fp, c_fp]),
+    "otgan_feature_head_bwd_amax_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp]),
     "otgan_tanh_fwd_f32": (c_int, [c_fp, c_long, c_fp, c_fp]),
     "otgan_tanh_bwd_f32": (c_int, [c_fp, c_fp, c_long, c_fp, c_fp]),
     "otgan_feature_head_fwd_f32": (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp]),

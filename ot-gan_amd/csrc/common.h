@@ -88,6 +88,32 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// ---- amax records filled by the kernel that WRITES a tensor (otgan_layers.h: "amax records") -------------
+// record[0] accumulates max |v| as the bit pattern of the float: for non-negative floats unsigned order = numeric
+// order, infinity sorts above every finite value and NaN above infinity, so a NaN anywhere makes the record NaN -- what
+// absmax_kernel reports.  max is order-free: deterministic.  One L2 load per wave, an atomic only when the wave would
+// raise the record (the k-th wave does with probability ~1/k).  The caller zeroes record[0] before the producing launch.
+__device__ __forceinline__ unsigned amax_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+__device__ __forceinline__ unsigned amax_bits4(f32x4 v, unsigned mb) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned b = amax_bits(v[k]);
+    mb = b > mb ? b : mb;
+  }
+  return mb;
+}
+__device__ __forceinline__ void amax_commit(float* rec, unsigned mb) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned w = (unsigned)__shfl_xor((int)mb, o, 64);
+    mb = w > mb ? w : mb;
+  }
+  if ((threadIdx.x & 63) == 0 && mb != 0u) {
+    unsigned* p = reinterpret_cast<unsigned*>(rec);
+    if (mb > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      __hip_atomic_fetch_max(p, mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 // exp(x) for x <= 0 (max-shifted) through the native 2^x unit.
 __device__ __forceinline__ float exp_neg(float x) {
   return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);

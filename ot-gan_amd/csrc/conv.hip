@@ -1095,6 +1095,7 @@ struct FewInArgs {
   const float* bias;
   float* y; int ldy, coff;
   int N, H, W, logW, ph, pw, TR;
+  float* amax;   // amax record of y (common.h: amax_commit), or null
 };
 
 template <int KS>
@@ -1127,6 +1128,7 @@ __global__ __launch_bounds__(256) void conv_rgbin_fwd_kernel(FewInArgs a) {
   // this wave's pixels: a quarter of the tile's rows, two horizontally adjacent pixels per iteration (they share
   // the KS + 1 input positions of every filter row)
   const int rows = a.TR >> 2, rbase = wave * rows, pairs = a.W >> 1;
+  unsigned mb = 0u;
   for (int pi = 0; pi < rows * pairs; ++pi) {
     const int r = rbase + pi / pairs, c0 = (pi % pairs) * 2;
     f32x2 acc0 = b, acc1 = b;
@@ -1152,8 +1154,16 @@ __global__ __launch_bounds__(256) void conv_rgbin_fwd_kernel(FewInArgs a) {
     dst[64] = acc0[1];
     dst[a.ldy] = acc1[0];
     dst[a.ldy + 64] = acc1[1];
+    const unsigned b0 = amax_bits(acc0[0]), b1 = amax_bits(acc0[1]), b2 = amax_bits(acc1[0]), b3 = amax_bits(acc1[1]);
+    const unsigned b01 = b0 > b1 ? b0 : b1, b23 = b2 > b3 ? b2 : b3, bq = b01 > b23 ? b01 : b23;
+    mb = bq > mb ? bq : mb;
   }
+  if (a.amax) amax_commit(a.amax, mb);
 }
+
+// set by a pass whose output kernel fills the requested otgan_conv_desc::y_amax_out / dx_amax_out record itself; the
+// entry points run a separate reduction of the output otherwise
+static thread_local bool g_amax_written = false;
 
 static bool launch_rgbin_fwd(const otgan_conv_desc* d, int pad_t, int pad_l, const float* x, const float* wT,
                              const float* bias, float* y, hipStream_t s) {
@@ -1164,12 +1174,14 @@ static bool launch_rgbin_fwd(const otgan_conv_desc* d, int pad_t, int pad_l, con
   a.x = x; a.ldx = d->ldx; a.wT = wT; a.K = d->KH * d->KW * 3; a.bias = bias;
   a.y = y; a.ldy = d->ldy; a.coff = d->y_coff;
   a.N = d->N; a.H = d->H; a.W = d->W; a.logW = 0; a.ph = pad_t; a.pw = pad_l;
+  a.amax = d->y_amax_out;
   a.TR = 256 / d->W;
   if (a.TR < 4 || a.TR > d->H || d->H % a.TR) return false;
   const dim3 grid(d->N * (d->H / a.TR), d->Cout / 128);
   const size_t lds = sizeof(float4) * (size_t)(a.TR + d->KH - 1) * (d->W + d->KW - 1);
   if (d->KH == 5) hipLaunchKernelGGL(conv_rgbin_fwd_kernel<5>, grid, dim3(256), lds, s, a);
   else hipLaunchKernelGGL(conv_rgbin_fwd_kernel<3>, grid, dim3(256), lds, s, a);
+  g_amax_written = a.amax != nullptr;
   return true;
 }
 
@@ -1634,6 +1646,7 @@ inline WinoS2Geo wino_s2_geo(const otgan_conv_desc* d, const Geo& g) {
   w.N = d->N; w.H = d->H; w.W = d->W; w.C = d->C; w.Ceff = g.Ceff; w.doubled = doubled_act(d->preact) ? 1 : 0;
   w.act = act_kind(d->preact); w.ldx = d->ldx; w.Cout = d->Cout; w.ldy = d->ldy; w.y_coff = d->y_coff;
   w.x_amax = d->x_amax; w.dy_amax = d->dy_amax;
+  w.y_amax_out = d->y_amax_out; w.dx_amax_out = d->dx_amax_out;
   w.plain = d->stride == 1 ? 1 : 0;
   return w;
 }
@@ -2074,6 +2087,21 @@ int otgan_absmax_f32(const float* x, long rows, int C, long ld, float* record, v
   return OTGAN_OK;
 }
 
+int otgan_conv2d_amax_fused(const otgan_conv_desc* d, int which) {
+  Geo g;
+  if (!d || make_geo(d, &g)) return 0;
+  if (which == 0) {
+    if (d->y_accumulate || d->Cout % 4 || d->ldy % 4 || d->y_coff % 4) return 0;
+    if (wino_s2_ok(d, g)) return 1;                                   // the output transform of the strided / wide 3x3 passes
+    // RGB-in layer (launch_rgbin_fwd)
+    return d->preact == OTGAN_ACT_NONE && d->C == 3 && d->stride == 1 && d->upsample == 0 && d->KH == d->KW &&
+           (d->KH == 5 || d->KH == 3) && d->Cout % 128 == 0 && d->W >= 16 && d->W <= 64 && 256 / d->W >= 4 &&
+           256 / d->W <= d->H && d->H % (256 / d->W) == 0;
+  }
+  if (which == 1) return d->C % 4 == 0 && wino_s2_ok(d, g) ? 1 : 0;
+  return 0;
+}
+
 int otgan_conv2d_prepare_filters_f32(const otgan_conv_desc* d, int which, const float* w, void* filters,
                                      size_t filter_bytes, void* stream) {
   Geo g;
@@ -2117,7 +2145,28 @@ int otgan_conv2d_fwd_pf_f32(const otgan_conv_desc* d, const float* x, const int3
   return conv2d_fwd_impl(d, x, cmap, wT, (const float*)filters, bias, y, workspace, workspace_bytes, stream);
 }
 
+static int conv2d_fwd_body(const otgan_conv_desc* d, const float* x, const int32_t* cmap, const float* wT,
+                           const float* filters, const float* bias, float* y, void* workspace,
+                           size_t workspace_bytes, void* stream);
 static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32_t* cmap, const float* wT,
+                           const float* filters, const float* bias, float* y, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  if (d && d->y_amax_out) {
+    OTGAN_CHECK_ARG(!d->y_accumulate && d->Cout % 4 == 0 && d->ldy % 4 == 0 && d->y_coff % 4 == 0 && aligned16(y),
+                    "y_amax_out: needs Cout, ldy, y_coff multiples of 4, a 16-byte aligned y and no y_accumulate");
+  }
+  g_amax_written = false;
+  const int rc = conv2d_fwd_body(d, x, cmap, wT, filters, bias, y, workspace, workspace_bytes, stream);
+  if (rc == OTGAN_OK && d->y_amax_out && !g_amax_written) {
+    // this pass has no fused record: one reduction over the output it just wrote (same value)
+    Geo g;
+    make_geo(d, &g);
+    WINO(wino_absmax)(y + d->y_coff, (long)d->N * g.OH * g.OW, d->Cout, d->ldy, d->y_amax_out, (hipStream_t)stream);
+    OTGAN_CHECK_LAUNCH("conv2d fwd (amax of y)");
+  }
+  return rc;
+}
+static int conv2d_fwd_body(const otgan_conv_desc* d, const float* x, const int32_t* cmap, const float* wT,
                            const float* filters, const float* bias, float* y, void* workspace,
                            size_t workspace_bytes, void* stream) {
   Geo g;
@@ -2153,6 +2202,7 @@ static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32
     w.x_op = shared_x_operand(d);
     ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * wino_s2_blocks(w) * (double)wino_s2_tiles(w) * g.Ceff * d->Cout, 0.0, s);
     rc = WINO(wino_s2_fwd)(w, x, wT, bias, y, (float*)workspace, s, filters);
+    g_amax_written = w.y_amax_out != nullptr && !w.y_accumulate;
     OTGAN_CHECK_LAUNCH("conv2d fwd (winograd, stride 2)");
     return rc;
   }
@@ -2294,7 +2344,25 @@ int otgan_conv2d_dgrad_pf_f32(const otgan_conv_desc* d, const float* dy, const f
                            stream);
 }
 
+static int conv2d_dgrad_body(const otgan_conv_desc* d, const float* dy, const float* w, const float* filters,
+                             const float* x, const int32_t* inv, float* dx, int lddx, int accumulate,
+                             void* workspace, size_t workspace_bytes, void* stream);
 static int conv2d_dgrad_impl(const otgan_conv_desc* d, const float* dy, const float* w, const float* filters,
+                             const float* x, const int32_t* inv, float* dx, int lddx, int accumulate,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  if (d && d->dx_amax_out) {
+    OTGAN_CHECK_ARG(!accumulate && d->C % 4 == 0 && lddx % 4 == 0 && aligned16(dx),
+                    "dx_amax_out: needs C and lddx multiples of 4, a 16-byte aligned dx and no accumulation");
+  }
+  g_amax_written = false;
+  const int rc = conv2d_dgrad_body(d, dy, w, filters, x, inv, dx, lddx, accumulate, workspace, workspace_bytes, stream);
+  if (rc == OTGAN_OK && d->dx_amax_out && !g_amax_written) {
+    WINO(wino_absmax)(dx, (long)d->N * d->H * d->W, d->C, lddx, d->dx_amax_out, (hipStream_t)stream);
+    OTGAN_CHECK_LAUNCH("conv2d dgrad (amax of dx)");
+  }
+  return rc;
+}
+static int conv2d_dgrad_body(const otgan_conv_desc* d, const float* dy, const float* w, const float* filters,
                              const float* x, const int32_t* inv, float* dx, int lddx, int accumulate,
                              void* workspace, size_t workspace_bytes, void* stream) {
   Geo g;
@@ -2391,6 +2459,7 @@ static int conv2d_dgrad_impl(const otgan_conv_desc* d, const float* dy, const fl
     const WinoS2Geo wg = wino_s2_geo(d, g);
     ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * wino_s2_blocks(wg) * (double)wino_s2_tiles(wg) * g.Ceff * d->Cout, 0.0, s);
     rc = WINO(wino_s2_dgrad)(wg, dy, w, x, dx, lddx, accumulate, (float*)workspace, s, filters);
+    g_amax_written = wg.dx_amax_out != nullptr && !accumulate;
     OTGAN_CHECK_LAUNCH("conv2d dgrad (winograd, stride 2)");
     return rc;
   }

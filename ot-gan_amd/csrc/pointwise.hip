@@ -298,6 +298,50 @@ __global__ void glu_bwd_kernel(const float* __restrict__ x, const float* __restr
     dx[r * 2 * C + C + c] = d * a * s * (1.f - s);
   }
 }
+// float4 forms (C % 4 == 0) that also leave the largest |output| in an amax record (rec may be NULL): the next
+// Winograd layer scales its fp16 operands by it, and reading the tensor once more just for that was 0.33 ms of a
+// DCGAN step (absmax_kernel, 20 launches)
+__global__ __launch_bounds__(256) void glu_fwd4_kernel(const float* __restrict__ x, long rows, int C4,
+                                                       float* __restrict__ y, float* __restrict__ rec) {
+  const long total = rows * C4;
+  unsigned mb = 0u;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / C4;
+    const long c = i - r * C4;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + 4 * (r * 2 * C4 + c));
+    const f32x4 l = *reinterpret_cast<const f32x4*>(x + 4 * (r * 2 * C4 + C4 + c));
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = a[k] * sigmoidf_(l[k]);
+    *reinterpret_cast<f32x4*>(y + 4 * i) = o;
+    mb = amax_bits4(o, mb);
+  }
+  if (rec) amax_commit(rec, mb);
+}
+__global__ __launch_bounds__(256) void glu_bwd4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       long rows, int C4, float* __restrict__ dx,
+                                                       float* __restrict__ rec) {
+  const long total = rows * C4;
+  unsigned mb = 0u;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / C4;
+    const long c = i - r * C4;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + 4 * (r * 2 * C4 + c));
+    const f32x4 l = *reinterpret_cast<const f32x4*>(x + 4 * (r * 2 * C4 + C4 + c));
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dy + 4 * i);
+    f32x4 da, dl;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float s = sigmoidf_(l[k]);
+      da[k] = d[k] * s;
+      dl[k] = d[k] * a[k] * s * (1.f - s);
+    }
+    *reinterpret_cast<f32x4*>(dx + 4 * (r * 2 * C4 + c)) = da;
+    *reinterpret_cast<f32x4*>(dx + 4 * (r * 2 * C4 + C4 + c)) = dl;
+    mb = amax_bits4(dl, amax_bits4(da, mb));
+  }
+  if (rec) amax_commit(rec, mb);
+}
 __global__ void tanh_fwd_kernel(const float* __restrict__ x, long n, float* __restrict__ y) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     y[i] = tanhf(x[i]);
@@ -347,7 +391,8 @@ __global__ __launch_bounds__(256) void feature_head_bwd_kernel(const float* __re
                                                                const float* __restrict__ f,
                                                                const float* __restrict__ norm,
                                                                const float* __restrict__ df, int HW,
-                                                               int C, float* __restrict__ dx) {
+                                                               int C, float* __restrict__ dx,
+                                                               float* __restrict__ rec) {
   __shared__ double red[4];
   const int n = blockIdx.x;
   const long per = (long)HW * C;
@@ -359,6 +404,7 @@ __global__ __launch_bounds__(256) void feature_head_bwd_kernel(const float* __re
   const float dot = (float)s, inv = 1.f / norm[n];
   const float* xp = x + n * per;
   float* dxp = dx + n * per;
+  unsigned mb = 0u;
   for (long i = threadIdx.x; i < per; i += blockDim.x) {
     const long p = i / C;
     const int c = (int)(i - p * C);
@@ -366,8 +412,12 @@ __global__ __launch_bounds__(256) void feature_head_bwd_kernel(const float* __re
     const long ip = p * 2 * C + c, in = ip + C;
     const float dup = (dfp[ip] - fp[ip] * dot) * inv;
     const float dun = (dfp[in] - fp[in] * dot) * inv;
-    dxp[i] = v > 0.f ? dup : (v < 0.f ? -dun : 0.f);
+    const float o = v > 0.f ? dup : (v < 0.f ? -dun : 0.f);
+    dxp[i] = o;
+    const unsigned b = amax_bits(o);
+    mb = b > mb ? b : mb;
   }
+  if (rec) amax_commit(rec, mb);
 }
 
 // ---- optimisers / EMA ----------------------------------------------------------------------------
@@ -528,21 +578,38 @@ int otgan_colsum_f32(const float* a, long rows, int cols, long lda, float* out, 
   return OTGAN_OK;
 }
 
-int otgan_glu_fwd_f32(const float* x, long rows, int C, float* y, void* stream) {
+
+int otgan_glu_fwd_amax_f32(const float* x, long rows, int C, float* y, float* y_amax, void* stream) {
   OTGAN_CHECK_ARG(x && y && rows > 0 && C > 0, "bad arguments");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, 4.0 * 3 * (double)rows * C, s);
-  hipLaunchKernelGGL(glu_fwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, s, x, rows, C, y);
+  if (C % 4 == 0 && aligned16(x) && aligned16(y)) {
+    hipLaunchKernelGGL(glu_fwd4_kernel, dim3(grid_for(rows * C, 8)), dim3(256), 0, s, x, rows, C / 4, y, y_amax);
+  } else {
+    OTGAN_CHECK_ARG(!y_amax, "glu: an amax record needs C %% 4 == 0 and 16-byte aligned tensors");
+    hipLaunchKernelGGL(glu_fwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, s, x, rows, C, y);
+  }
   OTGAN_CHECK_LAUNCH("glu fwd");
   return OTGAN_OK;
 }
-int otgan_glu_bwd_f32(const float* x, const float* dy, long rows, int C, float* dx, void* stream) {
+int otgan_glu_fwd_f32(const float* x, long rows, int C, float* y, void* stream) {
+  return otgan_glu_fwd_amax_f32(x, rows, C, y, nullptr, stream);
+}
+int otgan_glu_bwd_amax_f32(const float* x, const float* dy, long rows, int C, float* dx, float* dx_amax, void* stream) {
   OTGAN_CHECK_ARG(x && dy && dx && rows > 0 && C > 0, "bad arguments");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, 4.0 * 5 * (double)rows * C, s);
-  hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, s, x, dy, rows, C, dx);
+  if (C % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(dx)) {
+    hipLaunchKernelGGL(glu_bwd4_kernel, dim3(grid_for(rows * C, 8)), dim3(256), 0, s, x, dy, rows, C / 4, dx, dx_amax);
+  } else {
+    OTGAN_CHECK_ARG(!dx_amax, "glu: an amax record needs C %% 4 == 0 and 16-byte aligned tensors");
+    hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, s, x, dy, rows, C, dx);
+  }
   OTGAN_CHECK_LAUNCH("glu bwd");
   return OTGAN_OK;
+}
+int otgan_glu_bwd_f32(const float* x, const float* dy, long rows, int C, float* dx, void* stream) {
+  return otgan_glu_bwd_amax_f32(x, dy, rows, C, dx, nullptr, stream);
 }
 int otgan_tanh_fwd_f32(const float* x, long n, float* y, void* stream) {
   OTGAN_CHECK_ARG(x && y && n > 0, "bad arguments");
@@ -566,14 +633,18 @@ int otgan_feature_head_fwd_f32(const float* x, int N, int HW, int C, float* f, f
   OTGAN_CHECK_LAUNCH("feature head fwd");
   return OTGAN_OK;
 }
-int otgan_feature_head_bwd_f32(const float* x, const float* f, const float* norm, const float* df,
-                               int N, int HW, int C, float* dx, void* stream) {
+int otgan_feature_head_bwd_amax_f32(const float* x, const float* f, const float* norm, const float* df,
+                                    int N, int HW, int C, float* dx, float* dx_amax, void* stream) {
   OTGAN_CHECK_ARG(x && f && norm && df && dx && N > 0 && HW > 0 && C > 0, "bad arguments");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, 4.0 * 10 * (double)N * HW * C, s);
-  hipLaunchKernelGGL(feature_head_bwd_kernel, dim3(N), dim3(256), 0, s, x, f, norm, df, HW, C, dx);
+  hipLaunchKernelGGL(feature_head_bwd_kernel, dim3(N), dim3(256), 0, s, x, f, norm, df, HW, C, dx, dx_amax);
   OTGAN_CHECK_LAUNCH("feature head bwd");
   return OTGAN_OK;
+}
+int otgan_feature_head_bwd_f32(const float* x, const float* f, const float* norm, const float* df,
+                               int N, int HW, int C, float* dx, void* stream) {
+  return otgan_feature_head_bwd_amax_f32(x, f, norm, df, N, HW, C, dx, nullptr, stream);
 }
 
 int otgan_adam_step_f32(float* p, const float* grad, float* v, float* mg, long n, double lr,

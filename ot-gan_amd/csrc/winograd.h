@@ -59,6 +59,10 @@ struct WinoS2Geo {
   int up = 0;
   int y_accumulate = 0;   // forward: y += result + bias (otgan_conv_desc::y_accumulate)
   float* x_op = nullptr;  // as in WinoGeo
+  // otgan_conv_desc::y_amax_out / dx_amax_out: the output transform of the forward pass / the input gradient also
+  // max-accumulates the magnitudes it writes into record[0]
+  float* y_amax_out = nullptr;
+  float* dx_amax_out = nullptr;
 };
 inline int wino_s2_classes(const WinoS2Geo& g) { return g.plain ? 1 : 4; }
 inline int wino_s2_out_h(const WinoS2Geo& g) { return g.plain ? g.H : g.H / 2; }

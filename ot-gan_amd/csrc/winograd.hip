@@ -402,11 +402,13 @@ struct OutArgs {
   const float* Mh;
   const float* bias;
   int accumulate;
+  float* amax;          // amax record of the values written (common.h: amax_commit), or null
 };
 __global__ __launch_bounds__(256) void wino_output_kernel(OutArgs a) {
   const int c4n = a.C >> 2;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= a.T * c4n) return;
+  if (idx >= a.T * c4n) return;   // (an exited lane reads as 0 in the record's wave reduction: ds_bpermute of a disabled lane)
+  unsigned mb = 0u;
   const int c = (int)(idx % c4n) * 4;
   const long t = idx / c4n;
   const int tb = (int)(t % a.TW), ta = (int)((t / a.TW) % a.TH);
@@ -434,10 +436,12 @@ __global__ __launch_bounds__(256) void wino_output_kernel(OutArgs a) {
     for (int j = 0; j < WM; ++j) {
       float* dst = v.p + n * v.sn + (WM * ta + i) * v.sh + (WM * tb + j) * v.sw + c;
       f32x4 o = y[j] + b;
+      mb = amax_bits4(o, mb);
       if (a.accumulate) o += ld4(dst);
       st4(dst, o);
     }
   }
+  if (a.amax) amax_commit(a.amax, mb);
 }
 
 // zero columns [k0, k1) of every row and frequency of a blocked operand (K padded to the GEMM's granule)
@@ -726,6 +730,7 @@ struct OutS2Args {
   int plain;            // one class, nothing structurally zero (a 3x3 stride-1 layer)
   int up;               // plain only: x / dx are half-resolution images behind a 2x nearest-neighbour upsample --
                         // the 4x4 tile of gradients is summed over its 2x2 groups
+  float* amax;          // amax record of the values written, or null (not with `up`)
 };
 // (A^T M A) of the class's M, rows i0 .. i0+1 only (two output rows at a time keep the register count down)
 // DOUBLED (CReLU / CELU): a thread owns TWO channels (both halves of each): the two 36-value column passes of four
@@ -738,6 +743,7 @@ __global__ __launch_bounds__(256) void wino_s2_output_kernel(OutS2Args a) {
   const int cvn = a.C / VW;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= a.T * cvn) return;
+  unsigned mb = 0u;
   const int c = (int)(idx % cvn) * VW;
   const long t = idx / cvn;
   const int tb = (int)(t % a.TW), ta = (int)((t / a.TW) % a.TH);
@@ -830,10 +836,16 @@ __global__ __launch_bounds__(256) void wino_s2_output_kernel(OutS2Args a) {
         }
       }
       float* dst = dv.p + off;
+#pragma unroll
+      for (int q = 0; q < VW; ++q) {
+        const unsigned b = amax_bits(o[q]);
+        mb = b > mb ? b : mb;
+      }
       if (a.accumulate) o += ldv(dst);
       *reinterpret_cast<VT*>(dst) = o;
     }
   }
+  if (a.amax) amax_commit(a.amax, mb);
 }
 
 
@@ -1698,6 +1710,7 @@ int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float
   oa.v[0].p = y + g.y_coff; oa.v[0].sn = (long)OH * OW * g.ldy; oa.v[0].sh = (long)OW * g.ldy; oa.v[0].sw = g.ldy;
   oa.TH = OH / WM; oa.TW = OW / WM; oa.C = g.Cout; oa.T = T; oa.ldm = g.Cout; oa.Mh = Mh; oa.bias = bias;
   oa.accumulate = g.y_accumulate;
+  oa.amax = g.y_accumulate ? nullptr : g.y_amax_out;
   hipLaunchKernelGGL(wino_output_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 1), dim3(256), 0, s, oa);
   return OTGAN_OK;
 }
@@ -1750,6 +1763,7 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   }
   oa.TH = OH / WM; oa.TW = OW / WM; oa.C = g.C; oa.Ceff = g.Ceff; oa.T = T; oa.ldm = K4; oa.Xh = Xh;
   oa.accumulate = accumulate;
+  oa.amax = (accumulate || g.up) ? nullptr : g.dx_amax_out;
   const dim3 grid(grid1(T * (g.C / (g.doubled ? 2 : 4))), 1, wino_s2_classes(g)), blk(256);
   if (g.doubled) {
     if (g.act == 2) hipLaunchKernelGGL((wino_s2_output_kernel<2, true>), grid, blk, 0, s, oa);

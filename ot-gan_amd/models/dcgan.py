@@ -13,6 +13,7 @@ of drawing it (parity tests), `device` places a freshly drawn latent.
 """
 import torch
 
+from .. import ops
 from ..utils import nn
 
 # (filters, stride, pre-activated) per critic convolution; all 5x5  (models/dcgan.py:11-14)
@@ -43,7 +44,7 @@ def gen_spec(batch_size, init=False, nonlinearity='crelu', ema=None, noise=None,
         noise = torch.rand((batch_size, 100), device=device or 'cuda') * 2.0 - 1.0
     with nn.arg_scope([nn.conv2d, nn.dense], counters={}, init=init, weight_norm=True, ema=ema):
         x = nn.glu(nn.dense(noise, 2 * base * base * 1024, pre_activation=None))   # split along axis 1
-        x = x.view(noise.shape[0], base, base, 1024)
+        x = ops.carry_amax(x.view(noise.shape[0], base, base, 1024), x)   # (the GLU's amax record survives the reshape)
         for filters in _GEN:
             # nearest-neighbour x2 (fused into the conv's gather) -> 5x5 conv -> gated linear unit
             x = nn.glu(nn.conv2d(x, filters, filter_size=[5, 5], pre_activation=None, upsample=True))

@@ -185,6 +185,55 @@ def absmax_record(t):
     return rec
 
 
+# ---- amax records written by the kernel that PRODUCES a tensor (otgan_layers.h: y_amax_out / dx_amax_out) -------------
+# A Winograd layer scales its fp16 GEMM operands by the largest magnitude of the tensor they are a transform of.  The
+# record used to come from one more pass over the tensor (absmax_record: 20 launches, 0.33 ms of a DCGAN step); now the
+# kernel that writes the tensor -- GLU forward / backward, the output transforms of the strided layers, the RGB-in
+# layer, the feature head's backward -- leaves it in a zeroed slot, and the tensor carries the slot to its consumer
+# as a Python attribute (checked against the tensor's version counter; a tensor that arrives without one, e.g.
+# through a view or from outside, is reduced as before).  OTGAN_FUSED_AMAX=0 disables the producers.
+_AMAX_SLOTS = 256
+_amax_pool = {}       # device -> [zeroed [slots, 128] tensor, next free slot]
+_FUSED_AMAX = os.environ.get("OTGAN_FUSED_AMAX", "1") != "0"
+
+
+def amax_slot(device):
+    """A zeroed 128-float amax record (one launch zeroes 256 of them)."""
+    ent = _amax_pool.get(device)
+    if ent is None or ent[1] >= _AMAX_SLOTS:
+        ent = [torch.zeros((_AMAX_SLOTS, 128), dtype=torch.float32, device=device), 0]
+        _amax_pool[device] = ent
+    rec = ent[0][ent[1]]
+    ent[1] += 1
+    return rec
+
+
+def tag_amax(t, rec):
+    """`t` was just written by a kernel that max-accumulated |t| into rec[0]."""
+    t._otgan_amax = (rec, t._version)
+    return t
+
+
+def amax_of(t):
+    """The producer's amax record of `t`, or None (no record, or the tensor was modified since)."""
+    tag = getattr(t, "_otgan_amax", None)
+    if tag is None or tag[1] != t._version:
+        return None
+    return tag[0]
+
+
+def carry_amax(dst, src):
+    """`dst` holds the same values as `src` (a view / reshape): the record still describes it."""
+    rec = amax_of(src)
+    if rec is not None:
+        tag_amax(dst, rec)
+    return dst
+
+
+def amax_fused(desc, which):
+    return _FUSED_AMAX and bool(_lib.lib().otgan_conv2d_amax_fused(ctypes.byref(desc), which))
+
+
 def shared_x_operand(desc, device):
     """Buffer for `otgan_conv_desc::x_operand` (the forward pass leaves its transformed input there, the weight
     gradient of the same x reads it back instead of transforming x again), or None when the layer's two passes do not
@@ -279,14 +328,24 @@ class Conv2dFunction(torch.autograd.Function):
         wd, wT, inv_norm, filt = cached_weights(V, g, compute)
         ctx.x_rec = None
         if filt["fwd"] is not None and x.is_contiguous() and C % 4 == 0:
-            # Winograd passes: one reduction of x for the forward pass now and the weight gradient later
-            ctx.x_rec = absmax_record(x)
+            # Winograd passes: the record x's producer left (else one reduction of x), for the forward pass now and
+            # the weight gradient later
+            ctx.x_rec = amax_of(x)
+            if ctx.x_rec is None:
+                ctx.x_rec = absmax_record(x)
             desc.x_amax = ctx.x_rec.data_ptr()
         # 288 GB of HBM: keep the transformed input of the Winograd passes for the weight gradient (0.15-0.6 GB a layer)
         ctx.x_op = None
         if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and cmap is None and filt["fwd"] is not None:
             ctx.x_op = shared_x_operand(desc, x.device)
+        y_rec = None
+        if amax_fused(desc, 0) and cmap is None:
+            y_rec = amax_slot(x.device)          # the kernel that writes y also leaves max |y| (for the next layer)
+            desc.y_amax_out = y_rec.data_ptr()
         conv_fwd_raw(desc, x, cmap, wT, b, y, filt["fwd"])
+        desc.y_amax_out = None
+        if y_rec is not None:
+            tag_amax(y, y_rec)
         ctx.save_for_backward(x, V2d, g, wd, inv_norm)
         ctx.filt = filt
         ctx.desc, ctx.cmap, ctx.inv = desc, cmap, inv
@@ -302,14 +361,23 @@ class Conv2dFunction(torch.autograd.Function):
         dx = dV = dg = db = None
         dy_rec = None
         if ctx.x_rec is not None and dy.shape[-1] % 4 == 0:
-            dy_rec = absmax_record(dy)        # shared by dgrad and wgrad
+            dy_rec = amax_of(dy)              # left by dy's producer, else reduced here; shared by dgrad and wgrad
+            if dy_rec is None:
+                dy_rec = absmax_record(dy)
             desc.dy_amax = dy_rec.data_ptr()
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             filt = ctx.filt
             if not filt["bwd_done"]:
                 filt["bwd"], filt["bwd_done"] = prepare_filters(desc, filt["bwd_which"], w), True
+            dx_rec = None
+            if amax_fused(desc, 1) and ctx.inv is None:
+                dx_rec = amax_slot(x.device)
+                desc.dx_amax_out = dx_rec.data_ptr()
             conv_dgrad_raw(desc, dy, w, x, ctx.inv, dx, x.shape[3], False, filt["bwd"])
+            desc.dx_amax_out = None
+            if dx_rec is not None:
+                tag_amax(dx, dx_rec)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw = torch.empty_like(V2d)
             conv_wgrad_raw(desc, x, ctx.cmap, dy, dw)
@@ -763,8 +831,11 @@ class GluFunction(torch.autograd.Function):
         C2 = x.shape[-1]
         rows = x.numel() // C2
         y = torch.empty(x.shape[:-1] + (C2 // 2,), dtype=x.dtype, device=x.device)
-        _lib.check(_lib.lib().otgan_glu_fwd_f32(x.data_ptr(), rows, C2 // 2, y.data_ptr(),
-                                                _lib.stream_ptr()), "glu_fwd")
+        rec = amax_slot(x.device) if (_FUSED_AMAX and (C2 // 2) % 4 == 0) else None
+        _lib.check(_lib.lib().otgan_glu_fwd_amax_f32(x.data_ptr(), rows, C2 // 2, y.data_ptr(), _lib.ptr(rec),
+                                                     _lib.stream_ptr()), "glu_fwd")
+        if rec is not None:
+            tag_amax(y, rec)
         ctx.save_for_backward(x)
         return y
 
@@ -774,8 +845,11 @@ class GluFunction(torch.autograd.Function):
         dy = dy.contiguous()
         C2 = x.shape[-1]
         dx = torch.empty_like(x)
-        _lib.check(_lib.lib().otgan_glu_bwd_f32(x.data_ptr(), dy.data_ptr(), x.numel() // C2,
-                                                C2 // 2, dx.data_ptr(), _lib.stream_ptr()), "glu_bwd")
+        rec = amax_slot(x.device) if (_FUSED_AMAX and (C2 // 2) % 4 == 0) else None
+        _lib.check(_lib.lib().otgan_glu_bwd_amax_f32(x.data_ptr(), dy.data_ptr(), x.numel() // C2,
+                                                     C2 // 2, dx.data_ptr(), _lib.ptr(rec), _lib.stream_ptr()), "glu_bwd")
+        if rec is not None:
+            tag_amax(dx, rec)
         return dx
 
 
@@ -822,9 +896,12 @@ class FeatureHeadFunction(torch.autograd.Function):
         df = df.contiguous()
         N, H, W, C = x.shape
         dx = torch.empty_like(x)
-        _lib.check(_lib.lib().otgan_feature_head_bwd_f32(x.data_ptr(), f.data_ptr(), norm.data_ptr(),
-                                                         df.data_ptr(), N, H * W, C, dx.data_ptr(),
-                                                         _lib.stream_ptr()), "head_bwd")
+        rec = amax_slot(x.device) if (_FUSED_AMAX and C % 4 == 0) else None
+        _lib.check(_lib.lib().otgan_feature_head_bwd_amax_f32(x.data_ptr(), f.data_ptr(), norm.data_ptr(),
+                                                              df.data_ptr(), N, H * W, C, dx.data_ptr(), _lib.ptr(rec),
+                                                              _lib.stream_ptr()), "head_bwd")
+        if rec is not None:
+            tag_amax(dx, rec)
         return dx
 
 
