@@ -61,8 +61,8 @@ typedef struct otgan_conv_desc {
    * call fails with OTGAN_ERR_ARG instead of silently writing / reading nothing.  NULL = each pass transforms x. */
   void* x_operand;
   /* Optional OUTPUT amax records (round 3): the kernel that WRITES y (forward) / dx (input gradient) also leaves the
-   * largest |value| it wrote in record[0] -- atomically max-accumulated as the float's bit pattern, so the caller must
-   * have zeroed record[0] before the call; NaN / infinity propagate as in otgan_absmax_f32.  The next Winograd layer
+   * largest |value| it wrote in the record -- atomically max-accumulated as the float's bit pattern, so the caller must
+   * have zeroed the record (all OTGAN_AMAX_RECORD_FLOATS floats) before the call; NaN / infinity propagate as in otgan_absmax_f32.  The next Winograd layer
    * takes the record as its x_amax / dy_amax and the separate reduction pass over the tensor (otgan_absmax_f32: one
    * more read of it) disappears.  otgan_conv2d_amax_fused(d, which) tells whether the pass does this inside its own
    * output kernel; otherwise a given record is filled by a separate reduction launch (same result).  Requires
@@ -86,11 +86,14 @@ size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which);
 size_t otgan_conv2d_operand_bytes(const otgan_conv_desc* d);
 
 /*
- * amax record of x[rows][C] (row stride ld floats, C and ld multiples of 4, 16-byte aligned): record[0] = the
- * largest |x| (NaN if any element is NaN).  record: OTGAN_AMAX_RECORD_FLOATS floats of device memory, written
- * asynchronously on `stream`; pass it as otgan_conv_desc::x_amax / dy_amax.  Deterministic.
+ * amax record of x[rows][C] (row stride ld floats, C and ld multiples of 4, 16-byte aligned): the largest |x| (NaN if
+ * any element is NaN).  record: OTGAN_AMAX_RECORD_FLOATS floats of device memory, written asynchronously on `stream`;
+ * pass it as otgan_conv_desc::x_amax / dy_amax.  Deterministic.  Format: 16 sub-slots at a stride of 32 floats, each
+ * the bit pattern of a non-negative float; the record's value is their maximum (this call writes it to sub-slot 0 and
+ * zeroes the others; the kernels behind y_amax_out / dx_amax_out max-accumulate into all 16, one cache line each, so
+ * that their atomics do not queue up in one L2 channel).
  */
-#define OTGAN_AMAX_RECORD_FLOATS 128
+#define OTGAN_AMAX_RECORD_FLOATS 512
 int otgan_absmax_f32(const float* x, long rows, int C, long ld, float* record, void* stream);
 /* which: 0 forward (y_amax_out), 1 input gradient (dx_amax_out): 1 = the pass fills the record in its own output
  * kernel (no extra launch, no extra read), 0 = it would take a separate reduction. */

@@ -89,10 +89,15 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 // ---- amax records filled by the kernel that WRITES a tensor (otgan_layers.h: "amax records") -------------
-// record[0] accumulates max |v| as the bit pattern of the float: for non-negative floats unsigned order = numeric
-// order, infinity sorts above every finite value and NaN above infinity, so a NaN anywhere makes the record NaN -- what
-// absmax_kernel reports.  max is order-free: deterministic.  One L2 load per wave, an atomic only when the wave would
-// raise the record (the k-th wave does with probability ~1/k).  The caller zeroes record[0] before the producing launch.
+// A record is OTGAN_AMAX_RECORD_FLOATS = 512 floats: 16 sub-slots at a stride of 32 floats (one cache line each); its
+// value is the largest of the 16 entries, each the bit pattern of a non-negative float: for those unsigned order =
+// numeric order, infinity sorts above every finite value and NaN above infinity, so a NaN anywhere makes the record
+// NaN -- what absmax_kernel reports.  max is order-free: deterministic.  A producing kernel reduces per workgroup
+// (shuffles, LDS) and max-accumulates into sub-slot blockIdx.x % 16 with ONE atomic -- and only when it would raise the
+// entry (the k-th workgroup does with probability ~1/k).  Same-address atomics serialise in their L2 channel at a few
+// ns each: one atomic per WAVE into one word cost a 16 k-wave GLU launch 50 us (32 -> 81 us); per workgroup over 16
+// lines it is not measurable.  The caller zeroes the record before the producing launch.
+constexpr int kAmaxSub = 16, kAmaxSubStride = 32;
 __device__ __forceinline__ unsigned amax_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
 __device__ __forceinline__ unsigned amax_bits4(f32x4 v, unsigned mb) {
 #pragma unroll
@@ -102,17 +107,37 @@ __device__ __forceinline__ unsigned amax_bits4(f32x4 v, unsigned mb) {
   }
   return mb;
 }
+// every thread of the workgroup that is still alive calls this (one-dimensional workgroups of <= 1024 threads; a lane
+// that has exited reads as 0 in the shuffles: ds_bpermute of a disabled lane)
 __device__ __forceinline__ void amax_commit(float* rec, unsigned mb) {
+  __shared__ unsigned s_amax[16];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const unsigned w = (unsigned)__shfl_xor((int)mb, o, 64);
     mb = w > mb ? w : mb;
   }
-  if ((threadIdx.x & 63) == 0 && mb != 0u) {
-    unsigned* p = reinterpret_cast<unsigned*>(rec);
-    if (mb > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-      __hip_atomic_fetch_max(p, mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) s_amax[wave] = mb;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned m = 0u;
+    for (int w = 0; w < nw; ++w) m = s_amax[w] > m ? s_amax[w] : m;
+    if (m != 0u) {
+      unsigned* p = reinterpret_cast<unsigned*>(rec) + kAmaxSubStride * ((blockIdx.x + blockIdx.y + blockIdx.z) & (kAmaxSub - 1));
+      if (m > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        __hip_atomic_fetch_max(p, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
+}
+// value of a record (any thread; plain loads: the record was written by an earlier launch)
+__device__ __forceinline__ float amax_record_value(const float* rec) {
+  unsigned m = 0u;
+#pragma unroll
+  for (int k = 0; k < kAmaxSub; ++k) {
+    const unsigned b = __float_as_uint(rec[k * kAmaxSubStride]) & 0x7fffffffu;
+    m = b > m ? b : m;
+  }
+  return __uint_as_float(m);
 }
 // exp(x) for x <= 0 (max-shifted) through the native 2^x unit.
 __device__ __forceinline__ float exp_neg(float x) {

@@ -210,6 +210,7 @@ struct AmaxArgs {
   float gain[WA];       // absolute row sums of the 1-D transform matrix
   float fold;           // taps summed into one filter tap before the transform (1, or 4 for un-folded upsampling filters)
   int floor_one;        // ELU / CELU applied inside the transform: |act(x)| <= max(|x|, 1)
+  int record_only;      // hdr is an amax RECORD (common.h): sub-slot 0 = the maximum, the other sub-slots 0, no scales
   float* scratch;
   unsigned* counter;
 };
@@ -220,6 +221,10 @@ constexpr int kAmaxBlocks = 2048, kAmaxSlots = 64;
 
 // header of an operand from the largest magnitude of its source tensor (threads 0 .. 35 one frequency each)
 __device__ __forceinline__ void write_scales(const AmaxArgs& a, float amax, int tid) {
+  if (a.record_only) {
+    if (tid < kAmaxSub) a.hdr[tid * kAmaxSubStride] = tid == 0 ? amax : 0.f;
+    return;
+  }
   if (a.floor_one && amax == amax) amax = fmaxf(amax, 1.f);
   if (tid < WF) {
     const int i = tid / WA, j = tid - i * WA;
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(AmaxArgs a) {
   if (tid == 0) *a.counter = 0;
 }
 // the 36 scales from an amax record the caller already has (a.x = the record)
-__global__ __launch_bounds__(64) void scales_from_amax_kernel(AmaxArgs a) { write_scales(a, a.x[0], threadIdx.x); }
+__global__ __launch_bounds__(64) void scales_from_amax_kernel(AmaxArgs a) { write_scales(a, amax_record_value(a.x), threadIdx.x); }
 
 // ---- streaming kernels --------------------------------------------------------------------
 // A "view" of a small-grid image: element (n, a, b, c) at p[n*sn + a*sh + b*sw + c].
@@ -1249,13 +1254,14 @@ AmaxScratch& amax_scratch() {
 // scales of the operand at `base` (header) for a transform with row gains `gain` of the tensor x[rows][C] (row stride
 // ld); `given`: the caller's amax record of that tensor (otgan_layers.h) -- then only the 36 scales are computed
 void op_scales(const float* x, long rows, int C, long ld, float* base, const float (&gain)[WA], float fold, bool floor_one,
-               hipStream_t s, const float* given = nullptr) {
+               hipStream_t s, const float* given = nullptr, bool record_only = false) {
   if (X3_NP != 2) return;   // three bf16 pieces carry the full exponent range: no scales
   static std::atomic<unsigned> seq{0};
   AmaxArgs a;
   a.x = x; a.rows = rows; a.ld = rows == 1 ? C : ld; a.C = C; a.hdr = base;
   for (int i = 0; i < WA; ++i) a.gain[i] = gain[i];
   a.fold = fold; a.floor_one = floor_one ? 1 : 0;
+  a.record_only = record_only ? 1 : 0;
   if (given) {
     a.x = given;
     hipLaunchKernelGGL(scales_from_amax_kernel, dim3(1), dim3(64), 0, s, a);
@@ -1330,7 +1336,7 @@ int wgrad_splits(const WinoGeo& g) {
 
 void wino_absmax(const float* x, long rows, int C, long ld, float* record, hipStream_t s) {
   const float unit[WA] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-  op_scales(x, rows, C, ld, record, unit, 1.f, false, s);
+  op_scales(x, rows, C, ld, record, unit, 1.f, false, s, nullptr, true);
 }
 
 bool winograd_enabled() {

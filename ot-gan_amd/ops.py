@@ -175,10 +175,10 @@ def conv_dgrad_raw(desc, dy, w, x, inv, dx, lddx, accumulate, filters=None):
 
 
 def absmax_record(t):
-    """amax record (otgan_layers.h: otgan_absmax_f32) of a contiguous NHWC tensor: 128 floats on its device, [0] =
+    """amax record (otgan_layers.h: otgan_absmax_f32) of a contiguous NHWC tensor: AMAX_RECORD_FLOATS floats on its device, value =
     max |t|.  The Winograd passes scale their two-piece fp16 operands by it; computing it here, once per tensor,
     lets forward + wgrad (x) and dgrad + wgrad (dy) share one reduction."""
-    rec = torch.empty(128, dtype=torch.float32, device=t.device)
+    rec = torch.empty(AMAX_RECORD_FLOATS, dtype=torch.float32, device=t.device)
     C = t.shape[-1]
     _lib.check(_lib.lib().otgan_absmax_f32(t.data_ptr(), t.numel() // C, C, C, rec.data_ptr(), _lib.stream_ptr()),
                "absmax")
@@ -192,16 +192,17 @@ def absmax_record(t):
 # layer, the feature head's backward -- leaves it in a zeroed slot, and the tensor carries the slot to its consumer
 # as a Python attribute (checked against the tensor's version counter; a tensor that arrives without one, e.g.
 # through a view or from outside, is reduced as before).  OTGAN_FUSED_AMAX=0 disables the producers.
+AMAX_RECORD_FLOATS = 512     # otgan_layers.h: OTGAN_AMAX_RECORD_FLOATS
 _AMAX_SLOTS = 256
-_amax_pool = {}       # device -> [zeroed [slots, 128] tensor, next free slot]
+_amax_pool = {}       # device -> [zeroed [slots, AMAX_RECORD_FLOATS] tensor, next free slot]
 _FUSED_AMAX = os.environ.get("OTGAN_FUSED_AMAX", "1") != "0"
 
 
 def amax_slot(device):
-    """A zeroed 128-float amax record (one launch zeroes 256 of them)."""
+    """A zeroed amax record (one launch zeroes 256 of them)."""
     ent = _amax_pool.get(device)
     if ent is None or ent[1] >= _AMAX_SLOTS:
-        ent = [torch.zeros((_AMAX_SLOTS, 128), dtype=torch.float32, device=device), 0]
+        ent = [torch.zeros((_AMAX_SLOTS, AMAX_RECORD_FLOATS), dtype=torch.float32, device=device), 0]
         _amax_pool[device] = ent
     rec = ent[0][ent[1]]
     ent[1] += 1
@@ -404,7 +405,7 @@ def dense_op(x, V, g, b, preact=0, segs=None):
 
 def absmax_record_strided(t_ptr, rows, C, ld, device):
     """amax record of a channel slice [rows][C] (row stride ld floats) of a larger NHWC buffer."""
-    rec = torch.empty(128, dtype=torch.float32, device=device)
+    rec = torch.empty(AMAX_RECORD_FLOATS, dtype=torch.float32, device=device)
     _lib.check(_lib.lib().otgan_absmax_f32(t_ptr, rows, C, ld, rec.data_ptr(), _lib.stream_ptr()), "absmax")
     return rec
 

@@ -19,7 +19,8 @@ def _rec_value(t):
     from otgan_amd import ops
     rec = ops.amax_of(t)
     assert rec is not None, "the producer left no amax record"
-    return rec[0].item()
+    sub = rec.view(16, 32)[:, 0]                 # 16 sub-slots, one cache line each: the value is their maximum
+    return float("nan") if bool(torch.isnan(sub).any()) else sub.max().item()
 
 
 def test_glu_records_are_exact_and_tagged():
