@@ -105,6 +105,27 @@ int otgan_matching_two_batch_rows_f32(const float* fa, const float* fb, int N, i
                                       size_t workspace_bytes, void* stream);
 
 /*
+ * Training-mode two-batch matching: the injected gradients of the reference's step directly --
+ *   grad_a = f_aa - f_ab   (train.py:111, generated shards)      grad_b = f_bb - f_ba   (train.py:125-126, data shards)
+ * -- as [2N, D] arrays (leading dimension ldo), grad_b nullable (generator steps: five out of six, train.py:214).  The
+ * four matched arrays are never formed: each half of a difference is ONE plan application with three terms; dist is
+ * the closed form [2 T(a1a2) + 2 T(b2b1) - T(a1b1) - T(a1b2) - T(a2b1) - T(a2b2)] / (4N), T = sum(M) - <M,C>, from
+ * the Sinkhorn kernel's statistics (no pass over the features).  Cosine cost.  Workspace:
+ * otgan_matching_grad_workspace_bytes.  The _rows_ variant produces rows [row_begin, +row_count) (inside one
+ * mini-batch) into [row_count, D] buffers, K_pre as in otgan_matching_two_batch_rows_f32.
+ */
+size_t otgan_matching_grad_workspace_bytes(int N, int D);
+int otgan_matching_two_batch_grad_f32(const float* fa, const float* fb, int N, int D, long ldf,
+                                      float sinkhorn_lambda, int iters, float* grad_a, float* grad_b, long ldo,
+                                      float* entropy, double* dist, double* stats, void* workspace,
+                                      size_t workspace_bytes, void* stream);
+int otgan_matching_two_batch_rows_grad_f32(const float* fa, const float* fb, int N, int D, long ldf,
+                                           float sinkhorn_lambda, int iters, int row_begin, int row_count,
+                                           const float* K_pre, float* grad_a, float* grad_b, long ldo, float* entropy,
+                                           double* dist, double* stats, void* workspace, size_t workspace_bytes,
+                                           void* stream);
+
+/*
  * Single-batch matching (matching.py:88-136): fa, fb [n, D]; 999 is added to the a-a and
  * b-b cost diagonals.  stats: [3][4] doubles (aa, bb, ab).
  */

@@ -1086,7 +1086,7 @@ static bool launch_fewout_tile(const GatherA& ga, const Taps& t, const FewOutArg
 // RGB-in forward (the first convolution of both critics: 3 input channels, no pre-activation): lanes run along
 // the OUTPUT channels.  A lane keeps the KS*KS*3 weights of its two channels (co, co + 64: one packed accumulator)
 // in registers for the whole tile, the input pixel -- identical for all lanes -- comes out of an LDS tile (with
-// halo) as one broadcast ds_read_b128 and enters the packed FMA as a broadcast operand.  Every store is 64
+// halo) as one broadcast ds_read_b128 and feeds both channels' FMAs.  Every store is 64
 // consecutive channels of one pixel (256 contiguous bytes).  The generic implicit GEMM spent its time in scalar gathers of
 // the 3-channel pixels (38 TFLOP/s); this form is bound by the packed FMAs and the 134 MB it writes.
 struct FewInArgs {
@@ -1141,12 +1141,18 @@ __global__ __launch_bounds__(256) void conv_rgbin_fwd_kernel(FewInArgs a) {
 #pragma unroll
       for (int kw = 0; kw < KS; ++kw) {
         const f32x2* wt = w + (kh * KS + kw) * 3;
-        acc0 = __builtin_elementwise_fma(wt[0], f32x2{xs[kw].x, xs[kw].x}, acc0);
-        acc0 = __builtin_elementwise_fma(wt[1], f32x2{xs[kw].y, xs[kw].y}, acc0);
-        acc0 = __builtin_elementwise_fma(wt[2], f32x2{xs[kw].z, xs[kw].z}, acc0);
-        acc1 = __builtin_elementwise_fma(wt[0], f32x2{xs[kw + 1].x, xs[kw + 1].x}, acc1);
-        acc1 = __builtin_elementwise_fma(wt[1], f32x2{xs[kw + 1].y, xs[kw + 1].y}, acc1);
-        acc1 = __builtin_elementwise_fma(wt[2], f32x2{xs[kw + 1].z, xs[kw + 1].z}, acc1);
+        // Two scalar v_fma_f32 per product, pinned in asm.  The packed form (v_pk_fma_f32 with the pixel value broadcast
+        // through op_sel) is what the compiler makes of `acc = fma(w2, {x, x}, acc)`, and it is (a) slower here -- 137 us
+        // against 94 us per launch at 256 images: packed fp32 VALU buys nothing on this machine -- and (b) FRAGILE beside
+        // matrix work: with a wave of the 256 x 128 Winograd-domain GEMM (wino_bgemm_x3n_kernel, round 3: the first GEMM
+        // kernel that lets other workgroups share its compute unit) resident on the same SIMD, the low half of lanes
+        // 48 - 63 of these packed FMAs came back wrong in 60 % of the launches (tools/debug/corun_repro.py: two streams;
+        // tools/debug/dist_two_rank_trace.py: two processes on one GPU).  The same kernel with scalar FMAs: 0 of 1800, as
+        // for every other kernel of the library as the neighbour (tests/test_corun_gpu.py).
+#define RGB_FMA(acc, w2, xv) do { float r0_, r1_; asm volatile("v_fma_f32 %0, %2, %4, %5\n\tv_fma_f32 %1, %3, %4, %6" : "=&v"(r0_), "=&v"(r1_) : "v"((w2)[0]), "v"((w2)[1]), "v"(xv), "v"((acc)[0]), "v"((acc)[1])); (acc)[0] = r0_; (acc)[1] = r1_; } while (0)
+        RGB_FMA(acc0, wt[0], xs[kw].x); RGB_FMA(acc0, wt[1], xs[kw].y); RGB_FMA(acc0, wt[2], xs[kw].z);
+        RGB_FMA(acc1, wt[0], xs[kw + 1].x); RGB_FMA(acc1, wt[1], xs[kw + 1].y); RGB_FMA(acc1, wt[2], xs[kw + 1].z);
+#undef RGB_FMA
       }
     }
     float* dst = a.y + (img + (long)(r0 + r) * a.W + c0) * a.ldy + a.coff + co;

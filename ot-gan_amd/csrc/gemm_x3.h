@@ -374,8 +374,13 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
       }
       const unsigned dst = lds_base + buf * X3_STAGE + (isA ? 0 : X3_NP * X3_TA) + piece * X3_TA + rg * 1024;
       // scalar base + per-lane 32-bit offset (the builtin expands to 64-bit per-lane addresses inside the loop);
-      // M0 = LDS address of the chunk.  Nothing else in this kernel uses M0.
-      asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst) : "memory");
+      // M0 = LDS address of the chunk.  Nothing else in this kernel uses M0.  The s_nop is REQUIRED: an SALU write of
+      // M0 needs one wait state before an LDS-DMA instruction reads it, and nothing pads the inside of an asm statement
+      // (cdna_hip_programming.md 5.7).  Without it a load occasionally went to the PREVIOUS M0 -- the chunk before it, or
+      // for a wave's first load whatever M0 held at launch, which can lie outside the workgroup's LDS: round 3 saw a
+      // co-resident workgroup of ANOTHER kernel (conv_rgbin_fwd) corrupted once the 256 x 128 kernel let others share a
+      // compute unit (tools/debug/dist_two_rank_trace.py); the 256 x 256 kernel owns its compute unit and never showed it.
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst) : "memory");
     }
   };
   f32x16 acc[X3_MT][X3_NT];
@@ -432,8 +437,12 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     // LOAD: stage st+1 exists.
     auto stage = [&](int st, int bufn, const X3Frags& F, X3Frags& G, auto issue_c, auto pend_c, auto load_c) {
       constexpr bool ISSUE = decltype(issue_c)::value, PEND = decltype(pend_c)::value, LOAD = decltype(load_c)::value;
-      if (PEND) X3_WAIT_VM(X3_PER_WAVE);
-      else X3_WAIT_VM(0);
+      // vmcnt: this wave's share of stage st+1 has landed; lgkmcnt(0): its fragment reads of stage st have RETURNED --
+      // the buffer they came from is refilled right after the barrier (round 3: seen as a race in the 256 x 128
+      // kernel, two workgroups per compute unit; the same order is kept here.  Inline asm: the compiler's waitcnt pass
+      // drops an lgkmcnt(0) it finds in an s_waitcnt builtin)
+      if (PEND) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(X3_PER_WAVE) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       // six term groups of 16 MFMAs; in front of each: two of the twelve refill loads (all twelve at once keep the
       // wave in its VMEM issue queue for several hundred cycles while the matrix pipe drains) and four of the 24
@@ -596,8 +605,11 @@ __device__ __forceinline__ void x3n_sched_group() {
 #else
 #define X3N_STAMP(i) do { } while (0)
 #endif
+#ifndef X3N_NUM_VGPR
+#define X3N_NUM_VGPR 128
+#endif
 template <bool TL>
-__global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_bgemm_x3n_kernel(BgArgs a) {
+__global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2), amdgpu_num_vgpr(X3N_NUM_VGPR))) void wino_bgemm_x3n_kernel(BgArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
   const int x = blockIdx.x;
   X3N_STAMP(0);
@@ -704,7 +716,7 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int i = i0; i < i0 + n; ++i) {
       const u16* src = cbase[i] + (TL ? ((((kb >> 1) * ccbn[i]) << 9) + ((kb & 1) << 8)) : (kb << 9));
       const unsigned dst = cdst[i] + buf * X3N_STAGE;
-      asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst) : "memory");
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst) : "memory");
     }
   };
   f32x16 acc[X3_MT][X3N_NT];
@@ -751,8 +763,12 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     // refilled, and with eight waves on the compute unit a read still queued in the LDS can be overtaken by the
     // first refill (seen: one wave's last B fragment of a stage stale, a few launches in ten; the MFMAs behind the
     // barrier need these fragments at once anyway)
-    if (PEND) __builtin_amdgcn_s_waitcnt(0x0070 | (X3N_PER_WAVE & 15) | ((X3N_PER_WAVE >> 4) << 14));
-    else __builtin_amdgcn_s_waitcnt(0x0070);
+    // (inline asm: the compiler's waitcnt pass rewrites an s_waitcnt BUILTIN and dropped its lgkmcnt(0) -- it tracks the
+    // registers the reads fill, not the LDS bytes a later DMA overwrites; the kernel then raced a few launches in a
+    // thousand, more with a second process on the GPU)
+    static_assert(X3N_PER_WAVE == 6, "the wait below is written for six loads per wave and stage");
+    if (PEND) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const int rbuf = bufn == 0 ? X3_NSTAGE - 1 : bufn - 1;
     const unsigned char* pa = smem3 + bufn * X3N_STAGE + fa;
@@ -1119,7 +1135,7 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
       const int piece = li >> 3, rg = li & 7;
       const u16* src = c.base[i] + koff;
       const unsigned dst = lds_base + buf * X3_STAGE + (isA ? 0 : X3_NP * X3_TA) + piece * X3_TA + rg * 1024;
-      asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst) : "memory");
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst) : "memory");
     }
   };
   // next stage of the stream; past the end of the range the last stage is fetched again (into a free buffer, never
@@ -1159,7 +1175,8 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
   // without waiting), the buffer this stage was read from is refilled three stages ahead, 96 MFMAs on F with the
   // 24 fragment reads of the next stage (into G) in between
   auto stage = [&](Cur& c, int bufn, const X3Frags& F, X3Frags& G, bool landed) {
-    if (!landed) X3_WAIT_VM(X3_PER_WAVE);
+    if (!landed) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(X3_PER_WAVE) : "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (fragment reads returned before their buffer is refilled)
     __builtin_amdgcn_s_barrier();
     const int rbuf = bufn == 0 ? X3_NSTAGE - 1 : bufn - 1;
     const unsigned char* pa = smem3 + bufn * X3_STAGE + fa;

@@ -568,7 +568,11 @@ struct ApplyBlock {
   int rows;
   int nterms;
   float alpha;
-  ApplyTerm t[2];
+  ApplyTerm t[3];
+  // the accumulators are multiplied by rescale[t] BEFORE term t is added (1 or 0: untouched).  A power of two is
+  // exact, so "(-1/2)(M2 F1 + M3 F2) + M0 F0" -- an injected gradient f_aa - f_ab (train.py:111) -- is one block:
+  // the two half-weight terms first, rescale[2] = -0.5, then the unit term
+  float rescale[3];
 };
 struct ApplyArgs {
   ApplyBlock b[8];
@@ -589,6 +593,13 @@ __global__ __launch_bounds__(256) void plan_apply_kernel(ApplyArgs a) {
   typename SCfg::acc_t acc[SCfg::MT][SCfg::NT];
   zero_acc<SCfg>(acc);
   for (int t = 0; t < blk.nterms; ++t) {
+    const float rs = blk.rescale[t];
+    if (rs != 0.f && rs != 1.f) {
+#pragma unroll
+      for (int i = 0; i < SCfg::MT; ++i)
+#pragma unroll
+        for (int j = 0; j < SCfg::NT; ++j) acc[i][j] *= rs;
+    }
     LA la;
     LB lb;
     la.init(blk.t[t].plan + (long)row0 * blk.t[t].ldp, blk.t[t].ldp, blk.rows - row0, blk.t[t].kdim);
@@ -1035,7 +1046,7 @@ struct MatchWs {
   long planeF, planeP;
   size_t bytes;
 };
-MatchWs carve_match(void* base, size_t cap, int P, int n, int D, int feat_rows) {
+MatchWs carve_match(void* base, size_t cap, int P, int n, int D, int feat_rows, bool grad = false) {
   Carver c(base, cap);
   MatchWs w;
   const CostPlan cp = plan_cost(P, n, n, D);
@@ -1045,11 +1056,13 @@ MatchWs carve_match(void* base, size_t cap, int P, int n, int D, int feat_rows) 
   if (w.x3 && x3_plan_cost(P, n, n, D).nsplit > nsplit) nsplit = x3_plan_cost(P, n, n, D).nsplit;
   w.sq_a = (float*)c.take(sizeof(float) * feat_rows);
   w.sq_b = (float*)c.take(sizeof(float) * feat_rows);
-  w.planeF = (long)x3_plane_elems(2 * (size_t)feat_rows, D);
-  w.planeP = (long)x3_plane_elems((size_t)P * n, n);
+  // grad variant (otgan_matching_two_batch_grad_f32): feature stack [a1 b1 b2 a2 a1 b1] (3 n-row blocks more than the
+  // four halves) and ONE plan operand of twelve n-row blocks (PT; PM unused)
+  w.planeF = (long)x3_plane_elems((grad ? 3 : 2) * (size_t)feat_rows, D);
+  w.planeP = (long)x3_plane_elems((grad ? 2 : 1) * (size_t)P * n, n);
   w.FP = (u16*)c.take(w.x3 ? sizeof(u16) * 3 * (size_t)w.planeF : 0);
   w.PT = (u16*)c.take(w.x3 ? sizeof(u16) * 3 * (size_t)w.planeP : 0);
-  w.PM = (u16*)c.take(w.x3 ? sizeof(u16) * 3 * (size_t)w.planeP : 0);
+  w.PM = (u16*)c.take(w.x3 && !grad ? sizeof(u16) * 3 * (size_t)w.planeP : 0);
   w.partial = (float*)c.take(sizeof(float) * pnm * nsplit);
   w.K = (float*)c.take(sizeof(float) * pnm);
   w.plan = (float*)c.take(sizeof(float) * pnm);
@@ -1302,6 +1315,155 @@ int otgan_matching_two_batch_rows_f32(const float* fa, const float* fb, int N, i
   OTGAN_CHECK_LAUNCH("matching finalize");
   if (stats) hipMemcpyAsync(stats, w.stats, sizeof(double) * 24, hipMemcpyDeviceToDevice, s);
   return OTGAN_OK;
+}
+
+// ---- training-mode matching: the injected gradients directly (round 3) ---------------------------------------
+// The reference only ever consumes the DIFFERENCES of the matched features (train.py:111,125-126: grad_ys =
+// features_a_a - features_a_b for the generated shards, features_b_b - features_b_a for the data shards) and the
+// distance.  Per half-batch a difference is one three-term plan application,
+//   g(a1) = M0 a2 - (M2 b1 + M3 b2)/2      g(a2) = M0^T a1 - (M4 b1 + M5 b2)/2
+//   g(b1) = M1^T b2 - (M2^T a1 + M4^T a2)/2  g(b2) = M1 b1 - (M3^T a1 + M5^T a2)/2
+// (problems a1a2, b2b1, a1b1, a1b2, a2b1, a2b2 = M0 .. M5), so four output blocks (two on the five generator steps out
+// of six, which need no data-side gradient) replace eight, the four [2N, D] matched arrays are never written, the two
+// subtractions disappear, and the distance comes from the Sinkhorn kernel's statistics (closed form) instead of a pass
+// over five [2N, D] arrays.
+static int matching_grad_impl(const float* fa, const float* fb, int N, int D, long ldf, float lambda, int iters,
+                              int row_begin, int row_count, const float* K_pre, float* grad_a, float* grad_b, long ldo,
+                              float* entropy, double* dist, double* stats, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  OTGAN_CHECK_ARG(fa && fb && grad_a && entropy && dist, "null pointer");
+  OTGAN_CHECK_ARG(N > 0 && D > 0 && ldf >= D && ldo >= D && iters >= 0, "bad sizes N=%d D=%d", N, D);
+  OTGAN_CHECK_ARG(row_begin >= 0 && row_count > 0 && row_begin + row_count <= 2 * N,
+                  "row range [%d, %d) outside [0, %d)", row_begin, row_begin + row_count, 2 * N);
+  const bool full = row_begin == 0 && row_count == 2 * N;
+  const int half = row_begin / N;
+  OTGAN_CHECK_ARG(full || (row_begin + row_count - 1) / N == half, "row range must not straddle the two mini-batches");
+  hipStream_t s = (hipStream_t)stream;
+  MatchWs w = carve_match(workspace, workspace_bytes, 6, N, D, 2 * N, true);
+  if (!workspace || workspace_bytes < w.bytes) {
+    otgan_set_error("workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
+    return OTGAN_ERR_WORKSPACE;
+  }
+  const float *fa1 = fa, *fa2 = fa + (long)N * ldf, *fb1 = fb, *fb2 = fb + (long)N * ldf;
+  const float* X[6] = {fa1, fb2, fa1, fa1, fa2, fa2};
+  const float* Y[6] = {fa2, fb1, fb1, fb2, fb1, fb2};
+  int rc = OTGAN_OK;
+  const bool x3 = w.x3 && ldf % 4 == 0 && ldo % 4 == 0 && aligned16(fa) && aligned16(fb) && aligned16(grad_a) &&
+                  aligned16(grad_b) && row_begin % 16 == 0;
+  const int nstack = grad_b ? 6 : 4;
+  if (x3) {
+    // stacked feature operand [a1 b1 b2 a2 (a1 b1)]: every difference contracts over three ADJACENT blocks
+    SplitSrc ss;
+    memset(&ss, 0, sizeof(ss));
+    const float* blocks[6] = {fa1, fb1, fb2, fa2, fa1, fb1};
+    ss.n = nstack;
+    for (int i = 0; i < nstack; ++i) { ss.src[i] = blocks[i]; ss.ld[i] = ldf; ss.row0[i] = (long)i * N; ss.scale[i] = 1.f; }
+    x3_split(ss, N, D, w.FP, w.planeF, s);
+  }
+  const float* Kuse = K_pre;
+  if (!K_pre) {
+    if (x3) {
+      // rows of the stack: a1 0, b1 N, b2 2N, a2 3N
+      const long xrow[6] = {0, 2L * N, 0, 0, 3L * N, 3L * N};
+      const long yrow[6] = {3L * N, N, N, 2L * N, N, 2L * N};
+      ProfScope ps(OTGAN_PROF_COST_GEMM, 12.0 * N * (double)N * D, 16.0 * N * (double)D, s);
+      rc = launch_cost_x3(w.FP, w.planeF, (long)nstack * N, xrow, yrow, nullptr, 6, N, N, D, lambda, w.partial, w.K, s);
+    } else {
+      rc = launch_cost(X, Y, nullptr, nullptr, nullptr, 6, N, N, D, ldf, lambda, OTGAN_COST_COSINE, w.partial, w.K, s);
+    }
+    if (rc) return rc;
+    Kuse = w.K;
+  }
+  rc = launch_sinkhorn(Kuse, 6, N, N, iters, lambda, w.plan, w.planT, w.stats, w.fg, s);
+  if (rc) return rc;
+  const size_t nn = (size_t)N * N;
+  const float *M[6], *T[6];
+  for (int p = 0; p < 6; ++p) { M[p] = w.plan + p * nn; T[p] = w.planT + p * nn; }
+  // the four differences: {unit-weight plan, its features, the two half-weight plans and their features}
+  struct Diff {
+    const float *P0, *F0, *P1, *F1, *P2, *F2;
+  };
+  const Diff diff[4] = {
+      {M[0], fa2, M[2], fb1, M[3], fb2},   // g(a1)   (matching.py:64,66,67,80)
+      {T[0], fa1, M[4], fb1, M[5], fb2},   // g(a2)   (:70,68,69,80)
+      {T[1], fb2, T[2], fa1, T[4], fa2},   // g(b1)   (:65,72,74,82)
+      {M[1], fb1, T[3], fa1, T[5], fa2},   // g(b2)   (:71,73,75,82)
+  };
+  // output blocks of this call: which difference, where it goes, which plan rows
+  int which[4], nblk = 0;
+  float* outp[4];
+  const int r0 = full ? 0 : row_begin - half * N, cnt = full ? N : row_count;
+  if (full) {
+    which[nblk] = 0; outp[nblk++] = grad_a;
+    which[nblk] = 1; outp[nblk++] = grad_a + (long)N * ldo;
+    if (grad_b) {
+      which[nblk] = 2; outp[nblk++] = grad_b;
+      which[nblk] = 3; outp[nblk++] = grad_b + (long)N * ldo;
+    }
+  } else {
+    which[nblk] = half; outp[nblk++] = grad_a;
+    if (grad_b) { which[nblk] = 2 + half; outp[nblk++] = grad_b; }
+  }
+  if (x3) {
+    // plan operand: per difference three n-row blocks in the order of its features in the stack
+    //   g(a2): stack rows [0, 3N)  = a1 b1 b2 -> M0   -T4/2 -T5/2      (A = the TRANSPOSE of the plan applied: out = A^T F)
+    //   g(a1): stack rows [N, 4N)  = b1 b2 a2 -> -T2/2 -T3/2  T0
+    //   g(b1): stack rows [2N, 5N) = b2 a2 a1 -> M1   -M4/2 -M2/2
+    //   g(b2): stack rows [3N, 6N) = a2 a1 b1 -> -M5/2 -M3/2  T1
+    SplitSrc sp;
+    memset(&sp, 0, sizeof(sp));
+    const float* src[4][3] = {{T[2], T[3], T[0]}, {M[0], T[4], T[5]}, {M[1], M[4], M[2]}, {M[5], M[3], T[1]}};
+    const float scl[4][3] = {{-0.5f, -0.5f, 1.f}, {1.f, -0.5f, -0.5f}, {1.f, -0.5f, -0.5f}, {-0.5f, -0.5f, 1.f}};
+    const long frow[4] = {N, 0, 2L * N, 3L * N};
+    sp.n = 3 * nblk;
+    for (int z = 0; z < nblk; ++z)
+      for (int t = 0; t < 3; ++t) {
+        const int i = 3 * z + t;
+        sp.src[i] = src[which[z]][t]; sp.ld[i] = N; sp.row0[i] = (long)i * N; sp.scale[i] = scl[which[z]][t];
+      }
+    x3_split(sp, N, N, w.PT, w.planeP, s);
+    X3ApplyBlock xb[4];
+    for (int z = 0; z < nblk; ++z) xb[z] = X3ApplyBlock{w.PT, 3L * z * N, frow[which[z]], 3 * N, outp[z]};
+    rc = launch_apply_x3(xb, nblk, w.PT, w.planeP, N, w.FP, w.planeF, r0, cnt, D, ldo, s);
+  } else {
+    ApplyBlock blk[4];
+    memset(blk, 0, sizeof(blk));
+    const long ro = (long)r0 * N;
+    for (int z = 0; z < nblk; ++z) {
+      const Diff& d = diff[which[z]];
+      blk[z].out = outp[z]; blk[z].rows = cnt; blk[z].nterms = 3; blk[z].alpha = 1.f;
+      blk[z].t[0] = ApplyTerm{d.P1 + ro, d.F1, (long)N, N};
+      blk[z].t[1] = ApplyTerm{d.P2 + ro, d.F2, (long)N, N};
+      blk[z].t[2] = ApplyTerm{d.P0 + ro, d.F0, (long)N, N};
+      blk[z].rescale[2] = -0.5f;
+    }
+    rc = launch_apply(blk, nblk, cnt, D, ldf, ldo, s);
+  }
+  if (rc) return rc;
+  hipLaunchKernelGGL(entropy_finalize_kernel, dim3(1), dim3(1), 0, s, w.stats, 6, N, entropy);
+  hipLaunchKernelGGL(closed_form_distance_kernel, dim3(1), dim3(1), 0, s, w.stats, N, dist);
+  OTGAN_CHECK_LAUNCH("matching finalize");
+  if (stats) hipMemcpyAsync(stats, w.stats, sizeof(double) * 24, hipMemcpyDeviceToDevice, s);
+  return OTGAN_OK;
+}
+
+size_t otgan_matching_grad_workspace_bytes(int N, int D) {
+  if (N <= 0 || D <= 0) return 0;
+  return carve_match(nullptr, 0, 6, N, D, 2 * N, true).bytes;
+}
+int otgan_matching_two_batch_grad_f32(const float* fa, const float* fb, int N, int D, long ldf, float lambda, int iters,
+                                      float* grad_a, float* grad_b, long ldo, float* entropy, double* dist,
+                                      double* stats, void* workspace, size_t workspace_bytes, void* stream) {
+  return matching_grad_impl(fa, fb, N, D, ldf, lambda, iters, 0, 2 * N, nullptr, grad_a, grad_b, ldo, entropy, dist, stats,
+                            workspace, workspace_bytes, stream);
+}
+int otgan_matching_two_batch_rows_grad_f32(const float* fa, const float* fb, int N, int D, long ldf, float lambda,
+                                           int iters, int row_begin, int row_count, const float* K_pre, float* grad_a,
+                                           float* grad_b, long ldo, float* entropy, double* dist, double* stats,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+  OTGAN_CHECK_ARG(!(row_begin == 0 && row_count == 2 * N), "the row-range variant takes a range inside one mini-batch");
+  return matching_grad_impl(fa, fb, N, D, ldf, lambda, iters, row_begin, row_count, K_pre, grad_a, grad_b, ldo, entropy,
+                            dist, stats, workspace, workspace_bytes, stream);
 }
 
 int otgan_matching_single_batch_f32(const float* fa, const float* fb, int n, int D, long ldf,

@@ -1099,11 +1099,17 @@ bool launch_narrow(const BgArgs& b0, int nsplit, int min_k, hipStream_t s) {
     static const long maxt = [] { const char* e = getenv("OTGAN_X3_NARROW_MAXT"); return e ? atol(e) : 32L; }();
     if ((long)b0.tiles_m * b0.tiles_n > maxt) return false;
   }
+  {   // dev knobs: OTGAN_X3_NARROW_NT=0 / OTGAN_X3_NARROW_TL=0 keep one instantiation on the 256 x 256 tile
+    const char* e = getenv(TL ? "OTGAN_X3_NARROW_TL" : "OTGAN_X3_NARROW_NT");
+    if (e && e[0] == '0') return false;
+  }
   BgArgs b = b0;
   b.tiles_n = (b.N + X3N_BN - 1) / X3N_BN;
   const unsigned gx = build_fmap(b);
-  ensure_lds<wino_bgemm_x3n_kernel<TL>>(X3N_LDS);
-  hipLaunchKernelGGL((wino_bgemm_x3n_kernel<TL>), dim3(gx, nsplit, 1), dim3(X3_THREADS), X3N_LDS, s, b);
+  // (dev knob OTGAN_X3_NARROW_LDS=<bytes>: ask for more LDS than the kernel uses, e.g. 100000 = one workgroup per CU)
+  static const size_t lds = [] { const char* e = getenv("OTGAN_X3_NARROW_LDS"); const size_t v = e ? (size_t)atol(e) : 0; return v > X3N_LDS ? v : X3N_LDS; }();
+  ensure_lds<wino_bgemm_x3n_kernel<TL>>(lds);
+  hipLaunchKernelGGL((wino_bgemm_x3n_kernel<TL>), dim3(gx, nsplit, 1), dim3(X3_THREADS), lds, s, b);
   return true;
 }
 #else

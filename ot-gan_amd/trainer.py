@@ -113,34 +113,42 @@ class OTGAN:
         return S * self.args.batch_size if self.args.single_batch else (S // 2) * self.args.batch_size
 
     # ---------------------------------------------------------------- matching (train.py:88-98)
-    def _match(self, f_gen, f_dat, pending_dat=None):
+    def _match(self, f_gen, f_dat, pending_dat=None, need_dat=True):
+        """-> (grad_gen, grad_dat or None, distance, entropy): the injected upstream gradients of train.py:111,125-126
+        (un-normalised matched differences) for this rank's samples.  `need_dat=False` (generator steps) skips the
+        data-side gradient."""
         a = self.args
+        plain = not (a.single_batch or a.no_sinkhorn)
         if self.scope == "global" and self.world > 1:
             S = self.world * self.shards
-            fa = parallel.gather_feature_shards(f_gen, self.shards)
-            fb = (list(torch.chunk(pending_dat.wait(), S, 0)) if pending_dat is not None
-                  else parallel.gather_feature_shards(f_dat, self.shards))
-            if not (a.single_batch or a.no_sinkhorn):
+            allg = parallel.all_gather_rows(f_gen)
+            alld = pending_dat.wait() if pending_dat is not None else parallel.all_gather_rows(f_dat)
+            if plain:
                 # The cost matrices are row-sharded like the reference (matching.py:29-39): a rank
                 # of the first half computes its rows of (a1,a2) (a1,b1) (a1,b2), a rank of the
                 # second half its rows of (b2,b1) (a2,b1) (a2,b2); the slices are all-gathered.
                 # Every rank then solves the six (small, on-chip) Sinkhorn problems and applies the
                 # plans only to the rows of its own samples.
+                fa, fb = list(torch.chunk(allg, S, 0)), list(torch.chunk(alld, S, 0))
                 K = self._sharded_log_kernels(f_gen, f_dat, fa, fb)
-                outs, ent, dist = matching.get_matched_features_rows(
-                    fa, fb, a.sinkhorn_lambda, a.nr_sinkhorn_iter, self.rank * self.nb, self.nb, K)
-                return outs[0] - outs[2], outs[1] - outs[3], dist, ent
+                g_gen, g_dat, ent, dist = matching.matched_feature_grads(
+                    allg, alld, a.sinkhorn_lambda, a.nr_sinkhorn_iter, need_b=need_dat,
+                    rows=(self.rank * self.nb, self.nb), log_kernels=K)
+                return g_gen, g_dat, dist, ent
+            fa, fb = list(torch.chunk(allg, S, 0)), list(torch.chunk(alld, S, 0))
         else:
             if pending_dat is not None:       # forced-collective mode at world size 1: same rows, via RCCL
                 f_dat = pending_dat.wait()
+            if plain:
+                g_gen, g_dat, ent, dist = matching.matched_feature_grads(
+                    f_gen, f_dat, a.sinkhorn_lambda, a.nr_sinkhorn_iter, need_b=need_dat)
+                return g_gen, g_dat, dist, ent
             fa = list(torch.chunk(f_gen, self.shards, 0))
             fb = list(torch.chunk(f_dat, self.shards, 0))
         if a.single_batch:
             m = matching.get_matched_features_single_batch(fa, fb, a.sinkhorn_lambda, a.nr_sinkhorn_iter)
-        elif a.no_sinkhorn:
-            m = matching.get_matched_features_random(fa, fb)
         else:
-            m = matching.get_matched_features(fa, fb, a.sinkhorn_lambda, a.nr_sinkhorn_iter)
+            m = matching.get_matched_features_random(fa, fb)
         dist = m.distance if m.distance is not None else matching.calc_distance(fa, fb, m)
         lo = self.rank * self.shards if (self.scope == "global" and self.world > 1) else 0
         pick = lambda lst: torch.cat(lst[lo:lo + self.shards], 0)
@@ -195,7 +203,7 @@ class OTGAN:
             # follows requires_grad, not the `inputs` list of autograd.grad) and only propagate d/dx
             with _frozen(self.disc_params):
                 f_gen = self.discriminator(x_gen, **self.model_opts)
-            g_gen, _g_dat, dist, ent = self._match(f_gen.detach(), f_dat, pending)
+            g_gen, _g_dat, dist, ent = self._match(f_gen.detach(), f_dat, pending, need_dat=False)
             if self.gen_buckets is not None:
                 self.gen_buckets.arm()
             grads = torch.autograd.grad(f_gen, self.gen_params, g_gen)                            # train.py:112

@@ -9,6 +9,8 @@
         reference utils/matching.py:3-9     (list rotation only; no kernel)
     calc_distance(features_a, features_b, matched_features)
         reference utils/matching.py:139-153 -> otgan_calc_distance_f32
+    matched_feature_grads(fa, fb, ...)      (added) the differences the training step injects as grad_ys
+        reference train.py:111,125-126      -> otgan_matching_two_batch_grad_f32
 
 `features_a` / `features_b` are lists of S equally-shaped `[B, D]` float32 CUDA tensors
 (`a` = generated, `b` = data; shards [0,S/2) form mini-batch 1, [S/2,S) mini-batch 2).
@@ -188,6 +190,51 @@ def get_matched_features_rows(features_a, features_b, sinkhorn_lambda, nr_sinkho
                                              stats.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
     _lib.check(rc, "otgan_matching_two_batch_rows_f32")
     return outs, entropy, dist
+
+
+def matched_feature_grads(fa, fb, sinkhorn_lambda, nr_sinkhorn_iter, need_b=True, rows=None, log_kernels=None):
+    """Training-mode two-batch matching (otgan_matching_two_batch_grad_f32): the reference's injected gradients
+    `features_a_a - features_a_b` (train.py:111) and `features_b_b - features_b_a` (train.py:125-126) directly, without
+    forming the four matched arrays.  fa, fb: flat [2N, D] feature arrays (shards in order: rows [0, N) = mini-batch 1,
+    utils/matching.py:16-19).  `need_b=False` (generator steps) skips the data-side gradient.  `rows=(row_begin,
+    row_count)`: only that row range (inside one mini-batch: the samples of one data-parallel rank), `log_kernels` as in
+    get_matched_features_rows.  Returns (grad_a, grad_b or None, entropy, distance): [rows, D] float32 tensors, a 0-d
+    float32 and a 0-d float64 tensor (closed form of calc_distance from the Sinkhorn statistics)."""
+    for t in (fa, fb):
+        if not t.is_cuda:
+            raise _lib.OtganError("matching needs CUDA (MI355X) tensors; there is no CPU fallback")
+        if t.dtype != torch.float32 or t.dim() != 2 or t.shape != fa.shape or t.shape[0] % 2:
+            raise ValueError("fa and fb must be float32 [2N, D] tensors of one shape")
+    fa, fb = fa.detach().contiguous(), fb.detach().contiguous()
+    L = _lib.lib()
+    rows_total, D = fa.shape
+    N = rows_total // 2
+    dev = fa.device
+    nrows = rows_total if rows is None else int(rows[1])
+    grad_a = torch.empty((nrows, D), dtype=fa.dtype, device=dev)
+    grad_b = torch.empty((nrows, D), dtype=fa.dtype, device=dev) if need_b else None
+    entropy = torch.empty((), dtype=torch.float32, device=dev)
+    dist = torch.empty((), dtype=torch.float64, device=dev)
+    ws = _workspace(L.otgan_matching_grad_workspace_bytes(N, D), dev)
+    if rows is None:
+        if log_kernels is not None:
+            raise ValueError("log_kernels are only taken by the row-range variant")
+        rc = L.otgan_matching_two_batch_grad_f32(fa.data_ptr(), fb.data_ptr(), N, D, D, float(sinkhorn_lambda),
+                                                 int(nr_sinkhorn_iter), grad_a.data_ptr(), _lib.ptr(grad_b), D,
+                                                 entropy.data_ptr(), dist.data_ptr(), None, ws.data_ptr(), ws.numel(),
+                                                 _lib.stream_ptr())
+        _lib.check(rc, "otgan_matching_two_batch_grad_f32")
+    else:
+        if log_kernels is not None:
+            log_kernels = log_kernels.contiguous()
+            assert tuple(log_kernels.shape) == (6, N, N) and log_kernels.dtype == torch.float32
+        rc = L.otgan_matching_two_batch_rows_grad_f32(fa.data_ptr(), fb.data_ptr(), N, D, D, float(sinkhorn_lambda),
+                                                      int(nr_sinkhorn_iter), int(rows[0]), int(rows[1]),
+                                                      _lib.ptr(log_kernels), grad_a.data_ptr(), _lib.ptr(grad_b), D,
+                                                      entropy.data_ptr(), dist.data_ptr(), None, ws.data_ptr(),
+                                                      ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "otgan_matching_two_batch_rows_grad_f32")
+    return grad_a, grad_b, entropy, dist
 
 
 def get_matched_features_single_batch(features_a, features_b, sinkhorn_lambda, nr_sinkhorn_iter):

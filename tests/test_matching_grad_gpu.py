@@ -1,0 +1,129 @@
+"""GPU: training-mode matching (otgan_matching_two_batch_grad_f32 / _rows_grad_): the injected gradients
+`features_a_a - features_a_b` (reference train.py:111) and `features_b_b - features_b_a` (train.py:125-126) and the
+closed-form distance, against the fp64 oracle (oracle/matching_np.py, pinned to the reference-generated fixtures) and
+against the reference-generated golden vectors themselves.  Tolerances: differences 2e-3 relative L2 (a difference
+of two matched features, each good to 2e-4, that partly cancel), loss 1e-4 relative -- the north-star figure."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import matching_np as M
+
+pytestmark = pytest.mark.gpu
+REL_DIFF = 2e-3
+REL_LOSS = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from otgan_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def _rel(got, ref):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
+
+
+def _t(x, dev):
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32), device=dev)
+
+
+def test_grad_vs_golden(dev, list_case):
+    """the five reference-generated fixtures: grad = two_aa - two_ab, two_bb - two_ba of the reference's own outputs"""
+    from otgan_amd.utils import matching
+    g = list_case
+    fa = _t(np.concatenate(list(g["fa"])), dev)
+    fb = _t(np.concatenate(list(g["fb"])), dev)
+    ga, gb, ent, dist = matching.matched_feature_grads(fa, fb, float(g["lam"]), int(g["iters"]))
+    ra = np.concatenate(list(g["two_aa"])) - np.concatenate(list(g["two_ab"]))
+    rb = np.concatenate(list(g["two_bb"])) - np.concatenate(list(g["two_ba"]))
+    assert _rel(ga.cpu().numpy(), ra) < REL_DIFF
+    assert _rel(gb.cpu().numpy(), rb) < REL_DIFF
+    assert float(ent) == pytest.approx(float(g["two_entropy"]), rel=2e-4)
+    ref = float(g["two_distance"])
+    atol = 2e-6 if g["name"] == "survey" else 1e-7         # (see tests/test_matching_gpu.py::_loss_ok)
+    assert abs(float(dist) - ref) <= REL_LOSS * abs(ref) + atol
+    # generator steps: no data-side gradient; the generated-side one is the same bits
+    ga2, gb2, _, dist2 = matching.matched_feature_grads(fa, fb, float(g["lam"]), int(g["iters"]), need_b=False)
+    assert gb2 is None and torch.equal(ga2, ga) and float(dist2) == float(dist)
+
+
+def _clustered(seed, rows, D):
+    rng = np.random.RandomState(seed)
+    ca, cb = rng.randn(32, D), rng.randn(32, D)
+    fa = M.clustered_features(rng, rows, D, ca).astype(np.float32)
+    fb = M.clustered_features(rng, rows, D, cb).astype(np.float32)
+    return fa, fb
+
+
+@pytest.mark.parametrize("N,D,iters", [(128, 32768, 100),     # configs[1]: the exact-fp32 engine, three-term blocks
+                                       (256, 7296, 200),      # configs[3] width: the split-precision engine
+                                       (256, 131072, 100)],   # configs[4]: 64x64 critic width
+                         ids=["N128_D32768", "N256_D7296", "N256_D131072"])
+def test_grad_full_size_vs_oracle(dev, N, D, iters):
+    from otgan_amd.utils import matching
+    lam = 500.0
+    fa, fb = _clustered(3, 2 * N, D)
+    A, B = _t(fa, dev), _t(fb, dev)
+    ga, gb, ent, dist = matching.matched_feature_grads(A, B, lam, iters)
+    f64 = lambda z: z.astype(np.float64)
+    fa1, fa2, fb1, fb2 = f64(fa[:N]), f64(fa[N:]), f64(fb[:N]), f64(fb[N:])
+    plans, costs, ent_ref = M.two_batch_plans(fa1, fa2, fb1, fb2, lam, iters)
+    dref = M.closed_form_from(plans, costs, N)
+    ra, rb = [], []
+    for half in (0, 1):
+        aa, bb, ab, ba = M.matched_rows(plans, fa1, fa2, fb1, fb2, half, 0, N)
+        ra.append(aa - ab)
+        rb.append(bb - ba)
+    assert _rel(ga.cpu().numpy(), np.concatenate(ra)) < REL_DIFF
+    assert _rel(gb.cpu().numpy(), np.concatenate(rb)) < REL_DIFF
+    assert float(ent) == pytest.approx(float(ent_ref), rel=2e-4)
+    assert abs(float(dist) - dref) <= REL_LOSS * abs(dref) + 1e-7, (float(dist), dref)
+    # the same differences from the four matched arrays of the inference-mode entry point
+    out = matching.get_matched_features([A[:N], A[N:]], [B[:N], B[N:]], lam, iters)
+    da = (torch.cat(out[0]) - torch.cat(out[2])).cpu().numpy()
+    assert _rel(ga.cpu().numpy(), da) < 1e-4
+
+
+def test_rows_grad_rank_of_8(dev):
+    """the rank-level call of the 8-GPU configurations (N = 1024, 256 rows per rank, D = 7296, 200 iterations), with
+    and without precomputed log-kernels, ranks 0, 3, 4, 7 against the oracle's rows"""
+    from otgan_amd import trainer
+    from otgan_amd.utils import matching
+    S, Bs, D, lam, iters, WORLD = 16, 128, 7296, 500.0, 200, 8
+    N, nb = S * Bs // 2, 256
+    fa_h, fb_h = _clustered(11, 2 * N, D)
+    fa_d, fb_d = _t(fa_h, dev), _t(fb_h, dev)
+    fa, fb = list(torch.chunk(fa_d, S, 0)), list(torch.chunk(fb_d, S, 0))
+    slices = [trainer.rank_log_kernel_slices(r, WORLD, fa_d[r * nb:(r + 1) * nb], fb_d[r * nb:(r + 1) * nb], fa, fb, lam)
+              for r in range(WORLD)]
+    K = trainer.assemble_log_kernels(torch.stack(slices, 0), WORLD)
+    f64 = lambda z: z.astype(np.float64)
+    fa1, fa2, fb1, fb2 = f64(fa_h[:N]), f64(fa_h[N:]), f64(fb_h[:N]), f64(fb_h[N:])
+    plans, costs, ent_ref = M.two_batch_plans(fa1, fa2, fb1, fb2, lam, iters)
+    dref = M.closed_form_from(plans, costs, N)
+    for r, pre in ((0, K), (3, None), (4, K), (7, K)):
+        ga, gb, ent, dist = matching.matched_feature_grads(fa_d, fb_d, lam, iters, rows=(r * nb, nb), log_kernels=pre)
+        half, r0 = divmod(r * nb, N)
+        aa, bb, ab, ba = M.matched_rows(plans, fa1, fa2, fb1, fb2, half, r0, r0 + nb)
+        assert _rel(ga.cpu().numpy(), aa - ab) < REL_DIFF, r
+        assert _rel(gb.cpu().numpy(), bb - ba) < REL_DIFF, r
+        assert float(ent) == pytest.approx(float(ent_ref), rel=2e-4)
+        assert abs(float(dist) - dref) <= REL_LOSS * abs(dref) + 1e-7, (r, float(dist), dref)
+    ga2, gb2, _, _ = matching.matched_feature_grads(fa_d, fb_d, lam, iters, need_b=False, rows=(7 * nb, nb), log_kernels=K)
+    assert gb2 is None and torch.equal(ga2, ga)
+
+
+def test_grad_abi_errors(dev):
+    from otgan_amd import _lib
+    from otgan_amd.utils import matching
+    fa = torch.rand(64, 32, device=dev)
+    with pytest.raises(_lib.OtganError):
+        matching.matched_feature_grads(fa, fa, 10.0, 5, rows=(24, 16))        # straddles the two mini-batches
+    with pytest.raises(_lib.OtganError):
+        matching.matched_feature_grads(fa.cpu(), fa.cpu(), 10.0, 5)
+    with pytest.raises(ValueError):
+        matching.matched_feature_grads(fa[:63], fa[:63], 10.0, 5)

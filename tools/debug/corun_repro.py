@@ -1,0 +1,99 @@
+"""dev: does a kernel running BESIDE the Winograd-domain GEMM on the same GPU (second stream of one process) compute
+wrong values?  Stream A loops a GEMM-heavy convolution layer, stream B loops a victim layer on fixed inputs and checks
+every result against the first one.
+    python tools/debug/corun_repro.py [victim: rgbin|glu|head|s2] [iterations]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from otgan_amd import _lib, ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+_lib.lib()
+victim = sys.argv[1] if len(sys.argv) > 1 else "rgbin"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+g = torch.Generator().manual_seed(1)
+
+
+def params(k, cin, cout):
+    return ((torch.randn(k, k, cin, cout, generator=g) * 0.05).to(dev), torch.ones(cout, device=dev), torch.zeros(cout, device=dev))
+
+
+# co-runner: a strided critic layer at batch 4 (tiny M, K = 4096: long GEMM with few workgroups, like the two-rank test)
+xa = torch.randn(4, 8, 8, 512, generator=g).to(dev)
+Va, ga, ba = params(5, 1024, 1024)
+xa2 = torch.randn(4, 16, 16, 256, generator=g).to(dev)
+Va2, ga2, ba2 = params(5, 512, 512)
+
+
+def corun():
+    ops.conv2d_op(xa, Va, ga, ba, stride=2, preact=ops.ACT["crelu"])
+    ops.conv2d_op(xa2, Va2, ga2, ba2, stride=2, preact=ops.ACT["crelu"])
+
+
+if victim == "rgbin":
+    xv = (torch.rand(4, 32, 32, 3, generator=g) * 2 - 1).to(dev)
+    Vv, gv, bv = params(5, 3, 128)
+    run_victim = lambda: ops.conv2d_op(xv, Vv, gv, bv, stride=1, preact=ops.ACT[None])
+elif victim == "rgbin3":
+    xv = (torch.rand(4, 32, 32, 3, generator=g) * 2 - 1).to(dev)
+    Vv, gv, bv = params(3, 3, 128)
+    run_victim = lambda: ops.conv2d_op(xv, Vv, gv, bv, stride=1, preact=ops.ACT[None])
+elif victim in ("rgbout", "rgbin_grad", "growth"):
+    if victim == "rgbout":
+        xv = torch.randn(4, 32, 32, 128, generator=g).to(dev).requires_grad_(True)
+        Vv, gv, bv = params(5, 128, 3)
+        kw = dict(stride=1, preact=ops.ACT[None])
+    elif victim == "rgbin_grad":
+        xv = (torch.rand(4, 32, 32, 3, generator=g) * 2 - 1).to(dev).requires_grad_(True)
+        Vv, gv, bv = params(5, 3, 128)
+        kw = dict(stride=1, preact=ops.ACT[None])
+    else:
+        xv = torch.randn(4, 32, 32, 64, generator=g).to(dev).requires_grad_(True)
+        Vv, gv, bv = params(3, 128, 16)
+        kw = dict(stride=1, preact=ops.ACT["crelu"])
+    Vv.requires_grad_(True)
+    dyv = None
+
+    def run_victim():
+        global dyv
+        with torch.enable_grad():
+            y = ops.conv2d_op(xv, Vv, gv, bv, **kw)
+            if dyv is None:
+                dyv = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(dev)
+            dx, dV = torch.autograd.grad(y, [xv, Vv], dyv)
+        return torch.cat([y.detach().reshape(-1), dx.reshape(-1), dV.reshape(-1)])
+elif victim == "glu":
+    xv = torch.randn(4, 16, 16, 512, generator=g).to(dev)
+    run_victim = lambda: ops.glu(xv)
+elif victim == "head":
+    xv = torch.randn(4, 4, 4, 1024, generator=g).to(dev)
+    run_victim = lambda: ops.feature_head(xv)
+else:
+    xv = torch.randn(4, 32, 32, 128, generator=g).to(dev)
+    Vv, gv, bv = params(5, 256, 256)
+    run_victim = lambda: ops.conv2d_op(xv, Vv, gv, bv, stride=2, preact=ops.ACT["crelu"])
+
+with torch.no_grad():
+    corun()
+    ref = run_victim().clone()
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    bad = 0
+    for it in range(iters):
+        with torch.cuda.stream(sa):
+            for _ in range(3):
+                corun()
+        with torch.cuda.stream(sb):
+            outs = [run_victim() for _ in range(12)]
+        torch.cuda.synchronize()
+        for o in outs:
+            if not torch.equal(o, ref):
+                d = (o != ref)
+                idx = d.nonzero()
+                bad += 1
+                if bad <= 5:
+                    print(f"iter {it}: {int(d.sum())} elements differ, index range {idx.min(0).values.tolist()} .. {idx.max(0).values.tolist()}", flush=True)
+    print("CORUN", victim, "mismatching results:", bad, "of", iters * 12, flush=True)

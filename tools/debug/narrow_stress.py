@@ -19,6 +19,22 @@ CASES = [  # name, N, H, C, Cout, k, stride, upsample, preact
     ("tiny", 4, 16, 128, 256, 5, 2, False, "crelu"),
     ("tiny_up", 4, 8, 256, 256, 5, 1, True, None),
 ]
+# the layers of the DCGAN nets at 4 images per rank (tests/test_dist_gpu.py): OTGAN_STRESS_CASES=b4
+B4_CASES = [
+    ("g0_b4", 4, 4, 1024, 1024, 5, 1, True, None),
+    ("g1_b4", 4, 8, 512, 512, 5, 1, True, None),
+    ("g2_b4", 4, 16, 256, 256, 5, 1, True, None),
+    ("d1_b4", 4, 32, 128, 256, 5, 2, False, "crelu"),
+    ("d2_b4", 4, 16, 256, 512, 5, 2, False, "crelu"),
+    ("d3_b4", 4, 8, 512, 1024, 5, 2, False, "crelu"),
+    ("d1_b8", 8, 32, 128, 256, 5, 2, False, "crelu"),
+    ("d3_b8", 8, 8, 512, 1024, 5, 2, False, "crelu"),
+]
+if os.environ.get("OTGAN_STRESS_CASES") == "b4":
+    CASES = B4_CASES
+
+
+_params = {}
 
 
 def run(case, dev):
@@ -26,9 +42,12 @@ def run(case, dev):
     gen = torch.Generator().manual_seed(sum(map(ord, name)))
     mult = 2 if pre == "crelu" else 1
     x = torch.randn(N, H, H, C, generator=gen).to(dev).requires_grad_(True)
-    V = (torch.randn(k, k, C * mult, Cout, generator=gen) * 0.05).to(dev).requires_grad_(True)
-    g = torch.ones(Cout, device=dev, requires_grad=True)
-    b = torch.zeros(Cout, device=dev, requires_grad=True)
+    if name not in _params:      # ONE parameter set per case: the weight cache keeps an entry (and its filters) per V
+        _params.clear()
+        ops._wcache.clear()
+        _params[name] = ((torch.randn(k, k, C * mult, Cout, generator=gen) * 0.05).to(dev).requires_grad_(True),
+                         torch.ones(Cout, device=dev, requires_grad=True), torch.zeros(Cout, device=dev, requires_grad=True))
+    V, g, b = _params[name]
     y = ops.conv2d_op(x, V, g, b, stride=s, upsample=up, preact=ops.ACT[pre])
     dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7)).to(dev)
     dx, dV = torch.autograd.grad(y, [x, V], dy)
