@@ -35,6 +35,55 @@ def _time_steps(model, x, warmup, steps):
     return (time.perf_counter() - t0) / steps
 
 
+def roofline_of(prof, model, ms_per_step_prof, steps, default_cfg):
+    """`roofline` object of the dominant kernel class of a profiled pass (otgan_prof_* HIP-event totals)."""
+    conv = {k: prof[k] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")}
+    dom = max(conv, key=lambda k: conv[k]["ms"])
+    # The Winograd-domain batched GEMM is ONE kernel family serving all three conv classes (its
+    # launches are also counted inside them, together with the transform kernels): when it carries
+    # the step, the roofline is reported for its dominant variant.
+    nested = {k: prof[k]["ms"] for k in ("wino_gemm", "wino_gemm_bf16x3") if k in prof}
+    if nested:
+        top = max(nested, key=nested.get)
+        if nested[top] >= 0.3 * sum(v["ms"] for v in conv.values()):
+            dom = top
+    d = prof[dom]
+    ach = d["flop"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+    # HBM traffic per launch of that kernel class: from the committed rocprofv3 PMC passes
+    # (tools/pmc_bench.sh -> profiles/rNN_pmc_summary_<model>.json), not measurable in-process.
+    traffic, traffic_src = None, None
+    try:
+        if not (default_cfg or model == "densenet"):
+            raise LookupError("no PMC summary for this configuration")
+        for rnd in ("r03", "r02", "r02b", "r01"):          # newest committed PMC summary of this configuration
+            fn = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary_{model}.json")
+            if os.path.exists(fn):
+                with open(fn) as f:
+                    traffic = round(json.load(f)[dom]["hbm_bytes_per_launch"])
+                traffic_src = (f"profiles/{rnd}_pmc_summary_{model}.json: rocprofv3 --pmc passes of this command, "
+                               "committed (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); looked up, not measured in this run")
+                break
+    except Exception:
+        pass
+    kname = {"wino_gemm": "wino_gemm (wino_bgemm_kernel, fp32 MFMA)",
+             "wino_gemm_bf16x3": "wino_gemm_split (wino_bgemm_x3n_kernel 256x128 tile, two workgroups per CU / wino_bgemm_x3_kernel / "
+                                 "wino_bgemm_x3_stream_kernel: split-precision operands, two scaled fp16 pieces, 3 fp16 MFMA per product)"}
+    peak = PEAK_BF16_MFMA_TFLOPS if dom == "wino_gemm_bf16x3" else PEAK_F32_MFMA_TFLOPS
+    r = {"bound": "mfma", "kernel": kname.get(dom, dom), "achieved": round(ach, 2),
+         "peak": peak, "unit": "TFLOP/s",
+         "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+         "launches": d["launches"], "avg_ms": round(d["ms"] / max(d["launches"], 1), 4),
+         "time_share_of_step": round(d["ms"] / (ms_per_step_prof * steps), 4),
+         "pass": f"second pass of {steps} steps with per-launch HIP events "
+                 f"({ms_per_step_prof:.3f} ms/step; the headline pass ran unprofiled)"}
+    if dom == "wino_gemm_bf16x3":
+        # three fp16 MFMAs (hi*hi, hi*lo, lo*hi) evaluate one product of the 22-bit operands: `frac` counts executed
+        # matrix FLOP against the fp16 peak; products per second are fp32_equivalent_tflops
+        r["fp32_equivalent_tflops"] = round(ach / 3.0, 2)
+        r["mfma_per_product"] = 3
+    return r
+
+
 def secondary(dev, a):
     """Driver-timed numbers for the other BASELINE configurations, measured in this process after the headline
     (unprofiled wall clock around whole calls, inputs resident in HBM):
@@ -89,6 +138,16 @@ def secondary(dev, a):
         sec[tag] = {"images_per_sec": round(m.nb / per, 1), "ms_per_step": round(per * 1e3, 2), "img_per_gpu": bpg,
                     "steps": k, "warmup": w, "sinkhorn_iters": args.nr_sinkhorn_iter,
                     "note": "6 timed steps = 1 critic + 5 generator steps (the 5:1 mix), unprofiled wall clock"}
+        if not a.no_prof:
+            # the same six steps once more with per-launch HIP events: the configuration's own roofline object
+            from otgan_amd import _lib
+            _lib.prof_reset()
+            _lib.prof_enable(True)
+            per_prof = _time_steps(m, xs, 0, k)
+            prof = _lib.prof_collect()
+            _lib.prof_enable(False)
+            sec[tag]["roofline"] = roofline_of(prof, kw["model"], per_prof * 1e3, k, False)
+            sec[tag]["launches_per_step"] = round(sum(v["launches"] for c, v in prof.items() if not c.startswith("wino_gemm")) / k, 1)
         m.close()
         del m, xs
         torch.cuda.empty_cache()
@@ -238,49 +297,7 @@ def main():
                                                          "transitions run on the fp32 MFMA engine" if a.model == "densenet" else "")},
     }
     if prof:
-        conv = {k: prof[k] for k in ("conv_fwd", "conv_dgrad", "conv_wgrad")}
-        dom = max(conv, key=lambda k: conv[k]["ms"])
-        # The Winograd-domain batched GEMM is ONE kernel family serving all three conv classes (its
-        # launches are also counted inside them, together with the transform kernels): when it carries
-        # the step, the roofline is reported for its dominant variant.
-        nested = {k: prof[k]["ms"] for k in ("wino_gemm", "wino_gemm_bf16x3") if k in prof}
-        if nested:
-            top = max(nested, key=nested.get)
-            if nested[top] >= 0.3 * sum(v["ms"] for v in conv.values()):
-                dom = top
-        d = prof[dom]
-        ach = d["flop"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-        # HBM traffic per launch of that kernel class: from the committed rocprofv3 PMC passes
-        # (tools/pmc_bench.sh -> profiles/r01_pmc_summary.json), not measurable in-process.
-        traffic, traffic_src = None, None
-        try:
-            if not (default_cfg or a.model == "densenet"):
-                raise LookupError("no PMC summary for this configuration")
-            for rnd in ("r03", "r02", "r02b", "r01"):          # newest committed PMC summary of this configuration
-                fn = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary_{a.model}.json")
-                if os.path.exists(fn):
-                    with open(fn) as f:
-                        traffic = round(json.load(f)[dom]["hbm_bytes_per_launch"])
-                    traffic_src = (f"profiles/{rnd}_pmc_summary_{a.model}.json: rocprofv3 --pmc passes of this command, "
-                                   "committed (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); looked up, not measured in this run")
-                    break
-        except Exception:
-            pass
-        kname = {"wino_gemm": "wino_gemm (wino_bgemm_kernel, fp32 MFMA)",
-                 "wino_gemm_bf16x3": "wino_gemm_split (wino_bgemm_x3_kernel / wino_bgemm_x3_stream_kernel: split-precision operands, two scaled fp16 pieces, 3 fp16 MFMA per product)"}
-        peak = PEAK_BF16_MFMA_TFLOPS if dom == "wino_gemm_bf16x3" else PEAK_F32_MFMA_TFLOPS
-        out["roofline"] = {"bound": "mfma", "kernel": kname.get(dom, dom), "achieved": round(ach, 2),
-                           "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                           "launches": d["launches"], "avg_ms": round(d["ms"] / max(d["launches"], 1), 4),
-                           "pass": f"second pass of {a.steps} steps with per-launch HIP events "
-                                   f"({dt_prof / a.steps * 1e3:.3f} ms/step; the headline pass ran unprofiled)"}
-        if dom == "wino_gemm_bf16x3":
-            # three fp16 MFMAs (hi*hi, hi*lo, lo*hi) evaluate one product of the 22-bit operands; the executed
-            # FLOP per product halved against round 2's three-piece bf16 scheme (six MFMAs), so `frac` of the
-            # matrix-pipe peak is not comparable across the two: products per second are (fp32_equivalent)
-            out["roofline"]["fp32_equivalent_tflops"] = round(ach / 3.0, 2)
-            out["roofline"]["mfma_per_product"] = 3
+        out["roofline"] = roofline_of(prof, a.model, dt_prof / a.steps * 1e3, a.steps, default_cfg)
         out["kernel_classes"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                      "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flop"] > 0 else None}
                                  for k, v in prof.items() if v["launches"]}

@@ -70,6 +70,11 @@ typedef struct otgan_conv_desc {
    * accumulate (the record describes the values this call produced, not the sums in memory). */
   float* y_amax_out;
   float* dx_amax_out;
+  /* Optional, otgan_conv2d_prepare_filters_f32 only: amax record of the NORMALISED weights the filters are made from
+   * (un-folded w / wT: which = 2, 3 of the folded layers, which = 0, 1 of the strided and wide 3x3 layers), e.g. from
+   * otgan_weightnorm_fwd_amax_f32.  NULL = the call reduces the weights itself (one more read of them).  Ignored for
+   * filters made from FOLDED weights (a different tensor). */
+  const float* w_amax;
 } otgan_conv_desc;
 
 /*
@@ -198,6 +203,10 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
  * V, w: [K][Cout] (K = KH*KW*Cin_eff), wT: [Cout][K] (nullable), inv_norm: [Cout].        */
 int otgan_weightnorm_fwd_f32(const float* V, const float* g, int K, int Cout, float* w,
                              float* wT, float* inv_norm, void* stream);
+/* the same, also max-accumulating |w| into an amax record (zeroed by the caller; NULL = none): pass it as
+ * otgan_conv_desc::w_amax to otgan_conv2d_prepare_filters_f32 */
+int otgan_weightnorm_fwd_amax_f32(const float* V, const float* g, int K, int Cout, float* w, float* wT,
+                                  float* inv_norm, float* w_amax, void* stream);
 /* dV, dg from dw (scratch: Cout floats). */
 int otgan_weightnorm_bwd_f32(const float* V, const float* g, const float* inv_norm,
                              const float* dw, int K, int Cout, float* dV, float* dg,

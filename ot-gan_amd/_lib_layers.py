@@ -13,7 +13,7 @@ class ConvDesc(ctypes.Structure):
                 ("Cout", c_int), ("ldy", c_int), ("y_coff", c_int), ("preact", c_int),
                 ("list_quads", c_int), ("x_amax", ctypes.c_void_p), ("dy_amax", ctypes.c_void_p),
                 ("y_accumulate", c_int), ("x_operand", ctypes.c_void_p),
-                ("y_amax_out", ctypes.c_void_p), ("dx_amax_out", ctypes.c_void_p)]
+                ("y_amax_out", ctypes.c_void_p), ("dx_amax_out", ctypes.c_void_p), ("w_amax", ctypes.c_void_p)]
 
 
 P_DESC = ctypes.POINTER(ConvDesc)
@@ -52,6 +52,7 @@ SIGNATURES = {
     "otgan_conv2d_dgrad_pf_f32": (c_int, [P_DESC, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp,
                                           c_size_t, c_fp]),
     "otgan_weightnorm_fwd_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp]),
+    "otgan_weightnorm_fwd_amax_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "otgan_weightnorm_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp]),
     "otgan_weightnorm_fwd_batched16_f32": (c_int, [ctypes.POINTER(WnFwdLayer), c_int, c_fp]),
     "otgan_weightnorm_bwd_batched16_f32": (c_int, [ctypes.POINTER(WnBwdLayer), c_int, c_fp]),

@@ -1615,6 +1615,7 @@ inline WinoGeo wino_geo(const otgan_conv_desc* d) {
   w.N = d->N; w.H = d->H; w.W = d->W; w.Cin = d->C; w.Cout = d->Cout; w.ldx = d->ldx; w.ldy = d->ldy;
   w.y_coff = d->y_coff;
   w.x_amax = d->x_amax; w.dy_amax = d->dy_amax;
+  w.w_amax = d->w_amax;
   return w;
 }
 
@@ -1653,6 +1654,7 @@ inline WinoS2Geo wino_s2_geo(const otgan_conv_desc* d, const Geo& g) {
   w.act = act_kind(d->preact); w.ldx = d->ldx; w.Cout = d->Cout; w.ldy = d->ldy; w.y_coff = d->y_coff;
   w.x_amax = d->x_amax; w.dy_amax = d->dy_amax;
   w.y_amax_out = d->y_amax_out; w.dx_amax_out = d->dx_amax_out;
+  w.w_amax = d->w_amax;
   w.plain = d->stride == 1 ? 1 : 0;
   return w;
 }

@@ -138,10 +138,12 @@ __global__ __launch_bounds__(256) void weightnorm_apply_kernel(const float* __re
                                                                const float* __restrict__ inv,
                                                                int K, int Cout,
                                                                float* __restrict__ w,
-                                                               float* __restrict__ wT) {
+                                                               float* __restrict__ wT,
+                                                               float* __restrict__ rec) {
   __shared__ float tile[32][33];
   const int c0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  unsigned mb = 0u;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int k = k0 + ty + 8 * i, c = c0 + tx;
@@ -151,14 +153,19 @@ __global__ __launch_bounds__(256) void weightnorm_apply_kernel(const float* __re
       w[(long)k * Cout + c] = v;
     }
     tile[ty + 8 * i][tx] = v;
+    const unsigned b = amax_bits(v);
+    mb = b > mb ? b : mb;
   }
-  if (!wT) return;
-  __syncthreads();
+  if (wT) {
+    __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = c0 + ty + 8 * i, k = k0 + tx;
-    if (k < K && c < Cout) wT[(long)c * K + k] = tile[tx][ty + 8 * i];
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + ty + 8 * i, k = k0 + tx;
+      if (k < K && c < Cout) wT[(long)c * K + k] = tile[tx][ty + 8 * i];
+    }
   }
+  // amax record of the normalised weights (the Winograd filter operands are scaled by it: otgan_conv_desc::w_amax)
+  if (rec) amax_commit(rec, mb);
 }
 
 // dV = g*inv*(dw - V*dot*inv^2),  dg = dot*inv,  dot[c] = sum_k dw[k][c] V[k][c]
@@ -474,8 +481,8 @@ __global__ void ema_kernel(float* __restrict__ sh, const float* __restrict__ p, 
 
 extern "C" {
 
-int otgan_weightnorm_fwd_f32(const float* V, const float* g, int K, int Cout, float* w, float* wT,
-                             float* inv_norm, void* stream) {
+int otgan_weightnorm_fwd_amax_f32(const float* V, const float* g, int K, int Cout, float* w, float* wT,
+                                  float* inv_norm, float* w_amax, void* stream) {
   OTGAN_CHECK_ARG(V && g && w && inv_norm && K > 0 && Cout > 0, "bad arguments");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, 4.0 * 3 * (double)K * Cout, s);
@@ -487,9 +494,13 @@ int otgan_weightnorm_fwd_f32(const float* V, const float* g, int K, int Cout, fl
   hipLaunchKernelGGL(colreduce_finish_kernel<1>, dim3(ceil_div(Cout, 64)), dim3(256), 0, s, partial,
                      nchunk, Cout, inv_norm);
   dim3 grid(ceil_div(Cout, 32), ceil_div(K, 32));
-  hipLaunchKernelGGL(weightnorm_apply_kernel, grid, dim3(256), 0, s, V, g, inv_norm, K, Cout, w, wT);
+  hipLaunchKernelGGL(weightnorm_apply_kernel, grid, dim3(256), 0, s, V, g, inv_norm, K, Cout, w, wT, w_amax);
   OTGAN_CHECK_LAUNCH("weightnorm fwd");
   return OTGAN_OK;
+}
+int otgan_weightnorm_fwd_f32(const float* V, const float* g, int K, int Cout, float* w, float* wT, float* inv_norm,
+                             void* stream) {
+  return otgan_weightnorm_fwd_amax_f32(V, g, K, Cout, w, wT, inv_norm, nullptr, stream);
 }
 
 int otgan_weightnorm_bwd_f32(const float* V, const float* g, const float* inv_norm, const float* dw,

@@ -23,6 +23,7 @@ struct WinoGeo {
   // otgan_conv_desc::x_operand: the forward pass leaves its transformed input here (instead of in the workspace) and
   // the weight gradient of the same x reads it instead of transforming x again; null = each pass transforms
   float* x_op = nullptr;
+  const float* w_amax = nullptr;   // otgan_conv_desc::w_amax (filters made from the un-folded weights)
 };
 
 // amax record (otgan_layers.h) of x[rows][C], row stride ld
@@ -63,6 +64,7 @@ struct WinoS2Geo {
   // max-accumulates the magnitudes it writes into record[0]
   float* y_amax_out = nullptr;
   float* dx_amax_out = nullptr;
+  const float* w_amax = nullptr;   // otgan_conv_desc::w_amax
 };
 inline int wino_s2_classes(const WinoS2Geo& g) { return g.plain ? 1 : 4; }
 inline int wino_s2_out_h(const WinoS2Geo& g) { return g.plain ? g.H : g.H / 2; }

@@ -1384,14 +1384,14 @@ int wino_prepare_filters(const WinoGeo& g, int which, const float* w, long cls_s
   const int N4 = 4 * g.Cout;
   if (which == 2) {          // forward filters from the un-folded transposed weights wT[Cout][25*Cin]
     const bool x3 = use_x3() && g.Cin % X3_BK == 0;
-    if (x3) op_scales(w, 1, 25 * g.Cin * g.Cout, 0, out, kGainG, 4.f, false, s);   // a class tap = up to 2 x 2 of the 25
+    if (x3) op_scales(w, 1, 25 * g.Cin * g.Cout, 0, out, kGainG, 4.f, false, s, g.w_amax);   // a class tap = up to 2 x 2 of the 25
     hipLaunchKernelGGL(wino_filter_fwd_unfolded_kernel, dim3(op_grid(N4, g.Cin / 4)), dim3(256), 0, s, w, g.Cin, g.Cout, out,
                        x3 ? op_planes(out) : nullptr);
     return OTGAN_OK;
   }
   if (which == 3) {          // dgrad filters from the un-folded HWIO weights w[25][Cin][Cout]
     const bool x3 = use_x3() && N4 % X3_BK == 0;
-    if (x3) op_scales(w, 1, 25 * g.Cin * g.Cout, 0, out, kGainG, 4.f, false, s);
+    if (x3) op_scales(w, 1, 25 * g.Cin * g.Cout, 0, out, kGainG, 4.f, false, s, g.w_amax);
     hipLaunchKernelGGL(wino_filter_bwd_unfolded_kernel, dim3(op_grid(g.Cin, g.Cout)), dim3(256), 0, s, w, g.Cin, g.Cout, out,
                        x3 ? op_planes(out) : nullptr);
     return OTGAN_OK;
@@ -1674,7 +1674,7 @@ int wino_s2_prepare_filters(const WinoS2Geo& g, int which, const float* w, float
   if (which == 0) {
     const int Kf = s2_kf(g);
     const bool x3 = use_x3() && Kf % X3_BK == 0 && (g.plain || g.Ceff % X3_BK == 0);
-    if (x3) op_scales(w, 1, s2_taps(g) * g.Ceff * g.Cout, 0, out, kGainG, 1.f, false, s);
+    if (x3) op_scales(w, 1, s2_taps(g) * g.Ceff * g.Cout, 0, out, kGainG, 1.f, false, s, g.w_amax);
     hipLaunchKernelGGL(wino_s2_filter_fwd_kernel, dim3(op_grid(g.Cout, s2_k(g) / 4)), dim3(256), 0, s, w, g.Ceff, g.Cout, out,
                        x3 ? op_planes(out) : nullptr, g.plain, x3 ? Kf : s2_k(g));
     if (x3 && Kf > s2_k(g))
@@ -1683,7 +1683,7 @@ int wino_s2_prepare_filters(const WinoS2Geo& g, int which, const float* w, float
   } else {
     const int Kp = s2_kp(g);
     const bool x3 = use_x3() && Kp % X3_BK == 0;
-    if (x3) op_scales(w, 1, s2_taps(g) * g.Ceff * g.Cout, 0, out, kGainG, 1.f, false, s);
+    if (x3) op_scales(w, 1, s2_taps(g) * g.Ceff * g.Cout, 0, out, kGainG, 1.f, false, s, g.w_amax);
     hipLaunchKernelGGL(wino_s2_filter_bwd_kernel, dim3(op_grid(s2_k(g), Kp / 4)), dim3(256), 0, s, w, g.Ceff,
                        g.Cout, out, x3 ? op_planes(out) : nullptr, g.plain, Kp);
   }

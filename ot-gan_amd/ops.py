@@ -124,14 +124,19 @@ def cached_weights(V, g, compute):
 
 # ------------------------------------------------------------------------------- raw launchers
 def weightnorm_fwd(V2d, g):
-    """V2d: [K, Cout] view of the HWIO direction tensor.  Returns (w, wT, inv_norm)."""
+    """V2d: [K, Cout] view of the HWIO direction tensor.  Returns (w, wT, inv_norm); w and wT carry the amax record of
+    the normalised weights (the Winograd filter operands are scaled by it: prepare_filters)."""
     K, Cout = V2d.shape
     w = torch.empty_like(V2d)
     wT = torch.empty((Cout, K), dtype=V2d.dtype, device=V2d.device)
     inv = torch.empty(Cout, dtype=V2d.dtype, device=V2d.device)
-    _lib.check(_lib.lib().otgan_weightnorm_fwd_f32(V2d.data_ptr(), g.data_ptr(), K, Cout,
-                                                   w.data_ptr(), wT.data_ptr(), inv.data_ptr(),
-                                                   _lib.stream_ptr()), "weightnorm_fwd")
+    rec = amax_slot(V2d.device) if _FUSED_AMAX else None
+    _lib.check(_lib.lib().otgan_weightnorm_fwd_amax_f32(V2d.data_ptr(), g.data_ptr(), K, Cout,
+                                                        w.data_ptr(), wT.data_ptr(), inv.data_ptr(), _lib.ptr(rec),
+                                                        _lib.stream_ptr()), "weightnorm_fwd")
+    if rec is not None:
+        tag_amax(w, rec)
+        tag_amax(wT, rec)
     return w, wT, inv
 
 
@@ -255,8 +260,11 @@ def prepare_filters(desc, which, w):
     if not nbytes:
         return None
     buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=w.device)
+    rec = amax_of(w)            # left by weightnorm_fwd on the un-folded w / wT (folded weights are another tensor)
+    desc.w_amax = rec.data_ptr() if rec is not None else None
     _lib.check(L.otgan_conv2d_prepare_filters_f32(ctypes.byref(desc), which, w.data_ptr(), buf.data_ptr(),
                                                   buf.numel() * 4, _lib.stream_ptr()), "prepare_filters")
+    desc.w_amax = None
     return buf
 
 
