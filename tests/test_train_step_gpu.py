@@ -201,22 +201,17 @@ def _named(m):
     return named
 
 
-@pytest.mark.parametrize("model,size", [("dcgan", 32), ("densenet", 32), ("dcgan", 64)])
-@pytest.mark.parametrize("kind", ["disc", "gen"])
-def test_well_conditioned_step_gradients(dev, model, size, kind):
-    """Whole-step numerics in a well-conditioned setting: ELU (no CReLU sign flips), lambda = 20, 10 sweeps
-    (no lambda-amplified cancellation).  EVERY gradient tensor of the step must match the fp64 oracle step to
-    2e-4 .. 1e-3 relative L2 (see the end of the test), distance and entropy to 1e-4 (the loose CReLU /
-    lambda = 100 case above pins wiring only).
-    size = 64 is BASELINE configs[4]'s shape (generator stem 8x8, D = 65536 with ELU)."""
+def _well_conditioned_worst(dev, model, size, kind, seed):
+    """Worst per-tensor relative L2 error of the step's gradients against the fp64 oracle step (+ distance / entropy
+    checks) for one parameter / data seed."""
     from otgan_amd.trainer import OTGAN, default_args
     lam, iters = 20.0, 10
     args = default_args(model=model, batch_size=3, nr_gpu=2, sinkhorn_lambda=lam, nr_sinkhorn_iter=iters,
-                        nr_gen_per_disc=1, seed=5, nonlinearity="elu", image_size=size)
+                        nr_gen_per_disc=1, seed=seed, nonlinearity="elu", image_size=size)
     m = OTGAN(args, dev)
     if kind == "gen":
         m.step_counter = 1
-    gen = torch.Generator().manual_seed(12)
+    gen = torch.Generator().manual_seed(7 + seed)
     x = torch.rand(m.nb, size, size, 3, generator=gen) * 2 - 1
     noise = _noise(model, m.nb, gen)
     to_dev = lambda z: [t.to(dev) for t in z] if isinstance(z, list) else z.to(dev)
@@ -230,18 +225,41 @@ def test_well_conditioned_step_gradients(dev, model, size, kind):
     assert float(r["entropy"]) == pytest.approx(ent, rel=1e-4)
     names = list((m.generator if kind == "gen" else m.discriminator).named_variables())
     worst = max((_rel(a, b), n) for n, a, b in zip(names, r["grads"], gr))
-    # What this probes: the injected gradients f_aa - f_ab are differences of matched feature rows, so every gradient
-    # of the step carries ~100x the relative error of the critic's FORWARD features (measured: PyTorch-CPU fp32 has
-    # 1e-7 features / 5e-6 gradients here; the direct fp32 MFMA engine 1e-6 / 1e-4).  The DCGAN critic runs its 5x5
-    # stride-2 layers in Winograd F(4x4,3x3) form on fp32-exact products -- features 2e-6 .. 5e-6 from fp64, the
-    # accuracy class of fp32 Winograd everywhere (cuDNN / MIOpen use the same transform) -- which puts the critic-step
-    # gradients at 5e-4 (32x32) and the 64x64 ones, whose cancellation is ~4x deeper (D = 65536), at 1e-3.
-    # Generator-step tensors at 32x32 and everything in DenseNet (no Winograd layers) hold 2e-4.
-    if model == "densenet" or (kind == "gen" and size == 32):
-        tol = 2e-4
-    else:
-        tol = 1e-3 if size == 32 else 3e-3
-    assert worst[0] < tol, worst
+    m.close()
+    return worst
+
+
+# measured (round 3, seeds 5 / 6 / 7, worst tensor per seed; pytest -s prints them):
+#   dcgan 32 disc 6.3e-6, 6.2e-4 (one flipped head unit), 6.4e-6     gen 8.2e-6, 7.2e-6, 5.9e-6
+#   densenet disc 5.8e-6, 8.4e-6, 6.3e-6                              gen 4.3e-6, 7.5e-6, 3.6e-6
+#   dcgan 64 disc 1.5e-3 (flipped unit), 6.0e-6, 6.0e-6               gen 1.3e-4 (flipped unit), 7.6e-6, 8.7e-6
+# asserted on the median over seeds = measured median + 25 %
+_WELL_TOL = {("dcgan", 32, "disc"): 8.0e-6, ("dcgan", 32, "gen"): 9.0e-6, ("densenet", 32, "disc"): 8.0e-6,
+             ("densenet", 32, "gen"): 5.5e-6, ("dcgan", 64, "disc"): 7.5e-6, ("dcgan", 64, "gen"): 1.1e-5}
+
+
+@pytest.mark.parametrize("model,size", [("dcgan", 32), ("densenet", 32), ("dcgan", 64)])
+@pytest.mark.parametrize("kind", ["disc", "gen"])
+def test_well_conditioned_step_gradients(dev, model, size, kind):
+    """Whole-step numerics in a well-conditioned setting: ELU, lambda = 20, 10 sweeps (no lambda-amplified
+    cancellation).  EVERY gradient tensor of the step against the fp64 oracle step, distance and entropy to 1e-4.
+    size = 64 is BASELINE configs[4]'s shape (generator stem 8x8, D = 65536 with ELU).
+
+    Round 3: three parameter / data seeds per case.  The MEDIAN over seeds of the worst tensor's error is asserted at
+    what the default engine (Winograd F(4x4,3x3), two scaled fp16 pieces) achieves + 25 % -- 1e-5-class, the level of a
+    plain fp32 evaluation (PyTorch-CPU fp32: 5e-6 on these gradients; tests/test_engine_accuracy_gpu.py puts the four
+    GEMM engines side by side).  Round 2 asserted 1e-3 / 3e-3 here and attributed it to the Winograd transform; the
+    decomposition (tools/debug/step_error_parts.py: features 2-4e-6, matching on fixed features 1e-6, backward on a
+    fixed upstream gradient 2e-6) shows what it really was: the feature head is a CReLU whatever --nonlinearity says
+    (models/dcgan.py:16,19), and ONE of its ~1e5 pre-activations landing on the other side of zero than in fp64 moves
+    every gradient of the step by 2e-4 .. 5e-4 -- a coin flip per engine and seed (the direct engine and the three-piece
+    engine flip the same unit at seed 5, the default and the fp32-Winograd engine do not).  Hence: median tight, and
+    every single seed below the one-flipped-unit level."""
+    worst = [_well_conditioned_worst(dev, model, size, kind, seed) for seed in (5, 6, 7)]
+    print(f"\nwell-conditioned {model} {size} {kind}: worst tensor per seed " + ", ".join(f"{w[0]:.2e} ({w[1]})" for w in worst))
+    errs = sorted(w[0] for w in worst)
+    assert errs[1] < _WELL_TOL[(model, size, kind)], worst
+    assert errs[-1] < 3e-3, worst                 # a flipped head unit: bounded, not tight
 
 
 def test_ema_critic_step_matches_oracle(dev):
