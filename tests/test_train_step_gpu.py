@@ -262,17 +262,14 @@ def test_well_conditioned_step_gradients(dev, model, size, kind):
     assert errs[-1] < 3e-3, worst                 # a flipped head unit: bounded, not tight
 
 
-def test_ema_critic_step_matches_oracle(dev):
-    """--train_disc_against_ema (train.py:102-103,119-123): on a critic step the generated branch is the EMA
-    generator's samples (and its own matching).  After one critic + one generator update the shadows differ
-    from the weights; the next critic step is compared with the oracle fed the same shadows."""
+def _ema_critic_errors(dev, seed):
     from otgan_amd.trainer import OTGAN, default_args
     lam, iters = 20.0, 10
     args = default_args(model="dcgan", batch_size=3, nr_gpu=2, sinkhorn_lambda=lam, nr_sinkhorn_iter=iters,
-                        nr_gen_per_disc=1, seed=8, nonlinearity="elu", train_disc_against_ema=True,
+                        nr_gen_per_disc=1, seed=seed, nonlinearity="elu", train_disc_against_ema=True,
                         learning_rate_gen=0.05)       # large step: shadows and weights clearly apart
     m = OTGAN(args, dev)
-    gen = torch.Generator().manual_seed(13)
+    gen = torch.Generator().manual_seed(5 + seed)
     x = (torch.rand(m.nb, 32, 32, 3, generator=gen) * 2 - 1).to(dev)
     u = (torch.rand(m.nb, 100, generator=gen) * 2 - 1).to(dev)
     m.step(x, noise=u)        # critic update
@@ -288,20 +285,30 @@ def test_ema_critic_step_matches_oracle(dev):
     gr, dist, ent = o.grads("disc", x.double().cpu(), u.double().cpu(), 2, lam, iters, ema_P=o.ema_params(shadow))
     assert float(r["distance"]) == pytest.approx(dist, rel=1e-4, abs=1e-7)
     assert float(r["entropy"]) == pytest.approx(ent, rel=1e-4)
-    names = list(m.discriminator.named_variables())
-    # The feature head is a CReLU whatever --nonlinearity says (models/dcgan.py:16,19): its backward switches between
-    # two unrelated gradient entries where a pre-activation changes sign, so ONE of the 6 x 16384 final pre-activations
-    # landing on the other side of zero than in the fp64 oracle moves every critic gradient by ~1e-3 (measured: the
-    # same weights give 6e-6 or 1.3e-3 depending on the summation order of one GEMM upstream, tools/debug/ema_cache.py;
-    # and which weights the two Adam steps of size 0.05 above arrive at depends on the last bit of the gradients).
-    # The tight step-level parity lives in the well-conditioned cases above; this test pins the BRANCH: the gradients
-    # must be those of the EMA generator's samples, far closer to them than to the live generator's.
     gr_live, dist_live, _ = o.grads("disc", x.double().cpu(), u.double().cpu(), 2, lam, iters)
-    for n, a, b, c in zip(names, r["grads"], gr, gr_live):
-        e_ema, e_live = _rel(a, b), _rel(a, c)
-        assert e_ema < 5e-3 and e_live > 20 * e_ema, (n, e_ema, e_live)
-    # and it is NOT what the live generator would give
-    assert abs(dist_live - dist) > 1e-3 * abs(dist)
+    assert abs(dist_live - dist) > 1e-3 * abs(dist)                  # NOT what the live generator would give
+    e_ema = max(_rel(a, b) for a, b in zip(r["grads"], gr))
+    e_live = min(_rel(a, c) for a, c in zip(r["grads"], gr_live))
+    m.close()
+    return e_ema, e_live
+
+
+def test_ema_critic_step_matches_oracle(dev):
+    """--train_disc_against_ema (train.py:102-103,119-123): on a critic step the generated branch is the EMA
+    generator's samples (and its own matching).  After one critic + one generator update the shadows differ
+    from the weights; the next critic step is compared with the oracle fed the same shadows.
+
+    Round 3: three seeds.  A seed may carry a flipped CReLU unit of the feature head (models/dcgan.py:16,19: every
+    gradient of that step then moves by ~1e-3 -- round 2 asserted 5e-3 for everything because of it; after the two
+    updates of size 0.05 this happens more often than at initialisation: measured 6.1e-6, 2.6e-3, 1.4e-3).  Every seed is
+    bounded at that level and pins the BRANCH (the gradients are those of the EMA generator's samples, at least 20 x
+    closer to them than to the live generator's); the BEST seed must reach the accuracy of the well-conditioned step
+    above (measured + 25 %), which is what the arithmetic of this branch delivers when no unit flips."""
+    res = [_ema_critic_errors(dev, seed) for seed in (8, 9, 10)]
+    print("\nEMA critic step: (worst error vs EMA oracle, closest vs live oracle) per seed:", [(f"{a:.2e}", f"{b:.2e}") for a, b in res])
+    for e_ema, e_live in res:
+        assert e_ema < 5e-3 and e_live > 20 * e_ema, res
+    assert min(e for e, _ in res) < 7.7e-6, res
 
 
 @pytest.mark.parametrize("opt", ["adamax", "nesterov"])
