@@ -24,22 +24,42 @@ IGEMM_CASES = [
 ]
 
 
+def case_tensors(name, N, H, C, Cout, k, pre, out_shape=None):
+    """(x0, V0, dy) of a case.  OTGAN_WORKER_DATA=step: operands shaped like the tensors of a real training step instead
+    of Gaussians -- x = a * sigmoid(b) of wide Gaussians (what a GLU hands the next layer: heavy tail, most values near
+    zero), dy = log-normally spread gradients around 1e-6 (the critic's last layers see 1e-7 .. 1e-5) with ONE element
+    3e4 times the typical magnitude."""
+    gen = torch.Generator().manual_seed(sum(map(ord, name)))
+    mult = 2 if pre == "crelu" else 1
+    real = os.environ.get("OTGAN_WORKER_DATA") == "step"
+    if real:
+        x0 = (torch.randn(N, H, H, C, generator=gen) * 3) * torch.sigmoid(torch.randn(N, H, H, C, generator=gen) * 3)
+    else:
+        x0 = torch.randn(N, H, H, C, generator=gen)
+    V0 = torch.randn(k, k, C * mult, Cout, generator=gen) * 0.05
+    dy = None
+    if out_shape is not None:
+        g7 = torch.Generator().manual_seed(7)
+        dy = torch.randn(out_shape, generator=g7)
+        if real:
+            dy = dy * torch.exp(2.0 * torch.randn(out_shape, generator=g7)) * 1e-6
+            dy.view(-1)[dy.numel() // 3] = 3e-2
+    return x0, V0, dy
+
+
 def main(out):
     dev = torch.device("cuda:0")
     _lib.lib()
     res = {}
     for name, N, H, C, Cout, k, s, up, pre in (IGEMM_CASES if os.environ.get("OTGAN_WORKER_CASES") == "igemm" else CASES):
-        gen = torch.Generator().manual_seed(sum(map(ord, name)))
-        mult = 2 if pre == "crelu" else 1
-        x0 = torch.randn(N, H, H, C, generator=gen)
-        V0 = torch.randn(k, k, C * mult, Cout, generator=gen) * 0.05
+        x0, V0, _ = case_tensors(name, N, H, C, Cout, k, pre)
         for rep in range(2):
             x = x0.to(dev).requires_grad_(True)
             V = V0.to(dev).requires_grad_(True)
             g = torch.ones(Cout, device=dev, requires_grad=True)
             b = torch.zeros(Cout, device=dev, requires_grad=True)
             y = ops.conv2d_op(x, V, g, b, stride=s, upsample=up, preact=ops.ACT[pre])
-            dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7)).to(dev)
+            dy = case_tensors(name, N, H, C, Cout, k, pre, tuple(y.shape))[2].to(dev)
             dx, dV = torch.autograd.grad(y, [x, V], dy)
             for tag, t in (("y", y), ("dx", dx), ("dV", dV)):
                 res[f"{name}.{tag}.{rep}"] = t.detach().cpu().numpy()

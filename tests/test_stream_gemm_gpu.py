@@ -61,34 +61,44 @@ def test_three_bf16_pieces_build(tmp_path):
         assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-5, n
 
 
-def test_split_engines_are_no_worse_than_the_fp32_mfma_engine(tmp_path):
+@pytest.mark.parametrize("data", ["gaussian", "step"])
+def test_split_engines_are_no_worse_than_the_fp32_mfma_engine(tmp_path, data):
     """The precision claim of the convolution GEMMs, measured: against an fp64 evaluation of the same layers the
     default engine (two scaled fp16 pieces, 22 significand bits, three MFMAs per product) and the three-piece bf16
     engine (24 bits, six MFMAs) are at least as close as the SAME Winograd GEMMs executed with fp32 operands on the
-    fp32 MFMA pipe (OTGAN_WINO_FP32=1) -- their fp32 accumulation, not the operand split, sets the error."""
+    fp32 MFMA pipe (OTGAN_WINO_FP32=1) -- their fp32 accumulation, not the operand split, sets the error.
+    data = "step" (round 3): operands shaped like those of a real step -- post-GLU activations (heavy tail, mass near
+    zero), log-normally spread gradients around 1e-6 with one element 3e4 x the typical magnitude -- i.e. the dynamic
+    range the per-frequency scales of the fp16 pieces have to survive, on the device, not in a NumPy model."""
     import sys
     import torch
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
     import nets_torch as NT
     from stream_gemm_worker import CASES
-    runs = {"fp16x2": _run(1, tmp_path / "a.npz"), "bf16x3": _run(1, tmp_path / "b.npz", OTGAN_WINO_PIECES="3"),
-            "fp32": _run(1, tmp_path / "c.npz", OTGAN_WINO_FP32="1")}
-    for name, N, H, C, Cout, k, s, up, pre in CASES:
-        gen = torch.Generator().manual_seed(sum(map(ord, name)))
-        mult = 2 if pre == "crelu" else 1
-        x = torch.randn(N, H, H, C, generator=gen).double().requires_grad_(True)
-        V = (torch.randn(k, k, C * mult, Cout, generator=gen) * 0.05).double().requires_grad_(True)
-        g = torch.ones(Cout, dtype=torch.float64)
-        b = torch.zeros(Cout, dtype=torch.float64)
-        y = NT.conv2d([x], {"V": V, "g": g, "b": b}, pre, s, up)
-        dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7)).double()
-        dx, dV = torch.autograd.grad(y, [x, V], dy)
-        for tag, ref in (("y", y), ("dx", dx), ("dV", dV)):
-            ref = ref.detach().numpy()
-            err = {e: float(np.linalg.norm(r[f"{name}.{tag}.0"] - ref) / np.linalg.norm(ref)) for e, r in runs.items()}
-            assert err["fp16x2"] < 2e-5 and err["bf16x3"] < 2e-5, (name, tag, err)
-            assert err["fp16x2"] <= 1.25 * err["fp32"] + 1e-7, (name, tag, err)
-            assert err["bf16x3"] <= 1.25 * err["fp32"] + 1e-7, (name, tag, err)
+    os.environ["OTGAN_WORKER_DATA"] = data
+    try:
+        from stream_gemm_worker import case_tensors
+        extra = {"OTGAN_WORKER_DATA": data}
+        runs = {"fp16x2": _run(1, tmp_path / "a.npz", **extra), "bf16x3": _run(1, tmp_path / "b.npz", OTGAN_WINO_PIECES="3", **extra),
+                "fp32": _run(1, tmp_path / "c.npz", OTGAN_WINO_FP32="1", **extra)}
+        for name, N, H, C, Cout, k, s, up, pre in CASES:
+            x0, V0, _ = case_tensors(name, N, H, C, Cout, k, pre)
+            x = x0.double().requires_grad_(True)
+            V = V0.double().requires_grad_(True)
+            g = torch.ones(Cout, dtype=torch.float64)
+            b = torch.zeros(Cout, dtype=torch.float64)
+            y = NT.conv2d([x], {"V": V, "g": g, "b": b}, pre, s, up)
+            dy = case_tensors(name, N, H, C, Cout, k, pre, tuple(y.shape))[2].double()
+            dx, dV = torch.autograd.grad(y, [x, V], dy)
+            for tag, ref in (("y", y), ("dx", dx), ("dV", dV)):
+                ref = ref.detach().numpy()
+                err = {e: float(np.linalg.norm(r[f"{name}.{tag}.0"] - ref) / np.linalg.norm(ref)) for e, r in runs.items()}
+                print(f"{data:8s} {name:10s} {tag:3s} " + "  ".join(f"{e} {v:.2e}" for e, v in err.items()))
+                assert err["fp16x2"] < 2e-5 and err["bf16x3"] < 2e-5, (name, tag, err)
+                assert err["fp16x2"] <= 1.25 * err["fp32"] + 1e-7, (name, tag, err)
+                assert err["bf16x3"] <= 1.25 * err["fp32"] + 1e-7, (name, tag, err)
+    finally:
+        os.environ.pop("OTGAN_WORKER_DATA", None)
 
 
 def test_igemm_split_loop_is_no_worse_than_the_fp32_loop(tmp_path):
