@@ -283,6 +283,15 @@ int otgan_feature_head_bwd_amax_f32(const float* x, const float* f, const float*
  * Python doubles before they become fp32 graph constants.                                  */
 int otgan_adam_step_f32(float* p, const float* grad, float* v, float* mg, long n, double lr,
                         double mom1, double mom2, double t, void* stream);
+/* The same step over a FLAT parameter buffer p whose gradient comes as one device tensor per variable (what the
+ * backward pass returns): variable i owns p[offsets[i] .. offsets[i+1]) and reads grads[i][0 ..]; `grads` and `offsets`
+ * (nseg + 1 entries, ascending) are HOST arrays, nseg <= OTGAN_ADAM_MAX_SEGMENTS.  No concatenation of the gradients
+ * (151 MB per DCGAN generator step).  ema_shadow (nullable, same layout as p): shadow = ema_decay * shadow +
+ * (1 - ema_decay) * p_new in the same pass (train.py:63-64,223). */
+#define OTGAN_ADAM_MAX_SEGMENTS 32
+int otgan_adam_step_gather_f32(float* p, const float* const* grads, const long* offsets, int nseg, float* v, float* mg,
+                               double lr, double mom1, double mom2, double t, float* ema_shadow, double ema_decay,
+                               void* stream);
 int otgan_adamax_step_f32(float* p, const float* grad, float* v, float* mg, long n, double lr,
                           double mom1, double mom2, void* stream);
 int otgan_nesterov_step_f32(float* p, const float* grad, float* v, long n, double lr, double mom1,

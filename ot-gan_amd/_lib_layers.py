@@ -68,6 +68,8 @@ SIGNATURES = {
     "otgan_feature_head_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp]),
     "otgan_adam_step_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_long, c_double, c_double, c_double,
                                     c_double, c_fp]),
+    "otgan_adam_step_gather_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_double, c_double, c_double, c_double,
+                                           c_fp, c_double, c_fp]),
     "otgan_adamax_step_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_long, c_double, c_double, c_double, c_fp]),
     "otgan_nesterov_step_f32": (c_int, [c_fp, c_fp, c_fp, c_long, c_double, c_double, c_fp]),
     "otgan_ema_update_f32": (c_int, [c_fp, c_fp, c_long, c_double, c_fp]),

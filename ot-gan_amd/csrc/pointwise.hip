@@ -428,24 +428,36 @@ __global__ __launch_bounds__(256) void feature_head_bwd_kernel(const float* __re
 }
 
 // ---- optimisers / EMA ----------------------------------------------------------------------------
+// one element of the reference's Adam (nn.py:61-69): returns the updated parameter.  Shared by both kernels so that
+// they round identically (fp contraction is decided per expression tree).
+__device__ __forceinline__ float adam_elem(float p, float gi, float* __restrict__ v, float* __restrict__ mg, long j, float lr,
+                                           float mom1, float om1, float mom2, float om2, float c1, float c2) {
+  // no fused multiply-adds here: which product of `a * b + c * d` keeps its rounding is the compiler's choice per
+  // kernel, and the two kernels (and the reference's TensorFlow CPU graph, which has none) must agree bit for bit
+#pragma clang fp contract(off)
+  float vhat;
+  if (mom1 > 0.f) {
+    const float vt = mom1 * v[j] + om1 * gi;            // nn.py:61
+    v[j] = vt;
+    vhat = vt / c1;                                     // nn.py:62
+  } else {
+    vhat = gi;
+  }
+  const float mgt = mom2 * mg[j] + om2 * gi * gi;           // nn.py:66
+  mg[j] = mgt;
+  const float mghat = mgt / c2;                              // nn.py:67
+  const float step = lr * (vhat / sqrtf(mghat + 1e-8f));     // nn.py:68-69 (eps inside sqrt)
+  return p - step;
+}
+__device__ __forceinline__ float ema_elem(float sh, float p, float decay, float omd) {
+#pragma clang fp contract(off)
+  return decay * sh + omd * p;
+}
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ v,
                             float* __restrict__ mg, long n, float lr, float mom1, float om1,
                             float mom2, float om2, float c1, float c2) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float gi = g[i];
-    float vhat;
-    if (mom1 > 0.f) {
-      const float vt = mom1 * v[i] + om1 * gi;            // nn.py:61
-      v[i] = vt;
-      vhat = vt / c1;                                     // nn.py:62
-    } else {
-      vhat = gi;
-    }
-    const float mgt = mom2 * mg[i] + om2 * gi * gi;           // nn.py:66
-    mg[i] = mgt;
-    const float mghat = mgt / c2;                              // nn.py:67
-    p[i] -= lr * (vhat / sqrtf(mghat + 1e-8f));                // nn.py:68-69 (eps inside sqrt)
-  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    p[i] = adam_elem(p[i], g[i], v, mg, i, lr, mom1, om1, mom2, om2, c1, c2);
 }
 __global__ void adamax_kernel(float* __restrict__ p, const float* __restrict__ g,
                               float* __restrict__ v, float* __restrict__ mg, long n, float lr,
@@ -471,10 +483,31 @@ __global__ void nesterov_kernel(float* __restrict__ p, const float* __restrict__
     v[i] = vn;
   }
 }
+// Adam over a flat parameter buffer whose gradient arrives as one tensor per variable (what autograd returns): blockIdx.y
+// = variable, so no thread ever searches for its segment; same arithmetic, element by element, as adam_kernel.  With
+// `sh` the EMA of the updated parameters (train.py:63-64,223: shadow <- decay * shadow + (1 - decay) * p) rides along:
+// one read of p less than a separate pass, one launch less.
+struct AdamSegs {
+  const float* g[OTGAN_ADAM_MAX_SEGMENTS];
+  long off[OTGAN_ADAM_MAX_SEGMENTS + 1];
+};
+__global__ void adam_gather_kernel(float* __restrict__ p, AdamSegs segs, float* __restrict__ v, float* __restrict__ mg,
+                                   float lr, float mom1, float om1, float mom2, float om2, float c1, float c2,
+                                   float* __restrict__ sh, float decay, float omd) {
+  const int seg = blockIdx.y;
+  const long base = segs.off[seg], n = segs.off[seg + 1] - base;
+  const float* __restrict__ g = segs.g[seg];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long j = base + i;
+    const float pn = adam_elem(p[j], g[i], v, mg, j, lr, mom1, om1, mom2, om2, c1, c2);
+    p[j] = pn;
+    if (sh) sh[j] = ema_elem(sh[j], pn, decay, omd);
+  }
+}
 __global__ void ema_kernel(float* __restrict__ sh, const float* __restrict__ p, long n, float decay,
                            float omd) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    sh[i] = decay * sh[i] + omd * p[i];
+    sh[i] = ema_elem(sh[i], p[i], decay, omd);
 }
 
 }  // namespace
@@ -669,6 +702,31 @@ int otgan_adam_step_f32(float* p, const float* grad, float* v, float* mg, long n
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, grad, v, mg, n, (float)lr,
                      (float)mom1, (float)(1.0 - mom1), (float)mom2, (float)(1.0 - mom2), c1, c2);
   OTGAN_CHECK_LAUNCH("adam");
+  return OTGAN_OK;
+}
+int otgan_adam_step_gather_f32(float* p, const float* const* grads, const long* offsets, int nseg, float* v, float* mg,
+                               double lr, double mom1, double mom2, double t, float* ema_shadow, double ema_decay,
+                               void* stream) {
+  OTGAN_CHECK_ARG(p && grads && offsets && mg && nseg > 0 && nseg <= OTGAN_ADAM_MAX_SEGMENTS && t >= 1.0 && (mom1 <= 0.0 || v),
+                  "bad arguments (at most %d segments)", OTGAN_ADAM_MAX_SEGMENTS);
+  hipStream_t s = (hipStream_t)stream;
+  AdamSegs segs;
+  memset(&segs, 0, sizeof(segs));
+  long longest = 0;
+  for (int i = 0; i < nseg; ++i) {
+    OTGAN_CHECK_ARG(grads[i] && offsets[i + 1] > offsets[i], "segment %d: null gradient or empty range", i);
+    segs.g[i] = grads[i];
+    segs.off[i] = offsets[i];
+    if (offsets[i + 1] - offsets[i] > longest) longest = offsets[i + 1] - offsets[i];
+  }
+  segs.off[nseg] = offsets[nseg];
+  const long n = offsets[nseg] - offsets[0];
+  ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, 4.0 * (ema_shadow ? 9 : 7) * (double)n, s);
+  const float c1 = 1.f - powf((float)mom1, (float)t), c2 = 1.f - powf((float)mom2, (float)t);   // (see otgan_adam_step_f32)
+  hipLaunchKernelGGL(adam_gather_kernel, dim3(grid_for(longest), nseg), dim3(256), 0, s, p, segs, v, mg, (float)lr,
+                     (float)mom1, (float)(1.0 - mom1), (float)mom2, (float)(1.0 - mom2), c1, c2, ema_shadow,
+                     (float)ema_decay, (float)(1.0 - ema_decay));
+  OTGAN_CHECK_LAUNCH("adam (gathered gradients)");
   return OTGAN_OK;
 }
 int otgan_adamax_step_f32(float* p, const float* grad, float* v, float* mg, long n, double lr,

@@ -927,6 +927,24 @@ def adam_step(p, grad, v, mg, lr, mom1, mom2, t):
                                               float(t), _lib.stream_ptr()), "adam_step")
 
 
+ADAM_MAX_SEGMENTS = 32      # otgan_layers.h: OTGAN_ADAM_MAX_SEGMENTS
+
+
+def adam_step_gather(p_flat, grads, offsets, v, mg, lr, mom1, mom2, t, ema_shadow=None, ema_decay=0.0):
+    """Adam on a flat parameter buffer from per-variable gradient tensors (no concatenation); optionally the EMA of the
+    updated parameters in the same launch (otgan_adam_step_gather_f32)."""
+    n = len(grads)
+    bump_weights_epoch(p_flat)
+    if ema_shadow is not None:
+        bump_weights_epoch(ema_shadow)
+    gp = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads])
+    off = (ctypes.c_long * (n + 1))(*offsets)
+    _lib.check(_lib.lib().otgan_adam_step_gather_f32(p_flat.data_ptr(), ctypes.cast(gp, ctypes.c_void_p),
+                                                     ctypes.cast(off, ctypes.c_void_p), n, _lib.ptr(v), mg.data_ptr(),
+                                                     float(lr), float(mom1), float(mom2), float(t), _lib.ptr(ema_shadow),
+                                                     float(ema_decay), _lib.stream_ptr()), "adam_step_gather")
+
+
 def adamax_step(p, grad, v, mg, lr, mom1, mom2):
     bump_weights_epoch(p)
     _lib.check(_lib.lib().otgan_adamax_step_f32(p.data_ptr(), grad.data_ptr(), _lib.ptr(v),

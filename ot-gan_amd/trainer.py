@@ -103,6 +103,8 @@ class OTGAN:
         self.gen_buckets = parallel.GradBuckets(self.gen_params) if overlap else None
         self.gen_optimizer = mk[args.optimizer](self.gen_params, **kw)          # train.py:142
         self.disc_optimizer = mk[args.optimizer](self.disc_params, **kw)        # train.py:143
+        # the generator's Adam step can carry the EMA of the updated weights along (one launch, one read of p less)
+        self.ema_fused = self.gen_optimizer.fuse_ema(self.ema)
         self.step_counter = 0
         self.last = {}
 
@@ -211,7 +213,8 @@ class OTGAN:
                      else parallel.allreduce_sum_(list(grads)))
             if apply_updates:
                 self.gen_optimizer(grads, lr=a.learning_rate_gen)                                 # train.py:142
-                self.maintain_averages()                                                          # train.py:223
+                if not self.ema_fused:
+                    self.maintain_averages()                                                      # train.py:223
         self.step_counter += 1
         self.last = {"kind": kind, "distance": dist, "entropy": ent}      # device scalars, no sync
         if not apply_updates:

@@ -13,6 +13,7 @@ reference's *effective* initialisation (the data-dependent init te
 nn.py:133-162 are built but never run by train.py, so V ~ N(0, 0.05), g = 1, b = 0).
 """
 import contextlib
+import os
 import threading
 from collections import OrderedDict
 
@@ -121,6 +122,19 @@ class FlatGroup:
             return None
         ids = {id(p) for p in params}
         return grp if all(id(p) in ids for p in grp.params) else None
+
+    def offsets(self):
+        """Start of every member inside the flat buffer, in buffer order, plus the total."""
+        out, off = [], 0
+        for p in self.params:
+            out.append(off)
+            off += p.numel()
+        return out + [off]
+
+    def in_buffer_order(self, tensors, params):
+        """Per-parameter tensors (given in the order of `params`) re-ordered to buffer order, contiguous."""
+        pos = {id(p): i for i, p in enumerate(params)}
+        return [tensors[pos[id(p)]].contiguous() for p in self.params]
 
     def flatten_like(self, tensors, params):
         """Concatenate per-parameter tensors (given in the order of `params`) in buffer order."""
@@ -397,10 +411,17 @@ class _Updates:
         self.state = [{}] if self.group is not None else [{} for _ in self.params]
         self.t = 1.0
 
+    def fuse_ema(self, ema):
+        """Let the step also update `ema`'s shadows of these parameters (same launch).  True if it will; the caller then
+        skips ema.update().  Only the flat-buffer Adam takes it."""
+        return False
+
     def __call__(self, grads, lr=None):
         lr = self.lr if lr is None else lr
         with torch.no_grad():
-            if self.group is not None:      # the update is elementwise: run it on the flat buffer
+            if self.group is not None and self._step_gather(list(grads), lr):
+                pass                        # one launch straight from the per-variable gradient tensors
+            elif self.group is not None:    # the update is elementwise: run it on the flat buffer
                 self._step(self.group.flat, self.group.flatten_like(list(grads), self.params), self.state[0], lr)
             else:
                 for p, g, st in zip(self.params, grads, self.state):
@@ -423,7 +444,35 @@ class _Updates:
                 st[k] = None if v is None else v.to(p.device).clone()
 
 
+    def _step_gather(self, grads, lr):
+        return False
+
+
 class _Adam(_Updates):
+    _ema = None
+
+    def fuse_ema(self, ema):
+        flat = getattr(ema, "_flat", None)
+        if self.group is None or flat is None or flat[1] is not self.group or len(self.params) > ops.ADAM_MAX_SEGMENTS:
+            return False
+        self._ema = ema
+        return True
+
+    def _step_gather(self, grads, lr):
+        if len(self.params) > ops.ADAM_MAX_SEGMENTS or os.environ.get("OTGAN_ADAM_GATHER", "1") == "0":
+            if self._ema is not None:       # (the caller was told the shadows are ours)
+                raise RuntimeError("fused EMA needs the gathered Adam step")
+            return False
+        st, p = self.state[0], self.group.flat
+        if not st:
+            st["mg"] = torch.zeros_like(p)
+            st["v"] = torch.zeros_like(p) if self.mom1 > 0 else None
+        ema = self._ema
+        ops.adam_step_gather(p, self.group.in_buffer_order(grads, self.params), self.group.offsets(), st["v"], st["mg"],
+                             lr, self.mom1, self.mom2, self.t,
+                             ema._flat[0] if ema is not None else None, ema.decay if ema is not None else 0.0)
+        return True
+
     def _step(self, p, g, st, lr):
         if not st:
             st["mg"] = torch.zeros_like(p)

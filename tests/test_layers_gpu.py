@@ -579,3 +579,35 @@ def test_shared_x_operand(dev, case):
         cmap, _ = ops.channel_maps((C // 2, C // 2), ops.ACT[pre], dev)
         with pytest.raises(_lib.OtganError):
             ops.conv_fwd_raw(desc, x, cmap, wT, b, torch.empty(N, OH, OW, Cout, device=dev))
+
+
+def test_adam_gathered_gradients_and_fused_ema(dev):
+    """otgan_adam_step_gather_f32: the flat-buffer Adam step reading one gradient tensor per variable, with the EMA of
+    the updated weights in the same launch, is BIT-IDENTICAL to concatenating the gradients, otgan_adam_step_f32 and
+    otgan_ema_update_f32 (nn.py:50-73, train.py:63-64,223)."""
+    from otgan_amd import ops
+    g = torch.Generator().manual_seed(21)
+    sizes = [(5, 5, 8, 16), (16,), (16,), (100, 64), (3,), (3,)]
+    offs = [0]
+    for sz in sizes:
+        offs.append(offs[-1] + int(np.prod(sz)))
+    n = offs[-1]
+    p0 = torch.randn(n, generator=g).to(dev)
+    grads = [torch.randn(sz, generator=g).to(dev) * 10 ** float(torch.randn((), generator=g)) for sz in sizes]
+    for mom1 in (0.5, 0.0):
+        pa, pb = p0.clone(), p0.clone()
+        va = torch.zeros(n, device=dev) if mom1 > 0 else None
+        vb = torch.zeros(n, device=dev) if mom1 > 0 else None
+        mga, mgb = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        sha, shb = p0.clone(), p0.clone()
+        for t in (1.0, 2.0, 3.0):
+            ops.adam_step_gather(pa, grads, offs, va, mga, 3e-4, mom1, 0.999, t, sha, 0.999)
+            ops.adam_step(pb, torch.cat([x.reshape(-1) for x in grads]), vb, mgb, 3e-4, mom1, 0.999, t)
+            ops.ema_update(shb, pb, 0.999)
+        assert torch.equal(mga, mgb), float((mga - mgb).abs().max())
+        if mom1 > 0:
+            assert torch.equal(va, vb), float((va - vb).abs().max())
+        assert torch.equal(pa, pb), (float((pa - pb).abs().max()), int((pa != pb).sum()))
+        assert torch.equal(sha, shb), (float((sha - shb).abs().max()), int((sha != shb).sum()))
+    with pytest.raises(Exception):
+        ops.adam_step_gather(pa, grads * 6, list(range(37)), va, mga, 3e-4, 0.5, 0.999, 1.0)     # > 32 segments
