@@ -11,7 +11,7 @@ def cls_of(name):
         return "conv_fwd" if m.group(2) == "0" else "conv_dgrad"
     if "conv_fewout_kernel" in name:
         return "conv_fewout(fwd|dgrad)"
-    if "wino_bgemm_x3_kernel" in name or "wino_bgemm_x3_stream_kernel" in name:
+    if "wino_bgemm_x3_kernel" in name or "wino_bgemm_x3n_kernel" in name or "wino_bgemm_x3_stream_kernel" in name:
         return "wino_gemm_bf16x3"
     if "wino_bgemm_kernel" in name:
         return "wino_gemm"

@@ -10,7 +10,7 @@ def cls_of(name):
     m = re.search(r"conv_igemm_kernel<GemmCfg<[^>]*>, (true|false), (\d), (\d)>", name)
     if m:
         return "conv_fwd" if m.group(2) == "0" else "conv_dgrad"
-    if "wino_bgemm_x3_kernel" in name or "wino_bgemm_x3_stream_kernel" in name:
+    if "wino_bgemm_x3_kernel" in name or "wino_bgemm_x3n_kernel" in name or "wino_bgemm_x3_stream_kernel" in name:
         return "wino_gemm_bf16x3"
     if "wino_bgemm_kernel" in name:
         return "wino_gemm"
