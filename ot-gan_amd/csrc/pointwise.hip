@@ -371,6 +371,79 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
   return s;
 }
 
+// one block per sample: norm = sqrt(sum x^2) (= ||[relu(x), relu(-x)]||); f = crelu(x)/norm.
+// Round 3: float4 walks with the whole block's loads in flight (the scalar one-element-per-thread loops of rounds 1-2
+// reached 1.4 TB/s: a sample is only 64 KB, so what counts is how many bytes a block has outstanding); C % 4 == 0
+// and 16-byte aligned tensors, else the scalar kernels below.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void feature_head_fwd4_kernel(const float* __restrict__ x, int HW, int C4,
+                                                                    float* __restrict__ f, float* __restrict__ norm) {
+  __shared__ double red[THREADS / 64];
+  const int n = blockIdx.x;
+  const long per4 = (long)HW * C4;
+  const f32x4* xp = reinterpret_cast<const f32x4*>(x) + n * per4;
+  double s = 0;
+  for (long i = threadIdx.x; i < per4; i += THREADS) {
+    const f32x4 v = xp[i];
+    s += (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
+  }
+  s = block_sum_d(s, red);
+  const float nrm = (float)sqrt(s);
+  if (threadIdx.x == 0) norm[n] = nrm;
+  f32x4* fp = reinterpret_cast<f32x4*>(f) + n * per4 * 2;
+  for (long i = threadIdx.x; i < per4; i += THREADS) {
+    const long p = i / C4;
+    const long c = i - p * C4;
+    const f32x4 v = xp[i];          // (second read: L2)
+    f32x4 a, b;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      a[k] = fmaxf(v[k], 0.f) / nrm;        // models/dcgan.py:16,19 (no epsilon)
+      b[k] = fmaxf(-v[k], 0.f) / nrm;
+    }
+    fp[p * 2 * C4 + c] = a;
+    fp[p * 2 * C4 + C4 + c] = b;
+  }
+}
+// du = (df - f (f.df)) / norm ;  dx = du[+] * [x>0] - du[-] * [x<0]
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void feature_head_bwd4_kernel(const float* __restrict__ x, const float* __restrict__ f,
+                                                                    const float* __restrict__ norm, const float* __restrict__ df,
+                                                                    int HW, int C4, float* __restrict__ dx, float* __restrict__ rec) {
+  __shared__ double red[THREADS / 64];
+  const int n = blockIdx.x;
+  const long per4 = (long)HW * C4;
+  const f32x4* fp = reinterpret_cast<const f32x4*>(f) + n * per4 * 2;
+  const f32x4* dfp = reinterpret_cast<const f32x4*>(df) + n * per4 * 2;
+  double s = 0;
+  for (long i = threadIdx.x; i < 2 * per4; i += THREADS) {
+    const f32x4 a = fp[i], b = dfp[i];
+    s += (double)a[0] * b[0] + (double)a[1] * b[1] + (double)a[2] * b[2] + (double)a[3] * b[3];
+  }
+  s = block_sum_d(s, red);
+  const float dot = (float)s, inv = 1.f / norm[n];
+  const f32x4* xp = reinterpret_cast<const f32x4*>(x) + n * per4;
+  f32x4* dxp = reinterpret_cast<f32x4*>(dx) + n * per4;
+  unsigned mb = 0u;
+  for (long i = threadIdx.x; i < per4; i += THREADS) {
+    const long p = i / C4;
+    const long c = i - p * C4;
+    const f32x4 v = xp[i];
+    const long ip = p * 2 * C4 + c, in = ip + C4;
+    const f32x4 fpv = fp[ip], fnv = fp[in], dpv = dfp[ip], dnv = dfp[in];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float dup = (dpv[k] - fpv[k] * dot) * inv;
+      const float dun = (dnv[k] - fnv[k] * dot) * inv;
+      o[k] = v[k] > 0.f ? dup : (v[k] < 0.f ? -dun : 0.f);
+    }
+    dxp[i] = o;
+    mb = amax_bits4(o, mb);
+  }
+  if (rec) amax_commit(rec, mb);
+}
+
 // one block per sample: norm = sqrt(sum x^2) (= ||[relu(x), relu(-x)]||); f = crelu(x)/norm
 __global__ __launch_bounds__(256) void feature_head_fwd_kernel(const float* __restrict__ x, int HW,
                                                                int C, float* __restrict__ f,
@@ -673,7 +746,10 @@ int otgan_feature_head_fwd_f32(const float* x, int N, int HW, int C, float* f, f
   OTGAN_CHECK_ARG(x && f && norm && N > 0 && HW > 0 && C > 0, "bad arguments");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, 4.0 * 4 * (double)N * HW * C, s);
-  hipLaunchKernelGGL(feature_head_fwd_kernel, dim3(N), dim3(256), 0, s, x, HW, C, f, norm);
+  if (C % 4 == 0 && aligned16(x) && aligned16(f))
+    hipLaunchKernelGGL(feature_head_fwd4_kernel<1024>, dim3(N), dim3(1024), 0, s, x, HW, C / 4, f, norm);
+  else
+    hipLaunchKernelGGL(feature_head_fwd_kernel, dim3(N), dim3(256), 0, s, x, HW, C, f, norm);
   OTGAN_CHECK_LAUNCH("feature head fwd");
   return OTGAN_OK;
 }
@@ -682,7 +758,10 @@ int otgan_feature_head_bwd_amax_f32(const float* x, const float* f, const float*
   OTGAN_CHECK_ARG(x && f && norm && df && dx && N > 0 && HW > 0 && C > 0, "bad arguments");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, 4.0 * 10 * (double)N * HW * C, s);
-  hipLaunchKernelGGL(feature_head_bwd_kernel, dim3(N), dim3(256), 0, s, x, f, norm, df, HW, C, dx, dx_amax);
+  if (C % 4 == 0 && aligned16(x) && aligned16(f) && aligned16(df) && aligned16(dx))
+    hipLaunchKernelGGL(feature_head_bwd4_kernel<1024>, dim3(N), dim3(1024), 0, s, x, f, norm, df, HW, C / 4, dx, dx_amax);
+  else
+    hipLaunchKernelGGL(feature_head_bwd_kernel, dim3(N), dim3(256), 0, s, x, f, norm, df, HW, C, dx, dx_amax);
   OTGAN_CHECK_LAUNCH("feature head bwd");
   return OTGAN_OK;
 }
