@@ -611,3 +611,120 @@ def test_adam_gathered_gradients_and_fused_ema(dev):
         assert torch.equal(sha, shb), (float((sha - shb).abs().max()), int((sha != shb).sum()))
     with pytest.raises(Exception):
         ops.adam_step_gather(pa, grads * 6, list(range(37)), va, mga, 3e-4, 0.5, 0.999, 1.0)     # > 32 segments
+
+
+# ---- DenseNet at the BASELINE batch (configs[3]: 256 images per GPU) -------------------------------------------------
+DENSE_FULL = [  # name, H, C0 (segments), preact: one dense block per resolution of the critic / generator (models/densenet.py:11-21,60-73)
+    ("critic_32x32", 32, (32,), "crelu"),
+    ("critic_16x16", 16, (144,), "crelu"),
+    ("critic_8x8", 8, (200,), "crelu"),
+    ("generator_16x16", 16, (144, 16), "crelu"),
+    ("critic_32x32_celu", 32, (32,), "celu"),          # --nonlinearity celu: smooth, so the GRADIENTS can be held tight too
+    ("critic_16x16_celu", 16, (144,), "celu"),
+    ("generator_16x16_celu", 16, (144, 16), "celu"),
+]
+
+
+@pytest.mark.parametrize("case", DENSE_FULL, ids=[c[0] for c in DENSE_FULL])
+def test_full_size_dense_block_split_matches_chain(dev, case, monkeypatch):
+    """A 16-layer dense block at 256 images, where no oracle finishes in seconds: the block computed as wide Winograd
+    convolutions of finished channel groups + short growth chains (the default; its GEMMs take the tile-count dependent
+    branches of the bench -- 256 x 128 tiles, K padding, K splits of the weight gradients, batched weight norm) against
+    the SAME block as a plain chain of 16-output convolutions on the dense16 kernels (OTGAN_DENSE_SPLIT=0): two
+    different algorithms, kernels and summation orders for every output, input gradient and weight gradient.  Each is
+    pinned to the fp64 oracle at small sizes (test_dense_block_split_matches_chain)."""
+    from otgan_amd import ops
+    name, H, segs0, pre = case
+    B, L, F = 256, 16, 16
+    gen = torch.Generator().manual_seed(sum(map(ord, name)))
+    mult = 2 if pre in ("crelu", "celu") else 1
+    C0 = sum(segs0)
+    x = torch.randn(B, H, H, C0, generator=gen)
+    P = []
+    for k in range(L):
+        P.append(((torch.randn(3, 3, (C0 + k * F) * mult, F, generator=gen) * 0.05), torch.rand(F, generator=gen) + 0.5,
+                  torch.randn(F, generator=gen) * 0.1))
+    dy = torch.randn(B, H, H, C0 + L * F, generator=gen)
+
+    def run(split):
+        monkeypatch.setenv("OTGAN_DENSE_SPLIT", "1" if split else "0")
+        ops.bump_weights_epoch()
+        x0 = x.to(dev).requires_grad_(True)
+        params = [[t.to(dev).requires_grad_(True) for t in p] for p in P]
+        y = ops.dense_block_op(x0, segs0, params, 3, ops.ACT[pre])
+        grads = torch.autograd.grad(y, [x0] + [t for p in params for t in p], dy.to(dev))
+        return y.detach(), grads
+
+    y_s, g_s = run(True)
+    y_c, g_c = run(False)
+    assert _rel(y_s, y_c) < 2e-5
+    # CReLU: of the ~1e8 pre-activations of the block a few dozen sit within fp32 rounding of zero and land on either
+    # side in the two evaluation orders; each flips one derivative mask (measured 9e-5 .. 5e-4 on the input gradient).
+    # The smooth CELU cases hold the gradients as tight as the outputs.
+    gtol = 5e-5 if pre == "celu" else 2e-3
+    assert _rel(g_s[0], g_c[0]) < gtol, "input gradient"
+    worst = max((_rel(a, c), i) for i, (a, c) in enumerate(zip(g_s[1:], g_c[1:])))
+    assert worst[0] < gtol, f"parameter gradient {worst}"
+
+
+TRANS_FULL = [  # name, H, C, Cout, stride, up, pre: the DenseNet transitions (models/densenet.py:17-21,67-73) at 256 images
+    ("critic_t1", 32, 288, 144, 2, False, "crelu"),
+    ("critic_t2", 16, 400, 200, 2, False, "crelu"),
+    ("critic_t3", 8, 456, 228, 2, False, "crelu"),
+    ("generator_up1", 8, 288, 144, 1, True, "crelu"),
+    ("generator_up2", 16, 416, 208, 1, True, "crelu"),
+]
+
+
+@pytest.mark.parametrize("case", TRANS_FULL, ids=[c[0] for c in TRANS_FULL])
+def test_full_size_transition_identities(dev, case):
+    """The DenseNet transition layers at 256 images: y is linear in W whatever the pre-activation, so
+    <conv(x, W) - b, dy> == <W, wgrad(x, dy)> and conv(x, W1 + W2) == conv(x, W1) + conv(x, W2) tie the forward and
+    weight-gradient kernels of the shapes the bench runs (stride-2 implicit GEMMs with 128 x 160 / 128 x 224 tiles and K
+    splits; 3x3 on the upsampled grid through the one-class Winograd passes) to one another; the input gradient is tied
+    to the forward pass by Euler's identity for the degree-1 homogeneous CReLU, <x, dgrad(dy)> == <y, dy> (zero bias)."""
+    from otgan_amd import ops
+    name, H, C, Cout, stride, up, pre = case
+    B, k = 256, 3
+    gen = torch.Generator().manual_seed(sum(map(ord, name)))
+    x = torch.randn(B, H, H, C, generator=gen).to(dev)
+    V = (torch.randn(k, k, 2 * C, Cout, generator=gen) * 0.05).to(dev)
+    V2 = (torch.randn(k, k, 2 * C, Cout, generator=gen) * 0.05).to(dev)
+    ones, zeros = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+
+    def conv(xx, VV, grad=False):
+        # g = ||V|| per output column makes the normalised weight W == V (weight norm is then the identity map)
+        gn = VV.reshape(-1, Cout).norm(dim=0)
+        return ops.conv2d_op(xx, VV, gn, zeros, stride=stride, upsample=up, preact=ops.ACT[pre])
+
+    xg = x.clone().requires_grad_(True)
+    Vg = V.clone().requires_grad_(True)
+    gn = V.reshape(-1, Cout).norm(dim=0).detach()
+    y = ops.conv2d_op(xg, Vg, gn, zeros, stride=stride, upsample=up, preact=ops.ACT[pre])
+    dy = torch.randn(y.shape, generator=gen).to(dev)
+    dx, dV = torch.autograd.grad(y, [xg, Vg], dy)
+    # dV is the gradient through weight norm: W = g V / ||V|| with g = ||V||  =>  <V, dV> = 0 (radial part removed) and
+    # the tangential part equals that of dW.  Linearity in W: <y, dy> = <W, dW>; recover dW from the raw launcher instead.
+    V2d = V.reshape(-1, Cout).contiguous()
+    w, wT, _ = ops.weightnorm_fwd(V2d, gn)
+    assert _rel(w, V2d) < 1e-6
+    lhs = float((y.detach().double() * dy.double()).sum())
+    # the inner products are net sums of ~1e8 terms of either sign: their fp32 rounding scales with sum |y dy|, not with the net
+    scale = float((y.detach().double().abs() * dy.double().abs()).sum())
+    # <W, dW> through the chain rule of weight norm: dV = (g/||V||) (dW - V <V, dW>/||V||^2) = dW - V <V,dW>/||V||^2 per column
+    # => <V, dV> = 0 and <W, dW> = sum_c <V_c, dW_c> is not recoverable from dV alone; use dg instead: dg_c = <V_c, dW_c>/||V_c||
+    gvar = gn.clone().requires_grad_(True)
+    y2 = ops.conv2d_op(x, V, gvar, zeros, stride=stride, upsample=up, preact=ops.ACT[pre])
+    (dg,) = torch.autograd.grad(y2, [gvar], dy)
+    rhs = float((dg.double() * gn.double()).sum())           # sum_c g_c dg_c = <W, dW>
+    assert abs(lhs - rhs) <= 2e-6 * scale, ("wgrad / weight norm", lhs, rhs, scale)
+    # additivity in the weights (g = column norms of the SUM for all three, so that W is exactly V, V2, V + V2)
+    with torch.no_grad():
+        ya = conv(x, V)
+        yb = conv(x, V2)
+        ys = conv(x, V + V2)
+    assert float((ys - ya - yb).norm() / ys.norm()) < 1e-5
+    # input gradient: CReLU is positively homogeneous of degree 1, so is y(x) (zero bias): Euler's identity
+    # <x, dy/dx . dy> == <y, dy> ties dgrad (activation derivative, class / tap bookkeeping) to the forward pass exactly
+    rhs_x = float((x.double() * dx.double()).sum())
+    assert abs(lhs - rhs_x) <= 2e-6 * scale, ("dgrad", lhs, rhs_x, scale)
