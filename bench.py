@@ -106,26 +106,39 @@ def secondary(dev, a):
     blocks = []
     for N, D, L, rows in ((128, 32768, 100, None), (256, 131072, 100, None), (1024, 32768, 100, None),
                           (1024, 32768, 100, 256), (1024, 7296, 200, 256)):
-        fa = list(torch.chunk(feats(2 * N, D, 0.0), 2, 0))
-        fb = list(torch.chunk(feats(2 * N, D, 0.5) ** 2, 2, 0))
-        fb = [torch.nn.functional.normalize(t, dim=1) for t in fb]
-        call = ((lambda: matching.get_matched_features(fa, fb, 500.0, L)) if rows is None else
-                (lambda: matching.get_matched_features_rows(fa, fb, 500.0, L, 0, rows)))
-        for _ in range(2):
-            call()
-        torch.cuda.synchronize()
-        reps = 5
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            call()
-        torch.cuda.synchronize()
-        us = (time.perf_counter() - t0) / reps * 1e6
-        # algorithmic FLOP: 12 N^2 D cost + 24 N^2 D plan application (rows variant: the rank's share of the latter)
-        flop = 12.0 * N * N * D + 24.0 * N * N * D * (1.0 if rows is None else rows / (2.0 * N))
-        blocks.append({"N": N, "D": D, "iters": L, "rows": "all" if rows is None else rows, "us": round(us, 1),
-                       "tflops": round(flop / us / 1e6, 1)})
-        del fa, fb
-    sec["matching_block"] = {"unit": "microseconds per call (wall, 5 calls); TFLOP/s on 12*N^2*D + 24*N^2*D*(rows/2N)",
+        fa_flat = feats(2 * N, D, 0.0)
+        fb_flat = torch.nn.functional.normalize(feats(2 * N, D, 0.5) ** 2, dim=1)
+        fa, fb = list(torch.chunk(fa_flat, 2, 0)), list(torch.chunk(fb_flat, 2, 0))
+        rr = None if rows is None else (0, rows)
+        # three entry points: the reference's operator (four matched arrays + calc_distance statistics) and the
+        # training-mode one the step calls (the injected gradients directly; generator steps need no data-side gradient)
+        calls = {"four_matched_arrays": ((lambda: matching.get_matched_features(fa, fb, 500.0, L)) if rows is None else
+                                         (lambda: matching.get_matched_features_rows(fa, fb, 500.0, L, 0, rows))),
+                 "grads_generator_step": lambda: matching.matched_feature_grads(fa_flat, fb_flat, 500.0, L, need_b=False, rows=rr),
+                 "grads_critic_step": lambda: matching.matched_feature_grads(fa_flat, fb_flat, 500.0, L, need_b=True, rows=rr)}
+        case = {"N": N, "D": D, "iters": L, "rows": "all" if rows is None else rows}
+        for tag, call in calls.items():
+            for _ in range(2):
+                call()
+            torch.cuda.synchronize()
+            reps = 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                call()
+            torch.cuda.synchronize()
+            us = (time.perf_counter() - t0) / reps * 1e6
+            if tag == "four_matched_arrays":
+                # algorithmic FLOP: 12 N^2 D cost + 24 N^2 D plan application (rows variant: the rank's share of the latter)
+                flop = 12.0 * N * N * D + 24.0 * N * N * D * (1.0 if rows is None else rows / (2.0 * N))
+                case["us"] = round(us, 1)
+                case["tflops"] = round(flop / us / 1e6, 1)
+            else:
+                case["us_" + tag] = round(us, 1)
+        blocks.append(case)
+        del fa, fb, fa_flat, fb_flat
+    sec["matching_block"] = {"unit": "microseconds per call (wall, 5 calls); `us` / `tflops` (on 12*N^2*D + 24*N^2*D*(rows/2N)): the "
+                                     "reference's operator = four matched arrays; us_grads_*: the training-mode entry the step calls "
+                                     "(otgan_matching_two_batch_grad_f32: injected gradients directly, closed-form distance)",
                              "cases": blocks}
     torch.cuda.empty_cache()
     for tag, kw, size, bpg, (w, k) in (
