@@ -153,7 +153,7 @@ struct ConvALoader {
     nt = 0;
     nd = 0;
     sgn = 1.f;
-    cm_next = (VEC && g.cmap) ? g.cmap[4 * (threadIdx.x % CPR)] : 0;
+    cm_next = (VEC && g.cmap && 4 * (threadIdx.x % CPR) < g.Ck) ? g.cmap[4 * (threadIdx.x % CPR)] : 0;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int r = r0 + p * RPP;
@@ -1081,6 +1081,131 @@ static bool launch_fewout_tile(const GatherA& ga, const Taps& t, const FewOutArg
     hipLaunchKernelGGL((conv_fewout_tile_kernel<ACT, 4>), grid, dim3(kFewTileThreads), lds, s, ga, t, fa, ft);
   }
   return true;
+}
+
+// RGB-out input gradient (the last convolution of both generators, 3 output channels: models/dcgan.py:48,
+// models/densenet.py:86): dx[pix][c] = act'(x) . sum_{tap, j<3} dy[pix - tap][j] * W[tap][d(c)][j] for MANY channels c
+// from a K = 9*3 or 25*3 deep sum -- a streaming kernel (read x for the activation mask, write dx), not a GEMM: the
+// implicit-GEMM path ran its 16-deep K tiles almost empty and wrote through the paired epilogue at 1.1 TB/s.
+// Lanes run along channel quads (every load / store of a wave is 4 pixels x 256 contiguous bytes); a workgroup owns
+// (image, 16-column strip, 64 channels), keeps those channels' weights in LDS for the whole strip ([tap][half][j][64],
+// one ds_read_b128 per (tap, half, j)) and walks down the strip 4 rows at a time with the dy tile (+ halo, padded
+// to float4 per pixel) in LDS; a lane accumulates 4 neighbouring pixels so that every weight read feeds 12 FMAs per
+// channel and a dy row window is read once per filter row.
+// acc += w * x as four scalar v_fma_f32, pinned in asm: what the compiler makes of the vector form is v_pk_fma_f32 with x
+// broadcast through op_sel, and beside a wave of the 256 x 128 Winograd-domain GEMM on the same SIMD the low halves of
+// lanes 48 - 63 of exactly these accumulate chains come back wrong (conv_rgbin_fwd_kernel below has the story; this
+// kernel reproduced it in 46 of 480 launches: elements 0 and 2 of the lanes with slot & 3 == 3, every channel quad alike,
+// also with s_waitcnt lgkmcnt(0) + s_nop 7 between the LDS reads and the FMAs -- tools/debug/corun_lanes.py).  Packed
+// fp32 buys no VALU throughput on this machine, so nothing is lost.
+__device__ __forceinline__ void fma4_pinned(f32x4& acc, const f32x4 w, const float x) {
+  float a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+  asm("v_fma_f32 %0, %4, %8, %0\n\tv_fma_f32 %1, %5, %8, %1\n\tv_fma_f32 %2, %6, %8, %2\n\tv_fma_f32 %3, %7, %8, %3"
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+      : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(x));
+  acc = f32x4{a0, a1, a2, a3};
+}
+struct FewDgArgs {
+  const float* dy;   // offset to the layer's channel range; [N, H, W, ldy], NJ channels used
+  int ldy;
+  const float* w;    // HWIO [K*K][Ceff][NJ]
+  const int* inv;    // paired: effective index of +c (inv[c]) and -c (inv[C + c]); null: c, C + c
+  const float* x;    // layer input (activation derivative), null without a pre-activation
+  int ldx;
+  float* dx;
+  int lddx;
+  int N, H, W, C, Ceff, pad_t, pad_l, act, accumulate;
+};
+constexpr int kFdTW = 16, kFdTH = 4, kFdCH = 64;
+template <int K, bool PAIRED, int NJ>
+__global__ __launch_bounds__(256) void conv_fewout_dgrad_kernel(FewDgArgs a) {
+  constexpr int HALVES = PAIRED ? 2 : 1;
+  constexpr int LH = kFdTH + K - 1, LW = kFdTW + K - 1, WIN = 4 + K - 1;
+  __shared__ __attribute__((aligned(16))) float wl[K * K][HALVES][NJ][kFdCH];
+  __shared__ float4 dyt[LH][LW];
+  const int n = blockIdx.x, w0 = blockIdx.y * kFdTW, c0 = blockIdx.z * kFdCH;
+  for (int i = threadIdx.x; i < K * K * HALVES * kFdCH; i += 256) {
+    const int cc = i % kFdCH, half = (i / kFdCH) % HALVES, tap = i / (kFdCH * HALVES);
+    const int c = c0 + cc;
+    float v[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) v[j] = 0.f;
+    if (c < a.C) {
+      const int d = a.inv ? a.inv[half * a.C + c] : half * a.C + c;
+      const float* src = a.w + ((long)tap * a.Ceff + d) * NJ;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) v[j] = src[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) wl[tap][half][j][cc] = v[j];
+  }
+  const int q = threadIdx.x & 15, slot = threadIdx.x >> 4;
+  const int r = slot >> 2, cg = (slot & 3) * 4;
+  const int c = c0 + 4 * q;
+  const float* dyn = a.dy + (long)n * a.H * a.W * a.ldy;
+  for (int h0 = 0; h0 < a.H; h0 += kFdTH) {
+    __syncthreads();   // the previous tile's reads (and, the first time, the weights' writes)
+    for (int i = threadIdx.x; i < LH * LW; i += 256) {
+      const int rr = i / LW, cc = i - rr * LW;
+      const int hh = h0 + a.pad_t - (K - 1) + rr, ww = w0 + a.pad_l - (K - 1) + cc;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (hh >= 0 && hh < a.H && ww >= 0 && ww < a.W) {
+        const float* sp = dyn + ((long)hh * a.W + ww) * a.ldy;
+        v.x = sp[0];
+        if (NJ > 1) v.y = sp[1];
+        if (NJ > 2) v.z = sp[2];
+        if (NJ > 3) v.w = sp[3];
+      }
+      dyt[rr][cc] = v;
+    }
+    __syncthreads();
+    f32x4 acc[HALVES][4];
+#pragma unroll
+    for (int hf = 0; hf < HALVES; ++hf)
+#pragma unroll
+      for (int px = 0; px < 4; ++px) acc[hf][px] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1   // (fully unrolled the compiler hoists all K*K*NJ weight reads: 512 VGPRs and scratch)
+    for (int kh = 0; kh < K; ++kh) {
+      float4 win[WIN];
+#pragma unroll
+      for (int i = 0; i < WIN; ++i) win[i] = dyt[r + K - 1 - kh][cg + i];
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw) {
+#pragma unroll
+        for (int hf = 0; hf < HALVES; ++hf) {
+          f32x4 wv[NJ];
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) wv[j] = *reinterpret_cast<const f32x4*>(&wl[kh * K + kw][hf][j][4 * q]);
+#pragma unroll
+          for (int px = 0; px < 4; ++px) {
+            const float4 dv = win[px + K - 1 - kw];
+            fma4_pinned(acc[hf][px], wv[0], dv.x);
+            if (NJ > 1) fma4_pinned(acc[hf][px], wv[1], dv.y);
+            if (NJ > 2) fma4_pinned(acc[hf][px], wv[2], dv.z);
+            if (NJ > 3) fma4_pinned(acc[hf][px], wv[3], dv.w);
+          }
+        }
+      }
+    }
+    if (c < a.C) {
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        const long pix = ((long)n * a.H + h0 + r) * a.W + w0 + cg + px;
+        f32x4 o = acc[0][px];
+        if (a.act) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + pix * a.ldx + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (PAIRED) o[e] = act_deriv(a.act, xv[e]) * acc[0][px][e] - act_deriv(a.act, -xv[e]) * acc[HALVES - 1][px][e];
+            else o[e] *= act_deriv(a.act, xv[e]);
+          }
+        }
+        float* dst = a.dx + pix * a.lddx + c;
+        if (a.accumulate) o += *reinterpret_cast<const f32x4*>(dst);
+        *reinterpret_cast<f32x4*>(dst) = o;
+      }
+    }
+  }
 }
 
 // RGB-in forward (the first convolution of both critics: 3 input channels, no pre-activation): lanes run along
@@ -2214,8 +2339,14 @@ static int conv2d_fwd_body(const otgan_conv_desc* d, const float* x, const int32
     OTGAN_CHECK_LAUNCH("conv2d fwd (winograd, stride 2)");
     return rc;
   }
-  if (filters && wino_up3_ok(d, g) && !wino_ok(d, g) && cmap == nullptr && aligned16(x) && aligned16(y) && aligned16(bias) &&
-      aligned16(workspace) && workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 0)) {
+  if (filters && wino_up3_ok(d, g) && !wino_ok(d, g)) {
+    // prepared filters of a 3x3 upsampling layer are made from the UN-folded weights and the caller may pass the
+    // un-folded wT with them: nothing below may run with those, so a failed precondition is an error, not a reroute
+    // (as in the input gradient)
+    OTGAN_CHECK_ARG(cmap == nullptr && aligned16(x) && aligned16(y) && aligned16(bias) && aligned16(workspace) && workspace &&
+                        workspace_bytes >= otgan_conv2d_workspace_bytes(d, 0),
+                    "winograd forward of a 3x3 upsampling layer (prepared filters given): single-tensor input, 16-byte "
+                    "aligned operands, workspace of otgan_conv2d_workspace_bytes(d, 0)");
     WinoUp3Geo w = wino_up3_geo(d, g);
     w.x_op = shared_x_operand(d);
     ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * kWinoFreq * (double)wino_up3_tiles(w) * g.Ceff * d->Cout, 0.0, s);
@@ -2435,6 +2566,29 @@ static int conv2d_dgrad_body(const otgan_conv_desc* d, const float* dy, const fl
     if (!launch_fewout_tile<0>(ga, t, fa, s))
       hipLaunchKernelGGL(conv_fewout_kernel<0>, dim3(ceil_div(ga.Mtot, 64)), dim3(256), 0, s, ga, t, fa);
     OTGAN_CHECK_LAUNCH("conv2d dgrad (few inputs)");
+    return OTGAN_OK;
+  }
+  if (d->Cout == 3 && d->stride == 1 && d->upsample == 0 && d->KH == d->KW && (d->KH == 3 || d->KH == 5) && d->C % 4 == 0 &&
+      lddx % 4 == 0 && aligned16(dx) && (kind == 0 || (aligned16(x) && d->ldx % 4 == 0)) && (inv == nullptr || paired) &&
+      d->W % kFdTW == 0 && d->H % kFdTH == 0 && getenv("OTGAN_DISABLE_FEWOUT_DGRAD") == nullptr) {
+    // RGB-out layer: streaming kernel, lanes along the input channels
+    FewDgArgs fa;
+    fa.dy = dy + d->y_coff; fa.ldy = d->ldy;
+    fa.w = w; fa.inv = inv;
+    fa.x = kind ? x : nullptr; fa.ldx = d->ldx;
+    fa.dx = dx; fa.lddx = lddx;
+    fa.N = d->N; fa.H = d->H; fa.W = d->W; fa.C = d->C; fa.Ceff = g.Ceff;
+    fa.pad_t = g.pad_t; fa.pad_l = g.pad_l; fa.act = kind; fa.accumulate = accumulate;
+    const dim3 grid(d->N, d->W / kFdTW, ceil_div(d->C, kFdCH));
+    ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * (double)d->N * d->H * d->W * d->KH * d->KW * d->Cout * g.Ceff, 0.0, s);
+    if (d->KH == 3) {
+      if (paired) hipLaunchKernelGGL((conv_fewout_dgrad_kernel<3, true, 3>), grid, dim3(256), 0, s, fa);
+      else hipLaunchKernelGGL((conv_fewout_dgrad_kernel<3, false, 3>), grid, dim3(256), 0, s, fa);
+    } else {
+      if (paired) hipLaunchKernelGGL((conv_fewout_dgrad_kernel<5, true, 3>), grid, dim3(256), 0, s, fa);
+      else hipLaunchKernelGGL((conv_fewout_dgrad_kernel<5, false, 3>), grid, dim3(256), 0, s, fa);
+    }
+    OTGAN_CHECK_LAUNCH("conv2d dgrad (few outputs)");
     return OTGAN_OK;
   }
   if (d->Cout == 16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->upsample == 0 && d->ldy % 4 == 0 &&

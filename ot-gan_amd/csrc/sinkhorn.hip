@@ -1587,6 +1587,7 @@ int otgan_cost_matrix_batched_f32(const float* const* X, const float* const* Y, 
     const long plane = (long)x3_plane_elems((size_t)P * ((size_t)n + m), D);
     const float* uniq[2 * kMaxProb];
     long urow[2 * kMaxProb];
+    int ulen[2 * kMaxProb];
     int nu = 0;
     long rows = 0, xrow[kMaxProb], yrow[kMaxProb];
     SplitSrc sx, sy;
@@ -1594,15 +1595,15 @@ int otgan_cost_matrix_batched_f32(const float* const* X, const float* const* Y, 
     memset(&sy, 0, sizeof(sy));
     auto place = [&](const float* ptr, int r, SplitSrc& ss) -> long {
       for (int i = 0; i < nu; ++i)
-        if (uniq[i] == ptr) return urow[i];
-      uniq[nu] = ptr; urow[nu] = rows;
+        if (uniq[i] == ptr && ulen[i] >= r) return urow[i];   // same block, at least as many rows already split
+      uniq[nu] = ptr; urow[nu] = rows; ulen[nu] = r;
       ss.src[ss.n] = ptr; ss.ld[ss.n] = ldf; ss.row0[ss.n] = rows; ss.scale[ss.n] = 1.f;
       ++ss.n; ++nu;
       rows += r;          // n and m are multiples of 32: every block starts on a row-block boundary
       return rows - r;
     };
     for (int p = 0; p < P; ++p) xrow[p] = place(X[p], n, sx);
-    for (int p = 0; p < P; ++p) yrow[p] = place(Y[p], m, sy);   // (a pointer used as X and as Y needs n == m to be reused)
+    for (int p = 0; p < P; ++p) yrow[p] = place(Y[p], m, sy);   // (a pointer used as X with fewer rows is placed again)
     ProfScope ps(OTGAN_PROF_COST_GEMM, 2.0 * P * n * (double)m * D, 4.0 * P * ((double)n + m) * D, s);
     if (sx.n) x3_split(sx, n, D, FP, plane, s);
     if (sy.n) x3_split(sy, m, D, FP, plane, s);

@@ -69,21 +69,31 @@ def build_parser():
     return p
 
 
-def inception_hook(model, args, classifier, state):
-    """train.py:245-272: scores of `eval_samples` samples of the generator and of its EMA copy, running maximum."""
-    from .utils.inception import get_inception_score
+def inception_hook(model, args, classifier, state, rank=0, world=1):
+    """train.py:245-272: scores of `eval_samples` samples of the generator and of its EMA copy, running maximum.
+    Every rank takes part: it draws and classifies its share of the samples (its own latent stream, seed + rank) and
+    the class probabilities are gathered, so no rank waits at the next epoch's first collective while rank 0 alone
+    samples and scores 2 x 50 000 images.  All ranks get the same scores; rank 0 prints them."""
+    from .utils.inception import class_probabilities, inception_score_from_probs
+    from . import parallel
+    share = -(-args.eval_samples // world)
     out = {}
     for tag, ema in (("", False), ("EMA ", True)):
-        imgs = []
-        while sum(x.shape[0] for x in imgs) < args.eval_samples:
-            imgs.append(model.sample(min(1000, args.eval_samples), ema=ema).float().cpu().numpy())
-        x = np.concatenate(imgs)[:args.eval_samples]
-        score = get_inception_score([127.5 * (im + 1.) for im in x], splits=10, classifier=classifier)   # train.py:260-262
-        print('%sinception score was %.6f, std was %.3f' % (tag, score[0], score[1]))
+        probs, have = [], 0
+        while have < share:
+            x = model.sample(min(1000, share - have), ema=ema).float().cpu().numpy()
+            probs.append(class_probabilities([127.5 * (im + 1.) for im in x], classifier))   # train.py:260-262
+            have += x.shape[0]
+        p = torch.from_numpy(np.concatenate(probs)[:share].astype(np.float32)).to(model.device)
+        p = parallel.all_gather_rows(p)[:args.eval_samples].cpu().numpy()
+        score = inception_score_from_probs(p, splits=10)
+        if rank == 0:
+            print('%sinception score was %.6f, std was %.3f' % (tag, score[0], score[1]))
         if score[0] > state["max"]:
             state["max"], state["iter"] = score[0], state["epoch"]
         out[tag.strip() or "live"] = score
-    print('max inception score was %.6f, iter was %d' % (state["max"], state["iter"]))
+    if rank == 0:
+        print('max inception score was %.6f, iter was %d' % (state["max"], state["iter"]))
     return out
 
 
@@ -179,7 +189,7 @@ def main(argv=None):
         print('starting training')
     mean_dist_gen, mean_dist_disc = [], []
     classifier, score_state = None, {"max": 0.0, "iter": 0, "epoch": 0}
-    if args.inception_model and rank == 0:
+    if args.inception_model:      # on every rank: each classifies its share of the samples
         from .utils.inception import load_classifier
         classifier = load_classifier(args.inception_model, dev)
     elif rank == 0:
@@ -208,15 +218,15 @@ def main(argv=None):
         f = lambda lst: float(torch.stack([z.double() for z in lst]).mean()) if lst else float('nan')
         mean_dist_gen.append(f(dg))
         mean_dist_disc.append(f(dd))
+        if classifier is not None and (epoch + 1) % args.eval_every == 0 and epoch != current_epoch:   # train.py:245
+            score_state["epoch"] = epoch
+            inception_hook(model, args, classifier, score_state, rank, world)
         if rank == 0:
             print("Iteration %d, time = %ds, train distance before gen = %.6f, train distance before disc = %.6f, "
                   "avg matching entropy = %.6f" % (epoch, time.time() - begin, mean_dist_gen[-1],
                                                    mean_dist_disc[-1], f(ent)))          # train.py:231
             save_tile_png(model.sample(100), os.path.join(args.save_dir, 'sample%d.png' % epoch))
             save_tile_png(model.sample(100, ema=True), os.path.join(args.save_dir, 'ema_sample%d.png' % epoch))
-            if classifier is not None and (epoch + 1) % args.eval_every == 0 and epoch != current_epoch:   # train.py:245
-                score_state["epoch"] = epoch
-                inception_hook(model, args, classifier, score_state)
             if (epoch + 1) % args.save_every == 0 and epoch != current_epoch:                          # train.py:275-277
                 torch.save(model.state_dict(), os.path.join(args.save_dir, 'med_gan_params-%d' % epoch))
                 np.savez(os.path.join(args.save_dir, 'distances.npz'), mean_dist_gen=np.array(mean_dist_gen),

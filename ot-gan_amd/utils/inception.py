@@ -54,8 +54,14 @@ def get_inception_score(images, splits=10, classifier=None, batch_size=100):
     if classifier is None:
         raise RuntimeError("no Inception classifier: the reference downloads one (utils/inception.py:18); pass "
                            "`classifier=` or train.py --inception_model <TorchScript file>")
+    return inception_score_from_probs(class_probabilities(images, classifier, batch_size), splits)
+
+
+def class_probabilities(images, classifier, batch_size=100):
+    """[n, classes] class probabilities of a list of [H, W, 3] images in 0..255, `batch_size` at a time
+    (utils/inception.py:35-42, bs = 100)."""
     preds = []
-    for i in range(0, len(images), batch_size):                                  # utils/inception.py:35-42, bs = 100
+    for i in range(0, len(images), batch_size):
         batch = np.stack([im.astype(np.float32) for im in images[i:i + batch_size]], 0)
         preds.append(np.asarray(classifier(batch)))
-    return inception_score_from_probs(np.concatenate(preds, 0), splits)
+    return np.concatenate(preds, 0)

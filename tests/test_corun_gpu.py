@@ -4,7 +4,9 @@ Round 3's default GEMM (wino_bgemm_x3n_kernel: 256 x 128 tile, two workgroups pe
 leaves room for other workgroups on its compute unit, which is what happens whenever two ranks share a GPU (the
 gloo tests) or a collective's kernels overlap the backward pass.  Found the hard way: the RGB-in forward kernel's
 packed fp32 FMAs returned wrong values in lanes 48-63 in 60 % of the launches with a GEMM wave on the same SIMD
-(it now uses scalar FMAs); this test keeps every kernel family of a DCGAN / DenseNet step honest as the neighbour."""
+(it now uses scalar FMAs; round 3's RGB-out input-gradient kernel reproduced the same signature and got the same cure,
+and every translation unit except the Winograd transforms is built without packed fp32, csrc/Makefile); this test keeps
+every kernel family of a DCGAN / DenseNet step honest as the neighbour."""
 import os
 import subprocess
 import sys
@@ -15,7 +17,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("victim", ["rgbin", "rgbin3", "rgbin_grad", "rgbout", "growth", "s2", "glu", "head"])
+@pytest.mark.parametrize("victim", ["rgbin", "rgbin3", "rgbin_grad", "rgbout", "growth", "s2", "up", "matching", "glu", "head"])
 def test_neighbour_of_the_gemm_computes_the_same(victim):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "debug", "corun_repro.py"), victim, "60"],
                        capture_output=True, text=True, timeout=900)

@@ -81,6 +81,12 @@ CONV_CASES = [
     ("rgb_in_many", 72, 32, 32, (3,), 32, 5, 1, False, None),
     ("few_out_small_crelu", 2, 4, 4, (16,), 2, 5, 1, False, "crelu"),
     ("few_out_list", 2, 8, 8, (16, 8), 3, 3, 1, False, "crelu"),
+    # RGB-out input gradient on the streaming kernel (conv_fewout_dgrad_kernel): list input with interleaved (+c, -c)
+    # order and a ragged last 64-channel chunk, single activations, 5x5 with a doubled ELU, rectangular image
+    ("rgb_out_list_crelu", 3, 16, 16, (40, 16, 24), 3, 3, 1, False, "crelu"),
+    ("rgb_out_elu_rect", 2, 16, 32, (72,), 3, 3, 1, False, "elu"),
+    ("rgb_out_celu_k5", 2, 16, 16, (36,), 3, 5, 1, False, "celu"),
+    ("rgb_out_relu", 2, 16, 16, (20,), 3, 3, 1, False, "relu"),
     # DenseNet transition shapes: outputs just above 128 / 192 columns take one exact column tile (128x160, 128x224)
     ("wide160_s2_list", 128, 32, 32, (32, 16, 16), 144, 3, 2, False, "crelu"),
     ("wide224_up_list", 32, 16, 16, (32, 16, 16), 208, 3, 1, True, "crelu"),

@@ -65,6 +65,27 @@ elif victim in ("rgbout", "rgbin_grad", "growth"):
                 dyv = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(dev)
             dx, dV = torch.autograd.grad(y, [xv, Vv], dyv)
         return torch.cat([y.detach().reshape(-1), dx.reshape(-1), dV.reshape(-1)])
+elif victim == "up":
+    # a folded 5x5 upsampling layer of the generator, forward and both gradients: the transform kernels of winograd.hip
+    # (the only translation unit still built with packed fp32, csrc/Makefile) beside the other stream's GEMM
+    xv = torch.randn(4, 16, 16, 256, generator=g).to(dev).requires_grad_(True)
+    Vv, gv, bv = params(5, 256, 256)
+    Vv.requires_grad_(True)
+    dyv = torch.randn(4, 32, 32, 256, generator=g).to(dev)
+
+    def run_victim():
+        with torch.enable_grad():
+            y = ops.conv2d_op(xv, Vv, gv, bv, stride=1, upsample=True, preact=ops.ACT[None])
+            dx, dV = torch.autograd.grad(y, [xv, Vv], dyv)
+        return torch.cat([y.detach().reshape(-1), dx.reshape(-1), dV.reshape(-1)])
+elif victim == "matching":
+    from otgan_amd.utils import matching
+    fa = torch.nn.functional.normalize(torch.rand(128, 8192, generator=g), dim=1).to(dev)
+    fb = torch.nn.functional.normalize(torch.rand(128, 8192, generator=g), dim=1).to(dev)
+
+    def run_victim():
+        ga_, gb_, ent, dist = matching.matched_feature_grads(fa, fb, 500.0, 100)
+        return torch.cat([ga_.reshape(-1), gb_.reshape(-1), ent.reshape(-1).float(), dist.reshape(-1).float()])
 elif victim == "glu":
     xv = torch.randn(4, 16, 16, 512, generator=g).to(dev)
     run_victim = lambda: ops.glu(xv)
