@@ -1092,6 +1092,176 @@ static bool launch_fewout_tile(const GatherA& ga, const Taps& t, const FewOutArg
 // one ds_read_b128 per (tap, half, j)) and walks down the strip 4 rows at a time with the dy tile (+ halo, padded
 // to float4 per pixel) in LDS; a lane accumulates 4 neighbouring pixels so that every weight read feeds 12 FMAs per
 // channel and a dy row window is read once per filter row.
+// Few-output layers on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: exact fp32 products, the same arithmetic as the
+// VALU kernels, at twice the scalar FMA rate and without the per-FMA operand traffic).  Three outputs waste a 16-column
+// tile, so the filter COLUMNS go into the tile as well: with n = kw * J + j (15 of 16 columns for a 5 x 5 RGB layer)
+//     acc[(h, w')][n] = sum_{kh, d} act(src[(h + kh - pad, w')][d]) * W[(kh, kw)][j][d]      K = KH * channels
+// is a GEMM whose A rows are whole image rows read where they lie -- the vertical taps are K steps, not a gather -- and
+//     out[(h, w)][j] = sum_kw acc[(h, w + dw(kw))][kw * J + j]
+// is a horizontal shift-and-add inside one image row (zero padding at both ends, no halo between workgroups), done
+// through a per-wave LDS strip.  A wave owns RB = 4 consecutive output rows of one image and STREAMS the RB + KH - 1
+// input rows they depend on past its RB row accumulators: an input row is loaded once (a lane: one float4 of its pixel's
+// channels per 16-channel step, whose four elements feed four MFMAs against one ds_read_b128 of weights -- the K index
+// of the instruction is a permutation of the channels, the same one on both operands) and multiplied into the up to KH
+// output rows it belongs to; the row loop is unrolled, so which accumulator a (row, kh) pair adds into is static.
+// (Row by row with the vertical taps as the outer K loop every input row was fetched KH times from L2 -- a 16 KiB row
+// does not survive in L1 -- and the kernel ran at the VALU kernel's speed: 138 us against 147 us.)
+// 5.4 GFLOP for the DCGAN RGB-out forward at 256 images: 34 us at the fp32 matrix peak, 27 us to read x once.
+template <int ACT, int MT, int KH>
+__global__ __launch_bounds__(256) void conv_fewout_mfma_kernel(GatherA g, Taps taps, FewOutArgs a, int KW, int flip) {
+  extern __shared__ __attribute__((aligned(16))) float4 s_mw[];   // [KH][8][64] weights of a 128-channel chunk, then the strips
+  constexpr int W = MT * 16, PADW = 2, PAD = (KH - 1) / 2, RB = 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int H = 1 << g.logGH;
+  const int blocks_per_img = H / RB;
+  const int task = blockIdx.x * 4 + wave;
+  const int n = task / blocks_per_img, ha = (task - n * blocks_per_img) * RB;
+  const int NJ = a.J, ncol = KW * NJ;
+  float* P = reinterpret_cast<float*>(s_mw + KH * 8 * 64) + wave * (W + 2 * PADW) * 16;
+  P[lane < 32 ? lane : (W + PADW) * 16 + (lane - 32)] = 0.f;   // the strip's two zero pixels at either end
+  f32x4 acc[RB][MT];
+#pragma unroll
+  for (int r = 0; r < RB; ++r)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[r][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int d0 = 0; d0 < g.Ck; d0 += 128) {
+    __syncthreads();   // the previous chunk's weights are consumed
+    for (int i = threadIdx.x; i < KH * 8 * 64; i += 256) {
+      const int l = i & 63, cs = (i >> 6) & 7, kh = i >> 9;
+      const int nn = l & 15, kw = nn / NJ, j = nn - kw * NJ;
+      const int d = d0 + cs * 16 + 4 * (l >> 4);
+      float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (nn < ncol && d < g.Ck)
+        wv = *reinterpret_cast<const float4*>(a.w + taps.boff[(flip ? KH - 1 - kh : kh) * KW + kw] + j * a.sJ + d);
+      s_mw[i] = wv;
+    }
+    __syncthreads();
+    // the lane's eight channel quads of this chunk (source channel and sign: channel map / doubled pre-activation); the
+    // last chunk may be a half (64 | channels)
+    const int nhalf = g.Ck - d0 >= 128 ? 2 : 1;
+    int sc[8];
+    float sg[8];
+#pragma unroll
+    for (int cs = 0; cs < 8; ++cs) {
+      const int d = d0 + cs * 16 + 4 * kq;
+      sc[cs] = 0;
+      sg[cs] = 1.f;
+      if (d < g.Ck) decode_map(g, d, g.cmap ? g.cmap[d] : 0, sc[cs], sg[cs]);
+    }
+    // input row t of the wave is image row ha - PAD + t and adds, through filter row kh, into output row ha + t - kh
+#pragma unroll
+    for (int t = 0; t < RB + 2 * PAD; ++t) {
+      const int ih = ha - PAD + t;
+      if ((unsigned)ih >= (unsigned)H) continue;   // (a row of the zero padding adds nothing)
+      const float* xrow = g.x + (((long)n * H + ih) * W + li) * g.ldx;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if (half >= nhalf) break;
+        float4 xv[4][MT];
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            xv[c4][mt] = *reinterpret_cast<const float4*>(xrow + (long)(mt * 16) * g.ldx + sc[half * 4 + c4]);
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+          const float s_ = sg[half * 4 + c4];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            xv[c4][mt].x = act_apply<ACT>(s_ * xv[c4][mt].x);
+            xv[c4][mt].y = act_apply<ACT>(s_ * xv[c4][mt].y);
+            xv[c4][mt].z = act_apply<ACT>(s_ * xv[c4][mt].z);
+            xv[c4][mt].w = act_apply<ACT>(s_ * xv[c4][mt].w);
+          }
+        }
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+          if (t - kh < 0 || t - kh >= RB) continue;   // static
+          constexpr int kRB = RB;
+          const int r = (t - kh + kRB) % kRB;
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4) {
+            const float4 wv = s_mw[(kh * 8 + half * 4 + c4) * 64 + lane];
+            // element-major: the MT chains of one element are independent of each other
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c4][mt].x, wv.x, acc[r][mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c4][mt].y, wv.y, acc[r][mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c4][mt].z, wv.z, acc[r][mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[c4][mt].w, wv.w, acc[r][mt], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // shift-and-add along the row: the accumulator tile (lane: column n = li, rows 4 kq .. 4 kq + 3) goes to the wave's strip,
+  // then lane o = (w, j) sums its KW shifted entries.  Lanes exchange data through the strip, so every lane must pass the
+  // same points in the same order: a loop whose trip count depends on the lane lets the compiler run the lanes that leave
+  // early AHEAD (it sank the next row's strip writes of lanes 48 - 63 above the other lanes' reads of this row); uniform
+  // trip count + wave barriers.
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) P[(PADW + mt * 16 + 4 * kq + q) * 16 + li] = acc[r][mt][q];
+    __builtin_amdgcn_wave_barrier();
+    const long pix0 = ((long)n * H + ha + r) * W;
+    for (int o0 = 0; o0 < W * NJ; o0 += 64) {
+      const int o = o0 + lane;
+      if (o < W * NJ) {
+        const int w = o / NJ, j = o - w * NJ;
+        float v = a.bias ? a.bias[j] : 0.f;
+        for (int kw = 0; kw < KW; ++kw) v += P[(PADW + w + sx16(taps.dhw[kw])) * 16 + kw * NJ + j];
+        float* dst = a.out + (pix0 + w) * a.ldo + a.coff + j;
+        *dst = a.accumulate ? *dst + v : v;
+      }
+    }
+  }
+}
+// launches the matrix-pipe kernel when the layer qualifies: a KH x KW rectangle of taps (row-major in `t`, KH = 3 or 5,
+// dh = +-(kh - pad)) with KW * J <= 16 columns and |dw| <= 2, stride 1, rows of 16 / 32 / 64 pixels, 4 | H, 64 | channels
+template <int ACT>
+static bool launch_fewout_mfma(const GatherA& ga, const Taps& t, const FewOutArgs& fa, int KH, int KW, hipStream_t s) {
+  static const bool off = getenv("OTGAN_DISABLE_FEWOUT_MFMA") != nullptr;
+  if (off || ga.sa != 1 || ga.logUp != 0 || fa.so != 1 || fa.J < 1 || KW * fa.J > 16 || t.n != KH * KW || (KH != 3 && KH != 5)) return false;
+  const int W = 1 << ga.logGW, H = 1 << ga.logGH;
+  if (W != ga.W || H != ga.H || (W != 16 && W != 32 && W != 64) || H % 4 || ga.Ck % 64 || ga.ldx % 4 || fa.sJ % 4) return false;
+  const int pad = (KH - 1) / 2;
+  const int flip = (t.dhw[0] >> 16) > 0 ? 1 : 0;
+  for (int i = 0; i < t.n; ++i) {
+    const int dw = (int)(short)(t.dhw[i] & 0xffff), kh = i / KW;
+    if (dw < -2 || dw > 2 || t.boff[i] % 4) return false;
+    if ((t.dhw[i] >> 16) != (flip ? pad - kh : kh - pad) || dw != (int)(short)(t.dhw[i % KW] & 0xffff)) return false;
+  }
+  const long rows = (long)ga.Mtot / W;
+  if (rows % 16) return false;   // four waves of four output rows per workgroup
+  const dim3 grid((unsigned)(rows / 16));
+  const size_t lds = sizeof(float4) * (size_t)KH * 8 * 64 + sizeof(float) * 4 * (W + 4) * 16;
+#define FEW_MFMA(MT_, KH_)                                                                                              \
+  do {                                                                                                                  \
+    static bool once = (hipFuncSetAttribute((const void*)conv_fewout_mfma_kernel<ACT, MT_, KH_>,                        \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024), true);              \
+    (void)once;                                                                                                         \
+    hipLaunchKernelGGL((conv_fewout_mfma_kernel<ACT, MT_, KH_>), grid, dim3(256), lds, s, ga, t, fa, KW, flip);         \
+  } while (0)
+  if (KH == 5) {
+    if (W == 16) FEW_MFMA(1, 5);
+    else if (W == 32) FEW_MFMA(2, 5);
+    else FEW_MFMA(4, 5);
+  } else {
+    if (W == 16) FEW_MFMA(1, 3);
+    else if (W == 32) FEW_MFMA(2, 3);
+    else FEW_MFMA(4, 3);
+  }
+#undef FEW_MFMA
+  return true;
+}
+
 // acc += w * x as four scalar v_fma_f32, pinned in asm: what the compiler makes of the vector form is v_pk_fma_f32 with x
 // broadcast through op_sel, and beside a wave of the 256 x 128 Winograd-domain GEMM on the same SIMD the low halves of
 // lanes 48 - 63 of exactly these accumulate chains come back wrong (conv_rgbin_fwd_kernel below has the story; this
@@ -2434,11 +2604,14 @@ static int conv2d_fwd_body(const otgan_conv_desc* d, const float* x, const int32
     const dim3 grid(ceil_div(ga.Mtot, 64));
     const int act = act_kind(d->preact);
     if (act == 1) {
-      if (!launch_fewout_tile<1>(ga, ct.taps[0], fa, s)) hipLaunchKernelGGL(conv_fewout_kernel<1>, grid, dim3(256), 0, s, ga, ct.taps[0], fa);
+      if (!launch_fewout_mfma<1>(ga, ct.taps[0], fa, d->KH, d->KW, s) && !launch_fewout_tile<1>(ga, ct.taps[0], fa, s))
+        hipLaunchKernelGGL(conv_fewout_kernel<1>, grid, dim3(256), 0, s, ga, ct.taps[0], fa);
     } else if (act == 2) {
-      if (!launch_fewout_tile<2>(ga, ct.taps[0], fa, s)) hipLaunchKernelGGL(conv_fewout_kernel<2>, grid, dim3(256), 0, s, ga, ct.taps[0], fa);
+      if (!launch_fewout_mfma<2>(ga, ct.taps[0], fa, d->KH, d->KW, s) && !launch_fewout_tile<2>(ga, ct.taps[0], fa, s))
+        hipLaunchKernelGGL(conv_fewout_kernel<2>, grid, dim3(256), 0, s, ga, ct.taps[0], fa);
     } else {
-      if (!launch_fewout_tile<0>(ga, ct.taps[0], fa, s)) hipLaunchKernelGGL(conv_fewout_kernel<0>, grid, dim3(256), 0, s, ga, ct.taps[0], fa);
+      if (!launch_fewout_mfma<0>(ga, ct.taps[0], fa, d->KH, d->KW, s) && !launch_fewout_tile<0>(ga, ct.taps[0], fa, s))
+        hipLaunchKernelGGL(conv_fewout_kernel<0>, grid, dim3(256), 0, s, ga, ct.taps[0], fa);
     }
     OTGAN_CHECK_LAUNCH("conv2d fwd (few outputs)");
     return OTGAN_OK;
@@ -2563,7 +2736,7 @@ static int conv2d_dgrad_body(const otgan_conv_desc* d, const float* dy, const fl
     fa.out = dx; fa.ldo = lddx; fa.coff = 0; fa.J = d->C;
     fa.so = 1; fa.OHf = g.Hin; fa.OWf = g.Win; fa.accumulate = accumulate;
     ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * ga.Mtot * (double)t.n * d->Cout * d->C, 0.0, s);
-    if (!launch_fewout_tile<0>(ga, t, fa, s))
+    if (!launch_fewout_mfma<0>(ga, t, fa, d->KH, d->KW, s) && !launch_fewout_tile<0>(ga, t, fa, s))
       hipLaunchKernelGGL(conv_fewout_kernel<0>, dim3(ceil_div(ga.Mtot, 64)), dim3(256), 0, s, ga, t, fa);
     OTGAN_CHECK_LAUNCH("conv2d dgrad (few inputs)");
     return OTGAN_OK;

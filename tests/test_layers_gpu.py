@@ -87,6 +87,14 @@ CONV_CASES = [
     ("rgb_out_elu_rect", 2, 16, 32, (72,), 3, 3, 1, False, "elu"),
     ("rgb_out_celu_k5", 2, 16, 16, (36,), 3, 5, 1, False, "celu"),
     ("rgb_out_relu", 2, 16, 16, (20,), 3, 3, 1, False, "relu"),
+    # RGB-out forward / RGB-in input gradient on the fp32 matrix pipe (conv_fewout_mfma_kernel): channels a multiple of
+    # 64, rows of 16 / 32 / 64 pixels; one and a half chunks of 128 channels, list input through the channel map
+    ("rgb_out_mfma_two_chunks", 2, 16, 32, (192,), 3, 5, 1, False, None),
+    ("rgb_out_mfma_list_crelu", 2, 16, 16, (32, 16, 8, 8), 3, 3, 1, False, "crelu"),
+    ("rgb_out_mfma_celu_192", 2, 8, 16, (96,), 3, 3, 1, False, "celu"),
+    ("rgb_out_mfma_w64_elu", 1, 8, 64, (64,), 3, 3, 1, False, "elu"),
+    ("rgb_in_mfma_dgrad", 3, 16, 32, (3,), 64, 5, 1, False, None),
+    ("two_out_mfma", 2, 8, 16, (64,), 2, 5, 1, False, "relu"),
     # DenseNet transition shapes: outputs just above 128 / 192 columns take one exact column tile (128x160, 128x224)
     ("wide160_s2_list", 128, 32, 32, (32, 16, 16), 144, 3, 2, False, "crelu"),
     ("wide224_up_list", 32, 16, 16, (32, 16, 16), 208, 3, 1, True, "crelu"),

@@ -201,10 +201,19 @@ def _named(m):
     return named
 
 
-def _well_conditioned_worst(dev, model, size, kind, seed):
+def _well_conditioned_worst(dev, model, size, kind, seed, same_head_signs=False):
     """Worst per-tensor relative L2 error of the step's gradients against the fp64 oracle step (+ distance / entropy
-    checks) for one parameter / data seed."""
+    checks) for one parameter / data seed.  `same_head_signs`: the oracle's feature head takes its CReLU sign pattern
+    from the path under test (oracle/nets_torch.py FORCED_HEAD_SIGNS)."""
     from otgan_amd.trainer import OTGAN, default_args
+    from otgan_amd.utils import nn as hip_nn
+    from oracle import nets_torch as NTO
+    signs = []
+    real_head = hip_nn.feature_head
+
+    def recording_head(z):
+        signs.append(torch.sign(z.detach()).cpu())      # (an activation that rounds to exactly 0 has happened: seed 7 at 64 x 64)
+        return real_head(z)
     lam, iters = 20.0, 10
     args = default_args(model=model, batch_size=3, nr_gpu=2, sinkhorn_lambda=lam, nr_sinkhorn_iter=iters,
                         nr_gen_per_disc=1, seed=seed, nonlinearity="elu", image_size=size)
@@ -215,12 +224,20 @@ def _well_conditioned_worst(dev, model, size, kind, seed):
     x = torch.rand(m.nb, size, size, 3, generator=gen) * 2 - 1
     noise = _noise(model, m.nb, gen)
     to_dev = lambda z: [t.to(dev) for t in z] if isinstance(z, list) else z.to(dev)
-    r = m.step(x.to(dev), noise=to_dev(noise), apply_updates=False)
-    assert r["kind"] == kind
+    hip_nn.feature_head = recording_head
+    try:
+        r = m.step(x.to(dev), noise=to_dev(noise), apply_updates=False)
+    finally:
+        hip_nn.feature_head = real_head
+    assert r["kind"] == kind and len(signs) == (2 if kind == "gen" else 1)
     o = CpuOTGAN(model, "elu", dtype=torch.float64, use_c_matching=False, image_size=size)
     o.load(_named(m))
     to64 = lambda z: [t.double() for t in z] if isinstance(z, list) else z.double()
-    gr, dist, ent = o.grads(kind, x.double(), to64(noise), 2, lam, iters)
+    NTO.FORCED_HEAD_SIGNS = signs if same_head_signs else None
+    try:
+        gr, dist, ent = o.grads(kind, x.double(), to64(noise), 2, lam, iters)
+    finally:
+        NTO.FORCED_HEAD_SIGNS = None
     assert float(r["distance"]) == pytest.approx(dist, rel=1e-4, abs=1e-7)
     assert float(r["entropy"]) == pytest.approx(ent, rel=1e-4)
     names = list((m.generator if kind == "gen" else m.discriminator).named_variables())
@@ -229,13 +246,14 @@ def _well_conditioned_worst(dev, model, size, kind, seed):
     return worst
 
 
-# measured (round 3, seeds 5 / 6 / 7, worst tensor per seed; pytest -s prints them):
-#   dcgan 32 disc 6.3e-6, 6.2e-4 (one flipped head unit), 6.4e-6     gen 8.2e-6, 7.2e-6, 5.9e-6
-#   densenet disc 5.8e-6, 8.4e-6, 6.3e-6                              gen 4.3e-6, 7.5e-6, 3.6e-6
-#   dcgan 64 disc 1.5e-3 (flipped unit), 6.0e-6, 6.0e-6               gen 1.3e-4 (flipped unit), 7.6e-6, 8.7e-6
-# asserted on the median over seeds = measured median + 25 %
-_WELL_TOL = {("dcgan", 32, "disc"): 8.0e-6, ("dcgan", 32, "gen"): 9.0e-6, ("densenet", 32, "disc"): 8.0e-6,
-             ("densenet", 32, "gen"): 5.5e-6, ("dcgan", 64, "disc"): 7.5e-6, ("dcgan", 64, "gen"): 1.1e-5}
+# measured (round 3, seeds 5 / 6 / 7, worst tensor per seed, head sign pattern shared with the oracle; pytest -s prints them):
+#   dcgan 32 disc 6.3e-6, 6.2e-6, 6.3e-6      gen 8.2e-6, 6.0e-6, 8.0e-6
+#   densenet disc 5.8e-6, 8.4e-6, 6.3e-6      gen 4.3e-6, 7.5e-6, 3.6e-6
+#   dcgan 64 disc 6.0e-6, 5.9e-6, 5.9e-6      gen 1.1e-5, 7.5e-6, 9.2e-6
+# (with the oracle's own signs: dcgan 32 disc seed 6 6.2e-4, dcgan 64 disc seed 5 1.2e-3 and seed 7 4e-4 -- one unit each)
+# asserted: every seed at the measured maximum + 25 % (see the test)
+_WELL_TOL = {("dcgan", 32, "disc"): 8.0e-6, ("dcgan", 32, "gen"): 1.05e-5, ("densenet", 32, "disc"): 1.05e-5,
+             ("densenet", 32, "gen"): 9.5e-6, ("dcgan", 64, "disc"): 7.5e-6, ("dcgan", 64, "gen"): 1.4e-5}
 
 
 @pytest.mark.parametrize("model,size", [("dcgan", 32), ("densenet", 32), ("dcgan", 64)])
@@ -245,21 +263,25 @@ def test_well_conditioned_step_gradients(dev, model, size, kind):
     cancellation).  EVERY gradient tensor of the step against the fp64 oracle step, distance and entropy to 1e-4.
     size = 64 is BASELINE configs[4]'s shape (generator stem 8x8, D = 65536 with ELU).
 
-    Round 3: three parameter / data seeds per case.  The MEDIAN over seeds of the worst tensor's error is asserted at
-    what the default engine (Winograd F(4x4,3x3), two scaled fp16 pieces) achieves + 25 % -- 1e-5-class, the level of a
-    plain fp32 evaluation (PyTorch-CPU fp32: 5e-6 on these gradients; tests/test_engine_accuracy_gpu.py puts the four
-    GEMM engines side by side).  Round 2 asserted 1e-3 / 3e-3 here and attributed it to the Winograd transform; the
-    decomposition (tools/debug/step_error_parts.py: features 2-4e-6, matching on fixed features 1e-6, backward on a
-    fixed upstream gradient 2e-6) shows what it really was: the feature head is a CReLU whatever --nonlinearity says
-    (models/dcgan.py:16,19), and ONE of its ~1e5 pre-activations landing on the other side of zero than in fp64 moves
-    every gradient of the step by 2e-4 .. 5e-4 -- a coin flip per engine and seed (the direct engine and the three-piece
-    engine flip the same unit at seed 5, the default and the fp32-Winograd engine do not).  Hence: median tight, and
-    every single seed below the one-flipped-unit level."""
-    worst = [_well_conditioned_worst(dev, model, size, kind, seed) for seed in (5, 6, 7)]
+    Round 3: three parameter / data seeds per case, EVERY seed asserted at what the default engine (Winograd F(4x4,3x3),
+    two scaled fp16 pieces) achieves + 25 % -- 1e-5-class, the level of a plain fp32 evaluation (PyTorch-CPU fp32: 5e-6
+    on these gradients; tests/test_engine_accuracy_gpu.py puts the four GEMM engines side by side) -- with the oracle's
+    feature head taking its CReLU sign pattern from the path under test.  Round 2 asserted 1e-3 / 3e-3 here and
+    attributed it to the Winograd transform; the decomposition (tools/debug/step_error_parts.py: features 2-4e-6,
+    matching on fixed features 1e-6, backward on a fixed upstream gradient 2e-6) shows what it really was: the feature
+    head is a CReLU whatever --nonlinearity says (models/dcgan.py:16,19), and ONE of its 1e5 .. 8e5 pre-activations landing
+    on the other side of zero than in fp64 moves every gradient of the step by 2e-4 .. 1e-3.  That is a coin flip per
+    engine, kernel and seed: at 32 x 32 about one seed in three has such a unit, at 64 x 64 (four times the units) three to
+    five in six (tools/debug/step_seeds_64.py; changing the summation order of the generator's RGB-out convolution --
+    to a MORE accurate kernel -- moved them to other seeds).  With the same sign pattern on both sides the comparison
+    measures arithmetic and nothing else; one un-forced seed per case stays, bounded at the flipped-unit level."""
+    tol = _WELL_TOL[(model, size, kind)]
+    worst = [_well_conditioned_worst(dev, model, size, kind, seed, same_head_signs=True) for seed in (5, 6, 7)]
     print(f"\nwell-conditioned {model} {size} {kind}: worst tensor per seed " + ", ".join(f"{w[0]:.2e} ({w[1]})" for w in worst))
-    errs = sorted(w[0] for w in worst)
-    assert errs[1] < _WELL_TOL[(model, size, kind)], worst
-    assert errs[-1] < 3e-3, worst                 # a flipped head unit: bounded, not tight
+    assert max(w[0] for w in worst) < tol, worst
+    free = _well_conditioned_worst(dev, model, size, kind, 5)
+    print(f"  un-forced head signs, seed 5: {free[0]:.2e} ({free[1]})")
+    assert free[0] < 3e-3, free                 # a flipped head unit: bounded, not tight
 
 
 def _ema_critic_errors(dev, seed):
