@@ -1696,6 +1696,127 @@ __global__ __launch_bounds__(320) void conv_outer2_kernel(Outer2Args a) {
   }
 }
 
+// The same weight gradient on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32, exact fp32 products): per filter row kh a GEMM
+//     dW[(kh, kw)][d][j] = sum_pix  wide[pix][d] * narrow[pix + sgn * ((kh, kw) - pad)][j]
+// with M = wide channels, N = (kw, j) (15 of 16 columns for a 5 x 5 RGB layer) and K = pixels.  A lane loads one float4 of
+// wide (4 channels of one of the group's 4 pixels: a wave-load is 4 pixels x 256 contiguous bytes) and feeds its elements to
+// four MFMAs -- 64 channels per wave, the channel of output row i of MFMA s is 4 i + s -- against one ds_read_b32 per filter
+// row of the narrow tile (a lane reads the pixel its column's kw points at).  KH x 4 accumulator tiles per wave; a
+// workgroup is 2 channel groups x 2 pixel streams, the streams are added through LDS at the end.  Same arguments, slabs
+// and split as conv_outer2_kernel.  5.4 GFLOP for the DCGAN RGB-out layer: 34 us at the fp32 matrix peak.
+template <int ACT, int KH>
+__global__ __launch_bounds__(256) void conv_outer_mfma_kernel(Outer2Args a) {
+  extern __shared__ __attribute__((aligned(16))) float4 s_nm[];   // narrow tile [(TRo + 4)][(W + 4)] float4; then the stream reduction
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cg = wave & 1, ps = wave >> 1;
+  const int li = lane & 15, kq = lane >> 4;
+  const int d = blockIdx.x * 128 + cg * 64 + 4 * li;     // the lane's channel quad (A operand); rows 4 li + s of the outputs
+  const bool cok = d < a.wideC;
+  int sc = d;
+  float sgnw = 1.f;
+  if (a.wide_is_x && cok) {
+    GatherA gm;
+    gm.cmap = a.cmap; gm.Creal = a.Creal; gm.doubled = a.doubled;
+    decode_map(gm, d, a.cmap ? a.cmap[d] : 0, sc, sgnw);
+  }
+  // the lane's B column: n = li -> (kw, j); columns past KW * J compute garbage that is never stored
+  const int ncol = a.KW * a.J;
+  const int kwn = li < ncol ? li / a.J : a.KW - 1, jn = li < ncol ? li - kwn * a.J : 0;
+  const int LW = a.W + 2 * kOuterHalo;
+  const int boff = (kOuterHalo + kq + a.sgn * (kwn - a.pw)) * 4 + jn;   // float index inside a tile row, pixel group at column 0
+  f32x4 acc[KH][4];
+#pragma unroll
+  for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) acc[kh][s_] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int units_per_img = a.H / a.TRo;
+  const int u0 = blockIdx.y * a.units_per_block;
+  int u1 = u0 + a.units_per_block;
+  if (u1 > a.units) u1 = a.units;
+  const int groups = a.TRo * (a.W >> 2);     // 4-pixel groups of a unit
+  const int logW4 = a.logW - 2;
+  const float* s_nf = reinterpret_cast<const float*>(s_nm);
+  for (int u = u0; u < u1; ++u) {
+    const int n = u / units_per_img, r0 = (u - n * units_per_img) * a.TRo;
+    const long img = (long)n * a.H * a.W;
+    __syncthreads();   // previous unit's tile fully consumed
+    for (int i = tid; i < (a.TRo + 2 * kOuterHalo) * LW; i += 256) {
+      const int lr = i / LW, lc = i - lr * LW;
+      const int r = r0 - kOuterHalo + lr, q = lc - kOuterHalo;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)r < (unsigned)a.H && (unsigned)q < (unsigned)a.W) {
+        const float* np = a.narrow + (img + (long)r * a.W + q) * a.ldn;
+        v.x = np[0];
+        if (a.J > 1) v.y = np[1];
+        if (a.J > 2) v.z = np[2];
+        if (a.J > 3) v.w = np[3];
+        if (!a.wide_is_x) {   // the narrow operand is the layer input: pre-activation applies to it
+          v.x = act_apply<ACT>(v.x); v.y = act_apply<ACT>(v.y); v.z = act_apply<ACT>(v.z); v.w = act_apply<ACT>(v.w);
+        }
+      }
+      s_nm[i] = v;
+    }
+    __syncthreads();
+    // two groups per iteration: both loads in flight before the first MFMA
+    for (int gq = ps; gq < groups; gq += 4) {
+      float4 wv[2];
+      int row[2], col[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int gi = gq + 2 * h;
+        row[h] = gi >> logW4;
+        col[h] = (gi & ((a.W >> 2) - 1)) << 2;
+        wv[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cok && gi < groups)
+          wv[h] = *reinterpret_cast<const float4*>(a.wide + (img + (long)(r0 + row[h]) * a.W + col[h] + kq) * a.ldw + sc);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (gq + 2 * h >= groups) break;   // block-uniform
+        if (a.wide_is_x) {
+          wv[h].x = act_apply<ACT>(sgnw * wv[h].x); wv[h].y = act_apply<ACT>(sgnw * wv[h].y);
+          wv[h].z = act_apply<ACT>(sgnw * wv[h].z); wv[h].w = act_apply<ACT>(sgnw * wv[h].w);
+        }
+        const float* nb = s_nf + ((row[h] + kOuterHalo) * LW + col[h]) * 4 + boff;
+        float bv[KH];
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) bv[kh] = nb[a.sgn * (kh - a.ph) * LW * 4];
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+          acc[kh][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[h].x, bv[kh], acc[kh][0], 0, 0, 0);
+          acc[kh][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[h].y, bv[kh], acc[kh][1], 0, 0, 0);
+          acc[kh][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[h].z, bv[kh], acc[kh][2], 0, 0, 0);
+          acc[kh][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[h].w, bv[kh], acc[kh][3], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // add the two pixel streams through LDS (stream 1 writes, stream 0 adds and stores)
+  __syncthreads();
+  f32x4* red = reinterpret_cast<f32x4*>(s_nm) + (size_t)cg * KH * 4 * 64;
+  if (ps == 1) {
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) red[(kh * 4 + s_) * 64 + lane] = acc[kh][s_];
+  }
+  __syncthreads();
+  if (ps == 0 && li < ncol) {
+    float* out = a.slab + (long)blockIdx.y * a.slab_stride;
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        const f32x4 v = acc[kh][s_] + red[(kh * 4 + s_) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int dd = blockIdx.x * 128 + cg * 64 + 4 * (4 * kq + q) + s_;   // output row i = 4 kq + q -> channel 4 i + s
+          if (dd < a.wideC) out[(long)(kh * a.KW + kwn) * a.sT + (long)dd * a.sC + jn * a.sJ] = v[q];
+        }
+      }
+  }
+}
+
 // out[i] = sum_k slab[k][i], deterministic.  A 256-thread block owns 64 groups of VW consecutive elements; its four
 // waves take the splits k = w, w + 4, ... (four independent loads in flight each) and are combined through LDS in
 // wave order.  (One thread per element summing all splits in sequence: 33 us for 100 slabs of 72 K floats, 0.85 TB/s,
@@ -3035,7 +3156,23 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
       size_t lds = sizeof(float4) * (o2.TRo + 2 * kOuterHalo) * (d->W + 2 * kOuterHalo);
       const size_t red = sizeof(float) * (size_t)d->KH * 32 * d->KW * 16;
       if (red > lds) lds = red;
-      {
+      static const bool mfma_off = getenv("OTGAN_DISABLE_OUTER_MFMA") != nullptr;
+      if (!mfma_off && d->KH == d->KW && d->KW * oa.J <= 16 && d->W % 4 == 0 && (o2.TRo * d->W) % 16 == 0) {
+        // fp32 matrix pipe: 2 channel groups x 2 pixel streams per workgroup
+        size_t l2 = sizeof(float4) * (o2.TRo + 2 * kOuterHalo) * (d->W + 2 * kOuterHalo);
+        const size_t r2 = sizeof(float4) * 2 * (size_t)d->KH * 4 * 64;
+        if (r2 > l2) l2 = r2;
+        ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * (double)p.M * (double)p.slab_elems, 0.0, s);
+#define OTGAN_OUTERM(ACT_)                                                                              \
+  do {                                                                                                  \
+    if (d->KW == 5) hipLaunchKernelGGL((conv_outer_mfma_kernel<ACT_, 5>), g2, dim3(256), l2, s, o2);    \
+    else hipLaunchKernelGGL((conv_outer_mfma_kernel<ACT_, 3>), g2, dim3(256), l2, s, o2);               \
+  } while (0)
+        if (act == 1) OTGAN_OUTERM(1);
+        else if (act == 2) OTGAN_OUTERM(2);
+        else OTGAN_OUTERM(0);
+#undef OTGAN_OUTERM
+      } else {
         ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * (double)p.M * (double)p.slab_elems, 0.0, s);
 #define OTGAN_OUTER2(ACT_)                                                                              \
   do {                                                                                                  \
