@@ -292,6 +292,14 @@ int otgan_adam_step_f32(float* p, const float* grad, float* v, float* mg, long n
 int otgan_adam_step_gather_f32(float* p, const float* const* grads, const long* offsets, int nseg, float* v, float* mg,
                                double lr, double mom1, double mom2, double t, float* ema_shadow, double ema_decay,
                                void* stream);
+/* Up to OTGAN_COPY2D_MAX_SEGMENTS strided 2-D copies in ONE launch: dst[s][r * dst_ld[s] + c] = src[s][r * src_ld[s] + c]
+ * for r < rows[s], c < cols[s].  All arrays are HOST arrays of nseg entries.  (The growth layers of a DenseNet block read
+ * sub-blocks of their normalised weights -- rows of every filter tap, models/densenet.py:11-16 through
+ * ops.py DenseBlockFunction -- as contiguous tensors: 28 slices per block and weight version, one launch instead of
+ * 28 framework copies.) */
+#define OTGAN_COPY2D_MAX_SEGMENTS 64
+int otgan_copy2d_batched_f32(const float* const* src, float* const* dst, const int* rows, const int* cols,
+                             const long* src_ld, const long* dst_ld, int nseg, void* stream);
 int otgan_adamax_step_f32(float* p, const float* grad, float* v, float* mg, long n, double lr,
                           double mom1, double mom2, void* stream);
 int otgan_nesterov_step_f32(float* p, const float* grad, float* v, long n, double lr, double mom1,

@@ -560,6 +560,43 @@ __global__ void nesterov_kernel(float* __restrict__ p, const float* __restrict__
 // = variable, so no thread ever searches for its segment; same arithmetic, element by element, as adam_kernel.  With
 // `sh` the EMA of the updated parameters (train.py:63-64,223: shadow <- decay * shadow + (1 - decay) * p) rides along:
 // one read of p less than a separate pass, one launch less.
+// ---- batched strided 2-D copies (otgan_copy2d_batched_f32) ----
+struct Copy2dSegs {
+  const float* src[OTGAN_COPY2D_MAX_SEGMENTS];
+  float* dst[OTGAN_COPY2D_MAX_SEGMENTS];
+  int rows[OTGAN_COPY2D_MAX_SEGMENTS], cols[OTGAN_COPY2D_MAX_SEGMENTS];
+  long sld[OTGAN_COPY2D_MAX_SEGMENTS], dld[OTGAN_COPY2D_MAX_SEGMENTS];
+};
+__global__ __launch_bounds__(256) void copy2d_batched_kernel(Copy2dSegs g) {
+  const int sg = blockIdx.y;
+  const int rows = g.rows[sg], cols = g.cols[sg];
+  const float* __restrict__ src = g.src[sg];
+  float* __restrict__ dst = g.dst[sg];
+  const long sld = g.sld[sg], dld = g.dld[sg];
+  const long total = (long)rows * cols;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / cols, c = i - r * cols;
+    dst[r * dld + c] = src[r * sld + c];
+  }
+}
+extern "C" int otgan_copy2d_batched_f32(const float* const* src, float* const* dst, const int* rows, const int* cols,
+                                        const long* src_ld, const long* dst_ld, int nseg, void* stream) {
+  OTGAN_CHECK_ARG(src && dst && rows && cols && src_ld && dst_ld && nseg > 0 && nseg <= OTGAN_COPY2D_MAX_SEGMENTS, "bad arguments");
+  Copy2dSegs g;
+  long most = 0;
+  for (int i = 0; i < nseg; ++i) {
+    OTGAN_CHECK_ARG(src[i] && dst[i] && rows[i] > 0 && cols[i] > 0 && src_ld[i] >= cols[i] && dst_ld[i] >= cols[i], "bad segment");
+    g.src[i] = src[i]; g.dst[i] = dst[i]; g.rows[i] = rows[i]; g.cols[i] = cols[i]; g.sld[i] = src_ld[i]; g.dld[i] = dst_ld[i];
+    const long t = (long)rows[i] * cols[i];
+    most = t > most ? t : most;
+  }
+  long bx = (most + 256 * 4 - 1) / (256 * 4);
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(copy2d_batched_kernel, dim3((unsigned)bx, (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, g);
+  OTGAN_CHECK_LAUNCH("copy2d_batched");
+  return OTGAN_OK;
+}
+
 struct AdamSegs {
   const float* g[OTGAN_ADAM_MAX_SEGMENTS];
   long off[OTGAN_ADAM_MAX_SEGMENTS + 1];

@@ -540,11 +540,30 @@ def _split_block_weights(Vs, per_layer, plan, F):
     val = {"wide": [_wide_operands(per_layer, range(wd["d0"], L), wd["row0"], wd["nrows"], wd["order"], F, wd["desc"])
                     for wd in plan["wide"]],
            "w_g": [None] * L, "wT_g": [None] * L}
-    for k in range(L):
-        r0 = plan["own_row0"][k]
-        if plan["own_len"][k]:
-            val["w_g"][k] = per_layer[k][0].view(9, -1, F)[:, r0:, :].contiguous().view(-1, F)
-            val["wT_g"][k] = per_layer[k][1].view(F, 9, -1)[:, :, r0:].contiguous().view(F, -1)
+    # every layer's own-chain rows (rows r0 .. of each of the 9 taps) as contiguous tensors: two flat buffers carved
+    # into the layers' slices, filled by ONE batched strided copy (28 slices per 16-layer block; as framework copies these
+    # were 100 of the DenseNet step's launches)
+    own = [k for k in range(L) if plan["own_len"][k]]
+    if own:
+        dev, dt = per_layer[own[0]][0].device, per_layer[own[0]][0].dtype
+        sizes = [9 * (per_layer[k][0].shape[0] // 9 - plan["own_row0"][k]) * F for k in own]
+        flat_w = torch.empty(sum(sizes), dtype=dt, device=dev)
+        flat_wT = torch.empty(sum(sizes), dtype=dt, device=dev)
+        segs, off = [], 0
+        for k, sz in zip(own, sizes):
+            r0 = plan["own_row0"][k]
+            ceff = per_layer[k][0].shape[0] // 9
+            n_own = ceff - r0
+            w_k, wT_k = per_layer[k][0], per_layer[k][1]
+            assert w_k.is_contiguous() and wT_k.is_contiguous()
+            val["w_g"][k] = flat_w[off:off + sz].view(9 * n_own, F)
+            val["wT_g"][k] = flat_wT[off:off + sz].view(F, 9 * n_own)
+            # w [9][ceff][F] -> [9][n_own][F]: 9 rows of n_own * F floats;  wT [F * 9][ceff] -> [F * 9][n_own]
+            segs.append((w_k.data_ptr() + 4 * r0 * F, val["w_g"][k].data_ptr(), 9, n_own * F, ceff * F, n_own * F))
+            segs.append((wT_k.data_ptr() + 4 * r0, val["wT_g"][k].data_ptr(), 9 * F, n_own, ceff, n_own))
+            off += sz
+        copy2d_batched(segs)
+        val["_own_flat"] = (flat_w, flat_wT)
     _block_cache[key] = (ws, val, plan["key"])
     while len(_block_cache) > 64:
         _block_cache.popitem(last=False)
@@ -943,6 +962,26 @@ def adam_step_gather(p_flat, grads, offsets, v, mg, lr, mom1, mom2, t, ema_shado
                                                      ctypes.cast(off, ctypes.c_void_p), n, _lib.ptr(v), mg.data_ptr(),
                                                      float(lr), float(mom1), float(mom2), float(t), _lib.ptr(ema_shadow),
                                                      float(ema_decay), _lib.stream_ptr()), "adam_step_gather")
+
+
+COPY2D_MAX_SEGMENTS = 64   # include/otgan_layers.h
+
+
+def copy2d_batched(segs):
+    """Strided 2-D copies in one launch (otgan_copy2d_batched_f32): segs = [(src_ptr, dst_ptr, rows, cols, src_ld, dst_ld)],
+    element units, at most COPY2D_MAX_SEGMENTS per launch (longer lists take several)."""
+    for i0 in range(0, len(segs), COPY2D_MAX_SEGMENTS):
+        part = segs[i0:i0 + COPY2D_MAX_SEGMENTS]
+        n = len(part)
+        src = (ctypes.c_void_p * n)(*[q[0] for q in part])
+        dst = (ctypes.c_void_p * n)(*[q[1] for q in part])
+        rows = (ctypes.c_int * n)(*[q[2] for q in part])
+        cols = (ctypes.c_int * n)(*[q[3] for q in part])
+        sld = (ctypes.c_long * n)(*[q[4] for q in part])
+        dld = (ctypes.c_long * n)(*[q[5] for q in part])
+        cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+        _lib.check(_lib.lib().otgan_copy2d_batched_f32(cast(src), cast(dst), cast(rows), cast(cols), cast(sld), cast(dld), n,
+                                                       _lib.stream_ptr()), "copy2d_batched")
 
 
 def adamax_step(p, grad, v, mg, lr, mom1, mom2):
