@@ -9,8 +9,8 @@ def cls_of(name):
     m = re.search(r"conv_igemm_kernel<GemmCfg<[^>]*>, (true|false), (\d), (\d)>", name)
     if m:
         return "conv_fwd" if m.group(2) == "0" else "conv_dgrad"
-    if "conv_fewout_kernel" in name:
-        return "conv_fewout(fwd|dgrad)"
+    if "conv_fewout" in name or "conv_rgbin" in name:          # (VALU / fp32-matrix-pipe kernels of the RGB layers)
+        return "conv_few_channels(fwd|dgrad)"
     if "wino_bgemm_x3_kernel" in name or "wino_bgemm_x3n_kernel" in name or "wino_bgemm_x3_stream_kernel" in name:
         return "wino_gemm_bf16x3"
     if "wino_bgemm_kernel" in name:
@@ -21,7 +21,7 @@ def cls_of(name):
         return "conv_dgrad"
     if "dense16_wgrad" in name:
         return "conv_wgrad"
-    if "conv_wgrad" in name or "conv_outer_kernel" in name:
+    if "conv_wgrad" in name or "conv_outer" in name:
         return "conv_wgrad"
     if "cost_partial_kernel" in name:
         return "cost_gemm"
