@@ -274,6 +274,21 @@ struct ConvALoader {
       }
     }
   }
+  // ... as two scaled fp16 planes (gemm_mainloop_x2h)
+  float xs = 1.f;
+  __device__ __forceinline__ void store2(unsigned char* t) const {
+    const int c4 = threadIdx.x % CPR, r0 = threadIdx.x / CPR;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int r = r0 + p * RPP;
+      if (r < BR) {
+        float4 v = reg[p];
+        v.x = act_apply<ACT>(v.x * sgn) * xs; v.y = act_apply<ACT>(v.y * sgn) * xs;
+        v.z = act_apply<ACT>(v.z * sgn) * xs; v.w = act_apply<ACT>(v.w * sgn) * xs;
+        x2h_store4(t, BR * kX3sRowBytes, r, 4 * c4, v);
+      }
+    }
+  }
 };
 
 // Weight ("B") operand: element (n, k=(tap, c)) at w[boff[tap] + row(n)*ldbn + c].
@@ -394,6 +409,19 @@ struct ConvBLoader {
       if (r < BR) x3s_store4(t, BR * kX3sRowBytes, r, 4 * c4, reg[p]);
     }
   }
+  float xs = 1.f;
+  __device__ __forceinline__ void store2(unsigned char* t) const {
+    const int c4 = threadIdx.x % CPR, r0 = threadIdx.x / CPR;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int r = r0 + p * RPP;
+      if (r < BR) {
+        float4 v = reg[p];
+        v.x *= xs; v.y *= xs; v.z *= xs; v.w *= xs;
+        x2h_store4(t, BR * kX3sRowBytes, r, 4 * c4, v);
+      }
+    }
+  }
 };
 
 // ---------------------------------------------------------------------------------------
@@ -412,9 +440,15 @@ struct EpiArgs {
   const float* xsrc;     // dgrad: layer input (activation derivative), stored resolution
   int ldxs, xH, xW, logUpX;
   int act;               // 1 relu-type, 2 elu-type
+  // XS == 2 (two scaled fp16 pieces): amax records of the A tensor (x / dy) and of the weights; floor_one: the A operand
+  // passes an ELU-type activation (|elu(x)| <= max(|x|, 1))
+  const float* amax_a;
+  const float* amax_b;
+  int floor_one;
 };
 
-template <class Cfg, bool VEC, int EPI, int ACT, bool X3S = false>
+// XS: 0 fp32 MFMA, 1 three bf16 pieces (six MFMAs per product), 2 two scaled fp16 pieces (three)
+template <class Cfg, bool VEC, int EPI, int ACT, int XS = 0>
 __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, ClassTab ct,
                                                                  WeightB wb, EpiArgs e) {
   using LA = ConvALoader<Cfg, Cfg::BM, VEC, ACT>;
@@ -431,8 +465,21 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Cla
   typename Cfg::acc_t acc[Cfg::MT][Cfg::NT];
   zero_acc<Cfg>(acc);
   const int nkt = VEC ? taps.n * ((g.Ck + Cfg::BK - 1) / Cfg::BK) : (taps.n * g.Ck + Cfg::BK - 1) / Cfg::BK;
-  if constexpr (X3S) gemm_mainloop_x3s<Cfg>(la, lb, nkt, reinterpret_cast<unsigned char*>(smem), acc);   // bf16 pipe, three pieces
-  else gemm_mainloop<Cfg>(la, lb, nkt, smem, acc);
+  float descale = 1.f;
+  if constexpr (XS == 2) {
+    float aA = amax_record_value(e.amax_a);
+    const float aB = amax_record_value(e.amax_b);
+    if (e.floor_one && aA == aA) aA = fmaxf(aA, 1.f);
+    int eA, eB;
+    la.xs = x2h_scale(aA, &eA);
+    lb.xs = x2h_scale(aB, &eB);
+    descale = __builtin_ldexpf(1.f, eA + eB - 28);
+    gemm_mainloop_x2h<Cfg>(la, lb, nkt, reinterpret_cast<unsigned char*>(smem), acc);
+  } else if constexpr (XS == 1) {
+    gemm_mainloop_x3s<Cfg>(la, lb, nkt, reinterpret_cast<unsigned char*>(smem), acc);   // bf16 pipe, three pieces
+  } else {
+    gemm_mainloop<Cfg>(la, lb, nkt, smem, acc);
+  }
 
   const int oa = ct.oa[cls], ob = ct.ob[cls];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -456,7 +503,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Cla
           const long xpix = ((long)n * e.xH + (oh >> e.logUpX)) * e.xW + (ow >> e.logUpX);
           const float xv = e.xsrc[xpix * e.ldxs + c];
           // d/dx [act(x) ; act(-x)] . [g+ ; g-] = act'(x) g+ - act'(-x) g-
-          const float gp = acc[mt][0][r], gn = acc[mt][Cfg::NT - 1][r];
+          const float gp = acc[mt][0][r] * descale, gn = acc[mt][Cfg::NT - 1][r] * descale;
           const float v = act_deriv(e.act, xv) * gp - act_deriv(e.act, -xv) * gn;
           float* dst = e.out + opix * e.ldo + e.coff + c;
           *dst = e.accumulate ? (*dst + v) : v;
@@ -466,7 +513,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Cla
         for (int nt = 0; nt < Cfg::NT; ++nt) {
           const int col = nblk * Cfg::BN + (wn * Cfg::NT + nt) * Cfg::TS + lcol;
           if (col >= e.ncols) continue;
-          float v = acc[mt][nt][r];
+          float v = acc[mt][nt][r] * descale;
           if (EPI == EPI_FWD) {
             v += e.bias ? e.bias[col] : 0.f;
           } else if (EPI == EPI_DG_ACT) {
@@ -1464,6 +1511,36 @@ __global__ __launch_bounds__(256) void conv_rgbin_fwd_kernel(FewInArgs a) {
 
 // set by a pass whose output kernel fills the requested otgan_conv_desc::y_amax_out / dx_amax_out record itself; the
 // entry points run a separate reduction of the output otherwise
+// amax records of the two operand tensors of a generic implicit GEMM, for its two-scaled-fp16-piece main loop (three
+// MFMAs per product instead of six on three bf16 pieces): the caller's records when it has them (otgan_conv_desc::
+// x_amax / dy_amax / w_amax), else reduced here into two scratch records at the tail of the workspace (one pass over the
+// tensor each: 60 us for a 300 MB block buffer against 250 us saved in the GEMM).  Leaves e.amax_a / e.amax_b null --
+// the three-piece loop runs -- when the tensors do not qualify or the workspace has no room.  OTGAN_IGEMM_X2H=0: never.
+static void igemm_records(EpiArgs& e, const float* a_rec, const float* a, long a_rows, int a_C, long a_ld,
+                          const float* b_rec, const float* b, long b_elems, int elu_type, void* workspace,
+                          size_t workspace_bytes, size_t ws_used, hipStream_t s) {
+  static const bool off = [] { const char* v = getenv("OTGAN_IGEMM_X2H"); return v && v[0] == '0'; }();
+  e.amax_a = e.amax_b = nullptr;
+  e.floor_one = elu_type ? 1 : 0;
+  if (off || wino_pieces() != 2) return;
+  const size_t rec_bytes = sizeof(float) * OTGAN_AMAX_RECORD_FLOATS;
+  float* scratch = nullptr;
+  const size_t at = (ws_used + 255) / 256 * 256;
+  if (workspace && at + 2 * rec_bytes <= workspace_bytes) scratch = reinterpret_cast<float*>(static_cast<char*>(workspace) + at);
+  if (!a_rec) {
+    if (!scratch || a_C % 4 || a_ld % 4 || (reinterpret_cast<uintptr_t>(a) & 15)) return;
+    wino_p2::wino_absmax(a, a_rows, a_C, a_ld, scratch, s);
+    a_rec = scratch;
+  }
+  if (!b_rec) {
+    if (!scratch || b_elems % 4 || (reinterpret_cast<uintptr_t>(b) & 15)) return;
+    wino_p2::wino_absmax(b, 1, (int)b_elems, 0, scratch + OTGAN_AMAX_RECORD_FLOATS, s);
+    b_rec = scratch + OTGAN_AMAX_RECORD_FLOATS;
+  }
+  e.amax_a = a_rec;
+  e.amax_b = b_rec;
+}
+
 static thread_local bool g_amax_written = false;
 
 static bool launch_rgbin_fwd(const otgan_conv_desc* d, int pad_t, int pad_l, const float* x, const float* wT,
@@ -2293,9 +2370,15 @@ template <class Cfg, int EPI, int ACT>
 void launch_igemm3_x3s(dim3 grid, hipStream_t s, const GatherA& ga, const ClassTab& ct, const WeightB& wb,
                        const EpiArgs& e) {
   static_assert(Cfg::BK == 16 && Cfg::TS == 32, "");
+  if (e.amax_a && e.amax_b) {   // both records at hand: two scaled fp16 pieces, three MFMAs per product
+    constexpr size_t lds2 = X2hLds<Cfg>::BYTES;
+    ensure_lds<conv_igemm_kernel<Cfg, true, EPI, ACT, 2>>(lds2);
+    hipLaunchKernelGGL((conv_igemm_kernel<Cfg, true, EPI, ACT, 2>), grid, dim3(Cfg::THREADS), lds2, s, ga, ct, wb, e);
+    return;
+  }
   constexpr size_t lds = X3sLds<Cfg>::BYTES;
-  ensure_lds<conv_igemm_kernel<Cfg, true, EPI, ACT, true>>(lds);
-  hipLaunchKernelGGL((conv_igemm_kernel<Cfg, true, EPI, ACT, true>), grid, dim3(Cfg::THREADS), lds, s, ga, ct, wb, e);
+  ensure_lds<conv_igemm_kernel<Cfg, true, EPI, ACT, 1>>(lds);
+  hipLaunchKernelGGL((conv_igemm_kernel<Cfg, true, EPI, ACT, 1>), grid, dim3(Cfg::THREADS), lds, s, ga, ct, wb, e);
 }
 inline bool igemm_x3s() {
   static const bool on = [] {
@@ -2459,11 +2542,12 @@ size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which) {
                                                                          : WINO(wino_s2_wgrad_ws_floats)(w);
     s2 = align_up(sizeof(float) * fl, 256) + 256;
   }
+  const size_t recs = 256 + 2 * sizeof(float) * OTGAN_AMAX_RECORD_FLOATS;   // igemm_records()
   if (which == 1) {
     // legacy (un-folded) dgrad through a 2x upsample: gradient on the virtual grid
-    const size_t gen = (d->upsample && !g.fold)
+    const size_t gen = ((d->upsample && !g.fold)
                ? align_up(sizeof(float) * (size_t)d->N * g.Hin * g.Win * d->C, 256)
-               : 256;
+               : 0) + recs;
     return gen > s2 ? gen : s2;
   }
   if (which == 2) {
@@ -2473,7 +2557,7 @@ size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which) {
     const size_t gen = align_up(sizeof(float) * slabs, 256) + 256;
     return gen > s2 ? gen : s2;
   }
-  return s2 > 256 ? s2 : 256;
+  return s2 > recs ? s2 : recs;
 }
 
 size_t otgan_conv2d_filter_bytes(const otgan_conv_desc* d, int which) {
@@ -2754,6 +2838,9 @@ static int conv2d_fwd_body(const otgan_conv_desc* d, const float* x, const int32
   flops = 2.0 * ga.Mtot * (double)Ktot * d->Cout;
   ProfScope ps(OTGAN_PROF_CONV_FWD, flops, 0.0, s);
   const int act = act_kind(d->preact);
+  if (vec && (long)Ktot * d->Cout < (1L << 31))
+    igemm_records(e, d->x_amax, x, (long)d->N * d->H * d->W, d->C, d->ldx, d->w_amax, wT, (long)Ktot * d->Cout, act == 2,
+                  workspace, workspace_bytes, 0, s);
   launch_fwd(act, vec, g.Ceff, ga.Mtot, d->Cout, 1, s, ga, ct, wb, e);
   OTGAN_CHECK_LAUNCH("conv2d fwd");
   return OTGAN_OK;
@@ -3015,6 +3102,13 @@ static int conv2d_dgrad_body(const otgan_conv_desc* d, const float* dy, const fl
   }
   {
     ProfScope ps(OTGAN_PROF_CONV_DGRAD, flops, 0.0, s);
+    if (vec && !g.fold) {
+      const size_t used = pool ? sizeof(float) * (size_t)d->N * g.Hin * g.Win * d->C : 0;
+      const long welems = (long)d->KH * d->KW * g.Ceff * d->Cout;
+      if (welems < (1L << 31))
+        igemm_records(e, d->dy_amax, dy + d->y_coff, (long)d->N * g.OH * g.OW, d->Cout, d->ldy, d->w_amax, w, welems, 0, workspace,
+                      workspace_bytes, used, s);
+    }
     if (paired) launch_igemm<EPI_DG_PAIR, 0>(vec, d->Cout, ga.Mtot, d->C, true, ct.ncls, s, ga, ct, wb, e);
     else if (kind) launch_igemm<EPI_DG_ACT, 0>(vec, d->Cout, ga.Mtot, d->C, false, ct.ncls, s, ga, ct, wb, e);
     else launch_igemm<EPI_DG_PLAIN, 0>(vec, d->Cout, ga.Mtot, d->C, false, ct.ncls, s, ga, ct, wb, e);

@@ -212,6 +212,100 @@ __device__ __forceinline__ void gemm_mainloop_x3s(LA& la, LB& lb, int nkt, unsig
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Two scaled fp16 pieces (round 3): x * 2^s = hi + lo, 22 significand bits, THREE v_mfma_f32_32x32x16_f16 per 16-wide
+// k slab (hi*hi, hi*lo, lo*hi) instead of six on three bf16 pieces -- the arithmetic of the Winograd-domain GEMMs
+// (gemm_x3.h) in the implicit-GEMM main loop.  One power-of-two scale per OPERAND TENSOR, from its largest magnitude
+// (an amax record, common.h): the loaders multiply while staging (`xs`), the epilogue multiplies the sums by the inverse
+// product (exact).  Same LDS layout as above with two planes: 32 KB for a 128 x 128 tile.
+// A loader provides store2(unsigned char* tile) and a public `float xs`.
+// ---------------------------------------------------------------------------------------
+typedef _Float16 gt_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 gt_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void x2h_store4(unsigned char* tile, int plane, int r, int k, float4 v) {
+  gt_f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+  const gt_f16x2 ha = __builtin_convertvector(a, gt_f16x2), hb = __builtin_convertvector(b, gt_f16x2);
+  a -= __builtin_convertvector(ha, gt_f32x2);
+  b -= __builtin_convertvector(hb, gt_f32x2);
+  const gt_f16x2 la = __builtin_convertvector(a, gt_f16x2), lb = __builtin_convertvector(b, gt_f16x2);
+  unsigned char* d = tile + x3s_off(r, k);
+  *reinterpret_cast<gt_u32x2*>(d) = gt_u32x2{__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb)};
+  *reinterpret_cast<gt_u32x2*>(d + plane) = gt_u32x2{__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb)};
+}
+// scale of a tensor with largest magnitude amax: |x| 2^(14 - e) < 2^14 with amax = m 2^e, 0.5 <= m < 1; *e_out = e.
+// NaN / infinite amax: NaN scale (the result stays loud); all-zero tensor: e = 0.
+__device__ __forceinline__ float x2h_scale(float amax, int* e_out) {
+  int e = 0;
+  if (amax > 0.f) e = __builtin_amdgcn_frexp_expf(amax);
+  *e_out = e;
+  if (!(amax <= 3.0e38f)) return __builtin_nanf("");
+  return __builtin_ldexpf(1.f, 14 - e);
+}
+
+template <class Cfg>
+struct X2hLds {
+  static constexpr int PA = Cfg::BM * kX3sRowBytes, PB = Cfg::BN * kX3sRowBytes;   // plane bytes
+  static constexpr int TA = 2 * PA, TB = 2 * PB;                                   // one buffer of an operand
+  static constexpr int BYTES = 2 * (TA + TB);
+};
+
+template <class Cfg, class LA, class LB>
+__device__ __forceinline__ void gemm_mainloop_x2h(LA& la, LB& lb, int nkt, unsigned char* smem,
+                                                  typename Cfg::acc_t (&acc)[Cfg::MT][Cfg::NT]) {
+  constexpr int MT = Cfg::MT, NT = Cfg::NT, TS = Cfg::TS;
+  static_assert(TS == 32 && Cfg::BK == 16, "split-precision main loop: 32x32 tiles, BK = 16");
+  using L = X2hLds<Cfg>;
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + 2 * L::TA;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int li = lane & 31, lh = lane >> 5;
+  int a_off[MT], b_off[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) a_off[mt] = x3s_off((wm * MT + mt) * TS + li, 8 * lh);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) b_off[nt] = x3s_off((wn * NT + nt) * TS + li, 8 * lh);
+  if (nkt <= 0) return;
+  la.load(0);
+  lb.load(0);
+  la.store2(sA);
+  lb.store2(sB);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    const bool more = (kt + 1 < nkt);
+    if (more) {
+      la.load(kt + 1);
+      lb.load(kt + 1);
+    }
+    const unsigned char* pa = sA + cur * L::TA;
+    const unsigned char* pb = sB + cur * L::TB;
+    gt_f16x8 fa[2][MT], fb[2][NT];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) fa[p][mt] = *reinterpret_cast<const gt_f16x8*>(pa + p * L::PA + a_off[mt]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) fb[p][nt] = *reinterpret_cast<const gt_f16x8*>(pb + p * L::PB + b_off[nt]);
+    }
+    // lo*hi, hi*lo, hi*hi (smallest first); term-major: consecutive MFMAs never share an accumulator
+#pragma unroll
+    for (int term = 0; term < 3; ++term) {
+      constexpr int pa_of[3] = {1, 0, 0}, pb_of[3] = {0, 1, 0};
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[pa_of[term]][mt], fb[pb_of[term]][nt], acc[mt][nt], 0, 0, 0);
+    }
+    if (more) {
+      la.store2(sA + (cur ^ 1) * L::TA);
+      lb.store2(sB + (cur ^ 1) * L::TB);
+    }
+    __syncthreads();
+  }
+}
+
 template <class Cfg>
 __device__ __forceinline__ void zero_acc(typename Cfg::acc_t (&acc)[Cfg::MT][Cfg::NT]) {
 #pragma unroll

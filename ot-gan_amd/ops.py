@@ -335,6 +335,9 @@ class Conv2dFunction(torch.autograd.Function):
                                       "bwd_done": False, "bwd_which": 3 if unf_b else 1}
 
         wd, wT, inv_norm, filt = cached_weights(V, g, compute)
+        w_rec = amax_of(wT)              # left by the weight-norm kernel (same values in w and wT); the implicit-GEMM passes'
+        ctx.w_rec = w_rec                # two-piece fp16 loop scales the weights by it (else it reduces them itself)
+        desc.w_amax = w_rec.data_ptr() if w_rec is not None else None
         ctx.x_rec = None
         if filt["fwd"] is not None and x.is_contiguous() and C % 4 == 0:
             # Winograd passes: the record x's producer left (else one reduction of x), for the forward pass now and
@@ -383,6 +386,7 @@ class Conv2dFunction(torch.autograd.Function):
             if amax_fused(desc, 1) and ctx.inv is None:
                 dx_rec = amax_slot(x.device)
                 desc.dx_amax_out = dx_rec.data_ptr()
+            desc.w_amax = ctx.w_rec.data_ptr() if ctx.w_rec is not None else None    # (prepare_filters cleared it)
             conv_dgrad_raw(desc, dy, w, x, ctx.inv, dx, x.shape[3], False, filt["bwd"])
             desc.dx_amax_out = None
             if dx_rec is not None:
