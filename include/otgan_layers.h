@@ -66,8 +66,10 @@ typedef struct otgan_conv_desc {
    * takes the record as its x_amax / dy_amax and the separate reduction pass over the tensor (otgan_absmax_f32: one
    * more read of it) disappears.  otgan_conv2d_amax_fused(d, which) tells whether the pass does this inside its own
    * output kernel; otherwise a given record is filled by a separate reduction launch (same result).  Requires
-   * Cout % 4 == 0 (forward) / C % 4 == 0 (input gradient), 4-aligned channel strides; not with y_accumulate /
-   * accumulate (the record describes the values this call produced, not the sums in memory). */
+   * Cout % 4 == 0 (forward) / C % 4 == 0 (input gradient), 4-aligned channel strides.  y_amax_out with y_accumulate:
+   * the record receives the SUMS the call leaves in memory, so that several calls that finish different parts of a
+   * buffer can share one record (the growth layers and wide convolutions of a dense block); dx_amax_out: not with
+   * `accumulate`. */
   float* y_amax_out;
   float* dx_amax_out;
   /* Optional, otgan_conv2d_prepare_filters_f32 only: amax record of the NORMALISED weights the filters are made from

@@ -445,6 +445,7 @@ struct EpiArgs {
   const float* amax_a;
   const float* amax_b;
   int floor_one;
+  float* amax_out;       // fwd: amax record of the values written (otgan_conv_desc::y_amax_out), or null
 };
 
 // XS: 0 fp32 MFMA, 1 three bf16 pieces (six MFMAs per product), 2 two scaled fp16 pieces (three)
@@ -486,6 +487,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Cla
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int lcol = Cfg::acc_col(lane);
   const int gmask = (1 << g.logGW) - 1, hmask = (1 << g.logGH) - 1;
+  unsigned omax = 0u;
 #pragma unroll
   for (int mt = 0; mt < Cfg::MT; ++mt) {
 #pragma unroll
@@ -516,6 +518,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Cla
           float v = acc[mt][nt][r] * descale;
           if (EPI == EPI_FWD) {
             v += e.bias ? e.bias[col] : 0.f;
+            { const unsigned b_ = amax_bits(v); omax = b_ > omax ? b_ : omax; }
           } else if (EPI == EPI_DG_ACT) {
             const long xpix = ((long)n * e.xH + (oh >> e.logUpX)) * e.xW + (ow >> e.logUpX);
             v *= act_deriv(e.act, e.xsrc[xpix * e.ldxs + col]);
@@ -525,6 +528,9 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Cla
         }
       }
     }
+  }
+  if constexpr (EPI == EPI_FWD) {
+    if (e.amax_out) amax_commit(e.amax_out, omax);   // (every thread of the workgroup reaches this point)
   }
 }
 
@@ -1397,9 +1403,9 @@ __global__ __launch_bounds__(256) void conv_fewout_dgrad_kernel(FewDgArgs a) {
           for (int px = 0; px < 4; ++px) {
             const float4 dv = win[px + K - 1 - kw];
             fma4_pinned(acc[hf][px], wv[0], dv.x);
-            if (NJ > 1) fma4_pinned(acc[hf][px], wv[1], dv.y);
-            if (NJ > 2) fma4_pinned(acc[hf][px], wv[2], dv.z);
-            if (NJ > 3) fma4_pinned(acc[hf][px], wv[3], dv.w);
+            if constexpr (NJ > 1) fma4_pinned(acc[hf][px], wv[1], dv.y);
+            if constexpr (NJ > 2) fma4_pinned(acc[hf][px], wv[2], dv.z);
+            if constexpr (NJ > 3) fma4_pinned(acc[hf][px], wv[3], dv.w);
           }
         }
       }
@@ -1529,12 +1535,12 @@ static void igemm_records(EpiArgs& e, const float* a_rec, const float* a, long a
   if (workspace && at + 2 * rec_bytes <= workspace_bytes) scratch = reinterpret_cast<float*>(static_cast<char*>(workspace) + at);
   if (!a_rec) {
     if (!scratch || a_C % 4 || a_ld % 4 || (reinterpret_cast<uintptr_t>(a) & 15)) return;
-    wino_p2::wino_absmax(a, a_rows, a_C, a_ld, scratch, s);
+    wino_p2::wino_absmax(a, a_rows, a_C, a_ld, scratch, s, false);
     a_rec = scratch;
   }
   if (!b_rec) {
     if (!scratch || b_elems % 4 || (reinterpret_cast<uintptr_t>(b) & 15)) return;
-    wino_p2::wino_absmax(b, 1, (int)b_elems, 0, scratch + OTGAN_AMAX_RECORD_FLOATS, s);
+    wino_p2::wino_absmax(b, 1, (int)b_elems, 0, scratch + OTGAN_AMAX_RECORD_FLOATS, s, false);
     b_rec = scratch + OTGAN_AMAX_RECORD_FLOATS;
   }
   e.amax_a = a_rec;
@@ -2590,7 +2596,7 @@ static inline float* shared_x_operand(const otgan_conv_desc* d) {
 int otgan_absmax_f32(const float* x, long rows, int C, long ld, float* record, void* stream) {
   OTGAN_CHECK_ARG(x && record && aligned16(x) && aligned16(record), "null or misaligned pointer");
   OTGAN_CHECK_ARG(rows >= 1 && C >= 4 && C % 4 == 0 && (rows == 1 || (ld >= C && ld % 4 == 0)), "rows >= 1, C and ld multiples of 4, ld >= C");
-  WINO(wino_absmax)(x, rows, C, ld, record, (hipStream_t)stream);
+  WINO(wino_absmax)(x, rows, C, ld, record, (hipStream_t)stream, false);
   OTGAN_CHECK_LAUNCH("absmax");
   return OTGAN_OK;
 }
@@ -2599,12 +2605,16 @@ int otgan_conv2d_amax_fused(const otgan_conv_desc* d, int which) {
   Geo g;
   if (!d || make_geo(d, &g)) return 0;
   if (which == 0) {
-    if (d->y_accumulate || d->Cout % 4 || d->ldy % 4 || d->y_coff % 4) return 0;
+    if (d->Cout % 4 || d->ldy % 4 || d->y_coff % 4) return 0;
     if (wino_s2_ok(d, g)) return 1;                                   // the output transform of the strided / wide 3x3 passes
+    if (d->y_accumulate) return d->Cout == 16;                        // growth layers (dense16 kernels); else reduced afterwards
     // RGB-in layer (launch_rgbin_fwd)
-    return d->preact == OTGAN_ACT_NONE && d->C == 3 && d->stride == 1 && d->upsample == 0 && d->KH == d->KW &&
-           (d->KH == 5 || d->KH == 3) && d->Cout % 128 == 0 && d->W >= 16 && d->W <= 64 && 256 / d->W >= 4 &&
-           256 / d->W <= d->H && d->H % (256 / d->W) == 0;
+    if (d->preact == OTGAN_ACT_NONE && d->C == 3 && d->stride == 1 && d->upsample == 0 && d->KH == d->KW &&
+        (d->KH == 5 || d->KH == 3) && d->Cout % 128 == 0 && d->W >= 16 && d->W <= 64 && 256 / d->W >= 4 &&
+        256 / d->W <= d->H && d->H % (256 / d->W) == 0)
+      return 1;
+    // the implicit-GEMM kernel's epilogue (every layer that is neither folded, nor Winograd, nor a few-output layer)
+    return !wino_ok(d, g) && !g.fold && !wino_up3_ok(d, g) && d->Cout > 4 ? 1 : 0;
   }
   if (which == 1) return d->C % 4 == 0 && wino_s2_ok(d, g) ? 1 : 0;
   return 0;
@@ -2660,8 +2670,8 @@ static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32
                            const float* filters, const float* bias, float* y, void* workspace,
                            size_t workspace_bytes, void* stream) {
   if (d && d->y_amax_out) {
-    OTGAN_CHECK_ARG(!d->y_accumulate && d->Cout % 4 == 0 && d->ldy % 4 == 0 && d->y_coff % 4 == 0 && aligned16(y),
-                    "y_amax_out: needs Cout, ldy, y_coff multiples of 4, a 16-byte aligned y and no y_accumulate");
+    OTGAN_CHECK_ARG(d->Cout % 4 == 0 && d->ldy % 4 == 0 && d->y_coff % 4 == 0 && aligned16(y),
+                    "y_amax_out: needs Cout, ldy, y_coff multiples of 4 and a 16-byte aligned y");
   }
   g_amax_written = false;
   const int rc = conv2d_fwd_body(d, x, cmap, wT, filters, bias, y, workspace, workspace_bytes, stream);
@@ -2669,7 +2679,7 @@ static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32
     // this pass has no fused record: one reduction over the output it just wrote (same value)
     Geo g;
     make_geo(d, &g);
-    WINO(wino_absmax)(y + d->y_coff, (long)d->N * g.OH * g.OW, d->Cout, d->ldy, d->y_amax_out, (hipStream_t)stream);
+    WINO(wino_absmax)(y + d->y_coff, (long)d->N * g.OH * g.OW, d->Cout, d->ldy, d->y_amax_out, (hipStream_t)stream, true);
     OTGAN_CHECK_LAUNCH("conv2d fwd (amax of y)");
   }
   return rc;
@@ -2710,7 +2720,7 @@ static int conv2d_fwd_body(const otgan_conv_desc* d, const float* x, const int32
     w.x_op = shared_x_operand(d);
     ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * wino_s2_blocks(w) * (double)wino_s2_tiles(w) * g.Ceff * d->Cout, 0.0, s);
     rc = WINO(wino_s2_fwd)(w, x, wT, bias, y, (float*)workspace, s, filters);
-    g_amax_written = w.y_amax_out != nullptr && !w.y_accumulate;
+    g_amax_written = w.y_amax_out != nullptr;    // (with y_accumulate: the sums it wrote)
     OTGAN_CHECK_LAUNCH("conv2d fwd (winograd, stride 2)");
     return rc;
   }
@@ -2828,7 +2838,8 @@ static int conv2d_fwd_body(const otgan_conv_desc* d, const float* x, const int32
     dg.C = d->C; dg.Ceff = g.Ceff; dg.doubled = doubled_act(d->preact) ? 1 : 0;
     dg.act = act_kind(d->preact); dg.ldx = d->ldx; dg.cmap = cmap;
     ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * ga.Mtot * (double)Ktot * d->Cout, 0.0, s);
-    rc = dense16_fwd(dg, x, wT, bias, y, d->ldy, d->y_coff, d->y_accumulate, s);
+    rc = dense16_fwd(dg, x, wT, bias, y, d->ldy, d->y_coff, d->y_accumulate, s, d->y_amax_out);
+    g_amax_written = d->y_amax_out != nullptr;
     OTGAN_CHECK_LAUNCH("conv2d fwd (dense16)");
     return rc;
   }
@@ -2841,7 +2852,9 @@ static int conv2d_fwd_body(const otgan_conv_desc* d, const float* x, const int32
   if (vec && (long)Ktot * d->Cout < (1L << 31))
     igemm_records(e, d->x_amax, x, (long)d->N * d->H * d->W, d->C, d->ldx, d->w_amax, wT, (long)Ktot * d->Cout, act == 2,
                   workspace, workspace_bytes, 0, s);
+  e.amax_out = d->y_amax_out;
   launch_fwd(act, vec, g.Ceff, ga.Mtot, d->Cout, 1, s, ga, ct, wb, e);
+  g_amax_written = e.amax_out != nullptr;
   OTGAN_CHECK_LAUNCH("conv2d fwd");
   return OTGAN_OK;
 }
@@ -2877,7 +2890,7 @@ static int conv2d_dgrad_impl(const otgan_conv_desc* d, const float* dy, const fl
   g_amax_written = false;
   const int rc = conv2d_dgrad_body(d, dy, w, filters, x, inv, dx, lddx, accumulate, workspace, workspace_bytes, stream);
   if (rc == OTGAN_OK && d->dx_amax_out && !g_amax_written) {
-    WINO(wino_absmax)(dx, (long)d->N * d->H * d->W, d->C, lddx, d->dx_amax_out, (hipStream_t)stream);
+    WINO(wino_absmax)(dx, (long)d->N * d->H * d->W, d->C, lddx, d->dx_amax_out, (hipStream_t)stream, true);
     OTGAN_CHECK_LAUNCH("conv2d dgrad (amax of dx)");
   }
   return rc;

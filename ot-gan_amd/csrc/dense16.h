@@ -16,8 +16,9 @@ struct Dense16Geo {
 
 bool dense16_enabled();
 // y[pix, coff + n] (+)= bias[n] + sum_{tap, e} act(+-x[pix + tap, c(e)]) * wT[n][tap*Ceff + e]
+// amax_out (nullable): amax record (common.h) that max-accumulates the magnitudes of the values written
 int dense16_fwd(const Dense16Geo& g, const float* x, const float* wT, const float* bias, float* y,
-                int ldy, int coff, int accumulate, hipStream_t s);
+                int ldy, int coff, int accumulate, hipStream_t s, float* amax_out = nullptr);
 
 // ---- weight gradient ----------------------------------------------------------------------
 // Tiling shared by the LDS kernels: a block tile is TR full rows (64*PT pixels) of one image.

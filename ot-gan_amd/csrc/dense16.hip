@@ -32,6 +32,7 @@ struct FwdArgs {
   float* y;
   int M, H, W, logW, ldx, C, Ceff, doubled, K, ldy, coff;
   int accumulate;   // y += instead of y = (the growth layers of a split dense block add onto the block-input convolution's result)
+  float* amax;      // amax record of the values written (common.h), or null
 };
 
 template <int ACT>
@@ -136,7 +137,10 @@ __global__ __launch_bounds__(256) void dense16_fwd_kernel(FwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = lane & 15, g = lane >> 4;
   const int tile0 = (blockIdx.x * 4 + wave) * PT;
-  if (tile0 * 16 >= a.M) return;
+  if (tile0 * 16 >= a.M) {
+    if (a.amax) amax_commit(a.amax, 0u);   // (the workgroup's barrier in there counts every wave once)
+    return;
+  }
   Pix<PT> px;
 #pragma unroll
   for (int t = 0; t < PT; ++t) {
@@ -183,6 +187,7 @@ __global__ __launch_bounds__(256) void dense16_fwd_kernel(FwdArgs a) {
   }
   // D[m = 4g + r][n = p]
   const float b = a.bias ? a.bias[p] : 0.f;
+  unsigned omax = 0u;
 #pragma unroll
   for (int t = 0; t < PT; ++t)
 #pragma unroll
@@ -190,9 +195,13 @@ __global__ __launch_bounds__(256) void dense16_fwd_kernel(FwdArgs a) {
       const long m = (long)(tile0 + t) * 16 + 4 * g + r;
       if (m < a.M) {
         float* yp = a.y + m * a.ldy + a.coff + p;
-        *yp = acc[t][r] + b + (a.accumulate ? *yp : 0.f);
+        const float o = acc[t][r] + b + (a.accumulate ? *yp : 0.f);
+        *yp = o;
+        const unsigned ob = amax_bits(o);
+        omax = ob > omax ? ob : omax;
       }
     }
+  if (a.amax) amax_commit(a.amax, omax);
 }
 
 
@@ -222,6 +231,7 @@ struct FwdLdsArgs {
   int N, H, W, logW, ldx, C, Ceff, doubled, K, ldy, coff;
   int TR, RS;  // tile rows, LDS row stride in pixels
   int accumulate;
+  float* amax;  // amax record of the values written (common.h), or null
 };
 
 constexpr int kPixQuads = 10;  // LDS quads (16 B) per pixel
@@ -390,14 +400,19 @@ __global__ __launch_bounds__(256, 2) void dense16_fwd_lds_kernel(FwdLdsArgs a) {
   }
   const float b = a.bias ? a.bias[p] : 0.f;
   const long m0 = (img_base + (long)r0 * a.W);
+  unsigned omax = 0u;
 #pragma unroll
   for (int t = 0; t < PT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const long m = m0 + (wave * PT + t) * 16 + 4 * g + r;
       float* yp = a.y + m * a.ldy + a.coff + p;
-      *yp = acc[t][r] + b + (a.accumulate ? *yp : 0.f);
+      const float o = acc[t][r] + b + (a.accumulate ? *yp : 0.f);
+      *yp = o;
+      const unsigned ob = amax_bits(o);
+      omax = ob > omax ? ob : omax;
     }
+  if (a.amax) amax_commit(a.amax, omax);
 }
 
 // =======================================================================================
@@ -589,14 +604,19 @@ __global__ __launch_bounds__(256, 2) void dense16_fwd_x3_kernel(FwdLdsArgs a) {
   }
   const float b = a.bias ? a.bias[p] : 0.f;
   const long m0 = (img_base + (long)r0 * a.W);
+  unsigned omax = 0u;
 #pragma unroll
   for (int t = 0; t < PT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const long m = m0 + (wave * PT + t) * 16 + 4 * g + r;
       float* yp = a.y + m * a.ldy + a.coff + p;
-      *yp = acc[t][r] + b + (a.accumulate ? *yp : 0.f);
+      const float o = acc[t][r] + b + (a.accumulate ? *yp : 0.f);
+      *yp = o;
+      const unsigned ob = amax_bits(o);
+      omax = ob > omax ? ob : omax;
     }
+  if (a.amax) amax_commit(a.amax, omax);
 }
 
 // =======================================================================================
@@ -942,9 +962,10 @@ bool dense16_enabled() {
 }
 
 int dense16_fwd(const Dense16Geo& g, const float* x, const float* wT, const float* bias, float* y,
-                int ldy, int coff, int accumulate, hipStream_t s) {
+                int ldy, int coff, int accumulate, hipStream_t s, float* amax_out) {
   FwdArgs a;
   a.accumulate = accumulate;
+  a.amax = amax_out;
   a.x = x; a.cmap = g.cmap; a.wT = wT; a.bias = bias; a.y = y;
   a.M = g.N * g.H * g.W;
   a.H = g.H; a.W = g.W; a.logW = ilog2i(g.W);
@@ -960,6 +981,7 @@ int dense16_fwd(const Dense16Geo& g, const float* x, const float* wT, const floa
     while (PT > 1 && (long)g.N * g.H * g.W / (64 * PT) < 512) PT >>= 1;
     FwdLdsArgs l;
     l.accumulate = accumulate;
+    l.amax = amax_out;
     l.x = x; l.cmap = g.cmap; l.wT = wT; l.bias = bias; l.y = y;
     l.N = g.N; l.H = g.H; l.W = g.W; l.logW = ilog2i(g.W); l.ldx = g.ldx; l.C = g.C; l.Ceff = g.Ceff;
     l.doubled = g.doubled; l.K = 9 * g.Ceff; l.ldy = ldy; l.coff = coff;

@@ -221,6 +221,14 @@ constexpr int kAmaxBlocks = 2048, kAmaxSlots = 64;
 
 // header of an operand from the largest magnitude of its source tensor (threads 0 .. 35 one frequency each)
 __device__ __forceinline__ void write_scales(const AmaxArgs& a, float amax, int tid) {
+  if (a.record_only == 2) {   // max-accumulate into a record the caller zeroed (or that other producers share)
+    if (tid == 0) {
+      unsigned* p = reinterpret_cast<unsigned*>(a.hdr);
+      const unsigned b = __float_as_uint(amax) & 0x7fffffffu;
+      if (b > *p) *p = b;      // (one writer: the last block of this launch; other producers of the record run before / after it on the stream)
+    }
+    return;
+  }
   if (a.record_only) {
     if (tid < kAmaxSub) a.hdr[tid * kAmaxSubStride] = tid == 0 ? amax : 0.f;
     return;
@@ -441,8 +449,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(OutArgs a) {
     for (int j = 0; j < WM; ++j) {
       float* dst = v.p + n * v.sn + (WM * ta + i) * v.sh + (WM * tb + j) * v.sw + c;
       f32x4 o = y[j] + b;
-      mb = amax_bits4(o, mb);
       if (a.accumulate) o += ld4(dst);
+      mb = amax_bits4(o, mb);     // the value that ends up in memory (with `accumulate`: the sum)
       st4(dst, o);
     }
   }
@@ -1260,14 +1268,14 @@ AmaxScratch& amax_scratch() {
 // scales of the operand at `base` (header) for a transform with row gains `gain` of the tensor x[rows][C] (row stride
 // ld); `given`: the caller's amax record of that tensor (otgan_layers.h) -- then only the 36 scales are computed
 void op_scales(const float* x, long rows, int C, long ld, float* base, const float (&gain)[WA], float fold, bool floor_one,
-               hipStream_t s, const float* given = nullptr, bool record_only = false) {
+               hipStream_t s, const float* given = nullptr, bool record_only = false, bool record_accumulate = false) {
   if (X3_NP != 2) return;   // three bf16 pieces carry the full exponent range: no scales
   static std::atomic<unsigned> seq{0};
   AmaxArgs a;
   a.x = x; a.rows = rows; a.ld = rows == 1 ? C : ld; a.C = C; a.hdr = base;
   for (int i = 0; i < WA; ++i) a.gain[i] = gain[i];
   a.fold = fold; a.floor_one = floor_one ? 1 : 0;
-  a.record_only = record_only ? 1 : 0;
+  a.record_only = record_only ? (record_accumulate ? 2 : 1) : 0;
   if (given) {
     a.x = given;
     hipLaunchKernelGGL(scales_from_amax_kernel, dim3(1), dim3(64), 0, s, a);
@@ -1340,9 +1348,9 @@ int wgrad_splits(const WinoGeo& g) {
 
 }  // namespace
 
-void wino_absmax(const float* x, long rows, int C, long ld, float* record, hipStream_t s) {
+void wino_absmax(const float* x, long rows, int C, long ld, float* record, hipStream_t s, bool accumulate) {
   const float unit[WA] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-  op_scales(x, rows, C, ld, record, unit, 1.f, false, s, nullptr, true);
+  op_scales(x, rows, C, ld, record, unit, 1.f, false, s, nullptr, true, accumulate);
 }
 
 bool winograd_enabled() {
@@ -1722,7 +1730,7 @@ int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float
   oa.v[0].p = y + g.y_coff; oa.v[0].sn = (long)OH * OW * g.ldy; oa.v[0].sh = (long)OW * g.ldy; oa.v[0].sw = g.ldy;
   oa.TH = OH / WM; oa.TW = OW / WM; oa.C = g.Cout; oa.T = T; oa.ldm = g.Cout; oa.Mh = Mh; oa.bias = bias;
   oa.accumulate = g.y_accumulate;
-  oa.amax = g.y_accumulate ? nullptr : g.y_amax_out;
+  oa.amax = g.y_amax_out;
   hipLaunchKernelGGL(wino_output_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 1), dim3(256), 0, s, oa);
   return OTGAN_OK;
 }

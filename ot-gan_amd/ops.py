@@ -350,12 +350,17 @@ class Conv2dFunction(torch.autograd.Function):
         ctx.x_op = None
         if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and cmap is None and filt["fwd"] is not None:
             ctx.x_op = shared_x_operand(desc, x.device)
+        if ctx.x_rec is None:
+            x_tag = amax_of(x)               # implicit-GEMM passes scale their two-piece operands by it (else they reduce x)
+            desc.x_amax = x_tag.data_ptr() if x_tag is not None else None
         y_rec = None
-        if amax_fused(desc, 0) and cmap is None:
+        if amax_fused(desc, 0):
             y_rec = amax_slot(x.device)          # the kernel that writes y also leaves max |y| (for the next layer)
             desc.y_amax_out = y_rec.data_ptr()
         conv_fwd_raw(desc, x, cmap, wT, b, y, filt["fwd"])
         desc.y_amax_out = None
+        if ctx.x_rec is None:
+            desc.x_amax = None
         if y_rec is not None:
             tag_amax(y, y_rec)
         ctx.save_for_backward(x, V2d, g, wd, inv_norm)
@@ -689,19 +694,36 @@ class DenseBlockFunction(torch.autograd.Function):
             bias_all = torch.cat([b for b in params[2::3]])
             rows = N * H * W
             ctx.x_recs, ctx.x_ops = [], []
+            # amax records without extra passes (OTGAN_DENSE_AMAX=0: one reduction per slice, as in round 2).  Every kernel
+            # that writes growth channels -- the two wide convolutions (the second one adds onto the first) and the 16-output
+            # kernels of the chains -- max-accumulates the values it leaves in memory into ONE record of the growth
+            # region, rec_g: at any time an upper bound of every FINISHED growth channel (it also covers partial sums of
+            # unfinished ones: a bound that is a little too large costs a fraction of a bit of the 22).  The first half's
+            # record is a snapshot of rec_g taken when its last layer is done; the block's output carries
+            # max(record of x0, rec_g) for the transition that reads the whole buffer.
+            shared = os.environ.get("OTGAN_DENSE_AMAX", "1") != "0" and _FUSED_AMAX
+            rec_x0 = amax_of(x0) if shared else None
+            rec_g = amax_slot(buf.device) if shared else None
 
             def wide_fwd(i):
                 wd, ops_ = plan["wide"][i], sw["wide"][i]
                 desc = wd["desc"]
                 src = buf[..., wd["x_off"]:]       # channel slice: same rows, pointer advanced by x_off floats
-                rec = absmax_record_strided(src.data_ptr(), rows, wd["C"], Ctot, buf.device)
+                if shared and i == 0 and rec_x0 is not None:
+                    rec = rec_x0
+                elif shared and i > 0:
+                    rec = rec_g.clone()            # (2 KiB) the bound as of now: later layers keep raising rec_g
+                else:
+                    rec = absmax_record_strided(src.data_ptr(), rows, wd["C"], Ctot, buf.device)
                 ctx.x_recs.append(rec)
                 desc.x_amax = rec.data_ptr()
                 if any(ctx.needs_input_grad[4:]):
                     ctx.x_ops.append(shared_x_operand(desc, buf.device))    # read back by this convolution's wgrad
                 desc.y_accumulate = wd["accumulate"]
+                desc.y_amax_out = rec_g.data_ptr() if shared else None
                 conv_fwd_raw(desc, src, None, ops_["wT"], None if wd["accumulate"] else bias_all, buf, ops_["fwd"])
                 desc.y_accumulate = 0
+                desc.y_amax_out = None
 
             wide_fwd(0)
             for k in range(L):
@@ -711,9 +733,11 @@ class DenseBlockFunction(torch.autograd.Function):
                     g0 = plan["g0"][k]
                     desc = ConvDesc(N, H, W, n_own * F, Ctot, 0, ksize, ksize, 1, F, Ctot, C0 + k * F, preact, 1)
                     desc.y_accumulate = 1
+                    desc.y_amax_out = rec_g.data_ptr() if shared else None
                     cmap, inv = channel_maps((F,) * n_own, preact, x0.device)
                     conv_fwd_raw(desc, buf[..., C0 + g0 * F:], cmap, sw["wT_g"][k], None, buf)
                     desc.y_accumulate = 0
+                    desc.y_amax_out = None
                 descs.append(desc)
                 maps.append((cmap, inv))
                 for i, wd in enumerate(plan["wide"]):
@@ -722,6 +746,9 @@ class DenseBlockFunction(torch.autograd.Function):
             ctx.sw = sw
             ctx.save_for_backward(buf, *saved)
             ctx.descs, ctx.maps = descs, maps
+            if shared:
+                x0_rec = ctx.x_recs[0]     # the producer's record of x0, or the reduction wide_fwd(0) made
+                tag_amax(buf, torch.maximum(x0_rec, rec_g))
             return buf
 
         for k in range(L):
