@@ -236,7 +236,7 @@ class GradBuckets:
                 self.count.append(cnt)
                 lo, cnt = off, 0
         self.armed = False
-        self.left, self.works = [], []
+        self.left, self.works, self.deferred = [], [], []
         self.handles = [p.register_hook(lambda g, i=i: self._on_grad(i, g)) for i, p in enumerate(self.params)]
 
     def remove(self):
@@ -252,6 +252,7 @@ class GradBuckets:
         self.armed = True
         self.left = list(self.count)
         self.works = []
+        self.deferred = []
 
     def _on_grad(self, i, g):
         if not self.armed:
@@ -266,6 +267,11 @@ class GradBuckets:
                 host = seg.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM)
                 seg.copy_(host)
+            elif os.environ.get("OTGAN_SERIAL_COLLECTIVES") == "1":
+                # no collective kernel beside the backward pass's kernels (DESIGN section 3 "Four hazards", item 3: two VALU
+                # kernels computed wrong values next to waves of the 256 x 128 GEMM; RCCL's reduction kernels could not be
+                # tried on the one-GPU boxes of this build): all buckets go out after the last gradient, in finish()
+                self.deferred.append(seg)
             else:
                 self.works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
         return None
@@ -274,6 +280,12 @@ class GradBuckets:
         if any(self.left):
             self.armed = False
             raise RuntimeError("GradBuckets.finish(): some variables received no gradient in this backward pass")
+        if self.deferred:
+            if torch.cuda.is_available():
+                torch.cuda.current_stream().synchronize()      # the backward pass has drained
+            for seg in self.deferred:
+                self.works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
+            self.deferred = []
         for w in self.works:
             w.wait()
         self.works = []

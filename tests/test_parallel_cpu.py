@@ -84,7 +84,13 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_plumbing_gloo():
+@pytest.mark.parametrize("serial", [False, True], ids=["overlapped", "serial_collectives"])
+def test_two_rank_plumbing_gloo(serial, monkeypatch):
+    # serial: OTGAN_SERIAL_COLLECTIVES=1 -- the gradient buckets go out after the backward pass instead of inside it
+    if serial:
+        monkeypatch.setenv("OTGAN_SERIAL_COLLECTIVES", "1")
+    else:
+        monkeypatch.delenv("OTGAN_SERIAL_COLLECTIVES", raising=False)
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
