@@ -1515,6 +1515,87 @@ __global__ __launch_bounds__(256) void conv_rgbin_fwd_kernel(FewInArgs a) {
   if (a.amax) amax_commit(a.amax, mb);
 }
 
+// The same layer on the fp32 matrix pipe: M = 16 pixels of an image row, N = 16 output channels, K = (tap, rgb) -- 75 of
+// 76 for a 5 x 5 filter, 19 v_mfma_f32_16x16x4_f32 per tile.  A lane keeps its column's weights for all eight column tiles
+// of a 64-channel group in REGISTERS for the whole workgroup (19 x 4 = 76), the A operand is one ds_read_b32 per K step
+// from the haloed input tile (a lane's K index picks tap and colour: an offset table; the pad index reads the pixel's
+// zero fourth float) and feeds four MFMAs.  A workgroup = 4 waves x 4 segments of 16 pixels per 256-pixel tile, two tiles.
+// 5 GFLOP at 256 images: 32 us at the fp32 matrix peak, 27 us to write y.
+template <int KS>
+__global__ __launch_bounds__(256) void conv_rgbin_mfma_kernel(FewInArgs a, int tiles_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float4 s_rm[];   // [(TR + KS - 1)][(W + KS - 1)] pixels (r, g, b, 0)
+  constexpr int KT = KS * KS * 3, STEPS = (KT + 3) / 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  constexpr int NT = 4;            // 64 channels per workgroup: 76 weight registers, three waves per SIMD (eight tiles: 264 VGPRs, one)
+  const int co0 = blockIdx.y * (16 * NT);
+  const int LW = a.W + KS - 1, LH = a.TR + KS - 1;
+  // B fragments: b[k = 4 s + kq][n = li] of column tile nt
+  float bw[STEPS][NT];
+  int aoff[STEPS];
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) {
+    const int k = 4 * st + kq;
+    const bool kin = k < KT;
+    const int tap = kin ? k / 3 : 0, j = kin ? k - 3 * tap : 3;     // j = 3: the zero component
+    const int kh = tap / KS, kw = tap - kh * KS;
+    aoff[st] = (kh * LW + kw) * 4 + j;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bw[st][nt] = kin ? a.wT[(long)(co0 + nt * 16 + li) * a.K + k] : 0.f;
+  }
+  float bias[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bias[nt] = a.bias ? a.bias[co0 + nt * 16 + li] : 0.f;
+  const int tiles_per_img = a.H / a.TR;
+  const float* s_f = reinterpret_cast<const float*>(s_rm);
+  const int segs_per_row = a.W >> 4, segs = a.TR * segs_per_row;    // 16 segments of 16 pixels per tile
+  unsigned mb = 0u;
+  for (int tb = 0; tb < tiles_per_block; ++tb) {
+    const int tile = blockIdx.x * tiles_per_block + tb;
+    const int n = tile / tiles_per_img, r0 = (tile - n * tiles_per_img) * a.TR;
+    const long img = (long)n * a.H * a.W;
+    __syncthreads();   // the previous tile is consumed
+    for (int i = tid; i < LH * LW; i += 256) {
+      const int lr = i / LW, lc = i - lr * LW;
+      const int ih = r0 + lr - a.ph, iw = lc - a.pw;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W) {
+        const float* px = a.x + (img + (long)ih * a.W + iw) * a.ldx;
+        v = make_float4(px[0], px[1], px[2], 0.f);
+      }
+      s_rm[i] = v;
+    }
+    __syncthreads();
+    for (int sg = wave; sg < segs; sg += 4) {
+      const int r = sg / segs_per_row, c0 = (sg - r * segs_per_row) << 4;
+      const float* abase = s_f + (r * LW + c0 + li) * 4;
+      f32x4 acc[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      float av[STEPS];
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) av[st] = abase[aoff[st]];
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], bw[st][nt], acc[nt], 0, 0, 0);
+      // D[i = 4 kq + q][n = li]: pixel c0 + 4 kq + q, channel co0 + nt * 16 + li
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float* dst = a.y + (img + (long)(r0 + r) * a.W + c0 + 4 * kq + q) * a.ldy + a.coff + co0 + li;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float o = acc[nt][q] + bias[nt];
+          dst[nt * 16] = o;
+          const unsigned ob = amax_bits(o);
+          mb = ob > mb ? ob : mb;
+        }
+      }
+    }
+  }
+  if (a.amax) amax_commit(a.amax, mb);
+}
+
 // set by a pass whose output kernel fills the requested otgan_conv_desc::y_amax_out / dx_amax_out record itself; the
 // entry points run a separate reduction of the output otherwise
 // amax records of the two operand tensors of a generic implicit GEMM, for its two-scaled-fp16-piece main loop (three
@@ -1561,8 +1642,18 @@ static bool launch_rgbin_fwd(const otgan_conv_desc* d, int pad_t, int pad_l, con
   a.amax = d->y_amax_out;
   a.TR = 256 / d->W;
   if (a.TR < 4 || a.TR > d->H || d->H % a.TR) return false;
-  const dim3 grid(d->N * (d->H / a.TR), d->Cout / 128);
   const size_t lds = sizeof(float4) * (size_t)(a.TR + d->KH - 1) * (d->W + d->KW - 1);
+  const int tiles = d->N * (d->H / a.TR);
+  static const bool mfma_off = getenv("OTGAN_DISABLE_RGBIN_MFMA") != nullptr;
+  if (!mfma_off && d->W % 16 == 0) {   // fp32 matrix pipe; two tiles per workgroup while that leaves two workgroups per CU
+    const int tpb = (tiles % 2 == 0 && (long)(tiles / 2) * (d->Cout / 64) >= 1024) ? 2 : 1;
+    const dim3 gm(tiles / tpb, d->Cout / 64);
+    if (d->KH == 5) hipLaunchKernelGGL(conv_rgbin_mfma_kernel<5>, gm, dim3(256), lds, s, a, tpb);
+    else hipLaunchKernelGGL(conv_rgbin_mfma_kernel<3>, gm, dim3(256), lds, s, a, tpb);
+    g_amax_written = a.amax != nullptr;
+    return true;
+  }
+  const dim3 grid(tiles, d->Cout / 128);
   if (d->KH == 5) hipLaunchKernelGGL(conv_rgbin_fwd_kernel<5>, grid, dim3(256), lds, s, a);
   else hipLaunchKernelGGL(conv_rgbin_fwd_kernel<3>, grid, dim3(256), lds, s, a);
   g_amax_written = a.amax != nullptr;
