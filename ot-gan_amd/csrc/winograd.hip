@@ -79,11 +79,19 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 // store k .. k+3 of row `row`, frequency f, of a [WF][rows][ld] operand: fp32 row-major in F, or (P non-null)
 // as two fp16 planes of the SCALED value in the blocked layout; the scale of frequency f sits in the operand's
 // header, X3_HDR floats in front of the planes (written by absmax_kernel before the producer runs)
-__device__ __forceinline__ void st_operand(float* F, u16* P, long rows, int ld, int f, long row, int k, f32x4 v) {
+// (`sc`: the scale of frequency f -- hdr_scale(P, f) for producers that run after the header is written, the producer's
+// own table for those that derive the scales themselves, ScaleSrc)
+__device__ __forceinline__ float hdr_scale(const u16* P, int f) {
+#if X3_PIECES == 2
+  return P ? (reinterpret_cast<const float*>(P) - X3_HDR)[16 + f] : 1.f;
+#else
+  return 1.f;
+#endif
+}
+__device__ __forceinline__ void st_operand(float* F, u16* P, long rows, int ld, int f, long row, int k, f32x4 v, float sc) {
   if (P) {
     const long fs = op_fstride(rows, ld);
 #if X3_PIECES == 2
-    const float sc = (reinterpret_cast<const float*>(P) - X3_HDR)[16 + f];
     st_split4h(P, WF * fs, f * fs + op_off(row, k, ld >> 4), v * sc);
 #else
     st_split4(P, WF * fs, f * fs + op_off(row, k, ld >> 4), v);   // three bf16 pieces: no scale
@@ -336,7 +344,53 @@ struct WView {
 
 // V[f][t][coff + c] = (B^T d B)[f];  d = 6x6 patch at (4ta-1, 4tb-1), zero outside [0,H)x[0,W).
 // blockIdx.z selects one of up to four views (dgrad: the four output-parity classes of dy).
+// Where a producer kernel takes the scales of its two-piece operand from: rec == null -- the header in front of the planes
+// (an earlier launch wrote it: absmax_kernel); else it derives them from the amax record itself, every workgroup for its
+// own use, and the first one also leaves them in the header for the GEMM that follows (round 3: one 5 us launch per
+// operand less, 17 per DCGAN step).  Same arithmetic as write_scales().
+struct ScaleSrc {
+  const float* rec;
+  float gain[WA];
+  float fold;
+  int floor_one;
+};
+__device__ __forceinline__ void producer_scale_table(const ScaleSrc& ss, u16* P, float* s_sc) {
+#if X3_PIECES == 2
+  if (P) {
+    const int tid = threadIdx.x;
+    if (tid < WF) {
+      float* hdr = reinterpret_cast<float*>(P) - X3_HDR;
+      float sc;
+      if (ss.rec) {
+        float amax = amax_record_value(ss.rec);
+        if (ss.floor_one && amax == amax) amax = fmaxf(amax, 1.f);
+        const int i = tid / WA, j = tid - i * WA;
+        const float bound = amax * ss.fold * (ss.gain[i] * ss.gain[j]);
+        float inv = 1.f;
+        sc = 1.f;
+        if (!(bound <= 3.0e38f)) {          // NaN or infinite
+          sc = inv = __builtin_nanf("");
+        } else if (bound > 0.f) {
+          const int e = x3_scale_exp(amax * ss.fold, ss.gain[i], ss.gain[j]);
+          sc = __builtin_ldexpf(1.f, 14 - e);
+          inv = __builtin_ldexpf(1.f, e - 14);
+        }
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+          hdr[16 + tid] = sc;
+          hdr[64 + tid] = inv;
+          if (tid == 0) hdr[0] = amax;
+        }
+      } else {
+        sc = hdr[16 + tid];
+      }
+      s_sc[tid] = sc;
+    }
+    __syncthreads();
+  }
+#endif
+}
 struct InArgs {
+  ScaleSrc ss;
   View v[4];
   int coff[4];
   int H, W, TH, TW, C;   // C = channels of the view
@@ -363,6 +417,8 @@ __device__ __forceinline__ f32x4 wino_act(f32x4 v) {
 // are produced: 36 float4 of state per thread.
 template <int ACT, bool DOUBLED>
 __global__ __launch_bounds__(256) void wino_input_kernel(InArgs a) {
+  __shared__ float s_sc[WF];
+  producer_scale_table(a.ss, a.P, s_sc);
   long t;
   int k4;
   if (!op_thread(a.P != nullptr, a.T, (a.Cpad > a.C ? a.Cpad : a.C) >> 2, t, k4)) return;
@@ -374,7 +430,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(InArgs a) {
   const int pass = DOUBLED ? (int)blockIdx.y : 0;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   if (c >= a.C) {   // K padding (single-view, non-doubled callers only)
-    for (int f = 0; f < WF; ++f) st_operand(a.V, a.P, a.T, a.ldv, f, t, c, zero);
+    for (int f = 0; f < WF; ++f) st_operand(a.V, a.P, a.T, a.ldv, f, t, c, zero, 1.f);
     return;
   }
   f32x4 T[WA][WA];
@@ -401,7 +457,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(InArgs a) {
     bt1(T[i], o);
 #pragma unroll
     for (int j = 0; j < WA; ++j)
-      if (a.s2_skip < 0 || s2_present(cls, i * WA + j, a.s2_skip)) st_operand(a.V, a.P, a.T, a.ldv, i * WA + j, t, k0, o[j]);
+      if (a.s2_skip < 0 || s2_present(cls, i * WA + j, a.s2_skip)) st_operand(a.V, a.P, a.T, a.ldv, i * WA + j, t, k0, o[j], s_sc[i * WA + j]);
   }
 }
 
@@ -463,11 +519,13 @@ __global__ __launch_bounds__(256) void op_zero_cols_kernel(u16* P, long rows, in
   int k4;
   if (!op_thread(true, rows, (k1 - k0) >> 2, row, k4)) return;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  for (int f = 0; f < WF; ++f) st_operand(nullptr, P, rows, ld, f, row, k0 + 4 * k4, z);
+  for (int f = 0; f < WF; ++f) st_operand(nullptr, P, rows, ld, f, row, k0 + 4 * k4, z, 1.f);   // zeros: no scale (the header may not exist yet)
 }
 
 // dM[f][t][coff + c] = (A dY A^T)[f],  dY = the 4x4 tile of the view at (4ta, 4tb)
 __global__ __launch_bounds__(256) void wino_outadj_kernel(InArgs a) {
+  __shared__ float s_sc[WF];
+  producer_scale_table(a.ss, a.P, s_sc);
   long t;
   int k4;
   if (!op_thread(a.P != nullptr, a.T, a.C >> 2, t, k4)) return;
@@ -490,7 +548,7 @@ __global__ __launch_bounds__(256) void wino_outadj_kernel(InArgs a) {
     f32x4 o[WA];
     a1(u[i], o);
 #pragma unroll
-    for (int j = 0; j < WA; ++j) st_operand(a.V, a.P, a.T, a.ldv, i * WA + j, t, a.coff[blockIdx.z] + c, o[j]);
+    for (int j = 0; j < WA; ++j) st_operand(a.V, a.P, a.T, a.ldv, i * WA + j, t, a.coff[blockIdx.z] + c, o[j], s_sc[i * WA + j]);
   }
 }
 
@@ -509,7 +567,7 @@ __global__ __launch_bounds__(256) void wino_filter_fwd_kernel(const float* __res
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) g[i][j] = ld4(src + (long)(i * 3 + j) * Cin);
-  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, rows, Cin, f, row, ci, v); });
+  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, rows, Cin, f, row, ci, v, hdr_scale(P, f)); });
 }
 
 // backward filters (flipped taps): U'[f][ci][cls*Cout + co] from weff[cls][tap][ci][co]
@@ -526,7 +584,7 @@ __global__ __launch_bounds__(256) void wino_filter_bwd_kernel(const float* __res
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) g[i][j] = ld4(src + (long)((2 - i) * 3 + (2 - j)) * Cin * Cout);
-  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, Cin, 4 * Cout, f, ci, cls * Cout + co, v); });
+  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, Cin, 4 * Cout, f, ci, cls * Cout + co, v, hdr_scale(P, f)); });
 }
 
 // The same two transforms straight from the UN-folded 5x5 weights (the fold of the 2x nearest-neighbour upsampling,
@@ -562,7 +620,7 @@ __global__ __launch_bounds__(256) void wino_filter_fwd_unfolded_kernel(const flo
         for (int j = 0; j < 3; ++j)
           if (fold5_tap(ph, kh) == i && fold5_tap(pw, kw) == j) g[i][j] += v;
     }
-  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, rows, Cin, f, row, ci, v); });
+  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, rows, Cin, f, row, ci, v, hdr_scale(P, f)); });
 }
 
 // U'[f][ci][cls*Cout + co] (flipped taps) from w[kh*5 + kw][ci][co]
@@ -592,7 +650,7 @@ __global__ __launch_bounds__(256) void wino_filter_bwd_unfolded_kernel(const flo
         for (int j = 0; j < 3; ++j)
           if (fold5_tap(ph, kh) == 2 - i && fold5_tap(pw, kw) == 2 - j) g[i][j] += v;
     }
-  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, Cin, 4 * Cout, f, ci, cls * Cout + co, v); });
+  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, Cin, 4 * Cout, f, ci, cls * Cout + co, v, hdr_scale(P, f)); });
 }
 
 // dweff[cls][tap][ci][co] = (G^T dU G)[tap],  dU[f] = sum over splits of slab[split][f][ci][cls*Cout + co]
@@ -659,7 +717,7 @@ __global__ __launch_bounds__(256) void wino_s2_filter_fwd_kernel(const float* __
     }
   tf_filter(g, [&](int f, f32x4 v) {
     if (plain || s2_present(cls, f, 0))   // absent blocks are never read by the GEMM
-      st_operand(U, P, Cout, ld, f, co, cls * Ceff + ce, v);
+      st_operand(U, P, Cout, ld, f, co, cls * Ceff + ce, v, hdr_scale(P, f));
   });
 }
 
@@ -674,7 +732,7 @@ __global__ __launch_bounds__(256) void wino_s2_filter_bwd_kernel(const float* __
   const int co = k4 * 4;
   if (co >= Cout) {   // K padding: zero columns [Cout, Kp)
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    for (int f = 0; f < WF; ++f) st_operand(U, P, rows, Kp, f, r, co, z);
+    for (int f = 0; f < WF; ++f) st_operand(U, P, rows, Kp, f, r, co, z, 1.f);
     return;
   }
   const int ce = (int)(r % Ceff), cls = (int)(r / Ceff);
@@ -688,7 +746,7 @@ __global__ __launch_bounds__(256) void wino_s2_filter_bwd_kernel(const float* __
       const int kh = plain ? 2 - i : s2_tap(pi, 2 - i), kw = plain ? 2 - j : s2_tap(pj, 2 - j);
       g[i][j] = (kh >= 0 && kw >= 0) ? ld4(w + ((long)(kh * kk + kw) * Ceff + ce) * Cout + co) : zero;
     }
-  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, rows, Kp, f, r, co, v); });
+  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, rows, Kp, f, r, co, v, hdr_scale(P, f)); });
 }
 
 // dw[kh*5+kw][ce][co] = (G^T dU G)[i][j] of the tap's class; dU[f] = sum of slab[split][f][cls*Ceff+ce][co]
@@ -1348,6 +1406,23 @@ int wgrad_splits(const WinoGeo& g) {
 
 }  // namespace
 
+// scales of an operand whose producer kernel (wino_input_kernel / wino_outadj_kernel, `ia`) is launched next: with the
+// caller's amax record the producer derives them itself (ScaleSrc) -- no launch; without one, the reduction as before.
+// OTGAN_INKERNEL_SCALES=0: always the separate launch.
+void producer_scales(InArgs& ia, const float* x, long rows, int C, long ld, float* base, const float (&gain)[WA], float fold,
+                     bool floor_one, hipStream_t s, const float* given) {
+  ia.ss.rec = nullptr;
+  if (X3_NP != 2) return;
+  static const bool inkernel = [] { const char* e = getenv("OTGAN_INKERNEL_SCALES"); return !(e && e[0] == '0'); }();
+  if (given && inkernel) {
+    ia.ss.rec = given;
+    for (int i = 0; i < WA; ++i) ia.ss.gain[i] = gain[i];
+    ia.ss.fold = fold;
+    ia.ss.floor_one = floor_one ? 1 : 0;
+    return;
+  }
+  op_scales(x, rows, C, ld, base, gain, fold, floor_one, s, given);
+}
 void wino_absmax(const float* x, long rows, int C, long ld, float* record, hipStream_t s, bool accumulate) {
   const float unit[WA] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
   op_scales(x, rows, C, ld, record, unit, 1.f, false, s, nullptr, true, accumulate);
@@ -1437,7 +1512,7 @@ int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stri
   ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
   ia.H = g.H; ia.W = g.W; ia.TH = g.H / WM; ia.TW = g.W / WM; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.V = V;
   ia.P = VP;
-  if (x3) op_scales(x, (long)g.N * g.H * g.W, g.Cin, g.ldx, V, kGainBt, 1.f, false, s, g.x_amax);
+  if (x3) producer_scales(ia, x, (long)g.N * g.H * g.W, g.Cin, g.ldx, V, kGainBt, 1.f, false, s, g.x_amax);
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cin / 4), 1, 1), dim3(256), 0, s, ia);
   BgArgs b;
   memset(&b, 0, sizeof(b));
@@ -1479,7 +1554,7 @@ int wino_dgrad(const WinoGeo& g, const float* dy, const float* weff, long cls_st
   for (int cls = 0; cls < 4; ++cls) ia.coff[cls] = cls * g.Cout;
   ia.H = g.H; ia.W = g.W; ia.TH = g.H / WM; ia.TW = g.W / WM; ia.C = g.Cout; ia.T = T; ia.ldv = K4; ia.V = DV;
   ia.P = VP;
-  if (x3) op_scales(dy + g.y_coff, (long)g.N * 4 * g.H * g.W, g.Cout, g.ldy, DV, kGainBt, 1.f, false, s, g.dy_amax);
+  if (x3) producer_scales(ia, dy + g.y_coff, (long)g.N * 4 * g.H * g.W, g.Cout, g.ldy, DV, kGainBt, 1.f, false, s, g.dy_amax);
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cout / 4), 1, 4), dim3(256), 0, s, ia);
   BgArgs b;
   memset(&b, 0, sizeof(b));
@@ -1520,7 +1595,7 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
       ia.s2_skip = -1;
       ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
       ia.H = g.H; ia.W = g.W; ia.TH = g.H / WM; ia.TW = g.W / WM; ia.C = g.Cin; ia.T = T; ia.ldv = g.Cin; ia.P = VP;
-      op_scales(x, (long)g.N * g.H * g.W, g.Cin, g.ldx, Vb, kGainBt, 1.f, false, s, g.x_amax);
+      producer_scales(ia, x, (long)g.N * g.H * g.W, g.Cin, g.ldx, Vb, kGainBt, 1.f, false, s, g.x_amax);
       hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, g.Cin / 4), 1, 1), dim3(256), 0, s, ia);
     }
     InArgs da;
@@ -1529,7 +1604,7 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
     class_views(g, dy + g.y_coff, g.ldy, da.v);
     for (int cls = 0; cls < 4; ++cls) da.coff[cls] = cls * g.Cout;
     da.H = g.H; da.W = g.W; da.TH = g.H / WM; da.TW = g.W / WM; da.C = g.Cout; da.T = T; da.ldv = N4; da.P = MP;
-    op_scales(dy + g.y_coff, (long)g.N * 4 * g.H * g.W, g.Cout, g.ldy, Mb, kGainA, 1.f, false, s, g.dy_amax);
+    producer_scales(da, dy + g.y_coff, (long)g.N * 4 * g.H * g.W, g.Cout, g.ldy, Mb, kGainA, 1.f, false, s, g.dy_amax);
     hipLaunchKernelGGL(wino_outadj_kernel, dim3(op_grid(T, g.Cout / 4), 1, 4), dim3(256), 0, s, da);
     BgArgs b;
     memset(&b, 0, sizeof(b));
@@ -1624,9 +1699,9 @@ void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, u16* VP, h
   const long T = wino_s2_tiles(g);
   if (ld == 0) ld = s2_k(g);
   // (the activation is applied inside the transform: |relu(+-x)| <= |x|, |elu(x)| <= max(|x|, 1))
-  if (VP) op_scales(x, (long)g.N * (g.H >> g.up) * (g.W >> g.up), g.C, g.ldx, reinterpret_cast<float*>(VP) - X3_HDR, kGainBt, 1.f, g.act == 2, s, g.x_amax);
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
+  if (VP) producer_scales(ia, x, (long)g.N * (g.H >> g.up) * (g.W >> g.up), g.C, g.ldx, reinterpret_cast<float*>(VP) - X3_HDR, kGainBt, 1.f, g.act == 2, s, g.x_amax);
   ia.s2_skip = -1;
   s2_views(g, x, g.ldx, ia.v);
   if (g.up) {   // the stored image is half the grid (plain layers only)
@@ -1757,7 +1832,7 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   ia.H = OH; ia.W = OW; ia.TH = OH / WM; ia.TW = OW / WM; ia.C = g.Cout; ia.T = T; ia.ldv = Kp; ia.V = DV;
   ia.P = VP;
   ia.Cpad = Kp;
-  if (x3) op_scales(dy + g.y_coff, (long)g.N * OH * OW, g.Cout, g.ldy, DV, kGainBt, 1.f, false, s, g.dy_amax);
+  if (x3) producer_scales(ia, dy + g.y_coff, (long)g.N * OH * OW, g.Cout, g.ldy, DV, kGainBt, 1.f, false, s, g.dy_amax);
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, Kp / 4), 1, 1), dim3(256), 0, s, ia);
   BgArgs b;
   memset(&b, 0, sizeof(b));
@@ -1814,7 +1889,7 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
     da.s2_skip = -1;
     da.v[0].p = dy + g.y_coff; da.v[0].sn = (long)OH * OW * g.ldy; da.v[0].sh = (long)OW * g.ldy; da.v[0].sw = g.ldy;
     da.H = OH; da.W = OW; da.TH = OH / WM; da.TW = OW / WM; da.C = g.Cout; da.T = T; da.ldv = g.Cout; da.P = MP;
-    op_scales(dy + g.y_coff, (long)g.N * OH * OW, g.Cout, g.ldy, Mb, kGainA, 1.f, false, s, g.dy_amax);
+    producer_scales(da, dy + g.y_coff, (long)g.N * OH * OW, g.Cout, g.ldy, Mb, kGainA, 1.f, false, s, g.dy_amax);
     hipLaunchKernelGGL(wino_outadj_kernel, dim3(op_grid(T, g.Cout / 4), 1, 1), dim3(256), 0, s, da);
     BgArgs b;
     memset(&b, 0, sizeof(b));
@@ -1872,7 +1947,7 @@ __global__ __launch_bounds__(256) void wino_up3_filter_fwd_kernel(const float* _
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) g[i][j] = ld4(wT + ((long)co * 9 + i * 3 + j) * Ceff + ce);
-  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, Cout, Ceff, f, co, ce, v); });
+  tf_filter(g, [&](int f, f32x4 v) { st_operand(U, P, Cout, Ceff, f, co, ce, v, hdr_scale(P, f)); });
 }
 }  // namespace
 
@@ -1895,9 +1970,9 @@ int wino_up3_fwd(const WinoUp3Geo& g, const float* x, const float* bias, float* 
   float* V = g.x_op ? g.x_op : ws;
   float* Mh = ws + operand_floats(nV);
   float* U = const_cast<float*>(prep);
-  op_scales(x, (long)g.N * g.H * g.W, g.C, g.ldx, V, kGainBt, 1.f, false, s, g.x_amax);   // |relu(+-x)| <= |x|
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
+  producer_scales(ia, x, (long)g.N * g.H * g.W, g.C, g.ldx, V, kGainBt, 1.f, false, s, g.x_amax);   // |relu(+-x)| <= |x|
   ia.s2_skip = -1;
   ia.up = 1;
   ia.v[0].p = x; ia.v[0].sn = (long)g.H * g.W * g.ldx; ia.v[0].sh = (long)g.W * g.ldx; ia.v[0].sw = g.ldx;
