@@ -264,6 +264,11 @@ int otgan_glu_bwd_f32(const float* x, const float* dy, long rows, int C, float* 
  * needs C % 4 == 0 and 16-byte aligned tensors) */
 int otgan_glu_fwd_amax_f32(const float* x, long rows, int C, float* y, float* y_amax, void* stream);
 int otgan_glu_bwd_amax_f32(const float* x, const float* dy, long rows, int C, float* dx, float* dx_amax, void* stream);
+/* The same, also writing colsum[2 C] = the column sums of dx (the bias gradient of the convolution in front of the GLU,
+ * models/dcgan.py:39-47: conv -> GLU) without another pass over dx.  scratch: 256 * 2 C floats.  C % 4 == 0, 16-byte
+ * aligned tensors; dx_amax nullable. */
+int otgan_glu_bwd_colsum_f32(const float* x, const float* dy, long rows, int C, float* dx, float* dx_amax, float* colsum,
+                             float* scratch, void* stream);
 /* tanh output (models/dcgan.py:50) */
 int otgan_tanh_fwd_f32(const float* x, long n, float* y, void* stream);
 int otgan_tanh_bwd_f32(const float* y, const float* dy, long n, float* dx, void* stream);

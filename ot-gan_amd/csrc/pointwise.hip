@@ -349,6 +349,58 @@ __global__ __launch_bounds__(256) void glu_bwd4_kernel(const float* __restrict__
   }
   if (rec) amax_commit(rec, mb);
 }
+// GLU backward that also leaves the column sums of what it writes (the bias gradient of the convolution in front of the
+// GLU: otherwise one more read of dx, 268 MB for the generator's last gated layer).  Same work split as
+// colreduce4_kernel: a block covers 64 of the C columns of dy (their a and gate halves of x / dx) and a chunk of rows,
+// 16 row lanes per block; partial[chunk][2 C] is summed by colreduce_finish_kernel.
+__global__ __launch_bounds__(256) void glu_bwd4_colsum_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              long rows, int C, float* __restrict__ dx,
+                                                              float* __restrict__ rec, float* __restrict__ partial) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cq = lane & 15, rsub = (lane >> 4) + 4 * wave;
+  const int c = blockIdx.x * 64 + 4 * cq;
+  const int chunk = blockIdx.y;
+  const long per = ceil_div_l(rows, (long)gridDim.y);
+  const long r0 = chunk * per;
+  long r1 = r0 + per;
+  if (r1 > rows) r1 = rows;
+  f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sl = {0.f, 0.f, 0.f, 0.f};
+  unsigned mb = 0u;
+  if (c < C) {
+    for (long r = r0 + rsub; r < r1; r += 16) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(x + r * 2 * C + c);
+      const f32x4 l = *reinterpret_cast<const f32x4*>(x + r * 2 * C + C + c);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(dy + r * C + c);
+      f32x4 da, dl;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float sg = sigmoidf_(l[k]);
+        da[k] = d[k] * sg;
+        dl[k] = d[k] * a[k] * sg * (1.f - sg);
+      }
+      *reinterpret_cast<f32x4*>(dx + r * 2 * C + c) = da;
+      *reinterpret_cast<f32x4*>(dx + r * 2 * C + C + c) = dl;
+      sa += da;
+      sl += dl;
+      mb = amax_bits4(dl, amax_bits4(da, mb));
+    }
+  }
+  __shared__ f32x4 red[2][16][17];
+  red[0][rsub][cq] = sa;
+  red[1][rsub][cq] = sl;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int half = threadIdx.x >> 4, q = threadIdx.x & 15;
+    const int cc = blockIdx.x * 64 + 4 * q;
+    if (cc < C) {
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += red[half][k][q];
+      *reinterpret_cast<f32x4*>(partial + (long)chunk * 2 * C + half * C + cc) = t;
+    }
+  }
+  if (rec) amax_commit(rec, mb);
+}
 __global__ void tanh_fwd_kernel(const float* __restrict__ x, long n, float* __restrict__ y) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     y[i] = tanhf(x[i]);
@@ -760,6 +812,23 @@ int otgan_glu_bwd_amax_f32(const float* x, const float* dy, long rows, int C, fl
     hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, s, x, dy, rows, C, dx);
   }
   OTGAN_CHECK_LAUNCH("glu bwd");
+  return OTGAN_OK;
+}
+int otgan_glu_bwd_colsum_f32(const float* x, const float* dy, long rows, int C, float* dx, float* dx_amax, float* colsum,
+                             float* scratch, void* stream) {
+  OTGAN_CHECK_ARG(x && dy && dx && colsum && scratch && rows > 0 && C > 0 && C % 4 == 0 && aligned16(x) && aligned16(dy) &&
+                      aligned16(dx) && aligned16(scratch),
+                  "glu bwd with column sums: C %% 4 == 0 and 16-byte aligned tensors");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, 4.0 * 5 * (double)rows * C, s);
+  const int colblocks = ceil_div(C, 64);
+  long nchunk = ceil_div(1024, colblocks);              // aim for >= 1024 workgroups
+  if (nchunk > kChunks) nchunk = kChunks;
+  if (nchunk > ceil_div_l(rows, 64)) nchunk = ceil_div_l(rows, 64);
+  if (nchunk < 1) nchunk = 1;
+  hipLaunchKernelGGL(glu_bwd4_colsum_kernel, dim3(colblocks, (int)nchunk), dim3(256), 0, s, x, dy, rows, C, dx, dx_amax, scratch);
+  hipLaunchKernelGGL(colreduce_finish_kernel<0>, dim3(ceil_div(2 * C, 64)), dim3(256), 0, s, scratch, (int)nchunk, 2 * C, colsum);
+  OTGAN_CHECK_LAUNCH("glu bwd (+ column sums)");
   return OTGAN_OK;
 }
 int otgan_glu_bwd_f32(const float* x, const float* dy, long rows, int C, float* dx, void* stream) {

@@ -201,6 +201,15 @@ AMAX_RECORD_FLOATS = 512     # otgan_layers.h: OTGAN_AMAX_RECORD_FLOATS
 _AMAX_SLOTS = 256
 _amax_pool = {}       # device -> [zeroed [slots, AMAX_RECORD_FLOATS] tensor, next free slot]
 _FUSED_AMAX = os.environ.get("OTGAN_FUSED_AMAX", "1") != "0"
+_GLU_COLSUM = os.environ.get("OTGAN_GLU_COLSUM", "1") != "0"
+
+
+def colsum_of(t):
+    """Column sums of `t` left by its producer (GluFunction.backward), or None."""
+    tag = getattr(t, "_otgan_colsum", None)
+    if tag is None or tag[1] != t._version:
+        return None
+    return tag[0]
 
 
 def amax_slot(device):
@@ -402,8 +411,10 @@ class Conv2dFunction(torch.autograd.Function):
             dV2d, dg = weightnorm_bwd(V2d, g, inv_norm, dw)
             dV = dV2d.view(ctx.vshape)
         if ctx.has_b and ctx.needs_input_grad[3]:
-            rows = dy.numel() // dy.shape[-1]
-            db = colsum(dy.data_ptr(), rows, dy.shape[-1], dy.shape[-1], dy.device)
+            db = colsum_of(dy)
+            if db is None:
+                rows = dy.numel() // dy.shape[-1]
+                db = colsum(dy.data_ptr(), rows, dy.shape[-1], dy.shape[-1], dy.device)
         return dx, dV, dg, db, None, None, None, None
 
 
@@ -905,8 +916,18 @@ class GluFunction(torch.autograd.Function):
         C2 = x.shape[-1]
         dx = torch.empty_like(x)
         rec = amax_slot(x.device) if (_FUSED_AMAX and (C2 // 2) % 4 == 0) else None
-        _lib.check(_lib.lib().otgan_glu_bwd_amax_f32(x.data_ptr(), dy.data_ptr(), x.numel() // C2,
-                                                     C2 // 2, dx.data_ptr(), _lib.ptr(rec), _lib.stream_ptr()), "glu_bwd")
+        if _GLU_COLSUM and (C2 // 2) % 4 == 0:
+            # dx is the output gradient of the convolution in front of the GLU: leave its column sums (that layer's
+            # bias gradient) with it instead of reading dx once more there
+            cs = torch.empty(C2, dtype=x.dtype, device=x.device)
+            scratch = torch.empty(256 * C2, dtype=x.dtype, device=x.device)
+            _lib.check(_lib.lib().otgan_glu_bwd_colsum_f32(x.data_ptr(), dy.data_ptr(), x.numel() // C2, C2 // 2,
+                                                           dx.data_ptr(), _lib.ptr(rec), cs.data_ptr(), scratch.data_ptr(),
+                                                           _lib.stream_ptr()), "glu_bwd_colsum")
+            dx._otgan_colsum = (cs, dx._version)
+        else:
+            _lib.check(_lib.lib().otgan_glu_bwd_amax_f32(x.data_ptr(), dy.data_ptr(), x.numel() // C2,
+                                                         C2 // 2, dx.data_ptr(), _lib.ptr(rec), _lib.stream_ptr()), "glu_bwd")
         if rec is not None:
             tag_amax(dx, rec)
         return dx

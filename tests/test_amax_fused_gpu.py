@@ -113,3 +113,42 @@ def test_backward_records(monkeypatch):
     assert calls == [], calls
     _critic_pair(dev, 5, strip=True)
     assert len(calls) >= 2          # stripped forward records are reduced again (backward ones still arrive tagged)
+
+
+def test_glu_backward_leaves_the_bias_gradient():
+    """GluFunction.backward tags its result with its column sums (otgan_glu_bwd_colsum_f32): the bias gradient of the
+    convolution in front of the GLU, which then skips its own reduction (ops.colsum_of); a ragged last 64-column block and
+    more rows than one chunk."""
+    from otgan_amd import ops
+    dev = _dev()
+    torch.manual_seed(3)
+    for shape in ((4, 8, 8, 2 * 72), (256, 16, 16, 2 * 256), (2, 4, 4, 2 * 8)):
+        x = torch.randn(shape, device=dev, requires_grad=True)
+        y = ops.glu(x)
+        dy = torch.randn_like(y)
+        seen = {}
+
+        class Probe(torch.autograd.Function):          # sits where the convolution's backward would: sees the GLU's dx
+            @staticmethod
+            def forward(ctx, t):
+                return t.view_as(t)
+
+            @staticmethod
+            def backward(ctx, g):
+                seen["colsum"] = ops.colsum_of(g)
+                seen["g"] = g
+                return g
+        x2 = torch.randn(shape, device=dev, requires_grad=True)
+        y2 = ops.glu(Probe.apply(x2))
+        y2.backward(dy)
+        cs, g = seen["colsum"], seen["g"]
+        assert cs is not None and cs.shape == (shape[-1],)
+        ref = g.double().reshape(-1, shape[-1]).sum(0)
+        assert float((cs.double() - ref).abs().max()) <= 2e-6 * float(g.double().abs().reshape(-1, shape[-1]).sum(0).max()) + 1e-12
+        # and the values of dx itself against autograd through the formula
+        xr = x2.detach().double().requires_grad_(True)
+        a, l = xr[..., :shape[-1] // 2], xr[..., shape[-1] // 2:]
+        (a * torch.sigmoid(l)).backward(dy.double())
+        assert float((g.double() - xr.grad).abs().max()) < 1e-5
+        g.add_(1.0)                                     # modified since: the tag must not be trusted any more
+        assert ops.colsum_of(g) is None
