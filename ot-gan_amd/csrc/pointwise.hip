@@ -180,6 +180,25 @@ __global__ void weightnorm_bwd_kernel(const float* __restrict__ V, const float* 
     dV[i] = g[c] * iv * (dw[i] - V[i] * dot[c] * iv * iv);
   }
 }
+// colreduce_finish_kernel<0> + weightnorm_dg_kernel in one launch: dot[c] = sum of the row-chunk partials (same order),
+// dg[c] = dot[c] * inv[c]
+__global__ __launch_bounds__(256) void wn_dot_finish_kernel(const float* __restrict__ partial, int nchunk, int cols,
+                                                            const float* __restrict__ inv, float* __restrict__ dot,
+                                                            float* __restrict__ dg) {
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (c < cols)
+    for (int k = part; k < nchunk; k += 4) s += partial[(long)k * cols + c];
+  __shared__ float red[4][64];
+  red[part][lane] = s;
+  __syncthreads();
+  if (part == 0 && c < cols) {
+    const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    dot[c] = t;
+    dg[c] = t * inv[c];
+  }
+}
 __global__ void weightnorm_dg_kernel(const float* __restrict__ dot, const float* __restrict__ inv,
                                      int Cout, float* __restrict__ dg) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -707,10 +726,7 @@ int otgan_weightnorm_bwd_f32(const float* V, const float* g, const float* inv_no
   int nchunk = 0;
   int rc = colreduce<2>(dw, V, K, Cout, Cout, partial, &nchunk, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(colreduce_finish_kernel<0>, dim3(ceil_div(Cout, 64)), dim3(256), 0, s, partial,
-                     nchunk, Cout, scratch);
-  hipLaunchKernelGGL(weightnorm_dg_kernel, dim3(ceil_div(Cout, 256)), dim3(256), 0, s, scratch,
-                     inv_norm, Cout, dg);
+  hipLaunchKernelGGL(wn_dot_finish_kernel, dim3(ceil_div(Cout, 64)), dim3(256), 0, s, partial, nchunk, Cout, inv_norm, scratch, dg);
   const long total = (long)K * Cout;
   hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, V, g, inv_norm, dw,
                      scratch, total, Cout, dV);
