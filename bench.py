@@ -306,8 +306,8 @@ def main():
                                      else "fp32 MFMA" + ("; dense blocks are cut into wide 3x3 convolutions of finished channel "
                                                          "groups (Winograd F(4x4,3x3) GEMMs on two scaled fp16 pieces, as in the "
                                                          "DCGAN configuration) + short 16-output growth chains whose 32x32 forward "
-                                                         "uses a three-way bf16 split (fp32-exact products); the stride-2 "
-                                                         "transitions run on the fp32 MFMA engine" if a.model == "densenet" else "")},
+                                                         "uses a three-way bf16 split (fp32-exact products), dgrad / wgrad the fp32 MFMA engine; the "
+                                                         "stride-2 / upsampling transitions are implicit GEMMs on two scaled fp16 pieces" if a.model == "densenet" else "")},
     }
     if prof:
         out["roofline"] = roofline_of(prof, a.model, dt_prof / a.steps * 1e3, a.steps, default_cfg)
