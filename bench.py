@@ -294,6 +294,10 @@ def main():
                                 "note": "timed window starts on a critic step; the reference's schedule is 1 critic : "
                                         f"{args.nr_gen_per_disc} generator steps (train.py:24,214)"},
                    **({"collectives": "forced (RCCL, world size 1)"} if (world == 1 and model.collectives) else {}),
+                   "collectives_mode": (parallel.collectives_mode() + (" (default: no collective kernel runs beside the step's "
+                                        "kernels; OTGAN_OVERLAP_COLLECTIVES=1 opts into buckets inside the backward pass)"
+                                        if parallel.collectives_mode() == "serial" else " (opt-in)")
+                                        if model.collectives else "none (single process, no collectives)"),
                    "last_distance": float(last["distance"]), "last_entropy": float(last["entropy"]),
                    "precision_note": ("fp32 tensors and fp32 accumulation everywhere; the Winograd-domain GEMMs multiply "
                                       "operands stored as two fp16 pieces of the power-of-two-scaled value (hi + lo = 22 "

@@ -76,21 +76,17 @@ def self_launch(script, argv, nranks):
     (no WORLD_SIZE in the environment) and more than one rank is wanted, re-execute it under
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node nranks` on the loopback address and return the
     children's exit code.  The caller exits with it."""
-    import socket
     import subprocess
     import sys
     check_devices(nranks)
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
     if single_device_mode():
         env.setdefault("OTGAN_DIST_BACKEND", "gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    # --standalone: torchrun's own rendezvous picks a free port on the loopback address (no bind-then-close race)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={nranks}", script] + list(argv)
     return subprocess.call(cmd, env=env)
 
 
@@ -109,6 +105,26 @@ def _skip_collectives():
 
 def get_rank():
     return dist.get_rank() if dist.is_initialized() else 0
+
+
+def collectives_mode():
+    """'serial' or 'overlapped': may a collective's kernels run BESIDE the step's own kernels?
+
+    Overlapped: the gradient buckets leave inside the backward pass and the feature all-gather runs under the generator's
+    forward pass (RCCL's stream next to the compute stream).  Serial: every collective is enqueued behind the compute
+    that precedes it and the compute stream waits for it before it continues, so no collective kernel is ever
+    co-resident with a kernel of this library.  DESIGN section 3 "Four hazards", item 3: kernels co-resident with the
+    256 x 128 GEMM were seen computing wrong values, and RCCL's own kernels (not recompilable) have never run beside that
+    GEMM on the one-GPU boxes of this build -- so SERIAL IS THE DEFAULT on RCCL, and overlap is an explicit opt-in
+    (OTGAN_OVERLAP_COLLECTIVES=1) for whoever has verified a multi-GPU run against its single-GPU twin.
+    OTGAN_SERIAL_COLLECTIVES=1 (round 3's switch) still forces serial.  gloo (tests) stages through the host and is
+    synchronous either way."""
+    if os.environ.get("OTGAN_SERIAL_COLLECTIVES") == "1":
+        return "serial"
+    v = os.environ.get("OTGAN_OVERLAP_COLLECTIVES")
+    if v is not None and v != "":
+        return "overlapped" if v != "0" else "serial"
+    return "serial"
 
 
 def _staged():
@@ -154,6 +170,9 @@ def all_gather_rows_async(x):
         return PendingGather(all_gather_rows(x), None)
     out = torch.empty((w * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     work = dist.all_gather_into_tensor(out, x, async_op=True)
+    if collectives_mode() == "serial":
+        work.wait()      # the compute stream waits here: nothing enqueued after this call runs beside the gather
+        work = None
     return PendingGather(out, work)
 
 
@@ -267,10 +286,9 @@ class GradBuckets:
                 host = seg.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM)
                 seg.copy_(host)
-            elif os.environ.get("OTGAN_SERIAL_COLLECTIVES") == "1":
-                # no collective kernel beside the backward pass's kernels (DESIGN section 3 "Four hazards", item 3: two VALU
-                # kernels computed wrong values next to waves of the 256 x 128 GEMM; RCCL's reduction kernels could not be
-                # tried on the one-GPU boxes of this build): all buckets go out after the last gradient, in finish()
+            elif collectives_mode() == "serial":
+                # no collective kernel beside the backward pass's kernels (collectives_mode): all buckets go out after
+                # the last gradient, in finish()
                 self.deferred.append(seg)
             else:
                 self.works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
@@ -281,8 +299,8 @@ class GradBuckets:
             self.armed = False
             raise RuntimeError("GradBuckets.finish(): some variables received no gradient in this backward pass")
         if self.deferred:
-            if torch.cuda.is_available():
-                torch.cuda.current_stream().synchronize()      # the backward pass has drained
+            # the process group orders a collective behind everything already enqueued on the current stream (the whole
+            # backward pass by now) and wait() below makes the stream wait for it: no host synchronisation needed
             for seg in self.deferred:
                 self.works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
             self.deferred = []

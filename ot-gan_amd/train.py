@@ -142,12 +142,15 @@ def auto_ranks(nr_gpu, devices, scope='global'):
     return 1
 
 
-def main(argv=None):
+def main(argv=None, self_launch=False):
+    """`self_launch`: set by the command-line entry points (train.py at the repository root, `python -m`): the plain
+    invocation drives every visible device.  An in-process caller (a test, a notebook) gets a single-rank run in its
+    own process unless it passes --ranks explicitly -- never a surprise SystemExit."""
     args = build_parser().parse_args(argv)
     assert args.nr_gpu % 2 == 0                                   # train.py:34
     from . import parallel
     from .trainer import OTGAN
-    if not parallel.launched():
+    if not parallel.launched() and (self_launch or args.ranks):
         # one command drives every device, like the reference's tower loop (train.py:72-85): a rank is a process
         # here, so the plain invocation re-executes itself under torch.distributed.run
         want = args.ranks or auto_ranks(args.nr_gpu, torch.cuda.device_count() if torch.cuda.is_available() else 0,
@@ -240,4 +243,4 @@ def main(argv=None):
 
 
 if __name__ == '__main__':
-    main()
+    main(self_launch=True)

@@ -63,10 +63,18 @@ def run(force):
     m.close()
     return out
 
+os.environ.pop("OTGAN_OVERLAP_COLLECTIVES", None)
+os.environ.pop("OTGAN_SERIAL_COLLECTIVES", None)
+assert parallel.collectives_mode() == "serial"           # the default on RCCL: no collective kernel beside the step's kernels
 a, b = run(True), run(False)
-for (ga, da), (gb_, db) in zip(a, b):
-    assert abs(da - db) <= 1e-12 * abs(db), (da, db)     # fp64 atomics in the distance reduction: order-dependent last bits
-    assert all(torch.equal(s, t) for s, t in zip(ga, gb_))
+os.environ["OTGAN_OVERLAP_COLLECTIVES"] = "1"            # opt-in: buckets inside the backward pass, gather under the generator
+assert parallel.collectives_mode() == "overlapped"
+c = run(True)
+os.environ.pop("OTGAN_OVERLAP_COLLECTIVES")
+for other in (a, c):
+    for (ga, da), (gb_, db) in zip(other, b):
+        assert abs(da - db) <= 1e-12 * abs(db), (da, db)     # fp64 atomics in the distance reduction: order-dependent last bits
+        assert all(torch.equal(s, t) for s, t in zip(ga, gb_))
 torch.cuda.synchronize()
 dist.destroy_process_group()
 print("RCCL_WS1_OK")

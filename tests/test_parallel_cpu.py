@@ -86,11 +86,13 @@ def _worker(rank, world, port, out):
 
 @pytest.mark.parametrize("serial", [False, True], ids=["overlapped", "serial_collectives"])
 def test_two_rank_plumbing_gloo(serial, monkeypatch):
-    # serial: OTGAN_SERIAL_COLLECTIVES=1 -- the gradient buckets go out after the backward pass instead of inside it
+    # serial (the default, parallel.collectives_mode): the gradient buckets go out after the backward pass instead of
+    # inside it; overlapped: OTGAN_OVERLAP_COLLECTIVES=1
+    monkeypatch.delenv("OTGAN_SERIAL_COLLECTIVES", raising=False)
     if serial:
-        monkeypatch.setenv("OTGAN_SERIAL_COLLECTIVES", "1")
+        monkeypatch.delenv("OTGAN_OVERLAP_COLLECTIVES", raising=False)
     else:
-        monkeypatch.delenv("OTGAN_SERIAL_COLLECTIVES", raising=False)
+        monkeypatch.setenv("OTGAN_OVERLAP_COLLECTIVES", "1")
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
@@ -103,6 +105,20 @@ def test_two_rank_plumbing_gloo(serial, monkeypatch):
         assert p.exitcode == 0
     got = sorted(q.get(timeout=5) for _ in range(world))
     assert got == [(0, True), (1, True)]
+
+
+def test_collectives_are_serial_unless_overlap_is_asked_for(monkeypatch):
+    from otgan_amd import parallel
+    monkeypatch.delenv("OTGAN_SERIAL_COLLECTIVES", raising=False)
+    monkeypatch.delenv("OTGAN_OVERLAP_COLLECTIVES", raising=False)
+    assert parallel.collectives_mode() == "serial"
+    monkeypatch.setenv("OTGAN_OVERLAP_COLLECTIVES", "1")
+    assert parallel.collectives_mode() == "overlapped"
+    monkeypatch.setenv("OTGAN_SERIAL_COLLECTIVES", "1")         # round 3's switch wins
+    assert parallel.collectives_mode() == "serial"
+    monkeypatch.delenv("OTGAN_SERIAL_COLLECTIVES")
+    monkeypatch.setenv("OTGAN_OVERLAP_COLLECTIVES", "0")
+    assert parallel.collectives_mode() == "serial"
 
 
 def test_single_process_passthrough():

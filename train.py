@@ -8,4 +8,4 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from otgan_amd.train import main  # noqa: E402
 
 if __name__ == '__main__':
-    main()
+    main(self_launch=True)
