@@ -716,7 +716,11 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int i = i0; i < i0 + n; ++i) {
       const u16* src = cbase[i] + (TL ? ((((kb >> 1) * ccbn[i]) << 9) + ((kb & 1) << 8)) : (kb << 9));
       const unsigned dst = cdst[i] + buf * X3N_STAGE;
+#ifdef X3N_DBG_NODMA   // (tools/debug/build_corun_variants.sh: the kernel as a neighbour without one of its ingredients; results garbage)
+      asm volatile("" ::"v"(voff), "s"(src), "s"(dst) : "memory");
+#else
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(dst) : "memory");
+#endif
     }
   };
   f32x16 acc[X3_MT][X3N_NT];
@@ -782,14 +786,25 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       if (LOAD) {
 #pragma unroll
         for (int q = q0; q < q1; ++q) {
+#ifdef X3N_DBG_NOREAD
+          if (q < NRA) G.a[q / X3_NP][q % X3_NP] = F.a[q / X3_NP][q % X3_NP];
+          else G.b[(q - NRA) / X3_NP][(q - NRA) % X3_NP] = F.b[(q - NRA) / X3_NP][(q - NRA) % X3_NP];
+#else
           if (q < NRA) G.a[q / X3_NP][q % X3_NP] = read_frag(pa + (q % X3_NP) * X3_TA + (q / X3_NP) * 1024);
           else G.b[(q - NRA) / X3_NP][(q - NRA) % X3_NP] = read_frag(pb + ((q - NRA) % X3_NP) * X3N_TB + ((q - NRA) / X3_NP) * 1024);
+#endif
         }
       }
 #pragma unroll
       for (int i = 0; i < X3_MT; ++i)
 #pragma unroll
-        for (int j = 0; j < X3N_NT; ++j) acc[i][j] = X3_MFMA(F.a[i][X3_PA[t]], F.b[j][X3_PB[t]], acc[i][j]);
+        for (int j = 0; j < X3N_NT; ++j) {
+#ifdef X3N_DBG_NOMFMA
+          asm volatile("" : "+v"(acc[i][j]) : "v"(F.a[i][X3_PA[t]]), "v"(F.b[j][X3_PB[t]]));
+#else
+          acc[i][j] = X3_MFMA(F.a[i][X3_PA[t]], F.b[j][X3_PB[t]], acc[i][j]);
+#endif
+        }
       if (LOAD) x3n_sched_group<TL ? 2 : 1, q1 - q0, X3_MT * X3N_NT>();
     });
   };

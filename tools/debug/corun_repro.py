@@ -29,8 +29,8 @@ Va2, ga2, ba2 = params(5, 512, 512)
 
 
 def corun():
-    ops.conv2d_op(xa, Va, ga, ba, stride=2, preact=ops.ACT["crelu"])
-    ops.conv2d_op(xa2, Va2, ga2, ba2, stride=2, preact=ops.ACT["crelu"])
+    return (ops.conv2d_op(xa, Va, ga, ba, stride=2, preact=ops.ACT["crelu"]),
+            ops.conv2d_op(xa2, Va2, ga2, ba2, stride=2, preact=ops.ACT["crelu"]))
 
 
 if victim == "rgbin":
@@ -86,6 +86,43 @@ elif victim == "matching":
     def run_victim():
         ga_, gb_, ent, dist = matching.matched_feature_grads(fa, fb, 500.0, 100)
         return torch.cat([ga_.reshape(-1), gb_.reshape(-1), ent.reshape(-1).float(), dist.reshape(-1).float()])
+elif victim == "matching256":
+    # N = 256: the persistent multi-workgroup Sinkhorn (sinkhorn_panel_kernel) and the split-precision cost / plan GEMMs
+    from otgan_amd.utils import matching
+    fa = torch.nn.functional.normalize(torch.rand(512, 4096, generator=g), dim=1).to(dev)
+    fb = torch.nn.functional.normalize(torch.rand(512, 4096, generator=g), dim=1).to(dev)
+
+    def run_victim():
+        ga_, gb_, ent, dist = matching.matched_feature_grads(fa, fb, 500.0, 50)
+        return torch.cat([ga_.reshape(-1), gb_.reshape(-1), ent.reshape(-1).float()])
+elif victim == "adam":
+    # the gathered Adam step with the fused EMA (otgan_adam_step_gather_f32) from fixed state
+    sizes = [128 * 1024, 5 * 5 * 256 * 256, 256, 3 * 1000 + 7]
+    offs = [0]
+    for n_ in sizes:
+        offs.append(offs[-1] + n_)
+    p0 = torch.randn(offs[-1], generator=g).to(dev)
+    grads = [torch.randn(n_, generator=g).to(dev) for n_ in sizes]
+    v0, m0, e0 = torch.randn(offs[-1], generator=g).to(dev), torch.rand(offs[-1], generator=g).to(dev), torch.randn(offs[-1], generator=g).to(dev)
+
+    def run_victim():
+        p, v, mg, e = p0.clone(), v0.clone(), m0.clone(), e0.clone()
+        ops.adam_step_gather(p, grads, offs, v, mg, 3e-4, 0.5, 0.999, 3.0, e, 0.999)
+        return torch.cat([p, v, mg, e])
+elif victim == "wn":
+    # weight norm forward + backward (column reductions over [K][Cout]) through a small direct convolution
+    xv = torch.randn(4, 8, 8, 64, generator=g).to(dev)
+    Vv = (torch.randn(3, 3, 64, 96, generator=g) * 0.05).to(dev).requires_grad_(True)
+    gv = torch.rand(96, generator=g).add(0.5).to(dev).requires_grad_(True)
+    bv = torch.zeros(96, device=dev).requires_grad_(True)
+    dyv = torch.randn(4, 8, 8, 96, generator=g).to(dev)
+
+    def run_victim():
+        ops.bump_weights_epoch()
+        with torch.enable_grad():
+            y = ops.conv2d_op(xv, Vv, gv, bv, stride=1, preact=ops.ACT[None])
+            dV, dg, db = torch.autograd.grad(y, [Vv, gv, bv], dyv)
+        return torch.cat([y.detach().reshape(-1), dV.reshape(-1), dg.reshape(-1), db.reshape(-1)])
 elif victim == "glu":
     xv = torch.randn(4, 16, 16, 512, generator=g).to(dev)
     run_victim = lambda: ops.glu(xv)
@@ -98,15 +135,14 @@ else:
     run_victim = lambda: ops.conv2d_op(xv, Vv, gv, bv, stride=2, preact=ops.ACT["crelu"])
 
 with torch.no_grad():
-    corun()
+    gref = [t.clone() for t in corun()]
     ref = run_victim().clone()
     torch.cuda.synchronize()
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
-    bad = 0
+    bad = gbad = 0
     for it in range(iters):
         with torch.cuda.stream(sa):
-            for _ in range(3):
-                corun()
+            gouts = [corun() for _ in range(3)]
         with torch.cuda.stream(sb):
             outs = [run_victim() for _ in range(12)]
         torch.cuda.synchronize()
@@ -117,4 +153,10 @@ with torch.no_grad():
                 bad += 1
                 if bad <= 5:
                     print(f"iter {it}: {int(d.sum())} elements differ, index range {idx.min(0).values.tolist()} .. {idx.max(0).values.tolist()}", flush=True)
-    print("CORUN", victim, "mismatching results:", bad, "of", iters * 12, flush=True)
+        for go in gouts:      # the GEMM layers themselves as the victim
+            for t, r in zip(go, gref):
+                if not torch.equal(t, r):
+                    gbad += 1
+                    if gbad <= 5:
+                        print(f"iter {it}: GEMM-side layer output differs in {int((t != r).sum())} elements", flush=True)
+    print("CORUN", victim, "mismatching results:", bad, "of", iters * 12, "; GEMM-side mismatches:", gbad, "of", iters * 6, flush=True)
