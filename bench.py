@@ -55,7 +55,7 @@ def roofline_of(prof, model, ms_per_step_prof, steps, default_cfg):
     try:
         if not (default_cfg or model == "densenet"):
             raise LookupError("no PMC summary for this configuration")
-        for rnd in ("r03", "r02", "r02b", "r01"):          # newest committed PMC summary of this configuration
+        for rnd in ("r04", "r03", "r02", "r02b", "r01"):          # newest committed PMC summary of this configuration
             fn = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary_{model}.json")
             if os.path.exists(fn):
                 with open(fn) as f:
@@ -71,7 +71,9 @@ def roofline_of(prof, model, ms_per_step_prof, steps, default_cfg):
     peak = PEAK_BF16_MFMA_TFLOPS if dom == "wino_gemm_bf16x3" else PEAK_F32_MFMA_TFLOPS
     r = {"bound": "mfma", "kernel": kname.get(dom, dom), "achieved": round(ach, 2),
          "peak": peak, "unit": "TFLOP/s",
-         "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+         "frac": round(ach / peak, 4),
+         # not measured in this run (PMC counters need rocprofv3's own passes): null here, the committed profile's figure beside it
+         "traffic": None, "traffic_from_committed_profile": traffic, "traffic_source": traffic_src,
          "launches": d["launches"], "avg_ms": round(d["ms"] / max(d["launches"], 1), 4),
          "time_share_of_step": round(d["ms"] / (ms_per_step_prof * steps), 4),
          "pass": f"second pass of {steps} steps with per-launch HIP events "
@@ -117,6 +119,30 @@ def secondary(dev, a):
                  "grads_generator_step": lambda: matching.matched_feature_grads(fa_flat, fb_flat, 500.0, L, need_b=False, rows=rr),
                  "grads_critic_step": lambda: matching.matched_feature_grads(fa_flat, fb_flat, 500.0, L, need_b=True, rows=rr)}
         case = {"N": N, "D": D, "iters": L, "rows": "all" if rows is None else rows}
+        if rows is not None:
+            # What rank 0 of 2N / rows ranks runs per step in the global matching scope (trainer._match): its three
+            # [rows, N] cost row slices (the reference's sharding of the cost GEMMs, utils/matching.py:29-39), then -- on the
+            # all-gathered six log-kernels -- the Sinkhorn problems and the plans applied to its own rows.  The all-gather
+            # of the slices (6 N^2 floats in total) is NOT in this time; the assembled log-kernels are precomputed here.
+            # The calls above, without precomputed log-kernels, make the library compute all six N x N costs itself:
+            # more cost work than a rank does (labelled below).
+            from otgan_amd import trainer as T
+            W = 2 * N // rows
+            own = lambda t, r: t[r * rows:(r + 1) * rows]
+            allk = torch.stack([T.rank_log_kernel_slices(r, W, own(fa_flat, r), own(fb_flat, r), fa_flat, fb_flat, 500.0)
+                                for r in range(W)], 0)
+            K6 = T.assemble_log_kernels(allk, W)
+            del allk
+
+            def rank_step(need_b):
+                T.rank_log_kernel_slices(0, W, own(fa_flat, 0), own(fb_flat, 0), fa_flat, fb_flat, 500.0)
+                return matching.matched_feature_grads(fa_flat, fb_flat, 500.0, L, need_b=need_b, rows=rr, log_kernels=K6)
+            calls["rank_generator_step"] = lambda: rank_step(False)
+            calls["rank_critic_step"] = lambda: rank_step(True)
+            case["ranks"] = W
+            case["note"] = ("us_rank_*: what one rank of %d runs (cost row slices + Sinkhorn + plans on its rows; slice "
+                            "all-gather excluded); us / us_grads_*: the same rows WITHOUT precomputed log-kernels -- the "
+                            "library computes all six N x N costs, not a rank's workload" % W)
         for tag, call in calls.items():
             for _ in range(2):
                 call()
@@ -135,10 +161,12 @@ def secondary(dev, a):
             else:
                 case["us_" + tag] = round(us, 1)
         blocks.append(case)
+        K6 = None
         del fa, fb, fa_flat, fb_flat
     sec["matching_block"] = {"unit": "microseconds per call (wall, 5 calls); `us` / `tflops` (on 12*N^2*D + 24*N^2*D*(rows/2N)): the "
                                      "reference's operator = four matched arrays; us_grads_*: the training-mode entry the step calls "
-                                     "(otgan_matching_two_batch_grad_f32: injected gradients directly, closed-form distance)",
+                                     "(otgan_matching_two_batch_grad_f32: injected gradients directly, closed-form distance); "
+                                     "us_rank_*: the per-step matching work of one data-parallel rank (see the case's note)",
                              "cases": blocks}
     torch.cuda.empty_cache()
     for tag, kw, size, bpg, (w, k) in (

@@ -135,6 +135,25 @@ int otgan_matching_single_batch_f32(const float* fa, const float* fb, int n, int
                                     float* entropy, double* dist, double* stats,
                                     void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * Training-mode single-batch matching: what the --single_batch step consumes (train.py:111,125-126 on the outputs of
+ * matching.py:131-134) -- grad_a = f_aa - f_ab = M_aa a - M_ab b and grad_b = f_bb - f_ba = M_bb b - M_ab^T a (grad_b
+ * nullable: generator steps) as two-term plan applications, dist = (T_bb + T_aa - 2 T_ab) / (2n), T = sum(M) - <M,C>, from the
+ * Sinkhorn statistics.  The _rows_ variant produces rows [row_begin, +row_count) of [0, n) -- the samples of one
+ * data-parallel rank -- into [row_count, D] buffers; K_pre (nullable) = the three [n, n] log-kernels a-a, b-b (both with
+ * -lambda*999 on the diagonal), a-b, e.g. assembled from the ranks' row slices (the reference shards exactly these
+ * GEMMs over its towers, matching.py:99-104).  Workspace: otgan_matching_single_batch_grad_workspace_bytes.
+ */
+size_t otgan_matching_single_batch_grad_workspace_bytes(int n, int D);
+int otgan_matching_single_batch_grad_f32(const float* fa, const float* fb, int n, int D, long ldf, float sinkhorn_lambda,
+                                         int iters, float* grad_a, float* grad_b, long ldo, float* entropy, double* dist,
+                                         double* stats, void* workspace, size_t workspace_bytes, void* stream);
+int otgan_matching_single_batch_rows_grad_f32(const float* fa, const float* fb, int n, int D, long ldf,
+                                              float sinkhorn_lambda, int iters, int row_begin, int row_count,
+                                              const float* K_pre, float* grad_a, float* grad_b, long ldo, float* entropy,
+                                              double* dist, double* stats, void* workspace, size_t workspace_bytes,
+                                              void* stream);
+
 /* Staged entry points (same kernels, exposed for parity tests and custom pipelines). */
 
 /* K[n,m] = -lambda * (cost(X[n,D], Y[m,D]) + diag_add * I)     (matching.py:31,50,109) */

@@ -110,12 +110,20 @@ def dense(x, p, pre=None, init=False, init_scale=1.0):
 # differ only where |x| is at rounding level, so the VALUE moves by rounding-level amounts -- but a gradient comparison no
 # longer depends on which side of zero such a unit fell (one such unit moves every gradient of a step by 2e-4 .. 5e-4).
 FORCED_HEAD_SIGNS = None
+# per forced call: (units whose forced sign differs from sign(x) of this evaluation, largest |x| among them relative to the
+# RMS of its sample's pre-activations) -- the tests bound both, so that a forward kernel flipping many or large units fails
+FORCED_HEAD_REPORT = []
 
 
 def feature_head(x):
     """models/dcgan.py:16-19"""
     if FORCED_HEAD_SIGNS is not None:
         sign = FORCED_HEAD_SIGNS.pop(0).to(x.device)      # -1 / 0 / +1: relu'(0) = 0 on both halves, as in the reference
+        with torch.no_grad():
+            differ = sign.to(x.dtype) != torch.sign(x)
+            rms = x.reshape(x.shape[0], -1).pow(2).mean(1).sqrt().reshape(-1, 1, 1, 1)
+            rel = (x.abs() / rms)[differ]
+            FORCED_HEAD_REPORT.append((int(differ.sum()), float(rel.max()) if rel.numel() else 0.0))
         zero = torch.zeros_like(x)
         x = torch.cat([torch.where(sign > 0, x, zero), torch.where(sign < 0, -x, zero)], 3)
     else:

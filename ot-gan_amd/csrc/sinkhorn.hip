@@ -682,6 +682,15 @@ __global__ void closed_form_distance_kernel(const double* stats, int N, double* 
   dist[0] = (2.0 * T[0] + 2.0 * T[1] - (T[2] + T[3] + T[4] + T[5])) / (4.0 * N) + failure_poison(stats, 6);
 }
 
+// single-batch distance the same way (matching.py:147-152 with the three plans of :131-134):
+// nd_xy = sum(M_xy) - <M_xy, C_xy> (the 999 on the diagonal meets plan entries that are exactly 0),
+// dist = (nd_bb + nd_aa - 2 nd_ab) / (2 n)
+__global__ void closed_form_single_distance_kernel(const double* stats, int n, double* dist) {
+  double T[3];
+  for (int p = 0; p < 3; ++p) T[p] = stats[p * 4 + 2] - stats[p * 4 + 1];
+  dist[0] = (T[1] + T[0] - 2.0 * T[2]) / (2.0 * n) + failure_poison(stats, 3);
+}
+
 // ======================================================================================
 // 5. The matching GEMMs on the bf16 matrix pipe with split-precision operands (gemm_x3.h)
 // ======================================================================================
@@ -1530,6 +1539,106 @@ int otgan_matching_single_batch_f32(const float* fa, const float* fb, int n, int
   if (rc) return rc;
   if (stats) hipMemcpyAsync(stats, w.stats, sizeof(double) * 12, hipMemcpyDeviceToDevice, s);
   return OTGAN_OK;
+}
+
+// Training-mode single-batch matching: the injected gradients f_aa - f_ab (train.py:111) and f_bb - f_ba (train.py:125-126)
+// of --single_batch directly, for all rows or for the rows of one data-parallel rank, with the three log-kernels
+// optionally precomputed (the rank's row slices of matching.py:99-104, all-gathered: K_pre [3][n][n] in the order a-a
+// (+999 I), b-b (+999 I), a-b).  g(a) = M_aa a - M_ab b, g(b) = M_bb b - M_ab^T a: two-term plan applications.
+static int single_grad_impl(const float* fa, const float* fb, int n, int D, long ldf, float lambda, int iters, int row_begin,
+                            int row_count, const float* K_pre, float* grad_a, float* grad_b, long ldo, float* entropy,
+                            double* dist, double* stats, void* workspace, size_t workspace_bytes, void* stream) {
+  OTGAN_CHECK_ARG(fa && fb && grad_a && entropy && dist, "null pointer");
+  OTGAN_CHECK_ARG(n > 0 && D > 0 && ldf >= D && ldo >= D && iters >= 0, "bad sizes n=%d D=%d", n, D);
+  OTGAN_CHECK_ARG(row_begin >= 0 && row_count > 0 && row_begin + row_count <= n,
+                  "row range [%d, %d) outside [0, %d)", row_begin, row_begin + row_count, n);
+  hipStream_t s = (hipStream_t)stream;
+  MatchWs w = carve_match(workspace, workspace_bytes, 3, n, D, n, true);
+  if (!workspace || workspace_bytes < w.bytes) {
+    otgan_set_error("workspace too small: need %zu bytes, got %zu", w.bytes, workspace_bytes);
+    return OTGAN_ERR_WORKSPACE;
+  }
+  const float* X[3] = {fa, fb, fa};
+  const float* Y[3] = {fa, fb, fb};
+  const float diag[3] = {999.f, 999.f, 0.f};  // matching.py:109-110
+  const bool x3 = w.x3 && ldf % 4 == 0 && ldo % 4 == 0 && aligned16(fa) && aligned16(fb) && aligned16(grad_a) &&
+                  aligned16(grad_b) && row_begin % 16 == 0;
+  int rc = OTGAN_OK;
+  if (x3) x3_split_features(w, fa, fb, n, D, ldf, s);   // stacked rows: a [0, n), b [n, 2n)
+  const float* Kuse = K_pre;
+  if (!K_pre) {
+    if (x3) {
+      const long xrow[3] = {0, n, 0};
+      const long yrow[3] = {0, n, n};
+      ProfScope ps(OTGAN_PROF_COST_GEMM, 6.0 * n * (double)n * D, 8.0 * n * (double)D, s);
+      rc = launch_cost_x3(w.FP, w.planeF, 2L * n, xrow, yrow, diag, 3, n, n, D, lambda, w.partial, w.K, s);
+    } else {
+      rc = launch_cost(X, Y, nullptr, nullptr, diag, 3, n, n, D, ldf, lambda, OTGAN_COST_COSINE, w.partial, w.K, s);
+    }
+    if (rc) return rc;
+    Kuse = w.K;
+  }
+  rc = launch_sinkhorn(Kuse, 3, n, n, iters, lambda, w.plan, w.planT, w.stats, w.fg, s);
+  if (rc) return rc;
+  const size_t nn = (size_t)n * n;
+  const float *M[3], *T[3];
+  for (int p = 0; p < 3; ++p) { M[p] = w.plan + p * nn; T[p] = w.planT + p * nn; }
+  const int nblk = grad_b ? 2 : 1;
+  float* outp[2] = {grad_a, grad_b};
+  if (x3) {
+    // plan operand (A = the TRANSPOSE of the plan applied: out = A^T F), per difference two n-row blocks in the order
+    // of the feature stack [a; b]:   g(a): T_aa, -T_ab        g(b): -M_ab, T_bb
+    SplitSrc sp;
+    memset(&sp, 0, sizeof(sp));
+    const float* src[2][2] = {{T[0], T[2]}, {M[2], T[1]}};
+    const float scl[2][2] = {{1.f, -1.f}, {-1.f, 1.f}};
+    sp.n = 2 * nblk;
+    for (int z = 0; z < nblk; ++z)
+      for (int t = 0; t < 2; ++t) {
+        const int i = 2 * z + t;
+        sp.src[i] = src[z][t]; sp.ld[i] = n; sp.row0[i] = (long)i * n; sp.scale[i] = scl[z][t];
+      }
+    x3_split(sp, n, n, w.PT, w.planeP, s);
+    X3ApplyBlock xb[2];
+    for (int z = 0; z < nblk; ++z) xb[z] = X3ApplyBlock{w.PT, 2L * z * n, 0, 2 * n, outp[z]};
+    rc = launch_apply_x3(xb, nblk, w.PT, w.planeP, n, w.FP, w.planeF, row_begin, row_count, D, ldo, s);
+  } else {
+    ApplyBlock blk[2];
+    memset(blk, 0, sizeof(blk));
+    const long ro = (long)row_begin * n;
+    const float *P1[2] = {M[2], T[2]}, *F1[2] = {fb, fa}, *P0[2] = {M[0], M[1]}, *F0[2] = {fa, fb};
+    for (int z = 0; z < nblk; ++z) {
+      blk[z].out = outp[z]; blk[z].rows = row_count; blk[z].nterms = 2; blk[z].alpha = 1.f;
+      blk[z].t[0] = ApplyTerm{P1[z] + ro, F1[z], (long)n, n};
+      blk[z].t[1] = ApplyTerm{P0[z] + ro, F0[z], (long)n, n};
+      blk[z].rescale[1] = -1.f;     // (-1)(M_ab b) + M_aa a
+    }
+    rc = launch_apply(blk, nblk, row_count, D, ldf, ldo, s);
+  }
+  if (rc) return rc;
+  hipLaunchKernelGGL(entropy_finalize_kernel, dim3(1), dim3(1), 0, s, w.stats, 3, n, entropy);
+  hipLaunchKernelGGL(closed_form_single_distance_kernel, dim3(1), dim3(1), 0, s, w.stats, n, dist);
+  OTGAN_CHECK_LAUNCH("single-batch matching finalize");
+  if (stats) hipMemcpyAsync(stats, w.stats, sizeof(double) * 12, hipMemcpyDeviceToDevice, s);
+  return OTGAN_OK;
+}
+
+size_t otgan_matching_single_batch_grad_workspace_bytes(int n, int D) {
+  if (n <= 0 || D <= 0) return 0;
+  return carve_match(nullptr, 0, 3, n, D, n, true).bytes;
+}
+int otgan_matching_single_batch_grad_f32(const float* fa, const float* fb, int n, int D, long ldf, float lambda, int iters,
+                                         float* grad_a, float* grad_b, long ldo, float* entropy, double* dist,
+                                         double* stats, void* workspace, size_t workspace_bytes, void* stream) {
+  return single_grad_impl(fa, fb, n, D, ldf, lambda, iters, 0, n, nullptr, grad_a, grad_b, ldo, entropy, dist, stats, workspace,
+                          workspace_bytes, stream);
+}
+int otgan_matching_single_batch_rows_grad_f32(const float* fa, const float* fb, int n, int D, long ldf, float lambda,
+                                              int iters, int row_begin, int row_count, const float* K_pre, float* grad_a,
+                                              float* grad_b, long ldo, float* entropy, double* dist, double* stats,
+                                              void* workspace, size_t workspace_bytes, void* stream) {
+  return single_grad_impl(fa, fb, n, D, ldf, lambda, iters, row_begin, row_count, K_pre, grad_a, grad_b, ldo, entropy, dist,
+                          stats, workspace, workspace_bytes, stream);
 }
 
 // workspace of the (batched) staged cost entry point: split-K partial sums, the toy cost's row statistics and --

@@ -131,9 +131,17 @@ class OTGAN:
                 # second half its rows of (b2,b1) (a2,b1) (a2,b2); the slices are all-gathered.
                 # Every rank then solves the six (small, on-chip) Sinkhorn problems and applies the
                 # plans only to the rows of its own samples.
-                fa, fb = list(torch.chunk(allg, S, 0)), list(torch.chunk(alld, S, 0))
-                K = self._sharded_log_kernels(f_gen, f_dat, fa, fb)
+                K = self._sharded_log_kernels(f_gen, f_dat, allg, alld)
                 g_gen, g_dat, ent, dist = matching.matched_feature_grads(
+                    allg, alld, a.sinkhorn_lambda, a.nr_sinkhorn_iter, need_b=need_dat,
+                    rows=(self.rank * self.nb, self.nb), log_kernels=K)
+                return g_gen, g_dat, dist, ent
+            if a.single_batch:
+                # --single_batch in the global scope, row-sharded like the reference (matching.py:99-104): this rank's rows
+                # of the a-a, b-b and a-b costs, all-gathered; every rank solves the three problems and applies the plans to
+                # its own rows only (training-mode entry: the injected differences directly)
+                K = self._sharded_single_log_kernels(f_gen, f_dat, allg, alld)
+                g_gen, g_dat, ent, dist = matching.matched_feature_grads_single_batch(
                     allg, alld, a.sinkhorn_lambda, a.nr_sinkhorn_iter, need_b=need_dat,
                     rows=(self.rank * self.nb, self.nb), log_kernels=K)
                 return g_gen, g_dat, dist, ent
@@ -145,9 +153,13 @@ class OTGAN:
                 g_gen, g_dat, ent, dist = matching.matched_feature_grads(
                     f_gen, f_dat, a.sinkhorn_lambda, a.nr_sinkhorn_iter, need_b=need_dat)
                 return g_gen, g_dat, dist, ent
+            if a.single_batch:
+                g_gen, g_dat, ent, dist = matching.matched_feature_grads_single_batch(
+                    f_gen, f_dat, a.sinkhorn_lambda, a.nr_sinkhorn_iter, need_b=need_dat)
+                return g_gen, g_dat, dist, ent
             fa = list(torch.chunk(f_gen, self.shards, 0))
             fb = list(torch.chunk(f_dat, self.shards, 0))
-        if a.single_batch:
+        if a.single_batch:      # (not reached: both scopes take the training-mode entry above)
             m = matching.get_matched_features_single_batch(fa, fb, a.sinkhorn_lambda, a.nr_sinkhorn_iter)
         else:
             m = matching.get_matched_features_random(fa, fb)
@@ -163,6 +175,11 @@ class OTGAN:
         mine = rank_log_kernel_slices(self.rank, self.world, f_gen, f_dat, fa, fb, self.args.sinkhorn_lambda)
         allk = parallel.all_gather_rows(mine.unsqueeze(0))                              # [W,3,nb,N]
         return assemble_log_kernels(allk, self.world)
+
+    def _sharded_single_log_kernels(self, f_gen, f_dat, allg, alld):
+        mine = rank_single_log_kernel_slices(f_gen, f_dat, allg, alld, self.args.sinkhorn_lambda)
+        allk = parallel.all_gather_rows(mine.unsqueeze(0))                              # [W,3,nb,n]
+        return assemble_single_log_kernels(allk, self.args.sinkhorn_lambda)
 
     # ---------------------------------------------------------------- one sess.run
     def step(self, x_data, noise=None, apply_updates=True):
@@ -284,15 +301,35 @@ def rank_log_kernel_slices(rank, world, f_gen, f_dat, fa, fb, lam):
     row sharding of the cost GEMMs (matching.py:29-39): a rank of the first half owns rows of a1 / b1 and
     makes its rows of (a1,a2) (a1,b1) (a1,b2); a rank of the second half owns rows of a2 / b2 and makes
     its rows of (b2,b1) (a2,b1) (a2,b2).  f_gen / f_dat: the rank's own [nb, D] features; fa / fb: the
-    gathered global shard lists.  Returns [3, nb, N]."""
-    h = len(fa) // 2
-    a2 = torch.cat(fa[h:], 0)
-    b1, b2 = torch.cat(fb[:h], 0), torch.cat(fb[h:], 0)
+    gathered global features, flat [2N, D] (halves taken as views) or as shard lists.  Returns [3, nb, N]."""
+    def halves(f):      # a flat [2N, D] tensor (views, no copy) or the reference's shard list
+        if torch.is_tensor(f):
+            return f[:f.shape[0] // 2], f[f.shape[0] // 2:]
+        return torch.cat(f[:len(f) // 2], 0), torch.cat(f[len(f) // 2:], 0)
+    a2 = halves(fa)[1]
+    b1, b2 = halves(fb)
     # one launch for the rank's three slices; blocks named twice (the rank's own rows, b1) are staged once
     if rank < world // 2:   # my rows belong to a1 / b1:  p0 (a1,a2), p2 (a1,b1), p3 (a1,b2)
         return matching.cost_log_kernels([f_gen, f_gen, f_gen], [a2, b1, b2], lam)
     # my rows belong to a2 / b2:  p1 (b2,b1), p4 (a2,b1), p5 (a2,b2)
     return matching.cost_log_kernels([f_dat, f_gen, f_gen], [b1, b1, b2], lam)
+
+
+def rank_single_log_kernel_slices(f_gen, f_dat, allg, alld, lam):
+    """--single_batch: the three [nb, n] log-kernel row slices one rank computes -- its rows of a-a, b-b and a-b, exactly the
+    reference's per-tower GEMMs (matching.py:99-104); the 999 on the a-a / b-b diagonals (:107-108) is added after the
+    slices are assembled.  f_gen / f_dat: the rank's own [nb, D] features; allg / alld: the gathered [n, D] arrays.
+    Returns [3, nb, n]."""
+    return matching.cost_log_kernels([f_gen, f_dat, f_gen], [allg, alld, alld], lam)
+
+
+def assemble_single_log_kernels(allk, lam):
+    """[world, 3, nb, n] all-gathered slices -> [3, n, n] (a-a, b-b, a-b) with -lambda*999 on the a-a / b-b diagonals."""
+    n = allk.shape[3]
+    K = allk.permute(1, 0, 2, 3).reshape(3, n, n).contiguous()
+    K[0].diagonal().add_(-float(lam) * 999.0)
+    K[1].diagonal().add_(-float(lam) * 999.0)
+    return K
 
 
 def assemble_log_kernels(allk, world):

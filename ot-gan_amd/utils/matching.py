@@ -237,6 +237,39 @@ def matched_feature_grads(fa, fb, sinkhorn_lambda, nr_sinkhorn_iter, need_b=True
     return grad_a, grad_b, entropy, dist
 
 
+def matched_feature_grads_single_batch(fa, fb, sinkhorn_lambda, nr_sinkhorn_iter, need_b=True, rows=None, log_kernels=None):
+    """Training-mode --single_batch matching (otgan_matching_single_batch_grad_f32 / _rows_grad_): the injected gradients
+    `features_a_a - features_a_b` (train.py:111) and `features_b_b - features_b_a` (train.py:125-126) of
+    get_matched_features_single_batch (utils/matching.py:88-136) directly.  fa, fb: flat [n, D] arrays (all shards);
+    `rows=(row_begin, row_count)`: only the rows of one data-parallel rank; `log_kernels` [3, n, n]: the a-a, b-b (both with
+    -lambda*999 on the diagonal) and a-b log-kernels, e.g. all-gathered row slices (utils/matching.py:99-104).  Returns
+    (grad_a, grad_b or None, entropy, distance) like matched_feature_grads."""
+    for t in (fa, fb):
+        if not t.is_cuda:
+            raise _lib.OtganError("matching needs CUDA (MI355X) tensors; there is no CPU fallback")
+        if t.dtype != torch.float32 or t.dim() != 2 or t.shape != fa.shape:
+            raise ValueError("fa and fb must be float32 [n, D] tensors of one shape")
+    fa, fb = fa.detach().contiguous(), fb.detach().contiguous()
+    L = _lib.lib()
+    n, D = fa.shape
+    dev = fa.device
+    r0, cnt = (0, n) if rows is None else (int(rows[0]), int(rows[1]))
+    grad_a = torch.empty((cnt, D), dtype=fa.dtype, device=dev)
+    grad_b = torch.empty((cnt, D), dtype=fa.dtype, device=dev) if need_b else None
+    entropy = torch.empty((), dtype=torch.float32, device=dev)
+    dist = torch.empty((), dtype=torch.float64, device=dev)
+    ws = _workspace(L.otgan_matching_single_batch_grad_workspace_bytes(n, D), dev)
+    if log_kernels is not None:
+        log_kernels = log_kernels.contiguous()
+        assert tuple(log_kernels.shape) == (3, n, n) and log_kernels.dtype == torch.float32
+    rc = L.otgan_matching_single_batch_rows_grad_f32(fa.data_ptr(), fb.data_ptr(), n, D, D, float(sinkhorn_lambda),
+                                                     int(nr_sinkhorn_iter), r0, cnt, _lib.ptr(log_kernels),
+                                                     grad_a.data_ptr(), _lib.ptr(grad_b), D, entropy.data_ptr(),
+                                                     dist.data_ptr(), None, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+    _lib.check(rc, "otgan_matching_single_batch_rows_grad_f32")
+    return grad_a, grad_b, entropy, dist
+
+
 def get_matched_features_single_batch(features_a, features_b, sinkhorn_lambda, nr_sinkhorn_iter):
     """Single-batch matching (reference utils/matching.py:88-136)."""
     _check_lists(features_a, features_b)

@@ -117,6 +117,60 @@ def test_rows_grad_rank_of_8(dev):
     assert gb2 is None and torch.equal(ga2, ga)
 
 
+def test_single_batch_grad_vs_golden(dev, list_case):
+    """--single_batch, training mode: grad = single_aa - single_ab, single_bb - single_ba of the reference's own outputs"""
+    from otgan_amd.utils import matching
+    g = list_case
+    fa = _t(np.concatenate(list(g["fa"])), dev)
+    fb = _t(np.concatenate(list(g["fb"])), dev)
+    ga, gb, ent, dist = matching.matched_feature_grads_single_batch(fa, fb, float(g["lam"]), int(g["iters"]))
+    ra = np.concatenate(list(g["single_aa"])) - np.concatenate(list(g["single_ab"]))
+    rb = np.concatenate(list(g["single_bb"])) - np.concatenate(list(g["single_ba"]))
+    assert _rel(ga.cpu().numpy(), ra) < REL_DIFF
+    assert _rel(gb.cpu().numpy(), rb) < REL_DIFF
+    assert float(ent) == pytest.approx(float(g["single_entropy"]), rel=2e-4)
+    ref = float(g["single_distance"])
+    atol = 2e-6 if g["name"] == "survey" else 1e-7
+    assert abs(float(dist) - ref) <= REL_LOSS * abs(ref) + atol
+    ga2, gb2, _, dist2 = matching.matched_feature_grads_single_batch(fa, fb, float(g["lam"]), int(g["iters"]), need_b=False)
+    assert gb2 is None and torch.equal(ga2, ga) and float(dist2) == float(dist)
+
+
+def test_single_batch_rows_grad_rank_of_8(dev):
+    """--single_batch in the global scope, row-sharded like the reference (matching.py:99-104): eight ranks x 128 rows
+    (n = 1024, D = 7296, 100 iterations), every rank's three cost row slices assembled into the [3, n, n] log-kernels, the
+    rows of ranks 0, 3, 4, 7 -- with the assembled kernels and with the library's own -- against the fp64 oracle; the
+    all-rows call on the same inputs must give the same rows"""
+    from otgan_amd import trainer
+    from otgan_amd.utils import matching
+    WORLD, nb, D, lam, iters = 8, 128, 7296, 500.0, 100
+    n = WORLD * nb
+    fa_h, fb_h = _clustered(13, n, D)
+    fa_d, fb_d = _t(fa_h, dev), _t(fb_h, dev)
+    slices = [trainer.rank_single_log_kernel_slices(fa_d[r * nb:(r + 1) * nb], fb_d[r * nb:(r + 1) * nb], fa_d, fb_d, lam)
+              for r in range(WORLD)]
+    K = trainer.assemble_single_log_kernels(torch.stack(slices, 0), lam)
+    assert tuple(K.shape) == (3, n, n)
+    ref = M.get_matched_features_single_batch(list(np.split(fa_h.astype(np.float64), WORLD)),
+                                              list(np.split(fb_h.astype(np.float64), WORLD)), lam, iters)
+    dref = float(M.calc_distance(list(np.split(fa_h.astype(np.float64), WORLD)), list(np.split(fb_h.astype(np.float64), WORLD)), ref))
+    ra = np.concatenate(ref[0]) - np.concatenate(ref[2])
+    rb = np.concatenate(ref[1]) - np.concatenate(ref[3])
+    full_a, full_b, ent_f, dist_f = matching.matched_feature_grads_single_batch(fa_d, fb_d, lam, iters)
+    assert _rel(full_a.cpu().numpy(), ra) < REL_DIFF and _rel(full_b.cpu().numpy(), rb) < REL_DIFF
+    assert abs(float(dist_f) - dref) <= REL_LOSS * abs(dref) + 1e-7, (float(dist_f), dref)
+    for r, pre in ((0, K), (3, None), (4, K), (7, K)):
+        ga, gb, ent, dist = matching.matched_feature_grads_single_batch(fa_d, fb_d, lam, iters, rows=(r * nb, nb), log_kernels=pre)
+        sl = slice(r * nb, (r + 1) * nb)
+        assert _rel(ga.cpu().numpy(), ra[sl]) < REL_DIFF, r
+        assert _rel(gb.cpu().numpy(), rb[sl]) < REL_DIFF, r
+        assert _rel(ga.cpu().numpy(), full_a[sl].cpu().numpy()) < 1e-5, r
+        assert float(ent) == pytest.approx(float(ref[4]), rel=2e-4)
+        assert abs(float(dist) - dref) <= REL_LOSS * abs(dref) + 1e-7, (r, float(dist), dref)
+    ga2, gb2, _, _ = matching.matched_feature_grads_single_batch(fa_d, fb_d, lam, iters, need_b=False, rows=(7 * nb, nb), log_kernels=K)
+    assert gb2 is None and torch.equal(ga2, ga)
+
+
 def test_grad_abi_errors(dev):
     from otgan_amd import _lib
     from otgan_amd.utils import matching

@@ -234,10 +234,18 @@ def _well_conditioned_worst(dev, model, size, kind, seed, same_head_signs=False)
     o.load(_named(m))
     to64 = lambda z: [t.double() for t in z] if isinstance(z, list) else z.double()
     NTO.FORCED_HEAD_SIGNS = signs if same_head_signs else None
+    del NTO.FORCED_HEAD_REPORT[:]
     try:
         gr, dist, ent = o.grads(kind, x.double(), to64(noise), 2, lam, iters)
     finally:
         NTO.FORCED_HEAD_SIGNS = None
+    if same_head_signs:
+        # the forced pattern may differ from the oracle's own ONLY in a handful of units that sit at rounding level: a
+        # forward kernel that flipped many units, or one that is not tiny, fails here
+        flipped = sum(c for c, _ in NTO.FORCED_HEAD_REPORT)
+        biggest = max([v for _, v in NTO.FORCED_HEAD_REPORT] + [0.0])
+        assert len(NTO.FORCED_HEAD_REPORT) == len(signs)
+        assert flipped <= 8 and biggest <= 1e-5, (flipped, biggest)
     assert float(r["distance"]) == pytest.approx(dist, rel=1e-4, abs=1e-7)
     assert float(r["entropy"]) == pytest.approx(ent, rel=1e-4)
     names = list((m.generator if kind == "gen" else m.discriminator).named_variables())
@@ -251,9 +259,11 @@ def _well_conditioned_worst(dev, model, size, kind, seed, same_head_signs=False)
 #   densenet disc 5.8e-6, 8.4e-6, 6.3e-6      gen 4.3e-6, 7.5e-6, 3.6e-6
 #   dcgan 64 disc 6.0e-6, 5.9e-6, 5.9e-6      gen 1.1e-5, 7.5e-6, 9.2e-6
 # (with the oracle's own signs: dcgan 32 disc seed 6 6.2e-4, dcgan 64 disc seed 5 1.2e-3 and seed 7 4e-4 -- one unit each)
-# asserted: every seed at the measured maximum + 25 % (see the test)
-_WELL_TOL = {("dcgan", 32, "disc"): 8.0e-6, ("dcgan", 32, "gen"): 1.05e-5, ("densenet", 32, "disc"): 1.05e-5,
-             ("densenet", 32, "gen"): 9.5e-6, ("dcgan", 64, "disc"): 7.5e-6, ("dcgan", 64, "gen"): 1.4e-5}
+# asserted: every seed at 3 x the measured maximum (see the test)
+# round 4: 3 x the measured maximum instead of + 25 % -- a compiler or summation-order change moves these by tens of
+# per cent; the sign pattern the oracle takes over is now counted and bounded (<= 8 units, |x| <= 1e-5 of the sample's RMS)
+_WELL_TOL = {("dcgan", 32, "disc"): 1.9e-5, ("dcgan", 32, "gen"): 2.5e-5, ("densenet", 32, "disc"): 2.5e-5,
+             ("densenet", 32, "gen"): 2.3e-5, ("dcgan", 64, "disc"): 1.8e-5, ("dcgan", 64, "gen"): 3.3e-5}
 
 
 @pytest.mark.parametrize("model,size", [("dcgan", 32), ("densenet", 32), ("dcgan", 64)])
@@ -284,8 +294,10 @@ def test_well_conditioned_step_gradients(dev, model, size, kind):
     assert free[0] < 3e-3, free                 # a flipped head unit: bounded, not tight
 
 
-def _ema_critic_errors(dev, seed):
+def _ema_critic_errors(dev, seed, same_head_signs=True):
     from otgan_amd.trainer import OTGAN, default_args
+    from otgan_amd.utils import nn as hip_nn
+    from oracle import nets_torch as NTO
     lam, iters = 20.0, 10
     args = default_args(model="dcgan", batch_size=3, nr_gpu=2, sinkhorn_lambda=lam, nr_sinkhorn_iter=iters,
                         nr_gen_per_disc=1, seed=seed, nonlinearity="elu", train_disc_against_ema=True,
@@ -300,11 +312,30 @@ def _ema_critic_errors(dev, seed):
     shadow = {n: m.ema.average(p) for n, p in zip(names_g, m.gen_params)}
     p0 = m.gen_params[0]
     assert _rel(shadow[names_g[0]], p0) > 1e-5                       # the EMA generator is a different network
-    r = m.step(x, noise=u, apply_updates=False)
-    assert r["kind"] == "disc"
+    signs = []
+    real_head = hip_nn.feature_head
+
+    def recording_head(z):
+        signs.append(torch.sign(z.detach()).cpu())
+        return real_head(z)
+    hip_nn.feature_head = recording_head
+    try:
+        r = m.step(x, noise=u, apply_updates=False)
+    finally:
+        hip_nn.feature_head = real_head
+    assert r["kind"] == "disc" and len(signs) == 1
     o = CpuOTGAN("dcgan", "elu", dtype=torch.float64, use_c_matching=False)
     o.load(_named(m))
-    gr, dist, ent = o.grads("disc", x.double().cpu(), u.double().cpu(), 2, lam, iters, ema_P=o.ema_params(shadow))
+    NTO.FORCED_HEAD_SIGNS = list(signs) if same_head_signs else None
+    del NTO.FORCED_HEAD_REPORT[:]
+    try:
+        gr, dist, ent = o.grads("disc", x.double().cpu(), u.double().cpu(), 2, lam, iters, ema_P=o.ema_params(shadow))
+    finally:
+        NTO.FORCED_HEAD_SIGNS = None
+    if same_head_signs:
+        flipped = sum(c for c, _ in NTO.FORCED_HEAD_REPORT)
+        biggest = max([v for _, v in NTO.FORCED_HEAD_REPORT] + [0.0])
+        assert flipped <= 8 and biggest <= 1e-5, (flipped, biggest)
     assert float(r["distance"]) == pytest.approx(dist, rel=1e-4, abs=1e-7)
     assert float(r["entropy"]) == pytest.approx(ent, rel=1e-4)
     gr_live, dist_live, _ = o.grads("disc", x.double().cpu(), u.double().cpu(), 2, lam, iters)
@@ -328,9 +359,58 @@ def test_ema_critic_step_matches_oracle(dev):
     above (measured + 25 %), which is what the arithmetic of this branch delivers when no unit flips."""
     res = [_ema_critic_errors(dev, seed) for seed in (8, 9, 10)]
     print("\nEMA critic step: (worst error vs EMA oracle, closest vs live oracle) per seed:", [(f"{a:.2e}", f"{b:.2e}") for a, b in res])
+    # round 4: the oracle's feature head takes the sign pattern of the path under test (counted and bounded, as in
+    # test_well_conditioned_step_gradients), so EVERY seed measures arithmetic: all three at 3 x the level the un-flipped
+    # seed reached in round 3 (6.1e-6), and the branch is pinned on every seed
     for e_ema, e_live in res:
-        assert e_ema < 5e-3 and e_live > 20 * e_ema, res
-    assert min(e for e, _ in res) < 7.7e-6, res
+        assert e_ema < 1.9e-5 and e_live > 20 * e_ema, res
+    free = _ema_critic_errors(dev, 9, same_head_signs=False)       # un-forced: bounded at the flipped-unit level
+    assert free[0] < 5e-3 and free[1] > 20 * free[0], free
+
+
+@pytest.mark.parametrize("model,iters,D", [("dcgan", 100, 32768), ("densenet", 200, 7296)])
+def test_full_batch_step_is_finite_and_its_distance_matches_the_matching_oracle(dev, model, iters, D):
+    """One whole critic step and one whole generator step at the BASELINE batch (256 images = 2 shards x 128, lambda 500,
+    configs[1] / configs[3] iteration counts): every gradient finite, and the step's reported distance / entropy equal the
+    fp64 matching oracle evaluated on the features the step itself produced (recorded at the feature head) to 1e-4."""
+    from otgan_amd.trainer import OTGAN, default_args
+    from otgan_amd.utils import nn as hip_nn
+    from oracle import matching_np as M
+    lam = 500.0
+    args = default_args(model=model, batch_size=128, nr_gpu=2, sinkhorn_lambda=lam, nr_sinkhorn_iter=iters,
+                        nr_gen_per_disc=1, seed=3)
+    m = OTGAN(args, dev)
+    gen = torch.Generator().manual_seed(11)
+    x = (torch.rand(m.nb, 32, 32, 3, generator=gen) * 2 - 1).to(dev)
+    feats = []
+    real_head = hip_nn.feature_head
+
+    def recording_head(z):
+        f = real_head(z)
+        feats.append(f.detach())
+        return f
+    for kind in ("disc", "gen"):
+        del feats[:]
+        hip_nn.feature_head = recording_head
+        try:
+            r = m.step(x, apply_updates=False)
+        finally:
+            hip_nn.feature_head = real_head
+        assert r["kind"] == kind
+        for g in r["grads"]:
+            assert bool(torch.isfinite(g).all())
+        if kind == "disc":          # one critic pass over [data; generated]
+            f_dat, f_gen = feats[0][:m.nb], feats[0][m.nb:]
+        else:                       # critic on the data (no grad), then on the generated images
+            f_dat, f_gen = feats[0], feats[1]
+        assert f_gen.shape == (m.nb, D)
+        fa, fb = f_gen.double().cpu().numpy(), f_dat.double().cpu().numpy()
+        N = m.nb // 2
+        plans, costs, ent_ref = M.two_batch_plans(fa[:N], fa[N:], fb[:N], fb[N:], lam, iters)
+        dref = M.closed_form_from(plans, costs, N)
+        assert abs(float(r["distance"]) - dref) <= 1e-4 * abs(dref) + 1e-7, (kind, float(r["distance"]), dref)
+        assert float(r["entropy"]) == pytest.approx(float(ent_ref), rel=2e-4)
+    m.close()
 
 
 @pytest.mark.parametrize("opt", ["adamax", "nesterov"])
