@@ -233,7 +233,8 @@ def _well_conditioned_worst(dev, model, size, kind, seed, same_head_signs=False)
     o = CpuOTGAN(model, "elu", dtype=torch.float64, use_c_matching=False, image_size=size)
     o.load(_named(m))
     to64 = lambda z: [t.double() for t in z] if isinstance(z, list) else z.double()
-    NTO.FORCED_HEAD_SIGNS = signs if same_head_signs else None
+    n_heads = len(signs)
+    NTO.FORCED_HEAD_SIGNS = signs if same_head_signs else None       # (the oracle pops them)
     del NTO.FORCED_HEAD_REPORT[:]
     try:
         gr, dist, ent = o.grads(kind, x.double(), to64(noise), 2, lam, iters)
@@ -244,8 +245,9 @@ def _well_conditioned_worst(dev, model, size, kind, seed, same_head_signs=False)
         # forward kernel that flipped many units, or one that is not tiny, fails here
         flipped = sum(c for c, _ in NTO.FORCED_HEAD_REPORT)
         biggest = max([v for _, v in NTO.FORCED_HEAD_REPORT] + [0.0])
-        assert len(NTO.FORCED_HEAD_REPORT) == len(signs)
-        assert flipped <= 8 and biggest <= 1e-5, (flipped, biggest)
+        assert len(NTO.FORCED_HEAD_REPORT) == n_heads
+        # (measured: 0 - 2 units per case, |x| <= 4e-6 of the sample's RMS -- the forward features are good to 2-4e-6)
+        assert flipped <= 8 and biggest <= 2e-5, (flipped, biggest)
     assert float(r["distance"]) == pytest.approx(dist, rel=1e-4, abs=1e-7)
     assert float(r["entropy"]) == pytest.approx(ent, rel=1e-4)
     names = list((m.generator if kind == "gen" else m.discriminator).named_variables())
@@ -261,7 +263,7 @@ def _well_conditioned_worst(dev, model, size, kind, seed, same_head_signs=False)
 # (with the oracle's own signs: dcgan 32 disc seed 6 6.2e-4, dcgan 64 disc seed 5 1.2e-3 and seed 7 4e-4 -- one unit each)
 # asserted: every seed at 3 x the measured maximum (see the test)
 # round 4: 3 x the measured maximum instead of + 25 % -- a compiler or summation-order change moves these by tens of
-# per cent; the sign pattern the oracle takes over is now counted and bounded (<= 8 units, |x| <= 1e-5 of the sample's RMS)
+# per cent; the sign pattern the oracle takes over is now counted and bounded (<= 8 units, |x| <= 2e-5 of the sample's RMS)
 _WELL_TOL = {("dcgan", 32, "disc"): 1.9e-5, ("dcgan", 32, "gen"): 2.5e-5, ("densenet", 32, "disc"): 2.5e-5,
              ("densenet", 32, "gen"): 2.3e-5, ("dcgan", 64, "disc"): 1.8e-5, ("dcgan", 64, "gen"): 3.3e-5}
 
@@ -335,7 +337,7 @@ def _ema_critic_errors(dev, seed, same_head_signs=True):
     if same_head_signs:
         flipped = sum(c for c, _ in NTO.FORCED_HEAD_REPORT)
         biggest = max([v for _, v in NTO.FORCED_HEAD_REPORT] + [0.0])
-        assert flipped <= 8 and biggest <= 1e-5, (flipped, biggest)
+        assert flipped <= 8 and biggest <= 2e-5, (flipped, biggest)
     assert float(r["distance"]) == pytest.approx(dist, rel=1e-4, abs=1e-7)
     assert float(r["entropy"]) == pytest.approx(ent, rel=1e-4)
     gr_live, dist_live, _ = o.grads("disc", x.double().cpu(), u.double().cpu(), 2, lam, iters)
