@@ -77,6 +77,15 @@ typedef struct otgan_conv_desc {
    * otgan_weightnorm_fwd_amax_f32.  NULL = the call reduces the weights itself (one more read of them).  Ignored for
    * filters made from FOLDED weights (a different tensor). */
   const float* w_amax;
+  /* (round 4) x_amax may point to x_amax_count consecutive records (OTGAN_AMAX_RECORD_FLOATS floats apart); the bound used
+   * is their maximum.  0 or 1 = one record.  Only the growth-layer kernels (Cout = 16) read more than the first. */
+  int x_amax_count;
+  /* (round 4) CRELU / CELU list inputs: nonzero = every list element is exactly this many channels wide and lies at channel
+   * i * list_width of x, i.e. the channel map is the per-element interleave [x_0, -x_0, x_1, -x_1, ...] of equal slices.
+   * With list_width = 16, CRELU, y_accumulate, no bias, an x_amax record and `filters` prepared by
+   * otgan_dense16_prepare_filters_f32, a growth layer (3x3, stride 1, Cout = 16) runs on the two-scaled-fp16-piece kernel
+   * (otgan_dense16_h2_ok tells).  0 = unknown (the channel map decides). */
+  int list_width;
 } otgan_conv_desc;
 
 /*
@@ -187,6 +196,15 @@ int otgan_conv2d_dgrad_f32(const otgan_conv_desc* d, const float* dy, const floa
  * The buffer's content is tied to the descriptor and to the OTGAN_WINO_* switches of the process.
  */
 size_t otgan_conv2d_filter_bytes(const otgan_conv_desc* d, int which);
+/* Growth layers of a split dense block (ops.py DenseBlockFunction): the chain weights wT [16][9 * 32 * nslices] (CReLU over
+ * `nslices` list elements of 16 channels) pre-split into two scaled fp16 pieces in MFMA fragment order, up to
+ * OTGAN_DENSE16_MAX_BATCH layers per launch; pass the buffer as `filters` of otgan_conv2d_fwd_pf_f32.
+ * otgan_dense16_h2_ok(d): 1 if a forward call with this descriptor (plus filters and x_amax) takes that kernel. */
+#define OTGAN_DENSE16_MAX_BATCH 16
+size_t otgan_dense16_filter_bytes(int nslices);
+int otgan_dense16_prepare_filters_f32(const float* const* wT, const int* nslices, void* const* filters, int count,
+                                      void* stream);
+int otgan_dense16_h2_ok(const otgan_conv_desc* d);
 int otgan_conv2d_prepare_filters_f32(const otgan_conv_desc* d, int which, const float* w, void* filters,
                                      size_t filter_bytes, void* stream);
 int otgan_conv2d_fwd_pf_f32(const otgan_conv_desc* d, const float* x, const int32_t* cmap,

@@ -13,7 +13,8 @@ class ConvDesc(ctypes.Structure):
                 ("Cout", c_int), ("ldy", c_int), ("y_coff", c_int), ("preact", c_int),
                 ("list_quads", c_int), ("x_amax", ctypes.c_void_p), ("dy_amax", ctypes.c_void_p),
                 ("y_accumulate", c_int), ("x_operand", ctypes.c_void_p),
-                ("y_amax_out", ctypes.c_void_p), ("dx_amax_out", ctypes.c_void_p), ("w_amax", ctypes.c_void_p)]
+                ("y_amax_out", ctypes.c_void_p), ("dx_amax_out", ctypes.c_void_p), ("w_amax", ctypes.c_void_p),
+                ("x_amax_count", c_int), ("list_width", c_int)]
 
 
 P_DESC = ctypes.POINTER(ConvDesc)
@@ -47,6 +48,9 @@ SIGNATURES = {
                                        c_size_t, c_fp]),
     "otgan_conv2d_wgrad_f32": (c_int, [P_DESC, c_fp, c_fp, c_fp, c_fp, c_fp, c_size_t, c_fp]),
     "otgan_conv2d_filter_bytes": (c_size_t, [P_DESC, c_int]),
+    "otgan_dense16_filter_bytes": (c_size_t, [c_int]),
+    "otgan_dense16_prepare_filters_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp]),
+    "otgan_dense16_h2_ok": (c_int, [P_DESC]),
     "otgan_conv2d_prepare_filters_f32": (c_int, [P_DESC, c_int, c_fp, c_fp, c_size_t, c_fp]),
     "otgan_conv2d_fwd_pf_f32": (c_int, [P_DESC, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_size_t, c_fp]),
     "otgan_conv2d_dgrad_pf_f32": (c_int, [P_DESC, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp,

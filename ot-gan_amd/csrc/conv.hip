@@ -2657,6 +2657,25 @@ size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which) {
   return s2 > recs ? s2 : recs;
 }
 
+// growth layer that the two-scaled-fp16-piece kernel takes (given filters and an x_amax record)
+static bool dense16_h2_desc_ok(const otgan_conv_desc* d) {
+  return d && d->Cout == 16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->upsample == 0 && d->preact == OTGAN_ACT_CRELU &&
+         d->list_width == 16 && d->C >= 16 && d->C % 16 == 0 && d->ldx % 4 == 0 && d->y_accumulate && d->ldy % 4 == 0 &&
+         dense16_enabled() && dense16_h2_shape_ok(d->N, d->H, d->W);
+}
+int otgan_dense16_h2_ok(const otgan_conv_desc* d) { return dense16_h2_desc_ok(d) ? 1 : 0; }
+size_t otgan_dense16_filter_bytes(int nslices) { return dense16_h2_filter_bytes(nslices); }
+int otgan_dense16_prepare_filters_f32(const float* const* wT, const int* nslices, void* const* filters, int count,
+                                      void* stream) {
+  OTGAN_CHECK_ARG(wT && nslices && filters && count >= 1 && count <= OTGAN_DENSE16_MAX_BATCH, "1 <= count <= %d layers",
+                  OTGAN_DENSE16_MAX_BATCH);
+  for (int i = 0; i < count; ++i)
+    OTGAN_CHECK_ARG(wT[i] && filters[i] && nslices[i] >= 1 && aligned16(wT[i]) && aligned16(filters[i]), "null / misaligned layer %d", i);
+  const int rc = dense16_h2_prepare(wT, nslices, filters, count, (hipStream_t)stream);
+  OTGAN_CHECK_LAUNCH("dense16 prepare filters");
+  return rc;
+}
+
 size_t otgan_conv2d_filter_bytes(const otgan_conv_desc* d, int which) {
   Geo g;
   if (make_geo(d, &g) != OTGAN_OK || which < 0 || which > 3) return 0;
@@ -2921,6 +2940,15 @@ static int conv2d_fwd_body(const otgan_conv_desc* d, const float* x, const int32
     }
     OTGAN_CHECK_LAUNCH("conv2d fwd (few outputs)");
     return OTGAN_OK;
+  }
+  if (growth16 && filters && dense16_h2_desc_ok(d) && d->x_amax && aligned16(filters) && !bias && aligned16(y)) {
+    // the chain of a split dense block on two scaled fp16 pieces (dense16.hip, round 4)
+    ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * ga.Mtot * (double)Ktot * d->Cout, 0.0, s);
+    rc = dense16_fwd_h2(d->N, d->H, d->W, d->C / 16, x, d->ldx, filters, d->x_amax, d->x_amax_count > 1 ? d->x_amax_count : 1,
+                        y, d->ldy, d->y_coff, s, d->y_amax_out);
+    g_amax_written = d->y_amax_out != nullptr;
+    OTGAN_CHECK_LAUNCH("conv2d fwd (dense16, fp16 x 2)");
+    return rc;
   }
   if (growth16) {
     // DenseNet growth layer: LDS-free streaming MFMA kernel (dense16.hip)

@@ -20,6 +20,16 @@ bool dense16_enabled();
 int dense16_fwd(const Dense16Geo& g, const float* x, const float* wT, const float* bias, float* y,
                 int ldy, int coff, int accumulate, hipStream_t s, float* amax_out = nullptr);
 
+// ---- the chains of a split dense block on two scaled fp16 pieces (round 4) --------------------
+// CReLU chains over `nsl` list elements of exactly 16 channels: x = first channel of the first slice, wq = the
+// layer's weights prepared by dense16_h2_prepare (dense16_h2_filter_bytes(nsl) bytes, 16-byte aligned), rec = `nrec`
+// consecutive amax records whose maximum bounds |x|.  y[pix, coff + n] += sum (always accumulating, no bias).
+size_t dense16_h2_filter_bytes(int nsl);
+bool dense16_h2_shape_ok(int N, int H, int W);
+int dense16_h2_prepare(const float* const* wT, const int* nsl, void* const* out, int count, hipStream_t s);
+int dense16_fwd_h2(int N, int H, int W, int nsl, const float* x, int ldx, const void* wq, const float* rec, int nrec,
+                   float* y, int ldy, int coff, hipStream_t s, float* amax_out);
+
 // ---- weight gradient ----------------------------------------------------------------------
 // Tiling shared by the LDS kernels: a block tile is TR full rows (64*PT pixels) of one image.
 struct Dense16Tiling {

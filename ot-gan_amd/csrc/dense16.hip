@@ -620,6 +620,272 @@ __global__ __launch_bounds__(256, 2) void dense16_fwd_x3_kernel(FwdLdsArgs a) {
 }
 
 // =======================================================================================
+// Growth-layer forward on TWO SCALED fp16 PIECES (round 4): the chains of a split dense block.
+//
+// What bound dense16_fwd_x3_kernel (rocprofv3 SQ counters, profiles/r04_pmc_sq_dense_before.txt): 6 VALU instructions per
+// MFMA (every lane split its weights and every staged activation into three bf16 pieces, once per chunk and tap pair),
+// waves parked at barriers / s_waitcnt for half of their cycles (two barriers per 16-channel chunk, two workgroups per
+// compute unit) -- MFMA busy 0.26, LDS issue stalls 2 %.  Here:
+//   * x * 2^sx = hi + lo in fp16 (22 bits; the arithmetic of the Winograd-domain GEMMs, gemm_x3.h): THREE
+//     v_mfma_f32_16x16x32_f16 per product (hi*hi, hi*lo, lo*hi) instead of six, two LDS planes instead of three; sx from
+//     the amax records of the slices read (one record per finished growth slice, written by this kernel's epilogue in
+//     the layer that finished it, plus the record of the wide convolutions' sums);
+//   * the weights arrive PRE-SPLIT in MFMA fragment order (dense16_h2_prepare: once per weight update, one launch per
+//     block), a lane's operand of a (slice, sign, tap pair) is two 16-byte loads, no VALU;
+//   * a K step is one 16-channel source SLICE with both CReLU signs (32 effective channels): one global load, one split,
+//     relu(x) and relu(-x) from the same two pieces by a sign mask (fp16 negation is exact) -- half the staging work and
+//     half the barriers per effective channel;
+//   * the weights of the slice ride along through LDS (20 KB behind the four planes of (TR + 2) x (W + 2) pixels x 32
+//     bytes: 64 KB per workgroup at 32 x 32, two workgroups per compute unit): no memory wait inside the matrix loop.
+// Only for the CReLU chains of equal 16-channel list elements (otgan_conv_desc::list_width == 16); everything else keeps
+// the kernels above.
+// =======================================================================================
+typedef _Float16 d16_h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 d16_h8 __attribute__((ext_vector_type(8)));
+typedef float d16_f2 __attribute__((ext_vector_type(2)));
+constexpr int kH2HdrBytes = 64;                       // int exponent of the weights' scale, padding
+constexpr int kH2SliceU16 = 2 * 5 * 2 * 64 * 8;       // [sign][tap pair][piece][lane][8] fp16 per source slice
+
+struct FwdH2Args {
+  const float* x;        // first channel of the first slice; [N, H, W, ldx]
+  const unsigned char* wq;   // prepared weights (dense16_h2_prepare)
+  float* y;
+  const float* rec;      // amax records of the input: nrec consecutive records (512 floats apart)
+  int nrec;
+  int nsl;               // source slices of 16 channels
+  int N, H, W, logW, ldx, ldy, coff, TR, RS;
+  float* amax;           // amax record of the sums written, or null
+};
+
+struct H2PrepArgs {
+  const float* wT[16];   // [16][9 * 32 * nsl]
+  unsigned char* out[16];
+  int nsl[16];
+};
+// one workgroup per layer: largest magnitude -> exponent -> the two fp16 pieces of w * 2^(14 - e) in fragment order
+__global__ __launch_bounds__(1024) void dense16_h2_prep_kernel(H2PrepArgs a) {
+  __shared__ float red[16];
+  const int L = blockIdx.x, tid = threadIdx.x;
+  const float* w = a.wT[L];
+  const int nsl = a.nsl[L], Ceff = 32 * nsl, K = 9 * Ceff, total = 16 * K;
+  float m = 0.f;
+  bool bad = false;
+  for (int i = tid; i < total; i += 1024) {
+    const float v = fabsf(w[i]);
+    bad = bad || !(v <= 3.0e38f);
+    m = fmaxf(m, v);
+  }
+  if (bad) m = __builtin_nanf("");
+  for (int o = 32; o; o >>= 1) {
+    const float t = __shfl_xor(m, o);
+    m = (t != t || m != m) ? __builtin_nanf("") : fmaxf(m, t);
+  }
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = red[0];
+  for (int i = 1; i < 16; ++i) m = (red[i] != red[i] || m != m) ? __builtin_nanf("") : fmaxf(m, red[i]);
+  int e = 0;
+  if (m > 0.f) e = __builtin_amdgcn_frexp_expf(m);
+  const float sc = (m == m) ? __builtin_ldexpf(1.f, 14 - e) : m;
+  if (tid == 0) *reinterpret_cast<int*>(a.out[L]) = e;
+  unsigned short* q = reinterpret_cast<unsigned short*>(a.out[L] + kH2HdrBytes);
+  const int items = nsl * 2 * 5 * 64;               // (slice, sign, tap pair, lane): 8 k values each
+  for (int it = tid; it < items; it += 1024) {
+    const int lane = it & 63, tp = (it >> 6) % 5, sign = (it / 320) & 1, sl = it / 640;
+    const int n = lane & 15, g = lane >> 4;
+    const int tap = 2 * tp + (g >> 1);
+    unsigned short* dh = q + (long)sl * kH2SliceU16 + (((sign * 5 + tp) * 2 + 0) * 64 + lane) * 8;
+    unsigned short* dl = dh + 64 * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = 0.f;
+      if (tap < 9) v = w[(long)n * K + tap * Ceff + 32 * sl + 16 * sign + 8 * (g & 1) + j] * sc;
+      const _Float16 h = (_Float16)v;
+      const _Float16 l = (_Float16)(v - (float)h);
+      dh[j] = __builtin_bit_cast(unsigned short, h);
+      dl[j] = __builtin_bit_cast(unsigned short, l);
+    }
+  }
+}
+
+template <int PT, bool W8>
+__global__ __launch_bounds__(256, 2) void dense16_fwd_h2_kernel(FwdH2Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smemh[];
+  __shared__ float s_sc[2];
+  constexpr int NIT = PT + 1;
+  constexpr int WBYTES = kH2SliceU16 * 2;                    // prepared weights of one slice: 20 steps x 1 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 15, g = lane >> 4;
+  const int tiles_per_img = a.H / a.TR;
+  const int n = blockIdx.x / tiles_per_img;
+  const int r0 = (blockIdx.x - n * tiles_per_img) * a.TR;
+  const int PLANE = (a.TR + 2) * a.RS * 32;                 // bytes of one (sign, piece) plane
+  unsigned char* const smw = smemh + 4 * PLANE;             // the slice's weights behind the four planes
+  for (int i = tid; i < 4 * PLANE / 16; i += 256) reinterpret_cast<u32x4*>(smemh)[i] = u32x4{0u, 0u, 0u, 0u};
+  // input scale: the maximum of the records' sub-slots (bit patterns of non-negative floats: unsigned order)
+  if (wave == 0) {
+    unsigned mb = 0u;
+    for (int i = lane; i < 16 * a.nrec; i += 64) {
+      const unsigned v = reinterpret_cast<const unsigned*>(a.rec)[(long)(i >> 4) * (kAmaxSub * kAmaxSubStride) + (i & 15) * kAmaxSubStride];
+      mb = v > mb ? v : mb;
+    }
+    for (int o = 32; o; o >>= 1) {
+      const unsigned t = __shfl_xor(mb, o);
+      mb = t > mb ? t : mb;
+    }
+    if (lane == 0) {
+      const float amax = __uint_as_float(mb);
+      int e = 0;
+      if (amax > 0.f) e = __builtin_amdgcn_frexp_expf(amax);
+      const int ew = *reinterpret_cast<const int*>(a.wq);
+      s_sc[0] = (amax <= 3.0e38f) ? __builtin_ldexpf(1.f, 14 - e) : __builtin_nanf("");
+      s_sc[1] = (amax <= 3.0e38f) ? __builtin_ldexpf(1.f, e + ew - 28) : __builtin_nanf("");   // (a NaN record stays loud)
+    }
+  }
+  const int slot = tid & 3;
+  const int total = (a.TR + 2) * a.W * 4;
+  const long img_base = (long)n * a.H * a.W;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  // staging items of this thread: (pixel of the (TR + 2) x W band, quad of 4 channels); source offset (floats, slice 0;
+  // negative: outside the image or the band) and LDS byte offset, computed once
+  long xoff[NIT];
+  int loff[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = it * 256 + tid;
+    const int px = i >> 2;
+    const int row = px >> a.logW, col = px & (a.W - 1);
+    const int ir = r0 - 1 + row;
+    const bool ok = i < total && (unsigned)ir < (unsigned)a.H;
+    xoff[it] = ok ? (img_base + (long)ir * a.W + col) * a.ldx + 4 * slot : -1;
+    loff[it] = i < total ? (row * a.RS + col + 1) * 32 + slot * 8 : -1;
+  }
+  f32x4 R[NIT];
+  u32x4 WR[5];
+  const unsigned char* wsrc = a.wq + kH2HdrBytes + tid * 16;
+  auto stage_load = [&](int sl) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) R[it] = xoff[it] >= 0 ? *reinterpret_cast<const f32x4*>(a.x + xoff[it] + 16 * sl) : zero;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) WR[q] = *reinterpret_cast<const u32x4*>(wsrc + (long)sl * WBYTES + q * 4096);
+  };
+  auto stage_store = [&](float sx) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (loff[it] >= 0) {
+        unsigned wd[4][2];       // [plane: +hi, +lo, -hi, -lo][element pair]
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const d16_f2 v = d16_f2{R[it][2 * h], R[it][2 * h + 1]} * sx;
+          const d16_h2 hi = __builtin_convertvector(v, d16_h2);
+          const d16_h2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, d16_f2), d16_h2);
+          const d16_h2 z = {(_Float16)0.f, (_Float16)0.f};
+          // relu(x) = hi+ + lo+, relu(-x) = hi- + lo- from the same two pieces (fp16 negation is exact): the sign of hi
+          // decides per element (hi = 0: |x 2^sx| < 2^-25, both sides take the sub-ulp lo piece or drop it -- 2^-39 of amax)
+          typedef short d16_s2 __attribute__((ext_vector_type(2)));
+          const unsigned neg = __builtin_bit_cast(unsigned, (d16_s2)(__builtin_bit_cast(d16_s2, hi) >> 15));   // 0xffff per negative half
+          const unsigned lb = __builtin_bit_cast(unsigned, lo);
+          wd[0][h] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(hi, z));
+          wd[1][h] = lb & ~neg;
+          wd[2][h] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(-hi, z));
+          wd[3][h] = (lb ^ 0x80008000u) & neg;
+        }
+        unsigned char* dst = smemh + loff[it];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x2*>(dst + q * PLANE) = u32x2{wd[q][0], wd[q][1]};
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) *reinterpret_cast<u32x4*>(smw + q * 4096 + tid * 16) = WR[q];
+  };
+  int ab[PT];
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    const int q0 = (wave * PT + t) * 16;
+    int rr, cc;
+    if (W8) {
+      rr = (q0 >> 3) + (p >> 3);
+      cc = p & 7;
+    } else {
+      rr = q0 >> a.logW;
+      cc = (q0 & (a.W - 1)) + p;
+    }
+    ab[t] = ((rr + 1) * a.RS + cc + 1) * 32 + 16 * (g & 1);
+  }
+  f32x4 acc[PT];
+#pragma unroll
+  for (int t = 0; t < PT; ++t) acc[t] = zero;
+  const int hiTap = g >> 1;
+  // Weights of a slice: twenty 1 KiB steps (sign, tap pair, piece), each the 64 lanes' 16-byte MFMA operands in lane order.
+  // They travel with the activations: loaded (coalesced, L2 hits) while the previous slice is multiplied, stored into LDS
+  // behind the planes, read back as two ds_read_b128 per step -- the matrix loop waits on LDS only, never on memory
+  // (a first version read them from global memory inside the loop: ten exposed L2 latencies per slice, 73 us; a register
+  // ring three steps ahead: 59 us, but its loads queue behind the next slice's activation loads in vmcnt order).
+  stage_load(0);
+  __syncthreads();               // zero fill and scales complete
+  const float sx = s_sc[0];
+  stage_store(sx);
+  __syncthreads();
+  const long m0 = (img_base + (long)r0 * a.W);
+  float yv[PT][4];
+  for (int sl = 0; sl < a.nsl; ++sl) {
+    const bool more = sl + 1 < a.nsl;
+    if (more) {
+      stage_load(sl + 1);
+    } else {
+      // the sums this workgroup adds onto: fetched under the last slice's matrix work
+#pragma unroll
+      for (int t = 0; t < PT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yv[t][r] = a.y[(m0 + (wave * PT + t) * 16 + 4 * g + r) * a.ldy + a.coff + p];
+    }
+#pragma unroll
+    for (int st = 0; st < 10; ++st) {
+      const int sign = st / 5, tp = st % 5;
+      const unsigned char* plane = smemh + 2 * sign * PLANE;
+      const d16_h8 Bh = *reinterpret_cast<const d16_h8*>(smw + st * 2048 + lane * 16);
+      const d16_h8 Bl = *reinterpret_cast<const d16_h8*>(smw + st * 2048 + 1024 + lane * 16);
+      const int t0 = 2 * tp, t1 = (2 * tp + 1 < 9) ? 2 * tp + 1 : 8;    // (the ninth tap's partner: tap 8 against zero weights)
+      const int sh0 = ((t0 / 3 - 1) * a.RS + (t0 % 3 - 1)) * 32;
+      const int sh1 = ((t1 / 3 - 1) * a.RS + (t1 % 3 - 1)) * 32;
+      const int sh = hiTap ? sh1 : sh0;
+      d16_h8 Ah[PT], Al[PT];
+#pragma unroll
+      for (int t = 0; t < PT; ++t) {
+        const unsigned char* ap = plane + ab[t] + sh;
+        Ah[t] = *reinterpret_cast<const d16_h8*>(ap);
+        Al[t] = *reinterpret_cast<const d16_h8*>(ap + PLANE);
+      }
+      // term-major: consecutive matrix instructions never share an accumulator (smallest terms first)
+#pragma unroll
+      for (int t = 0; t < PT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[t], Bh, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < PT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[t], Bl, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < PT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[t], Bh, acc[t], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) {
+      stage_store(sx);
+      __syncthreads();
+    }
+  }
+  const float so = s_sc[1];
+  unsigned omax = 0u;
+#pragma unroll
+  for (int t = 0; t < PT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long m = m0 + (wave * PT + t) * 16 + 4 * g + r;
+      const float o = fmaf(acc[t][r], so, yv[t][r]);          // the chains add onto the wide convolutions' sums
+      a.y[m * a.ldy + a.coff + p] = o;
+      const unsigned ob = amax_bits(o);
+      omax = ob > omax ? ob : omax;
+    }
+  if (a.amax) amax_commit(a.amax, omax);
+}
+
+// =======================================================================================
 // Weight gradient:  dW[tap][e][n] = sum_q act(x)[q][e] * dy[q - tap][n]
 //
 // MFMA roles: M = 16 effective channels, N = the 16 output channels, K = pixels.  A block owns
@@ -1027,6 +1293,53 @@ int dense16_fwd(const Dense16Geo& g, const float* x, const float* wT, const floa
   if (tiles >= 8192) launch_fwd_pt<4>(a, g.act, sgn, (tiles + 15) / 16, s);
   else if (tiles >= 4096) launch_fwd_pt<2>(a, g.act, sgn, (tiles + 7) / 8, s);
   else launch_fwd_pt<1>(a, g.act, sgn, (tiles + 3) / 4, s);
+  return OTGAN_OK;
+}
+
+size_t dense16_h2_filter_bytes(int nsl) { return nsl > 0 ? (size_t)kH2HdrBytes + (size_t)nsl * kH2SliceU16 * 2 : 0; }
+
+bool dense16_h2_shape_ok(int N, int H, int W) {
+  static const bool on = [] {
+    const char* e = getenv("OTGAN_DENSE16_H2");
+    return !(e && e[0] == '0');
+  }();
+  if (!on || !(W == 8 || W == 16 || W == 32) || H * W < 64) return false;
+  int PT = H * W >= 256 ? 4 : H * W / 64;
+  while (PT > 1 && (long)N * H * W / (64 * PT) < 512) PT >>= 1;
+  const int TR = 64 * PT / W;
+  return TR >= 1 && H % TR == 0;
+}
+
+int dense16_h2_prepare(const float* const* wT, const int* nsl, void* const* out, int count, hipStream_t s) {
+  H2PrepArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int i = 0; i < count; ++i) { a.wT[i] = wT[i]; a.nsl[i] = nsl[i]; a.out[i] = (unsigned char*)out[i]; }
+  hipLaunchKernelGGL(dense16_h2_prep_kernel, dim3(count), dim3(1024), 0, s, a);
+  return OTGAN_OK;
+}
+
+int dense16_fwd_h2(int N, int H, int W, int nsl, const float* x, int ldx, const void* wq, const float* rec, int nrec,
+                   float* y, int ldy, int coff, hipStream_t s, float* amax_out) {
+  int PT = H * W >= 256 ? 4 : H * W / 64;
+  while (PT > 1 && (long)N * H * W / (64 * PT) < 512) PT >>= 1;
+  FwdH2Args a;
+  a.x = x; a.wq = (const unsigned char*)wq; a.y = y; a.rec = rec; a.nrec = nrec; a.nsl = nsl;
+  a.N = N; a.H = H; a.W = W; a.logW = ilog2i(W); a.ldx = ldx; a.ldy = ldy; a.coff = coff;
+  a.TR = 64 * PT / W;
+  a.RS = W == 8 ? 16 : W + 2;
+  a.amax = amax_out;
+  const size_t lds = (size_t)4 * (a.TR + 2) * a.RS * 32 + (size_t)kH2SliceU16 * 2;
+  const dim3 grid(N * (H / a.TR)), blk(256);
+  const bool w8 = W == 8;
+#define D16_H2(PT_)                                                                                  \
+  do {                                                                                               \
+    if (w8) hipLaunchKernelGGL((dense16_fwd_h2_kernel<PT_, true>), grid, blk, lds, s, a);            \
+    else hipLaunchKernelGGL((dense16_fwd_h2_kernel<PT_, false>), grid, blk, lds, s, a);              \
+  } while (0)
+  if (PT == 4) D16_H2(4);
+  else if (PT == 2) D16_H2(2);
+  else D16_H2(1);
+#undef D16_H2
   return OTGAN_OK;
 }
 

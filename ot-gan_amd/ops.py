@@ -584,6 +584,26 @@ def _split_block_weights(Vs, per_layer, plan, F):
             off += sz
         copy2d_batched(segs)
         val["_own_flat"] = (flat_w, flat_wT)
+        val["h2"] = [None] * L
+        if plan.get("h2"):
+            # the chain weights pre-split into two scaled fp16 pieces in MFMA fragment order: one launch per block and
+            # weight update (otgan_dense16_prepare_filters_f32)
+            lib = _lib.lib()
+            nsl = [plan["own_len"][k] for k in own]
+            fbytes = [int(lib.otgan_dense16_filter_bytes(n)) for n in nsl]
+            flat_q = torch.empty(sum(fbytes), dtype=torch.uint8, device=dev)
+            off = 0
+            for k, nb in zip(own, fbytes):
+                val["h2"][k] = flat_q[off:off + nb]
+                off += nb
+            n = len(own)
+            pw = (ctypes.c_void_p * n)(*[val["wT_g"][k].data_ptr() for k in own])
+            pn = (ctypes.c_int * n)(*nsl)
+            pf = (ctypes.c_void_p * n)(*[val["h2"][k].data_ptr() for k in own])
+            _lib.check(lib.otgan_dense16_prepare_filters_f32(ctypes.cast(pw, ctypes.c_void_p), ctypes.cast(pn, ctypes.c_void_p),
+                                                              ctypes.cast(pf, ctypes.c_void_p), n, _lib.stream_ptr()),
+                       "dense16_prepare_filters")
+            val["_h2_flat"] = flat_q
     _block_cache[key] = (ws, val, plan["key"])
     while len(_block_cache) > 64:
         _block_cache.popitem(last=False)
@@ -633,9 +653,13 @@ def _split_block_plan(N, H, W, C0, L, F, segs0, preact, device):
             g0[k] = s1
     for wd in wide:
         wd["back"] = _row_order_back(wd["order"])
-    return {"wide": wide, "g0": g0, "own_len": [k - g0[k] for k in range(L)],
+    # the chains on the two-scaled-fp16-piece kernel (CReLU, 16-channel list elements; otgan_layers.h: list_width)
+    probe = ConvDesc(N, H, W, F, Ctot, 0, 3, 3, 1, F, Ctot, C0, preact, 1)
+    probe.y_accumulate, probe.list_width = 1, F
+    h2 = bool(lib.otgan_dense16_h2_ok(ctypes.byref(probe))) and os.environ.get("OTGAN_DENSE_AMAX", "1") != "0" and _FUSED_AMAX
+    return {"wide": wide, "g0": g0, "own_len": [k - g0[k] for k in range(L)], "h2": h2,
             "own_row0": [(C0 + g0[k] * F) * mult for k in range(L)],
-            "key": (H, W, C0, L, F, tuple(segs0), preact, tuple(g0))}
+            "key": (N, H, W, C0, L, F, tuple(segs0), preact, tuple(g0), h2)}
 
 
 class DenseBlockFunction(torch.autograd.Function):
@@ -705,16 +729,23 @@ class DenseBlockFunction(torch.autograd.Function):
             bias_all = torch.cat([b for b in params[2::3]])
             rows = N * H * W
             ctx.x_recs, ctx.x_ops = [], []
-            # amax records without extra passes (OTGAN_DENSE_AMAX=0: one reduction per slice, as in round 2).  Every kernel
-            # that writes growth channels -- the two wide convolutions (the second one adds onto the first) and the 16-output
-            # kernels of the chains -- max-accumulates the values it leaves in memory into ONE record of the growth
-            # region, rec_g: at any time an upper bound of every FINISHED growth channel (it also covers partial sums of
-            # unfinished ones: a bound that is a little too large costs a fraction of a bit of the 22).  The first half's
-            # record is a snapshot of rec_g taken when its last layer is done; the block's output carries
-            # max(record of x0, rec_g) for the transition that reads the whole buffer.
+            # amax records without extra passes (OTGAN_DENSE_AMAX=0: one reduction per slice, as in round 2): every kernel
+            # that writes growth channels -- the wide convolutions (the second one adds onto the first) and the 16-output
+            # kernels of the chains -- leaves the largest magnitude of the values it writes in a record (layout below);
+            # the block's output carries max(record of x0, all of them) for the transition that reads the whole buffer.
             shared = os.environ.get("OTGAN_DENSE_AMAX", "1") != "0" and _FUSED_AMAX
             rec_x0 = amax_of(x0) if shared else None
-            rec_g = amax_slot(buf.device) if shared else None
+            # round 4: ONE zeroed array of records per block.  Group i (the layers between two wide convolutions) owns
+            # rows [gbase(i), gbase(i + 1)): first the record of the sums the group's wide convolution leaves in the
+            # growth channels it writes (W_i: bounds every slice a layer of the group finishes without a chain kernel,
+            # and the partial sums of the others), then one record per layer of the group, written by the chain kernel
+            # that finishes the layer's slice.  A chain kernel reads rows [gbase, gbase + 1 + j) -- consecutive records,
+            # otgan_conv_desc::x_amax_count -- as the bound of the slices it multiplies (the two-scaled-fp16-piece
+            # kernel needs it; records are only ever read by launches after their writers: deterministic).
+            wides = plan["wide"]
+            gbase = [wd["d0"] + i for i, wd in enumerate(wides)] + [L + len(wides)]
+            gidx = {wd["d0"]: i for i, wd in enumerate(wides)}
+            R = torch.zeros((L + len(wides), AMAX_RECORD_FLOATS), dtype=torch.float32, device=buf.device) if shared else None
 
             def wide_fwd(i):
                 wd, ops_ = plan["wide"][i], sw["wide"][i]
@@ -723,7 +754,7 @@ class DenseBlockFunction(torch.autograd.Function):
                 if shared and i == 0 and rec_x0 is not None:
                     rec = rec_x0
                 elif shared and i > 0:
-                    rec = rec_g.clone()            # (2 KiB) the bound as of now: later layers keep raising rec_g
+                    rec = R[gbase[i - 1]:gbase[i]].amax(0)      # the finished slices of the group that feeds this convolution
                 else:
                     rec = absmax_record_strided(src.data_ptr(), rows, wd["C"], Ctot, buf.device)
                 ctx.x_recs.append(rec)
@@ -731,7 +762,7 @@ class DenseBlockFunction(torch.autograd.Function):
                 if any(ctx.needs_input_grad[4:]):
                     ctx.x_ops.append(shared_x_operand(desc, buf.device))    # read back by this convolution's wgrad
                 desc.y_accumulate = wd["accumulate"]
-                desc.y_amax_out = rec_g.data_ptr() if shared else None
+                desc.y_amax_out = R[gbase[i]].data_ptr() if shared else None
                 conv_fwd_raw(desc, src, None, ops_["wT"], None if wd["accumulate"] else bias_all, buf, ops_["fwd"])
                 desc.y_accumulate = 0
                 desc.y_amax_out = None
@@ -744,11 +775,18 @@ class DenseBlockFunction(torch.autograd.Function):
                     g0 = plan["g0"][k]
                     desc = ConvDesc(N, H, W, n_own * F, Ctot, 0, ksize, ksize, 1, F, Ctot, C0 + k * F, preact, 1)
                     desc.y_accumulate = 1
-                    desc.y_amax_out = rec_g.data_ptr() if shared else None
+                    desc.list_width = F
+                    if shared:
+                        gi = gidx[g0]
+                        desc.x_amax = R[gbase[gi]].data_ptr()
+                        desc.x_amax_count = 1 + n_own
+                        desc.y_amax_out = R[gbase[gi] + 1 + n_own].data_ptr()
                     cmap, inv = channel_maps((F,) * n_own, preact, x0.device)
-                    conv_fwd_raw(desc, buf[..., C0 + g0 * F:], cmap, sw["wT_g"][k], None, buf)
+                    conv_fwd_raw(desc, buf[..., C0 + g0 * F:], cmap, sw["wT_g"][k], None, buf, sw["h2"][k] if shared else None)
                     desc.y_accumulate = 0
                     desc.y_amax_out = None
+                    desc.x_amax = None
+                    desc.x_amax_count = 0
                 descs.append(desc)
                 maps.append((cmap, inv))
                 for i, wd in enumerate(plan["wide"]):
@@ -759,7 +797,7 @@ class DenseBlockFunction(torch.autograd.Function):
             ctx.descs, ctx.maps = descs, maps
             if shared:
                 x0_rec = ctx.x_recs[0]     # the producer's record of x0, or the reduction wide_fwd(0) made
-                tag_amax(buf, torch.maximum(x0_rec, rec_g))
+                tag_amax(buf, torch.maximum(x0_rec, R.amax(0)))
             return buf
 
         for k in range(L):
