@@ -69,7 +69,7 @@ typedef struct otgan_conv_desc {
    * Cout % 4 == 0 (forward) / C % 4 == 0 (input gradient), 4-aligned channel strides.  y_amax_out with y_accumulate:
    * the record receives the SUMS the call leaves in memory, so that several calls that finish different parts of a
    * buffer can share one record (the growth layers and wide convolutions of a dense block); dx_amax_out: not with
-   * `accumulate`. */
+   * `accumulate` -- round 4: allowed with `accumulate` too, the record then max-accumulates the SUMS left in dx. */
   float* y_amax_out;
   float* dx_amax_out;
   /* Optional, otgan_conv2d_prepare_filters_f32 only: amax record of the NORMALISED weights the filters are made from
@@ -205,6 +205,31 @@ size_t otgan_dense16_filter_bytes(int nslices);
 int otgan_dense16_prepare_filters_f32(const float* const* wT, const int* nslices, void* const* filters, int count,
                                       void* stream);
 int otgan_dense16_h2_ok(const otgan_conv_desc* d);
+/*
+ * Input gradient of those chains BY SLICE (round 4): the gradient of slice c of a group gathers from the `npairs` later
+ * layers of the group in one launch,  dG_c += [x_c > 0] G+ - [x_c < 0] G-  (CReLU; reference utils/nn.py:198-200 backward),
+ * instead of every layer adding into every earlier slice.  g / dx: the gradient buffer [N, H, W, ldg] at the first channel of
+ * slice c + 1 / of slice c; x: the forward buffer at slice c (row stride ldx).  Slices must be processed last to first
+ * (a source slice must be final).  filters: otgan_dense16_bwd_filter_bytes(npairs) bytes prepared by
+ * otgan_dense16_prepare_bwd_filters_f32 -- one otgan_dense16_bwd_pair per (output slice, source layer): `w` the source
+ * layer's chain weights HWIO [9][32 * nslices_src][16], `fwd_filters` that layer's forward buffer (scale exponent),
+ * `slice_index` the position of slice c in that chain, `pair_index` the pair's position in `filters`;
+ * all_fwd_filters: the forward buffers of every chain layer of the block (one scale for the block).
+ * rec0 / rec1: two ranges of consecutive amax records whose maximum bounds the source slices (rec1 nullable);
+ * amax_out (nullable, zeroed or shared): max-accumulates the sums written.  Geometry as otgan_dense16_h2_ok.
+ */
+typedef struct otgan_dense16_bwd_pair {
+  const float* w;
+  const void* fwd_filters;
+  void* filters;
+  int nslices_src, slice_index, pair_index;
+} otgan_dense16_bwd_pair;
+size_t otgan_dense16_bwd_filter_bytes(int npairs);
+int otgan_dense16_prepare_bwd_filters_f32(const otgan_dense16_bwd_pair* pairs, int npairs, const void* const* all_fwd_filters,
+                                          int nall, void* stream);
+int otgan_dense16_bwd_slice_f32(int N, int H, int W, int npairs, const float* g, int ldg, const void* filters, const float* x,
+                                int ldx, float* dx, const float* rec0, int nrec0, const float* rec1, int nrec1,
+                                float* amax_out, void* stream);
 int otgan_conv2d_prepare_filters_f32(const otgan_conv_desc* d, int which, const float* w, void* filters,
                                      size_t filter_bytes, void* stream);
 int otgan_conv2d_fwd_pf_f32(const otgan_conv_desc* d, const float* x, const int32_t* cmap,

@@ -20,6 +20,12 @@ class ConvDesc(ctypes.Structure):
 P_DESC = ctypes.POINTER(ConvDesc)
 
 
+class Dense16BwdPair(ctypes.Structure):
+    """Mirror of `otgan_dense16_bwd_pair`."""
+    _fields_ = [("w", ctypes.c_void_p), ("fwd_filters", ctypes.c_void_p), ("filters", ctypes.c_void_p),
+                ("nslices_src", c_int), ("slice_index", c_int), ("pair_index", c_int)]
+
+
 class WnFwdLayer(ctypes.Structure):
     """Mirror of `otgan_wn_fwd_layer`."""
     _fields_ = [("V", c_fp), ("g", c_fp), ("w", c_fp), ("wT", c_fp), ("inv", c_fp), ("K", c_int)]
@@ -51,6 +57,10 @@ SIGNATURES = {
     "otgan_dense16_filter_bytes": (c_size_t, [c_int]),
     "otgan_dense16_prepare_filters_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp]),
     "otgan_dense16_h2_ok": (c_int, [P_DESC]),
+    "otgan_dense16_bwd_filter_bytes": (c_size_t, [c_int]),
+    "otgan_dense16_prepare_bwd_filters_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_fp]),
+    "otgan_dense16_bwd_slice_f32": (c_int, [c_int, c_int, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_int,
+                                            c_fp, c_int, c_fp, c_fp]),
     "otgan_conv2d_prepare_filters_f32": (c_int, [P_DESC, c_int, c_fp, c_fp, c_size_t, c_fp]),
     "otgan_conv2d_fwd_pf_f32": (c_int, [P_DESC, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_size_t, c_fp]),
     "otgan_conv2d_dgrad_pf_f32": (c_int, [P_DESC, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp,

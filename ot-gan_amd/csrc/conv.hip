@@ -22,6 +22,7 @@
 // the memory latency hides under BK/2 * MT*NT * 64 cycles of matrix work.
 #include "gemm_tile.h"
 #include "dense16.h"
+#include <vector>
 #include "winograd.h"
 
 // winograd.hip exists twice in the library (winograd_api.inc): two scaled fp16 pieces per operand element (wino_p2,
@@ -2676,6 +2677,36 @@ int otgan_dense16_prepare_filters_f32(const float* const* wT, const int* nslices
   return rc;
 }
 
+size_t otgan_dense16_bwd_filter_bytes(int npairs) { return dense16_h2_bwd_filter_bytes(npairs); }
+int otgan_dense16_prepare_bwd_filters_f32(const otgan_dense16_bwd_pair* pairs, int npairs, const void* const* all_fwd_filters,
+                                          int nall, void* stream) {
+  OTGAN_CHECK_ARG(pairs && npairs >= 1 && npairs <= 4096 && all_fwd_filters && nall >= 1 && nall <= 16, "bad pair / layer counts");
+  std::vector<Dense16BwdPair> v((size_t)npairs);
+  for (int i = 0; i < npairs; ++i) {
+    const otgan_dense16_bwd_pair& p = pairs[i];
+    OTGAN_CHECK_ARG(p.w && p.fwd_filters && p.filters && aligned16(p.w) && aligned16(p.filters) && p.nslices_src >= 1 &&
+                        p.slice_index >= 0 && p.slice_index < p.nslices_src && p.pair_index >= 0,
+                    "bad pair %d", i);
+    v[i] = Dense16BwdPair{p.w, p.fwd_filters, p.filters, p.nslices_src, p.slice_index, p.pair_index};
+  }
+  for (int i = 0; i < nall; ++i) OTGAN_CHECK_ARG(all_fwd_filters[i], "null forward buffer %d", i);
+  const int rc = dense16_h2_bwd_prepare(v.data(), npairs, all_fwd_filters, nall, (hipStream_t)stream);
+  OTGAN_CHECK_LAUNCH("dense16 prepare bwd filters");
+  return rc;
+}
+int otgan_dense16_bwd_slice_f32(int N, int H, int W, int npairs, const float* g, int ldg, const void* filters, const float* x,
+                                int ldx, float* dx, const float* rec0, int nrec0, const float* rec1, int nrec1,
+                                float* amax_out, void* stream) {
+  OTGAN_CHECK_ARG(g && filters && x && dx && rec0 && nrec0 >= 1 && (rec1 || nrec1 == 0), "null pointer");
+  OTGAN_CHECK_ARG(npairs >= 1 && ldg % 4 == 0 && ldx % 4 == 0 && aligned16(g) && aligned16(x) && aligned16(dx) && aligned16(filters),
+                  "strides multiples of 4, 16-byte aligned buffers");
+  OTGAN_CHECK_ARG(dense16_enabled() && dense16_h2_shape_ok(N, H, W), "geometry not taken by the fp16 x 2 growth kernels");
+  ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * (double)N * H * W * 9.0 * 16.0 * npairs * 32.0, 0.0, (hipStream_t)stream);
+  const int rc = dense16_bwd_h2(N, H, W, npairs, g, ldg, filters, x, ldx, dx, rec0, nrec0, rec1, nrec1, (hipStream_t)stream, amax_out);
+  OTGAN_CHECK_LAUNCH("dense16 bwd slice");
+  return rc;
+}
+
 size_t otgan_conv2d_filter_bytes(const otgan_conv_desc* d, int which) {
   Geo g;
   if (make_geo(d, &g) != OTGAN_OK || which < 0 || which > 3) return 0;
@@ -3003,8 +3034,8 @@ static int conv2d_dgrad_impl(const otgan_conv_desc* d, const float* dy, const fl
                              const float* x, const int32_t* inv, float* dx, int lddx, int accumulate,
                              void* workspace, size_t workspace_bytes, void* stream) {
   if (d && d->dx_amax_out) {
-    OTGAN_CHECK_ARG(!accumulate && d->C % 4 == 0 && lddx % 4 == 0 && aligned16(dx),
-                    "dx_amax_out: needs C and lddx multiples of 4, a 16-byte aligned dx and no accumulation");
+    OTGAN_CHECK_ARG(d->C % 4 == 0 && lddx % 4 == 0 && aligned16(dx),
+                    "dx_amax_out: needs C and lddx multiples of 4 and a 16-byte aligned dx");
   }
   g_amax_written = false;
   const int rc = conv2d_dgrad_body(d, dy, w, filters, x, inv, dx, lddx, accumulate, workspace, workspace_bytes, stream);
@@ -3134,7 +3165,7 @@ static int conv2d_dgrad_body(const otgan_conv_desc* d, const float* dy, const fl
     const WinoS2Geo wg = wino_s2_geo(d, g);
     ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * wino_s2_blocks(wg) * (double)wino_s2_tiles(wg) * g.Ceff * d->Cout, 0.0, s);
     rc = WINO(wino_s2_dgrad)(wg, dy, w, x, dx, lddx, accumulate, (float*)workspace, s, filters);
-    g_amax_written = wg.dx_amax_out != nullptr && !accumulate;
+    g_amax_written = wg.dx_amax_out != nullptr;      // (round 4: with `accumulate` the output kernel tracks the sums it leaves)
     OTGAN_CHECK_LAUNCH("conv2d dgrad (winograd, stride 2)");
     return rc;
   }

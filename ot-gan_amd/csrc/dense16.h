@@ -30,6 +30,20 @@ int dense16_h2_prepare(const float* const* wT, const int* nsl, void* const* out,
 int dense16_fwd_h2(int N, int H, int W, int nsl, const float* x, int ldx, const void* wq, const float* rec, int nrec,
                    float* y, int ldy, int coff, hipStream_t s, float* amax_out);
 
+// input gradient of the chains by slice: dG_c += [x_c > 0] G+ - [x_c < 0] G-, gathered from the nsl later layers of the
+// group (g = gradient buffer at slice c + 1, dx = at slice c, x = forward buffer at slice c; wq = weights of the pairs
+// (c, c + 1 ...) prepared by dense16_h2_bwd_prepare; rec0 / rec1: two ranges of amax records bounding the sources)
+struct Dense16BwdPair {
+  const float* w;        // HWIO chain weights of the source layer [9][32 * nch][16]
+  const void* fwd;       // the source layer's forward prepared buffer
+  void* out_base;        // prepared buffer of the output slice (dense16_h2_bwd_filter_bytes(pairs of that slice))
+  int nch, cidx, pair_index;
+};
+size_t dense16_h2_bwd_filter_bytes(int nsl);
+int dense16_h2_bwd_prepare(const Dense16BwdPair* pairs, int npairs, const void* const* allfwd, int nall, hipStream_t s);
+int dense16_bwd_h2(int N, int H, int W, int nsl, const float* g, int ldg, const void* wq, const float* x, int ldx, float* dx,
+                   const float* rec0, int nrec0, const float* rec1, int nrec1, hipStream_t s, float* amax_out);
+
 // ---- weight gradient ----------------------------------------------------------------------
 // Tiling shared by the LDS kernels: a block tile is TR full rows (64*PT pixels) of one image.
 struct Dense16Tiling {

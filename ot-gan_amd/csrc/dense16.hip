@@ -886,6 +886,263 @@ __global__ __launch_bounds__(256, 2) void dense16_fwd_h2_kernel(FwdH2Args a) {
 }
 
 // =======================================================================================
+// Input gradient of the chains BY SLICE on two scaled fp16 pieces (round 4).
+//
+// The per-layer input gradient (dense16_dgrad_kernel) makes layer k add its share into every slice of its chain: a
+// 16-byte read-modify-write of the gradient buffer per (layer, earlier slice) pair -- 28 slice passes per half block, and
+// that traffic, not the matrix pipe, is what the kernel runs against.  Transposed: the gradient of ONE slice c gathers
+// from all later layers of its group in one launch,
+//     dG_c[q] += [x_c > 0] G+ - [x_c < 0] G-,   G+-[q][cc] = sum_{k > c} sum_{tap, n} G_k[q + d(tap)][n] w_k[8 - tap][e+-(c, cc)][n]
+// -- the forward kernel's loop with the roles turned: the K steps run over the gradient slices of the later layers
+// (two LDS planes: no activation, one sign), each step feeds two weight operands (the + and - effective channels of
+// slice c), and the slice's gradient is read and written ONCE.  Slices are processed last to first, so every source
+// slice is final when it is read.  Weights per (c, k) pair prepared like the forward ones (flipped taps), ONE scale
+// exponent for the whole block (the K loop sums over layers).
+// =======================================================================================
+struct BwdH2Args {
+  const float* g;        // gradient buffer at the first channel of slice c + 1; [N, H, W, ldg]
+  const unsigned char* wq;   // prepared weights of output slice c: header + nsl blocks (source layers c + 1 ...)
+  const float* x;        // forward buffer at the first channel of slice c
+  float* dx;             // gradient buffer at the first channel of slice c
+  const float* rec0;     // amax records bounding the source slices: nrec0 + nrec1 records in two ranges
+  const float* rec1;
+  int nrec0, nrec1;
+  int nsl;
+  int N, H, W, logW, ldg, ldx, TR, RS;
+  float* amax;           // amax record of the sums written, or null
+};
+
+struct H2BwdPrepArgs {
+  const float* w[64];         // HWIO weights of the source layer's chain: [9][32 * nch][16]
+  const unsigned char* fwd[64];   // the same layer's FORWARD prepared buffer (its header holds the layer's exponent)
+  unsigned char* out[64];     // this pair's 20 KB block
+  unsigned char* hdr[64];     // header of the output slice's buffer (written by pair 0 of the slice: flag)
+  int nch[64];                // slices of the source layer's chain
+  int cidx[64];               // index of slice c inside that chain
+  int first[64];
+  const unsigned char* allfwd[16];   // forward buffers of every layer with a chain (block-wide exponent)
+  int nall;
+};
+__global__ __launch_bounds__(256) void dense16_h2_bwd_prep_kernel(H2BwdPrepArgs a) {
+  const int P = blockIdx.x, tid = threadIdx.x;
+  int e = -1000;
+  for (int i = 0; i < a.nall; ++i) {
+    const int ei = *reinterpret_cast<const int*>(a.allfwd[i]);
+    e = ei > e ? ei : e;
+  }
+  if (a.first[P] && tid == 0) *reinterpret_cast<int*>(a.hdr[P]) = e;
+  const float sc = __builtin_ldexpf(1.f, 14 - e);
+  const float* w = a.w[P];
+  const int Ceff = 32 * a.nch[P];
+  unsigned short* q = reinterpret_cast<unsigned short*>(a.out[P]);
+  for (int it = tid; it < 2 * 5 * 64; it += 256) {               // (sign, tap pair, lane)
+    const int lane = it & 63, tp = (it >> 6) % 5, sign = it / 320;
+    const int cc = lane & 15, g = lane >> 4;
+    const int tapp = 2 * tp + (g >> 1);
+    unsigned short* dh = q + (((sign * 5 + tp) * 2 + 0) * 64 + lane) * 8;
+    unsigned short* dl = dh + 64 * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = 0.f;
+      if (tapp < 9) v = w[((long)(8 - tapp) * Ceff + 32 * a.cidx[P] + 16 * sign + cc) * 16 + 8 * (g & 1) + j] * sc;
+      const _Float16 h = (_Float16)v;
+      const _Float16 l = (_Float16)(v - (float)h);
+      dh[j] = __builtin_bit_cast(unsigned short, h);
+      dl[j] = __builtin_bit_cast(unsigned short, l);
+    }
+  }
+}
+
+template <int PT, bool W8>
+__global__ __launch_bounds__(256, 2) void dense16_bwd_h2_kernel(BwdH2Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smemh[];
+  __shared__ float s_sc[2];
+  constexpr int NIT = PT + 1;
+  constexpr int WBYTES = kH2SliceU16 * 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 15, g = lane >> 4;
+  const int tiles_per_img = a.H / a.TR;
+  const int n = blockIdx.x / tiles_per_img;
+  const int r0 = (blockIdx.x - n * tiles_per_img) * a.TR;
+  const int PLANE = (a.TR + 2) * a.RS * 32;
+  unsigned char* const smw = smemh + 2 * PLANE;
+  for (int i = tid; i < 2 * PLANE / 16; i += 256) reinterpret_cast<u32x4*>(smemh)[i] = u32x4{0u, 0u, 0u, 0u};
+  if (wave == 0) {
+    unsigned mb = 0u;
+    const int nr = a.nrec0 + a.nrec1;
+    for (int i = lane; i < 16 * nr; i += 64) {
+      const int r = i >> 4;
+      const float* base = r < a.nrec0 ? a.rec0 + (long)r * (kAmaxSub * kAmaxSubStride) : a.rec1 + (long)(r - a.nrec0) * (kAmaxSub * kAmaxSubStride);
+      const unsigned v = reinterpret_cast<const unsigned*>(base)[(i & 15) * kAmaxSubStride];
+      mb = v > mb ? v : mb;
+    }
+    for (int o = 32; o; o >>= 1) {
+      const unsigned t = __shfl_xor(mb, o);
+      mb = t > mb ? t : mb;
+    }
+    if (lane == 0) {
+      const float amax = __uint_as_float(mb);
+      int e = 0;
+      if (amax > 0.f) e = __builtin_amdgcn_frexp_expf(amax);
+      const int ew = *reinterpret_cast<const int*>(a.wq);
+      s_sc[0] = (amax <= 3.0e38f) ? __builtin_ldexpf(1.f, 14 - e) : __builtin_nanf("");
+      s_sc[1] = (amax <= 3.0e38f) ? __builtin_ldexpf(1.f, e + ew - 28) : __builtin_nanf("");
+    }
+  }
+  const int slot = tid & 3;
+  const int total = (a.TR + 2) * a.W * 4;
+  const long img_base = (long)n * a.H * a.W;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  long goff[NIT];
+  int loff[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = it * 256 + tid;
+    const int px = i >> 2;
+    const int row = px >> a.logW, col = px & (a.W - 1);
+    const int ir = r0 - 1 + row;
+    const bool ok = i < total && (unsigned)ir < (unsigned)a.H;
+    goff[it] = ok ? (img_base + (long)ir * a.W + col) * a.ldg + 4 * slot : -1;
+    loff[it] = i < total ? (row * a.RS + col + 1) * 32 + slot * 8 : -1;
+  }
+  f32x4 R[NIT];
+  u32x4 WR[5];
+  const unsigned char* wsrc = a.wq + kH2HdrBytes + tid * 16;
+  auto stage_load = [&](int sl) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) R[it] = goff[it] >= 0 ? *reinterpret_cast<const f32x4*>(a.g + goff[it] + 16 * sl) : zero;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) WR[q] = *reinterpret_cast<const u32x4*>(wsrc + (long)sl * WBYTES + q * 4096);
+  };
+  auto stage_store = [&](float sd) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (loff[it] >= 0) {
+        unsigned wd[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const d16_f2 v = d16_f2{R[it][2 * h], R[it][2 * h + 1]} * sd;
+          const d16_h2 hi = __builtin_convertvector(v, d16_h2);
+          const d16_h2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, d16_f2), d16_h2);
+          wd[0][h] = __builtin_bit_cast(unsigned, hi);
+          wd[1][h] = __builtin_bit_cast(unsigned, lo);
+        }
+        unsigned char* dst = smemh + loff[it];
+        *reinterpret_cast<u32x2*>(dst) = u32x2{wd[0][0], wd[0][1]};
+        *reinterpret_cast<u32x2*>(dst + PLANE) = u32x2{wd[1][0], wd[1][1]};
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) *reinterpret_cast<u32x4*>(smw + q * 4096 + tid * 16) = WR[q];
+  };
+  int ab[PT];
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    const int q0 = (wave * PT + t) * 16;
+    int rr, cc;
+    if (W8) {
+      rr = (q0 >> 3) + (p >> 3);
+      cc = p & 7;
+    } else {
+      rr = q0 >> a.logW;
+      cc = (q0 & (a.W - 1)) + p;
+    }
+    ab[t] = ((rr + 1) * a.RS + cc + 1) * 32 + 16 * (g & 1);
+  }
+  f32x4 acc[2][PT];
+#pragma unroll
+  for (int t = 0; t < PT; ++t) acc[0][t] = acc[1][t] = zero;
+  const int hiTap = g >> 1;
+  stage_load(0);
+  __syncthreads();
+  const float sd = s_sc[0];
+  stage_store(sd);
+  __syncthreads();
+  const long m0 = (img_base + (long)r0 * a.W);
+  float xv[PT][4], old[PT][4];
+  for (int sl = 0; sl < a.nsl; ++sl) {
+    const bool more = sl + 1 < a.nsl;
+    if (more) {
+      stage_load(sl + 1);
+    } else if (PT < 4) {       // (PT = 4: 32 more live registers would spill; loaded in the epilogue)
+#pragma unroll
+      for (int t = 0; t < PT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long m = m0 + (wave * PT + t) * 16 + 4 * g + r;
+          xv[t][r] = a.x[m * a.ldx + p];
+          old[t][r] = a.dx[m * a.ldg + p];
+        }
+    }
+#pragma unroll
+    for (int tp = 0; tp < 5; ++tp) {
+      const d16_h8 Bhp = *reinterpret_cast<const d16_h8*>(smw + tp * 2048 + lane * 16);
+      const d16_h8 Blp = *reinterpret_cast<const d16_h8*>(smw + tp * 2048 + 1024 + lane * 16);
+      const d16_h8 Bhn = *reinterpret_cast<const d16_h8*>(smw + (5 + tp) * 2048 + lane * 16);
+      const d16_h8 Bln = *reinterpret_cast<const d16_h8*>(smw + (5 + tp) * 2048 + 1024 + lane * 16);
+      const int t0 = 2 * tp, t1 = (2 * tp + 1 < 9) ? 2 * tp + 1 : 8;
+      const int sh0 = ((t0 / 3 - 1) * a.RS + (t0 % 3 - 1)) * 32;
+      const int sh1 = ((t1 / 3 - 1) * a.RS + (t1 % 3 - 1)) * 32;
+      const int sh = hiTap ? sh1 : sh0;
+      d16_h8 Ah[PT], Al[PT];
+#pragma unroll
+      for (int t = 0; t < PT; ++t) {
+        const unsigned char* ap = smemh + ab[t] + sh;
+        Ah[t] = *reinterpret_cast<const d16_h8*>(ap);
+        Al[t] = *reinterpret_cast<const d16_h8*>(ap + PLANE);
+      }
+#pragma unroll
+      for (int t = 0; t < PT; ++t) {
+        acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[t], Bhp, acc[0][t], 0, 0, 0);
+        acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[t], Bhn, acc[1][t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < PT; ++t) {
+        acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[t], Blp, acc[0][t], 0, 0, 0);
+        acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[t], Bln, acc[1][t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < PT; ++t) {
+        acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[t], Bhp, acc[0][t], 0, 0, 0);
+        acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[t], Bhn, acc[1][t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (more) {
+      stage_store(sd);
+      __syncthreads();
+    }
+  }
+  const float so = s_sc[1];
+  unsigned omax = 0u;
+  if (PT >= 4) {
+#pragma unroll
+    for (int t = 0; t < PT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long m = m0 + (wave * PT + t) * 16 + 4 * g + r;
+        xv[t][r] = a.x[m * a.ldx + p];
+        old[t][r] = a.dx[m * a.ldg + p];
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < PT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long m = m0 + (wave * PT + t) * 16 + 4 * g + r;
+      const float xq = xv[t][r];
+      float o = old[t][r];
+      // (a NaN scale must stay loud whatever the sign of x: add the sums, masked by a factor)
+      o = fmaf(acc[0][t][r] * so, xq > 0.f ? 1.f : 0.f, o);
+      o = fmaf(acc[1][t][r] * so, xq < 0.f ? -1.f : 0.f, o);
+      a.dx[m * a.ldg + p] = o;
+      const unsigned ob = amax_bits(o);
+      omax = ob > omax ? ob : omax;
+    }
+  if (a.amax) amax_commit(a.amax, omax);
+}
+
+// =======================================================================================
 // Weight gradient:  dW[tap][e][n] = sum_q act(x)[q][e] * dy[q - tap][n]
 //
 // MFMA roles: M = 16 effective channels, N = the 16 output channels, K = pixels.  A block owns
@@ -1340,6 +1597,53 @@ int dense16_fwd_h2(int N, int H, int W, int nsl, const float* x, int ldx, const 
   else if (PT == 2) D16_H2(2);
   else D16_H2(1);
 #undef D16_H2
+  return OTGAN_OK;
+}
+
+size_t dense16_h2_bwd_filter_bytes(int nsl) { return dense16_h2_filter_bytes(nsl); }
+
+int dense16_h2_bwd_prepare(const Dense16BwdPair* pairs, int npairs, const void* const* allfwd, int nall, hipStream_t s) {
+  for (int base = 0; base < npairs; base += 64) {
+    H2BwdPrepArgs a;
+    memset(&a, 0, sizeof(a));
+    const int cnt = npairs - base < 64 ? npairs - base : 64;
+    for (int i = 0; i < cnt; ++i) {
+      const Dense16BwdPair& pr = pairs[base + i];
+      a.w[i] = pr.w; a.fwd[i] = (const unsigned char*)pr.fwd; a.nch[i] = pr.nch; a.cidx[i] = pr.cidx;
+      a.hdr[i] = (unsigned char*)pr.out_base;
+      a.out[i] = (unsigned char*)pr.out_base + kH2HdrBytes + (size_t)pr.pair_index * kH2SliceU16 * 2;
+      a.first[i] = pr.pair_index == 0;
+    }
+    a.nall = nall;
+    for (int i = 0; i < nall; ++i) a.allfwd[i] = (const unsigned char*)allfwd[i];
+    hipLaunchKernelGGL(dense16_h2_bwd_prep_kernel, dim3(cnt), dim3(256), 0, s, a);
+  }
+  return OTGAN_OK;
+}
+
+int dense16_bwd_h2(int N, int H, int W, int nsl, const float* g, int ldg, const void* wq, const float* x, int ldx, float* dx,
+                   const float* rec0, int nrec0, const float* rec1, int nrec1, hipStream_t s, float* amax_out) {
+  int PT = H * W >= 256 ? 4 : H * W / 64;
+  while (PT > 1 && (long)N * H * W / (64 * PT) < 512) PT >>= 1;
+  BwdH2Args a;
+  a.g = g; a.wq = (const unsigned char*)wq; a.x = x; a.dx = dx;
+  a.rec0 = rec0; a.rec1 = rec1 ? rec1 : rec0; a.nrec0 = nrec0; a.nrec1 = rec1 ? nrec1 : 0; a.nsl = nsl;
+  a.N = N; a.H = H; a.W = W; a.logW = ilog2i(W); a.ldg = ldg; a.ldx = ldx;
+  a.TR = 64 * PT / W;
+  a.RS = W == 8 ? 16 : W + 2;
+  a.amax = amax_out;
+  const size_t lds = (size_t)2 * (a.TR + 2) * a.RS * 32 + (size_t)kH2SliceU16 * 2;
+  const dim3 grid(N * (H / a.TR)), blk(256);
+  const bool w8 = W == 8;
+#define D16_B2(PT_)                                                                                  \
+  do {                                                                                               \
+    if (w8) hipLaunchKernelGGL((dense16_bwd_h2_kernel<PT_, true>), grid, blk, lds, s, a);            \
+    else hipLaunchKernelGGL((dense16_bwd_h2_kernel<PT_, false>), grid, blk, lds, s, a);              \
+  } while (0)
+  if (PT == 4) D16_B2(4);
+  else if (PT == 2) D16_B2(2);
+  else D16_B2(1);
+#undef D16_B2
   return OTGAN_OK;
 }
 

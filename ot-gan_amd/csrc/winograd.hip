@@ -907,12 +907,12 @@ __global__ __launch_bounds__(256) void wino_s2_output_kernel(OutS2Args a) {
         }
       }
       float* dst = dv.p + off;
+      if (a.accumulate) o += ldv(dst);
 #pragma unroll
-      for (int q = 0; q < VW; ++q) {
+      for (int q = 0; q < VW; ++q) {      // the value that ends up in memory (with `accumulate`: the sum)
         const unsigned b = amax_bits(o[q]);
         mb = b > mb ? b : mb;
       }
-      if (a.accumulate) o += ldv(dst);
       *reinterpret_cast<VT*>(dst) = o;
     }
   }
@@ -1858,7 +1858,7 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   }
   oa.TH = OH / WM; oa.TW = OW / WM; oa.C = g.C; oa.Ceff = g.Ceff; oa.T = T; oa.ldm = K4; oa.Xh = Xh;
   oa.accumulate = accumulate;
-  oa.amax = (accumulate || g.up) ? nullptr : g.dx_amax_out;
+  oa.amax = g.up ? nullptr : g.dx_amax_out;
   const dim3 grid(grid1(T * (g.C / (g.doubled ? 2 : 4))), 1, wino_s2_classes(g)), blk(256);
   if (g.doubled) {
     if (g.act == 2) hipLaunchKernelGGL((wino_s2_output_kernel<2, true>), grid, blk, 0, s, oa);

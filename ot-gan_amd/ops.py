@@ -824,6 +824,11 @@ class DenseBlockFunction(torch.autograd.Function):
         grads = [None] * (3 * L)
         rows = N * H * W
         plan = ctx.plan
+        if (plan is not None and plan.get("h2") and ctx.batched and len(plan["wide"]) <= 2 and
+                os.environ.get("OTGAN_DENSE16_BWD_H2", "1") != "0"):
+            grads = DenseBlockFunction._backward_by_slice(ctx, buf, saved, G, dbuf, need_w)
+            dx0 = G[..., :C0].contiguous() if ctx.needs_input_grad[0] else None
+            return (dx0, None, None, None, *grads)
         if plan is not None:
             sw = ctx.sw
             dw_g = [None] * L
@@ -921,6 +926,127 @@ class DenseBlockFunction(torch.autograd.Function):
                 grads[3 * k + 2] = db_all[k * F:(k + 1) * F]
         dx0 = G[..., :C0].contiguous() if ctx.needs_input_grad[0] else None
         return (dx0, None, None, None, *grads)
+
+
+def _dense16_bwd_filters(sw, plan, L, F, device):
+    """Prepared weights of the by-slice input gradient (otgan_dense16_prepare_bwd_filters_f32): per output slice c one
+    buffer holding the pairs (c, k), k = the later layers of c's group.  Cached with the block's forward operands."""
+    hit = sw.get("h2_bwd")
+    if hit is not None:
+        return hit
+    from ._lib_layers import Dense16BwdPair
+    lib = _lib.lib()
+    starts = [wd["d0"] for wd in plan["wide"]] + [L]
+    gend = {}
+    for a, b in zip(starts[:-1], starts[1:]):
+        for c in range(a, b):
+            gend[c] = b
+    nsl = {c: gend[c] - 1 - c for c in range(L) if gend[c] - 1 - c >= 1}
+    sizes = {c: int(lib.otgan_dense16_bwd_filter_bytes(n)) for c, n in nsl.items()}
+    flat = torch.empty(sum(sizes.values()), dtype=torch.uint8, device=device)
+    out, off, pairs = {}, 0, []
+    for c in sorted(nsl):
+        out[c] = flat[off:off + sizes[c]]
+        off += sizes[c]
+        for j in range(nsl[c]):
+            k = c + 1 + j
+            pairs.append(Dense16BwdPair(sw["w_g"][k].data_ptr(), sw["h2"][k].data_ptr(), out[c].data_ptr(),
+                                        plan["own_len"][k], c - plan["g0"][k], j))
+    allf = [sw["h2"][k] for k in range(L) if sw["h2"][k] is not None]
+    if pairs:
+        arr = (Dense16BwdPair * len(pairs))(*pairs)
+        pf = (ctypes.c_void_p * len(allf))(*[t.data_ptr() for t in allf])
+        _lib.check(lib.otgan_dense16_prepare_bwd_filters_f32(ctypes.cast(arr, ctypes.c_void_p), len(pairs),
+                                                              ctypes.cast(pf, ctypes.c_void_p), len(allf), _lib.stream_ptr()),
+                   "dense16_prepare_bwd_filters")
+    res = {"flat": flat, "slice": out, "nsl": nsl}
+    sw["h2_bwd"] = res
+    return res
+
+
+def _backward_by_slice(ctx, buf, saved, G, dbuf, need_w):
+    """Backward of a split dense block whose chains run on the two-scaled-fp16-piece kernels (plan["h2"]): the input
+    gradient of the chains is gathered per SLICE, last slice first (otgan_dense16_bwd_slice_f32: one read-modify-write of
+    each slice instead of one per (layer, earlier slice) pair), and every kernel that adds into the gradient buffer leaves
+    the largest magnitude it wrote in a record -- no reduction passes over slices of the buffer (round 3: two per block).
+    Returns the list of parameter gradients (grads[3 k + 2], the biases, included)."""
+    L, C0, F = ctx.L, ctx.C0, ctx.F
+    N, H, W, Ctot = buf.shape
+    plan, sw = ctx.plan, ctx.sw
+    rows = N * H * W
+    lib = _lib.lib()
+    grads = [None] * (3 * L)
+    dw_g = [None] * L
+    wides = plan["wide"]
+    dw_wide = [None] * len(wides)
+    bw = _dense16_bwd_filters(sw, plan, L, F, buf.device)
+    # records: Rc bounds the incoming gradient and everything the wide convolutions' input gradients add; RS[c] what the
+    # slice kernel of slice c leaves.  A reader takes the maximum of Rc and the rows of the slices it reads.
+    tag = amax_of(dbuf)
+    Rc = tag.clone() if tag is not None else absmax_record(G)
+    RS = torch.zeros((L, AMAX_RECORD_FLOATS), dtype=torch.float32, device=buf.device)
+    gptr, bptr = G.data_ptr(), buf.data_ptr()
+
+    def wide_bwd(i, need_dx):
+        wd, ops_ = wides[i], sw["wide"][i]
+        desc = wd["desc"]
+        src, gsrc = buf[..., wd["x_off"]:], G[..., wd["x_off"]:]
+        dy_rec = torch.maximum(Rc, RS[wd["d0"]:].amax(0))
+        desc.x_amax = ctx.x_recs[i].data_ptr()
+        desc.dy_amax = dy_rec.data_ptr()
+        if need_w:
+            dw = torch.empty_like(ops_["w"])
+            conv_wgrad_raw(desc, src, None, G, dw)
+            dw_wide[i] = dw
+        if need_dx:
+            if not ops_["bwd_done"]:
+                ops_["bwd"], ops_["bwd_done"] = prepare_filters(desc, 1, ops_["w"]), True
+            desc.dx_amax_out = Rc.data_ptr() if i > 0 else None      # (i = 0 writes the block input's gradient: not read here)
+            conv_dgrad_raw(desc, G, ops_["w"], src, None, gsrc, Ctot, True, ops_["bwd"])
+            desc.dx_amax_out = None
+        desc.dy_amax = None
+
+    for c in reversed(range(L)):
+        for i in reversed(range(1, len(wides))):
+            if wides[i]["after"] == c:
+                wide_bwd(i, True)
+        n_src = bw["nsl"].get(c, 0)
+        if n_src:
+            off_c = 4 * (C0 + c * F)
+            _lib.check(lib.otgan_dense16_bwd_slice_f32(N, H, W, n_src, gptr + off_c + 4 * F, Ctot, bw["slice"][c].data_ptr(),
+                                                       bptr + off_c, Ctot, gptr + off_c, Rc.data_ptr(), 1,
+                                                       RS[c + 1].data_ptr(), n_src, RS[c].data_ptr(), _lib.stream_ptr()),
+                       "dense16_bwd_slice")
+        # the gradient of slice c is final: layer c's chain weight gradient
+        if need_w and plan["own_len"][c]:
+            desc = ctx.descs[c]
+            cmap, _inv = ctx.maps[c]
+            off = C0 + plan["g0"][c] * F
+            dw_g[c] = torch.empty_like(sw["w_g"][c])
+            conv_wgrad_raw(desc, buf[..., off:], cmap, G, dw_g[c])
+    wide_bwd(0, ctx.needs_input_grad[0])
+    if need_w:
+        assert ctx.batched and len(wides) <= 2
+        parts = []
+        for k in range(L):
+            pk = []
+            for i, wd in enumerate(wides):
+                if wd["d0"] <= k:
+                    nl = L - wd["d0"]
+                    pk.append((dw_wide[i].data_ptr() + 4 * (k - wd["d0"]) * F, wd["back"], wd["nrows"], nl * F))
+            if dw_g[k] is not None:
+                pk.append((dw_g[k].data_ptr(), None, dw_g[k].shape[0] // 9, F))
+            parts.append(pk)
+        dVs, dgs = weightnorm_bwd_block(saved[0::4], saved[1::4], saved[3::4], parts)
+        for k in range(L):
+            grads[3 * k:3 * k + 2] = [dVs[k].view(ctx.vshapes[k]), dgs[k]]
+        db_all = colsum(G.data_ptr() + 4 * C0, rows, L * F, Ctot, G.device)
+        for k in range(L):
+            grads[3 * k + 2] = db_all[k * F:(k + 1) * F]
+    return grads
+
+
+DenseBlockFunction._backward_by_slice = staticmethod(_backward_by_slice)
 
 
 def dense_block_op(x0, segs0, params, ksize=3, preact=1):
