@@ -320,7 +320,9 @@ __device__ __forceinline__ void panel_combine(float mx, float s, float* s_pm, fl
     float S = 0.f;
 #pragma unroll 4
     for (int k = 0; k < TPR; ++k) S += s_ps[k * RPW + line] * exp_neg(s_pm[k * RPW + line] - M);
-    if (gline < N) publish_tagged(out_global + gline, -(M + logf(S)), seq);
+    int gl = gline;
+    asm volatile("" : "+v"(gl));      // (address formed here, not carried around the loop in a register pair)
+    if (gline < N) publish_tagged(out_global + gl, -(M + logf(S)), seq);
   }
 }
 
@@ -356,40 +358,52 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
   bool ok = true;
   for (int it = 0; it <= a.iters && ok; ++it) {
     {  // rows: f from g (s_pot holds g); the extra pass it == iters is the final row softmax
-      float v[32];
+      // Two passes over the thread's 32 entries (max, then the shifted sum) WITHOUT keeping the 32 sums K + g in
+      // registers: with kr[32] they did not fit the 128 registers a 1024-thread workgroup leaves a lane (round 3:
+      // 23 - 27 spilled registers = scratch traffic inside the latency-critical loop).  The potentials are LDS
+      // broadcasts (every lane of a slice reads the same word): reading them twice costs less than the spills did.
       float mx = -3.0e38f;
 #pragma unroll
-      for (int e = 0; e < 32; ++e) {
-        v[e] = kr[e] + s_pot[q * 32 + e];
-        mx = fmaxf(mx, v[e]);
-      }
+      for (int e = 0; e < 32; ++e) mx = fmaxf(mx, kr[e] + s_pot[q * 32 + e]);
       float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < 32; ++e) s += exp_neg(v[e] - mx);
+      for (int e = 0; e < 32; ++e) s += exp_neg(kr[e] + s_pot[q * 32 + e] - mx);
       panel_combine<TPR, RPW>(mx, s, s_pm, s_ps, line, q, gline, N, f, ++phase);
     }
     {
       bool okl = true;
-      s_pot[t] = t < N ? consume_tagged(f + t, phase, a.fail, okl) : 0.f;
+      int tt = t;
+      asm volatile("" : "+v"(tt));      // (keeps the 64-bit slot addresses out of the loop-carried registers: they spilled)
+      s_pot[t] = t < N ? consume_tagged(f + tt, phase, a.fail, okl) : 0.f;
       ok = __syncthreads_and(okl) != 0;
     }
     if (it == a.iters || !ok) break;
-    {  // columns: g from f (s_pot holds f)
-      float v[32];
-      float mx = -3.0e38f;
+    {  // columns: g from f (s_pot holds f): the column panel lives in LDS; four chunks of eight keep the sums K + f of
+       // a chunk in registers between its max and its shifted sum (one LDS read per entry), merged online
+      float mx = -3.0e38f, s = 0.f;
 #pragma unroll
-      for (int e = 0; e < 32; ++e) {
-        v[e] = s_kc[(q * 32 + e) * RPW + line] + s_pot[q * 32 + e];
-        mx = fmaxf(mx, v[e]);
+      for (int c = 0; c < 4; ++c) {
+        float v[8];
+        float m = -3.0e38f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[e] = s_kc[(q * 32 + 8 * c + e) * RPW + line] + s_pot[q * 32 + 8 * c + e];
+          m = fmaxf(m, v[e]);
+        }
+        float sc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sc += exp_neg(v[e] - m);
+        const float mn = fmaxf(mx, m);
+        s = s * exp_neg(mx - mn) + sc * exp_neg(m - mn);
+        mx = mn;
       }
-      float s = 0.f;
-#pragma unroll
-      for (int e = 0; e < 32; ++e) s += exp_neg(v[e] - mx);
       panel_combine<TPR, RPW>(mx, s, s_pm, s_ps, line, q, gline, N, g, ++phase);
     }
     {
       bool okl = true;
-      s_pot[t] = t < N ? consume_tagged(g + t, phase, a.fail, okl) : 0.f;
+      int tt = t;
+      asm volatile("" : "+v"(tt));
+      s_pot[t] = t < N ? consume_tagged(g + tt, phase, a.fail, okl) : 0.f;
       ok = __syncthreads_and(okl) != 0;
     }
   }
