@@ -218,6 +218,20 @@ int otgan_dense16_h2_ok(const otgan_conv_desc* d);
  * rec0 / rec1: two ranges of consecutive amax records whose maximum bounds the source slices (rec1 nullable);
  * amax_out (nullable, zeroed or shared): max-accumulates the sums written.  Geometry as otgan_dense16_h2_ok.
  */
+/*
+ * Whole chains in one call (the launches of a group's layers issued back to back from C: at 8 x 8 a chain kernel takes 9 us,
+ * less than one Python-level call).  A group = `nslices` consecutive 16-channel slices of the block buffer starting at
+ * `buf_group` (row stride ld floats); records = (nslices + 1) consecutive amax records [W, c_0, c_1, ...] as laid out by
+ * ops.py DenseBlockFunction (W: the wide convolutions' sums; c_j: left by the kernel that finishes slice j).
+ *   otgan_dense16_chain_fwd_f32: layers j = 1 .. nslices - 1 in order, layer j adds its chain over slices [0, j) onto slice
+ *     j (filters[j - 1]: its prepared weights), reads records [0, 1 + j), writes record 1 + j.
+ *   otgan_dense16_chain_bwd_f32: slices c = nslices - 2 .. 0, otgan_dense16_bwd_slice_f32 each (filters[c]; sources bounded
+ *     by rec0 (one record) and slice_records[c + 1 ..]; slice_records[c] receives the sums left).
+ */
+int otgan_dense16_chain_fwd_f32(int N, int H, int W, int nslices, float* buf_group, int ld, const void* const* filters,
+                                float* records, void* stream);
+int otgan_dense16_chain_bwd_f32(int N, int H, int W, int nslices, float* g_group, int ldg, const float* x_group, int ldx,
+                                const void* const* filters, const float* rec0, float* slice_records, void* stream);
 typedef struct otgan_dense16_bwd_pair {
   const float* w;
   const void* fwd_filters;

@@ -57,6 +57,8 @@ SIGNATURES = {
     "otgan_dense16_filter_bytes": (c_size_t, [c_int]),
     "otgan_dense16_prepare_filters_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp]),
     "otgan_dense16_h2_ok": (c_int, [P_DESC]),
+    "otgan_dense16_chain_fwd_f32": (c_int, [c_int, c_int, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_fp]),
+    "otgan_dense16_chain_bwd_f32": (c_int, [c_int, c_int, c_int, c_int, c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp]),
     "otgan_dense16_bwd_filter_bytes": (c_size_t, [c_int]),
     "otgan_dense16_prepare_bwd_filters_f32": (c_int, [c_fp, c_int, c_fp, c_int, c_fp]),
     "otgan_dense16_bwd_slice_f32": (c_int, [c_int, c_int, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_int,

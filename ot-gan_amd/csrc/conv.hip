@@ -2707,6 +2707,43 @@ int otgan_dense16_bwd_slice_f32(int N, int H, int W, int npairs, const float* g,
   return rc;
 }
 
+int otgan_dense16_chain_fwd_f32(int N, int H, int W, int nslices, float* buf_group, int ld, const void* const* filters,
+                                float* records, void* stream) {
+  OTGAN_CHECK_ARG(buf_group && filters && records && nslices >= 2 && nslices <= 17 && ld % 4 == 0 && aligned16(buf_group),
+                  "bad chain arguments");
+  OTGAN_CHECK_ARG(dense16_enabled() && dense16_h2_shape_ok(N, H, W), "geometry not taken by the fp16 x 2 growth kernels");
+  hipStream_t s = (hipStream_t)stream;
+  const int R = OTGAN_AMAX_RECORD_FLOATS;
+  for (int j = 1; j < nslices; ++j) {
+    OTGAN_CHECK_ARG(filters[j - 1] && aligned16(filters[j - 1]), "null / misaligned filters of chain layer %d", j);
+    ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * (double)N * H * W * 9.0 * 32.0 * j * 16.0, 0.0, s);
+    const int rc = dense16_fwd_h2(N, H, W, j, buf_group, ld, filters[j - 1], records, 1 + j, buf_group, ld, 16 * j, s,
+                                  records + (size_t)(1 + j) * R);
+    if (rc) return rc;
+  }
+  OTGAN_CHECK_LAUNCH("dense16 chain fwd");
+  return OTGAN_OK;
+}
+int otgan_dense16_chain_bwd_f32(int N, int H, int W, int nslices, float* g_group, int ldg, const float* x_group, int ldx,
+                                const void* const* filters, const float* rec0, float* slice_records, void* stream) {
+  OTGAN_CHECK_ARG(g_group && x_group && filters && rec0 && slice_records && nslices >= 2 && nslices <= 17 && ldg % 4 == 0 &&
+                      ldx % 4 == 0 && aligned16(g_group) && aligned16(x_group),
+                  "bad chain arguments");
+  OTGAN_CHECK_ARG(dense16_enabled() && dense16_h2_shape_ok(N, H, W), "geometry not taken by the fp16 x 2 growth kernels");
+  hipStream_t s = (hipStream_t)stream;
+  const int R = OTGAN_AMAX_RECORD_FLOATS;
+  for (int c = nslices - 2; c >= 0; --c) {
+    const int nsl = nslices - 1 - c;
+    OTGAN_CHECK_ARG(filters[c] && aligned16(filters[c]), "null / misaligned filters of slice %d", c);
+    ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * (double)N * H * W * 9.0 * 16.0 * nsl * 32.0, 0.0, s);
+    const int rc = dense16_bwd_h2(N, H, W, nsl, g_group + 16 * (c + 1), ldg, filters[c], x_group + 16 * c, ldx, g_group + 16 * c,
+                                  rec0, 1, slice_records + (size_t)(c + 1) * R, nsl, s, slice_records + (size_t)c * R);
+    if (rc) return rc;
+  }
+  OTGAN_CHECK_LAUNCH("dense16 chain bwd");
+  return OTGAN_OK;
+}
+
 size_t otgan_conv2d_filter_bytes(const otgan_conv_desc* d, int which) {
   Geo g;
   if (make_geo(d, &g) != OTGAN_OK || which < 0 || which > 3) return 0;

@@ -768,7 +768,30 @@ class DenseBlockFunction(torch.autograd.Function):
                 desc.y_amax_out = None
 
             wide_fwd(0)
-            for k in range(L):
+            chain_h2 = shared and plan.get("h2") and all(sw["h2"][k] is not None for k in range(L) if plan["own_len"][k])
+            if chain_h2:
+                # every group's chain in one library call (otgan_dense16_chain_fwd_f32: its layers' launches back to back)
+                lib = _lib.lib()
+                for gi, wd in enumerate(wides):
+                    d0, d1 = wd["d0"], (wides[gi + 1]["d0"] if gi + 1 < len(wides) else L)
+                    if gi > 0:
+                        wide_fwd(gi)        # (the group that feeds this one is finished)
+                    if d1 - d0 >= 2:
+                        pf = (ctypes.c_void_p * (d1 - d0 - 1))(*[sw["h2"][k].data_ptr() for k in range(d0 + 1, d1)])
+                        _lib.check(lib.otgan_dense16_chain_fwd_f32(N, H, W, d1 - d0, buf.data_ptr() + 4 * (C0 + d0 * F), Ctot,
+                                                                   ctypes.cast(pf, ctypes.c_void_p), R[gbase[gi]].data_ptr(),
+                                                                   _lib.stream_ptr()), "dense16_chain_fwd")
+                for k in range(L):      # descriptors / maps of the chain layers (their weight gradients use them)
+                    n_own = plan["own_len"][k]
+                    if n_own:
+                        desc = ConvDesc(N, H, W, n_own * F, Ctot, 0, ksize, ksize, 1, F, Ctot, C0 + k * F, preact, 1)
+                        desc.list_width = F
+                        descs.append(desc)
+                        maps.append(channel_maps((F,) * n_own, preact, x0.device))
+                    else:
+                        descs.append(None)
+                        maps.append((None, None))
+            for k in range(L) if not chain_h2 else ():
                 n_own = plan["own_len"][k]
                 desc = cmap = inv = None
                 if n_own:
@@ -1006,24 +1029,26 @@ def _backward_by_slice(ctx, buf, saved, G, dbuf, need_w):
             desc.dx_amax_out = None
         desc.dy_amax = None
 
-    for c in reversed(range(L)):
-        for i in reversed(range(1, len(wides))):
-            if wides[i]["after"] == c:
-                wide_bwd(i, True)
-        n_src = bw["nsl"].get(c, 0)
-        if n_src:
-            off_c = 4 * (C0 + c * F)
-            _lib.check(lib.otgan_dense16_bwd_slice_f32(N, H, W, n_src, gptr + off_c + 4 * F, Ctot, bw["slice"][c].data_ptr(),
-                                                       bptr + off_c, Ctot, gptr + off_c, Rc.data_ptr(), 1,
-                                                       RS[c + 1].data_ptr(), n_src, RS[c].data_ptr(), _lib.stream_ptr()),
-                       "dense16_bwd_slice")
-        # the gradient of slice c is final: layer c's chain weight gradient
-        if need_w and plan["own_len"][c]:
-            desc = ctx.descs[c]
-            cmap, _inv = ctx.maps[c]
-            off = C0 + plan["g0"][c] * F
-            dw_g[c] = torch.empty_like(sw["w_g"][c])
-            conv_wgrad_raw(desc, buf[..., off:], cmap, G, dw_g[c])
+    starts = [wd["d0"] for wd in wides] + [L]
+    for gi in reversed(range(len(wides))):
+        d0, d1 = starts[gi], starts[gi + 1]
+        if gi + 1 < len(wides):
+            wide_bwd(gi + 1, True)       # the later groups are final: their share in this group's slices
+        if d1 - d0 >= 2:
+            # slices d1 - 2 .. d0, last first, in one library call (otgan_dense16_chain_bwd_f32)
+            pf = (ctypes.c_void_p * (d1 - d0 - 1))(*[bw["slice"][c].data_ptr() for c in range(d0, d1 - 1)])
+            off0 = 4 * (C0 + d0 * F)
+            _lib.check(lib.otgan_dense16_chain_bwd_f32(N, H, W, d1 - d0, gptr + off0, Ctot, bptr + off0, Ctot,
+                                                       ctypes.cast(pf, ctypes.c_void_p), Rc.data_ptr(), RS[d0].data_ptr(),
+                                                       _lib.stream_ptr()), "dense16_chain_bwd")
+        # the gradients of the group's slices are final: the chain weight gradients of its layers
+        for c in reversed(range(d0, d1)):
+            if need_w and plan["own_len"][c]:
+                desc = ctx.descs[c]
+                cmap, _inv = ctx.maps[c]
+                off = C0 + plan["g0"][c] * F
+                dw_g[c] = torch.empty_like(sw["w_g"][c])
+                conv_wgrad_raw(desc, buf[..., off:], cmap, G, dw_g[c])
     wide_bwd(0, ctx.needs_input_grad[0])
     if need_w:
         assert ctx.batched and len(wides) <= 2
