@@ -205,6 +205,7 @@ struct BgArgs {
 #ifdef X3_TIMING
   unsigned long long* dbg;   // tools/ablate/x3_phase.hip: s_memtime stamps of workgroup x at dbg[64 x ..]
 #endif
+  unsigned x_total;          // 256 x 128 kernel: number of queue positions; the grid may be smaller (tile loop)
 };
 // 2^(eA + eB - 28) of frequency f (scaled two-piece operands): a product of two powers of two, exact
 __device__ __forceinline__ float x3_out_scale(const BgArgs& a, int f) { return a.hdrA[64 + f] * a.hdrB[64 + f]; }
@@ -608,113 +609,129 @@ __device__ __forceinline__ void x3n_sched_group() {
 #ifndef X3N_NUM_VGPR
 #define X3N_NUM_VGPR 128
 #endif
+// Round 4: the kernel walks tiles x, x + gridDim.x, ... of the frequency-major queue (gridDim.x a multiple of 8: a
+// workgroup stays on its XCD).  With a grid capped at the resident workgroups (two per compute unit) a workgroup starts
+// the first three stages of its NEXT tile -- LDS-DMA loads, no registers -- before it writes the current one out: they land
+// during the 256 stores per lane, and the next tile begins with its operands in LDS instead of with an HBM round trip
+// (6 - 7 k of a K = 256 tile's 43 k cycles).  Uncapped grid: one tile per workgroup, exactly the round-3 kernel.
+struct X3NTile {
+  int f, m0, n0, nst, steps0, kb0, kb1;
+  const u16* cbase[X3N_PER_WAVE];
+  int ccbn[X3N_PER_WAVE];
+};
 template <bool TL>
 __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2), amdgpu_num_vgpr(X3N_NUM_VGPR))) void wino_bgemm_x3n_kernel(BgArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-  const int x = blockIdx.x;
   X3N_STAMP(0);
-  int tm, tn, fsel = -1;
-  if (a.xmap == 4) {
-    const int tiles = a.tiles_m * a.tiles_n;
-    const int xcd = x & 7, idx = x >> 3;
-    const int slot = idx / tiles, tile = idx - slot * tiles;
-    const int code = (unsigned char)a.fmap[xcd][slot];
-    if (code == 255) return;
-    const int half = (tiles + 1) >> 1;
-    if ((code & 64) && tile >= half) return;
-    if ((code & 128) && tile < half) return;
-    fsel = __builtin_amdgcn_readfirstlane(code & 63);
-    tn = __builtin_amdgcn_readfirstlane(tile % a.tiles_n);
-    tm = __builtin_amdgcn_readfirstlane(tile / a.tiles_n);
-  } else {
-    tn = x % a.tiles_n;
-    tm = x / a.tiles_n;
-  }
-  const int f = fsel >= 0 ? fsel : lpt_frequency(a.seg_mode, blockIdx.z);
-  const int m0 = a.m_begin + tm * X3_BM, n0 = tn * X3N_BN;
-  const int Kz = a.ztab ? a.zK[f] : a.K;
-  if (a.seg_mode == 2 || a.seg_mode == 3) {
-    const int lo = a.seg_mode == 2 ? n0 : m0, ext = a.seg_mode == 2 ? a.N : a.M;
-    int hi = lo + (a.seg_mode == 2 ? X3N_BN : X3_BM) - 1;
-    if (hi >= ext) hi = ext - 1;
-    bool any = false;
-    for (int c = lo / a.seg_len; c <= hi / a.seg_len; ++c) any = any || s2_present(c, f, a.seg_skip);
-    if (!any) return;
-  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, g = lane >> 5;
-
-  int lo0 = 0, len0 = 0, lo1 = 0, len1 = 0;
-  if (a.seg_mode == 1) {
-    int c = 0, nrun = 0;
-    while (c < 4) {
-      if (!s2_present(c, f, a.seg_skip)) {
-        ++c;
-        continue;
-      }
-      int e = c + 1;
-      while (e < 4 && s2_present(e, f, a.seg_skip)) ++e;
-      if (nrun == 0) {
-        lo0 = c * a.seg_len;
-        len0 = (e - c) * a.seg_len;
-      } else {
-        lo1 = c * a.seg_len;
-        len1 = (e - c) * a.seg_len;
-      }
-      ++nrun;
-      c = e;
-    }
-  } else {
-    const int nkt_all = Kz / X3_BK;
-    const int kt0 = blockIdx.y * a.kt_per_split;
-    int nkt = nkt_all - kt0;
-    if (nkt > a.kt_per_split) nkt = a.kt_per_split;
-    if (nkt < 0) nkt = 0;
-    lo0 = kt0 * X3_BK;
-    len0 = nkt * X3_BK;
-  }
-  const int steps0 = len0 / X3_SK;
-  const int nst = steps0 + len1 / X3_SK;
-  const int kb0 = lo0 / X3_SK, kb1 = lo1 / X3_SK - steps0;
-  auto kb_of = [&](int st) { return st < steps0 ? kb0 + st : kb1 + st; };
-
-  // this wave's six chunk streams out of the stage's 24 (A: piece x eight row groups of 32, then B: piece x four):
-  // scalar base address at k block 0, LDS offset inside a stage, and (TL) the operand's column-block count
-  const u16* opA = a.Ap + (a.ztab ? a.zA[f] : f * a.sAp);
-  const u16* opB = a.Bp + (a.ztab ? a.zB[f] : f * a.sBp);
   const unsigned voff = TL ? (unsigned)(lane >> 5) * 1024u + (unsigned)(lane & 31) * 16u : (unsigned)lane * 16u;
   const unsigned lds_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)smem3;
-  const u16* cbase[X3N_PER_WAVE];
+  // LDS offsets of this wave's six chunk streams inside a stage (A: piece x eight row groups of 32, then B: piece x four)
   unsigned cdst[X3N_PER_WAVE];
-  int ccbn[X3N_PER_WAVE];
 #pragma unroll
   for (int i = 0; i < X3N_PER_WAVE; ++i) {
     const int li = wave * X3N_PER_WAVE + i;
     const bool isA = li < X3N_CHA;
     const int l2 = isA ? li : li - X3N_CHA;
     const int piece = isA ? l2 >> 3 : l2 >> 2, rg = isA ? l2 & 7 : l2 & 3;
-    const u16* opb = (isA ? opA : opB) + piece * (isA ? a.pA : a.pB);
-    if (TL) {
-      const int cbn = isA ? a.cbA : a.cbB;
-      int cb = ((isA ? m0 : n0) >> 4) + 2 * rg;
-      if (cb > ((cbn - 1) & ~1)) cb = (cbn - 1) & ~1;   // (see the 256 x 256 kernel: duplicates feed columns never stored)
-      cbase[i] = opb + ((long)cb << 9);
-      ccbn[i] = cbn;
-    } else {
-      int rb = ((isA ? m0 : n0) >> 5) + rg;
-      const int rbmax = (isA ? a.rbA : a.rbB) - 1;
-      if (rb > rbmax) rb = rbmax;
-      cbase[i] = opb + (((long)rb * a.kblocks) << 9);
-      ccbn[i] = 0;
-    }
     cdst[i] = lds_base + (isA ? piece * X3_TA + rg * 1024 : X3_NP * X3_TA + piece * X3N_TB + rg * 1024);
   }
-  auto issue = [&](int st, int buf, int i0 = 0, int n = X3N_PER_WAVE) {
-    const long kb = kb_of(st);
+  // tile x of the queue -> its frequency, position, K stages and operand streams; false: nothing to compute there
+  auto setup = [&](int x, X3NTile& T) -> bool {
+    int tm, tn, fsel = -1;
+    if (a.xmap == 4) {
+      const int tiles = a.tiles_m * a.tiles_n;
+      const int xcd = x & 7, idx = x >> 3;
+      const int slot = idx / tiles, tile = idx - slot * tiles;
+      const int code = (unsigned char)a.fmap[xcd][slot];
+      if (code == 255) return false;
+      const int half = (tiles + 1) >> 1;
+      if ((code & 64) && tile >= half) return false;
+      if ((code & 128) && tile < half) return false;
+      fsel = __builtin_amdgcn_readfirstlane(code & 63);
+      tn = __builtin_amdgcn_readfirstlane(tile % a.tiles_n);
+      tm = __builtin_amdgcn_readfirstlane(tile / a.tiles_n);
+    } else {
+      tn = x % a.tiles_n;
+      tm = x / a.tiles_n;
+    }
+    const int f = fsel >= 0 ? fsel : lpt_frequency(a.seg_mode, blockIdx.z);
+    const int m0 = a.m_begin + tm * X3_BM, n0 = tn * X3N_BN;
+    const int Kz = a.ztab ? a.zK[f] : a.K;
+    if (a.seg_mode == 2 || a.seg_mode == 3) {
+      const int lo = a.seg_mode == 2 ? n0 : m0, ext = a.seg_mode == 2 ? a.N : a.M;
+      int hi = lo + (a.seg_mode == 2 ? X3N_BN : X3_BM) - 1;
+      if (hi >= ext) hi = ext - 1;
+      bool any = false;
+      for (int c = lo / a.seg_len; c <= hi / a.seg_len; ++c) any = any || s2_present(c, f, a.seg_skip);
+      if (!any) return false;
+    }
+    int lo0 = 0, len0 = 0, lo1 = 0, len1 = 0;
+    if (a.seg_mode == 1) {
+      int c = 0, nrun = 0;
+      while (c < 4) {
+        if (!s2_present(c, f, a.seg_skip)) {
+          ++c;
+          continue;
+        }
+        int e = c + 1;
+        while (e < 4 && s2_present(e, f, a.seg_skip)) ++e;
+        if (nrun == 0) {
+          lo0 = c * a.seg_len;
+          len0 = (e - c) * a.seg_len;
+        } else {
+          lo1 = c * a.seg_len;
+          len1 = (e - c) * a.seg_len;
+        }
+        ++nrun;
+        c = e;
+      }
+    } else {
+      const int nkt_all = Kz / X3_BK;
+      const int kt0 = blockIdx.y * a.kt_per_split;
+      int nkt = nkt_all - kt0;
+      if (nkt > a.kt_per_split) nkt = a.kt_per_split;
+      if (nkt < 0) nkt = 0;
+      lo0 = kt0 * X3_BK;
+      len0 = nkt * X3_BK;
+    }
+    T.f = f; T.m0 = m0; T.n0 = n0;
+    T.steps0 = len0 / X3_SK;
+    T.nst = T.steps0 + len1 / X3_SK;
+    T.kb0 = lo0 / X3_SK;
+    T.kb1 = lo1 / X3_SK - T.steps0;
+    const u16* opA = a.Ap + (a.ztab ? a.zA[f] : f * a.sAp);
+    const u16* opB = a.Bp + (a.ztab ? a.zB[f] : f * a.sBp);
+#pragma unroll
+    for (int i = 0; i < X3N_PER_WAVE; ++i) {
+      const int li = wave * X3N_PER_WAVE + i;
+      const bool isA = li < X3N_CHA;
+      const int l2 = isA ? li : li - X3N_CHA;
+      const int piece = isA ? l2 >> 3 : l2 >> 2, rg = isA ? l2 & 7 : l2 & 3;
+      const u16* opb = (isA ? opA : opB) + piece * (isA ? a.pA : a.pB);
+      if (TL) {
+        const int cbn = isA ? a.cbA : a.cbB;
+        int cb = ((isA ? m0 : n0) >> 4) + 2 * rg;
+        if (cb > ((cbn - 1) & ~1)) cb = (cbn - 1) & ~1;   // (see the 256 x 256 kernel: duplicates feed columns never stored)
+        T.cbase[i] = opb + ((long)cb << 9);
+        T.ccbn[i] = cbn;
+      } else {
+        int rb = ((isA ? m0 : n0) >> 5) + rg;
+        const int rbmax = (isA ? a.rbA : a.rbB) - 1;
+        if (rb > rbmax) rb = rbmax;
+        T.cbase[i] = opb + (((long)rb * a.kblocks) << 9);
+        T.ccbn[i] = 0;
+      }
+    }
+    return true;
+  };
+  auto issue = [&](const X3NTile& T, int st, int buf, int i0 = 0, int n = X3N_PER_WAVE) {
+    const long kb = st < T.steps0 ? T.kb0 + st : T.kb1 + st;
 #pragma unroll
     for (int i = i0; i < i0 + n; ++i) {
-      const u16* src = cbase[i] + (TL ? ((((kb >> 1) * ccbn[i]) << 9) + ((kb & 1) << 8)) : (kb << 9));
+      const u16* src = T.cbase[i] + (TL ? ((((kb >> 1) * T.ccbn[i]) << 9) + ((kb & 1) << 8)) : (kb << 9));
       const unsigned dst = cdst[i] + buf * X3N_STAGE;
 #ifdef X3N_DBG_NODMA   // (tools/debug/build_corun_variants.sh: the kernel as a neighbour without one of its ingredients; results garbage)
       asm volatile("" ::"v"(voff), "s"(src), "s"(dst) : "memory");
@@ -723,13 +740,6 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #endif
     }
   };
-  f32x16 acc[X3_MT][X3N_NT];
-#pragma unroll
-  for (int i = 0; i < X3_MT; ++i)
-#pragma unroll
-    for (int j = 0; j < X3N_NT; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
   const int sw = (r >> 3) & 1;
   const int g4 = lane >> 4, l16 = lane & 15;
   const int ftl = (g4 & 1) * 512 + (8 * (g4 >> 1) + (l16 >> 2)) * 32 + ((((l16 >> 1) & 1) ^ (g4 >> 1)) * 16) + (l16 & 1) * 8;
@@ -757,6 +767,8 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
       for (int p = 0; p < X3_NP; ++p) F.b[t][p] = read_frag(pb + p * X3N_TB + t * 1024);
   };
+  f32x16 acc[X3_MT][X3N_NT];
+  X3NTile T;
   // one stage: stage st+1 has landed (counted vmcnt + barrier), the buffer stage st was read from is refilled with
   // stage st+3, then the 24 MFMAs of stage st on F in three term groups of eight, each with two of the six refill
   // loads and four of the twelve fragment reads of stage st+1 (into G) in front
@@ -782,7 +794,7 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       constexpr int t = decltype(tc)::value;
       constexpr int l0 = t * X3N_PER_WAVE / X3_NTERM, l1 = (t + 1) * X3N_PER_WAVE / X3_NTERM;
       constexpr int q0 = t * NR / X3_NTERM, q1 = (t + 1) * NR / X3_NTERM;
-      if (ISSUE) issue(st + 3, rbuf, l0, l1 - l0);
+      if (ISSUE) issue(T, st + 3, rbuf, l0, l1 - l0);
       if (LOAD) {
 #pragma unroll
         for (int q = q0; q < q1; ++q) {
@@ -810,68 +822,104 @@ __global__ __launch_bounds__(X3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   };
   using Y = std::true_type;
   using N = std::false_type;
-  X3NFrags F0, F1;
-  issue(0, 0);
-  issue(1, 1);
-  issue(2, 2);
-  X3_WAIT_VM(2 * X3N_PER_WAVE);
-  __builtin_amdgcn_s_barrier();
-  load_frags(F0, 0);
-  X3N_STAMP(1);
-  int st = 0, bufn = 1;
-  auto next = [&]() { bufn = bufn == X3_NSTAGE - 1 ? 0 : bufn + 1; };
-  for (; st + 6 <= nst; st += 2) {
-    stage(st, bufn, F0, F1, Y{}, Y{}, Y{});
-    next();
-    stage(st + 1, bufn, F1, F0, Y{}, Y{}, Y{});
-    next();
-    X3N_STAMP(4 + (st >> 1));
-  }
-  stage(st, bufn, F0, F1, Y{}, Y{}, Y{});
-  next();
-  stage(st + 1, bufn, F1, F0, N{}, Y{}, Y{});
-  next();
-  stage(st + 2, bufn, F0, F1, N{}, N{}, Y{});
-  next();
-  stage(st + 3, bufn, F1, F0, N{}, N{}, N{});
-  X3N_STAMP(2);
-
-  float* C = a.C + (a.ztab ? a.zC[f] : f * a.sC) + blockIdx.y * a.sSplit;
-  float es = a.epi ? a.epi_scale : 1.f;
-  const float eb = a.epi ? a.epi_bias : 0.f, ed = a.epi ? a.epi_diag[f & 7] : 0.f;
-  if (a.hdrA) es *= x3_out_scale(a, f);
-  if (m0 + X3_BM <= a.M && n0 + X3N_BN <= a.N && ed == 0.f) {
-    const long ld = a.ldc;
-    float* row = C + (long)(m0 + wm * X3_MT * 32 + 4 * g) * ld + (n0 + wn * X3N_NT * 32 + r);
-#pragma unroll
-    for (int i = 0; i < X3_MT; ++i) {
-#pragma unroll
-      for (int qh = 0; qh < 4; ++qh) {
-        float* p = row + (long)(i * 32 + 8 * qh) * ld;
-#pragma unroll
-        for (int ql = 0; ql < 4; ++ql) {
-#pragma unroll
-          for (int j = 0; j < X3N_NT; ++j) p[j * 32] = fmaf(es, acc[i][j][4 * qh + ql], eb);
-          p += ld;
-        }
-      }
-    }
-  } else {
+  const int xend = (int)a.x_total, xstep = (int)gridDim.x;
+  int x = blockIdx.x;
+  while (x < xend && !setup(x, T)) x += xstep;
+  if (x >= xend) return;
+  issue(T, 0, 0);
+  issue(T, 1, 1);
+  issue(T, 2, 2);
+  for (;;) {
 #pragma unroll
     for (int i = 0; i < X3_MT; ++i)
 #pragma unroll
       for (int j = 0; j < X3N_NT; ++j)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int rr = (q & 3) + 8 * (q >> 2) + 4 * g;
-          const int m = m0 + (wm * X3_MT + i) * 32 + rr;
-          const int n = n0 + (wn * X3N_NT + j) * 32 + r;
-          if (m < a.M && n < a.N) {
-            float v = acc[i][j][q];
-            if (a.epi || a.hdrA) v = fmaf(es, v, eb) + (m == n ? ed : 0.f);
-            C[(long)m * a.ldc + n] = v;
+        for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    X3NFrags F0, F1;
+    // (a following tile: the 18 loads were issued BEFORE the previous tile's stores -- at most 12 operations outstanding
+    // means all of them have landed, completion being in order)
+    X3_WAIT_VM(2 * X3N_PER_WAVE);
+    __builtin_amdgcn_s_barrier();
+    load_frags(F0, 0);
+    X3N_STAMP(1);
+    int st = 0, bufn = 1;
+    const int nst = T.nst;
+    auto next = [&]() { bufn = bufn == X3_NSTAGE - 1 ? 0 : bufn + 1; };
+    for (; st + 6 <= nst; st += 2) {
+      stage(st, bufn, F0, F1, Y{}, Y{}, Y{});
+      next();
+      stage(st + 1, bufn, F1, F0, Y{}, Y{}, Y{});
+      next();
+      X3N_STAMP(4 + (st >> 1));
+    }
+    stage(st, bufn, F0, F1, Y{}, Y{}, Y{});
+    next();
+    stage(st + 1, bufn, F1, F0, N{}, Y{}, Y{});
+    next();
+    stage(st + 2, bufn, F0, F1, N{}, N{}, Y{});
+    next();
+    stage(st + 3, bufn, F1, F0, N{}, N{}, N{});
+    X3N_STAMP(2);
+
+    // this tile's output position, then the next tile's operand streams (T is overwritten)
+    const int f = T.f, m0 = T.m0, n0 = T.n0;
+    int xn = x + xstep;
+    bool have = false;
+    while (xn < xend) {
+      if (setup(xn, T)) {
+        have = true;
+        break;
+      }
+      xn += xstep;
+    }
+    if (have) {
+      // every wave is past its last fragment read of this tile before the buffers are refilled
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue(T, 0, 0);
+      issue(T, 1, 1);
+      issue(T, 2, 2);
+    }
+    float* C = a.C + (a.ztab ? a.zC[f] : f * a.sC) + blockIdx.y * a.sSplit;
+    float es = a.epi ? a.epi_scale : 1.f;
+    const float eb = a.epi ? a.epi_bias : 0.f, ed = a.epi ? a.epi_diag[f & 7] : 0.f;
+    if (a.hdrA) es *= x3_out_scale(a, f);
+    if (m0 + X3_BM <= a.M && n0 + X3N_BN <= a.N && ed == 0.f) {
+      const long ld = a.ldc;
+      float* row = C + (long)(m0 + wm * X3_MT * 32 + 4 * g) * ld + (n0 + wn * X3N_NT * 32 + r);
+#pragma unroll
+      for (int i = 0; i < X3_MT; ++i) {
+#pragma unroll
+        for (int qh = 0; qh < 4; ++qh) {
+          float* p = row + (long)(i * 32 + 8 * qh) * ld;
+#pragma unroll
+          for (int ql = 0; ql < 4; ++ql) {
+#pragma unroll
+            for (int j = 0; j < X3N_NT; ++j) p[j * 32] = fmaf(es, acc[i][j][4 * qh + ql], eb);
+            p += ld;
           }
         }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < X3_MT; ++i)
+#pragma unroll
+        for (int j = 0; j < X3N_NT; ++j)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int rr = (q & 3) + 8 * (q >> 2) + 4 * g;
+            const int m = m0 + (wm * X3_MT + i) * 32 + rr;
+            const int n = n0 + (wn * X3N_NT + j) * 32 + r;
+            if (m < a.M && n < a.N) {
+              float v = acc[i][j][q];
+              if (a.epi || a.hdrA) v = fmaf(es, v, eb) + (m == n ? ed : 0.f);
+              C[(long)m * a.ldc + n] = v;
+            }
+          }
+    }
+    if (!have) break;
+    x = xn;
   }
 #ifdef X3_TIMING
   X3N_STAMP(3);

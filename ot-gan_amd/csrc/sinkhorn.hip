@@ -88,6 +88,10 @@ struct FinishArgs {
   float* K;  // [P][n][m]
 };
 
+// Sum of the K-split partial sums + the cost epilogue.  Round 4: the N = 128 case (128 splits of a 0.39 MB result = 50 MB)
+// ran at 1.5 TB/s with one output and 128 dependent-looking 4-byte loads per thread, 1.5 workgroups per compute unit;
+// now a workgroup owns 256 consecutive float4 outputs... (cost_finish4_kernel below) -- this scalar kernel stays for
+// totals that are not a multiple of 4.
 __global__ void cost_finish_kernel(FinishArgs a) {
   const long per = (long)a.n * a.m;
   const long total = per * a.P;
@@ -104,6 +108,59 @@ __global__ void cost_finish_kernel(FinishArgs a) {
     if (i == j) c += a.diag[p];
     a.K[idx] = -a.lambda * c;
   }
+}
+
+// 64 consecutive float4 outputs per workgroup; its four waves take a quarter of the splits each (8 independent 16-byte
+// loads in flight per lane), partial sums combined through LDS in wave order: a fixed summation order, deterministic.
+// (The sum over splits is grouped differently from the scalar kernel: results differ from it in the last bits.)
+__global__ __launch_bounds__(256) void cost_finish4_kernel(FinishArgs a) {
+  __shared__ f32x4 part[4][64];
+  const long per = (long)a.n * a.m;
+  const long total4 = per * a.P / 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long i4 = (long)blockIdx.x * 64 + lane;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (i4 < total4) {
+    const int s0 = wave * a.nsplit / 4, s1 = (wave + 1) * a.nsplit / 4;
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.ws) + i4;
+    int sp = s0;
+    for (; sp + 8 <= s1; sp += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + (long)(sp + u) * total4);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; sp < s1; ++sp) acc += __builtin_nontemporal_load(src + (long)sp * total4);
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave != 0 || i4 >= total4) return;
+  const f32x4 dot4 = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  f32x4 out;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const long idx = 4 * i4 + e;
+    const int p = (int)(idx / per);
+    const long rem = idx - (long)p * per;
+    const int i = (int)(rem / a.m), j = (int)(rem - (long)i * a.m);
+    float c;
+    if (a.cost_kind == OTGAN_COST_COSINE) c = 1.f - dot4[e];
+    else c = a.xsq[p][i] + a.ysq[p][j] - dot4[e] * a.inv_d;
+    if (i == j) c += a.diag[p];
+    out[e] = -a.lambda * c;
+  }
+  *reinterpret_cast<f32x4*>(a.K + 4 * i4) = out;
+}
+
+static void launch_cost_finish(const FinishArgs& fa, hipStream_t s) {
+  const long total = (long)fa.P * fa.n * fa.m;
+  if (total % 4 == 0 && fa.nsplit >= 4 && (reinterpret_cast<uintptr_t>(fa.ws) & 15) == 0 && (reinterpret_cast<uintptr_t>(fa.K) & 15) == 0) {
+    hipLaunchKernelGGL(cost_finish4_kernel, dim3((unsigned)ceil_div_l(total / 4, 64)), dim3(256), 0, s, fa);
+    return;
+  }
+  const int blocks = (int)(ceil_div_l(total, 256) < 2048 ? ceil_div_l(total, 256) : 2048);
+  hipLaunchKernelGGL(cost_finish_kernel, dim3(blocks), dim3(256), 0, s, fa);
 }
 
 // out[r] = 0.5 * mean_k x[r][k]^2   (toy_example/matching_cpu.py:17)
@@ -830,9 +887,7 @@ int launch_cost_x3(const u16* FP, long plane, long rows_total, const long* xrow,
   fa.ws = partial_ws; fa.nsplit = cp.nsplit; fa.P = P; fa.n = n; fa.m = m;
   fa.lambda = lambda; fa.inv_d = 1.f / (float)D; fa.cost_kind = OTGAN_COST_COSINE; fa.K = K;
   for (int p = 0; p < P; ++p) fa.diag[p] = diag ? diag[p] : 0.f;
-  const long total = (long)P * n * m;
-  const int blocks = (int)(ceil_div_l(total, 256) < 2048 ? ceil_div_l(total, 256) : 2048);
-  hipLaunchKernelGGL(cost_finish_kernel, dim3(blocks), dim3(256), 0, s, fa);
+  launch_cost_finish(fa, s);
   OTGAN_CHECK_LAUNCH("cost_finish_kernel");
   return OTGAN_OK;
 }
@@ -959,9 +1014,7 @@ int launch_cost(const float* const* X, const float* const* Y, const float* const
     fa.ysq[p] = ysq ? ysq[p] : nullptr;
     fa.diag[p] = diag ? diag[p] : 0.f;
   }
-  const long total = (long)P * n * m;
-  const int blocks = (int)(ceil_div_l(total, 256) < 2048 ? ceil_div_l(total, 256) : 2048);
-  hipLaunchKernelGGL(cost_finish_kernel, dim3(blocks), dim3(256), 0, s, fa);
+  launch_cost_finish(fa, s);
   OTGAN_CHECK_LAUNCH("cost_finish_kernel");
   return OTGAN_OK;
 }

@@ -1175,7 +1175,22 @@ bool launch_narrow(const BgArgs& b0, int nsplit, int min_k, hipStream_t s) {
   // (dev knob OTGAN_X3_NARROW_LDS=<bytes>: ask for more LDS than the kernel uses, e.g. 100000 = one workgroup per CU)
   static const size_t lds = [] { const char* e = getenv("OTGAN_X3_NARROW_LDS"); const size_t v = e ? (size_t)atol(e) : 0; return v > X3N_LDS ? v : X3N_LDS; }();
   ensure_lds<wino_bgemm_x3n_kernel<TL>>(lds);
-  hipLaunchKernelGGL((wino_bgemm_x3n_kernel<TL>), dim3(gx, nsplit, 1), dim3(X3_THREADS), lds, s, b);
+  // round 4: OTGAN_X3_PERSIST=1 caps the grid at the resident workgroups (two per compute unit) when there are more queue
+  // positions and no K splits: a workgroup then walks several tiles and starts the next one's operand stream before it
+  // writes the current one out (gemm_x3.h).  Measured on the DCGAN step, same box, A/B/A/B: 9.235 / 9.286 ms with one tile per
+  // workgroup against 9.358 / 9.377 ms capped (GEMM launches 0.243 -> 0.250 ms) -- the hardware dispatcher's dynamic
+  // placement of short workgroups beats a static walk, as it did for the 256 x 256 stream-K kernel: default off.
+  static const int persist = [] { const char* e = getenv("OTGAN_X3_PERSIST"); return e ? atoi(e) : 0; }();
+  static const unsigned resident = [] {
+    int dev = 0, cus = 256;
+    hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    return (unsigned)(2 * cus) & ~7u;
+  }();
+  b.x_total = gx;
+  unsigned grid_x = gx;
+  if (persist && nsplit == 1 && gx > resident && resident >= 8) grid_x = resident;
+  hipLaunchKernelGGL((wino_bgemm_x3n_kernel<TL>), dim3(grid_x, nsplit, 1), dim3(X3_THREADS), lds, s, b);
   return true;
 }
 #else
