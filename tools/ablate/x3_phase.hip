@@ -167,6 +167,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&ndbg, (size_t)ngrid * 64 * 8));
     CK(hipMemset(ndbg, 0, (size_t)ngrid * 64 * 8));
     c.dbg = ndbg;
+    c.x_total = ngrid;        // (round 4: the kernel walks queue positions up to x_total)
     const size_t nlds = X3N_LDS + 512;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_bgemm_x3n_kernel<false>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)nlds));
