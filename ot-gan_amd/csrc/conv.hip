@@ -175,6 +175,12 @@ struct ConvALoader {
     }
   }
 
+  // vector path: start at channel offset d0 (a multiple of BK) instead of 0 -- the K split of the forward pass
+  __device__ __forceinline__ void seek(int d0) {
+    nd = d0;
+    nt = 0;
+    cm_next = (VEC && g.cmap && d0 + 4 * (threadIdx.x % CPR) < g.Ck) ? g.cmap[d0 + 4 * (threadIdx.x % CPR)] : 0;
+  }
   // issue the loads of K tile kt (tiles are requested in order 0, 1, 2, ...)
   __device__ __forceinline__ void load(int kt) {
     const int c4 = threadIdx.x % CPR;
@@ -349,6 +355,10 @@ struct ConvBLoader {
     }
   }
 
+  __device__ __forceinline__ void seek(int d0) {
+    nd = d0;
+    nt = 0;
+  }
   __device__ __forceinline__ void load(int kt) {
     const int c4 = threadIdx.x % CPR;
     if (VEC) {
@@ -447,6 +457,11 @@ struct EpiArgs {
   const float* amax_b;
   int floor_one;
   float* amax_out;       // fwd: amax record of the values written (otgan_conv_desc::y_amax_out), or null
+  // fwd, vector path, one class, so == 1 (round 4): K split over channel slices -- blockIdx.z = split, the workgroup takes
+  // slices [split * per, ...) of every tap and writes its sums to partial[split][m][col]; igemm_splitk_finish_kernel adds
+  // them up, with bias and amax record.  0 / 1: no split.
+  int ksplit;
+  float* partial;
 };
 
 // XS: 0 fp32 MFMA, 1 three bf16 pieces (six MFMAs per product), 2 two scaled fp16 pieces (three)
@@ -458,7 +473,8 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Cla
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int m0 = blockIdx.x * Cfg::BM;
   const int nblk = blockIdx.y;
-  const int cls = blockIdx.z;
+  const bool ksplit = VEC && EPI == EPI_FWD && e.ksplit > 1;
+  const int cls = ksplit ? 0 : blockIdx.z;
   const Taps& taps = ct.taps[cls];
   LA la(g, taps);
   LB lb(wb, taps, wb.w + ct.woff[cls]);
@@ -466,7 +482,16 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Cla
   lb.init(nblk);
   typename Cfg::acc_t acc[Cfg::MT][Cfg::NT];
   zero_acc<Cfg>(acc);
-  const int nkt = VEC ? taps.n * ((g.Ck + Cfg::BK - 1) / Cfg::BK) : (taps.n * g.Ck + Cfg::BK - 1) / Cfg::BK;
+  int nkt = VEC ? taps.n * ((g.Ck + Cfg::BK - 1) / Cfg::BK) : (taps.n * g.Ck + Cfg::BK - 1) / Cfg::BK;
+  if (ksplit) {
+    const int nsl = (g.Ck + Cfg::BK - 1) / Cfg::BK, per = (nsl + e.ksplit - 1) / e.ksplit;
+    const int s0 = blockIdx.z * per;
+    int s1 = s0 + per;
+    if (s1 > nsl) s1 = nsl;
+    nkt = s1 > s0 ? taps.n * (s1 - s0) : 0;
+    la.seek(s0 * Cfg::BK);
+    lb.seek(s0 * Cfg::BK);
+  }
   float descale = 1.f;
   if constexpr (XS == 2) {
     float aA = amax_record_value(e.amax_a);
@@ -517,6 +542,10 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Cla
           const int col = nblk * Cfg::BN + (wn * Cfg::NT + nt) * Cfg::TS + lcol;
           if (col >= e.ncols) continue;
           float v = acc[mt][nt][r] * descale;
+          if (EPI == EPI_FWD && ksplit) {
+            e.partial[((long)blockIdx.z * g.Mtot + m) * e.ncols + col] = v;
+            continue;
+          }
           if (EPI == EPI_FWD) {
             v += e.bias ? e.bias[col] : 0.f;
             { const unsigned b_ = amax_bits(v); omax = b_ > omax ? b_ : omax; }
@@ -531,8 +560,28 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Cla
     }
   }
   if constexpr (EPI == EPI_FWD) {
-    if (e.amax_out) amax_commit(e.amax_out, omax);   // (every thread of the workgroup reaches this point)
+    if (e.amax_out && !ksplit) amax_commit(e.amax_out, omax);   // (every thread of the workgroup reaches this point)
   }
+}
+
+// out[m][coff + col] = bias[col] + sum over the K splits of partial[split][m][col]  (fixed order: deterministic), float4
+// along the columns; the amax record of the values written
+__global__ __launch_bounds__(256) void igemm_splitk_finish_kernel(const float* __restrict__ partial, int nsplit, long M, int ncols,
+                                                                  const float* __restrict__ bias, float* __restrict__ out, int ldo,
+                                                                  int coff, float* amax) {
+  const int c4n = ncols >> 2;
+  const long total = M * c4n;
+  unsigned mb = 0u;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long m = i / c4n;
+    const int c = (int)(i - m * c4n) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(partial + m * ncols + c);
+    for (int sp = 1; sp < nsplit; ++sp) v += *reinterpret_cast<const f32x4*>(partial + ((long)sp * M + m) * ncols + c);
+    if (bias) v += *reinterpret_cast<const f32x4*>(bias + c);
+    *reinterpret_cast<f32x4*>(out + m * ldo + coff + c) = v;
+    mb = amax_bits4(v, mb);
+  }
+  if (amax) amax_commit(amax, mb);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2621,6 +2670,23 @@ int otgan_conv2d_fold_weights_f32(const otgan_conv_desc* d, const float* w, floa
   return OTGAN_OK;
 }
 
+// K splits of the generic forward pass (0 / 1 = none): vector path on the 64 x 128 split-precision tile with fewer than
+// 256 tiles, at least 16 channel slices per split, plain output grid (no upsample / fold), columns a multiple of 4
+static int igemm_fwd_ksplit(const otgan_conv_desc* d, const Geo& g, bool vec, long Mtot) {
+  static const bool off = [] { const char* v = getenv("OTGAN_IGEMM_KSPLIT"); return v && v[0] == '0'; }();
+  if (off || !vec || g.fold || d->upsample || d->Cout % 4 || d->ldy % 4 || d->y_coff % 4 || g.Ceff % 4 || !igemm_x3s()) return 1;
+  if (d->Cout <= 32 || (d->Cout > 128 && d->Cout <= 160) || (d->Cout > 192 && d->Cout <= 224 && ceil_div((int)Mtot, 128) >= 256)) return 1;
+  const long tiles128 = (long)ceil_div((int)Mtot, 128) * ceil_div(d->Cout, 128);
+  if (tiles128 >= 512) return 1;                         // (CfgMain16: enough tiles)
+  const long tiles = (long)ceil_div((int)Mtot, 64) * ceil_div(d->Cout, 128);
+  if (tiles >= 256) return 1;
+  const int nsl = ceil_div(g.Ceff, 16);
+  int ks = (int)(512 / tiles);
+  if (ks > nsl / 16) ks = nsl / 16;
+  if (ks > 8) ks = 8;
+  return ks < 2 ? 1 : ks;
+}
+
 size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which) {
   Geo g;
   if (make_geo(d, &g) != OTGAN_OK) return 0;
@@ -2655,7 +2721,14 @@ size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which) {
     const size_t gen = align_up(sizeof(float) * slabs, 256) + 256;
     return gen > s2 ? gen : s2;
   }
-  return s2 > recs ? s2 : recs;
+  size_t gen = recs;
+  if (which == 0) {   // K-split partial sums of a few-tile forward pass behind the scratch records
+    const bool vec = map_quads(d) && (g.Ceff % 16 == 0) && (d->ldx % 4 == 0);
+    const long Mtot = (long)d->N * g.OH * g.OW;
+    const int ks = igemm_fwd_ksplit(d, g, vec, Mtot);
+    if (ks > 1) gen = align_up(recs, 256) + sizeof(float) * (size_t)ks * Mtot * d->Cout;
+  }
+  return s2 > gen ? s2 : gen;
 }
 
 // growth layer that the two-scaled-fp16-piece kernel takes (given filters and an x_amax record)
@@ -3040,6 +3113,26 @@ static int conv2d_fwd_body(const otgan_conv_desc* d, const float* x, const int32
     igemm_records(e, d->x_amax, x, (long)d->N * d->H * d->W, d->C, d->ldx, d->w_amax, wT, (long)Ktot * d->Cout, act == 2,
                   workspace, workspace_bytes, 0, s);
   e.amax_out = d->y_amax_out;
+  // K split of few-tile forward passes (round 4: the 8 x 8 -> 4 x 4 DenseNet transition is 128 tiles of 64 x 128 with
+  // K = 8208 -- one tile per second compute unit, 472 us at 9 % of the matrix pipe): channel slices over blockIdx.z,
+  // partial sums behind the amax scratch records in the workspace, a float4 finish kernel with bias and amax record
+  const int ks = igemm_fwd_ksplit(d, g, vec, ga.Mtot);
+  if (ks > 1) {
+    const size_t at = align_up(256 + 2 * sizeof(float) * OTGAN_AMAX_RECORD_FLOATS, 256);
+    const size_t need = at + sizeof(float) * (size_t)ks * ga.Mtot * d->Cout;
+    if (workspace && workspace_bytes >= need && aligned16(workspace) && aligned16(y) && aligned16(bias)) {
+      e.ksplit = ks;
+      e.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + at);
+      launch_fwd(act, vec, g.Ceff, ga.Mtot, d->Cout, ks, s, ga, ct, wb, e);
+      const long total4 = (long)ga.Mtot * (d->Cout / 4);
+      const int blocks = (int)(ceil_div_l(total4, 256) < 2048 ? ceil_div_l(total4, 256) : 2048);
+      hipLaunchKernelGGL(igemm_splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, e.partial, ks, (long)ga.Mtot, d->Cout, bias, y,
+                         d->ldy, d->y_coff, d->y_amax_out);
+      g_amax_written = d->y_amax_out != nullptr;
+      OTGAN_CHECK_LAUNCH("conv2d fwd (K split)");
+      return OTGAN_OK;
+    }
+  }
   launch_fwd(act, vec, g.Ceff, ga.Mtot, d->Cout, 1, s, ga, ct, wb, e);
   g_amax_written = e.amax_out != nullptr;
   OTGAN_CHECK_LAUNCH("conv2d fwd");
