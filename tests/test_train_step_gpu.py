@@ -288,7 +288,9 @@ def test_well_conditioned_step_gradients(dev, model, size, kind):
     to a MORE accurate kernel -- moved them to other seeds).  With the same sign pattern on both sides the comparison
     measures arithmetic and nothing else; one un-forced seed per case stays, bounded at the flipped-unit level."""
     tol = _WELL_TOL[(model, size, kind)]
-    worst = [_well_conditioned_worst(dev, model, size, kind, seed, same_head_signs=True) for seed in (5, 6, 7)]
+    # (three seeds at 32 x 32 DCGAN, two for the cases whose fp64 CPU oracle takes 10+ s per seed: the GPU suite has a budget)
+    seeds = (5, 6, 7) if (model, size) == ("dcgan", 32) else (5, 6)
+    worst = [_well_conditioned_worst(dev, model, size, kind, seed, same_head_signs=True) for seed in seeds]
     print(f"\nwell-conditioned {model} {size} {kind}: worst tensor per seed " + ", ".join(f"{w[0]:.2e} ({w[1]})" for w in worst))
     assert max(w[0] for w in worst) < tol, worst
     free = _well_conditioned_worst(dev, model, size, kind, 5)
