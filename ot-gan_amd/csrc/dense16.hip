@@ -1553,6 +1553,14 @@ int dense16_fwd(const Dense16Geo& g, const float* x, const float* wT, const floa
   return OTGAN_OK;
 }
 
+// pixel tiles of 16 per wave (workgroup = 64 PT pixels = full rows) of the fp16 x 2 growth kernels; dev knob
+// OTGAN_DENSE16_H2_PTMAX caps it (2: half-height tiles, three workgroups per compute unit at 32 x 32)
+static int h2_pt(int N, int H, int W) {
+  static const int cap = [] { const char* e = getenv("OTGAN_DENSE16_H2_PTMAX"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
+  int PT = H * W >= 256 ? 4 : H * W / 64;
+  while (PT > 1 && ((long)N * H * W / (64 * PT) < 512 || PT > cap)) PT >>= 1;
+  return PT;
+}
 size_t dense16_h2_filter_bytes(int nsl) { return nsl > 0 ? (size_t)kH2HdrBytes + (size_t)nsl * kH2SliceU16 * 2 : 0; }
 
 bool dense16_h2_shape_ok(int N, int H, int W) {
@@ -1561,8 +1569,7 @@ bool dense16_h2_shape_ok(int N, int H, int W) {
     return !(e && e[0] == '0');
   }();
   if (!on || !(W == 8 || W == 16 || W == 32) || H * W < 64) return false;
-  int PT = H * W >= 256 ? 4 : H * W / 64;
-  while (PT > 1 && (long)N * H * W / (64 * PT) < 512) PT >>= 1;
+  const int PT = h2_pt(N, H, W);
   const int TR = 64 * PT / W;
   return TR >= 1 && H % TR == 0;
 }
@@ -1577,8 +1584,7 @@ int dense16_h2_prepare(const float* const* wT, const int* nsl, void* const* out,
 
 int dense16_fwd_h2(int N, int H, int W, int nsl, const float* x, int ldx, const void* wq, const float* rec, int nrec,
                    float* y, int ldy, int coff, hipStream_t s, float* amax_out) {
-  int PT = H * W >= 256 ? 4 : H * W / 64;
-  while (PT > 1 && (long)N * H * W / (64 * PT) < 512) PT >>= 1;
+  const int PT = h2_pt(N, H, W);
   FwdH2Args a;
   a.x = x; a.wq = (const unsigned char*)wq; a.y = y; a.rec = rec; a.nrec = nrec; a.nsl = nsl;
   a.N = N; a.H = H; a.W = W; a.logW = ilog2i(W); a.ldx = ldx; a.ldy = ldy; a.coff = coff;
@@ -1623,8 +1629,7 @@ int dense16_h2_bwd_prepare(const Dense16BwdPair* pairs, int npairs, const void* 
 
 int dense16_bwd_h2(int N, int H, int W, int nsl, const float* g, int ldg, const void* wq, const float* x, int ldx, float* dx,
                    const float* rec0, int nrec0, const float* rec1, int nrec1, hipStream_t s, float* amax_out) {
-  int PT = H * W >= 256 ? 4 : H * W / 64;
-  while (PT > 1 && (long)N * H * W / (64 * PT) < 512) PT >>= 1;
+  const int PT = h2_pt(N, H, W);
   BwdH2Args a;
   a.g = g; a.wq = (const unsigned char*)wq; a.x = x; a.dx = dx;
   a.rec0 = rec0; a.rec1 = rec1 ? rec1 : rec0; a.nrec0 = nrec0; a.nrec1 = rec1 ? nrec1 : 0; a.nsl = nsl;
