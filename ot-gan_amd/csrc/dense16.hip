@@ -708,18 +708,23 @@ __global__ __launch_bounds__(1024) void dense16_h2_prep_kernel(H2PrepArgs a) {
   }
 }
 
-template <int PT, bool W8>
+template <int PT, int WW>
 __global__ __launch_bounds__(256, 2) void dense16_fwd_h2_kernel(FwdH2Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smemh[];
   __shared__ float s_sc[2];
   constexpr int NIT = PT + 1;
   constexpr int WBYTES = kH2SliceU16 * 2;                    // prepared weights of one slice: 20 steps x 1 KiB
+  // the image width is a template parameter: tile rows, LDS row stride and plane size are then compile-time constants and the
+  // plane / piece / tile offsets of the fragment reads fold into the ds_read immediates (one address add per tap pair
+  // instead of one per read: 100 -> 10 per slice)
+  constexpr bool W8 = WW == 8;
+  constexpr int TR = 64 * PT / WW, RS = WW == 8 ? 16 : WW + 2, LOGW = WW == 8 ? 3 : WW == 16 ? 4 : 5;
+  constexpr int PLANE = (TR + 2) * RS * 32;                 // bytes of one (sign, piece) plane
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = lane & 15, g = lane >> 4;
-  const int tiles_per_img = a.H / a.TR;
+  const int tiles_per_img = a.H / TR;
   const int n = blockIdx.x / tiles_per_img;
-  const int r0 = (blockIdx.x - n * tiles_per_img) * a.TR;
-  const int PLANE = (a.TR + 2) * a.RS * 32;                 // bytes of one (sign, piece) plane
+  const int r0 = (blockIdx.x - n * tiles_per_img) * TR;
   unsigned char* const smw = smemh + 4 * PLANE;             // the slice's weights behind the four planes
   for (int i = tid; i < 4 * PLANE / 16; i += 256) reinterpret_cast<u32x4*>(smemh)[i] = u32x4{0u, 0u, 0u, 0u};
   // input scale: the maximum of the records' sub-slots (bit patterns of non-negative floats: unsigned order)
@@ -743,8 +748,8 @@ __global__ __launch_bounds__(256, 2) void dense16_fwd_h2_kernel(FwdH2Args a) {
     }
   }
   const int slot = tid & 3;
-  const int total = (a.TR + 2) * a.W * 4;
-  const long img_base = (long)n * a.H * a.W;
+  const int total = (TR + 2) * WW * 4;
+  const long img_base = (long)n * a.H * WW;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   // staging items of this thread: (pixel of the (TR + 2) x W band, quad of 4 channels); source offset (floats, slice 0;
   // negative: outside the image or the band) and LDS byte offset, computed once
@@ -754,11 +759,11 @@ __global__ __launch_bounds__(256, 2) void dense16_fwd_h2_kernel(FwdH2Args a) {
   for (int it = 0; it < NIT; ++it) {
     const int i = it * 256 + tid;
     const int px = i >> 2;
-    const int row = px >> a.logW, col = px & (a.W - 1);
+    const int row = px >> LOGW, col = px & (WW - 1);
     const int ir = r0 - 1 + row;
     const bool ok = i < total && (unsigned)ir < (unsigned)a.H;
-    xoff[it] = ok ? (img_base + (long)ir * a.W + col) * a.ldx + 4 * slot : -1;
-    loff[it] = i < total ? (row * a.RS + col + 1) * 32 + slot * 8 : -1;
+    xoff[it] = ok ? (img_base + (long)ir * WW + col) * a.ldx + 4 * slot : -1;
+    loff[it] = i < total ? (row * RS + col + 1) * 32 + slot * 8 : -1;
   }
   f32x4 R[NIT];
   u32x4 WR[5];
@@ -807,10 +812,10 @@ __global__ __launch_bounds__(256, 2) void dense16_fwd_h2_kernel(FwdH2Args a) {
       rr = (q0 >> 3) + (p >> 3);
       cc = p & 7;
     } else {
-      rr = q0 >> a.logW;
-      cc = (q0 & (a.W - 1)) + p;
+      rr = q0 >> LOGW;
+      cc = (q0 & (WW - 1)) + p;
     }
-    ab[t] = ((rr + 1) * a.RS + cc + 1) * 32 + 16 * (g & 1);
+    ab[t] = ((rr + 1) * RS + cc + 1) * 32 + 16 * (g & 1);
   }
   f32x4 acc[PT];
 #pragma unroll
@@ -826,7 +831,7 @@ __global__ __launch_bounds__(256, 2) void dense16_fwd_h2_kernel(FwdH2Args a) {
   const float sx = s_sc[0];
   stage_store(sx);
   __syncthreads();
-  const long m0 = (img_base + (long)r0 * a.W);
+  const long m0 = (img_base + (long)r0 * WW);
   float yv[PT][4];
   for (int sl = 0; sl < a.nsl; ++sl) {
     const bool more = sl + 1 < a.nsl;
@@ -846,8 +851,8 @@ __global__ __launch_bounds__(256, 2) void dense16_fwd_h2_kernel(FwdH2Args a) {
       const d16_h8 Bh = *reinterpret_cast<const d16_h8*>(smw + st * 2048 + lane * 16);
       const d16_h8 Bl = *reinterpret_cast<const d16_h8*>(smw + st * 2048 + 1024 + lane * 16);
       const int t0 = 2 * tp, t1 = (2 * tp + 1 < 9) ? 2 * tp + 1 : 8;    // (the ninth tap's partner: tap 8 against zero weights)
-      const int sh0 = ((t0 / 3 - 1) * a.RS + (t0 % 3 - 1)) * 32;
-      const int sh1 = ((t1 / 3 - 1) * a.RS + (t1 % 3 - 1)) * 32;
+      const int sh0 = ((t0 / 3 - 1) * RS + (t0 % 3 - 1)) * 32;
+      const int sh1 = ((t1 / 3 - 1) * RS + (t1 % 3 - 1)) * 32;
       const int sh = hiTap ? sh1 : sh0;
       d16_h8 Ah[PT], Al[PT];
 #pragma unroll
@@ -953,18 +958,23 @@ __global__ __launch_bounds__(256) void dense16_h2_bwd_prep_kernel(H2BwdPrepArgs 
   }
 }
 
-template <int PT, bool W8>
+template <int PT, int WW>
 __global__ __launch_bounds__(256, 2) void dense16_bwd_h2_kernel(BwdH2Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smemh[];
   __shared__ float s_sc[2];
   constexpr int NIT = PT + 1;
   constexpr int WBYTES = kH2SliceU16 * 2;
+  // the image width is a template parameter: tile rows, LDS row stride and plane size are then compile-time constants and the
+  // plane / piece / tile offsets of the fragment reads fold into the ds_read immediates (one address add per tap pair
+  // instead of one per read: 100 -> 10 per slice)
+  constexpr bool W8 = WW == 8;
+  constexpr int TR = 64 * PT / WW, RS = WW == 8 ? 16 : WW + 2, LOGW = WW == 8 ? 3 : WW == 16 ? 4 : 5;
+  constexpr int PLANE = (TR + 2) * RS * 32;                 // bytes of one (sign, piece) plane
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = lane & 15, g = lane >> 4;
-  const int tiles_per_img = a.H / a.TR;
+  const int tiles_per_img = a.H / TR;
   const int n = blockIdx.x / tiles_per_img;
-  const int r0 = (blockIdx.x - n * tiles_per_img) * a.TR;
-  const int PLANE = (a.TR + 2) * a.RS * 32;
+  const int r0 = (blockIdx.x - n * tiles_per_img) * TR;
   unsigned char* const smw = smemh + 2 * PLANE;
   for (int i = tid; i < 2 * PLANE / 16; i += 256) reinterpret_cast<u32x4*>(smemh)[i] = u32x4{0u, 0u, 0u, 0u};
   if (wave == 0) {
@@ -990,8 +1000,8 @@ __global__ __launch_bounds__(256, 2) void dense16_bwd_h2_kernel(BwdH2Args a) {
     }
   }
   const int slot = tid & 3;
-  const int total = (a.TR + 2) * a.W * 4;
-  const long img_base = (long)n * a.H * a.W;
+  const int total = (TR + 2) * WW * 4;
+  const long img_base = (long)n * a.H * WW;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   long goff[NIT];
   int loff[NIT];
@@ -999,11 +1009,11 @@ __global__ __launch_bounds__(256, 2) void dense16_bwd_h2_kernel(BwdH2Args a) {
   for (int it = 0; it < NIT; ++it) {
     const int i = it * 256 + tid;
     const int px = i >> 2;
-    const int row = px >> a.logW, col = px & (a.W - 1);
+    const int row = px >> LOGW, col = px & (WW - 1);
     const int ir = r0 - 1 + row;
     const bool ok = i < total && (unsigned)ir < (unsigned)a.H;
-    goff[it] = ok ? (img_base + (long)ir * a.W + col) * a.ldg + 4 * slot : -1;
-    loff[it] = i < total ? (row * a.RS + col + 1) * 32 + slot * 8 : -1;
+    goff[it] = ok ? (img_base + (long)ir * WW + col) * a.ldg + 4 * slot : -1;
+    loff[it] = i < total ? (row * RS + col + 1) * 32 + slot * 8 : -1;
   }
   f32x4 R[NIT];
   u32x4 WR[5];
@@ -1044,10 +1054,10 @@ __global__ __launch_bounds__(256, 2) void dense16_bwd_h2_kernel(BwdH2Args a) {
       rr = (q0 >> 3) + (p >> 3);
       cc = p & 7;
     } else {
-      rr = q0 >> a.logW;
-      cc = (q0 & (a.W - 1)) + p;
+      rr = q0 >> LOGW;
+      cc = (q0 & (WW - 1)) + p;
     }
-    ab[t] = ((rr + 1) * a.RS + cc + 1) * 32 + 16 * (g & 1);
+    ab[t] = ((rr + 1) * RS + cc + 1) * 32 + 16 * (g & 1);
   }
   f32x4 acc[2][PT];
 #pragma unroll
@@ -1058,7 +1068,7 @@ __global__ __launch_bounds__(256, 2) void dense16_bwd_h2_kernel(BwdH2Args a) {
   const float sd = s_sc[0];
   stage_store(sd);
   __syncthreads();
-  const long m0 = (img_base + (long)r0 * a.W);
+  const long m0 = (img_base + (long)r0 * WW);
   float xv[PT][4], old[PT][4];
   for (int sl = 0; sl < a.nsl; ++sl) {
     const bool more = sl + 1 < a.nsl;
@@ -1081,8 +1091,8 @@ __global__ __launch_bounds__(256, 2) void dense16_bwd_h2_kernel(BwdH2Args a) {
       const d16_h8 Bhn = *reinterpret_cast<const d16_h8*>(smw + (5 + tp) * 2048 + lane * 16);
       const d16_h8 Bln = *reinterpret_cast<const d16_h8*>(smw + (5 + tp) * 2048 + 1024 + lane * 16);
       const int t0 = 2 * tp, t1 = (2 * tp + 1 < 9) ? 2 * tp + 1 : 8;
-      const int sh0 = ((t0 / 3 - 1) * a.RS + (t0 % 3 - 1)) * 32;
-      const int sh1 = ((t1 / 3 - 1) * a.RS + (t1 % 3 - 1)) * 32;
+      const int sh0 = ((t0 / 3 - 1) * RS + (t0 % 3 - 1)) * 32;
+      const int sh1 = ((t1 / 3 - 1) * RS + (t1 % 3 - 1)) * 32;
       const int sh = hiTap ? sh1 : sh0;
       d16_h8 Ah[PT], Al[PT];
 #pragma unroll
@@ -1571,7 +1581,7 @@ bool dense16_h2_shape_ok(int N, int H, int W) {
   if (!on || !(W == 8 || W == 16 || W == 32) || H * W < 64) return false;
   const int PT = h2_pt(N, H, W);
   const int TR = 64 * PT / W;
-  return TR >= 1 && H % TR == 0;
+  return TR >= 1 && H % TR == 0 && (W != 8 || PT == 1);   // (8-wide images: only the one-tile instantiation exists)
 }
 
 int dense16_h2_prepare(const float* const* wT, const int* nsl, void* const* out, int count, hipStream_t s) {
@@ -1594,14 +1604,11 @@ int dense16_fwd_h2(int N, int H, int W, int nsl, const float* x, int ldx, const 
   const size_t lds = (size_t)4 * (a.TR + 2) * a.RS * 32 + (size_t)kH2SliceU16 * 2;
   const dim3 grid(N * (H / a.TR)), blk(256);
   const bool w8 = W == 8;
-#define D16_H2(PT_)                                                                                  \
-  do {                                                                                               \
-    if (w8) hipLaunchKernelGGL((dense16_fwd_h2_kernel<PT_, true>), grid, blk, lds, s, a);            \
-    else hipLaunchKernelGGL((dense16_fwd_h2_kernel<PT_, false>), grid, blk, lds, s, a);              \
-  } while (0)
-  if (PT == 4) D16_H2(4);
-  else if (PT == 2) D16_H2(2);
-  else D16_H2(1);
+#define D16_H2(PT_, W_) hipLaunchKernelGGL((dense16_fwd_h2_kernel<PT_, W_>), grid, blk, lds, s, a)
+  (void)w8;
+  if (W == 32) { if (PT == 4) D16_H2(4, 32); else if (PT == 2) D16_H2(2, 32); else D16_H2(1, 32); }
+  else if (W == 16) { if (PT == 4) D16_H2(4, 16); else if (PT == 2) D16_H2(2, 16); else D16_H2(1, 16); }
+  else D16_H2(1, 8);
 #undef D16_H2
   return OTGAN_OK;
 }
@@ -1640,14 +1647,11 @@ int dense16_bwd_h2(int N, int H, int W, int nsl, const float* g, int ldg, const 
   const size_t lds = (size_t)2 * (a.TR + 2) * a.RS * 32 + (size_t)kH2SliceU16 * 2;
   const dim3 grid(N * (H / a.TR)), blk(256);
   const bool w8 = W == 8;
-#define D16_B2(PT_)                                                                                  \
-  do {                                                                                               \
-    if (w8) hipLaunchKernelGGL((dense16_bwd_h2_kernel<PT_, true>), grid, blk, lds, s, a);            \
-    else hipLaunchKernelGGL((dense16_bwd_h2_kernel<PT_, false>), grid, blk, lds, s, a);              \
-  } while (0)
-  if (PT == 4) D16_B2(4);
-  else if (PT == 2) D16_B2(2);
-  else D16_B2(1);
+#define D16_B2(PT_, W_) hipLaunchKernelGGL((dense16_bwd_h2_kernel<PT_, W_>), grid, blk, lds, s, a)
+  (void)w8;
+  if (W == 32) { if (PT == 4) D16_B2(4, 32); else if (PT == 2) D16_B2(2, 32); else D16_B2(1, 32); }
+  else if (W == 16) { if (PT == 4) D16_B2(4, 16); else if (PT == 2) D16_B2(2, 16); else D16_B2(1, 16); }
+  else D16_B2(1, 8);
 #undef D16_B2
   return OTGAN_OK;
 }
