@@ -339,8 +339,8 @@ def main():
                                      if a.model == "dcgan" and os.environ.get("OTGAN_WINO_FP32") != "1"
                                      else "fp32 MFMA" + ("; dense blocks are cut into wide 3x3 convolutions of finished channel "
                                                          "groups (Winograd F(4x4,3x3) GEMMs on two scaled fp16 pieces, as in the "
-                                                         "DCGAN configuration) + short 16-output growth chains whose 32x32 forward "
-                                                         "uses a three-way bf16 split (fp32-exact products), dgrad / wgrad the fp32 MFMA engine; the "
+                                                         "DCGAN configuration) + short 16-output growth chains whose forward and input gradient "
+                                                         "(gathered per slice) run on two scaled fp16 pieces too (round 4), the chain weight gradient on the fp32 MFMA engine; the "
                                                          "stride-2 / upsampling transitions are implicit GEMMs on two scaled fp16 pieces" if a.model == "densenet" else "")},
     }
     if prof:
