@@ -43,7 +43,7 @@ def _run_steps(model, x, u):
     return out
 
 
-def _worker(rank, world, port, path):
+def _worker(rank, world, port, path, single_batch=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK="0")
     from otgan_amd import parallel
@@ -52,7 +52,7 @@ def _worker(rank, world, port, path):
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     args = default_args(model="dcgan", batch_size=B, nr_gpu=2, sinkhorn_lambda=LAM, nr_sinkhorn_iter=ITERS,
-                        nr_gen_per_disc=1, seed=5, matching_scope="global")
+                        nr_gen_per_disc=1, seed=5, matching_scope="global", single_batch=single_batch)
     m = OTGAN(args, dev)
     assert m.shards == 1 and m.scope == "global"
     x, u = _data()
@@ -64,13 +64,16 @@ def _worker(rank, world, port, path):
     torch.distributed.destroy_process_group()
 
 
-def test_two_ranks_equal_single_process():
+@pytest.mark.parametrize("single_batch", [False, True], ids=["two_batch", "single_batch"])
+def test_two_ranks_equal_single_process(single_batch):
+    """single_batch (round 4): the global scope shards the three cost GEMMs over the ranks like the reference's towers
+    (utils/matching.py:99-104) and applies the plans to the rank's rows only (otgan_matching_single_batch_rows_grad_f32)."""
     assert torch.cuda.is_available()
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "r0.pt")
         port = _free_port()
         ctx = mp.get_context("spawn")
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, path)) for r in range(2)]
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, path, single_batch)) for r in range(2)]
         for p in procs:
             p.start()
         for p in procs:
@@ -80,7 +83,7 @@ def test_two_ranks_equal_single_process():
     from otgan_amd.trainer import OTGAN, default_args
     dev = torch.device("cuda:0")
     args = default_args(model="dcgan", batch_size=B, nr_gpu=2, sinkhorn_lambda=LAM, nr_sinkhorn_iter=ITERS,
-                        nr_gen_per_disc=1, seed=5)
+                        nr_gen_per_disc=1, seed=5, single_batch=single_batch)
     m = OTGAN(args, dev)          # world 1: both shards local
     x, u = _data()
     ref = _run_steps(m, x.to(dev), u.to(dev))
