@@ -684,6 +684,51 @@ __global__ __launch_bounds__(256) void wino_filter_adj_kernel(const float* __res
 }
 
 
+// The same with the un-folding of a 5 x 5 'SAME' upsampling layer in the same pass (round 4): dw[kh][kw][ci][co] = sum over
+// the four output-parity classes of (G^T dU G)[th(ph, kh)][tw(pw, kw)] -- conv.hip's unfold_wgrad_kernel, whose read of
+// dweff (36 / 25 of the weight bytes) and launch disappear.  Class order and start value as there: bit-identical.
+__global__ __launch_bounds__(256) void wino_filter_adj_unfold5_kernel(const float* __restrict__ slabs, int nsplit,
+                                                                    long split_stride, int Cin, int Cout,
+                                                                    float* __restrict__ dw) {
+  const int c4n = Cout >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)Cin * c4n) return;
+  const int co = (int)(idx % c4n) * 4;
+  const int ci = (int)(idx / c4n);
+  const long ldu = 4L * Cout, fs = (long)Cin * ldu;
+  // tap of the 3 x 3 class filter that filter row / column k folds into: floor((p + k - 2) / 2) - its minimum
+  constexpr int TH[2][5] = {{0, 0, 1, 1, 2}, {0, 1, 1, 2, 2}};
+  f32x4 acc[5][5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int cls = 0; cls < 4; ++cls) {
+    const float* src = slabs + (long)ci * ldu + (long)cls * Cout + co;
+    f32x4 dg[3][3];
+    tf_filter_adj(
+        [&](int j, f32x4(&u)[WA]) {
+#pragma unroll
+          for (int i = 0; i < WA; ++i) {
+            f32x4 sv = ld4(src + (i * WA + j) * fs);
+            for (int k = 1; k < nsplit; ++k) sv += ld4(src + k * split_stride + (i * WA + j) * fs);
+            u[i] = sv;
+          }
+        },
+        dg);
+#pragma unroll
+    for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 5; ++kw) acc[kh][kw] += dg[TH[cls >> 1][kh]][TH[cls & 1][kw]];
+  }
+  float* dst = dw + (long)ci * Cout + co;
+#pragma unroll
+  for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 5; ++kw) st4(dst + (long)(kh * 5 + kw) * Cin * Cout, acc[kh][kw]);
+}
+
 // ---- 5x5 stride-2 layers as four stride-1 3x3 sub-convolutions ------------------------------
 // Input row 2a + kh - 1 of output row a: kh = 0,2,4 read the ODD input rows at sub-image offsets
 // -1,0,+1, kh = 1,3 the EVEN rows at offsets 0,+1.  With the 2-tap windows zero-padded to three
@@ -1592,7 +1637,7 @@ int wino_dgrad(const WinoGeo& g, const float* dy, const float* weff, long cls_st
 }
 
 int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, long cls_stride, float* ws,
-               hipStream_t s) {
+               hipStream_t s, float* dw_unfolded5) {
   const long T = wino_tiles(g);
   const int N4 = 4 * g.Cout;
   if (use_x3_wgrad_tl() && T % 32 == 0 && g.Cin % 32 == 0 && N4 % 32 == 0) {
@@ -1629,8 +1674,12 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
     b.kt_per_split = (int)((T / X3_BK + ns - 1) / ns);
     b.sk_partial = x3_stream_area(ws, wino_wgrad_ws_floats(g));
     launch_bgemm_tl(b, ns, s);
-    hipLaunchKernelGGL(wino_filter_adj_kernel, dim3(grid1(4L * g.Cin * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
-                       (long)WF * g.Cin * N4, g.Cin, g.Cout, dweff, cls_stride);
+    if (dw_unfolded5)
+      hipLaunchKernelGGL(wino_filter_adj_unfold5_kernel, dim3(grid1((long)g.Cin * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
+                         (long)WF * g.Cin * N4, g.Cin, g.Cout, dw_unfolded5);
+    else
+      hipLaunchKernelGGL(wino_filter_adj_kernel, dim3(grid1(4L * g.Cin * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
+                         (long)WF * g.Cin * N4, g.Cin, g.Cout, dweff, cls_stride);
     return OTGAN_OK;
   }
   const int ns = wgrad_splits(g);
@@ -1660,8 +1709,12 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
   const int nkt = (int)((T + Cfg::BK - 1) / Cfg::BK);
   b.kt_per_split = (nkt + ns - 1) / ns;
   launch_bgemm<true>(b, ns, s);
-  hipLaunchKernelGGL(wino_filter_adj_kernel, dim3(grid1(4L * g.Cin * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
-                     (long)WF * g.Cin * N4, g.Cin, g.Cout, dweff, cls_stride);
+  if (dw_unfolded5)
+    hipLaunchKernelGGL(wino_filter_adj_unfold5_kernel, dim3(grid1((long)g.Cin * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
+                       (long)WF * g.Cin * N4, g.Cin, g.Cout, dw_unfolded5);
+  else
+    hipLaunchKernelGGL(wino_filter_adj_kernel, dim3(grid1(4L * g.Cin * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
+                       (long)WF * g.Cin * N4, g.Cin, g.Cout, dweff, cls_stride);
   return OTGAN_OK;
 }
 
