@@ -86,6 +86,15 @@ typedef struct otgan_conv_desc {
    * otgan_dense16_prepare_filters_f32, a growth layer (3x3, stride 1, Cout = 16) runs on the two-scaled-fp16-piece kernel
    * (otgan_dense16_h2_ok tells).  0 = unknown (the channel map decides). */
   int list_width;
+  /* (round 4) forward only: the layer is followed by a gated linear unit over the channel halves (reference
+   * models/dcgan.py:35-36: a, b = split(y, 2, axis = 3); a * sigmoid(b)).  Non-NULL glu_out: the kernel that writes y
+   * also writes the gated product to glu_out[N, OH, OW, Cout / 2] (contiguous, 16-byte aligned) -- y itself is still
+   * written, the backward pass of the unit needs it -- and, if glu_amax_out is non-NULL, max-accumulates the largest
+   * |gated value| into that (zeroed) amax record.  Only where otgan_conv2d_glu_fused(d) returns 1 (the Winograd path of
+   * the 5x5 upsampling layers, Cout % 8 == 0, y_coff == 0, ldy == Cout); any other layer with glu_out set is rejected
+   * with OTGAN_ERR_ARG.  Same arithmetic as otgan_glu_fwd_amax_f32 on y: bit-identical. */
+  float* glu_out;
+  float* glu_amax_out;
 } otgan_conv_desc;
 
 /*
@@ -98,6 +107,8 @@ typedef struct otgan_conv_desc {
 
 /* which: 0 fwd, 1 dgrad, 2 wgrad */
 size_t otgan_conv2d_workspace_bytes(const otgan_conv_desc* d, int which);
+/* 1: the forward pass of this layer can write the gated product of otgan_conv_desc::glu_out itself */
+int otgan_conv2d_glu_fused(const otgan_conv_desc* d);
 /* size of otgan_conv_desc::x_operand for this layer; 0 = forward and weight gradient do not share an operand */
 size_t otgan_conv2d_operand_bytes(const otgan_conv_desc* d);
 

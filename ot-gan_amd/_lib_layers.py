@@ -14,7 +14,8 @@ class ConvDesc(ctypes.Structure):
                 ("list_quads", c_int), ("x_amax", ctypes.c_void_p), ("dy_amax", ctypes.c_void_p),
                 ("y_accumulate", c_int), ("x_operand", ctypes.c_void_p),
                 ("y_amax_out", ctypes.c_void_p), ("dx_amax_out", ctypes.c_void_p), ("w_amax", ctypes.c_void_p),
-                ("x_amax_count", c_int), ("list_width", c_int)]
+                ("x_amax_count", c_int), ("list_width", c_int),
+                ("glu_out", ctypes.c_void_p), ("glu_amax_out", ctypes.c_void_p)]
 
 
 P_DESC = ctypes.POINTER(ConvDesc)
@@ -45,6 +46,7 @@ class WnBwdLayer(ctypes.Structure):
 SIGNATURES = {
     "otgan_conv2d_workspace_bytes": (c_size_t, [P_DESC, c_int]),
     "otgan_conv2d_operand_bytes": (c_size_t, [P_DESC]),
+    "otgan_conv2d_glu_fused": (c_int, [P_DESC]),
     "otgan_absmax_f32": (c_int, [c_fp, c_long, c_int, c_long, c_fp, c_fp]),
     "otgan_conv2d_amax_fused": (c_int, [P_DESC, c_int]),
     "otgan_conv2d_folded_weight_elems": (c_size_t, [P_DESC]),

@@ -108,20 +108,29 @@ __device__ __forceinline__ unsigned amax_bits4(f32x4 v, unsigned mb) {
   return mb;
 }
 // every thread of the workgroup that is still alive calls this (one-dimensional workgroups of <= 1024 threads; a lane
-// that has exited reads as 0 in the shuffles: ds_bpermute of a disabled lane)
+// that has exited reads as 0 in the shuffles: ds_bpermute of a disabled lane).  Waves that have exited altogether take no
+// part: the workgroup's maximum and the committing wave are found among the waves that arrive (round 4 -- until then
+// thread 0 read one LDS word per wave of the LAUNCH, stale LDS for a wave that had returned early: a last, partly
+// filled workgroup could raise the record by garbage; the shapes of the models fill their workgroups, the 4 x 4 layer of
+// a three-image batch did not).
 __device__ __forceinline__ void amax_commit(float* rec, unsigned mb) {
-  __shared__ unsigned s_amax[16];
+  __shared__ unsigned s_amax[2];   // [0] maximum, [1] lowest wave that arrived
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const unsigned w = (unsigned)__shfl_xor((int)mb, o, 64);
     mb = w > mb ? w : mb;
   }
-  const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-  if ((threadIdx.x & 63) == 0) s_amax[wave] = mb;
+  const unsigned wave = threadIdx.x >> 6;
+  const bool leader = (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1;
+  if (leader) { s_amax[0] = 0u; s_amax[1] = 0xffffffffu; }     // (every arriving wave writes the same two values)
   __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned m = 0u;
-    for (int w = 0; w < nw; ++w) m = s_amax[w] > m ? s_amax[w] : m;
+  if (leader) {
+    atomicMax(&s_amax[0], mb);
+    atomicMin(&s_amax[1], wave);
+  }
+  __syncthreads();
+  if (leader && s_amax[1] == wave) {
+    const unsigned m = s_amax[0];
     if (m != 0u) {
       unsigned* p = reinterpret_cast<unsigned*>(rec) + kAmaxSubStride * ((blockIdx.x + blockIdx.y + blockIdx.z) & (kAmaxSub - 1));
       if (m > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))

@@ -2914,6 +2914,13 @@ int otgan_conv2d_fwd_pf_f32(const otgan_conv_desc* d, const float* x, const int3
   return conv2d_fwd_impl(d, x, cmap, wT, (const float*)filters, bias, y, workspace, workspace_bytes, stream);
 }
 
+int otgan_conv2d_glu_fused(const otgan_conv_desc* d) {
+  Geo g;
+  if (!d || make_geo(d, &g) != OTGAN_OK) return 0;
+  static const bool off = getenv("OTGAN_WINO_GLU_FUSED") && getenv("OTGAN_WINO_GLU_FUSED")[0] == '0';
+  return !off && wino_ok(d, g) && d->Cout % 8 == 0 && d->y_coff == 0 && d->ldy == d->Cout && !d->y_accumulate;
+}
+
 static int conv2d_fwd_body(const otgan_conv_desc* d, const float* x, const int32_t* cmap, const float* wT,
                            const float* filters, const float* bias, float* y, void* workspace,
                            size_t workspace_bytes, void* stream);
@@ -2923,6 +2930,10 @@ static int conv2d_fwd_impl(const otgan_conv_desc* d, const float* x, const int32
   if (d && d->y_amax_out) {
     OTGAN_CHECK_ARG(d->Cout % 4 == 0 && d->ldy % 4 == 0 && d->y_coff % 4 == 0 && aligned16(y),
                     "y_amax_out: needs Cout, ldy, y_coff multiples of 4 and a 16-byte aligned y");
+  }
+  if (d && d->glu_out) {
+    OTGAN_CHECK_ARG(otgan_conv2d_glu_fused(d) && cmap == nullptr && aligned16(d->glu_out),
+                    "glu_out: only where otgan_conv2d_glu_fused(d) says so (single-tensor input, 16-byte aligned glu_out)");
   }
   g_amax_written = false;
   const int rc = conv2d_fwd_body(d, x, cmap, wT, filters, bias, y, workspace, workspace_bytes, stream);
@@ -3004,6 +3015,8 @@ static int conv2d_fwd_body(const otgan_conv_desc* d, const float* x, const int32
     const FoldTab f = make_fold(d, g);
     WinoGeo w = wino_geo(d);
     w.x_op = shared_x_operand(d);
+    w.glu_out = d->glu_out;
+    w.glu_amax = d->glu_out ? d->glu_amax_out : nullptr;
     // executed FLOP: 16 GEMMs of tiles x 4*Cout x Cin
     ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * kWinoFreq * (double)wino_tiles(w) * 4.0 * d->Cout * d->C, 0.0, s);
     rc = WINO(wino_fwd)(w, x, wT, f.woff[1] - f.woff[0], bias, y, (float*)workspace, s, filters);

@@ -24,6 +24,9 @@ struct WinoGeo {
   // the weight gradient of the same x reads it instead of transforming x again; null = each pass transforms
   float* x_op = nullptr;
   const float* w_amax = nullptr;   // otgan_conv_desc::w_amax (filters made from the un-folded weights)
+  // forward only, otgan_conv_desc::glu_out / glu_amax_out: [N, 2H, 2W, Cout/2] gated output written beside y (Cout % 8 == 0)
+  float* glu_out = nullptr;
+  float* glu_amax = nullptr;
 };
 
 // amax record (otgan_layers.h) of x[rows][C], row stride ld

@@ -472,6 +472,7 @@ struct OutArgs {
   const float* bias;
   int accumulate;
   float* amax;          // amax record of the values written (common.h: amax_commit), or null
+  WView gv[4];          // wino_output_glu_kernel: the gated output y[..., :C/2] * sigmoid(y[..., C/2:]) per class view
 };
 __global__ __launch_bounds__(256) void wino_output_kernel(OutArgs a) {
   const int c4n = a.C >> 2;
@@ -508,6 +509,62 @@ __global__ __launch_bounds__(256) void wino_output_kernel(OutArgs a) {
       if (a.accumulate) o += ld4(dst);
       mb = amax_bits4(o, mb);     // the value that ends up in memory (with `accumulate`: the sum)
       st4(dst, o);
+    }
+  }
+  if (a.amax) amax_commit(a.amax, mb);
+}
+
+// The generator's layers end in a gated linear unit over the channel halves (models/dcgan.py:35-36, 50): the same transform
+// for channel quad c of the value half and of the gate half by one thread, which writes y (the backward pass needs the
+// pre-activation) AND the gated product -- pointwise.hip's glu_fwd4_kernel (a read of y, one launch) disappears; same
+// arithmetic, bit-identical.  The value half goes to memory first and comes back from the cache when the gate is known
+// (16 quads: holding them would cost 64 registers of a kernel that lives on its loads in flight).
+__device__ __forceinline__ float wino_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+__global__ __launch_bounds__(256) void wino_output_glu_kernel(OutArgs a) {
+  const int ch = a.C >> 1, c4n = ch >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.T * c4n) return;
+  unsigned mb = 0u;
+  const int c = (int)(idx % c4n) * 4;
+  const long t = idx / c4n;
+  const int tb = (int)(t % a.TW), ta = (int)((t / a.TW) % a.TH);
+  const long n = t / ((long)a.TW * a.TH);
+  const WView v = a.v[blockIdx.z], gv = a.gv[blockIdx.z];
+  const long fs = a.T * a.ldm;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int cc = c + half * ch;
+    const float* in = a.Mh + t * a.ldm + a.coff[blockIdx.z] + cc;
+    f32x4 S[WM][WA];
+#pragma unroll
+    for (int j = 0; j < WA; ++j) {
+      f32x4 col[WA], o[WM];
+#pragma unroll
+      for (int i = 0; i < WA; ++i) col[i] = ld4(in + (i * WA + j) * fs);
+      at1(col, o);
+#pragma unroll
+      for (int i = 0; i < WM; ++i) S[i][j] = o[i];
+    }
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) b = ld4(a.bias + cc);
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      f32x4 y[WM];
+      at1(S[i], y);
+#pragma unroll
+      for (int j = 0; j < WM; ++j) {
+        float* dst = v.p + n * v.sn + (WM * ta + i) * v.sh + (WM * tb + j) * v.sw + c;
+        const f32x4 o = y[j] + b;
+        st4(dst + half * ch, o);
+        if (half) {
+          const f32x4 val = ld4(dst);
+          f32x4 gl;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) gl[k] = val[k] * wino_sigmoid(o[k]);
+          mb = amax_bits4(gl, mb);
+          st4(gv.p + n * gv.sn + (WM * ta + i) * gv.sh + (WM * tb + j) * gv.sw + c, gl);
+        }
+      }
     }
   }
   if (a.amax) amax_commit(a.amax, mb);
@@ -1590,6 +1647,12 @@ int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stri
   class_views(g, y + g.y_coff, g.ldy, oa.v);
   for (int cls = 0; cls < 4; ++cls) oa.coff[cls] = cls * g.Cout;
   oa.TH = g.H / WM; oa.TW = g.W / WM; oa.C = g.Cout; oa.T = T; oa.ldm = N4; oa.Mh = Mh; oa.bias = bias;
+  if (g.glu_out) {
+    class_views(g, g.glu_out, g.Cout / 2, oa.gv);
+    oa.amax = g.glu_amax;
+    hipLaunchKernelGGL(wino_output_glu_kernel, dim3(grid1(T * (g.Cout / 8)), 1, 4), dim3(256), 0, s, oa);
+    return OTGAN_OK;
+  }
   hipLaunchKernelGGL(wino_output_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 4), dim3(256), 0, s, oa);
   return OTGAN_OK;
 }

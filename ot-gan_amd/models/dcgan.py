@@ -47,7 +47,8 @@ def gen_spec(batch_size, init=False, nonlinearity='crelu', ema=None, noise=None,
         x = ops.carry_amax(x.view(noise.shape[0], base, base, 1024), x)   # (the GLU's amax record survives the reshape)
         for filters in _GEN:
             # nearest-neighbour x2 (fused into the conv's gather) -> 5x5 conv -> gated linear unit
-            x = nn.glu(nn.conv2d(x, filters, filter_size=[5, 5], pre_activation=None, upsample=True))
+            # (glu_hint: the layer's output kernel writes the gated product as well, nn.glu picks it up)
+            x = nn.glu(nn.conv2d(x, filters, filter_size=[5, 5], pre_activation=None, upsample=True, glu_hint=True))
         return nn.tanh(nn.conv2d(x, 3, filter_size=[5, 5], pre_activation=None, init_scale=0.1))
 
 

@@ -202,6 +202,7 @@ _AMAX_SLOTS = 256
 _amax_pool = {}       # device -> [zeroed [slots, AMAX_RECORD_FLOATS] tensor, next free slot]
 _FUSED_AMAX = os.environ.get("OTGAN_FUSED_AMAX", "1") != "0"
 _GLU_COLSUM = os.environ.get("OTGAN_GLU_COLSUM", "1") != "0"
+_GLU_FUSED = os.environ.get("OTGAN_WINO_GLU_FUSED", "1") != "0"   # (the library reads the same switch)
 
 
 def colsum_of(t):
@@ -304,7 +305,7 @@ class Conv2dFunction(torch.autograd.Function):
     V: [KH,KW,Cin_eff,Cout]; g, b: [Cout]."""
 
     @staticmethod
-    def forward(ctx, x, V, g, b, stride, upsample, preact, segs):
+    def forward(ctx, x, V, g, b, stride, upsample, preact, segs, glu_hint=False):
         _need_cuda(x, V, g, b)
         x = x.contiguous()
         N, H, W, C = x.shape
@@ -366,7 +367,19 @@ class Conv2dFunction(torch.autograd.Function):
         if amax_fused(desc, 0):
             y_rec = amax_slot(x.device)          # the kernel that writes y also leaves max |y| (for the next layer)
             desc.y_amax_out = y_rec.data_ptr()
+        y_glu = None
+        if glu_hint and _GLU_FUSED and cmap is None and _lib.lib().otgan_conv2d_glu_fused(ctypes.byref(desc)):
+            # the caller applies a gated linear unit to y next (models/dcgan.py:50): the kernel that writes y leaves the
+            # gated product (and its amax record) too; GluFunction.forward picks it up instead of reading y again
+            y_glu = torch.empty((N, OH, OW, Cout // 2), dtype=x.dtype, device=x.device)
+            glu_rec = amax_slot(x.device) if _FUSED_AMAX else None
+            desc.glu_out, desc.glu_amax_out = y_glu.data_ptr(), _lib.ptr(glu_rec)
         conv_fwd_raw(desc, x, cmap, wT, b, y, filt["fwd"])
+        if y_glu is not None:
+            desc.glu_out = desc.glu_amax_out = None
+            if glu_rec is not None:
+                tag_amax(y_glu, glu_rec)
+            y._otgan_glu = (y_glu, y._version)
         desc.y_amax_out = None
         if ctx.x_rec is None:
             desc.x_amax = None
@@ -415,12 +428,14 @@ class Conv2dFunction(torch.autograd.Function):
             if db is None:
                 rows = dy.numel() // dy.shape[-1]
                 db = colsum(dy.data_ptr(), rows, dy.shape[-1], dy.shape[-1], dy.device)
-        return dx, dV, dg, db, None, None, None, None
+        return dx, dV, dg, db, None, None, None, None, None
 
 
-def conv2d_op(x, V, g, b, stride=1, upsample=False, preact=0, segs=None):
+def conv2d_op(x, V, g, b, stride=1, upsample=False, preact=0, segs=None, glu_hint=False):
+    """glu_hint: the caller feeds the result to glu() next -- where the library can, the layer's output kernel also
+    writes the gated product and glu() takes it from there (same values; the hint changes nothing else)."""
     return Conv2dFunction.apply(x, V, g, b, int(stride), bool(upsample), int(preact),
-                                tuple(segs) if segs else None)
+                                tuple(segs) if segs else None, bool(glu_hint))
 
 
 def dense_op(x, V, g, b, preact=0, segs=None):
@@ -1089,6 +1104,12 @@ class GluFunction(torch.autograd.Function):
         x = x.contiguous()
         C2 = x.shape[-1]
         rows = x.numel() // C2
+        pre = getattr(x, "_otgan_glu", None)
+        if pre is not None and pre[1] == x._version:
+            # the layer that produced x already wrote the gated product (Conv2dFunction, glu_hint)
+            del x._otgan_glu
+            ctx.save_for_backward(x)
+            return pre[0]
         y = torch.empty(x.shape[:-1] + (C2 // 2,), dtype=x.dtype, device=x.device)
         rec = amax_slot(x.device) if (_FUSED_AMAX and (C2 // 2) % 4 == 0) else None
         _lib.check(_lib.lib().otgan_glu_fwd_amax_f32(x.data_ptr(), rows, C2 // 2, y.data_ptr(), _lib.ptr(rec),

@@ -310,10 +310,11 @@ def dense(x, num_units, pre_activation='celu', init_scale=1., counters={}, init=
 @_scoped
 def conv2d(x, num_filters, pre_activation='celu', filter_size=[3, 3], stride=[1, 1], pad='SAME',
            dilate=1, upsample=False, init_scale=1., counters={}, init=False, ema=None,
-           weight_norm=True, use_b=True, use_g=True, **kwargs):
+           weight_norm=True, use_b=True, use_g=True, glu_hint=False, **kwargs):
     """2-D convolution on an NHWC tensor or list of tensors (reference nn.py:327-338):
     optional 2x nearest-neighbour upsample, pre-activation over the list, weight-normalised
-    HWIO filter, TF 'SAME' padding, bias."""
+    HWIO filter, TF 'SAME' padding, bias.  `glu_hint` (not in the reference): the caller passes the
+    result to glu() next, see ops.conv2d_op -- values unchanged."""
     if pad != 'SAME' or dilate != 1:
         raise NotImplementedError("the reference models only use pad='SAME', dilate=1")
     if not (weight_norm and use_g and use_b):
@@ -338,7 +339,7 @@ def conv2d(x, num_filters, pre_activation='celu', filter_size=[3, 3], stride=[1,
                                preact=ops.ACT[pre_activation], segs=[int(t.shape[-1]) for t in xs])
         _run_data_init(y0, g, b, init_scale)
     return ops.conv2d_op(xin, V, g, b, stride=stride[0], upsample=upsample,
-                         preact=ops.ACT[pre_activation], segs=[int(t.shape[-1]) for t in xs])
+                         preact=ops.ACT[pre_activation], segs=[int(t.shape[-1]) for t in xs], glu_hint=glu_hint)
 
 
 class ConcatList(list):

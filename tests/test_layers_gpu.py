@@ -742,3 +742,38 @@ def test_full_size_transition_identities(dev, case):
     # <x, dy/dx . dy> == <y, dy> ties dgrad (activation derivative, class / tap bookkeeping) to the forward pass exactly
     rhs_x = float((x.double() * dx.double()).sum())
     assert abs(lhs - rhs_x) <= 2e-6 * scale, ("dgrad", lhs, rhs_x, scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 4, 4, 64, 64), (2, 8, 8, 32, 48), (4, 16, 16, 64, 128)], ids=["4x4", "8x8", "16x16"])
+def test_glu_in_output_transform(dev, shape):
+    """The generator's 5x5 upsampling layers write the gated linear unit of their output themselves (conv2d_op
+    glu_hint, otgan_conv_desc::glu_out; reference models/dcgan.py:35-36, 50): same pre-activation, gated product,
+    amax record and gradients as the separate glu launch, bit for bit."""
+    from otgan_amd import _lib, ops
+    import ctypes
+    N, H, W, C, Cout = shape
+    gen = torch.Generator().manual_seed(11)
+    x0 = torch.randn(N, H, W, C, generator=gen).to(dev)
+    V0 = (torch.randn(5, 5, C, Cout, generator=gen) * 0.05).to(dev)
+    g0, b0 = (1 + 0.1 * torch.randn(Cout, generator=gen)).to(dev), (0.1 * torch.randn(Cout, generator=gen)).to(dev)
+    dz = torch.randn(N, 2 * H, 2 * W, Cout // 2, generator=gen).to(dev)
+    desc = ops.make_desc(x0, C, True, 5, 5, 1, Cout, Cout, 0, 0)
+    assert _lib.lib().otgan_conv2d_glu_fused(ctypes.byref(desc)) == 1
+    res = []
+    for hint in (False, True):
+        x, V, g, b = (t.clone().requires_grad_(True) for t in (x0, V0, g0, b0))
+        y = ops.conv2d_op(x, V, g, b, stride=1, upsample=True, preact=0, glu_hint=hint)
+        assert hasattr(y, "_otgan_glu") == hint
+        z = ops.glu(y)
+        assert not hasattr(y, "_otgan_glu")
+        rec = ops.amax_of(z)
+        assert rec is not None
+        z.backward(dz)
+        res.append((y.detach(), z.detach(), rec.max().clone(), x.grad, V.grad, g.grad, b.grad))
+    for a, c in zip(*res):
+        assert torch.equal(a, c)
+    assert float(res[1][2]) == float(res[1][1].abs().max())
+    # a layer the fused form does not cover rejects glu_out instead of ignoring it
+    d2 = ops.make_desc(x0, C, False, 3, 3, 1, Cout, Cout, 0, 0)
+    assert _lib.lib().otgan_conv2d_glu_fused(ctypes.byref(d2)) == 0
