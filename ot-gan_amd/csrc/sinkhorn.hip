@@ -5,6 +5,8 @@
 #include <stdlib.h>
 
 #include "gemm_tile.h"
+// the matching GEMMs of N >= 256 on two scaled fp16 pieces (round 4; three bf16 pieces until then): section 5
+#define X3_PIECES 2
 #include "gemm_x3.h"
 #include "../../include/otgan.h"
 
@@ -787,9 +789,36 @@ struct SplitSrc {
   float scale[12];
   int n;
 };
-// src[i]: [rows x K] fp32 row-major  ->  dst: stacked operand (kblocks = K / 16), three bf16 planes.
+// src[i]: [rows x K] fp32 row-major  ->  dst: stacked operand (kblocks = K / 16), two fp16 planes of scale[i] * src[i] * 2^(14 - e).
 // A wave covers 16 rows x 16 k: every store instruction writes 512 contiguous bytes of one chunk.
-__global__ __launch_bounds__(256) void x3_split_rows_kernel(SplitSrc a, int rows, int K, u16* dst, long plane_stride) {
+//
+// The power-of-two scale of an operand needs the largest magnitude in it, and a reduction pass over the features of a
+// rank's problem would be one more read of 0.4 - 0.8 GB.  Instead: pass 0 splits with the exponent e0 the caller expects
+// (features of a cosine cost are rows of unit length: |x| < 2; plan entries are at most 1) and max-accumulates the
+// magnitudes it sees into the operand's record; pass 1 -- same grid, normally a few hundred idle workgroups -- reads the
+// record, writes the header the GEMM scales its sums by, and only when the expectation was wrong (|x| >= 2^(e0 + 1):
+// the hi piece could overflow; or < 2^(e0 - 12): lo pieces would go subnormal) splits everything again with the
+// exponent of the data.  Operand header: X3_HDR floats (gemm_x3.h) + one amax record (common.h) in front of the planes.
+constexpr int kX3HdrFloats = X3_HDR + kAmaxSub * kAmaxSubStride;
+constexpr size_t kX3HdrBytes = sizeof(float) * kX3HdrFloats;
+__host__ __device__ inline float* x3_hdr(const u16* planes) {
+  return reinterpret_cast<float*>(const_cast<u16*>(planes)) - kX3HdrFloats;
+}
+__global__ __launch_bounds__(256) void x3_split_rows_kernel(SplitSrc a, int rows, int K, u16* dst, long plane_stride, float* hdr,
+                                                            int e0, int pass) {
+  int e = e0;
+  if (pass == 1) {
+    const float amax = amax_record_value(hdr + X3_HDR);
+    const int ea = x3_scale_exp(amax, 1.f, 1.f);          // amax < 2^ea  (0 for an all-zero or NaN operand)
+    const bool keep = !(amax > 0.f) || (ea <= e0 + 1 && ea >= e0 - 12);
+    if (!keep) e = ea;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 40) {
+      if (threadIdx.x == 0) hdr[0] = amax;
+      hdr[16 + threadIdx.x] = ldexpf(1.f, 14 - e);
+      hdr[64 + threadIdx.x] = ldexpf(1.f, e - 14);
+    }
+    if (keep) return;
+  }
   const int nk4 = K >> 2, kgroups = (nk4 + 15) >> 4;
   const long b = blockIdx.x;
   const int i = blockIdx.y;
@@ -797,9 +826,11 @@ __global__ __launch_bounds__(256) void x3_split_rows_kernel(SplitSrc a, int rows
   const long row = (b / kgroups) * 16 + ((threadIdx.x >> 2) & 15);
   if (row >= rows || k4 >= nk4) return;
   f32x4 v = x3_ld4(a.src[i] + row * a.ld[i] + 4 * k4);
-  const float sc = a.scale[i];
-  v *= sc;
-  st_split4(dst, plane_stride, op_off(a.row0[i] + row, 4 * k4, K >> 4), v);
+  v *= a.scale[i];
+  const unsigned mb = amax_bits4(v, 0u);
+  v *= ldexpf(1.f, 14 - e);
+  st_split4h(dst, plane_stride, op_off(a.row0[i] + row, 4 * k4, K >> 4), v);
+  if (pass == 0) amax_commit(hdr + X3_HDR, mb);
 }
 
 template <auto Kern>
@@ -822,10 +853,34 @@ inline bool match_x3_enabled() {
 inline size_t x3_plane_elems(size_t rows, size_t K) { return ((rows + 31) / 32) * 32 * K; }
 inline long x3_row_off(long row, long K) { return (row >> 5) * (K >> 4) * 512; }   // element offset of row block row/32
 
-void x3_split(const SplitSrc& ss, int rows, int K, u16* dst, long plane_stride, hipStream_t s) {
-  const int nk4 = K / 4, kgroups = (nk4 + 15) / 16;
-  const dim3 grid((unsigned)(((long)(rows + 15) / 16) * kgroups), ss.n);
-  hipLaunchKernelGGL(x3_split_rows_kernel, grid, dim3(256), 0, s, ss, rows, K, dst, plane_stride);
+// one or more launches into operands that share a header (and with it one scale): all first passes, then all second ones
+struct X3SplitJob {
+  SplitSrc ss;
+  int rows, K;
+  u16* dst;
+  long plane_stride;
+};
+constexpr int kX3FeatureExp = 1;      // cosine-cost features: |x| < 2 expected (rows of unit length)
+void x3_split_group(const X3SplitJob* jobs, int njobs, float* hdr, int e0, hipStream_t s) {
+  hipMemsetAsync(hdr + X3_HDR, 0, sizeof(float) * kAmaxSub * kAmaxSubStride, s);
+  for (int pass = 0; pass < 2; ++pass)
+    for (int j = 0; j < njobs; ++j) {
+      const X3SplitJob& q = jobs[j];
+      if (!q.ss.n) continue;
+      const int nk4 = q.K / 4, kgroups = (nk4 + 15) / 16;
+      const dim3 grid((unsigned)(((long)(q.rows + 15) / 16) * kgroups), q.ss.n);
+      hipLaunchKernelGGL(x3_split_rows_kernel, grid, dim3(256), 0, s, q.ss, q.rows, q.K, q.dst, q.plane_stride, hdr, e0, pass);
+    }
+}
+void x3_split(const SplitSrc& ss, int rows, int K, u16* dst, long plane_stride, int e0, hipStream_t s) {
+  X3SplitJob q{ss, rows, K, dst, plane_stride};
+  x3_split_group(&q, 1, x3_hdr(dst), e0, s);
+}
+// expected exponent of a plan operand: entries of a plan are at most 1 (its rows and columns sum to 1 or less)
+inline int x3_plan_exp(const SplitSrc& ss) {
+  float m = 0.f;
+  for (int i = 0; i < ss.n; ++i) m = fmaxf(m, fabsf(ss.scale[i]));
+  return x3_scale_exp(m, 1.f, 1.f);
 }
 
 // the conditions under which the split-precision engine takes a matching problem of n x m blocks, feature width D
@@ -842,10 +897,21 @@ inline X3CostPlan x3_plan_cost(int P, int n, int m, int D) {
   X3CostPlan c;
   c.tiles = ceil_div(n, X3_BM) * ceil_div(m, X3_BN);
   const int nkt = D / X3_BK;
-  int want = c.tiles * P >= 192 ? 1 : ceil_div(256, c.tiles * P);
-  if (want > nkt / 4) want = nkt / 4 > 0 ? nkt / 4 : 1;      // >= 4 granules (8 stages) per split
-  if (want < 1) want = 1;
-  c.kt_per_split = ceil_div(nkt, want);
+  // The split count that minimises (rounds of 256 workgroups) x (granules per split + a workgroup's fixed cost: about four
+  // granules of prologue and write-out, ten with a partial tile that is written and read again).  Round 4: until then ceil(256 / tiles) splits -- 12 tiles (a rank's three row
+  // slices at N = 1024) became 264 workgroups, i.e. a second round for eight of them and twice the time (376 us, MFMA busy
+  // 0.41 in profiles/r04_pmc_kernels_matching_N1024_D32768_rows256_rank.txt).
+  const int max_split = nkt / 4 > 0 ? nkt / 4 : 1;            // >= 4 granules (8 stages) per split
+  static const int forced = [] { const char* e = getenv("OTGAN_X3_COST_SPLITS"); return e ? atoi(e) : 0; }();
+  long best_t = -1;
+  int best = 1;
+  for (int ns = 1; ns <= max_split && ns <= 256; ++ns) {
+    const int kt = ceil_div(nkt, ns), real = ceil_div(nkt, kt);
+    const long t = (long)ceil_div(c.tiles * P * real, 256) * (kt + (real > 1 ? 10 : 4));   // (+ the partial tile's write-out and re-read)
+    if (best_t < 0 || t < best_t) { best_t = t; best = real; }
+  }
+  if (forced > 0) best = forced < max_split ? forced : max_split;
+  c.kt_per_split = ceil_div(nkt, best);
   c.nsplit = ceil_div(nkt, c.kt_per_split);
   return c;
 }
@@ -858,6 +924,7 @@ int launch_cost_x3(const u16* FP, long plane, long rows_total, const long* xrow,
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.Ap = FP; b.Bp = FP; b.pA = plane; b.pB = plane;
+  b.hdrA = b.hdrB = x3_hdr(FP);
   b.M = n; b.N = m; b.K = D;
   b.ldc = m;
   b.tiles_m = ceil_div(n, X3_BM); b.tiles_n = ceil_div(m, X3_BN);
@@ -901,11 +968,12 @@ struct X3ApplyBlock {
   int K;
   float* out;        // row m_begin of this block's output
 };
-int launch_apply_x3(const X3ApplyBlock* blk, int nblk, const u16* PA_base, long planeA, int ncolsA, const u16* FP,
+int launch_apply_x3(const X3ApplyBlock* blk, int nblk, const u16* PA_base, const float* hdrA, long planeA, int ncolsA, const u16* FP,
                     long planeF, int m_begin, int m_count, int D, long ldo, hipStream_t s) {
   BgArgs b;
   memset(&b, 0, sizeof(b));
   b.Ap = PA_base; b.Bp = FP; b.pA = planeA; b.pB = planeF;
+  b.hdrA = hdrA; b.hdrB = x3_hdr(FP);
   b.M = m_begin + m_count; b.N = D;
   b.ldc = ldo;
   b.tiles_m = ceil_div(m_count, X3_BM); b.tiles_n = ceil_div(D, X3_BN);
@@ -1136,9 +1204,13 @@ MatchWs carve_match(void* base, size_t cap, int P, int n, int D, int feat_rows, 
   // four halves) and ONE plan operand of twelve n-row blocks (PT; PM unused)
   w.planeF = (long)x3_plane_elems((grad ? 3 : 2) * (size_t)feat_rows, D);
   w.planeP = (long)x3_plane_elems((grad ? 2 : 1) * (size_t)P * n, n);
-  w.FP = (u16*)c.take(w.x3 ? sizeof(u16) * 3 * (size_t)w.planeF : 0);
-  w.PT = (u16*)c.take(w.x3 ? sizeof(u16) * 3 * (size_t)w.planeP : 0);
-  w.PM = (u16*)c.take(w.x3 && !grad ? sizeof(u16) * 3 * (size_t)w.planeP : 0);
+  auto operand = [&](bool on, long plane) -> u16* {     // header + record, then the planes
+    char* p = (char*)c.take(on ? kX3HdrBytes + sizeof(u16) * X3_NP * (size_t)plane : 0);
+    return (u16*)(p ? p + kX3HdrBytes : (char*)nullptr);
+  };
+  w.FP = operand(w.x3, w.planeF);
+  w.PT = operand(w.x3, w.planeP);
+  w.PM = operand(w.x3 && !grad, w.planeP);
   w.partial = (float*)c.take(sizeof(float) * pnm * nsplit);
   w.K = (float*)c.take(sizeof(float) * pnm);
   w.plan = (float*)c.take(sizeof(float) * pnm);
@@ -1157,7 +1229,7 @@ void x3_split_features(const MatchWs& w, const float* fa, const float* fb, int r
   ss.n = 2;
   ss.src[0] = fa; ss.ld[0] = ldf; ss.row0[0] = 0; ss.scale[0] = 1.f;
   ss.src[1] = fb; ss.ld[1] = ldf; ss.row0[1] = rows; ss.scale[1] = 1.f;
-  x3_split(ss, rows, D, w.FP, w.planeF, s);
+  x3_split(ss, rows, D, w.FP, w.planeF, kX3FeatureExp, s);
 }
 
 // plans / transposed plans of P problems -> t-leading operands; order[i] = problem stored at rows [i n, (i+1) n)
@@ -1172,8 +1244,10 @@ void x3_split_plans(const MatchWs& w, const float* plan, const float* planT, int
     const int p = orderM[i];
     sm.src[i] = plan + (size_t)p * n * n; sm.ld[i] = n; sm.row0[i] = (long)i * n; sm.scale[i] = alpha[p];
   }
-  x3_split(st, n, n, w.PT, w.planeP, s);
-  x3_split(sm, n, n, w.PM, w.planeP, s);
+  // both operands behind ONE header (w.PT's): a launch of the plan application reads blocks of either
+  X3SplitJob jobs[2] = {{st, n, n, w.PT, w.planeP}, {sm, n, n, w.PM, w.planeP}};
+  const int e0 = x3_plan_exp(st) > x3_plan_exp(sm) ? x3_plan_exp(st) : x3_plan_exp(sm);
+  x3_split_group(jobs, 2, x3_hdr(w.PT), e0, s);
 }
 
 }  // namespace
@@ -1282,7 +1356,7 @@ int otgan_matching_two_batch_f32(const float* fa, const float* fb, int N, int D,
         {w.PM, 2 * n1, 0 * n1, 2 * N, f_ba},        // b1 <- (M2^T . a1 + M4^T . a2) / 2
         {w.PM, 4 * n1, 0 * n1, 2 * N, f_ba + half}, // b2 <- (M3^T . a1 + M5^T . a2) / 2
     };
-    rc = launch_apply_x3(xb, 8, w.PT < w.PM ? w.PT : w.PM, w.planeP, N, w.FP, w.planeF, 0, N, D, ldo, s);
+    rc = launch_apply_x3(xb, 8, w.PT < w.PM ? w.PT : w.PM, x3_hdr(w.PT), w.planeP, N, w.FP, w.planeF, 0, N, D, ldo, s);
   } else {
     rc = launch_apply(blk, 8, N, D, ldf, ldo, s);
   }
@@ -1381,7 +1455,7 @@ int otgan_matching_two_batch_rows_f32(const float* fa, const float* fb, int N, i
       xb[2] = {w.PT, 4 * n1, 2 * n1, 2 * N, f_ab};     // (M4 . b1 + M5 . b2) / 2
       xb[3] = {w.PM, 4 * n1, 0 * n1, 2 * N, f_ba};     // (M3^T . a1 + M5^T . a2) / 2
     }
-    rc = launch_apply_x3(xb, 4, w.PT < w.PM ? w.PT : w.PM, w.planeP, N, w.FP, w.planeF, r0, row_count, D, ldo, s);
+    rc = launch_apply_x3(xb, 4, w.PT < w.PM ? w.PT : w.PM, x3_hdr(w.PT), w.planeP, N, w.FP, w.planeF, r0, row_count, D, ldo, s);
   } else {
     rc = launch_apply(blk, 4, row_count, D, ldf, ldo, s);
   }
@@ -1434,7 +1508,7 @@ static int matching_grad_impl(const float* fa, const float* fb, int N, int D, lo
     const float* blocks[6] = {fa1, fb1, fb2, fa2, fa1, fb1};
     ss.n = nstack;
     for (int i = 0; i < nstack; ++i) { ss.src[i] = blocks[i]; ss.ld[i] = ldf; ss.row0[i] = (long)i * N; ss.scale[i] = 1.f; }
-    x3_split(ss, N, D, w.FP, w.planeF, s);
+    x3_split(ss, N, D, w.FP, w.planeF, kX3FeatureExp, s);
   }
   const float* Kuse = K_pre;
   if (!K_pre) {
@@ -1497,10 +1571,10 @@ static int matching_grad_impl(const float* fa, const float* fb, int N, int D, lo
         const int i = 3 * z + t;
         sp.src[i] = src[which[z]][t]; sp.ld[i] = N; sp.row0[i] = (long)i * N; sp.scale[i] = scl[which[z]][t];
       }
-    x3_split(sp, N, N, w.PT, w.planeP, s);
+    x3_split(sp, N, N, w.PT, w.planeP, x3_plan_exp(sp), s);
     X3ApplyBlock xb[4];
     for (int z = 0; z < nblk; ++z) xb[z] = X3ApplyBlock{w.PT, 3L * z * N, frow[which[z]], 3 * N, outp[z]};
-    rc = launch_apply_x3(xb, nblk, w.PT, w.planeP, N, w.FP, w.planeF, r0, cnt, D, ldo, s);
+    rc = launch_apply_x3(xb, nblk, w.PT, x3_hdr(w.PT), w.planeP, N, w.FP, w.planeF, r0, cnt, D, ldo, s);
   } else {
     ApplyBlock blk[4];
     memset(blk, 0, sizeof(blk));
@@ -1596,7 +1670,7 @@ int otgan_matching_single_batch_f32(const float* fa, const float* fb, int n, int
         {w.PT, 2 * n1, 1 * n1, n, f_ab},     // M_ab . b
         {w.PM, 2 * n1, 0 * n1, n, f_ba},     // M_ab^T . a
     };
-    rc = launch_apply_x3(xb, 4, w.PT < w.PM ? w.PT : w.PM, w.planeP, n, w.FP, w.planeF, 0, n, D, ldo, s);
+    rc = launch_apply_x3(xb, 4, w.PT < w.PM ? w.PT : w.PM, x3_hdr(w.PT), w.planeP, n, w.FP, w.planeF, 0, n, D, ldo, s);
   } else {
     rc = launch_apply(blk, 4, n, D, ldf, ldo, s);
   }
@@ -1665,10 +1739,10 @@ static int single_grad_impl(const float* fa, const float* fb, int n, int D, long
         const int i = 2 * z + t;
         sp.src[i] = src[z][t]; sp.ld[i] = n; sp.row0[i] = (long)i * n; sp.scale[i] = scl[z][t];
       }
-    x3_split(sp, n, n, w.PT, w.planeP, s);
+    x3_split(sp, n, n, w.PT, w.planeP, x3_plan_exp(sp), s);
     X3ApplyBlock xb[2];
     for (int z = 0; z < nblk; ++z) xb[z] = X3ApplyBlock{w.PT, 2L * z * n, 0, 2 * n, outp[z]};
-    rc = launch_apply_x3(xb, nblk, w.PT, w.planeP, n, w.FP, w.planeF, row_begin, row_count, D, ldo, s);
+    rc = launch_apply_x3(xb, nblk, w.PT, x3_hdr(w.PT), w.planeP, n, w.FP, w.planeF, row_begin, row_count, D, ldo, s);
   } else {
     ApplyBlock blk[2];
     memset(blk, 0, sizeof(blk));
@@ -1717,7 +1791,7 @@ static size_t cost_batched_ws(int P, int n, int m, int D, bool* x3_out) {
   if (x3 && x3_plan_cost(P, n, m, D).nsplit > nsplit) nsplit = x3_plan_cost(P, n, m, D).nsplit;
   size_t b = align_up(sizeof(float) * (size_t)P * n * m * nsplit, 256) + (size_t)P * (align_up(sizeof(float) * n, 256) +
                                                                                       align_up(sizeof(float) * m, 256));
-  if (x3) b += align_up(sizeof(u16) * 3 * x3_plane_elems((size_t)P * ((size_t)n + m), D), 256);
+  if (x3) b += align_up(kX3HdrBytes + sizeof(u16) * X3_NP * x3_plane_elems((size_t)P * ((size_t)n + m), D), 256);
   return b;
 }
 
@@ -1759,7 +1833,7 @@ int otgan_cost_matrix_batched_f32(const float* const* X, const float* const* Y, 
   for (int p = 0; p < P && x3; ++p) x3 = aligned16(X[p]) && aligned16(Y[p]);
   if (x3) {
     // every distinct block is split once into a stacked operand (a rank's slices share their X, two of them a Y)
-    u16* FP = (u16*)c.take(sizeof(u16) * 3 * x3_plane_elems((size_t)P * ((size_t)n + m), D));
+    u16* FP = (u16*)((char*)c.take(kX3HdrBytes + sizeof(u16) * X3_NP * x3_plane_elems((size_t)P * ((size_t)n + m), D)) + kX3HdrBytes);
     const long plane = (long)x3_plane_elems((size_t)P * ((size_t)n + m), D);
     const float* uniq[2 * kMaxProb];
     long urow[2 * kMaxProb];
@@ -1781,8 +1855,8 @@ int otgan_cost_matrix_batched_f32(const float* const* X, const float* const* Y, 
     for (int p = 0; p < P; ++p) xrow[p] = place(X[p], n, sx);
     for (int p = 0; p < P; ++p) yrow[p] = place(Y[p], m, sy);   // (a pointer used as X with fewer rows is placed again)
     ProfScope ps(OTGAN_PROF_COST_GEMM, 2.0 * P * n * (double)m * D, 4.0 * P * ((double)n + m) * D, s);
-    if (sx.n) x3_split(sx, n, D, FP, plane, s);
-    if (sy.n) x3_split(sy, m, D, FP, plane, s);
+    X3SplitJob jobs[2] = {{sx, n, D, FP, plane}, {sy, m, D, FP, plane}};
+    x3_split_group(jobs, 2, x3_hdr(FP), kX3FeatureExp, s);
     return launch_cost_x3(FP, plane, rows, xrow, yrow, diag_add, P, n, m, D, lambda, partial, K, s);
   }
   if (cost_kind == OTGAN_COST_SQEUCLID_MEAN) {
