@@ -805,7 +805,7 @@ __host__ __device__ inline float* x3_hdr(const u16* planes) {
   return reinterpret_cast<float*>(const_cast<u16*>(planes)) - kX3HdrFloats;
 }
 __global__ __launch_bounds__(256) void x3_split_rows_kernel(SplitSrc a, int rows, int K, u16* dst, long plane_stride, float* hdr,
-                                                            int e0, int pass) {
+                                                            int e0, int pass, long nblocks) {
   int e = e0;
   if (pass == 1) {
     const float amax = amax_record_value(hdr + X3_HDR);
@@ -820,16 +820,20 @@ __global__ __launch_bounds__(256) void x3_split_rows_kernel(SplitSrc a, int rows
     if (keep) return;
   }
   const int nk4 = K >> 2, kgroups = (nk4 + 15) >> 4;
-  const long b = blockIdx.x;
   const int i = blockIdx.y;
-  const int k4 = (int)(b % kgroups) * 16 + (threadIdx.x >> 6) * 4 + (threadIdx.x & 3);
-  const long row = (b / kgroups) * 16 + ((threadIdx.x >> 2) & 15);
-  if (row >= rows || k4 >= nk4) return;
-  f32x4 v = x3_ld4(a.src[i] + row * a.ld[i] + 4 * k4);
-  v *= a.scale[i];
-  const unsigned mb = amax_bits4(v, 0u);
-  v *= ldexpf(1.f, 14 - e);
-  st_split4h(dst, plane_stride, op_off(a.row0[i] + row, 4 * k4, K >> 4), v);
+  const float up = ldexpf(1.f, 14 - e);
+  unsigned mb = 0u;
+  // (pass 0: one position per workgroup; pass 1: a small grid that walks all of them in the rare case it has work)
+  for (long b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    const int k4 = (int)(b % kgroups) * 16 + (threadIdx.x >> 6) * 4 + (threadIdx.x & 3);
+    const long row = (b / kgroups) * 16 + ((threadIdx.x >> 2) & 15);
+    if (row >= rows || k4 >= nk4) continue;
+    f32x4 v = x3_ld4(a.src[i] + row * a.ld[i] + 4 * k4);
+    v *= a.scale[i];
+    mb = amax_bits4(v, mb);
+    v *= up;
+    st_split4h(dst, plane_stride, op_off(a.row0[i] + row, 4 * k4, K >> 4), v);
+  }
   if (pass == 0) amax_commit(hdr + X3_HDR, mb);
 }
 
@@ -868,8 +872,10 @@ void x3_split_group(const X3SplitJob* jobs, int njobs, float* hdr, int e0, hipSt
       const X3SplitJob& q = jobs[j];
       if (!q.ss.n) continue;
       const int nk4 = q.K / 4, kgroups = (nk4 + 15) / 16;
-      const dim3 grid((unsigned)(((long)(q.rows + 15) / 16) * kgroups), q.ss.n);
-      hipLaunchKernelGGL(x3_split_rows_kernel, grid, dim3(256), 0, s, q.ss, q.rows, q.K, q.dst, q.plane_stride, hdr, e0, pass);
+      const long nblocks = ((long)(q.rows + 15) / 16) * kgroups;
+      const dim3 grid((unsigned)(pass == 0 || nblocks < 1024 ? nblocks : 1024), q.ss.n);
+      hipLaunchKernelGGL(x3_split_rows_kernel, grid, dim3(256), 0, s, q.ss, q.rows, q.K, q.dst, q.plane_stride, hdr, e0, pass,
+                         nblocks);
     }
 }
 void x3_split(const SplitSrc& ss, int rows, int K, u16* dst, long plane_stride, int e0, hipStream_t s) {
@@ -893,11 +899,29 @@ inline bool x3_shape_ok(int n, int m, int D) {
 struct X3CostPlan {
   int tiles, nsplit, kt_per_split;
 };
+// OTGAN_MATCH_NARROW=1: the 256 x 128 tile kernel with two workgroups per compute unit (gemm_x3.h wino_bgemm_x3n_kernel, the
+// convolutions' GEMM since round 3) instead of the 256 x 256 one-workgroup kernel.  Measured at N = 1024, D = 32768 (a rank's
+// three cost slices / its plan application): 156 / 250 us against 145 / 242 us -- these contractions are thousands of stages
+// long, the second workgroup has no prologue or write-out to hide: default off.
+inline bool match_narrow() {
+  static const bool on = [] { const char* e = getenv("OTGAN_MATCH_NARROW"); return e && e[0] == '1'; }();
+  return on;
+}
+template <auto Kern>
+inline void x3n_ensure_lds() {
+  static const bool done = [] {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3N_LDS);
+    return true;
+  }();
+  (void)done;
+}
 inline X3CostPlan x3_plan_cost(int P, int n, int m, int D) {
   X3CostPlan c;
-  c.tiles = ceil_div(n, X3_BM) * ceil_div(m, X3_BN);
+  const bool narrow = match_narrow();
+  const int resident = narrow ? 512 : 256;
+  c.tiles = ceil_div(n, X3_BM) * ceil_div(m, narrow ? X3N_BN : X3_BN);
   const int nkt = D / X3_BK;
-  // The split count that minimises (rounds of 256 workgroups) x (granules per split + a workgroup's fixed cost: about four
+  // The split count that minimises (rounds of resident workgroups) x (granules per split + a workgroup's fixed cost: about four
   // granules of prologue and write-out, ten with a partial tile that is written and read again).  Round 4: until then ceil(256 / tiles) splits -- 12 tiles (a rank's three row
   // slices at N = 1024) became 264 workgroups, i.e. a second round for eight of them and twice the time (376 us, MFMA busy
   // 0.41 in profiles/r04_pmc_kernels_matching_N1024_D32768_rows256_rank.txt).
@@ -907,7 +931,8 @@ inline X3CostPlan x3_plan_cost(int P, int n, int m, int D) {
   int best = 1;
   for (int ns = 1; ns <= max_split && ns <= 256; ++ns) {
     const int kt = ceil_div(nkt, ns), real = ceil_div(nkt, kt);
-    const long t = (long)ceil_div(c.tiles * P * real, 256) * (kt + (real > 1 ? 10 : 4));   // (+ the partial tile's write-out and re-read)
+    if (nkt - (real - 1) * kt < 2) continue;                   // (the pipelined kernels need four stages in every split)
+    const long t = (long)ceil_div(c.tiles * P * real, resident) * (kt + (real > 1 ? 10 : 4));   // (+ the partial tile's write-out and re-read)
     if (best_t < 0 || t < best_t) { best_t = t; best = real; }
   }
   if (forced > 0) best = forced < max_split ? forced : max_split;
@@ -944,9 +969,16 @@ int launch_cost_x3(const u16* FP, long plane, long rows_total, const long* xrow,
   if (fuse) {   // K = -lambda (1 - dot) = lambda * dot - lambda
     b.epi = 1; b.epi_scale = lambda; b.epi_bias = -lambda;
   }
-  x3_ensure_lds<wino_bgemm_x3_kernel<true, false>>();
-  const dim3 grid(b.tiles_m * b.tiles_n, cp.nsplit, P);
-  hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, false>), grid, dim3(X3_THREADS), X3_LDS, s, b);
+  if (match_narrow()) {
+    b.tiles_n = ceil_div(m, X3N_BN);
+    b.x_total = (unsigned)(b.tiles_m * b.tiles_n);
+    x3n_ensure_lds<wino_bgemm_x3n_kernel<false>>();
+    hipLaunchKernelGGL((wino_bgemm_x3n_kernel<false>), dim3(b.x_total, cp.nsplit, P), dim3(X3_THREADS), X3N_LDS, s, b);
+  } else {
+    x3_ensure_lds<wino_bgemm_x3_kernel<true, false>>();
+    const dim3 grid(b.tiles_m * b.tiles_n, cp.nsplit, P);
+    hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, false>), grid, dim3(X3_THREADS), X3_LDS, s, b);
+  }
   OTGAN_CHECK_LAUNCH("cost GEMM (split precision)");
   if (fuse) return OTGAN_OK;
   FinishArgs fa;
@@ -993,10 +1025,16 @@ int launch_apply_x3(const X3ApplyBlock* blk, int nblk, const u16* PA_base, const
   b.C = base;
   b.kt_per_split = 1 << 28;    // one split: each block contracts over its whole zK
   ProfScope ps(OTGAN_PROF_PLAN_APPLY, flops, 0.0, s);
-  x3_ensure_lds<wino_bgemm_x3_kernel<true, true>>();
-  const dim3 grid(b.tiles_m * b.tiles_n, 1, nblk);
-  (void)minK;
-  hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, true>), grid, dim3(X3_THREADS), X3_LDS, s, b);
+  if (match_narrow() && minK >= 64 && minK % 32 == 0) {
+    b.tiles_n = ceil_div(D, X3N_BN);
+    b.x_total = (unsigned)(b.tiles_m * b.tiles_n);
+    x3n_ensure_lds<wino_bgemm_x3n_kernel<true>>();
+    hipLaunchKernelGGL((wino_bgemm_x3n_kernel<true>), dim3(b.x_total, 1, nblk), dim3(X3_THREADS), X3N_LDS, s, b);
+  } else {
+    x3_ensure_lds<wino_bgemm_x3_kernel<true, true>>();
+    const dim3 grid(b.tiles_m * b.tiles_n, 1, nblk);
+    hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, true>), grid, dim3(X3_THREADS), X3_LDS, s, b);
+  }
   OTGAN_CHECK_LAUNCH("plan application (split precision)");
   return OTGAN_OK;
 }
