@@ -193,9 +193,50 @@ __global__ void row_halfmeansq_kernel(const float* x, long ld, int rows, int D, 
 // half-sweep is bound by the CU's transcendental rate, 16384 v_exp_f32 per problem at 16 per clock = 0.5 us, plus
 // ~140 other VALU instructions per thread on two waves per SIMD, not by the barriers.  Kept this form: its plan
 // stores are fully coalesced.)
-__device__ __forceinline__ void small_half_step(const float (&kv)[32], const float* s_in,
+// Round 4 -- sweeps without exponentials.  With E = exp(K + f0 + g0) for potentials (f0, g0) of some earlier sweep and
+// u = exp(f - f0), v = exp(g - g0), the same two updates read u_i = 1 / sum_j E_ij v_j and v_j = 1 / sum_i E_ij u_i:
+// 32 multiply-adds per thread instead of 32 v_exp_f32 (a quarter-rate instruction: 16384 of them per problem and
+// half-sweep were what bounded the kernel) plus the max pass.  The iterates are the reference's (matching.py:52-54) up
+// to rounding; what the linear form cannot do is start: exp(K) underflows whole rows at lambda = 500.  So the kernel
+// runs the log-domain sweep until no potential moves by more than kLogSettle in a sweep (two or three sweeps),
+// materialises E once (as many exponentials as one sweep), and continues in the linear form; should a scaling factor
+// leave [e^-20, e^20] -- entries flushed to zero when E was made could begin to matter, or a sum overflow -- it folds u, v
+// into the potentials and goes back to the log-domain form (never observed past the first sweeps; a NaN takes the same
+// exit and stays loud).  The last half-step (the row softmax of matching.py:56) and the plan are log-domain as before.
+constexpr float kLogSettle = 5.f;                       // nats per sweep
+struct LinCtl {
+  int enabled;
+  float settle, lo, hi;    // kLogSettle; the scaling factors stay inside (lo, hi) = (e^-20, e^20)
+};
+// out[idx] = 1 / sum_e ev[e] * in[32 q + e]; true when some factor left (lo, hi) (or is not a number)
+__device__ __forceinline__ bool small_lin_step(const float (&ev)[32], const float* s_in, float* s_out,
+                                               float (*s_ps)[128], int idx, int q, int limit, const LinCtl& lc) {
+  const float4* in4 = reinterpret_cast<const float4*>(s_in + 32 * q);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float4 g = in4[c];
+    s0 = fmaf(ev[4 * c + 0], g.x, s0);
+    s1 = fmaf(ev[4 * c + 1], g.y, s1);
+    s2 = fmaf(ev[4 * c + 2], g.z, s2);
+    s3 = fmaf(ev[4 * c + 3], g.w, s3);
+  }
+  s_ps[q][idx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  bool far = false;
+  if (q == 0) {
+    const float S = (s_ps[0][idx] + s_ps[1][idx]) + (s_ps[2][idx] + s_ps[3][idx]);
+    const float u = idx < limit ? 1.f / S : 0.f;
+    s_out[idx] = u;
+    far = idx < limit && !(u > lc.lo && u < lc.hi);
+  }
+  return __syncthreads_or(far) != 0;
+}
+
+// returns true when some potential moved by more than kLogSettle (or is not a number)
+__device__ __forceinline__ bool small_half_step(const float (&kv)[32], const float* s_in,
                                                 float* s_out, float (*s_pm)[128],
-                                                float (*s_ps)[128], int idx, int q, int limit) {
+                                                float (*s_ps)[128], int idx, int q, int limit, float settle) {
   const float4* in4 = reinterpret_cast<const float4*>(s_in + 32 * q);
   float v[32];
   float mx = -3.0e38f;
@@ -214,14 +255,17 @@ __device__ __forceinline__ void small_half_step(const float (&kv)[32], const flo
   s_pm[q][idx] = mx;
   s_ps[q][idx] = s;
   __syncthreads();
+  bool moved = false;
   if (q == 0) {
     const float m0 = s_pm[0][idx], m1 = s_pm[1][idx], m2 = s_pm[2][idx], m3 = s_pm[3][idx];
     const float M = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
     const float S = s_ps[0][idx] * exp_neg(m0 - M) + s_ps[1][idx] * exp_neg(m1 - M) +
                     s_ps[2][idx] * exp_neg(m2 - M) + s_ps[3][idx] * exp_neg(m3 - M);
-    s_out[idx] = (idx < limit) ? -(M + logf(S)) : 0.f;
+    const float fresh = (idx < limit) ? -(M + logf(S)) : 0.f;
+    moved = !(fabsf(fresh - s_out[idx]) < settle);
+    s_out[idx] = fresh;
   }
-  __syncthreads();
+  return __syncthreads_or(moved) != 0;
 }
 
 __global__ __launch_bounds__(512) void sinkhorn_small_kernel(const float* __restrict__ Kmat,
@@ -229,7 +273,7 @@ __global__ __launch_bounds__(512) void sinkhorn_small_kernel(const float* __rest
                                                              float inv_lambda,
                                                              float* __restrict__ plan,
                                                              float* __restrict__ planT,
-                                                             double* __restrict__ stats) {
+                                                             double* __restrict__ stats, LinCtl lc) {
   const int p = blockIdx.x;
   const float* K = Kmat + (long)p * n * m;
   const int t = threadIdx.x, idx = t & 127, q = t >> 7;
@@ -256,11 +300,45 @@ __global__ __launch_bounds__(512) void sinkhorn_small_kernel(const float* __rest
   }
   __syncthreads();
 
+  __shared__ __attribute__((aligned(16))) float s_u[128];
+  __shared__ __attribute__((aligned(16))) float s_v[128];
+  float er[32], ec[32];
+  bool linear = false;
+  auto absorb = [&]() {   // back to potentials: f += log u, g += log v
+    if (t < n) s_f[t] += logf(s_u[t]);
+    if (t < m) s_g[t] += logf(s_v[t]);
+    __syncthreads();
+  };
   for (int it = 0; it < iters; ++it) {
-    small_half_step(kr, s_g, s_f, s_pm, s_ps, idx, q, n);  // rows:    f from g
-    small_half_step(kc, s_f, s_g, s_pm, s_ps, idx, q, m);  // columns: g from f
+    if (!linear) {
+      const bool mf = small_half_step(kr, s_g, s_f, s_pm, s_ps, idx, q, n, lc.settle);  // rows:    f from g
+      const bool mg = small_half_step(kc, s_f, s_g, s_pm, s_ps, idx, q, m, lc.settle);  // columns: g from f
+      if (!mf && !mg && it + 1 < iters && lc.enabled) {
+        // settled: E = exp(K + f + g) in both roles (masked entries: exp(-1e30) = 0), u = v = 1
+        const float fi = s_f[idx], gj = s_g[idx];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+          er[e] = expf(kr[e] + fi + s_g[32 * q + e]);
+          ec[e] = expf(kc[e] + s_f[32 * q + e] + gj);
+        }
+        if (t < 128) {
+          s_u[t] = 1.f;
+          s_v[t] = 1.f;
+        }
+        __syncthreads();
+        linear = true;
+      }
+    } else {
+      const bool fu = small_lin_step(er, s_v, s_u, s_ps, idx, q, n, lc);  // rows:    u from v
+      const bool fv = small_lin_step(ec, s_u, s_v, s_ps, idx, q, m, lc);  // columns: v from u
+      if (fu || fv) {
+        absorb();
+        linear = false;
+      }
+    }
   }
-  small_half_step(kr, s_g, s_f, s_pm, s_ps, idx, q, n);    // final row softmax (matching.py:56)
+  if (linear) absorb();
+  small_half_step(kr, s_g, s_f, s_pm, s_ps, idx, q, n, lc.settle);    // final row softmax (matching.py:56)
 
   // plan M_ij = exp(K_ij + f_i + g_j): column role writes M (coalesced along j), row role
   // writes M^T (coalesced along i) and the statistics.
@@ -385,111 +463,207 @@ __device__ __forceinline__ void panel_combine(float mx, float s, float* s_pm, fl
   }
 }
 
+// exp through the native 2^x unit for arguments of either sign (entries of E are at most e^kLogSettle)
+__device__ __forceinline__ float exp_native(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
+// the linear form's combine: the TPR partial sums of one line -> 1 / sum, published
+template <int TPR, int RPW>
+__device__ __forceinline__ void panel_combine_lin(float sum, float* s_ps, int line, int q, int gline, int N,
+                                                  unsigned long long* out_global, unsigned seq) {
+  s_ps[q * RPW + line] = sum;
+  __syncthreads();
+  if (q == 0) {
+    float S = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < TPR; ++k) S += s_ps[k * RPW + line];
+    int gl = gline;
+    asm volatile("" : "+v"(gl));
+    if (gline < N) publish_tagged(out_global + gl, 1.f / S, seq);
+  }
+}
+
+// Sweeps without exponentials as in sinkhorn_small_kernel (see there): xr / the column panel hold the log-kernel K while the
+// sweeps are log-domain and E = exp(K + f + g) while they are linear; s_f / s_g hold the potentials (of the last
+// log-domain sweep), s_u / s_v the scaling factors exchanged since.  Every workgroup of a problem consumes the same N
+// values per half-sweep and derives the mode from them alone (a flag word in LDS, four slots used in turn): the
+// workgroups of a problem switch together without talking about it.
 template <int TPR>  // slices per line: 8 (RPW 128, N <= 256), 16 (RPW 64, N <= 512), 32 (RPW 32)
-__global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs a) {
+__global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs a, LinCtl lc) {
   constexpr int RPW = kPanelThreads / TPR;
   extern __shared__ __attribute__((aligned(16))) float psm[];
-  float* s_kc = psm;                         // [TPR*32][RPW] column panel
-  float* s_pot = s_kc + TPR * 32 * RPW;      // [1024] potentials of the other side
-  float* s_pm = s_pot + 1024;                // [TPR][RPW]
+  float* s_kc = psm;                         // [TPR*32][RPW] column panel: K, or E in the linear sweeps
+  float* s_f = s_kc + TPR * 32 * RPW;        // [1024] row potentials (all rows of the problem)
+  float* s_g = s_f + 1024;                   // [1024] column potentials
+  float* s_u = s_g + 1024;                   // [1024] row scaling factors of the linear sweeps
+  float* s_v = s_u + 1024;                   // [1024]
+  float* s_pm = s_v + 1024;                  // [TPR][RPW]
   float* s_ps = s_pm + TPR * RPW;            // [TPR][RPW]
+  unsigned* s_flag = reinterpret_cast<unsigned*>(s_ps + TPR * RPW);   // [4]
   const int p = blockIdx.x / a.R, r = blockIdx.x % a.R;
   const int N = a.N;
   const float* K = a.K + (long)p * N * N;
   const int t = threadIdx.x, line = t % RPW, q = t / RPW;
   const int gline = r * RPW + line;  // global row (row role) / column (column role)
-  float kr[32];
+  float xr[32];
+  // index bases re-formed where they are used: left to itself the compiler keeps one loop-invariant LDS address per panel
+  // entry (32 registers, most of them spilled) instead of one base and immediate offsets
+  auto fresh = [](int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+  };
+  auto load_k = [&]() {
+    int gl = gline, q32 = q * 32;
+    asm volatile("" : "+v"(gl), "+v"(q32));   // (the addresses are formed here, not hoisted out of the sweep loop: 64 registers)
 #pragma unroll
-  for (int e = 0; e < 32; ++e) {
-    const int j = q * 32 + e;
-    kr[e] = (j < N && gline < N) ? K[(long)gline * N + j] : kNegBig;
-  }
+    for (int e = 0; e < 32; ++e) {
+      const int j = q32 + e;
+      xr[e] = (j < N && gl < N) ? K[(long)gl * N + j] : kNegBig;
+    }
+    const int kb = fresh(q * 32 * RPW + line);
 #pragma unroll 4
-  for (int e = 0; e < 32; ++e) {
-    const int i = q * 32 + e;
-    s_kc[i * RPW + line] = (i < N && gline < N) ? K[(long)i * N + gline] : kNegBig;
-  }
+    for (int e = 0; e < 32; ++e) {
+      const int i = q32 + e;
+      s_kc[kb + e * RPW] = (i < N && gl < N) ? K[(long)i * N + gl] : kNegBig;
+    }
+  };
   unsigned long long* f = a.f + (long)p * N;
   unsigned long long* g = a.g + (long)p * N;
   unsigned phase = 0;
-  s_pot[t] = 0.f;  // g = 0 (1024 threads cover the 1024 slots)
+  s_f[t] = 0.f;
+  s_g[t] = 0.f;  // g = 0 (1024 threads cover the 1024 slots)
+  if (t < 4) s_flag[t] = 0u;
   __syncthreads();
   bool ok = true;
-  for (int it = 0; it <= a.iters && ok; ++it) {
-    {  // rows: f from g (s_pot holds g); the extra pass it == iters is the final row softmax
-      // Two passes over the thread's 32 entries (max, then the shifted sum) WITHOUT keeping the 32 sums K + g in
-      // registers: with kr[32] they did not fit the 128 registers a 1024-thread workgroup leaves a lane (round 3:
-      // 23 - 27 spilled registers = scratch traffic inside the latency-critical loop).  The potentials are LDS
-      // broadcasts (every lane of a slice reads the same word): reading them twice costs less than the spills did.
-      float mx = -3.0e38f;
+  // one exchange: every thread takes slot t of `slots` into dst[t]; `mark` = this value asks for a mode change.
+  // Returns that request (the same in every workgroup of the problem); ok is cleared when a spin gave up.
+  auto consume_all = [&](const unsigned long long* slots, float* dst, auto&& mark) -> bool {
+    bool okl = true;
+    int tt = t;
+    asm volatile("" : "+v"(tt));      // (keeps the 64-bit slot addresses out of the loop-carried registers: they spilled)
+    const float val = t < N ? consume_tagged(slots + tt, phase, a.fail, okl) : 0.f;
+    const unsigned slot = phase & 3u;
+    if (t < N && mark(val, dst[t])) s_flag[slot] = 1u;
+    dst[t] = val;
+    ok = __syncthreads_and(okl) != 0;
+    const bool req = s_flag[slot] != 0u;
+    if (t == 0) s_flag[(slot + 2u) & 3u] = 0u;     // (last read two barriers ago, next written two half-sweeps from now)
+    return req;
+  };
+  auto log_rows = [&]() {   // f from g, published
+    // Two passes over the thread's 32 entries (max, then the shifted sum) WITHOUT keeping the 32 sums K + g in
+    // registers (round 3: 23 - 27 spilled registers inside the latency-critical loop).  The potentials are LDS
+    // broadcasts (every lane of a slice reads the same word): reading them twice costs less than the spills did.
+    const int q32 = fresh(q * 32);
+    float mx = -3.0e38f;
 #pragma unroll
-      for (int e = 0; e < 32; ++e) mx = fmaxf(mx, kr[e] + s_pot[q * 32 + e]);
-      float s = 0.f;
+    for (int e = 0; e < 32; ++e) mx = fmaxf(mx, xr[e] + s_g[q32 + e]);
+    float sm = 0.f;
 #pragma unroll
-      for (int e = 0; e < 32; ++e) s += exp_neg(kr[e] + s_pot[q * 32 + e] - mx);
-      panel_combine<TPR, RPW>(mx, s, s_pm, s_ps, line, q, gline, N, f, ++phase);
+    for (int e = 0; e < 32; ++e) sm += exp_neg(xr[e] + s_g[q32 + e] - mx);
+    panel_combine<TPR, RPW>(mx, sm, s_pm, s_ps, line, q, gline, N, f, ++phase);
+  };
+  auto moved = [&](float fresh, float old) { return !(fabsf(fresh - old) < lc.settle); };
+  auto far = [&](float fresh, float) { return !(fresh > lc.lo && fresh < lc.hi); };
+  bool linear = false, need_k = true;
+  auto absorb = [&]() {   // linear -> log: f += log u, g += log v; K comes back at the top of the loop (its one load site)
+    if (t < N) {
+      s_f[t] += logf(s_u[t]);
+      s_g[t] += logf(s_v[t]);
     }
-    {
-      bool okl = true;
-      int tt = t;
-      asm volatile("" : "+v"(tt));      // (keeps the 64-bit slot addresses out of the loop-carried registers: they spilled)
-      s_pot[t] = t < N ? consume_tagged(f + tt, phase, a.fail, okl) : 0.f;
-      ok = __syncthreads_and(okl) != 0;
+    linear = false;
+    need_k = true;
+  };
+  for (int it = 0;; ++it) {
+    if (it == a.iters && linear) absorb();
+    if (need_k) {
+      load_k();
+      __syncthreads();
+      need_k = false;
     }
-    if (it == a.iters || !ok) break;
-    {  // columns: g from f (s_pot holds f): the column panel lives in LDS; four chunks of eight keep the sums K + f of
-       // a chunk in registers between its max and its shifted sum (one LDS read per entry), merged online
-      float mx = -3.0e38f, s = 0.f;
+    if (it >= a.iters || !ok) break;
+    if (!linear) {
+      log_rows();
+      const bool mf = consume_all(f, s_f, moved);
+      if (!ok) break;
+      {  // columns: g from f: the column panel lives in LDS; four chunks of eight keep the sums K + f of a chunk in
+         // registers between its max and its shifted sum (one LDS read per entry), merged online
+        float mx = -3.0e38f, sm = 0.f;
+        const int q32 = fresh(q * 32), kb = fresh(q * 32 * RPW + line);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float v[8];
-        float m = -3.0e38f;
+        for (int c = 0; c < 4; ++c) {
+          float v[8];
+          float m = -3.0e38f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          v[e] = s_kc[(q * 32 + 8 * c + e) * RPW + line] + s_pot[q * 32 + 8 * c + e];
-          m = fmaxf(m, v[e]);
+          for (int e = 0; e < 8; ++e) {
+            v[e] = s_kc[kb + (8 * c + e) * RPW] + s_f[q32 + 8 * c + e];
+            m = fmaxf(m, v[e]);
+          }
+          float sc = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sc += exp_neg(v[e] - m);
+          const float mn = fmaxf(mx, m);
+          sm = sm * exp_neg(mx - mn) + sc * exp_neg(m - mn);
+          mx = mn;
         }
-        float sc = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sc += exp_neg(v[e] - m);
-        const float mn = fmaxf(mx, m);
-        s = s * exp_neg(mx - mn) + sc * exp_neg(m - mn);
-        mx = mn;
+        panel_combine<TPR, RPW>(mx, sm, s_pm, s_ps, line, q, gline, N, g, ++phase);
       }
-      panel_combine<TPR, RPW>(mx, s, s_pm, s_ps, line, q, gline, N, g, ++phase);
-    }
-    {
-      bool okl = true;
-      int tt = t;
-      asm volatile("" : "+v"(tt));
-      s_pot[t] = t < N ? consume_tagged(g + tt, phase, a.fail, okl) : 0.f;
-      ok = __syncthreads_and(okl) != 0;
+      const bool mg = consume_all(g, s_g, moved);
+      if (!ok) break;
+      if (lc.enabled && !mf && !mg && it + 1 < a.iters) {
+        // settled: E = exp(K + f + g) in both roles (masked entries: exp(-1e30) = 0), u = v = 1
+        const float fl = s_f[gline < N ? gline : 0], gl = s_g[gline < N ? gline : 0];
+        const int q32 = fresh(q * 32), kb = fresh(q * 32 * RPW + line);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) xr[e] = exp_native(xr[e] + fl + s_g[q32 + e]);
+#pragma unroll 4
+        for (int e = 0; e < 32; ++e) s_kc[kb + e * RPW] = exp_native(s_kc[kb + e * RPW] + s_f[q32 + e] + gl);
+        s_u[t] = 1.f;
+        s_v[t] = 1.f;
+        __syncthreads();
+        linear = true;
+      }
+    } else {
+      const int q32 = fresh(q * 32), kb = fresh(q * 32 * RPW + line);
+      float sm = 0.f;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) sm = fmaf(xr[e], s_v[q32 + e], sm);
+      panel_combine_lin<TPR, RPW>(sm, s_ps, line, q, gline, N, f, ++phase);
+      const bool fu = consume_all(f, s_u, far);
+      if (!ok) break;
+      sm = 0.f;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) sm = fmaf(s_kc[kb + e * RPW], s_u[q32 + e], sm);
+      panel_combine_lin<TPR, RPW>(sm, s_ps, line, q, gline, N, g, ++phase);
+      const bool fv = consume_all(g, s_v, far);
+      if (!ok) break;
+      if (fu || fv) absorb();
     }
   }
-  // here s_pot = final f (all rows); g of the last column step is in global memory.
+  if (ok) {   // the final row softmax (matching.py:56)
+    log_rows();
+    consume_all(f, s_f, moved);
+  }
+  // here s_f = final f (all rows), s_g = g of the last column step (all columns), xr / the panel = K
   // column role: plan[i][gline] = exp(K[i][gline] + f_i + g_gline), coalesced along the line
-  const float gl = gline < N ? value_of(g + gline) : 0.f;
+  const float gl = gline < N ? s_g[gline] : 0.f;
 #pragma unroll 4
   for (int e = 0; e < 32; ++e) {
     const int i = q * 32 + e;
     if (i < N && gline < N)
-      a.plan[(long)p * N * N + (long)i * N + gline] = expf(s_kc[i * RPW + line] + s_pot[i] + gl);
+      a.plan[(long)p * N * N + (long)i * N + gline] = expf(s_kc[i * RPW + line] + s_f[i] + gl);
   }
-  // row role: transposed plan and statistics; needs g for all columns
-  const float fl = gline < N ? s_pot[gline] : 0.f;
-  __syncthreads();
-  s_pot[t] = t < N ? value_of(g + t) : 0.f;
-  __syncthreads();
+  // row role: transposed plan and statistics
+  const float fl = gline < N ? s_f[gline] : 0.f;
   float h = 0.f, w = 0.f, sm = 0.f;
 #pragma unroll
   for (int e = 0; e < 32; ++e) {
     const int j = q * 32 + e;
     if (j < N && gline < N) {
-      const float lm = kr[e] + fl + s_pot[j];
+      const float lm = xr[e] + fl + s_g[j];
       const float mij = expf(lm);
       a.planT[(long)p * N * N + (long)j * N + gline] = mij;
       h -= mij * lm;
-      w -= mij * kr[e];
+      w -= mij * xr[e];
       sm += mij;
     }
   }
@@ -502,6 +676,25 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
   if (!ok && t == 0) a.stats[p * 4 + 3] = __builtin_nan("");
 }
 
+// OTGAN_SINKHORN_LINEAR=0: every sweep in the log domain (the kernels of rounds 1 - 3).  Test knobs:
+// OTGAN_SINKHORN_LIN_RANGE=<nats> (default 20) narrows the band of the scaling factors, OTGAN_SINKHORN_SETTLE=<nats>
+// (default 5) the entry condition -- tiny values force the fold-back path on every sweep.
+inline LinCtl lin_ctl() {
+  static const LinCtl c = [] {
+    LinCtl v;
+    const char* e = getenv("OTGAN_SINKHORN_LINEAR");
+    v.enabled = e && e[0] == '0' ? 0 : 1;
+    const char* r = getenv("OTGAN_SINKHORN_LIN_RANGE");
+    const float range = r && atof(r) > 0 ? (float)atof(r) : 20.f;
+    const char* st = getenv("OTGAN_SINKHORN_SETTLE");
+    v.settle = st && atof(st) > 0 ? (float)atof(st) : kLogSettle;
+    v.lo = expf(-range);
+    v.hi = expf(range);
+    return v;
+  }();
+  return c;
+}
+
 // The panel kernel spin-waits across its P*R workgroups, so ALL of them must be resident at once.
 // co_resident_capacity = (workgroups of this kernel one CU can host) x (CUs of the current device),
 // from the occupancy calculator -- on a partitioned / CU-masked device it is smaller than on the
@@ -511,7 +704,7 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
 template <int TPR>
 bool launch_panel(const PanelArgs& a, int P, hipStream_t s) {
   constexpr int RPW = kPanelThreads / TPR;
-  const size_t lds = sizeof(float) * ((size_t)TPR * 32 * RPW + 1024 + 2 * TPR * RPW);
+  const size_t lds = sizeof(float) * ((size_t)TPR * 32 * RPW + 4 * 1024 + 2 * TPR * RPW + 4);
   static thread_local int cap_dev = -1, capacity = 0;
   int dev = 0;
   hipGetDevice(&dev);
@@ -532,7 +725,7 @@ bool launch_panel(const PanelArgs& a, int P, hipStream_t s) {
   const char* lim = getenv("OTGAN_PANEL_MAX_WG");   // tests: pretend a smaller / partitioned device
   if (lim && atoi(lim) >= 0 && atoi(lim) < cap) cap = atoi(lim);
   if (P * a.R > cap) return false;
-  hipLaunchKernelGGL(sinkhorn_panel_kernel<TPR>, dim3(P * a.R), dim3(kPanelThreads), lds, s, a);
+  hipLaunchKernelGGL(sinkhorn_panel_kernel<TPR>, dim3(P * a.R), dim3(kPanelThreads), lds, s, a, lin_ctl());
   return true;
 }
 
@@ -1130,7 +1323,7 @@ int launch_sinkhorn(const float* K, int P, int n, int m, int iters, float lambda
   ProfScope ps(OTGAN_PROF_SINKHORN, 0.0, 0.0, s);
   if (n <= 128 && m <= 128) {
     hipLaunchKernelGGL(sinkhorn_small_kernel, dim3(P), dim3(512), 0, s, K, n, m, iters,
-                       1.f / lambda, plan, planT, stats);
+                       1.f / lambda, plan, planT, stats, lin_ctl());
     OTGAN_CHECK_LAUNCH("sinkhorn_small_kernel");
     return OTGAN_OK;
   }
