@@ -777,3 +777,43 @@ def test_glu_in_output_transform(dev, shape):
     # a layer the fused form does not cover rejects glu_out instead of ignoring it
     d2 = ops.make_desc(x0, C, False, 3, 3, 1, Cout, Cout, 0, 0)
     assert _lib.lib().otgan_conv2d_glu_fused(ctypes.byref(d2)) == 0
+
+
+@pytest.mark.gpu
+def test_dense_block_gradient_buffer_in_place(dev, monkeypatch):
+    """DenseBlockFunction.backward accumulates the earlier slices' gradients into the INCOMING gradient tensor when nothing
+    else references it (an engine-made tensor), and into a copy otherwise: a caller's `gradient=` tensor stays intact, a
+    gradient that torch's add hands to two blocks at once is not corrupted, and both paths give the same numbers."""
+    from otgan_amd import ops
+    gen = torch.Generator().manual_seed(21)
+    N, H, W, C0, L, F = 2, 8, 8, 32, 8, 16
+    x0 = torch.randn(N, H, W, C0, generator=gen).to(dev)
+    mk = lambda: [[(torch.randn(3, 3, (C0 + k * F) * 2, F, generator=gen) * 0.05).to(dev), (torch.rand(F, generator=gen) + 0.5).to(dev),
+                   (torch.randn(F, generator=gen) * 0.1).to(dev)] for k in range(L)]
+    PA, PB = mk(), mk()
+    w = torch.randn(N, H, W, C0 + L * F, generator=gen).to(dev)
+
+    def run(inplace):
+        monkeypatch.setattr(ops, "_GRAD_INPLACE", inplace)
+        ops.bump_weights_epoch()
+        xa, xb = x0.clone().requires_grad_(True), (0.5 * x0).requires_grad_(True)
+        pa = [[t.clone().requires_grad_(True) for t in p] for p in PA]
+        pb = [[t.clone().requires_grad_(True) for t in p] for p in PB]
+        ya = ops.dense_block_op(xa, (C0,), pa, 3, ops.ACT["crelu"])
+        yb = ops.dense_block_op(xb, (C0,), pb, 3, ops.ACT["crelu"])
+        # torch's add passes ONE gradient tensor to both blocks; the multiply makes it an engine-made tensor
+        loss = ((ya + yb) * w).sum() + (ya * ya).sum()
+        leaves = [xa, xb] + [t for p in pa + pb for t in p]
+        return torch.autograd.grad(loss, leaves)
+
+    g_in, g_cp = run(True), run(False)
+    for a, c in zip(g_in, g_cp):
+        assert torch.equal(a, c)
+    # a caller-owned gradient is never written to
+    monkeypatch.setattr(ops, "_GRAD_INPLACE", True)
+    xa = x0.clone().requires_grad_(True)
+    pa = [[t.clone().requires_grad_(True) for t in p] for p in PA]
+    ya = ops.dense_block_op(xa, (C0,), pa, 3, ops.ACT["crelu"])
+    gout = w.clone()
+    ya.backward(gradient=gout)
+    assert torch.equal(gout, w)
