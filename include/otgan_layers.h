@@ -78,7 +78,8 @@ typedef struct otgan_conv_desc {
    * filters made from FOLDED weights (a different tensor). */
   const float* w_amax;
   /* (round 4) x_amax may point to x_amax_count consecutive records (OTGAN_AMAX_RECORD_FLOATS floats apart); the bound used
-   * is their maximum.  0 or 1 = one record.  Only the growth-layer kernels (Cout = 16) read more than the first. */
+   * is their maximum.  0 or 1 = one record.  Read by the growth-layer kernels (Cout = 16) and by the Winograd passes of the
+   * strided 5x5 and the wide 3x3 stride-1 layers (as is dy_amax_count below); every other pass reads the first record only. */
   int x_amax_count;
   /* (round 4) CRELU / CELU list inputs: nonzero = every list element is exactly this many channels wide and lies at channel
    * i * list_width of x, i.e. the channel map is the per-element interleave [x_0, -x_0, x_1, -x_1, ...] of equal slices.
@@ -95,6 +96,8 @@ typedef struct otgan_conv_desc {
    * with OTGAN_ERR_ARG.  Same arithmetic as otgan_glu_fwd_amax_f32 on y: bit-identical. */
   float* glu_out;
   float* glu_amax_out;
+  /* (round 4) dy_amax points to this many consecutive records (see x_amax_count); 0 or 1 = one record. */
+  int dy_amax_count;
 } otgan_conv_desc;
 
 /*

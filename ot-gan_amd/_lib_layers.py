@@ -15,7 +15,7 @@ class ConvDesc(ctypes.Structure):
                 ("y_accumulate", c_int), ("x_operand", ctypes.c_void_p),
                 ("y_amax_out", ctypes.c_void_p), ("dx_amax_out", ctypes.c_void_p), ("w_amax", ctypes.c_void_p),
                 ("x_amax_count", c_int), ("list_width", c_int),
-                ("glu_out", ctypes.c_void_p), ("glu_amax_out", ctypes.c_void_p)]
+                ("glu_out", ctypes.c_void_p), ("glu_amax_out", ctypes.c_void_p), ("dy_amax_count", c_int)]
 
 
 P_DESC = ctypes.POINTER(ConvDesc)

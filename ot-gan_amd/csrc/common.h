@@ -148,6 +148,15 @@ __device__ __forceinline__ float amax_record_value(const float* rec) {
   }
   return __uint_as_float(m);
 }
+// maximum over `count` consecutive records (kAmaxSub * kAmaxSubStride floats apart); bit patterns: a NaN stays a NaN
+__device__ __forceinline__ float amax_records_value(const float* rec, int count) {
+  unsigned m = 0u;
+  for (int r = 0; r < count; ++r) {
+    const unsigned b = __float_as_uint(amax_record_value(rec + (long)r * kAmaxSub * kAmaxSubStride));
+    m = b > m ? b : m;
+  }
+  return __uint_as_float(m);
+}
 // exp(x) for x <= 0 (max-shifted) through the native 2^x unit.
 __device__ __forceinline__ float exp_neg(float x) {
   return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);

@@ -2293,6 +2293,8 @@ inline WinoS2Geo wino_s2_geo(const otgan_conv_desc* d, const Geo& g) {
   w.N = d->N; w.H = d->H; w.W = d->W; w.C = d->C; w.Ceff = g.Ceff; w.doubled = doubled_act(d->preact) ? 1 : 0;
   w.act = act_kind(d->preact); w.ldx = d->ldx; w.Cout = d->Cout; w.ldy = d->ldy; w.y_coff = d->y_coff;
   w.x_amax = d->x_amax; w.dy_amax = d->dy_amax;
+  w.x_amax_count = d->x_amax_count > 1 ? d->x_amax_count : 1;
+  w.dy_amax_count = d->dy_amax_count > 1 ? d->dy_amax_count : 1;
   w.y_amax_out = d->y_amax_out; w.dx_amax_out = d->dx_amax_out;
   w.w_amax = d->w_amax;
   w.plain = d->stride == 1 ? 1 : 0;

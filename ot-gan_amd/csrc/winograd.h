@@ -52,6 +52,7 @@ struct WinoS2Geo {
   int Cout, ldy, y_coff;
   const float* x_amax = nullptr;
   const float* dy_amax = nullptr;
+  int x_amax_count = 1, dy_amax_count = 1;   // consecutive records behind x_amax / dy_amax (their maximum counts)
   // 1: a 3x3 stride-1 layer instead (the block-input convolution of a DenseNet block, ops.py DenseBlockFunction):
   // ONE class on the full H x W grid (multiples of 4), taps taken as they are, nothing structurally zero;
   // wT: [Cout][9*Ceff], w: [9][Ceff][Cout].  Same kernels, same three passes.

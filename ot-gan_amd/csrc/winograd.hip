@@ -219,6 +219,7 @@ struct AmaxArgs {
   float fold;           // taps summed into one filter tap before the transform (1, or 4 for un-folded upsampling filters)
   int floor_one;        // ELU / CELU applied inside the transform: |act(x)| <= max(|x|, 1)
   int record_only;      // hdr is an amax RECORD (common.h): sub-slot 0 = the maximum, the other sub-slots 0, no scales
+  int nrec;             // scales_from_amax_kernel: x points to this many consecutive records (their maximum counts)
   float* scratch;
   unsigned* counter;
 };
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(AmaxArgs a) {
   if (tid == 0) *a.counter = 0;
 }
 // the 36 scales from an amax record the caller already has (a.x = the record)
-__global__ __launch_bounds__(64) void scales_from_amax_kernel(AmaxArgs a) { write_scales(a, amax_record_value(a.x), threadIdx.x); }
+__global__ __launch_bounds__(64) void scales_from_amax_kernel(AmaxArgs a) { write_scales(a, amax_records_value(a.x, a.nrec), threadIdx.x); }
 
 // ---- streaming kernels --------------------------------------------------------------------
 // A "view" of a small-grid image: element (n, a, b, c) at p[n*sn + a*sh + b*sw + c].
@@ -350,6 +351,7 @@ struct WView {
 // operand less, 17 per DCGAN step).  Same arithmetic as write_scales().
 struct ScaleSrc {
   const float* rec;
+  int nrec;            // consecutive records behind rec (otgan_conv_desc::x_amax_count / dy_amax_count)
   float gain[WA];
   float fold;
   int floor_one;
@@ -362,7 +364,7 @@ __device__ __forceinline__ void producer_scale_table(const ScaleSrc& ss, u16* P,
       float* hdr = reinterpret_cast<float*>(P) - X3_HDR;
       float sc;
       if (ss.rec) {
-        float amax = amax_record_value(ss.rec);
+        float amax = amax_records_value(ss.rec, ss.nrec);
         if (ss.floor_one && amax == amax) amax = fmaxf(amax, 1.f);
         const int i = tid / WA, j = tid - i * WA;
         const float bound = amax * ss.fold * (ss.gain[i] * ss.gain[j]);
@@ -1443,10 +1445,12 @@ AmaxScratch& amax_scratch() {
 // scales of the operand at `base` (header) for a transform with row gains `gain` of the tensor x[rows][C] (row stride
 // ld); `given`: the caller's amax record of that tensor (otgan_layers.h) -- then only the 36 scales are computed
 void op_scales(const float* x, long rows, int C, long ld, float* base, const float (&gain)[WA], float fold, bool floor_one,
-               hipStream_t s, const float* given = nullptr, bool record_only = false, bool record_accumulate = false) {
+               hipStream_t s, const float* given = nullptr, bool record_only = false, bool record_accumulate = false,
+               int given_count = 1) {
   if (X3_NP != 2) return;   // three bf16 pieces carry the full exponent range: no scales
   static std::atomic<unsigned> seq{0};
   AmaxArgs a;
+  a.nrec = given_count > 1 ? given_count : 1;
   a.x = x; a.rows = rows; a.ld = rows == 1 ? C : ld; a.C = C; a.hdr = base;
   for (int i = 0; i < WA; ++i) a.gain[i] = gain[i];
   a.fold = fold; a.floor_one = floor_one ? 1 : 0;
@@ -1527,18 +1531,20 @@ int wgrad_splits(const WinoGeo& g) {
 // caller's amax record the producer derives them itself (ScaleSrc) -- no launch; without one, the reduction as before.
 // OTGAN_INKERNEL_SCALES=0: always the separate launch.
 void producer_scales(InArgs& ia, const float* x, long rows, int C, long ld, float* base, const float (&gain)[WA], float fold,
-                     bool floor_one, hipStream_t s, const float* given) {
+                     bool floor_one, hipStream_t s, const float* given, int given_count = 1) {
   ia.ss.rec = nullptr;
+  ia.ss.nrec = 1;
   if (X3_NP != 2) return;
   static const bool inkernel = [] { const char* e = getenv("OTGAN_INKERNEL_SCALES"); return !(e && e[0] == '0'); }();
   if (given && inkernel) {
     ia.ss.rec = given;
+    ia.ss.nrec = given_count > 1 ? given_count : 1;
     for (int i = 0; i < WA; ++i) ia.ss.gain[i] = gain[i];
     ia.ss.fold = fold;
     ia.ss.floor_one = floor_one ? 1 : 0;
     return;
   }
-  op_scales(x, rows, C, ld, base, gain, fold, floor_one, s, given);
+  op_scales(x, rows, C, ld, base, gain, fold, floor_one, s, given, false, false, given_count);
 }
 void wino_absmax(const float* x, long rows, int C, long ld, float* record, hipStream_t s, bool accumulate) {
   const float unit[WA] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
@@ -1832,7 +1838,7 @@ void s2_input_transform(const WinoS2Geo& g, const float* x, float* V, u16* VP, h
   // (the activation is applied inside the transform: |relu(+-x)| <= |x|, |elu(x)| <= max(|x|, 1))
   InArgs ia;
   memset(&ia, 0, sizeof(ia));
-  if (VP) producer_scales(ia, x, (long)g.N * (g.H >> g.up) * (g.W >> g.up), g.C, g.ldx, reinterpret_cast<float*>(VP) - X3_HDR, kGainBt, 1.f, g.act == 2, s, g.x_amax);
+  if (VP) producer_scales(ia, x, (long)g.N * (g.H >> g.up) * (g.W >> g.up), g.C, g.ldx, reinterpret_cast<float*>(VP) - X3_HDR, kGainBt, 1.f, g.act == 2, s, g.x_amax, g.x_amax_count);
   ia.s2_skip = -1;
   s2_views(g, x, g.ldx, ia.v);
   if (g.up) {   // the stored image is half the grid (plain layers only)
@@ -1963,7 +1969,7 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   ia.H = OH; ia.W = OW; ia.TH = OH / WM; ia.TW = OW / WM; ia.C = g.Cout; ia.T = T; ia.ldv = Kp; ia.V = DV;
   ia.P = VP;
   ia.Cpad = Kp;
-  if (x3) producer_scales(ia, dy + g.y_coff, (long)g.N * OH * OW, g.Cout, g.ldy, DV, kGainBt, 1.f, false, s, g.dy_amax);
+  if (x3) producer_scales(ia, dy + g.y_coff, (long)g.N * OH * OW, g.Cout, g.ldy, DV, kGainBt, 1.f, false, s, g.dy_amax, g.dy_amax_count);
   hipLaunchKernelGGL((wino_input_kernel<0, false>), dim3(op_grid(T, Kp / 4), 1, 1), dim3(256), 0, s, ia);
   BgArgs b;
   memset(&b, 0, sizeof(b));
@@ -2020,7 +2026,7 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
     da.s2_skip = -1;
     da.v[0].p = dy + g.y_coff; da.v[0].sn = (long)OH * OW * g.ldy; da.v[0].sh = (long)OW * g.ldy; da.v[0].sw = g.ldy;
     da.H = OH; da.W = OW; da.TH = OH / WM; da.TW = OW / WM; da.C = g.Cout; da.T = T; da.ldv = g.Cout; da.P = MP;
-    producer_scales(da, dy + g.y_coff, (long)g.N * OH * OW, g.Cout, g.ldy, Mb, kGainA, 1.f, false, s, g.dy_amax);
+    producer_scales(da, dy + g.y_coff, (long)g.N * OH * OW, g.Cout, g.ldy, Mb, kGainA, 1.f, false, s, g.dy_amax, g.dy_amax_count);
     hipLaunchKernelGGL(wino_outadj_kernel, dim3(op_grid(T, g.Cout / 4), 1, 1), dim3(256), 0, s, da);
     BgArgs b;
     memset(&b, 0, sizeof(b));

@@ -767,14 +767,17 @@ class DenseBlockFunction(torch.autograd.Function):
                 wd, ops_ = plan["wide"][i], sw["wide"][i]
                 desc = wd["desc"]
                 src = buf[..., wd["x_off"]:]       # channel slice: same rows, pointer advanced by x_off floats
+                nrec = 1
                 if shared and i == 0 and rec_x0 is not None:
                     rec = rec_x0
                 elif shared and i > 0:
-                    rec = R[gbase[i - 1]:gbase[i]].amax(0)      # the finished slices of the group that feeds this convolution
+                    # the finished slices of the group that feeds this convolution: its rows of R as they are
+                    # (otgan_conv_desc::x_amax_count consecutive records; until round 4 an amax over them: one launch)
+                    rec, nrec = R[gbase[i - 1]:gbase[i]], gbase[i] - gbase[i - 1]
                 else:
                     rec = absmax_record_strided(src.data_ptr(), rows, wd["C"], Ctot, buf.device)
-                ctx.x_recs.append(rec)
-                desc.x_amax = rec.data_ptr()
+                ctx.x_recs.append((rec, nrec))
+                desc.x_amax, desc.x_amax_count = rec.data_ptr(), nrec
                 if any(ctx.needs_input_grad[4:]):
                     ctx.x_ops.append(shared_x_operand(desc, buf.device))    # read back by this convolution's wgrad
                 desc.y_accumulate = wd["accumulate"]
@@ -782,6 +785,7 @@ class DenseBlockFunction(torch.autograd.Function):
                 conv_fwd_raw(desc, src, None, ops_["wT"], None if wd["accumulate"] else bias_all, buf, ops_["fwd"])
                 desc.y_accumulate = 0
                 desc.y_amax_out = None
+                desc.x_amax_count = 0
 
             wide_fwd(0)
             chain_h2 = shared and plan.get("h2") and all(sw["h2"][k] is not None for k in range(L) if plan["own_len"][k])
@@ -835,7 +839,7 @@ class DenseBlockFunction(torch.autograd.Function):
             ctx.save_for_backward(buf, *saved)
             ctx.descs, ctx.maps = descs, maps
             if shared:
-                x0_rec = ctx.x_recs[0]     # the producer's record of x0, or the reduction wide_fwd(0) made
+                x0_rec = ctx.x_recs[0][0]     # the producer's record of x0, or the reduction wide_fwd(0) made
                 tag_amax(buf, torch.maximum(x0_rec, R.amax(0)))
             return buf
 
@@ -887,7 +891,7 @@ class DenseBlockFunction(torch.autograd.Function):
                 src, gsrc = buf[..., wd["x_off"]:], G[..., wd["x_off"]:]
                 n_out = (L - wd["d0"]) * F
                 dy_rec = absmax_record_strided(G.data_ptr() + 4 * (C0 + wd["d0"] * F), rows, n_out, Ctot, G.device)
-                desc.x_amax = ctx.x_recs[i].data_ptr()
+                desc.x_amax, desc.x_amax_count = ctx.x_recs[i][0].data_ptr(), ctx.x_recs[i][1]
                 desc.dy_amax = dy_rec.data_ptr()
                 if need_w:
                     dw = torch.empty_like(ops_["w"])
@@ -898,6 +902,7 @@ class DenseBlockFunction(torch.autograd.Function):
                         ops_["bwd"], ops_["bwd_done"] = prepare_filters(desc, 1, ops_["w"]), True
                     conv_dgrad_raw(desc, G, ops_["w"], src, None, gsrc, Ctot, True, ops_["bwd"])
                 desc.dy_amax = None
+                desc.x_amax_count = 0
 
             for k in reversed(range(L)):
                 for i in reversed(range(1, len(plan["wide"]))):
@@ -1028,18 +1033,20 @@ def _backward_by_slice(ctx, buf, saved, G, dbuf, need_w):
     bw = _dense16_bwd_filters(sw, plan, L, F, buf.device)
     # records: Rc bounds the incoming gradient and everything the wide convolutions' input gradients add; RS[c] what the
     # slice kernel of slice c leaves.  A reader takes the maximum of Rc and the rows of the slices it reads.
+    # One array: rows [0, L) = RS, row L = Rc -- a reader of the slices from d0 on passes rows [d0, L] as they are
+    # (otgan_conv_desc::dy_amax_count consecutive records; until round 4 an amax over the rows and a maximum with Rc: two launches).
     tag = amax_of(dbuf)
-    Rc = tag.clone() if tag is not None else absmax_record(G)
-    RS = torch.zeros((L, AMAX_RECORD_FLOATS), dtype=torch.float32, device=buf.device)
+    RR = torch.zeros((L + 1, AMAX_RECORD_FLOATS), dtype=torch.float32, device=buf.device)
+    RS, Rc = RR[:L], RR[L]
+    Rc.copy_(tag if tag is not None else absmax_record(G))
     gptr, bptr = G.data_ptr(), buf.data_ptr()
 
     def wide_bwd(i, need_dx):
         wd, ops_ = wides[i], sw["wide"][i]
         desc = wd["desc"]
         src, gsrc = buf[..., wd["x_off"]:], G[..., wd["x_off"]:]
-        dy_rec = torch.maximum(Rc, RS[wd["d0"]:].amax(0))
-        desc.x_amax = ctx.x_recs[i].data_ptr()
-        desc.dy_amax = dy_rec.data_ptr()
+        desc.x_amax, desc.x_amax_count = ctx.x_recs[i][0].data_ptr(), ctx.x_recs[i][1]
+        desc.dy_amax, desc.dy_amax_count = RR[wd["d0"]].data_ptr(), L + 1 - wd["d0"]
         if need_w:
             dw = torch.empty_like(ops_["w"])
             conv_wgrad_raw(desc, src, None, G, dw)
@@ -1051,6 +1058,7 @@ def _backward_by_slice(ctx, buf, saved, G, dbuf, need_w):
             conv_dgrad_raw(desc, G, ops_["w"], src, None, gsrc, Ctot, True, ops_["bwd"])
             desc.dx_amax_out = None
         desc.dy_amax = None
+        desc.dy_amax_count = desc.x_amax_count = 0
 
     starts = [wd["d0"] for wd in wides] + [L]
     for gi in reversed(range(len(wides))):
