@@ -90,10 +90,10 @@ struct FinishArgs {
   float* K;  // [P][n][m]
 };
 
-// Sum of the K-split partial sums + the cost epilogue.  Round 4: the N = 128 case (128 splits of a 0.39 MB result = 50 MB)
-// ran at 1.5 TB/s with one output and 128 dependent-looking 4-byte loads per thread, 1.5 workgroups per compute unit;
-// now a workgroup owns 256 consecutive float4 outputs... (cost_finish4_kernel below) -- this scalar kernel stays for
-// totals that are not a multiple of 4.
+// Sum of the K-split partial sums + the cost epilogue, one output per thread.  Round 4: at N = 128 (128 splits of a
+// 0.39 MB result = 50 MB of partial sums) this form ran at 1.5 TB/s -- 128 four-byte loads per thread, 1.5 workgroups
+// per compute unit; cost_finish4_kernel below (float4 outputs, the splits shared by four waves) took its place and
+// this kernel stays for totals that are not a multiple of 4 or fewer than four splits.
 __global__ void cost_finish_kernel(FinishArgs a) {
   const long per = (long)a.n * a.m;
   const long total = per * a.P;
@@ -958,13 +958,15 @@ __global__ void closed_form_single_distance_kernel(const double* stats, int n, d
 }
 
 // ======================================================================================
-// 5. The matching GEMMs on the bf16 matrix pipe with split-precision operands (gemm_x3.h)
+// 5. The matching GEMMs on the fp16 matrix pipe with split-precision operands (gemm_x3.h)
 // ======================================================================================
 // For N >= 256 (the 64x64 configuration and the multi-GPU problems) both GEMM families of the block run on
-// the 256 x 256 split-precision engine that carries the convolutions: every fp32 operand is three bf16
-// planes (hi + mid + lo = the full 24-bit significand), six MFMAs per product, fp32 accumulate -- measured
-// 2e-7 .. 5e-7 rel. L2 against fp64, i.e. the lambda-amplified cost GEMM keeps its full fp32 accuracy
-// (SURVEY 7.3-c asks for exactly this; plain bf16 / fp16 inputs fail the 1e-4 loss bound).
+// the 256 x 256 split-precision engine that carries the convolutions.  Round 4: every fp32 operand is two
+// scaled fp16 planes (x 2^s = hi + lo: 22 significand bits, three MFMAs per product, fp32 accumulate) -- rounds
+// 2 - 3 kept three bf16 planes here (24 bits, six MFMAs) because the log-kernel amplifies the dot product's
+// error by lambda; measured, the error of a D = 32768 dot product is the fp32 ACCUMULATION's (max |K - fp64|
+// 1.6e-4 at lambda = 500 with either operand form, 1.7e-3 with two K splits instead of 21: longer fp32 chains),
+// not the operands'.  Plain fp16 / bf16 inputs still fail the 1e-4 loss bound.
 //   * the stacked features [a1; a2; b1; b2] are split ONCE into the blocked operand layout (op_off): the cost
 //     GEMMs read it as the row-major NT operand (rows = samples, k = D), the plan application reads the same
 //     buffer as its t-leading B operand (rows = contraction index = samples, columns = D);
@@ -1415,9 +1417,9 @@ struct MatchWs {
   double* dot3;    // [3]
   // split-precision path (x3_shape_ok): stacked feature operand [fa; fb] and the plans as t-leading operands
   bool x3;
-  u16* FP;         // 3 planes x [2 * feat_rows][D]
-  u16* PT;         // 3 planes x [P * n][n]   (transposed plans: A operand of M . F)
-  u16* PM;         // 3 planes x [P * n][n]   (plans: A operand of M^T . F)
+  u16* FP;         // X3_NP planes x [2 * feat_rows][D], each operand behind its header + amax record (x3_hdr)
+  u16* PT;         // X3_NP planes x [P * n][n]   (transposed plans: A operand of M . F)
+  u16* PM;         // X3_NP planes x [P * n][n]   (plans: A operand of M^T . F)
   long planeF, planeP;
   size_t bytes;
 };

@@ -5,8 +5,11 @@ leaves room for other workgroups on its compute unit, which is what happens when
 gloo tests) or a collective's kernels overlap the backward pass.  Found the hard way: the RGB-in forward kernel's
 packed fp32 FMAs returned wrong values in lanes 48-63 in 60 % of the launches with a GEMM wave on the same SIMD
 (it now uses scalar FMAs; round 3's RGB-out input-gradient kernel reproduced the same signature and got the same cure,
-and every translation unit except the Winograd transforms is built without packed fp32, csrc/Makefile); this test keeps
-every kernel family of a DCGAN / DenseNet step honest as the neighbour."""
+and every translation unit except the Winograd transforms is built without packed fp32, csrc/Makefile).  Round 4 found
+the mechanism (tools/debug/corun_probe.*: a packed fp32 instruction with OP_SEL on SRC1 is the one
+form that returns wrong low halves beside a wave with MFMAs and LDS-DMA loads in flight; tests/test_isa_cpu.py asserts
+that the built library contains none); this test keeps every kernel family of a DCGAN / DenseNet step honest as the
+neighbour all the same."""
 import os
 import subprocess
 import sys
