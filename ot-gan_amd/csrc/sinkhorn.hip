@@ -185,33 +185,58 @@ __global__ void row_halfmeansq_kernel(const float* x, long ld, int rows, int D, 
 // ======================================================================================
 
 // ---- 2a. n, m <= 128: one 512-thread workgroup per problem, K resident in registers ------
-// Thread (idx = t & 127, q = t >> 7) holds row-role values K[idx][32q..32q+31] and
-// column-role values K[32q..32q+31][idx]; potentials live in LDS.  Per half-sweep: each
-// thread reduces its 32 values, the four quarter-partials are combined through LDS.
-// (Round 2 tried the four partials of a line in adjacent lanes, combined with two DPP exchanges and ONE barrier
-// per half-sweep instead of two: 1.12 us per half-sweep against 1.07 us for this form at N = 128 -- the
-// half-sweep is bound by the CU's transcendental rate, 16384 v_exp_f32 per problem at 16 per clock = 0.5 us, plus
-// ~140 other VALU instructions per thread on two waves per SIMD, not by the barriers.  Kept this form: its plan
-// stores are fully coalesced.)
+// Thread (idx = t >> 2, q = t & 3) holds row-role values K[idx][32q..32q+31] and column-role values K[32q..32q+31][idx];
+// potentials live in LDS.  The four slices of a line sit in ADJACENT lanes: a half-sweep is 32 entries per thread, two
+// quad exchanges (DPP) and ONE barrier.  (Rounds 1 - 3 had the slices 128 threads apart and combined them through LDS
+// with two barriers: round 2 measured this quad form at 1.12 us per half-sweep against 1.07 us, because the half-sweep was
+// bound by the transcendental rate -- 16384 v_exp_f32 per problem at 16 per clock = 0.5 us -- and the LDS form stored the
+// plan fully coalesced.  With the exponentials gone from most sweeps (below) the barriers and LDS round trips were what
+// was left: 0.77 us per linear half-sweep in the LDS form.)
+//
 // Round 4 -- sweeps without exponentials.  With E = exp(K + f0 + g0) for potentials (f0, g0) of some earlier sweep and
 // u = exp(f - f0), v = exp(g - g0), the same two updates read u_i = 1 / sum_j E_ij v_j and v_j = 1 / sum_i E_ij u_i:
-// 32 multiply-adds per thread instead of 32 v_exp_f32 (a quarter-rate instruction: 16384 of them per problem and
-// half-sweep were what bounded the kernel) plus the max pass.  The iterates are the reference's (matching.py:52-54) up
-// to rounding; what the linear form cannot do is start: exp(K) underflows whole rows at lambda = 500.  So the kernel
-// runs the log-domain sweep until no potential moves by more than kLogSettle in a sweep (two or three sweeps),
-// materialises E once (as many exponentials as one sweep), and continues in the linear form; should a scaling factor
-// leave [e^-20, e^20] -- entries flushed to zero when E was made could begin to matter, or a sum overflow -- it folds u, v
-// into the potentials and goes back to the log-domain form (never observed past the first sweeps; a NaN takes the same
-// exit and stays loud).  The last half-step (the row softmax of matching.py:56) and the plan are log-domain as before.
+// 32 multiply-adds per thread instead of 32 v_exp_f32 plus the max pass.  The iterates are the reference's
+// (matching.py:52-54) up to rounding; what the linear form cannot do is start: exp(K) underflows whole rows at
+// lambda = 500.  So the kernel runs the log-domain sweep until no potential moves by more than kLogSettle in a sweep (two
+// or three sweeps), materialises E once (as many exponentials as one sweep), and continues in the linear form; should a
+// scaling factor leave [e^-20, e^20] -- entries flushed to zero when E was made could begin to matter, or a sum overflow --
+// it folds u, v into the potentials and goes back to the log-domain form (a NaN takes the same exit and stays loud).  The
+// last half-step (the row softmax of matching.py:56) and the plan are log-domain as before.
 constexpr float kLogSettle = 5.f;                       // nats per sweep
 struct LinCtl {
   int enabled;
   float settle, lo, hi;    // kLogSettle; the scaling factors stay inside (lo, hi) = (e^-20, e^20)
+  int poll_delay;          // panel kernel: s_sleep units (64 clocks) between publishing and the first poll of an exchange
 };
+// value of lane (l ^ 1) / (l ^ 2) of the quad (DPP quad_perm [1,0,3,2] / [2,3,0,1])
+__device__ __forceinline__ float quad_xor1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xor2(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+// potentials of line i live at s[pot_slot(i)]: 36 floats per 32 lines, so that the four slices a quad reads at once (one
+// float4 each, 32 lines apart) fall into different LDS banks
+__device__ __forceinline__ int pot_slot(int i) { return i + 4 * (i >> 5); }
+constexpr int kPotFloats = 4 * 36;
+
+// "does any thread of the workgroup say yes", behind ONE barrier (the library's __syncthreads_or costs three): the yes
+// goes to a flag word in LDS, four words used in turn -- the word of this call was cleared two calls ago, and thread 0
+// clears the one two calls ahead behind the barrier (nobody reads or writes that one now).
+__device__ __forceinline__ bool block_any(bool yes, unsigned* s_flag, unsigned& turn) {
+  const unsigned slot = turn & 3u;
+  ++turn;
+  if (yes) s_flag[slot] = 1u;
+  __syncthreads();
+  const bool any = s_flag[slot] != 0u;
+  if (threadIdx.x == 0) s_flag[(slot + 2u) & 3u] = 0u;
+  return any;
+}
+
 // out[idx] = 1 / sum_e ev[e] * in[32 q + e]; true when some factor left (lo, hi) (or is not a number)
-__device__ __forceinline__ bool small_lin_step(const float (&ev)[32], const float* s_in, float* s_out,
-                                               float (*s_ps)[128], int idx, int q, int limit, const LinCtl& lc) {
-  const float4* in4 = reinterpret_cast<const float4*>(s_in + 32 * q);
+__device__ __forceinline__ bool small_lin_step(const float (&ev)[32], const float* s_in, float* s_out, int idx, int q,
+                                               int limit, const LinCtl& lc, unsigned* s_flag, unsigned& turn) {
+  const float4* in4 = reinterpret_cast<const float4*>(s_in + 36 * q);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
@@ -221,23 +246,22 @@ __device__ __forceinline__ bool small_lin_step(const float (&ev)[32], const floa
     s2 = fmaf(ev[4 * c + 2], g.z, s2);
     s3 = fmaf(ev[4 * c + 3], g.w, s3);
   }
-  s_ps[q][idx] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
+  float S = (s0 + s1) + (s2 + s3);
+  S += quad_xor1(S);
+  S += quad_xor2(S);                 // (s_q0 + s_q1) + (s_q2 + s_q3) in every lane of the quad
   bool far = false;
   if (q == 0) {
-    const float S = (s_ps[0][idx] + s_ps[1][idx]) + (s_ps[2][idx] + s_ps[3][idx]);
     const float u = idx < limit ? 1.f / S : 0.f;
-    s_out[idx] = u;
+    s_out[pot_slot(idx)] = u;
     far = idx < limit && !(u > lc.lo && u < lc.hi);
   }
-  return __syncthreads_or(far) != 0;
+  return block_any(far, s_flag, turn);
 }
 
-// returns true when some potential moved by more than kLogSettle (or is not a number)
-__device__ __forceinline__ bool small_half_step(const float (&kv)[32], const float* s_in,
-                                                float* s_out, float (*s_pm)[128],
-                                                float (*s_ps)[128], int idx, int q, int limit, float settle) {
-  const float4* in4 = reinterpret_cast<const float4*>(s_in + 32 * q);
+// log-domain half-step; returns true when some potential moved by more than `settle` (or is not a number)
+__device__ __forceinline__ bool small_half_step(const float (&kv)[32], const float* s_in, float* s_out, int idx, int q,
+                                                int limit, float settle, unsigned* s_flag, unsigned& turn) {
+  const float4* in4 = reinterpret_cast<const float4*>(s_in + 36 * q);
   float v[32];
   float mx = -3.0e38f;
 #pragma unroll
@@ -252,20 +276,18 @@ __device__ __forceinline__ bool small_half_step(const float (&kv)[32], const flo
   float s = 0.f;
 #pragma unroll
   for (int e = 0; e < 32; ++e) s += exp_neg(v[e] - mx);
-  s_pm[q][idx] = mx;
-  s_ps[q][idx] = s;
-  __syncthreads();
+  float M = fmaxf(mx, quad_xor1(mx));
+  M = fmaxf(M, quad_xor2(M));
+  float S = s * exp_neg(mx - M);
+  S += quad_xor1(S);
+  S += quad_xor2(S);
   bool moved = false;
   if (q == 0) {
-    const float m0 = s_pm[0][idx], m1 = s_pm[1][idx], m2 = s_pm[2][idx], m3 = s_pm[3][idx];
-    const float M = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-    const float S = s_ps[0][idx] * exp_neg(m0 - M) + s_ps[1][idx] * exp_neg(m1 - M) +
-                    s_ps[2][idx] * exp_neg(m2 - M) + s_ps[3][idx] * exp_neg(m3 - M);
     const float fresh = (idx < limit) ? -(M + logf(S)) : 0.f;
-    moved = !(fabsf(fresh - s_out[idx]) < settle);
-    s_out[idx] = fresh;
+    moved = !(fabsf(fresh - s_out[pot_slot(idx)]) < settle);
+    s_out[pot_slot(idx)] = fresh;
   }
-  return __syncthreads_or(moved) != 0;
+  return block_any(moved, s_flag, turn);
 }
 
 __global__ __launch_bounds__(512) void sinkhorn_small_kernel(const float* __restrict__ Kmat,
@@ -276,12 +298,15 @@ __global__ __launch_bounds__(512) void sinkhorn_small_kernel(const float* __rest
                                                              double* __restrict__ stats, LinCtl lc) {
   const int p = blockIdx.x;
   const float* K = Kmat + (long)p * n * m;
-  const int t = threadIdx.x, idx = t & 127, q = t >> 7;
-  __shared__ __attribute__((aligned(16))) float s_f[128];
-  __shared__ __attribute__((aligned(16))) float s_g[128];
-  __shared__ float s_pm[4][128];
-  __shared__ float s_ps[4][128];
+  const int t = threadIdx.x, idx = t >> 2, q = t & 3;
+  __shared__ __attribute__((aligned(16))) float s_f[kPotFloats];
+  __shared__ __attribute__((aligned(16))) float s_g[kPotFloats];
+  __shared__ __attribute__((aligned(16))) float s_u[kPotFloats];
+  __shared__ __attribute__((aligned(16))) float s_v[kPotFloats];
   __shared__ double s_red[3][8];
+  __shared__ unsigned s_flag[4];
+  unsigned turn = 0;
+  if (t < 4) s_flag[t] = 0u;
 
   float kr[32], kc[32];
 #pragma unroll
@@ -294,34 +319,34 @@ __global__ __launch_bounds__(512) void sinkhorn_small_kernel(const float* __rest
     const int i = 32 * q + e;
     kc[e] = (i < n && idx < m) ? K[(long)i * m + idx] : kNegBig;
   }
-  if (t < 128) {
+  if (t < kPotFloats) {
     s_f[t] = 0.f;
     s_g[t] = 0.f;
+    s_u[t] = 1.f;
+    s_v[t] = 1.f;
   }
   __syncthreads();
 
-  __shared__ __attribute__((aligned(16))) float s_u[128];
-  __shared__ __attribute__((aligned(16))) float s_v[128];
   float er[32], ec[32];
   bool linear = false;
   auto absorb = [&]() {   // back to potentials: f += log u, g += log v
-    if (t < n) s_f[t] += logf(s_u[t]);
-    if (t < m) s_g[t] += logf(s_v[t]);
+    if (t < n) s_f[pot_slot(t)] += logf(s_u[pot_slot(t)]);
+    if (t < m) s_g[pot_slot(t)] += logf(s_v[pot_slot(t)]);
     __syncthreads();
   };
   for (int it = 0; it < iters; ++it) {
     if (!linear) {
-      const bool mf = small_half_step(kr, s_g, s_f, s_pm, s_ps, idx, q, n, lc.settle);  // rows:    f from g
-      const bool mg = small_half_step(kc, s_f, s_g, s_pm, s_ps, idx, q, m, lc.settle);  // columns: g from f
+      const bool mf = small_half_step(kr, s_g, s_f, idx, q, n, lc.settle, s_flag, turn);  // rows:    f from g
+      const bool mg = small_half_step(kc, s_f, s_g, idx, q, m, lc.settle, s_flag, turn);  // columns: g from f
       if (!mf && !mg && it + 1 < iters && lc.enabled) {
         // settled: E = exp(K + f + g) in both roles (masked entries: exp(-1e30) = 0), u = v = 1
-        const float fi = s_f[idx], gj = s_g[idx];
+        const float fi = s_f[pot_slot(idx)], gj = s_g[pot_slot(idx)];
 #pragma unroll
         for (int e = 0; e < 32; ++e) {
-          er[e] = expf(kr[e] + fi + s_g[32 * q + e]);
-          ec[e] = expf(kc[e] + s_f[32 * q + e] + gj);
+          er[e] = expf(kr[e] + fi + s_g[36 * q + e]);
+          ec[e] = expf(kc[e] + s_f[36 * q + e] + gj);
         }
-        if (t < 128) {
+        if (t < kPotFloats) {
           s_u[t] = 1.f;
           s_v[t] = 1.f;
         }
@@ -329,8 +354,8 @@ __global__ __launch_bounds__(512) void sinkhorn_small_kernel(const float* __rest
         linear = true;
       }
     } else {
-      const bool fu = small_lin_step(er, s_v, s_u, s_ps, idx, q, n, lc);  // rows:    u from v
-      const bool fv = small_lin_step(ec, s_u, s_v, s_ps, idx, q, m, lc);  // columns: v from u
+      const bool fu = small_lin_step(er, s_v, s_u, idx, q, n, lc, s_flag, turn);  // rows:    u from v
+      const bool fv = small_lin_step(ec, s_u, s_v, idx, q, m, lc, s_flag, turn);  // columns: v from u
       if (fu || fv) {
         absorb();
         linear = false;
@@ -338,26 +363,26 @@ __global__ __launch_bounds__(512) void sinkhorn_small_kernel(const float* __rest
     }
   }
   if (linear) absorb();
-  small_half_step(kr, s_g, s_f, s_pm, s_ps, idx, q, n, lc.settle);    // final row softmax (matching.py:56)
+  small_half_step(kr, s_g, s_f, idx, q, n, lc.settle, s_flag, turn);    // final row softmax (matching.py:56)
 
-  // plan M_ij = exp(K_ij + f_i + g_j): column role writes M (coalesced along j), row role
-  // writes M^T (coalesced along i) and the statistics.
+  // plan M_ij = exp(K_ij + f_i + g_j): the column role writes M, the row role M^T and the statistics (a wave stores
+  // four 64-byte row segments per instruction: 0.8 MB per launch, once)
   {
-    const float gj = s_g[idx];
+    const float gj = s_g[pot_slot(idx)];
 #pragma unroll
     for (int e = 0; e < 32; ++e) {
       const int i = 32 * q + e;
-      if (i < n && idx < m) plan[(long)p * n * m + (long)i * m + idx] = expf(kc[e] + s_f[i] + gj);
+      if (i < n && idx < m) plan[(long)p * n * m + (long)i * m + idx] = expf(kc[e] + s_f[36 * q + e] + gj);
     }
   }
   float h = 0.f, w = 0.f, sm = 0.f;
   {
-    const float fi = s_f[idx];
+    const float fi = s_f[pot_slot(idx)];
 #pragma unroll
     for (int e = 0; e < 32; ++e) {
       const int j = 32 * q + e;
       if (idx < n && j < m) {
-        const float lm = kr[e] + fi + s_g[j];
+        const float lm = kr[e] + fi + s_g[36 * q + e];
         const float mij = expf(lm);
         planT[(long)p * n * m + (long)j * n + idx] = mij;
         h -= mij * lm;
@@ -466,19 +491,34 @@ __device__ __forceinline__ void panel_combine(float mx, float s, float* s_pm, fl
 // exp through the native 2^x unit for arguments of either sign (entries of E are at most e^kLogSettle)
 __device__ __forceinline__ float exp_native(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
-// the linear form's combine: the TPR partial sums of one line -> 1 / sum, published
+// The linear form's combine: the TPR partial sums of one line -> 1 / sum, published.  Round 4 (tools/debug/
+// build_panel_timing.sh): the first version had the RPW threads of slice 0 add the TPR partial sums of their line one
+// dependent 4-byte LDS read after the other -- 2.3 us of a 3.8 us half-sweep at N = 1024.  Spreading the lines over all
+// sixteen waves (one partial sum per thread, exchanges, every wave publishing its two lines) was slower still (0.77 ->
+// 0.95 ms per 100 sweeps): 32 separate 8-byte write-through stores instead of one 256-byte one.  So: ONE publishing
+// stripe of RPW x H threads (H = 64 / RPW, at least 1: a whole wave at RPW = 32), each summing TPR / H partial sums
+// fetched as independent 16-byte reads (rows of TPR + 4 floats: aligned, conflict-free), halves joined by one exchange,
+// and the RPW results published by consecutive lanes.
 template <int TPR, int RPW>
-__device__ __forceinline__ void panel_combine_lin(float sum, float* s_ps, int line, int q, int gline, int N,
+__device__ __forceinline__ void panel_combine_lin(float sum, float* s_part, int line, int q, int r, int N,
                                                   unsigned long long* out_global, unsigned seq) {
-  s_ps[q * RPW + line] = sum;
+  constexpr int LD = TPR + 4;
+  constexpr int H = RPW >= 64 ? 1 : 64 / RPW;       // threads per line in the publishing stripe
+  constexpr int PER = TPR / H;                      // partial sums per thread: 16 (RPW 32), 16 (RPW 64), 8 (RPW 128)
+  s_part[line * LD + q] = sum;
   __syncthreads();
-  if (q == 0) {
-    float S = 0.f;
-#pragma unroll 4
-    for (int k = 0; k < TPR; ++k) S += s_ps[k * RPW + line];
-    int gl = gline;
+  const int t = threadIdx.x;
+  if (t < RPW * H) {
+    const int ln = t % RPW, h = t / RPW;
+    const f32x4* src = reinterpret_cast<const f32x4*>(s_part + ln * LD + h * PER);
+    f32x4 acc = src[0];
+#pragma unroll
+    for (int c = 1; c < PER / 4; ++c) acc += src[c];
+    float S = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    if (H == 2) S += __shfl_xor(S, 32, 64);
+    int gl = r * RPW + ln;
     asm volatile("" : "+v"(gl));
-    if (gline < N) publish_tagged(out_global + gl, 1.f / S, seq);
+    if (h == 0 && gl < N) publish_tagged(out_global + gl, 1.f / S, seq);
   }
 }
 
@@ -487,8 +527,16 @@ __device__ __forceinline__ void panel_combine_lin(float sum, float* s_ps, int li
 // log-domain sweep), s_u / s_v the scaling factors exchanged since.  Every workgroup of a problem consumes the same N
 // values per half-sweep and derives the mode from them alone (a flag word in LDS, four slots used in turn): the
 // workgroups of a problem switch together without talking about it.
+#ifdef PANEL_TIMING   // dev (tools/debug/build_panel_timing.sh): where a linear half-sweep's time goes, thread 0 of workgroup 0
+#define PT_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); if (i) pt_acc[i] += now_ - pt_last; pt_last = now_; } } while (0)
+#else
+#define PT_STAMP(i) do { } while (0)
+#endif
 template <int TPR>  // slices per line: 8 (RPW 128, N <= 256), 16 (RPW 64, N <= 512), 32 (RPW 32)
 __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs a, LinCtl lc) {
+#ifdef PANEL_TIMING
+  unsigned long long pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_last = 0;
+#endif
   constexpr int RPW = kPanelThreads / TPR;
   extern __shared__ __attribute__((aligned(16))) float psm[];
   float* s_kc = psm;                         // [TPR*32][RPW] column panel: K, or E in the linear sweeps
@@ -498,7 +546,7 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
   float* s_v = s_u + 1024;                   // [1024]
   float* s_pm = s_v + 1024;                  // [TPR][RPW]
   float* s_ps = s_pm + TPR * RPW;            // [TPR][RPW]
-  unsigned* s_flag = reinterpret_cast<unsigned*>(s_ps + TPR * RPW);   // [4]
+  unsigned* s_flag = reinterpret_cast<unsigned*>(s_ps + TPR * RPW);   // [4] mode requests in turn, [4] a spin gave up
   const int p = blockIdx.x / a.R, r = blockIdx.x % a.R;
   const int N = a.N;
   const float* K = a.K + (long)p * N * N;
@@ -531,7 +579,7 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
   unsigned phase = 0;
   s_f[t] = 0.f;
   s_g[t] = 0.f;  // g = 0 (1024 threads cover the 1024 slots)
-  if (t < 4) s_flag[t] = 0u;
+  if (t < 8) s_flag[t] = 0u;
   __syncthreads();
   bool ok = true;
   // one exchange: every thread takes slot t of `slots` into dst[t]; `mark` = this value asks for a mode change.
@@ -540,11 +588,17 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
     bool okl = true;
     int tt = t;
     asm volatile("" : "+v"(tt));      // (keeps the 64-bit slot addresses out of the loop-carried registers: they spilled)
+    // a poll is a round trip through the fabric: one sent right behind the publish finds nothing and the next one costs
+    // a second round trip; wait for about the propagation time first
+    for (int w = lc.poll_delay; w > 0; w -= 16) __builtin_amdgcn_s_sleep(16);
     const float val = t < N ? consume_tagged(slots + tt, phase, a.fail, okl) : 0.f;
+    PT_STAMP(4);
     const unsigned slot = phase & 3u;
     if (t < N && mark(val, dst[t])) s_flag[slot] = 1u;
+    if (!okl) s_flag[4] = 1u;                      // a spin gave up: sticky
     dst[t] = val;
-    ok = __syncthreads_and(okl) != 0;
+    __syncthreads();                               // (ONE barrier: the library's __syncthreads_and costs three)
+    ok = s_flag[4] == 0u;
     const bool req = s_flag[slot] != 0u;
     if (t == 0) s_flag[(slot + 2u) & 3u] = 0u;     // (last read two barriers ago, next written two half-sweeps from now)
     return req;
@@ -625,15 +679,31 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
     } else {
       const int q32 = fresh(q * 32), kb = fresh(q * 32 * RPW + line);
       float sm = 0.f;
+      PT_STAMP(0);
 #pragma unroll
-      for (int e = 0; e < 32; ++e) sm = fmaf(xr[e], s_v[q32 + e], sm);
-      panel_combine_lin<TPR, RPW>(sm, s_ps, line, q, gline, N, f, ++phase);
+      for (int c = 0; c < 8; ++c) {        // (the factors as 16-byte broadcasts: 8 instead of 32 LDS instructions)
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(s_v + q32 + 4 * c);
+        sm = fmaf(xr[4 * c + 0], vv[0], sm);
+        sm = fmaf(xr[4 * c + 1], vv[1], sm);
+        sm = fmaf(xr[4 * c + 2], vv[2], sm);
+        sm = fmaf(xr[4 * c + 3], vv[3], sm);
+      }
+      PT_STAMP(1);
+      panel_combine_lin<TPR, RPW>(sm, s_pm, line, q, r, N, f, ++phase);
+      PT_STAMP(2);
       const bool fu = consume_all(f, s_u, far);
+      PT_STAMP(3);
       if (!ok) break;
       sm = 0.f;
 #pragma unroll
-      for (int e = 0; e < 32; ++e) sm = fmaf(s_kc[kb + e * RPW], s_u[q32 + e], sm);
-      panel_combine_lin<TPR, RPW>(sm, s_ps, line, q, gline, N, g, ++phase);
+      for (int c = 0; c < 8; ++c) {
+        const f32x4 uu = *reinterpret_cast<const f32x4*>(s_u + q32 + 4 * c);
+        sm = fmaf(s_kc[kb + (4 * c + 0) * RPW], uu[0], sm);
+        sm = fmaf(s_kc[kb + (4 * c + 1) * RPW], uu[1], sm);
+        sm = fmaf(s_kc[kb + (4 * c + 2) * RPW], uu[2], sm);
+        sm = fmaf(s_kc[kb + (4 * c + 3) * RPW], uu[3], sm);
+      }
+      panel_combine_lin<TPR, RPW>(sm, s_pm, line, q, r, N, g, ++phase);
       const bool fv = consume_all(g, s_v, far);
       if (!ok) break;
       if (fu || fv) absorb();
@@ -674,6 +744,11 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
     atomicAdd(&a.stats[p * 4 + 2], ds);
   }
   if (!ok && t == 0) a.stats[p * 4 + 3] = __builtin_nan("");
+#ifdef PANEL_TIMING
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    printf("panel timing (counter units, thread 0 of workgroup 0, linear row half-sweeps): fma %llu  combine+publish %llu  poll %llu  barrier after poll %llu\n",
+           pt_acc[1], pt_acc[2], pt_acc[4], pt_acc[3]);
+#endif
 }
 
 // OTGAN_SINKHORN_LINEAR=0: every sweep in the log domain (the kernels of rounds 1 - 3).  Test knobs:
@@ -690,6 +765,8 @@ inline LinCtl lin_ctl() {
     v.settle = st && atof(st) > 0 ? (float)atof(st) : kLogSettle;
     v.lo = expf(-range);
     v.hi = expf(range);
+    const char* pd = getenv("OTGAN_SINKHORN_POLL_DELAY");
+    v.poll_delay = pd ? atoi(pd) : 0;
     return v;
   }();
   return c;
@@ -704,7 +781,7 @@ inline LinCtl lin_ctl() {
 template <int TPR>
 bool launch_panel(const PanelArgs& a, int P, hipStream_t s) {
   constexpr int RPW = kPanelThreads / TPR;
-  const size_t lds = sizeof(float) * ((size_t)TPR * 32 * RPW + 4 * 1024 + 2 * TPR * RPW + 4);
+  const size_t lds = sizeof(float) * ((size_t)TPR * 32 * RPW + 4 * 1024 + 2 * TPR * RPW + 8);
   static thread_local int cap_dev = -1, capacity = 0;
   int dev = 0;
   hipGetDevice(&dev);
