@@ -3488,7 +3488,8 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
     float* dweff = ws + WINO(wino_wgrad_ws_floats)(wg);
     {
       ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * kWinoFreq * (double)wino_tiles(wg) * 4.0 * d->Cout * d->C, 0.0, s);
-      // 5 x 5 'SAME' (the DCGAN generator): the adjoint filter transform writes the un-folded gradient itself (round 4)
+      // 5 x 5 'SAME' (the DCGAN generator): the adjoint filter transform writes the un-folded gradient itself (round 4;
+      // OTGAN_WINO_UNFOLD_FUSED=0: the two kernels of round 3)
       static const bool fuse_off = getenv("OTGAN_WINO_UNFOLD_FUSED") && getenv("OTGAN_WINO_UNFOLD_FUSED")[0] == '0';
       const bool fuse = !fuse_off && d->KH == 5 && d->KW == 5 && g.pad_t == 2 && g.pad_l == 2;
       rc = WINO(wino_wgrad)(wg, x, dy, dweff, f.woff[1] - f.woff[0], ws, s, fuse ? dw : nullptr);

@@ -745,47 +745,70 @@ __global__ __launch_bounds__(256) void wino_filter_adj_kernel(const float* __res
 
 // The same with the un-folding of a 5 x 5 'SAME' upsampling layer in the same pass (round 4): dw[kh][kw][ci][co] = sum over
 // the four output-parity classes of (G^T dU G)[th(ph, kh)][tw(pw, kw)] -- conv.hip's unfold_wgrad_kernel, whose read of
-// dweff (36 / 25 of the weight bytes) and launch disappear.  Class order and start value as there: bit-identical.
+// dweff (36 / 25 of the weight bytes) and launch disappear.  The four classes of a (ci, co-quad) sit in ADJACENT lanes
+// and are added by quad broadcasts in class order from 0, as unfold_wgrad_kernel adds them (equal to 1 - 2 ulp, not bit
+// for bit: the compiler contracts the last multiply-adds of the transform differently here).  A first version with one
+// thread walking the four classes had a quarter of the threads and four times the dependent loads each: 143 us per
+// launch against 119 us for the two kernels it replaced; this one 69 us.
+__device__ __forceinline__ float quad_lane(float v, int lane_in_quad) {   // value of lane `lane_in_quad` of the caller's quad
+  const int x = __float_as_int(v);
+  int r;
+  switch (lane_in_quad) {
+    case 0: r = __builtin_amdgcn_update_dpp(0, x, 0x00, 0xF, 0xF, true); break;
+    case 1: r = __builtin_amdgcn_update_dpp(0, x, 0x55, 0xF, 0xF, true); break;
+    case 2: r = __builtin_amdgcn_update_dpp(0, x, 0xAA, 0xF, 0xF, true); break;
+    default: r = __builtin_amdgcn_update_dpp(0, x, 0xFF, 0xF, 0xF, true); break;
+  }
+  return __int_as_float(r);
+}
 __global__ __launch_bounds__(256) void wino_filter_adj_unfold5_kernel(const float* __restrict__ slabs, int nsplit,
                                                                     long split_stride, int Cin, int Cout,
                                                                     float* __restrict__ dw) {
   const int c4n = Cout >> 2;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long)Cin * c4n) return;
+  const long idx = (long)blockIdx.x * 64 + (threadIdx.x >> 2);
+  const int cls = threadIdx.x & 3;
+  if (idx >= (long)Cin * c4n) return;          // (whole quads leave together)
   const int co = (int)(idx % c4n) * 4;
   const int ci = (int)(idx / c4n);
   const long ldu = 4L * Cout, fs = (long)Cin * ldu;
+  const float* src = slabs + (long)ci * ldu + (long)cls * Cout + co;
+  f32x4 dg[3][3];
+  tf_filter_adj(
+      [&](int j, f32x4(&u)[WA]) {
+#pragma unroll
+        for (int i = 0; i < WA; ++i) {
+          f32x4 sv = ld4(src + (i * WA + j) * fs);
+          for (int k = 1; k < nsplit; ++k) sv += ld4(src + k * split_stride + (i * WA + j) * fs);
+          u[i] = sv;
+        }
+      },
+      dg);
   // tap of the 3 x 3 class filter that filter row / column k folds into: floor((p + k - 2) / 2) - its minimum
   constexpr int TH[2][5] = {{0, 0, 1, 1, 2}, {0, 1, 1, 2, 2}};
-  f32x4 acc[5][5];
-#pragma unroll
-  for (int i = 0; i < 5; ++i)
-#pragma unroll
-    for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int cls = 0; cls < 4; ++cls) {
-    const float* src = slabs + (long)ci * ldu + (long)cls * Cout + co;
-    f32x4 dg[3][3];
-    tf_filter_adj(
-        [&](int j, f32x4(&u)[WA]) {
-#pragma unroll
-          for (int i = 0; i < WA; ++i) {
-            f32x4 sv = ld4(src + (i * WA + j) * fs);
-            for (int k = 1; k < nsplit; ++k) sv += ld4(src + k * split_stride + (i * WA + j) * fs);
-            u[i] = sv;
-          }
-        },
-        dg);
-#pragma unroll
-    for (int kh = 0; kh < 5; ++kh)
-#pragma unroll
-      for (int kw = 0; kw < 5; ++kw) acc[kh][kw] += dg[TH[cls >> 1][kh]][TH[cls & 1][kw]];
-  }
+  const bool ph = (cls >> 1) != 0, pw = (cls & 1) != 0;
   float* dst = dw + (long)ci * Cout + co;
 #pragma unroll
-  for (int kh = 0; kh < 5; ++kh)
+  for (int kh = 0; kh < 5; ++kh) {
+    f32x4 row[3];
 #pragma unroll
-    for (int kw = 0; kw < 5; ++kw) st4(dst + (long)(kh * 5 + kw) * Cin * Cout, acc[kh][kw]);
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) row[j][c] = ph ? dg[TH[1][kh]][j][c] : dg[TH[0][kh]][j][c];
+#pragma unroll
+    for (int kw = 0; kw < 5; ++kw) {
+      f32x4 sum;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float x = pw ? row[TH[1][kw]][c] : row[TH[0][kw]][c];
+        float acc = 0.f + quad_lane(x, 0);
+        acc += quad_lane(x, 1);
+        acc += quad_lane(x, 2);
+        acc += quad_lane(x, 3);
+        sum[c] = acc;
+      }
+      if (((kh * 5 + kw) & 3) == cls) st4(dst + (long)(kh * 5 + kw) * Cin * Cout, sum);
+    }
+  }
 }
 
 // ---- 5x5 stride-2 layers as four stride-1 3x3 sub-convolutions ------------------------------
@@ -1744,7 +1767,7 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
     b.sk_partial = x3_stream_area(ws, wino_wgrad_ws_floats(g));
     launch_bgemm_tl(b, ns, s);
     if (dw_unfolded5)
-      hipLaunchKernelGGL(wino_filter_adj_unfold5_kernel, dim3(grid1((long)g.Cin * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
+      hipLaunchKernelGGL(wino_filter_adj_unfold5_kernel, dim3(grid1(4L * g.Cin * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
                          (long)WF * g.Cin * N4, g.Cin, g.Cout, dw_unfolded5);
     else
       hipLaunchKernelGGL(wino_filter_adj_kernel, dim3(grid1(4L * g.Cin * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
@@ -1779,7 +1802,7 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
   b.kt_per_split = (nkt + ns - 1) / ns;
   launch_bgemm<true>(b, ns, s);
   if (dw_unfolded5)
-    hipLaunchKernelGGL(wino_filter_adj_unfold5_kernel, dim3(grid1((long)g.Cin * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
+    hipLaunchKernelGGL(wino_filter_adj_unfold5_kernel, dim3(grid1(4L * g.Cin * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
                        (long)WF * g.Cin * N4, g.Cin, g.Cout, dw_unfolded5);
   else
     hipLaunchKernelGGL(wino_filter_adj_kernel, dim3(grid1(4L * g.Cin * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,

@@ -817,3 +817,27 @@ def test_dense_block_gradient_buffer_in_place(dev, monkeypatch):
     gout = w.clone()
     ya.backward(gradient=gout)
     assert torch.equal(gout, w)
+
+
+@pytest.mark.gpu
+def test_unfolded_weight_gradient_in_the_adjoint_filter_transform(tmp_path):
+    """The adjoint filter transform of the 5x5 upsampling layers writes the un-folded weight gradient itself
+    (wino_filter_adj_unfold5_kernel: the four parity classes in adjacent lanes, added in class order): the same sums as
+    the adjoint transform followed by conv.hip's unfold_wgrad_kernel (OTGAN_WINO_UNFOLD_FUSED=0; read once per process)
+    -- equal to 1 - 2 ulp, not bit for bit (the compiler contracts the transform's last multiply-adds differently in the
+    two kernels), and bit-reproducible from run to run."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for i, v in enumerate(("1", "1", "0")):
+        e = dict(os.environ)
+        e["OTGAN_WINO_UNFOLD_FUSED"] = v
+        f = str(tmp_path / f"g{i}.pt")
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "debug", "unfold_dbg.py"), f], cwd=root, env=e,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(f))
+    for a, b, c in zip(*outs):
+        assert torch.equal(a, b)                                   # fused, twice
+        assert float((a - c).abs().max()) <= 2e-6 * float(c.abs().max())   # fused against the two kernels it replaces
