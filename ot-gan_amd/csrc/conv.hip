@@ -534,7 +534,9 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Cla
           const float gp = acc[mt][0][r] * descale, gn = acc[mt][Cfg::NT - 1][r] * descale;
           const float v = act_deriv(e.act, xv) * gp - act_deriv(e.act, -xv) * gn;
           float* dst = e.out + opix * e.ldo + e.coff + c;
-          *dst = e.accumulate ? (*dst + v) : v;
+          const float o = e.accumulate ? (*dst + v) : v;
+          *dst = o;
+          { const unsigned b_ = amax_bits(o); omax = b_ > omax ? b_ : omax; }
         }
       } else {
 #pragma unroll
@@ -554,14 +556,17 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Cla
             v *= act_deriv(e.act, e.xsrc[xpix * e.ldxs + col]);
           }
           float* dst = e.out + opix * e.ldo + e.coff + col;
-          *dst = (EPI != EPI_FWD && e.accumulate) ? (*dst + v) : v;
+          const float o = (EPI != EPI_FWD && e.accumulate) ? (*dst + v) : v;
+          *dst = o;
+          if (EPI != EPI_FWD) { const unsigned b_ = amax_bits(o); omax = b_ > omax ? b_ : omax; }
         }
       }
     }
   }
-  if constexpr (EPI == EPI_FWD) {
-    if (e.amax_out && !ksplit) amax_commit(e.amax_out, omax);   // (every thread of the workgroup reaches this point)
-  }
+  // (every thread of the workgroup reaches this point.)  Round 4: the input-gradient epilogues leave the record too --
+  // the largest magnitude of what ends up in memory, sums included -- so that the gradient a transition hands to the dense
+  // block in front of it needs no reduction pass over the whole buffer (0.1 ms each at 32 x 32 x 480 channels).
+  if (e.amax_out && !ksplit) amax_commit(e.amax_out, omax);
 }
 
 // out[m][coff + col] = bias[col] + sum over the K splits of partial[split][m][col]  (fixed order: deterministic), float4
@@ -1391,6 +1396,7 @@ struct FewDgArgs {
   float* dx;
   int lddx;
   int N, H, W, C, Ceff, pad_t, pad_l, act, accumulate;
+  float* amax;     // otgan_conv_desc::dx_amax_out or null (round 4: the dense block behind an RGB-out layer reads it)
 };
 constexpr int kFdTW = 16, kFdTH = 4, kFdCH = 64;
 template <int K, bool PAIRED, int NJ>
@@ -1400,6 +1406,7 @@ __global__ __launch_bounds__(256) void conv_fewout_dgrad_kernel(FewDgArgs a) {
   __shared__ __attribute__((aligned(16))) float wl[K * K][HALVES][NJ][kFdCH];
   __shared__ float4 dyt[LH][LW];
   const int n = blockIdx.x, w0 = blockIdx.y * kFdTW, c0 = blockIdx.z * kFdCH;
+  unsigned mb = 0u;
   for (int i = threadIdx.x; i < K * K * HALVES * kFdCH; i += 256) {
     const int cc = i % kFdCH, half = (i / kFdCH) % HALVES, tap = i / (kFdCH * HALVES);
     const int c = c0 + cc;
@@ -1478,10 +1485,12 @@ __global__ __launch_bounds__(256) void conv_fewout_dgrad_kernel(FewDgArgs a) {
         }
         float* dst = a.dx + pix * a.lddx + c;
         if (a.accumulate) o += *reinterpret_cast<const f32x4*>(dst);
+        mb = amax_bits4(o, mb);
         *reinterpret_cast<f32x4*>(dst) = o;
       }
     }
   }
+  if (a.amax) amax_commit(a.amax, mb);
 }
 
 // RGB-in forward (the first convolution of both critics: 3 input channels, no pre-activation): lanes run along
@@ -2317,6 +2326,7 @@ inline WinoUp3Geo wino_up3_geo(const otgan_conv_desc* d, const Geo& g) {
   WinoUp3Geo w;
   w.N = d->N; w.H = d->H; w.W = d->W; w.C = d->C; w.Ceff = g.Ceff; w.ldx = d->ldx; w.Cout = d->Cout; w.ldy = d->ldy;
   w.y_coff = d->y_coff; w.x_amax = d->x_amax;
+  w.y_amax_out = d->y_amax_out;
   return w;
 }
 
@@ -2858,12 +2868,18 @@ int otgan_absmax_f32(const float* x, long rows, int C, long ld, float* record, v
   return OTGAN_OK;
 }
 
+// the implicit-GEMM input-gradient epilogue writes dx itself (no pooling pass behind it: no upsample) and every element of
+// dx once (all C columns: the kernel's column blocks cover them)
+static bool igemm_dgrad_amax_ok(const otgan_conv_desc* d, int lddx) {
+  return !d->upsample && d->C % 4 == 0 && lddx % 4 == 0;
+}
 int otgan_conv2d_amax_fused(const otgan_conv_desc* d, int which) {
   Geo g;
   if (!d || make_geo(d, &g)) return 0;
   if (which == 0) {
     if (d->Cout % 4 || d->ldy % 4 || d->y_coff % 4) return 0;
     if (wino_s2_ok(d, g)) return 1;                                   // the output transform of the strided / wide 3x3 passes
+    if (wino_up3_ok(d, g) && !wino_ok(d, g) && !d->y_accumulate) return 1;   // ... and of the 3x3 upsampling layers (round 4; with prepared filters)
     if (d->y_accumulate) return d->Cout == 16;                        // growth layers (dense16 kernels); else reduced afterwards
     // RGB-in layer (launch_rgbin_fwd)
     if (d->preact == OTGAN_ACT_NONE && d->C == 3 && d->stride == 1 && d->upsample == 0 && d->KH == d->KW &&
@@ -2873,7 +2889,17 @@ int otgan_conv2d_amax_fused(const otgan_conv_desc* d, int which) {
     // the implicit-GEMM kernel's epilogue (every layer that is neither folded, nor Winograd, nor a few-output layer)
     return !wino_ok(d, g) && !g.fold && !wino_up3_ok(d, g) && d->Cout > 4 ? 1 : 0;
   }
-  if (which == 1) return d->C % 4 == 0 && wino_s2_ok(d, g) ? 1 : 0;
+  if (which == 1) {
+    if (d->C % 4) return 0;
+    if (wino_s2_ok(d, g)) return 1;
+    if (wino_up3_dgrad_ok(d, g) && !wino_ok(d, g)) return 1;         // 3x3 upsampling layers (with prepared filters), round 4
+    if (d->Cout == 3 && d->stride == 1 && d->upsample == 0 && d->KH == d->KW && (d->KH == 3 || d->KH == 5) &&
+        d->W % kFdTW == 0 && d->H % kFdTH == 0)
+      return 1;                                                      // RGB-out layer (conv_fewout_dgrad_kernel), round 4
+    // implicit-GEMM input gradient (round 4): everything that is not a Winograd / few-channel / folded pass
+    return !wino_ok(d, g) && !g.fold && !wino_up3_dgrad_ok(d, g) && !d->upsample && d->C > 4 && d->Cout > 4 &&
+           !(d->Cout == 16 && d->KH == 3 && d->KW == 3 && d->stride == 1) ? 1 : 0;
+  }
   return 0;
 }
 
@@ -3004,6 +3030,7 @@ static int conv2d_fwd_body(const otgan_conv_desc* d, const float* x, const int32
     w.x_op = shared_x_operand(d);
     ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * kWinoFreq * (double)wino_up3_tiles(w) * g.Ceff * d->Cout, 0.0, s);
     rc = WINO(wino_up3_fwd)(w, x, bias, y, (float*)workspace, s, filters);
+    g_amax_written = w.y_amax_out != nullptr;
     OTGAN_CHECK_LAUNCH("conv2d fwd (winograd, 3x3 on upsampled input)");
     return rc;
   }
@@ -3272,6 +3299,8 @@ static int conv2d_dgrad_body(const otgan_conv_desc* d, const float* dy, const fl
     fa.dx = dx; fa.lddx = lddx;
     fa.N = d->N; fa.H = d->H; fa.W = d->W; fa.C = d->C; fa.Ceff = g.Ceff;
     fa.pad_t = g.pad_t; fa.pad_l = g.pad_l; fa.act = kind; fa.accumulate = accumulate;
+    fa.amax = d->dx_amax_out;
+    g_amax_written = fa.amax != nullptr;
     const dim3 grid(d->N, d->W / kFdTW, ceil_div(d->C, kFdCH));
     ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * (double)d->N * d->H * d->W * d->KH * d->KW * d->Cout * g.Ceff, 0.0, s);
     if (d->KH == 3) {
@@ -3303,9 +3332,11 @@ static int conv2d_dgrad_body(const otgan_conv_desc* d, const float* dy, const fl
     OTGAN_CHECK_ARG(inv == nullptr && lddx % 4 == 0 && aligned16(dy) && aligned16(dx) && aligned16(x) && aligned16(workspace) &&
                         workspace && workspace_bytes >= otgan_conv2d_workspace_bytes(d, 1),
                     "winograd dgrad of a 3x3 upsampling layer: single-tensor input, 16-byte aligned operands, workspace");
-    const WinoS2Geo wg = wino_up3_wgrad_geo(d, g);
+    WinoS2Geo wg = wino_up3_wgrad_geo(d, g);
+    wg.dx_amax_out = d->dx_amax_out;       // (round 4: a stored pixel is written by one thread of the output transform)
     ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * kWinoFreq * (double)wino_s2_tiles(wg) * g.Ceff * d->Cout, 0.0, s);
     rc = WINO(wino_s2_dgrad)(wg, dy, w, x, dx, lddx, accumulate, (float*)workspace, s, filters);
+    g_amax_written = wg.dx_amax_out != nullptr;
     OTGAN_CHECK_LAUNCH("conv2d dgrad (winograd, 3x3 on upsampled input)");
     return rc;
   }
@@ -3411,6 +3442,10 @@ static int conv2d_dgrad_body(const otgan_conv_desc* d, const float* dy, const fl
     e.so = st; e.OHf = g.Hin; e.OWf = g.Win;
     e.logUpX = g.logUp;
     e.accumulate = tacc;
+  }
+  if (!pool && d->dx_amax_out && igemm_dgrad_amax_ok(d, lddx)) {
+    e.amax_out = d->dx_amax_out;
+    g_amax_written = true;
   }
   {
     ProfScope ps(OTGAN_PROF_CONV_DGRAD, flops, 0.0, s);

@@ -87,6 +87,7 @@ struct WinoUp3Geo {
   int Cout, ldy, y_coff;
   const float* x_amax = nullptr;
   float* x_op = nullptr;  // as in WinoGeo (read back by the one-class weight gradient, WinoS2Geo plain + up)
+  float* y_amax_out = nullptr;   // otgan_conv_desc::y_amax_out: the output transform leaves the record of y (round 4)
 };
 inline long wino_up3_tiles(const WinoUp3Geo& g) { return (long)g.N * (2 * g.H / kWinoM) * (2 * g.W / kWinoM); }
 // wT: un-folded [Cout][9 * Ceff]

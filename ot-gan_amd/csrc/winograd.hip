@@ -928,7 +928,7 @@ struct OutS2Args {
   int plain;            // one class, nothing structurally zero (a 3x3 stride-1 layer)
   int up;               // plain only: x / dx are half-resolution images behind a 2x nearest-neighbour upsample --
                         // the 4x4 tile of gradients is summed over its 2x2 groups
-  float* amax;          // amax record of the values written, or null (not with `up`)
+  float* amax;          // amax record of the values written, or null
 };
 // (A^T M A) of the class's M, rows i0 .. i0+1 only (two output rows at a time keep the register count down)
 // DOUBLED (CReLU / CELU): a thread owns TWO channels (both halves of each): the two 36-value column passes of four
@@ -1008,8 +1008,14 @@ __global__ __launch_bounds__(256) void wino_s2_output_kernel(OutS2Args a) {
         }
         float* dst = dv.p + n * dv.sn + (2 * ta + i) * dv.sh + (2 * tb + j) * dv.sw + c;
         if (a.accumulate) o += ldv(dst);
+#pragma unroll
+        for (int q = 0; q < VW; ++q) {      // (round 4: a stored pixel is written by this thread alone: its record too)
+          const unsigned b = amax_bits(o[q]);
+          mb = b > mb ? b : mb;
+        }
         *reinterpret_cast<VT*>(dst) = o;
       }
+    if (a.amax) amax_commit(a.amax, mb);
     return;
   }
 #pragma unroll
@@ -1494,6 +1500,8 @@ void op_scales(const float* x, long rows, int C, long ld, float* base, const flo
   if (blocks > kAmaxBlocks) blocks = kAmaxBlocks;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  static const bool trace = getenv("OTGAN_AMAX_TRACE") != nullptr;   // dev: which tensors still get a reduction pass
+  if (trace) fprintf(stderr, "absmax launch: rows %ld C %d ld %ld gain0 %.2f record_only %d\n", rows, C, a.ld, gain[0], a.record_only);
   static const bool dbg = getenv("OTGAN_AMAX_DEBUG") != nullptr;
   if (dbg) {   // dynamic range of the tensor (dev tool: synchronises)
     (void)hipStreamSynchronize(s);
@@ -2018,7 +2026,7 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   }
   oa.TH = OH / WM; oa.TW = OW / WM; oa.C = g.C; oa.Ceff = g.Ceff; oa.T = T; oa.ldm = K4; oa.Xh = Xh;
   oa.accumulate = accumulate;
-  oa.amax = g.up ? nullptr : g.dx_amax_out;
+  oa.amax = g.dx_amax_out;
   const dim3 grid(grid1(T * (g.C / (g.doubled ? 2 : 4))), 1, wino_s2_classes(g)), blk(256);
   if (g.doubled) {
     if (g.act == 2) hipLaunchKernelGGL((wino_s2_output_kernel<2, true>), grid, blk, 0, s, oa);
@@ -2154,6 +2162,7 @@ int wino_up3_fwd(const WinoUp3Geo& g, const float* x, const float* bias, float* 
   memset(&oa, 0, sizeof(oa));
   oa.v[0].p = y + g.y_coff; oa.v[0].sn = (long)OH * OW * g.ldy; oa.v[0].sh = (long)OW * g.ldy; oa.v[0].sw = g.ldy;
   oa.TH = OH / WM; oa.TW = OW / WM; oa.C = g.Cout; oa.T = T; oa.ldm = g.Cout; oa.Mh = Mh; oa.bias = bias;
+  oa.amax = g.y_amax_out;
   hipLaunchKernelGGL(wino_output_kernel, dim3(grid1(T * (g.Cout / 4)), 1, 1), dim3(256), 0, s, oa);
   return OTGAN_OK;
 }

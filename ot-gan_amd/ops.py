@@ -411,7 +411,9 @@ class Conv2dFunction(torch.autograd.Function):
             if not filt["bwd_done"]:
                 filt["bwd"], filt["bwd_done"] = prepare_filters(desc, filt["bwd_which"], w), True
             dx_rec = None
-            if amax_fused(desc, 1) and ctx.inv is None:
+            # (a list input keeps a layer off the Winograd passes; the implicit-GEMM epilogue writes every real channel
+            # once whatever the channel map, round 4)
+            if amax_fused(desc, 1) and (ctx.inv is None or filt["bwd"] is None):
                 dx_rec = amax_slot(x.device)
                 desc.dx_amax_out = dx_rec.data_ptr()
             desc.w_amax = ctx.w_rec.data_ptr() if ctx.w_rec is not None else None    # (prepare_filters cleared it)
@@ -878,6 +880,8 @@ class DenseBlockFunction(torch.autograd.Function):
                 os.environ.get("OTGAN_DENSE16_BWD_H2", "1") != "0"):
             grads = DenseBlockFunction._backward_by_slice(ctx, buf, saved, G, dbuf, need_w)
             dx0 = G[..., :C0].contiguous() if ctx.needs_input_grad[0] else None
+            if dx0 is not None and _FUSED_AMAX and C0 % 4 == 0:
+                tag_amax(dx0, ctx.dx0_rec)
             return (dx0, None, None, None, *grads)
         if plan is not None:
             sw = ctx.sw
@@ -1039,6 +1043,8 @@ def _backward_by_slice(ctx, buf, saved, G, dbuf, need_w):
     RR = torch.zeros((L + 1, AMAX_RECORD_FLOATS), dtype=torch.float32, device=buf.device)
     RS, Rc = RR[:L], RR[L]
     Rc.copy_(tag if tag is not None else absmax_record(G))
+    R0 = amax_slot(buf.device)
+    ctx.dx0_rec = R0
     gptr, bptr = G.data_ptr(), buf.data_ptr()
 
     def wide_bwd(i, need_dx):
@@ -1054,7 +1060,9 @@ def _backward_by_slice(ctx, buf, saved, G, dbuf, need_w):
         if need_dx:
             if not ops_["bwd_done"]:
                 ops_["bwd"], ops_["bwd_done"] = prepare_filters(desc, 1, ops_["w"]), True
-            desc.dx_amax_out = Rc.data_ptr() if i > 0 else None      # (i = 0 writes the block input's gradient: not read here)
+            # i = 0 writes the block input's gradient (sums onto the incoming one): its own record, handed to the layer in
+            # front of the block with dx0 (round 4: that layer reduced the tensor itself)
+            desc.dx_amax_out = Rc.data_ptr() if i > 0 else R0.data_ptr()
             conv_dgrad_raw(desc, G, ops_["w"], src, None, gsrc, Ctot, True, ops_["bwd"])
             desc.dx_amax_out = None
         desc.dy_amax = None
@@ -1209,6 +1217,41 @@ class FeatureHeadFunction(torch.autograd.Function):
         if rec is not None:
             tag_amax(dx, rec)
         return dx
+
+
+class ConcatChannelsFunction(torch.autograd.Function):
+    """torch.cat(xs, dim = 3) of NHWC tensors that carries amax records both ways (round 4): the result is tagged with the
+    maximum of its elements' records (elements without one -- the 16-channel noise inputs of the DenseNet generator,
+    models/densenet.py:60-73 -- are reduced, they are small), and every piece of the gradient with the gradient's own
+    record: a bound of a channel subset is all a consumer's power-of-two scale needs.  Without this the dense block
+    behind the cat reduced its block input, and the layer in front of it its output gradient, once per step each."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        ctx.widths = [int(t.shape[-1]) for t in xs]
+        y = torch.cat(xs, 3)
+        if _FUSED_AMAX and all(w % 4 == 0 for w in ctx.widths) and any(amax_of(t) is not None for t in xs):
+            recs = [amax_of(t) if amax_of(t) is not None else absmax_record(t.contiguous()) for t in xs]
+            rec = recs[0]
+            for r in recs[1:]:
+                rec = torch.maximum(rec, r)
+            tag_amax(y, rec)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rec = amax_of(dy)
+        outs = []
+        for piece in dy.split(ctx.widths, 3):
+            piece = piece.contiguous()
+            if rec is not None:
+                tag_amax(piece, rec)
+            outs.append(piece)
+        return tuple(outs)
+
+
+def concat_channels(xs):
+    return ConcatChannelsFunction.apply(*xs)
 
 
 glu = GluFunction.apply

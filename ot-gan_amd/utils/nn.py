@@ -368,7 +368,7 @@ def dense_block(x, layers_per_block, filters_per_layer, pre_activation='celu', f
     dev = xs[0].device
     segs0 = [int(t.shape[-1]) for t in xs]
     x0 = xs.buffer if isinstance(xs, ConcatList) and xs.buffer is not None else (
-        xs[0] if len(xs) == 1 else torch.cat(xs, 3))
+        xs[0] if len(xs) == 1 else ops.concat_channels(xs))
     mult = 2 if pre_activation in ("celu", "crelu") else 1
     params = []
     c = sum(segs0)
