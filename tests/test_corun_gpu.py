@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("victim", ["rgbin", "rgbin3", "rgbin_grad", "rgbout", "growth", "s2", "up", "matching", "matching256", "adam",
                                     "wn", "glu", "head"])
 def test_neighbour_of_the_gemm_computes_the_same(victim):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "debug", "corun_repro.py"), victim, "15"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "debug", "corun_repro.py"), victim, "8"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     last = [l for l in r.stdout.splitlines() if l.startswith("CORUN")][-1]
