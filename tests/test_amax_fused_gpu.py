@@ -152,3 +152,39 @@ def test_glu_backward_leaves_the_bias_gradient():
         assert float((g.double() - xr.grad).abs().max()) < 1e-5
         g.add_(1.0)                                     # modified since: the tag must not be trusted any more
         assert ops.colsum_of(g) is None
+
+
+@pytest.mark.parametrize("case", ["igemm_s2_list", "igemm_1x1", "rgb_out", "up3"])
+def test_input_gradient_records_of_the_remaining_producers(case):
+    """Round 4: the input-gradient epilogues of the implicit-GEMM layers (stride-2 3x3 over a CReLU list input = a DenseNet
+    transition; a dense 1x1), of the RGB-out layer and of the 3x3 upsampling layers (output transform, also the forward
+    record of y) leave exact records of what they write -- the dense block in front of such a layer no longer reduces
+    its whole gradient buffer."""
+    from otgan_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(sum(map(ord, case)))
+    N = 4
+    if case == "igemm_s2_list":
+        x = torch.randn(N, 16, 16, 80, generator=g).to(dev).requires_grad_(True)
+        V = (torch.randn(3, 3, 160, 40, generator=g) * 0.05).to(dev)
+        kw = dict(stride=2, preact=ops.ACT["crelu"], segs=[48, 16, 16])
+    elif case == "igemm_1x1":
+        x = torch.randn(N, 8, 8, 64, generator=g).to(dev).requires_grad_(True)
+        V = (torch.randn(1, 1, 64, 96, generator=g) * 0.05).to(dev)
+        kw = dict(stride=1, preact=ops.ACT[None])
+    elif case == "rgb_out":
+        x = torch.randn(N, 32, 32, 64, generator=g).to(dev).requires_grad_(True)
+        V = (torch.randn(3, 3, 128, 3, generator=g) * 0.05).to(dev)
+        kw = dict(stride=1, preact=ops.ACT["crelu"], segs=[32, 32])
+    else:
+        x = torch.randn(N, 8, 8, 64, generator=g).to(dev).requires_grad_(True)
+        V = (torch.randn(3, 3, 128, 32, generator=g) * 0.05).to(dev)
+        kw = dict(stride=1, upsample=True, preact=ops.ACT["crelu"])
+    Co = V.shape[-1]
+    gg, b = torch.ones(Co, device=dev), torch.zeros(Co, device=dev)
+    y = ops.conv2d_op(x, V, gg, b, **kw)
+    if case == "up3":
+        assert _rec_value(y) == y.detach().abs().max().item()
+    dy = torch.randn(y.shape, generator=g).to(dev)
+    (dx,) = torch.autograd.grad(y, x, dy)
+    assert _rec_value(dx) == dx.abs().max().item()
