@@ -61,7 +61,7 @@ def test_three_bf16_pieces_build(tmp_path):
         assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-5, n
 
 
-@pytest.mark.parametrize("data", ["gaussian", "step"])
+@pytest.mark.parametrize("data", ["step"])       # ("gaussian" -- the easier operand distribution -- ran here until round 4: 15 s)
 def test_split_engines_are_no_worse_than_the_fp32_mfma_engine(tmp_path, data):
     """The precision claim of the convolution GEMMs, measured: against an fp64 evaluation of the same layers the
     default engine (two scaled fp16 pieces, 22 significand bits, three MFMAs per product) and the three-piece bf16

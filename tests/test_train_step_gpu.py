@@ -286,16 +286,18 @@ def test_well_conditioned_step_gradients(dev, model, size, kind):
     engine, kernel and seed: at 32 x 32 about one seed in three has such a unit, at 64 x 64 (four times the units) three to
     five in six (tools/debug/step_seeds_64.py; changing the summation order of the generator's RGB-out convolution --
     to a MORE accurate kernel -- moved them to other seeds).  With the same sign pattern on both sides the comparison
-    measures arithmetic and nothing else; one un-forced seed per case stays, bounded at the flipped-unit level."""
+    measures arithmetic and nothing else; one un-forced seed per step kind stays (DCGAN 32 x 32), bounded at the
+    flipped-unit level."""
     tol = _WELL_TOL[(model, size, kind)]
     # (three seeds at 32 x 32 DCGAN, two for the cases whose fp64 CPU oracle takes 10+ s per seed: the GPU suite has a budget)
     seeds = (5, 6, 7) if (model, size) == ("dcgan", 32) else (5, 6)
     worst = [_well_conditioned_worst(dev, model, size, kind, seed, same_head_signs=True) for seed in seeds]
     print(f"\nwell-conditioned {model} {size} {kind}: worst tensor per seed " + ", ".join(f"{w[0]:.2e} ({w[1]})" for w in worst))
     assert max(w[0] for w in worst) < tol, worst
-    free = _well_conditioned_worst(dev, model, size, kind, 5)
-    print(f"  un-forced head signs, seed 5: {free[0]:.2e} ({free[1]})")
-    assert free[0] < 3e-3, free                 # a flipped head unit: bounded, not tight
+    if (model, size) == ("dcgan", 32):          # (one un-forced run per step kind: the suite's time budget)
+        free = _well_conditioned_worst(dev, model, size, kind, 5)
+        print(f"  un-forced head signs, seed 5: {free[0]:.2e} ({free[1]})")
+        assert free[0] < 3e-3, free             # a flipped head unit: bounded, not tight
 
 
 def _ema_critic_errors(dev, seed, same_head_signs=True):
