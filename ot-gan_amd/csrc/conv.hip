@@ -3552,7 +3552,10 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
     float* slabs = p.nsplit > 1 ? (float*)workspace : dw;
     {
       ProfScope ps(OTGAN_PROF_CONV_WGRAD, 2.0 * (double)p.M * (double)p.slab_elems, 0.0, s);
-      rc = dense16_wgrad(dg, x, dy, d->ldy, d->y_coff, slabs, s);
+      // round 4: with amax records of the x slices and of dy the kernel runs on the fp16 matrix pipe
+      const bool recs = d->x_amax && d->dy_amax;
+      rc = dense16_wgrad(dg, x, dy, d->ldy, d->y_coff, slabs, s, recs ? d->x_amax : nullptr, d->x_amax_count > 1 ? d->x_amax_count : 1,
+                         recs ? d->dy_amax : nullptr, d->dy_amax_count > 1 ? d->dy_amax_count : 1);
       if (rc) return rc;
     }
     OTGAN_CHECK_LAUNCH("conv2d wgrad (dense16)");

@@ -58,8 +58,10 @@ struct Dense16Tiling {
 Dense16Tiling dense16_tiling(int N, int H, int W, int Ceff);
 // slab[split][tap][e][n] = sum over the split's pixels of act(+-x[pix + tap, c(e)]) * dy[pix, n]
 // (nsplit slabs of 9*Ceff*16 floats; the caller reduces them)
+// x_rec / dy_rec (round 4; both or neither): amax records bounding the x slices read and dy -- the kernel then runs on the
+// fp16 matrix pipe with two scaled fp16 pieces per operand (OTGAN_DENSE16_WGRAD_H2=0: always the fp32 pipe)
 int dense16_wgrad(const Dense16Geo& g, const float* x, const float* dy, int ldy, int coff, float* slabs,
-                  hipStream_t s);
+                  hipStream_t s, const float* x_rec = nullptr, int x_nrec = 0, const float* dy_rec = nullptr, int dy_nrec = 0);
 
 // ---- input gradient -----------------------------------------------------------------------
 // dx[q, c] (+)= act'(x[q,c]) * G+[q,c] - act'(-x[q,c]) * G-[q,c],

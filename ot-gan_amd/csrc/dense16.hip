@@ -1173,14 +1173,66 @@ struct WgArgs {
   int N, H, W, logW, ldx, C, Ceff, doubled, ldy;
   int TR, RS, tiles, tiles_per_split;
   long slab_elems;
+  // H2 (round 4): amax records of x (the slices read) and of dy -- operands as two scaled fp16 pieces
+  const float* x_rec;
+  const float* dy_rec;
+  int x_nrec, dy_nrec;
 };
 
 constexpr int kDyStride = 24;   // floats per pixel of the dy halo tile (16 + 8 pad)
 constexpr int kAStride = 40;    // floats per pixel of the activation tile
 
-template <int PT, int ACT>
+// H2 (round 4): the same kernel on the fp16 matrix pipe.  The fp32 form is bound by v_mfma_f32_16x16x4_f32 -- 18 of them
+// (32 clocks each) per four pixels, MFMA busy 0.52 of a pipe that peaks at 157 TFLOP/s: 128 us per launch at 32 x 32 x 256
+// images, 2.9 ms of a DenseNet step.  Here the staging pass writes every activation and every dy value ONCE as a packed
+// {hi, lo} pair of scaled fp16 pieces into the same LDS slots (x 2^(14 - e) from the tensors' amax records), the inner loop
+// takes runs of four consecutive pixels per lane (k-group g of a 16-pixel step = pixels 4g .. 4g + 3: one image row), picks
+// the hi and the lo halves apart with v_perm_b32, and feeds v_mfma_f32_16x16x16_f16: three per product (hi hi, hi lo,
+// lo hi: 22 bits), 54 of 8 clocks per 16 pixels instead of 72 of 32.  The three taps of a filter row share one six-pixel
+// window of dy reads.  Same accumulator layout, same reduction and slab write-out (times 2^(ex + edy - 28), exact).
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned wg_pack_pieces(float v) {      // {hi = fp16(v), lo = fp16(v - hi)} in one dword
+  const _Float16 h = (_Float16)v;
+  const _Float16 l = (_Float16)(v - (float)h);
+  return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+__device__ __forceinline__ h16x4 wg_halves(unsigned d0, unsigned d1, unsigned d2, unsigned d3, bool hi) {
+  // bytes of v_perm_b32(s0, s1, sel): 0-3 = s1, 4-7 = s0
+  const unsigned sel = hi ? 0x05040100u : 0x07060302u;
+  u32x2 r = {__builtin_amdgcn_perm(d1, d0, sel), __builtin_amdgcn_perm(d3, d2, sel)};
+  return __builtin_bit_cast(h16x4, r);
+}
+template <int PT, int ACT, bool H2 = false>
 __global__ __launch_bounds__(256, 2) void dense16_wgrad_kernel(WgArgs a) {
   extern __shared__ f32x4 smem4[];
+  __shared__ float s_wsc[3];     // H2: scale of x, scale of dy, 2^(ex + edy - 28)
+  if (H2 && threadIdx.x < 64) {
+    const int lane_ = threadIdx.x;
+    int ex[2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      const float* rec = w ? a.dy_rec : a.x_rec;
+      const int nrec = w ? a.dy_nrec : a.x_nrec;
+      unsigned mb = 0u;
+      for (int i = lane_; i < 16 * nrec; i += 64) {
+        const unsigned v = reinterpret_cast<const unsigned*>(rec)[(long)(i >> 4) * (kAmaxSub * kAmaxSubStride) + (i & 15) * kAmaxSubStride];
+        mb = v > mb ? v : mb;
+      }
+      for (int o = 32; o; o >>= 1) {
+        const unsigned t = __shfl_xor(mb, o);
+        mb = t > mb ? t : mb;
+      }
+      float amax = __uint_as_float(mb);
+      if (w == 0 && ACT == 2 && amax == amax) amax = fmaxf(amax, 1.f);      // |elu(x)| <= max(|x|, 1)
+      int e = 0;
+      if (amax > 0.f) e = __builtin_amdgcn_frexp_expf(amax);
+      ex[w] = e;
+      if (lane_ == 0) s_wsc[w] = (amax <= 3.0e38f) ? __builtin_ldexpf(1.f, 14 - e) : __builtin_nanf("");   // (a NaN record stays loud)
+    }
+    if (lane_ == 0) s_wsc[2] = __builtin_ldexpf(1.f, ex[0] + ex[1] - 28);
+  }
+  if (H2) __syncthreads();
+  const float sxs = H2 ? s_wsc[0] : 1.f, sds = H2 ? s_wsc[1] : 1.f;
   float* sA = reinterpret_cast<float*>(smem4);                       // [64*PT][40]
   float* sD = sA + 64 * PT * kAStride;                               // [(TR+2)*RS][24]
   constexpr int NA = 2 * PT;           // float4 staging items per thread: activations
@@ -1250,6 +1302,10 @@ __global__ __launch_bounds__(256, 2) void dense16_wgrad_kernel(WgArgs a) {
       f32x4 v = RA[it];
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = d16_act<ACT>(v[j] * sg);
+      if (H2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(wg_pack_pieces(v[j] * sxs));
+      }
       *reinterpret_cast<f32x4*>(sA + (i >> 3) * kAStride + 4 * slot) = v;
     }
 #pragma unroll
@@ -1258,7 +1314,12 @@ __global__ __launch_bounds__(256, 2) void dense16_wgrad_kernel(WgArgs a) {
       if (i < dtotal) {
         const int px = i >> 2;
         const int row = px >> a.logW, col = px & (a.W - 1);
-        *reinterpret_cast<f32x4*>(sD + (row * a.RS + col + 1) * kDyStride + 4 * (i & 3)) = RD[it];
+        f32x4 v = RD[it];
+        if (H2) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(wg_pack_pieces(v[j] * sds));
+        }
+        *reinterpret_cast<f32x4*>(sD + (row * a.RS + col + 1) * kDyStride + 4 * (i & 3)) = v;
       }
     }
   };
@@ -1278,6 +1339,39 @@ __global__ __launch_bounds__(256, 2) void dense16_wgrad_kernel(WgArgs a) {
   for (int tile = t_begin; tile < t_end; ++tile) {
     const bool more = tile + 1 < t_end;
     if (more) stage_load(tile + 1);
+    if constexpr (H2) {
+      const unsigned* uA = reinterpret_cast<const unsigned*>(sA);
+      const unsigned* uD = reinterpret_cast<const unsigned*>(sD);
+#pragma unroll 1
+      for (int s16 = 0; s16 < PT; ++s16) {
+        const int q0 = (wave * PT + s16) * 16 + 4 * g;          // first of this lane's four pixels (one image row)
+        const int row = q0 >> a.logW, col = q0 & (a.W - 1);
+        const unsigned* ap = uA + q0 * kAStride + p;
+        const unsigned a00 = ap[0], a01 = ap[kAStride], a02 = ap[2 * kAStride], a03 = ap[3 * kAStride];
+        const unsigned a10 = ap[16], a11 = ap[kAStride + 16], a12 = ap[2 * kAStride + 16], a13 = ap[3 * kAStride + 16];
+        const h16x4 A0h = wg_halves(a00, a01, a02, a03, true), A0l = wg_halves(a00, a01, a02, a03, false);
+        const h16x4 A1h = wg_halves(a10, a11, a12, a13, true), A1l = wg_halves(a10, a11, a12, a13, false);
+#pragma unroll
+        for (int r3 = 0; r3 < 3; ++r3) {                       // filter row: dy_ = r3 - 1 reads halo row (row + 1 - dy_)
+          const unsigned* dp = uD + ((row + 2 - r3) * a.RS + col) * kDyStride + p;     // halo column col = pixel col - 1
+          unsigned w[6];
+#pragma unroll
+          for (int c = 0; c < 6; ++c) w[c] = dp[c * kDyStride];
+#pragma unroll
+          for (int c3 = 0; c3 < 3; ++c3) {                     // dx_ = c3 - 1: pixels col + j - dx_  ->  window index j + 2 - c3
+            const int tap = r3 * 3 + c3;
+            const h16x4 Bh = wg_halves(w[2 - c3], w[3 - c3], w[4 - c3], w[5 - c3], true);
+            const h16x4 Bl = wg_halves(w[2 - c3], w[3 - c3], w[4 - c3], w[5 - c3], false);
+            acc[tap][0] = __builtin_amdgcn_mfma_f32_16x16x16f16(A0l, Bh, acc[tap][0], 0, 0, 0);
+            acc[tap][0] = __builtin_amdgcn_mfma_f32_16x16x16f16(A0h, Bl, acc[tap][0], 0, 0, 0);
+            acc[tap][0] = __builtin_amdgcn_mfma_f32_16x16x16f16(A0h, Bh, acc[tap][0], 0, 0, 0);
+            acc[tap][1] = __builtin_amdgcn_mfma_f32_16x16x16f16(A1l, Bh, acc[tap][1], 0, 0, 0);
+            acc[tap][1] = __builtin_amdgcn_mfma_f32_16x16x16f16(A1h, Bl, acc[tap][1], 0, 0, 0);
+            acc[tap][1] = __builtin_amdgcn_mfma_f32_16x16x16f16(A1h, Bh, acc[tap][1], 0, 0, 0);
+          }
+        }
+      }
+    } else
 #pragma unroll 2
     for (int s = 0; s < 4 * PT; ++s) {
       const int qq = (wave * 4 * PT + s) * 4 + perm;          // tile pixel of this k-slot
@@ -1322,7 +1416,7 @@ __global__ __launch_bounds__(256, 2) void dense16_wgrad_kernel(WgArgs a) {
     const int tap = i >> 1, mt = i & 1;
     const int e = chunk * 32 + 16 * mt + el;
     const int src_lane = (el >> 2) * 16 + n_out;
-    if (e < a.Ceff) slab[((long)tap * a.Ceff + e) * 16 + n_out] = redf[(i * 64 + src_lane) * 4 + (el & 3)];
+    if (e < a.Ceff) slab[((long)tap * a.Ceff + e) * 16 + n_out] = redf[(i * 64 + src_lane) * 4 + (el & 3)] * (H2 ? s_wsc[2] : 1.f);
   }
 }
 
@@ -1678,7 +1772,7 @@ Dense16Tiling dense16_tiling(int N, int H, int W, int Ceff) {
 }
 
 int dense16_wgrad(const Dense16Geo& g, const float* x, const float* dy, int ldy, int coff, float* slabs,
-                  hipStream_t s) {
+                  hipStream_t s, const float* x_rec, int x_nrec, const float* dy_rec, int dy_nrec) {
   const Dense16Tiling t = dense16_tiling(g.N, g.H, g.W, g.Ceff);
   if (!t.ok) {
     otgan_set_error("dense16 wgrad: unsupported geometry");
@@ -1690,21 +1784,32 @@ int dense16_wgrad(const Dense16Geo& g, const float* x, const float* dy, int ldy,
   a.doubled = g.doubled; a.ldy = ldy;
   a.TR = t.TR; a.RS = t.RS; a.tiles = t.tiles; a.tiles_per_split = t.tiles_per_split;
   a.slab_elems = (long)9 * g.Ceff * 16;
+  static const bool h2_off = [] { const char* e = getenv("OTGAN_DENSE16_WGRAD_H2"); return e && e[0] == '0'; }();
+  const bool h2 = !h2_off && x_rec && dy_rec && x_nrec > 0 && dy_nrec > 0 && g.W >= 4;
+  a.x_rec = x_rec; a.dy_rec = dy_rec; a.x_nrec = x_nrec; a.dy_nrec = dy_nrec;
   size_t lds = ((size_t)64 * t.PT * kAStride + (size_t)(t.TR + 2) * t.RS * kDyStride) * 4;
   if (lds < 18 * 64 * 16) lds = 18 * 64 * 16;   // wave-reduction scratch
   const dim3 grid(t.nsplit, t.nchunk), blk(256);
-#define D16_WG(PT_)                                                                             \
-  do {                                                                                          \
-    if (g.act == 1) hipLaunchKernelGGL((dense16_wgrad_kernel<PT_, 1>), grid, blk, lds, s, a);   \
-    else if (g.act == 2) hipLaunchKernelGGL((dense16_wgrad_kernel<PT_, 2>), grid, blk, lds, s, a); \
-    else hipLaunchKernelGGL((dense16_wgrad_kernel<PT_, 0>), grid, blk, lds, s, a);              \
+#define D16_WG2(PT_, H2_)                                                                             \
+  do {                                                                                                \
+    if (g.act == 1) hipLaunchKernelGGL((dense16_wgrad_kernel<PT_, 1, H2_>), grid, blk, lds, s, a);    \
+    else if (g.act == 2) hipLaunchKernelGGL((dense16_wgrad_kernel<PT_, 2, H2_>), grid, blk, lds, s, a); \
+    else hipLaunchKernelGGL((dense16_wgrad_kernel<PT_, 0, H2_>), grid, blk, lds, s, a);               \
+  } while (0)
+#define D16_WG(PT_)          \
+  do {                       \
+    if (h2) D16_WG2(PT_, true); \
+    else D16_WG2(PT_, false);   \
   } while (0)
   if (t.PT == 4) {
     // 72.6 KB of LDS: above the 64 KB default of dynamic shared memory
     static const bool once = [] {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&dense16_wgrad_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&dense16_wgrad_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&dense16_wgrad_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&dense16_wgrad_kernel<4, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&dense16_wgrad_kernel<4, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&dense16_wgrad_kernel<4, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&dense16_wgrad_kernel<4, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&dense16_wgrad_kernel<4, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&dense16_wgrad_kernel<4, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
       return true;
     }();
     (void)once;
@@ -1712,6 +1817,7 @@ int dense16_wgrad(const Dense16Geo& g, const float* x, const float* dy, int ldy,
   } else if (t.PT == 2) D16_WG(2);
   else D16_WG(1);
 #undef D16_WG
+#undef D16_WG2
   return OTGAN_OK;
 }
 

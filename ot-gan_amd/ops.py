@@ -840,6 +840,7 @@ class DenseBlockFunction(torch.autograd.Function):
             ctx.sw = sw
             ctx.save_for_backward(buf, *saved)
             ctx.descs, ctx.maps = descs, maps
+            ctx.fwd_recs = (R, gbase, gidx) if shared else None      # read again by the chains' weight gradients
             if shared:
                 x0_rec = ctx.x_recs[0][0]     # the producer's record of x0, or the reduction wide_fwd(0) made
                 tag_amax(buf, torch.maximum(x0_rec, R.amax(0)))
@@ -1087,7 +1088,16 @@ def _backward_by_slice(ctx, buf, saved, G, dbuf, need_w):
                 cmap, _inv = ctx.maps[c]
                 off = C0 + plan["g0"][c] * F
                 dw_g[c] = torch.empty_like(sw["w_g"][c])
+                if ctx.fwd_recs is not None:
+                    # records of the slices the layer read (the rows its forward kernel read) and of its output gradient (the
+                    # slices' rows from c on and the incoming bound): the kernel runs on the fp16 matrix pipe (round 4)
+                    R, gbase, gidx = ctx.fwd_recs
+                    desc.x_amax = R[gbase[gidx[plan["g0"][c]]]].data_ptr()
+                    desc.x_amax_count = 1 + plan["own_len"][c]
+                    desc.dy_amax, desc.dy_amax_count = RR[c].data_ptr(), L + 1 - c
                 conv_wgrad_raw(desc, buf[..., off:], cmap, G, dw_g[c])
+                desc.x_amax = desc.dy_amax = None
+                desc.x_amax_count = desc.dy_amax_count = 0
     wide_bwd(0, ctx.needs_input_grad[0])
     if need_w:
         assert ctx.batched and len(wides) <= 2
