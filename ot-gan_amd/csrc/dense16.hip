@@ -1762,7 +1762,12 @@ Dense16Tiling dense16_tiling(int N, int H, int W, int Ceff) {
   t.RS = W == 8 ? 16 : W + 2;
   t.tiles = N * (H / t.TR);
   t.nchunk = (Ceff + 31) / 32;
-  int want = (1536 + t.nchunk - 1) / t.nchunk;
+  // workgroups of the weight-gradient grid (pixel splits x channel chunks).  1536 until round 4 (three rounds of the 512
+  // resident ones, tuned for the fp32-pipe kernel); with the fp16-pipe kernel the per-workgroup epilogue (four-wave
+  // reduction through LDS, slab write) and the slab reduction weigh more: 768 measured best (wgrad + slab_reduce of a DenseNet
+  // step 2.52 -> 2.27 ms; 512: 2.41, 1024: 2.46)
+  static const int wg_target = [] { const char* e = getenv("OTGAN_DENSE16_WG_TARGET"); return e && atoi(e) > 0 ? atoi(e) : 768; }();
+  int want = (wg_target + t.nchunk - 1) / t.nchunk;
   if (want > t.tiles) want = t.tiles;
   if (want < 1) want = 1;
   t.tiles_per_split = (t.tiles + want - 1) / want;
