@@ -1177,6 +1177,7 @@ struct WgArgs {
   const float* x_rec;
   const float* dy_rec;
   int x_nrec, dy_nrec;
+  int xmap, nsplit, nchunk;   // 1: one-dimensional grid, (split, chunk) from the XCD-aware map in the kernel
 };
 
 constexpr int kDyStride = 24;   // floats per pixel of the dy halo tile (16 + 8 pad)
@@ -1239,9 +1240,19 @@ __global__ __launch_bounds__(256, 2) void dense16_wgrad_kernel(WgArgs a) {
   constexpr int ND = PT + 2;           // dy halo rows: (64*PT + 2W)*4/256 = PT + W/32 <= PT + 2
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = lane & 15, g = lane >> 4;
-  const int chunk = blockIdx.y;
+  // (split, chunk) of this workgroup.  xmap (round 4, one-dimensional grid): workgroup b runs on XCD b % 8 (round-robin
+  // placement, observed -- a speed matter only); the chunks of ONE pixel split are given to consecutive workgroups of the same
+  // XCD, so that the dy tile every chunk of the split reads again -- half the kernel's traffic at seven chunks -- comes out
+  // of that XCD's L2 instead of memory.
+  int chunk = blockIdx.y, split = blockIdx.x;
+  if (a.xmap) {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    chunk = idx % a.nchunk;
+    split = (idx / a.nchunk) * 8 + xcd;
+    if (split >= a.nsplit) return;
+  }
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  const int t_begin = blockIdx.x * a.tiles_per_split;
+  const int t_begin = split * a.tiles_per_split;
   const int t_end = min(t_begin + a.tiles_per_split, a.tiles);
   const int tiles_per_img = a.H / a.TR;
 
@@ -1408,7 +1419,7 @@ __global__ __launch_bounds__(256, 2) void dense16_wgrad_kernel(WgArgs a) {
     __syncthreads();
   }
   // D[m = 4g + r][n = p]  ->  slab[tap][chunk*32 + 16mt + m][n]; thread = (e_local, n): coalesced
-  float* slab = a.slabs + (long)blockIdx.x * a.slab_elems;
+  float* slab = a.slabs + (long)split * a.slab_elems;
   const float* redf = reinterpret_cast<const float*>(red);
   const int n_out = tid & 15, el = tid >> 4;
 #pragma unroll
@@ -1794,7 +1805,11 @@ int dense16_wgrad(const Dense16Geo& g, const float* x, const float* dy, int ldy,
   a.x_rec = x_rec; a.dy_rec = dy_rec; a.x_nrec = x_nrec; a.dy_nrec = dy_nrec;
   size_t lds = ((size_t)64 * t.PT * kAStride + (size_t)(t.TR + 2) * t.RS * kDyStride) * 4;
   if (lds < 18 * 64 * 16) lds = 18 * 64 * 16;   // wave-reduction scratch
-  const dim3 grid(t.nsplit, t.nchunk), blk(256);
+  static const bool xmap_off = [] { const char* e = getenv("OTGAN_DENSE16_WGRAD_XMAP"); return e && e[0] == '0'; }();
+  a.xmap = (!xmap_off && t.nchunk > 1) ? 1 : 0;
+  a.nsplit = t.nsplit; a.nchunk = t.nchunk;
+  const dim3 grid = a.xmap ? dim3(8u * ((t.nsplit + 7) / 8) * t.nchunk, 1) : dim3(t.nsplit, t.nchunk);
+  const dim3 blk(256);
 #define D16_WG2(PT_, H2_)                                                                             \
   do {                                                                                                \
     if (g.act == 1) hipLaunchKernelGGL((dense16_wgrad_kernel<PT_, 1, H2_>), grid, blk, lds, s, a);    \
