@@ -2691,14 +2691,26 @@ int otgan_conv2d_fold_weights_f32(const otgan_conv_desc* d, const float* w, floa
 static int igemm_fwd_ksplit(const otgan_conv_desc* d, const Geo& g, bool vec, long Mtot) {
   static const bool off = [] { const char* v = getenv("OTGAN_IGEMM_KSPLIT"); return v && v[0] == '0'; }();
   if (off || !vec || g.fold || d->upsample || d->Cout % 4 || d->ldy % 4 || d->y_coff % 4 || g.Ceff % 4 || !igemm_x3s()) return 1;
-  if (d->Cout <= 32 || (d->Cout > 128 && d->Cout <= 160) || (d->Cout > 192 && d->Cout <= 224 && ceil_div((int)Mtot, 128) >= 256)) return 1;
+  static const bool wide = [] { const char* v = getenv("OTGAN_IGEMM_KSPLIT_WIDE"); return !(v && v[0] == '0'); }();
+  if (d->Cout <= 32) return 1;
+  if (!wide && ((d->Cout > 128 && d->Cout <= 160) || (d->Cout > 192 && d->Cout <= 224 && ceil_div((int)Mtot, 128) >= 256))) return 1;
   const long tiles128 = (long)ceil_div((int)Mtot, 128) * ceil_div(d->Cout, 128);
-  if (tiles128 >= 512) return 1;                         // (CfgMain16: enough tiles)
+  if (!wide && tiles128 >= 512) return 1;                         // (CfgMain16: enough tiles)
   const long tiles = (long)ceil_div((int)Mtot, 64) * ceil_div(d->Cout, 128);
-  if (tiles >= 256) return 1;
+  // (counting the 128 x 160 / 128 x 224 tiles of the exact-width configurations instead was measured: the 512-tile
+  // 32x32 -> 16x16 transition does not gain from a split -- 552 us either way -- and the 128-tile one loses: 229 -> 316 us)
+  // Round 4, late: these kernels run one k step per global-load round trip (prefetch depth one), so with two workgroups
+  // per compute unit they are bound by memory LATENCY (the 16x16 -> 8x8 DenseNet transition: 512 tiles, 450 k steps of
+  // 1 us each, MFMA busy 0.14).  More workgroups in flight hide it: K splits up to 2048 workgroups (was: only below 256
+  // tiles, up to 512), also for the shapes of the exact-width column tiles (Cout 129 - 160, 193 - 224), slices of at
+  // least 8 x 16 channels.  Measured on the DenseNet step's forward transitions: 41.6 -> 32.2 ms per 18 steps.
+  static const int thr = [] { const char* v = getenv("OTGAN_IGEMM_KSPLIT_TILES"); return v && atoi(v) > 0 ? atoi(v) : 2048; }();
+  static const int target = [] { const char* v = getenv("OTGAN_IGEMM_KSPLIT_TARGET"); return v && atoi(v) > 0 ? atoi(v) : 2048; }();
+  static const int minsl = [] { const char* v = getenv("OTGAN_IGEMM_KSPLIT_MINSL"); return v && atoi(v) > 0 ? atoi(v) : 8; }();
+  if (tiles >= thr) return 1;
   const int nsl = ceil_div(g.Ceff, 16);
-  int ks = (int)(512 / tiles);
-  if (ks > nsl / 16) ks = nsl / 16;
+  int ks = (int)(target / tiles);
+  if (ks > nsl / minsl) ks = nsl / minsl;
   if (ks > 8) ks = 8;
   return ks < 2 ? 1 : ks;
 }
