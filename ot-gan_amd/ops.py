@@ -869,7 +869,7 @@ class DenseBlockFunction(torch.autograd.Function):
         # tensor itself is used when nothing else can see it -- contiguous and referenced only by the engine and this call
         # (a gradient that a torch op hands to two nodes at once, e.g. of `block_a + block_b`, has more references) --
         # instead of a copy of the whole buffer per block and pass (0.5 ms of a DenseNet step).
-        if _GRAD_INPLACE and dbuf.is_contiguous() and dbuf._use_count() <= 2:
+        if _GRAD_INPLACE and dbuf.is_contiguous() and hasattr(dbuf, "_use_count") and dbuf._use_count() <= 2:
             G = dbuf
         else:
             G = dbuf.contiguous().clone()
