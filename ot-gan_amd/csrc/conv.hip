@@ -2574,7 +2574,8 @@ void launch_igemm(bool vec_ok, int Ck, int rows, int ncols, bool paired, int ncl
   }
   if constexpr (EPI == EPI_FWD) {
     // forward of the wide-but-not-256 outputs: one exact column tile instead of two 128-wide ones
-    if (!paired && vec_ok && Ck % 32 == 0 && ncols > 128 && ncols <= 160 && (long)ceil_div(rows, 128) * ncls >= 256) {
+    static const bool w160 = [] { const char* v = getenv("OTGAN_IGEMM_W160"); return !(v && v[0] == '0'); }();
+    if (w160 && !paired && vec_ok && Ck % 32 == 0 && ncols > 128 && ncols <= 160 && (long)ceil_div(rows, 128) * ncls >= 256) {
       dim3 grid(ceil_div(rows, CfgW160::BM), 1, ncls);
       if (igemm_x3s()) launch_igemm3_x3s<CfgW160k16, EPI, ACT>(grid, s, ga, ct, wb, e);
       else launch_igemm3<CfgW160, true, EPI, ACT>(grid, s, ga, ct, wb, e);
