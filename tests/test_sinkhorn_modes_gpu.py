@@ -32,7 +32,7 @@ def test_matching_suite_in_every_sweep_regime(env):
     sel = [] if "OTGAN_SINKHORN_LIN_RANGE" in env else ["-k", "sinkhorn or golden or full_size or iteration or equivariance"]
     if "OTGAN_MATCH_NARROW" in env:     # the matching GEMMs of N >= 256 on the 256 x 128 kernel (off by default: 5 % slower)
         files = ["tests/test_matching_gpu.py", "tests/test_matching_grad_gpu.py"]
-        sel = ["-k", "full_size or batched or rank or rows or single_batch"]
+        sel = ["-k", "cost_matrix_batched or rank_of_8"]      # cost slices (NT kernel) and plan application (TL kernel) at N = 1024
     r = subprocess.run([sys.executable, "-m", "pytest", *files, "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", *sel],
                        cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
