@@ -1025,12 +1025,31 @@ __global__ void closed_form_distance_kernel(const double* stats, int N, double* 
   dist[0] = (2.0 * T[0] + 2.0 * T[1] - (T[2] + T[3] + T[4] + T[5])) / (4.0 * N) + failure_poison(stats, 6);
 }
 
-// single-batch distance the same way (matching.py:147-152 with the three plans of :131-134):
-// nd_xy = sum(M_xy) - <M_xy, C_xy> (the 999 on the diagonal meets plan entries that are exactly 0),
-// dist = (nd_bb + nd_aa - 2 nd_ab) / (2 n)
-__global__ void closed_form_single_distance_kernel(const double* stats, int n, double* dist) {
+// single-batch distance the same way (matching.py:147-152 with the three plans of :131-134): the reference's nd_xy is a dot
+// product with the REAL features, i.e. nd_xy = sum(M_xy) - <M_xy, C_xy> with the cosine cost WITHOUT the 999 the a-a / b-b
+// problems carry on their diagonals (matching.py:109-110), while the kernel statistics hold <M, C + 999 I>: 999 trace(M) is
+// added back (exactly 0 from lambda * 999 of about 90 upwards, 999 sum(M_ii) / (2 n) of bias for small lambda),
+// dist = (nd_bb + nd_aa - 2 nd_ab) / (2 n).  One workgroup of 256 threads; plan = the three [n][n] plans.
+__global__ void closed_form_single_distance_kernel(const double* stats, const float* plan, int n, double diag, double* dist) {
+  __shared__ double tr[2][256];
+  for (int p = 0; p < 2; ++p) {
+    double t = 0.0;
+    for (long i = threadIdx.x; i < n; i += 256) t += (double)plan[(long)p * n * n + i * (n + 1L)];
+    tr[p][threadIdx.x] = t;
+  }
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {          // fixed-order tree: deterministic
+    if ((int)threadIdx.x < w) {
+      tr[0][threadIdx.x] += tr[0][threadIdx.x + w];
+      tr[1][threadIdx.x] += tr[1][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x) return;
   double T[3];
   for (int p = 0; p < 3; ++p) T[p] = stats[p * 4 + 2] - stats[p * 4 + 1];
+  T[0] += diag * tr[0][0];
+  T[1] += diag * tr[1][0];
   dist[0] = (T[1] + T[0] - 2.0 * T[2]) / (2.0 * n) + failure_poison(stats, 3);
 }
 
@@ -2068,7 +2087,7 @@ static int single_grad_impl(const float* fa, const float* fb, int n, int D, long
   }
   if (rc) return rc;
   hipLaunchKernelGGL(entropy_finalize_kernel, dim3(1), dim3(1), 0, s, w.stats, 3, n, entropy);
-  hipLaunchKernelGGL(closed_form_single_distance_kernel, dim3(1), dim3(1), 0, s, w.stats, n, dist);
+  hipLaunchKernelGGL(closed_form_single_distance_kernel, dim3(1), dim3(256), 0, s, w.stats, w.plan, n, (double)diag[0], dist);
   OTGAN_CHECK_LAUNCH("single-batch matching finalize");
   if (stats) hipMemcpyAsync(stats, w.stats, sizeof(double) * 12, hipMemcpyDeviceToDevice, s);
   return OTGAN_OK;

@@ -6,6 +6,7 @@ fallback: CPU tensors raise OtganError.
 """
 import ctypes
 import os
+import sys
 from collections import OrderedDict
 
 import torch
@@ -548,6 +549,8 @@ def _row_order_back(order):
 
 
 _block_cache = OrderedDict()   # id(V of layer 0) -> (per-layer normalised weights it was made from, value)
+DENSE16_MAX_BATCH = 16         # otgan_layers.h: OTGAN_DENSE16_MAX_BATCH (chain layers per otgan_dense16_prepare_* call)
+DENSE16_MAX_CHAIN = 17         # slices per otgan_dense16_chain_{fwd,bwd}_f32 call (conv.hip)
 
 
 def _wide_operands(per_layer, layers, row0, nrows, order, F, desc):
@@ -675,9 +678,40 @@ def _split_block_plan(N, H, W, C0, L, F, segs0, preact, device):
     probe = ConvDesc(N, H, W, F, Ctot, 0, 3, 3, 1, F, Ctot, C0, preact, 1)
     probe.y_accumulate, probe.list_width = 1, F
     h2 = bool(lib.otgan_dense16_h2_ok(ctypes.byref(probe))) and os.environ.get("OTGAN_DENSE_AMAX", "1") != "0" and _FUSED_AMAX
-    return {"wide": wide, "g0": g0, "own_len": [k - g0[k] for k in range(L)], "h2": h2,
+    # the library prepares at most OTGAN_DENSE16_MAX_BATCH chain layers per call (forward and by-slice backward filters) and
+    # a chain call takes at most 17 slices per group: longer blocks / groups (layers_per_block > 18 at the default grouping)
+    # keep the fp32 growth kernels
+    own_len = [k - g0[k] for k in range(L)]
+    starts = sorted({wd["d0"] for wd in wide}) + [L]
+    if sum(1 for n in own_len if n) > DENSE16_MAX_BATCH or max(b - a for a, b in zip(starts[:-1], starts[1:])) > DENSE16_MAX_CHAIN:
+        h2 = False
+    return {"wide": wide, "g0": g0, "own_len": own_len, "h2": h2,
             "own_row0": [(C0 + g0[k] * F) * mult for k in range(L)],
             "key": (N, H, W, C0, L, F, tuple(segs0), preact, tuple(g0), h2)}
+
+
+def _calibrate_backward_arg_refs():
+    """sys.getrefcount of the gradient argument inside a custom Function's backward when nothing but the engine and the
+    call hold it (a CPU mini-graph; the count is a property of the interpreter / torch build, 6 on Python 3.10 + torch 2.10)."""
+    seen = []
+
+    class _Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, dy):
+            seen.append(sys.getrefcount(dy))
+            return dy
+
+    with torch.enable_grad():
+        x = torch.zeros(2, requires_grad=True)
+        (_Probe.apply(x) * 3).sum().backward()
+    return seen[0]
+
+
+_BACKWARD_ARG_REFS = _calibrate_backward_arg_refs()
 
 
 class DenseBlockFunction(torch.autograd.Function):
@@ -862,17 +896,34 @@ class DenseBlockFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dbuf):
-        buf, *saved = ctx.saved_tensors
-        L, C0, F = ctx.L, ctx.C0, ctx.F
-        N, H, W, Ctot = buf.shape
         # gradient w.r.t. the whole concatenation; the earlier slices' gradients are accumulated into it.  The incoming
         # tensor itself is used when nothing else can see it -- contiguous and referenced only by the engine and this call
         # (a gradient that a torch op hands to two nodes at once, e.g. of `block_a + block_b`, has more references) --
         # instead of a copy of the whole buffer per block and pass (0.5 ms of a DenseNet step).
-        if _GRAD_INPLACE and dbuf.is_contiguous() and hasattr(dbuf, "_use_count") and dbuf._use_count() <= 2:
+        # `_use_count` counts references to the C++ tensor, not Python references to its wrapper: a gradient that a tensor
+        # hook (register_hook) or an upstream custom Function has kept alive shows up in sys.getrefcount only.
+        # Both are checked, the second against the count an un-retained gradient has inside a custom backward in this
+        # interpreter / torch build (calibrated at import): a retained gradient is copied, never overwritten.
+        if (_GRAD_INPLACE and dbuf.is_contiguous() and hasattr(dbuf, "_use_count") and dbuf._use_count() <= 2 and
+                sys.getrefcount(dbuf) <= _BACKWARD_ARG_REFS):
             G = dbuf
         else:
             G = dbuf.contiguous().clone()
+        try:
+            return DenseBlockFunction._backward_impl(ctx, dbuf, G)
+        finally:
+            # the raw kernels wrote into G without bumping its version counter: a record (or column sums) tagged onto the
+            # incoming tensor would still pass the version check
+            if G is dbuf:
+                for tag in ("_otgan_amax", "_otgan_colsum"):
+                    if hasattr(dbuf, tag):
+                        delattr(dbuf, tag)
+
+    @staticmethod
+    def _backward_impl(ctx, dbuf, G):
+        buf, *saved = ctx.saved_tensors
+        L, C0, F = ctx.L, ctx.C0, ctx.F
+        N, H, W, Ctot = buf.shape
         need_w = any(ctx.needs_input_grad[4:])
         grads = [None] * (3 * L)
         rows = N * H * W

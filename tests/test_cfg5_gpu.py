@@ -13,6 +13,7 @@ import torch
 
 from oracle import matching_np as M
 from oracle import nets_torch as NT
+from conftest import REL_DIFF_INJECTED
 from tests import golden_nets as GN
 
 pytestmark = pytest.mark.gpu
@@ -154,7 +155,7 @@ def test_matching_cfg5_size_vs_oracle(dev):
     for k, got, want in zip("aa bb ab ba".split(), out[:4], ref[:4]):
         assert _rel(torch.stack(got), np.stack(want)) < 2e-4, k
     ga = torch.stack(out[0]) - torch.stack(out[2])
-    assert _rel(ga, np.stack(ref[0]) - np.stack(ref[2])) < 2e-3
+    assert _rel(ga, np.stack(ref[0]) - np.stack(ref[2])) < 2 * REL_DIFF_INJECTED     # (difference of two separately rounded arrays)
     assert float(out[4]) == pytest.approx(float(ref[4]), rel=2e-4)
     for d in (float(out.distance), float(matching.calc_distance(A, Bt, out)), float(matching.closed_form_distance(out))):
         assert abs(d - dref) <= 1e-4 * abs(dref) + 1e-7, (d, dref)

@@ -62,3 +62,21 @@ def test_blocks_that_are_not_cut(monkeypatch):
     monkeypatch.setenv("OTGAN_DENSE_GROUP", "0")                                         # block input only
     plan = ops._split_block_plan(8, 8, 8, 32, 16, 16, (32,), act, CPU)
     assert len(plan["wide"]) == 1 and plan["g0"] == [0] * 16
+
+
+def test_long_blocks_keep_the_fp32_growth_kernels(monkeypatch):
+    """the two-scaled-fp16-piece chain path prepares at most 16 chain layers per library call and a chain call
+    takes at most 17 slices; a block with more (layers_per_block = 32 at the default grouping: 30 own-chain layers) must not
+    select it -- it used to raise OtganError in the forward pass."""
+    for k in ("OTGAN_DENSE_SPLIT", "OTGAN_DENSE_GROUP", "OTGAN_DENSE_AMAX", "OTGAN_FUSED_AMAX"):
+        monkeypatch.delenv(k, raising=False)
+    act = ops.ACT["crelu"]
+    p16 = ops._split_block_plan(8, 16, 16, 32, 16, 16, (32,), act, CPU)
+    p32 = ops._split_block_plan(8, 16, 16, 32, 32, 16, (32,), act, CPU)
+    assert p16 is not None and p32 is not None
+    assert sum(1 for n in p16["own_len"] if n) == 14 and sum(1 for n in p32["own_len"] if n) == 30
+    assert p32["h2"] is False
+    # (whether the 16-layer block takes the fp16 chain kernels is the library's answer: otgan_dense16_h2_ok)
+    monkeypatch.setenv("OTGAN_DENSE_GROUP", "0")              # block input only: one group of 20 slices > 17 per chain call
+    p20 = ops._split_block_plan(8, 16, 16, 32, 20, 16, (32,), act, CPU)
+    assert p20 is not None and len(p20["wide"]) == 1 and p20["h2"] is False

@@ -463,6 +463,9 @@ def test_wino_outlier_zero_and_nan(dev):
     ("crelu_halves", 2, 8, 8, (32, 16), 16, "crelu"),     # 16 layers: the first 8 outputs enter the last 8 layers as one 128 -> 128 convolution
     ("elu_halves", 1, 8, 8, (64,), 16, "elu"),
     ("crelu_k_pad", 2, 8, 8, (24, 16), 16, "crelu"),       # 80 effective input channels (the 8x8 critic block has 400)
+    # 20 layers = 18 own-chain layers, more than one otgan_dense16_prepare_* call takes (16) -- the block must
+    # stay off the fp16 chain kernels instead of raising in the forward pass
+    ("crelu_20_layers", 1, 8, 8, (32,), 20, "crelu"),
 ], ids=lambda c: c[0])
 def test_dense_block_split_matches_chain(dev, case, monkeypatch):
     """A dense block computed as "block-input convolution (Winograd) + growth chain" (ops.DenseBlockFunction) against
@@ -817,6 +820,17 @@ def test_dense_block_gradient_buffer_in_place(dev, monkeypatch):
     gout = w.clone()
     ya.backward(gradient=gout)
     assert torch.equal(gout, w)
+    # a gradient that a tensor hook keeps alive has the same `_use_count()` as an un-retained one -- only the
+    # Python reference count shows it.  The retained tensor must hold the block's INCOMING gradient after the pass
+    # (2 * w * ya here), not the accumulated one.
+    kept = []
+    xa = x0.clone().requires_grad_(True)
+    pa = [[t.clone().requires_grad_(True) for t in p] for p in PA]
+    ya = ops.dense_block_op(xa, (C0,), pa, 3, ops.ACT["crelu"])
+    ya.register_hook(lambda g: kept.append(g))
+    expect = (2.0 * w * ya).detach().clone()
+    torch.autograd.grad(((ya * w) * ya).sum(), [xa] + [t for p in pa for t in p])
+    assert len(kept) == 1 and torch.allclose(kept[0], expect, rtol=1e-6, atol=1e-6)
 
 
 @pytest.mark.gpu

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import REL_DIFF_INJECTED, load_golden
 from oracle import matching_np as M
 
 pytestmark = pytest.mark.gpu
@@ -270,7 +270,7 @@ def test_full_size_vs_oracle(dev, S, B, D, iters):
     # injected gradient (train.py:111): f_aa - f_ab
     ga = (torch.stack(out[0]) - torch.stack(out[2])).cpu().numpy()
     gr = np.stack(ref[0]) - np.stack(ref[2])
-    assert _rel(ga, gr) < 2e-3
+    assert _rel(ga, gr) < 2 * REL_DIFF_INJECTED      # (here the difference of two separately rounded fp32 arrays)
     assert float(out[4]) == pytest.approx(float(ref[4]), rel=2e-4)
     for d in (float(out.distance), float(matching.calc_distance(A, Bt, out)),
               float(matching.closed_form_distance(out))):

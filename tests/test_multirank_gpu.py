@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import REL_DIFF_INJECTED
 from oracle import matching_np as M
 
 pytestmark = pytest.mark.gpu
@@ -75,7 +76,7 @@ def test_rank_of_8_rows_vs_oracle(dev, D, iters):
             assert _rel(got.cpu().numpy(), want) < REL_FEAT, (r, k)
         # the injected gradients of the rank's samples (train.py:111,125-126)
         g_gen = (outs[0] - outs[2]).cpu().numpy()
-        assert _rel(g_gen, ref[0] - ref[2]) < 2e-3, r
+        assert _rel(g_gen, ref[0] - ref[2]) < 2 * REL_DIFF_INJECTED, r     # (difference of two separately rounded fp32 arrays)
         assert float(ent) == pytest.approx(float(ent_ref), rel=2e-4)
         assert abs(float(dist) - dist_ref) <= REL_LOSS * abs(dist_ref) + 1e-7, (r, float(dist), dist_ref)
 
