@@ -1152,178 +1152,24 @@ bool use_fmap() {
 }
 unsigned build_fmap(BgArgs& b) { return x3_build_fmap(b); }
 
-// Persistent "stream" GEMM (gemm_x3.h): workgroups per XCD = compute units / 8; OTGAN_X3_STREAM=0 keeps the
-// one-tile-per-workgroup kernel.  The parked-tile area is the tail of every Winograd workspace.
-int x3_stream_mode() {   // 0: off, 1: where it pays (few tiles per compute unit), 2: every launch
-  // (read per launch, so that a debugging session can switch kernels inside one process: tools/debug/stream_step_diff.py)
-  const char* e = getenv("OTGAN_X3_STREAM");
-  return use_fmap() ? (e ? atoi(e) : 1) : 0;
-}
-int x3_stream_nw() {
-  static const int nw = [] {
-    if (!use_fmap()) return 0;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
-      cus = 256;
-    (void)hipGetLastError();
-    int n = cus / 8;
-    return n > X3_SK_MAXW ? X3_SK_MAXW : n;
-  }();
-  return nw;
-}
-size_t x3_stream_floats() { return x3_stream_nw() ? x3_stream_ws_floats(8 * x3_stream_nw()) + 4 : 0; }
-// the area inside a workspace of `total` floats (16-byte aligned start)
-float* x3_stream_area(float* ws, size_t total) {
-  if (!x3_stream_nw()) return nullptr;
-  float* p = ws + (total - x3_stream_floats());
-  return reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(p) + 15) & ~(uintptr_t)15);
-}
-unsigned long long x3_next_epoch() {
-  // multiples of 16 (the low four bits of a flag carry the writer's XCD), never 0 (= "consumed")
-  static std::atomic<unsigned long long> e{(0x9e3779b97f4a7c15ull ^ ((unsigned long long)(uintptr_t)&e << 17)) & ~15ull};
-  unsigned long long v = e.fetch_add(0x632be59bd9b4e010ull) + 0x632be59bd9b4e010ull;
-  return v ? v : 16;
-}
-// dev tool: OTGAN_X3_DUMP=k writes C of the k-th stream-eligible NT launch to /tmp/x3_dump_<k>_<tag>.bin
-int g_stream_idx = -1;
-void maybe_dump(const BgArgs& b, hipStream_t s) {
-  const char* e = getenv("OTGAN_X3_DUMP");
-  if (!e || g_stream_idx != atoi(e)) return;
-  (void)hipStreamSynchronize(s);
-  const size_t n = (size_t)WF * b.M * b.N;
-  std::vector<float> h(n);
-  (void)hipMemcpy(h.data(), b.C, n * 4, hipMemcpyDeviceToHost);
-  const char* tag = getenv("OTGAN_X3_DUMP_TAG");
-  char fn[256];
-  snprintf(fn, sizeof(fn), "/tmp/x3_dump_%d_%s.bin", g_stream_idx, tag ? tag : "x");
-  FILE* f = fopen(fn, "wb");
-  if (f) { fwrite(h.data(), 4, n, f); fclose(f); }
-  fprintf(stderr, "dumped %s: %d x %d x %d\n", fn, WF, b.M, b.N);
-  g_stream_idx = -1;
-}
-
-// plans are a function of the shape only: planned once per shape (a DCGAN step launches ~50 of these GEMMs)
-struct StreamPlan {
-  bool ok;
-  unsigned bound[8][41];
-  unsigned long long inv_tn;
-  unsigned char cmask[64];
-};
-bool cached_stream_plan(BgArgs& b, int nw) {
-  static std::mutex mu;
-  static std::map<std::array<int, 7>, StreamPlan> cache;
-  const std::array<int, 7> key = {b.M, b.N, b.K, b.seg_mode, b.seg_len, b.seg_skip, nw};
-  std::lock_guard<std::mutex> lock(mu);
-  auto it = cache.find(key);
-  if (it == cache.end()) {
-    StreamPlan p;
-    memset(&p, 0, sizeof(p));
-    p.ok = x3_plan_stream(b, nw);
-    if (p.ok) {
-      memcpy(p.bound, b.sk_bound, sizeof(p.bound));
-      p.inv_tn = b.sk_inv_tn;
-      memcpy(p.cmask, b.sk_cmask, sizeof(p.cmask));
-    }
-    it = cache.emplace(key, p).first;
-  }
-  const StreamPlan& p = it->second;
-  if (!p.ok) return false;
-  memcpy(b.sk_bound, p.bound, sizeof(p.bound));
-  b.sk_inv_tn = p.inv_tn;
-  memcpy(b.sk_cmask, p.cmask, sizeof(p.cmask));
-  b.sk_nw = nw;
-  return true;
-}
-// does the selection rule send a GEMM with this many 256 x 256 tiles per frequency to the stream kernel?
-bool stream_wanted(long tiles, int seg_mode) {
-  const int mode = x3_stream_mode();
-  if (!mode || !x3_stream_nw()) return false;
-  if (mode != 1) return true;
-  const long per_xcd2 = tiles * 9;   // 2 x tiles per XCD (4.5 frequencies each)
-  static const long half_rounds = [] { const char* e = getenv("OTGAN_X3_STREAM_HALF_ROUNDS"); return e ? atol(e) : 3L; }();
-  return seg_mode != 1 && per_xcd2 > 2L * x3_stream_nw() && per_xcd2 <= half_rounds * x3_stream_nw();
-}
-template <bool TL>
-bool launch_stream(BgArgs& b, hipStream_t s) {
-  if (!b.sk_partial || !x3_stream_nw() || !x3_stream_mode() || b.xmap != 4) return false;
-  // Where it pays.  With six MFMAs per product (three bf16 pieces) the stream kernel won 1.1 - 1.33 x up to 1.5 tiles per
-  // compute unit, was a wash around 2.25 and lost 5 % from 4.5 on (full rounds, nothing parked).  With three MFMAs per
-  // product a K stage is half as long and the kernel's per-stage bookkeeping and per-tile table weigh twice as much
-  // (tools/ablate/x3_phase.hip, -DX3_PIECES=2; us one-tile -> stream): 0.56 tiles per CU 258 -> 276, 1.125 269 -> 225,
-  // 2.25 234 -> 245, 4.5 233 -> 289, 9 270 -> 334; whole DCGAN step, same box: never 10.97 ms, <= 1.5 tiles 11.12,
-  // <= 2.5 tiles 11.30.  What is left is the one case where the one-tile grid wastes most of a round: just above
-  // one tile per compute unit (the second round 1/8 .. 1/2 full).  Forward passes of the strided layers balance their
-  // three K lengths longest-first already.
-  if (!stream_wanted((long)b.tiles_m * b.tiles_n, b.seg_mode)) return false;
-  if (!cached_stream_plan(b, x3_stream_nw())) return false;
-  {   // dev tool: OTGAN_X3_STREAM_ONLY=k lets only the k-th eligible launch (counted since the variable last changed)
-      // take the stream kernel; OTGAN_X3_STREAM_LOG=1 prints every eligible launch
-    static int cnt = 0, last_only = -2;
-    const char* eo = getenv("OTGAN_X3_STREAM_ONLY");
-    const int only = eo ? atoi(eo) : -1;
-    if (only != last_only) { cnt = 0; last_only = only; }
-    const int idx = cnt++;
-    g_stream_idx = idx;
-    if (getenv("OTGAN_X3_STREAM_LOG"))
-      fprintf(stderr, "stream-eligible launch %d: %s M=%d N=%d K=%d seg=%d/%d/%d tiles=%dx%d%s\n", idx, TL ? "TL" : "NT", b.M, b.N, b.K,
-              b.seg_mode, b.seg_len, b.seg_skip, b.tiles_m, b.tiles_n, (only >= 0 && idx != only) ? " (one-tile)" : "");
-    if (only >= 0 && idx != only) return false;
-  }
-  if (getenv("OTGAN_X3_OWN_PARTIAL")) {   // dev tool: parked tiles in a buffer of their own instead of the workspace tail
-    static float* own = nullptr;
-    if (!own) { void* p = nullptr; (void)hipMalloc(&p, (x3_stream_floats() + 64) * 4); (void)hipMemset(p, 0, (x3_stream_floats() + 64) * 4); own = (float*)p; }
-    b.sk_partial = own;
-  }
-  ensure_lds<wino_bgemm_x3_stream_kernel<TL>>(X3_SK_LDS);
-  b.sk_epoch = x3_next_epoch();
-  hipLaunchKernelGGL((wino_bgemm_x3_stream_kernel<TL>), dim3(8 * b.sk_nw), dim3(X3_THREADS), X3_SK_LDS, s, b);
-  return true;
-}
-
 #if X3_PIECES == 2
-// The 256 x 128 tile kernel (two workgroups per compute unit; gemm_x3.h): OTGAN_X3_NARROW=0 keeps every launch on the
-// 256 x 256 tile, 1 (default) = every launch the kernel can take, 2 = only launches with at most `OTGAN_X3_NARROW_MAXT`
-// 256 x 256 tiles per frequency.
-int x3_narrow_mode() {
-  const char* e = getenv("OTGAN_X3_NARROW");
-  return use_fmap() ? (e ? atoi(e) : 1) : 0;
+// The 256 x 128 tile kernel (two workgroups per compute unit; gemm_x3.h) takes every launch it can: two-piece operands, at
+// least four K stages, an even stage count (K splits included).  OTGAN_X3_NARROW=0 keeps every launch on the 256 x 256 tile
+// (the bit-identity test of the two tiles, tests/test_stream_gemm_gpu.py).
+bool x3_narrow_on() {
+  static const bool on = [] { const char* e = getenv("OTGAN_X3_NARROW"); return !(e && e[0] == '0'); }();
+  return on && use_fmap();
 }
 template <bool TL>
 bool launch_narrow(const BgArgs& b0, int nsplit, int min_k, hipStream_t s) {
-  const int mode = x3_narrow_mode();
-  if (!mode || b0.ztab || b0.N < X3N_BN || min_k < 4 * X3_SK || (min_k / X3_SK) % 2) return false;
+  if (!x3_narrow_on() || b0.ztab || b0.N < X3N_BN || min_k < 4 * X3_SK || (min_k / X3_SK) % 2) return false;
   if (b0.seg_mode == 1 && (b0.seg_len / X3_SK) % 2) return false;
-  if (mode == 2) {
-    static const long maxt = [] { const char* e = getenv("OTGAN_X3_NARROW_MAXT"); return e ? atol(e) : 32L; }();
-    if ((long)b0.tiles_m * b0.tiles_n > maxt) return false;
-  }
-  {   // dev knobs: OTGAN_X3_NARROW_NT=0 / OTGAN_X3_NARROW_TL=0 keep one instantiation on the 256 x 256 tile
-    const char* e = getenv(TL ? "OTGAN_X3_NARROW_TL" : "OTGAN_X3_NARROW_NT");
-    if (e && e[0] == '0') return false;
-  }
   BgArgs b = b0;
   b.tiles_n = (b.N + X3N_BN - 1) / X3N_BN;
   const unsigned gx = build_fmap(b);
-  // (dev knob OTGAN_X3_NARROW_LDS=<bytes>: ask for more LDS than the kernel uses, e.g. 100000 = one workgroup per CU)
-  static const size_t lds = [] { const char* e = getenv("OTGAN_X3_NARROW_LDS"); const size_t v = e ? (size_t)atol(e) : 0; return v > X3N_LDS ? v : X3N_LDS; }();
-  ensure_lds<wino_bgemm_x3n_kernel<TL>>(lds);
-  // round 4: OTGAN_X3_PERSIST=1 caps the grid at the resident workgroups (two per compute unit) when there are more queue
-  // positions and no K splits: a workgroup then walks several tiles and starts the next one's operand stream before it
-  // writes the current one out (gemm_x3.h).  Measured on the DCGAN step, same box, A/B/A/B: 9.235 / 9.286 ms with one tile per
-  // workgroup against 9.358 / 9.377 ms capped (GEMM launches 0.243 -> 0.250 ms) -- the hardware dispatcher's dynamic
-  // placement of short workgroups beats a static walk, as it did for the 256 x 256 stream-K kernel: default off.
-  static const int persist = [] { const char* e = getenv("OTGAN_X3_PERSIST"); return e ? atoi(e) : 0; }();
-  static const unsigned resident = [] {
-    int dev = 0, cus = 256;
-    hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    return (unsigned)(2 * cus) & ~7u;
-  }();
+  ensure_lds<wino_bgemm_x3n_kernel<TL>>(X3N_LDS);
   b.x_total = gx;
-  unsigned grid_x = gx;
-  if (persist && nsplit == 1 && gx > resident && resident >= 8) grid_x = resident;
-  hipLaunchKernelGGL((wino_bgemm_x3n_kernel<TL>), dim3(grid_x, nsplit, 1), dim3(X3_THREADS), lds, s, b);
+  hipLaunchKernelGGL((wino_bgemm_x3n_kernel<TL>), dim3(gx, nsplit, 1), dim3(X3_THREADS), X3N_LDS, s, b);
   return true;
 }
 #else
@@ -1361,15 +1207,11 @@ void launch_bgemm(const BgArgs& a, int nsplit, hipStream_t s) {
     else if (nsplit > 1) min_k = a.K - (nsplit - 1) * b.kt_per_split * X3_BK;
     dim3 grid(b.tiles_m * b.tiles_n, nsplit, WF);
     if (use_fmap()) grid = dim3(build_fmap(b), nsplit, 1);
-    g_stream_idx = -1;
-    // the 256 x 128 tile kernel first (measured best on every DCGAN shape, also where the stream kernel used to win);
-    // OTGAN_X3_STREAM=2 forces the stream kernel, OTGAN_X3_NARROW=0 restores the round-2 selection
-    if (nsplit == 1 && x3_stream_mode() == 2 && launch_stream<false>(b, s)) { maybe_dump(b, s); return; }
-    if (launch_narrow<false>(b, nsplit, min_k, s)) { maybe_dump(b, s); return; }
-    if (nsplit == 1 && launch_stream<false>(b, s)) { maybe_dump(b, s); return; }
+    // the 256 x 128 tile kernel first (measured best on every DCGAN / DenseNet shape); what it cannot take (three-piece
+    // operands, odd stage counts, fewer than four stages) runs on the 256 x 256 tile
+    if (launch_narrow<false>(b, nsplit, min_k, s)) return;
     if (min_k >= 4 * X3_SK) hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, false>), grid, dim3(X3_THREADS), X3_LDS, s, b);
     else hipLaunchKernelGGL((wino_bgemm_x3_kernel<false, false>), grid, dim3(X3_THREADS), X3_LDS, s, b);
-    maybe_dump(b, s);
     return;
   }
   ensure_lds<wino_bgemm_kernel<TN>>(lds);
@@ -1404,9 +1246,7 @@ void launch_bgemm_tl(const BgArgs& a, int nsplit, hipStream_t s) {
   const int min_k = nsplit > 1 ? a.K - (nsplit - 1) * b.kt_per_split * X3_BK : a.K;
   dim3 grid(b.tiles_m * b.tiles_n, nsplit, WF);
   if (use_fmap()) grid = dim3(build_fmap(b), nsplit, 1);
-  if (nsplit == 1 && x3_stream_mode() == 2 && launch_stream<true>(b, s)) return;
   if (launch_narrow<true>(b, nsplit, min_k, s)) return;
-  if (nsplit == 1 && launch_stream<true>(b, s)) return;
   if (min_k >= 4 * X3_SK) hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, true>), grid, dim3(X3_THREADS), X3_LDS, s, b);
   else hipLaunchKernelGGL((wino_bgemm_x3_kernel<false, true>), grid, dim3(X3_THREADS), X3_LDS, s, b);
 }
@@ -1535,8 +1375,6 @@ void class_views(const WinoGeo& g, P base, int ld, V (&v)[4]) {
 
 // K splits of the wgrad GEMM on the bf16 pipe (256 x 256 tiles: few tiles, long K)
 int x3_wgrad_splits(int M, int N, long T) {
-  // the stream kernel balances the contraction over the compute units itself
-  if (stream_wanted((long)((M + X3_BM - 1) / X3_BM) * ((N + X3_BN - 1) / X3_BN), 0)) return 1;
   const int blocks = ((M + X3_BM - 1) / X3_BM) * ((N + X3_BN - 1) / X3_BN) * WF;
   static const int target = [] { const char* e = getenv("OTGAN_X3_SPLIT_TARGET"); return e ? atoi(e) : 256; }();
   int ns = (target + blocks - 1) / blocks;
@@ -1602,7 +1440,7 @@ size_t wino_fwd_ws_floats(const WinoGeo& g) {
   const size_t T = (size_t)wino_tiles(g);
   return operand_floats(op_elems(T, g.Cin)) + operand_floats(op_elems(T, 4 * g.Cout)) +
          operand_floats(std::max(op_elems(4 * g.Cout, g.Cin), op_elems(g.Cin, 4 * g.Cout))) +
-         WF * T * (size_t)(4 * g.Cout > g.Cin ? 4 * g.Cout : g.Cin) + x3_stream_floats();
+         WF * T * (size_t)(4 * g.Cout > g.Cin ? 4 * g.Cout : g.Cin);
 }
 size_t wino_dgrad_ws_floats(const WinoGeo& g) { return wino_fwd_ws_floats(g); }
 size_t wino_wgrad_ws_floats(const WinoGeo& g) {
@@ -1610,8 +1448,7 @@ size_t wino_wgrad_ws_floats(const WinoGeo& g) {
   const size_t Tp = (T + 63) / 64 * 64;
   const int ns = std::max(wgrad_splits(g), x3_wgrad_splits(g.Cin, 4 * g.Cout, (long)Tp));
   return operand_floats(std::max(op_elems(g.Cin, Tp), op_elems(Tp, g.Cin))) +
-         operand_floats(std::max(op_elems(4 * g.Cout, Tp), op_elems(Tp, 4 * g.Cout))) + (size_t)ns * WF * 4 * g.Cout * g.Cin +
-         x3_stream_floats();
+         operand_floats(std::max(op_elems(4 * g.Cout, Tp), op_elems(Tp, 4 * g.Cout))) + (size_t)ns * WF * 4 * g.Cout * g.Cin;
 }
 
 size_t wino_filter_floats(const WinoGeo& g, int which) {
@@ -1677,7 +1514,6 @@ int wino_fwd(const WinoGeo& g, const float* x, const float* weffT, long cls_stri
   b.sA = T * g.Cin; b.sB = (long)N4 * g.Cin; b.sC = T * N4;
   b.tiles_m = (int)((T + Cfg::BM - 1) / Cfg::BM); b.tiles_n = (N4 + Cfg::BN - 1) / Cfg::BN;
   b.kt_per_split = (g.Cin + Cfg::BK - 1) / Cfg::BK;
-  b.sk_partial = x3_stream_area(ws, wino_fwd_ws_floats(g));
   launch_bgemm<false>(b, 1, s);
   OutArgs oa;
   memset(&oa, 0, sizeof(oa));
@@ -1725,7 +1561,6 @@ int wino_dgrad(const WinoGeo& g, const float* dy, const float* weff, long cls_st
   b.sA = T * K4; b.sB = (long)g.Cin * K4; b.sC = T * g.Cin;
   b.tiles_m = (int)((T + Cfg::BM - 1) / Cfg::BM); b.tiles_n = (g.Cin + Cfg::BN - 1) / Cfg::BN;
   b.kt_per_split = (K4 + Cfg::BK - 1) / Cfg::BK;
-  b.sk_partial = x3_stream_area(ws, wino_dgrad_ws_floats(g));
   launch_bgemm<false>(b, 1, s);
   OutArgs oa;
   memset(&oa, 0, sizeof(oa));
@@ -1772,7 +1607,6 @@ int wino_wgrad(const WinoGeo& g, const float* x, const float* dy, float* dweff, 
     b.C = slabs; b.M = g.Cin; b.N = N4; b.K = (int)T;
     b.ldc = N4; b.sC = (long)g.Cin * N4; b.sSplit = (long)WF * g.Cin * N4;
     b.kt_per_split = (int)((T / X3_BK + ns - 1) / ns);
-    b.sk_partial = x3_stream_area(ws, wino_wgrad_ws_floats(g));
     launch_bgemm_tl(b, ns, s);
     if (dw_unfolded5)
       hipLaunchKernelGGL(wino_filter_adj_unfold5_kernel, dim3(grid1(4L * g.Cin * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
@@ -1907,7 +1741,7 @@ size_t wino_s2_fwd_ws_floats(const WinoS2Geo& g) {
   const size_t T = (size_t)wino_s2_tiles(g), K4 = (size_t)s2_k(g);
   const size_t Kp = (size_t)s2_kp(g), Kf = (size_t)s2_kf(g);
   return operand_floats(op_elems(T, Kf)) + operand_floats(op_elems(T, Kp)) +
-         operand_floats(std::max(op_elems(g.Cout, Kf), op_elems(K4, Kp))) + WF * T * K4 + x3_stream_floats();
+         operand_floats(std::max(op_elems(g.Cout, Kf), op_elems(K4, Kp))) + WF * T * K4;
 }
 size_t wino_s2_dgrad_ws_floats(const WinoS2Geo& g) { return wino_s2_fwd_ws_floats(g); }
 size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g) {
@@ -1915,7 +1749,7 @@ size_t wino_s2_wgrad_ws_floats(const WinoS2Geo& g) {
   const size_t Tp = (T + 63) / 64 * 64;
   const int ns = std::max(s2_wgrad_splits(g), x3_wgrad_splits((int)K4, g.Cout, (long)Tp));
   return operand_floats(std::max(op_elems(K4, Tp), op_elems(Tp, K4))) + operand_floats(std::max(op_elems(g.Cout, Tp), op_elems(Tp, g.Cout))) +
-         (size_t)ns * WF * K4 * g.Cout + x3_stream_floats();
+         (size_t)ns * WF * K4 * g.Cout;
 }
 
 size_t wino_s2_filter_floats(const WinoS2Geo& g, int which) {
@@ -1965,7 +1799,6 @@ int wino_s2_fwd(const WinoS2Geo& g, const float* x, const float* wT, const float
   b.tiles_m = (int)((T + Cfg::BM - 1) / Cfg::BM); b.tiles_n = (g.Cout + Cfg::BN - 1) / Cfg::BN;
   b.kt_per_split = (K4 + Cfg::BK - 1) / Cfg::BK;
   b.seg_mode = g.plain ? 0 : 1; b.seg_len = g.Ceff; b.seg_skip = 0;
-  b.sk_partial = x3_stream_area(ws, wino_s2_fwd_ws_floats(g));
   launch_bgemm<false>(b, 1, s);
   OutArgs oa;
   memset(&oa, 0, sizeof(oa));
@@ -2012,7 +1845,6 @@ int wino_s2_dgrad(const WinoS2Geo& g, const float* dy, const float* w, const flo
   b.tiles_m = (int)((T + Cfg::BM - 1) / Cfg::BM); b.tiles_n = (K4 + Cfg::BN - 1) / Cfg::BN;
   b.kt_per_split = (Kp + Cfg::BK - 1) / Cfg::BK;
   b.seg_mode = g.plain ? 0 : 2; b.seg_len = g.Ceff; b.seg_skip = WA - 1;
-  b.sk_partial = x3_stream_area(ws, wino_s2_dgrad_ws_floats(g));
   launch_bgemm<false>(b, 1, s);
   OutS2Args oa;
   memset(&oa, 0, sizeof(oa));
@@ -2066,7 +1898,6 @@ int wino_s2_wgrad(const WinoS2Geo& g, const float* x, const float* dy, float* dw
     b.ldc = g.Cout; b.sC = (long)K4 * g.Cout; b.sSplit = (long)WF * K4 * g.Cout;
     b.kt_per_split = (int)((T / X3_BK + ns - 1) / ns);
     b.seg_mode = g.plain ? 0 : 3; b.seg_len = g.Ceff; b.seg_skip = 0;
-    b.sk_partial = x3_stream_area(ws, wino_s2_wgrad_ws_floats(g));
     launch_bgemm_tl(b, ns, s);
     hipLaunchKernelGGL(wino_s2_filter_adj_kernel, dim3(grid1((long)K4 * (g.Cout / 4))), dim3(256), 0, s, slabs, ns,
                        (long)WF * K4 * g.Cout, g.Ceff, g.Cout, dw, g.plain);
@@ -2122,7 +1953,7 @@ __global__ __launch_bounds__(256) void wino_up3_filter_fwd_kernel(const float* _
 size_t wino_up3_filter_floats(const WinoUp3Geo& g) { return operand_floats(op_elems(g.Cout, g.Ceff)); }
 size_t wino_up3_fwd_ws_floats(const WinoUp3Geo& g) {
   const size_t T = (size_t)wino_up3_tiles(g);
-  return operand_floats(op_elems(T, g.Ceff)) + WF * T * (size_t)g.Cout + x3_stream_floats();
+  return operand_floats(op_elems(T, g.Ceff)) + WF * T * (size_t)g.Cout;
 }
 int wino_up3_prepare_filters(const WinoUp3Geo& g, const float* wT, float* out, hipStream_t s) {
   op_scales(wT, 1, 9 * g.Ceff * g.Cout, 0, out, kGainG, 1.f, false, s);
@@ -2156,7 +1987,6 @@ int wino_up3_fwd(const WinoUp3Geo& g, const float* x, const float* bias, float* 
   b.sA = T * g.Ceff; b.sB = (long)g.Cout * g.Ceff; b.sC = T * g.Cout;
   b.tiles_m = (int)((T + Cfg::BM - 1) / Cfg::BM); b.tiles_n = (g.Cout + Cfg::BN - 1) / Cfg::BN;
   b.kt_per_split = (g.Ceff + Cfg::BK - 1) / Cfg::BK;
-  b.sk_partial = x3_stream_area(ws, wino_up3_fwd_ws_floats(g));
   launch_bgemm<false>(b, 1, s);
   OutArgs oa;
   memset(&oa, 0, sizeof(oa));

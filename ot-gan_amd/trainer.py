@@ -26,6 +26,36 @@ class _frozen:
         return False
 
 
+class _Region:
+    """`with model._timed(name):` -- two events on the current stream around a region of the step, only while timers are
+    enabled (bench.py, ranks > 1); no synchronisation until `collect_timers()`."""
+    __slots__ = ("pairs", "e0")
+
+    def __init__(self, pairs):
+        self.pairs = pairs
+
+    def __enter__(self):
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e0.record()
+
+    def __exit__(self, *exc):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.pairs.append((self.e0, e1))
+        return False
+
+
+class _NoRegion:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_REGION = _NoRegion()
+
+
 class OTGAN:
     """State of one training run.  `args` carries the reference's flags (train.py:14-33)
     plus: image_size, matching_scope ('global' = one OT problem set over all ranks, the
@@ -107,6 +137,33 @@ class OTGAN:
         self.ema_fused = self.gen_optimizer.fuse_ema(self.ema)
         self.step_counter = 0
         self.last = {}
+        self.timers = None        # name -> [(start event, end event)]; see enable_timers()
+
+    # ---------------------------------------------------------------- per-region step times (bench.py, ranks > 1)
+    def enable_timers(self, on=True):
+        """Event-time the exchange steps of the data-parallel step on this rank's compute stream: `allgather` (feature
+        all-gathers and the cost-slice all-gather, including what the stream waits for them), `matching` (the rank's cost
+        row slices, the Sinkhorn problems and the plans applied to its rows: `_match` without its gathers) and `allreduce`
+        (the gradient SUM).  In the default serial schedule the stream waits for every collective where it is issued,
+        so the regions do not overlap compute and their sum is the non-scaling part of the step."""
+        self.timers = {} if on else None
+
+    def _timed(self, name):
+        if self.timers is None:
+            return _NO_REGION
+        return _Region(self.timers.setdefault(name, []))
+
+    def collect_timers(self, steps):
+        """-> {name_ms: mean milliseconds per step over `steps` steps}; synchronises."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, pairs in (self.timers or {}).items():
+            out[name + "_ms"] = round(sum(a.elapsed_time(b) for a, b in pairs) / max(1, steps), 4)
+        if "match_total_ms" in out:
+            out["matching_ms"] = round(out.pop("match_total_ms") - out.get("allgather_in_match_ms", 0.0), 4)
+        out["allgather_ms"] = round(out.pop("allgather_in_match_ms", 0.0) + out.pop("allgather_early_ms", 0.0), 4)
+        self.timers = {} if self.timers is not None else None
+        return out
 
     def sinkhorn_rows(self):
         """Rows N of one Sinkhorn problem of this run (matching.py:16-19: the shards of the matching scope form two
@@ -123,8 +180,9 @@ class OTGAN:
         plain = not (a.single_batch or a.no_sinkhorn)
         if self.scope == "global" and self.world > 1:
             S = self.world * self.shards
-            allg = parallel.all_gather_rows(f_gen)
-            alld = pending_dat.wait() if pending_dat is not None else parallel.all_gather_rows(f_dat)
+            with self._timed("allgather_in_match"):
+                allg = parallel.all_gather_rows(f_gen)
+                alld = pending_dat.wait() if pending_dat is not None else parallel.all_gather_rows(f_dat)
             if plain:
                 # The cost matrices are row-sharded like the reference (matching.py:29-39): a rank
                 # of the first half computes its rows of (a1,a2) (a1,b1) (a1,b2), a rank of the
@@ -173,12 +231,14 @@ class OTGAN:
 
     def _sharded_log_kernels(self, f_gen, f_dat, fa, fb):
         mine = rank_log_kernel_slices(self.rank, self.world, f_gen, f_dat, fa, fb, self.args.sinkhorn_lambda)
-        allk = parallel.all_gather_rows(mine.unsqueeze(0))                              # [W,3,nb,N]
+        with self._timed("allgather_in_match"):
+            allk = parallel.all_gather_rows(mine.unsqueeze(0))                          # [W,3,nb,N]
         return assemble_log_kernels(allk, self.world)
 
     def _sharded_single_log_kernels(self, f_gen, f_dat, allg, alld):
         mine = rank_single_log_kernel_slices(f_gen, f_dat, allg, alld, self.args.sinkhorn_lambda)
-        allk = parallel.all_gather_rows(mine.unsqueeze(0))                              # [W,3,nb,n]
+        with self._timed("allgather_in_match"):
+            allk = parallel.all_gather_rows(mine.unsqueeze(0))                          # [W,3,nb,n]
         return assemble_single_log_kernels(allk, self.args.sinkhorn_lambda)
 
     # ---------------------------------------------------------------- one sess.run
@@ -199,12 +259,14 @@ class OTGAN:
                 x_gen = self.generator(batch_size=self.nb, ema=ema, device=self.device, **gkw)
             f_all = self.discriminator(torch.cat([x_data, x_gen], 0), **self.model_opts)
             f_dat, f_gen = f_all[:self.nb], f_all[self.nb:]
-            g_gen, g_dat, dist, ent = self._match(f_gen.detach(), f_dat.detach())
+            with self._timed("match_total"):
+                g_gen, g_dat, dist, ent = self._match(f_gen.detach(), f_dat.detach())
             if self.disc_buckets is not None:
                 self.disc_buckets.arm()
             grads = torch.autograd.grad(f_all, self.disc_params, torch.cat([g_dat, g_gen], 0))   # train.py:127-128
-            grads = (self.disc_buckets.finish() if self.disc_buckets is not None
-                     else parallel.allreduce_sum_(list(grads)))                                   # train.py:134-139
+            with self._timed("allreduce"):
+                grads = (self.disc_buckets.finish() if self.disc_buckets is not None
+                         else parallel.allreduce_sum_(list(grads)))                               # train.py:134-139
             if apply_updates:
                 self.disc_optimizer(grads, lr=-a.learning_rate_disc)                              # train.py:143
         else:
@@ -213,21 +275,24 @@ class OTGAN:
                 f_dat = self.discriminator(x_data, **self.model_opts)
             # the real-data features are final here: start their all-gather now, it overlaps the
             # generator forward and the second critic pass
-            pending = (parallel.all_gather_rows_async(f_dat)
-                       if (self.scope == "global" and self.world > 1) or (self.collectives and self.world == 1)
-                       else None)
+            with self._timed("allgather_early"):
+                pending = (parallel.all_gather_rows_async(f_dat)
+                           if (self.scope == "global" and self.world > 1) or (self.collectives and self.world == 1)
+                           else None)
             x_gen = self.generator(batch_size=self.nb, device=self.device, **gkw)
             # only the generator's variables are differentiated in this step (train.py:112): run the critic with
             # its variables frozen, so that its layers skip their weight gradients (autograd's needs_input_grad
             # follows requires_grad, not the `inputs` list of autograd.grad) and only propagate d/dx
             with _frozen(self.disc_params):
                 f_gen = self.discriminator(x_gen, **self.model_opts)
-            g_gen, _g_dat, dist, ent = self._match(f_gen.detach(), f_dat, pending, need_dat=False)
+            with self._timed("match_total"):
+                g_gen, _g_dat, dist, ent = self._match(f_gen.detach(), f_dat, pending, need_dat=False)
             if self.gen_buckets is not None:
                 self.gen_buckets.arm()
             grads = torch.autograd.grad(f_gen, self.gen_params, g_gen)                            # train.py:112
-            grads = (self.gen_buckets.finish() if self.gen_buckets is not None
-                     else parallel.allreduce_sum_(list(grads)))
+            with self._timed("allreduce"):
+                grads = (self.gen_buckets.finish() if self.gen_buckets is not None
+                         else parallel.allreduce_sum_(list(grads)))
             if apply_updates:
                 self.gen_optimizer(grads, lr=a.learning_rate_gen)                                 # train.py:142
                 if not self.ema_fused:

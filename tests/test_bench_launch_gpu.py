@@ -37,6 +37,12 @@ def test_bench_gpus2_self_launches_two_ranks():
     assert c["step_mix"] == {**c["step_mix"], "critic_steps": 1, "generator_steps": 5}
     import math
     assert math.isfinite(c["last_distance"]) and math.isfinite(c["last_entropy"])
+    # per-rank exchange times (round 5): both ranks report matching / all-gather / all-reduce milliseconds per step
+    per = c["rank_times"]["per_rank"]
+    assert [t["rank"] for t in per] == [0, 1]
+    for t in per:
+        assert t["matching_ms"] > 0 and t["allgather_ms"] > 0 and t["allreduce_ms"] > 0
+        assert t["matching_ms"] + t["allgather_ms"] + t["allreduce_ms"] < t["ms_per_step"]
 
 
 def test_bench_gpus2_without_devices_fails_loudly():

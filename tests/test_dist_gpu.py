@@ -141,3 +141,78 @@ def test_data_dependent_init_gives_identical_replicas():
         if k.endswith("/g") and "generator" in k:
             moved += int(not torch.all(a[k] == 1.0))
     assert moved > 0                        # the pass really ran (g left its default of 1)
+
+
+# ---- eight ranks of the REAL trainer on one device -------------------------------------------------
+# The reference drives all towers from one process (train.py:72-85,134-139) and puts shards [n/2, n) into mini-batch 2
+# (utils/matching.py:16-19,35-39).  With eight ranks, ranks 4 - 7 own rows of the SECOND half: their cost slices are
+# (b2,b1) (a2,b1) (a2,b2) (trainer.rank_log_kernel_slices, r >= world / 2) and their plan rows sit behind the first
+# half's -- code that two ranks (one per half) never reach with more than one rank per half.  All four combinations of
+# {two shards per rank, one shard per rank} x {two-batch, --single_batch} run inside ONE set of eight processes.
+EIGHT_CASES = [(16, False), (8, False), (16, True), (8, True)]      # (--nr_gpu, --single_batch)
+B8 = 2
+
+
+def _data8(nr_gpu):
+    g = torch.Generator().manual_seed(321 + nr_gpu)
+    n = nr_gpu * B8
+    return torch.rand(n, 32, 32, 3, generator=g) * 2 - 1, torch.rand(n, 100, generator=g) * 2 - 1
+
+
+def _args8(nr_gpu, single_batch):
+    from otgan_amd.trainer import default_args
+    return default_args(model="dcgan", batch_size=B8, nr_gpu=nr_gpu, sinkhorn_lambda=LAM, nr_sinkhorn_iter=ITERS,
+                        nr_gen_per_disc=1, seed=5, matching_scope="global", single_batch=single_batch)
+
+
+def _worker8(rank, world, port, path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from otgan_amd import parallel
+    from otgan_amd.trainer import OTGAN
+    parallel.init_from_env(backend="gloo")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    out = {}
+    for nr_gpu, single in EIGHT_CASES:
+        m = OTGAN(_args8(nr_gpu, single), dev)
+        assert m.shards == nr_gpu // world and m.scope == "global" and m.world == world
+        x, u = _data8(nr_gpu)
+        sl = slice(rank * m.nb, (rank + 1) * m.nb)
+        out[(nr_gpu, single)] = _run_steps(m, x[sl].to(dev), u[sl].to(dev))
+        m.close()
+    if rank in (0, world - 1):          # the all-reduced gradients of a first-half and of a second-half rank
+        torch.save(out, path + str(rank))
+    parallel.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_eight_ranks_equal_single_process():
+    assert torch.cuda.is_available()
+    world = 8
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "r")
+        port = _free_port()
+        ctx = mp.get_context("spawn")
+        procs = [ctx.Process(target=_worker8, args=(r, world, port, path)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(900)
+            assert p.exitcode == 0
+        got0, got7 = torch.load(path + "0"), torch.load(path + str(world - 1))
+    from otgan_amd.trainer import OTGAN
+    dev = torch.device("cuda:0")
+    for nr_gpu, single in EIGHT_CASES:
+        m = OTGAN(_args8(nr_gpu, single), dev)      # world 1: all shards local, halves = shards [0, S/2) | [S/2, S)
+        x, u = _data8(nr_gpu)
+        ref = _run_steps(m, x.to(dev), u.to(dev))
+        m.close()
+        g0, g7 = got0[(nr_gpu, single)], got7[(nr_gpu, single)]
+        for kind in ("disc", "gen"):
+            assert g0[kind + "_dist"] == pytest.approx(ref[kind + "_dist"], rel=1e-4, abs=1e-8), (nr_gpu, single, kind)
+            assert g7[kind + "_dist"] == g0[kind + "_dist"]
+            for a, a7, b in zip(g0[kind], g7[kind], ref[kind]):
+                assert torch.equal(a, a7)               # every rank holds the same all-reduced sum
+                err = float((a - b).norm() / b.norm().clamp_min(1e-30))
+                assert err < 2e-3, (nr_gpu, single, kind, err)
