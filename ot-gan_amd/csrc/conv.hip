@@ -1335,8 +1335,7 @@ __global__ __launch_bounds__(256) void conv_fewout_mfma_kernel(GatherA g, Taps t
 // dh = +-(kh - pad)) with KW * J <= 16 columns and |dw| <= 2, stride 1, rows of 16 / 32 / 64 pixels, 4 | H, 64 | channels
 template <int ACT>
 static bool launch_fewout_mfma(const GatherA& ga, const Taps& t, const FewOutArgs& fa, int KH, int KW, hipStream_t s) {
-  static const bool off = getenv("OTGAN_DISABLE_FEWOUT_MFMA") != nullptr;
-  if (off || ga.sa != 1 || ga.logUp != 0 || fa.so != 1 || fa.J < 1 || KW * fa.J > 16 || t.n != KH * KW || (KH != 3 && KH != 5)) return false;
+  if (ga.sa != 1 || ga.logUp != 0 || fa.so != 1 || fa.J < 1 || KW * fa.J > 16 || t.n != KH * KW || (KH != 3 && KH != 5)) return false;
   const int W = 1 << ga.logGW, H = 1 << ga.logGH;
   if (W != ga.W || H != ga.H || (W != 16 && W != 32 && W != 64) || H % 4 || ga.Ck % 64 || ga.ldx % 4 || fa.sJ % 4) return false;
   const int pad = (KH - 1) / 2;
@@ -1665,14 +1664,14 @@ __global__ __launch_bounds__(256) void conv_rgbin_mfma_kernel(FewInArgs a, int t
 // MFMAs per product instead of six on three bf16 pieces): the caller's records when it has them (otgan_conv_desc::
 // x_amax / dy_amax / w_amax), else reduced here into two scratch records at the tail of the workspace (one pass over the
 // tensor each: 60 us for a 300 MB block buffer against 250 us saved in the GEMM).  Leaves e.amax_a / e.amax_b null --
-// the three-piece loop runs -- when the tensors do not qualify or the workspace has no room.  OTGAN_IGEMM_X2H=0: never.
+// the three-piece loop runs -- when the tensors do not qualify or the workspace has no room (and always in the three-piece
+// build, OTGAN_WINO_PIECES=3).
 static void igemm_records(EpiArgs& e, const float* a_rec, const float* a, long a_rows, int a_C, long a_ld,
                           const float* b_rec, const float* b, long b_elems, int elu_type, void* workspace,
                           size_t workspace_bytes, size_t ws_used, hipStream_t s) {
-  static const bool off = [] { const char* v = getenv("OTGAN_IGEMM_X2H"); return v && v[0] == '0'; }();
   e.amax_a = e.amax_b = nullptr;
   e.floor_one = elu_type ? 1 : 0;
-  if (off || wino_pieces() != 2) return;
+  if (wino_pieces() != 2) return;
   const size_t rec_bytes = sizeof(float) * OTGAN_AMAX_RECORD_FLOATS;
   float* scratch = nullptr;
   const size_t at = (ws_used + 255) / 256 * 256;
@@ -1707,8 +1706,7 @@ static bool launch_rgbin_fwd(const otgan_conv_desc* d, int pad_t, int pad_l, con
   if (a.TR < 4 || a.TR > d->H || d->H % a.TR) return false;
   const size_t lds = sizeof(float4) * (size_t)(a.TR + d->KH - 1) * (d->W + d->KW - 1);
   const int tiles = d->N * (d->H / a.TR);
-  static const bool mfma_off = getenv("OTGAN_DISABLE_RGBIN_MFMA") != nullptr;
-  if (!mfma_off && d->W % 16 == 0) {   // fp32 matrix pipe; two tiles per workgroup while that leaves two workgroups per CU
+  if (d->W % 16 == 0) {   // fp32 matrix pipe; two tiles per workgroup while that leaves two workgroups per CU
     const int tpb = (tiles % 2 == 0 && (long)(tiles / 2) * (d->Cout / 64) >= 1024) ? 2 : 1;
     const dim3 gm(tiles / tpb, d->Cout / 64);
     if (d->KH == 5) hipLaunchKernelGGL(conv_rgbin_mfma_kernel<5>, gm, dim3(256), lds, s, a, tpb);
@@ -2276,24 +2274,12 @@ inline WinoGeo wino_geo(const otgan_conv_desc* d) {
 // Wide 3x3 stride-1 layers (the block-input convolution of a DenseNet block: ops.py DenseBlockFunction) take the same
 // three passes with ONE class ("plain", winograd.h): 2.25 instead of 9 products per output.  Narrow ones do not pay
 // (the Winograd-domain result is 2.25 x Cout floats per pixel, written and read once): Cout >= 128.
-inline int wino_plain3_min_ceff() {
-  static const int v = [] {
-    const char* e = getenv("OTGAN_PLAIN3_MIN_CEFF");
-    return e ? atoi(e) : 64;
-  }();
-  return v;
-}
-inline int wino_plain3_min_cout() {
-  static const int v = [] {
-    const char* e = getenv("OTGAN_PLAIN3_MIN_COUT");
-    return e ? atoi(e) : 128;
-  }();
-  return v;
-}
+constexpr int wino_plain3_min_ceff() { return 64; }
+constexpr int wino_plain3_min_cout() { return 128; }
 inline bool wino_plain3_ok(const otgan_conv_desc* d, const Geo& g) {
   return d->stride == 1 && d->upsample == 0 && d->KH == 3 && d->KW == 3 && d->C % 4 == 0 && g.Ceff % 16 == 0 &&
          g.Ceff >= wino_plain3_min_ceff() && d->Cout % 32 == 0 && d->Cout >= wino_plain3_min_cout() && d->H % kWinoM == 0 && d->W % kWinoM == 0 && d->ldx % 4 == 0 &&
-         d->ldy % 4 == 0 && d->y_coff % 4 == 0 && WINO(winograd_enabled)() && getenv("OTGAN_DISABLE_WINO_PLAIN3") == nullptr;
+         d->ldy % 4 == 0 && d->y_coff % 4 == 0 && WINO(winograd_enabled)();
 }
 inline bool wino_s2_ok(const otgan_conv_desc* d, const Geo& g) {
   if (wino_plain3_ok(d, g)) return true;
@@ -2320,7 +2306,7 @@ inline double wino_s2_blocks(const WinoS2Geo& w) { return w.plain ? kWinoFreq : 
 inline bool wino_up3_ok(const otgan_conv_desc* d, const Geo& g) {
   return d->upsample == 1 && d->stride == 1 && d->KH == 3 && d->KW == 3 && d->preact == OTGAN_ACT_CRELU && d->C % 4 == 0 &&
          g.Ceff == 2 * d->C && g.Ceff % 32 == 0 && d->Cout % 4 == 0 && (2 * d->H) % kWinoM == 0 && (2 * d->W) % kWinoM == 0 &&
-         d->ldx % 4 == 0 && d->ldy % 4 == 0 && d->y_coff % 4 == 0 && WINO(winograd_enabled)() && getenv("OTGAN_DISABLE_WINO_UP3") == nullptr;
+         d->ldx % 4 == 0 && d->ldy % 4 == 0 && d->y_coff % 4 == 0 && WINO(winograd_enabled)();
 }
 inline WinoUp3Geo wino_up3_geo(const otgan_conv_desc* d, const Geo& g) {
   WinoUp3Geo w;
@@ -2333,8 +2319,7 @@ inline WinoUp3Geo wino_up3_geo(const otgan_conv_desc* d, const Geo& g) {
 // ... and their weight gradient: the one-class ("plain") passes of the strided-layer code on the upsampled grid, x read
 // through the upsample by the input transform; un-folded dw directly (no dweff, no unfold pass)
 inline bool wino_up3_wgrad_ok(const otgan_conv_desc* d, const Geo& g) {
-  return wino_up3_ok(d, g) && d->Cout % 16 == 0 && ((long)d->N * (2 * d->H / kWinoM) * (2 * d->W / kWinoM)) % 32 == 0 &&
-         getenv("OTGAN_DISABLE_WINO_UP3_WGRAD") == nullptr;
+  return wino_up3_ok(d, g) && d->Cout % 16 == 0 && ((long)d->N * (2 * d->H / kWinoM) * (2 * d->W / kWinoM)) % 32 == 0;
 }
 inline WinoS2Geo wino_up3_wgrad_geo(const otgan_conv_desc* d, const Geo& g) {
   WinoS2Geo w;
@@ -2346,7 +2331,7 @@ inline WinoS2Geo wino_up3_wgrad_geo(const otgan_conv_desc* d, const Geo& g) {
 
 // ... and their input gradient, when the caller hands over filters prepared from the UN-folded weights (which = 3)
 inline bool wino_up3_dgrad_ok(const otgan_conv_desc* d, const Geo& g) {
-  return wino_up3_ok(d, g) && d->Cout % 4 == 0 && getenv("OTGAN_DISABLE_WINO_UP3_DGRAD") == nullptr;
+  return wino_up3_ok(d, g) && d->Cout % 4 == 0;
 }
 
 inline int outer_unit_rows(int H) { return H >= 8 ? 8 : H; }
@@ -2394,8 +2379,8 @@ WgPlan plan_wgrad(const otgan_conv_desc* d, const Geo& g) {
     p.nchunks = p.M >= 256 * 64 ? 256 : (int)ceil_div_l(p.M, 64);
     if (d->stride == 1) {
       // the all-taps kernel streams its pixels serially per thread: 5 waves per workgroup and 256 workgroups leave
-      // ~1 wave per SIMD, nothing to hide the load latency with -> more, shorter chunks (OTGAN_OUTER_CHUNKS to vary)
-      static const int want = [] { const char* e = getenv("OTGAN_OUTER_CHUNKS"); return e ? atoi(e) : 512; }();
+      // ~1 wave per SIMD, nothing to hide the load latency with -> more, shorter chunks
+      constexpr int want = 512;
       if (p.M >= (long)want * 64) p.nchunks = want;
     }
     p.chunk = (int)ceil_div_l(p.M, p.nchunks);
@@ -2574,8 +2559,7 @@ void launch_igemm(bool vec_ok, int Ck, int rows, int ncols, bool paired, int ncl
   }
   if constexpr (EPI == EPI_FWD) {
     // forward of the wide-but-not-256 outputs: one exact column tile instead of two 128-wide ones
-    static const bool w160 = [] { const char* v = getenv("OTGAN_IGEMM_W160"); return !(v && v[0] == '0'); }();
-    if (w160 && !paired && vec_ok && Ck % 32 == 0 && ncols > 128 && ncols <= 160 && (long)ceil_div(rows, 128) * ncls >= 256) {
+    if (!paired && vec_ok && Ck % 32 == 0 && ncols > 128 && ncols <= 160 && (long)ceil_div(rows, 128) * ncls >= 256) {
       dim3 grid(ceil_div(rows, CfgW160::BM), 1, ncls);
       if (igemm_x3s()) launch_igemm3_x3s<CfgW160k16, EPI, ACT>(grid, s, ga, ct, wb, e);
       else launch_igemm3<CfgW160, true, EPI, ACT>(grid, s, ga, ct, wb, e);
@@ -2690,13 +2674,8 @@ int otgan_conv2d_fold_weights_f32(const otgan_conv_desc* d, const float* w, floa
 // K splits of the generic forward pass (0 / 1 = none): vector path on the 64 x 128 split-precision tile with fewer than
 // 256 tiles, at least 16 channel slices per split, plain output grid (no upsample / fold), columns a multiple of 4
 static int igemm_fwd_ksplit(const otgan_conv_desc* d, const Geo& g, bool vec, long Mtot) {
-  static const bool off = [] { const char* v = getenv("OTGAN_IGEMM_KSPLIT"); return v && v[0] == '0'; }();
-  if (off || !vec || g.fold || d->upsample || d->Cout % 4 || d->ldy % 4 || d->y_coff % 4 || g.Ceff % 4 || !igemm_x3s()) return 1;
-  static const bool wide = [] { const char* v = getenv("OTGAN_IGEMM_KSPLIT_WIDE"); return !(v && v[0] == '0'); }();
+  if (!vec || g.fold || d->upsample || d->Cout % 4 || d->ldy % 4 || d->y_coff % 4 || g.Ceff % 4 || !igemm_x3s()) return 1;
   if (d->Cout <= 32) return 1;
-  if (!wide && ((d->Cout > 128 && d->Cout <= 160) || (d->Cout > 192 && d->Cout <= 224 && ceil_div((int)Mtot, 128) >= 256))) return 1;
-  const long tiles128 = (long)ceil_div((int)Mtot, 128) * ceil_div(d->Cout, 128);
-  if (!wide && tiles128 >= 512) return 1;                         // (CfgMain16: enough tiles)
   const long tiles = (long)ceil_div((int)Mtot, 64) * ceil_div(d->Cout, 128);
   // (counting the 128 x 160 / 128 x 224 tiles of the exact-width configurations instead was measured: the 512-tile
   // 32x32 -> 16x16 transition does not gain from a split -- 552 us either way -- and the 128-tile one loses: 229 -> 316 us)
@@ -2705,9 +2684,7 @@ static int igemm_fwd_ksplit(const otgan_conv_desc* d, const Geo& g, bool vec, lo
   // 1 us each, MFMA busy 0.14).  More workgroups in flight hide it: K splits up to 2048 workgroups (was: only below 256
   // tiles, up to 512), also for the shapes of the exact-width column tiles (Cout 129 - 160, 193 - 224), slices of at
   // least 8 x 16 channels.  Measured on the DenseNet step's forward transitions: 41.6 -> 32.2 ms per 18 steps.
-  static const int thr = [] { const char* v = getenv("OTGAN_IGEMM_KSPLIT_TILES"); return v && atoi(v) > 0 ? atoi(v) : 2048; }();
-  static const int target = [] { const char* v = getenv("OTGAN_IGEMM_KSPLIT_TARGET"); return v && atoi(v) > 0 ? atoi(v) : 2048; }();
-  static const int minsl = [] { const char* v = getenv("OTGAN_IGEMM_KSPLIT_MINSL"); return v && atoi(v) > 0 ? atoi(v) : 8; }();
+  constexpr int thr = 2048, target = 2048, minsl = 8;
   if (tiles >= thr) return 1;
   const int nsl = ceil_div(g.Ceff, 16);
   int ks = (int)(target / tiles);
@@ -2862,7 +2839,6 @@ size_t otgan_conv2d_filter_bytes(const otgan_conv_desc* d, int which) {
 size_t otgan_conv2d_operand_bytes(const otgan_conv_desc* d) {
   Geo g;
   if (make_geo(d, &g) != OTGAN_OK) return 0;
-  if (getenv("OTGAN_DISABLE_X_OPERAND")) return 0;
   if (wino_s2_ok(d, g)) return sizeof(float) * WINO(wino_s2_x_operand_floats)(wino_s2_geo(d, g));
   if (wino_ok(d, g)) return sizeof(float) * WINO(wino_x_operand_floats)(wino_geo(d));
   if (wino_up3_ok(d, g) && wino_up3_wgrad_ok(d, g)) return sizeof(float) * WINO(wino_s2_x_operand_floats)(wino_up3_wgrad_geo(d, g));
@@ -3303,7 +3279,7 @@ static int conv2d_dgrad_body(const otgan_conv_desc* d, const float* dy, const fl
   }
   if (d->Cout == 3 && d->stride == 1 && d->upsample == 0 && d->KH == d->KW && (d->KH == 3 || d->KH == 5) && d->C % 4 == 0 &&
       lddx % 4 == 0 && aligned16(dx) && (kind == 0 || (aligned16(x) && d->ldx % 4 == 0)) && (inv == nullptr || paired) &&
-      d->W % kFdTW == 0 && d->H % kFdTH == 0 && getenv("OTGAN_DISABLE_FEWOUT_DGRAD") == nullptr) {
+      d->W % kFdTW == 0 && d->H % kFdTH == 0) {
     // RGB-out layer: streaming kernel, lanes along the input channels
     FewDgArgs fa;
     fa.dy = dy + d->y_coff; fa.ldy = d->ldy;
@@ -3621,8 +3597,7 @@ int otgan_conv2d_wgrad_f32(const otgan_conv_desc* d, const float* x, const int32
       size_t lds = sizeof(float4) * (o2.TRo + 2 * kOuterHalo) * (d->W + 2 * kOuterHalo);
       const size_t red = sizeof(float) * (size_t)d->KH * 32 * d->KW * 16;
       if (red > lds) lds = red;
-      static const bool mfma_off = getenv("OTGAN_DISABLE_OUTER_MFMA") != nullptr;
-      if (!mfma_off && d->KH == d->KW && d->KW * oa.J <= 16 && d->W % 4 == 0 && (o2.TRo * d->W) % 16 == 0) {
+      if (d->KH == d->KW && d->KW * oa.J <= 16 && d->W % 4 == 0 && (o2.TRo * d->W) % 16 == 0) {
         // fp32 matrix pipe: 2 channel groups x 2 pixel streams per workgroup
         size_t l2 = sizeof(float4) * (o2.TRo + 2 * kOuterHalo) * (d->W + 2 * kOuterHalo);
         const size_t r2 = sizeof(float4) * 2 * (size_t)d->KH * 4 * 64;

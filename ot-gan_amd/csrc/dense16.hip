@@ -1591,13 +1591,7 @@ int ilog2i(int v) {
 
 }  // namespace
 
-bool dense16_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("OTGAN_DISABLE_DENSE16");
-    return !(e && e[0] == '1');
-  }();
-  return on;
-}
+bool dense16_enabled() { return true; }
 
 int dense16_fwd(const Dense16Geo& g, const float* x, const float* wT, const float* bias, float* y,
                 int ldy, int coff, int accumulate, hipStream_t s, float* amax_out) {
@@ -1609,11 +1603,7 @@ int dense16_fwd(const Dense16Geo& g, const float* x, const float* wT, const floa
   a.H = g.H; a.W = g.W; a.logW = ilog2i(g.W);
   a.ldx = g.ldx; a.C = g.C; a.Ceff = g.Ceff; a.doubled = g.doubled;
   a.K = 9 * g.Ceff; a.ldy = ldy; a.coff = coff;
-  static const bool v1_only = [] {
-    const char* e = getenv("OTGAN_DENSE16_V1");
-    return e && e[0] == '1';
-  }();
-  if (!v1_only && g.W >= 8 && g.W <= 64 && g.H * g.W >= 64) {
+  if (g.W >= 8 && g.W <= 64 && g.H * g.W >= 64) {
     // haloed LDS tile: block = TR full rows = 64*PT pixels of one image
     int PT = g.H * g.W >= 256 ? 4 : g.H * g.W / 64;
     while (PT > 1 && (long)g.N * g.H * g.W / (64 * PT) < 512) PT >>= 1;
@@ -1631,11 +1621,7 @@ int dense16_fwd(const Dense16Geo& g, const float* x, const float* wT, const floa
       const bool w8 = g.W == 8;
       // split-precision forward only where it pays: the 64*4-pixel tiles of the 32x32 (and larger) stages
       // (measured 1.18x there; the 16x16 / 8x8 stages are bound by their chunk barriers, not by the matrix pipe)
-      static const bool x3_on = [] {
-        const char* e = getenv("OTGAN_DENSE16_FP32");
-        return !(e && e[0] == '1');
-      }();
-      const bool x3 = x3_on && PT == 4;
+      const bool x3 = PT == 4;
       const size_t lds3 = (size_t)3 * (l.TR + 2) * l.RS * 32;
 #define D16_LAUNCH(PT_, ACT_)                                                                               \
   do {                                                                                                      \
@@ -1668,12 +1654,11 @@ int dense16_fwd(const Dense16Geo& g, const float* x, const float* wT, const floa
   return OTGAN_OK;
 }
 
-// pixel tiles of 16 per wave (workgroup = 64 PT pixels = full rows) of the fp16 x 2 growth kernels; dev knob
-// OTGAN_DENSE16_H2_PTMAX caps it (2: half-height tiles, three workgroups per compute unit at 32 x 32)
+// pixel tiles of 16 per wave (workgroup = 64 PT pixels = full rows) of the fp16 x 2 growth kernels (half-height tiles --
+// three workgroups per compute unit at 32 x 32 -- measured 4 % slower in round 4)
 static int h2_pt(int N, int H, int W) {
-  static const int cap = [] { const char* e = getenv("OTGAN_DENSE16_H2_PTMAX"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
   int PT = H * W >= 256 ? 4 : H * W / 64;
-  while (PT > 1 && ((long)N * H * W / (64 * PT) < 512 || PT > cap)) PT >>= 1;
+  while (PT > 1 && (long)N * H * W / (64 * PT) < 512) PT >>= 1;
   return PT;
 }
 size_t dense16_h2_filter_bytes(int nsl) { return nsl > 0 ? (size_t)kH2HdrBytes + (size_t)nsl * kH2SliceU16 * 2 : 0; }
@@ -1777,7 +1762,7 @@ Dense16Tiling dense16_tiling(int N, int H, int W, int Ceff) {
   // resident ones, tuned for the fp32-pipe kernel); with the fp16-pipe kernel the per-workgroup epilogue (four-wave
   // reduction through LDS, slab write) and the slab reduction weigh more: 768 measured best (wgrad + slab_reduce of a DenseNet
   // step 2.52 -> 2.27 ms; 512: 2.41, 1024: 2.46)
-  static const int wg_target = [] { const char* e = getenv("OTGAN_DENSE16_WG_TARGET"); return e && atoi(e) > 0 ? atoi(e) : 768; }();
+  constexpr int wg_target = 768;
   int want = (wg_target + t.nchunk - 1) / t.nchunk;
   if (want > t.tiles) want = t.tiles;
   if (want < 1) want = 1;
@@ -1805,8 +1790,7 @@ int dense16_wgrad(const Dense16Geo& g, const float* x, const float* dy, int ldy,
   a.x_rec = x_rec; a.dy_rec = dy_rec; a.x_nrec = x_nrec; a.dy_nrec = dy_nrec;
   size_t lds = ((size_t)64 * t.PT * kAStride + (size_t)(t.TR + 2) * t.RS * kDyStride) * 4;
   if (lds < 18 * 64 * 16) lds = 18 * 64 * 16;   // wave-reduction scratch
-  static const bool xmap_off = [] { const char* e = getenv("OTGAN_DENSE16_WGRAD_XMAP"); return e && e[0] == '0'; }();
-  a.xmap = (!xmap_off && t.nchunk > 1) ? 1 : 0;
+  a.xmap = t.nchunk > 1 ? 1 : 0;
   a.nsplit = t.nsplit; a.nchunk = t.nchunk;
   const dim3 grid = a.xmap ? dim3(8u * ((t.nsplit + 7) / 8) * t.nchunk, 1) : dim3(t.nsplit, t.nchunk);
   const dim3 blk(256);

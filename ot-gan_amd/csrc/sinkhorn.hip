@@ -206,7 +206,6 @@ constexpr float kLogSettle = 5.f;                       // nats per sweep
 struct LinCtl {
   int enabled;
   float settle, lo, hi;    // kLogSettle; the scaling factors stay inside (lo, hi) = (e^-20, e^20)
-  int poll_delay;          // panel kernel: s_sleep units (64 clocks) between publishing and the first poll of an exchange
 };
 // value of lane (l ^ 1) / (l ^ 2) of the quad (DPP quad_perm [1,0,3,2] / [2,3,0,1])
 __device__ __forceinline__ float quad_xor1(float v) {
@@ -590,7 +589,6 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
     asm volatile("" : "+v"(tt));      // (keeps the 64-bit slot addresses out of the loop-carried registers: they spilled)
     // a poll is a round trip through the fabric: one sent right behind the publish finds nothing and the next one costs
     // a second round trip; wait for about the propagation time first
-    for (int w = lc.poll_delay; w > 0; w -= 16) __builtin_amdgcn_s_sleep(16);
     const float val = t < N ? consume_tagged(slots + tt, phase, a.fail, okl) : 0.f;
     PT_STAMP(4);
     const unsigned slot = phase & 3u;
@@ -765,8 +763,6 @@ inline LinCtl lin_ctl() {
     v.settle = st && atof(st) > 0 ? (float)atof(st) : kLogSettle;
     v.lo = expf(-range);
     v.hi = expf(range);
-    const char* pd = getenv("OTGAN_SINKHORN_POLL_DELAY");
-    v.poll_delay = pd ? atoi(pd) : 0;
     return v;
   }();
   return c;
@@ -1190,34 +1186,19 @@ inline bool x3_shape_ok(int n, int m, int D) {
 struct X3CostPlan {
   int tiles, nsplit, kt_per_split;
 };
-// OTGAN_MATCH_NARROW=1: the 256 x 128 tile kernel with two workgroups per compute unit (gemm_x3.h wino_bgemm_x3n_kernel, the
-// convolutions' GEMM since round 3) instead of the 256 x 256 one-workgroup kernel.  Measured at N = 1024, D = 32768 (a rank's
-// three cost slices / its plan application): 156 / 250 us against 145 / 242 us -- these contractions are thousands of stages
-// long, the second workgroup has no prologue or write-out to hide: default off.
-inline bool match_narrow() {
-  static const bool on = [] { const char* e = getenv("OTGAN_MATCH_NARROW"); return e && e[0] == '1'; }();
-  return on;
-}
-template <auto Kern>
-inline void x3n_ensure_lds() {
-  static const bool done = [] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3N_LDS);
-    return true;
-  }();
-  (void)done;
-}
+// (The 256 x 128 two-workgroups-per-CU kernel of the convolutions was measured 5 % slower on these contractions -- thousands of
+// stages long, no prologue or write-out for a second workgroup to hide: round 4, 156 / 250 us against 145 / 242 us at
+// N = 1024, D = 32768 -- and is not offered here.)
 inline X3CostPlan x3_plan_cost(int P, int n, int m, int D) {
   X3CostPlan c;
-  const bool narrow = match_narrow();
-  const int resident = narrow ? 512 : 256;
-  c.tiles = ceil_div(n, X3_BM) * ceil_div(m, narrow ? X3N_BN : X3_BN);
+  const int resident = 256;
+  c.tiles = ceil_div(n, X3_BM) * ceil_div(m, X3_BN);
   const int nkt = D / X3_BK;
   // The split count that minimises (rounds of resident workgroups) x (granules per split + a workgroup's fixed cost: about four
   // granules of prologue and write-out, ten with a partial tile that is written and read again).  Round 4: until then ceil(256 / tiles) splits -- 12 tiles (a rank's three row
   // slices at N = 1024) became 264 workgroups, i.e. a second round for eight of them and twice the time (376 us, MFMA busy
   // 0.41 in profiles/r04_pmc_kernels_matching_N1024_D32768_rows256_rank.txt).
   const int max_split = nkt / 4 > 0 ? nkt / 4 : 1;            // >= 4 granules (8 stages) per split
-  static const int forced = [] { const char* e = getenv("OTGAN_X3_COST_SPLITS"); return e ? atoi(e) : 0; }();
   long best_t = -1;
   int best = 1;
   for (int ns = 1; ns <= max_split && ns <= 256; ++ns) {
@@ -1226,7 +1207,6 @@ inline X3CostPlan x3_plan_cost(int P, int n, int m, int D) {
     const long t = (long)ceil_div(c.tiles * P * real, resident) * (kt + (real > 1 ? 10 : 4));   // (+ the partial tile's write-out and re-read)
     if (best_t < 0 || t < best_t) { best_t = t; best = real; }
   }
-  if (forced > 0) best = forced < max_split ? forced : max_split;
   c.kt_per_split = ceil_div(nkt, best);
   c.nsplit = ceil_div(nkt, c.kt_per_split);
   return c;
@@ -1260,16 +1240,9 @@ int launch_cost_x3(const u16* FP, long plane, long rows_total, const long* xrow,
   if (fuse) {   // K = -lambda (1 - dot) = lambda * dot - lambda
     b.epi = 1; b.epi_scale = lambda; b.epi_bias = -lambda;
   }
-  if (match_narrow()) {
-    b.tiles_n = ceil_div(m, X3N_BN);
-    b.x_total = (unsigned)(b.tiles_m * b.tiles_n);
-    x3n_ensure_lds<wino_bgemm_x3n_kernel<false>>();
-    hipLaunchKernelGGL((wino_bgemm_x3n_kernel<false>), dim3(b.x_total, cp.nsplit, P), dim3(X3_THREADS), X3N_LDS, s, b);
-  } else {
-    x3_ensure_lds<wino_bgemm_x3_kernel<true, false>>();
-    const dim3 grid(b.tiles_m * b.tiles_n, cp.nsplit, P);
-    hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, false>), grid, dim3(X3_THREADS), X3_LDS, s, b);
-  }
+  x3_ensure_lds<wino_bgemm_x3_kernel<true, false>>();
+  const dim3 grid(b.tiles_m * b.tiles_n, cp.nsplit, P);
+  hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, false>), grid, dim3(X3_THREADS), X3_LDS, s, b);
   OTGAN_CHECK_LAUNCH("cost GEMM (split precision)");
   if (fuse) return OTGAN_OK;
   FinishArgs fa;
@@ -1304,28 +1277,19 @@ int launch_apply_x3(const X3ApplyBlock* blk, int nblk, const u16* PA_base, const
   b.ztab = 1; b.m_begin = m_begin;
   double flops = 0;
   float* base = blk[0].out;
-  int minK = 1 << 30;
   for (int z = 0; z < nblk; ++z) {
     b.zA[z] = (blk[z].A - PA_base) + x3_row_off(blk[z].arow, ncolsA);
     b.zB[z] = x3_row_off(blk[z].frow, D);
     b.zC[z] = (blk[z].out - base) - (long)m_begin * ldo;
     b.zK[z] = blk[z].K;
-    if (blk[z].K < minK) minK = blk[z].K;
     flops += 2.0 * m_count * (double)blk[z].K * D;
   }
   b.C = base;
   b.kt_per_split = 1 << 28;    // one split: each block contracts over its whole zK
   ProfScope ps(OTGAN_PROF_PLAN_APPLY, flops, 0.0, s);
-  if (match_narrow() && minK >= 64 && minK % 32 == 0) {
-    b.tiles_n = ceil_div(D, X3N_BN);
-    b.x_total = (unsigned)(b.tiles_m * b.tiles_n);
-    x3n_ensure_lds<wino_bgemm_x3n_kernel<true>>();
-    hipLaunchKernelGGL((wino_bgemm_x3n_kernel<true>), dim3(b.x_total, 1, nblk), dim3(X3_THREADS), X3N_LDS, s, b);
-  } else {
-    x3_ensure_lds<wino_bgemm_x3_kernel<true, true>>();
-    const dim3 grid(b.tiles_m * b.tiles_n, 1, nblk);
-    hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, true>), grid, dim3(X3_THREADS), X3_LDS, s, b);
-  }
+  x3_ensure_lds<wino_bgemm_x3_kernel<true, true>>();
+  const dim3 grid(b.tiles_m * b.tiles_n, 1, nblk);
+  hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, true>), grid, dim3(X3_THREADS), X3_LDS, s, b);
   OTGAN_CHECK_LAUNCH("plan application (split precision)");
   return OTGAN_OK;
 }
@@ -1344,9 +1308,9 @@ inline CostPlan plan_cost(int P, int n, int m, int D) {
   const int nkt = ceil_div(D, SCfg::BK);
   // K splits.  With at least one tile per CU (256) no split is needed: the GEMM epilogue writes the
   // log-kernel itself (no partial sums in memory at all).  Small problems (N = 128: 6 tiles) need the
-  // parallelism: ~3 workgroups per CU (OTGAN_COST_WG_TARGET, default 768; 512 = 2 per CU measured 92 vs 67 us at
+  // parallelism: ~3 workgroups per CU (768; 512 = 2 per CU measured 92 vs 67 us at
   // N = 128, D = 32768: the engine hides its staging latency with co-resident workgroups), reduced by cost_finish_kernel.
-  static const int target = [] { const char* e = getenv("OTGAN_COST_WG_TARGET"); return e && atoi(e) > 0 ? atoi(e) : 768; }();
+  constexpr int target = 768;
   int want = c.tiles * P >= 256 ? 1 : ceil_div(target, c.tiles * P);
   if (want < 1) want = 1;
   if (want > nkt) want = nkt;

@@ -1142,20 +1142,15 @@ __global__ __launch_bounds__(Cfg::THREADS) void wino_bgemm_kernel(BgArgs a) {
 // Frequency-major grid of the split-precision GEMMs (BgArgs::fmap): the 36 frequencies are dealt to the 8 XCDs by
 // longest-processing-time-first on their work (strided layers: 4, 2 or 1 parity classes are present at a
 // frequency -- contraction runs in the forward pass, surviving tiles in dgrad / wgrad), each XCD's queue longest
-// first.  Returns the grid size in x.  OTGAN_X3_FMAP=0 keeps the tile-residue maps of round 1.
-bool use_fmap() {
-  static const bool on = [] {
-    const char* e = getenv("OTGAN_X3_FMAP");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
+// first.  Returns the grid size in x.  (The tile-residue maps of round 1 -- BgArgs::xmap 0 / 1 / 2 -- remain for the fp32
+// engine and the matching GEMMs.)
+constexpr bool use_fmap() { return true; }
 unsigned build_fmap(BgArgs& b) { return x3_build_fmap(b); }
 
 #if X3_PIECES == 2
 // The 256 x 128 tile kernel (two workgroups per compute unit; gemm_x3.h) takes every launch it can: two-piece operands, at
 // least four K stages, an even stage count (K splits included).  OTGAN_X3_NARROW=0 keeps every launch on the 256 x 256 tile
-// (the bit-identity test of the two tiles, tests/test_stream_gemm_gpu.py).
+// (the bit-identity test of the two tiles, tests/test_gemm_engines_gpu.py).
 bool x3_narrow_on() {
   static const bool on = [] { const char* e = getenv("OTGAN_X3_NARROW"); return !(e && e[0] == '0'); }();
   return on && use_fmap();
@@ -1261,24 +1256,11 @@ bool use_x3() {
   }();
   return on;
 }
-// wgrad on the bf16 pipe (tile-contiguous operands from the transposing producers) unless
-// OTGAN_WINO_WGRAD_X3=0
-bool use_x3_wgrad() {
-  static const bool on = [] {
-    const char* e = getenv("OTGAN_WINO_WGRAD_X3");
-    return !(e && e[0] == '0');
-  }();
-  return on && use_x3();
-}
-// wgrad straight from the forward-layout operands (t-leading GEMM, no transposing producers) unless
-// OTGAN_WINO_WGRAD_TL=0
-bool use_x3_wgrad_tl() {
-  static const bool on = [] {
-    const char* e = getenv("OTGAN_WINO_WGRAD_TL");
-    return !(e && e[0] == '0');
-  }();
-  return on && use_x3_wgrad();
-}
+// wgrad on the fp16 / bf16 pipe whenever the other passes are
+bool use_x3_wgrad() { return use_x3(); }
+// ... straight from the forward-layout operands (t-leading GEMM) where the shape allows (tiles and channels multiples of
+// 32); the transposing producers (wino_prodT_kernel) serve the other shapes
+bool use_x3_wgrad_tl() { return use_x3_wgrad(); }
 // floats of workspace that hold n operand elements (three bf16 planes = 6 bytes per element)
 inline size_t operand_floats(size_t n) { return X3_HDR + (X3_NP * n + 1) / 2; }
 // the planes of a split operand follow its header
@@ -1334,28 +1316,12 @@ void op_scales(const float* x, long rows, int C, long ld, float* base, const flo
   a.scratch = sc.slots + (size_t)slot * kAmaxBlocks;
   a.counter = sc.counters + slot;
   const long n4 = rows * (C / 4);
-  static const long cap = [] { const char* e = getenv("OTGAN_AMAX_BLOCKS"); return e ? atol(e) : 256L; }();
+  constexpr long cap = 256;     // one workgroup per compute unit
   long blocks = (n4 + 256 * 8 - 1) / (256 * 8);
   if (blocks > cap) blocks = cap;
   if (blocks > kAmaxBlocks) blocks = kAmaxBlocks;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
-  static const bool trace = getenv("OTGAN_AMAX_TRACE") != nullptr;   // dev: which tensors still get a reduction pass
-  if (trace) fprintf(stderr, "absmax launch: rows %ld C %d ld %ld gain0 %.2f record_only %d\n", rows, C, a.ld, gain[0], a.record_only);
-  static const bool dbg = getenv("OTGAN_AMAX_DEBUG") != nullptr;
-  if (dbg) {   // dynamic range of the tensor (dev tool: synchronises)
-    (void)hipStreamSynchronize(s);
-    std::vector<float> h((size_t)rows * C);
-    for (long r = 0; r < rows; ++r) (void)hipMemcpy(h.data() + r * C, x + r * a.ld, (size_t)C * 4, hipMemcpyDeviceToHost);
-    double sum = 0, mx = 0;
-    long small = 0;
-    for (float v : h) { sum += fabs(v); mx = std::max(mx, (double)fabs(v)); }
-    for (float v : h) small += fabs(v) < mx * 9.5e-7 ? 1 : 0;   // below amax 2^-20
-    float rec = 0;
-    (void)hipMemcpy(&rec, base, 4, hipMemcpyDeviceToHost);
-    fprintf(stderr, "amax rows=%ld C=%d gain0=%.2f: amax %.3e (record %.3e) mean|x| %.3e ratio %.1e, %.1f%% below amax*2^-20\n", rows, C,
-            gain[0], mx, rec, sum / h.size(), mx / (sum / h.size() + 1e-300), 100.0 * small / h.size());
-  }
 }
 // elements of a [WF][rows][K] operand in either layout (rows padded to 32, K to 16)
 inline size_t op_elems(size_t rows, size_t K) { return WF * ((rows + 31) / 32 * 32) * ((K + 15) / 16 * 16); }
@@ -1376,7 +1342,7 @@ void class_views(const WinoGeo& g, P base, int ld, V (&v)[4]) {
 // K splits of the wgrad GEMM on the bf16 pipe (256 x 256 tiles: few tiles, long K)
 int x3_wgrad_splits(int M, int N, long T) {
   const int blocks = ((M + X3_BM - 1) / X3_BM) * ((N + X3_BN - 1) / X3_BN) * WF;
-  static const int target = [] { const char* e = getenv("OTGAN_X3_SPLIT_TARGET"); return e ? atoi(e) : 256; }();
+  constexpr int target = 256;
   int ns = (target + blocks - 1) / blocks;
   if (ns > 16) ns = 16;
   const int nkt = (int)((T + X3_BK - 1) / X3_BK);
@@ -1398,14 +1364,12 @@ int wgrad_splits(const WinoGeo& g) {
 
 // scales of an operand whose producer kernel (wino_input_kernel / wino_outadj_kernel, `ia`) is launched next: with the
 // caller's amax record the producer derives them itself (ScaleSrc) -- no launch; without one, the reduction as before.
-// OTGAN_INKERNEL_SCALES=0: always the separate launch.
 void producer_scales(InArgs& ia, const float* x, long rows, int C, long ld, float* base, const float (&gain)[WA], float fold,
                      bool floor_one, hipStream_t s, const float* given, int given_count = 1) {
   ia.ss.rec = nullptr;
   ia.ss.nrec = 1;
   if (X3_NP != 2) return;
-  static const bool inkernel = [] { const char* e = getenv("OTGAN_INKERNEL_SCALES"); return !(e && e[0] == '0'); }();
-  if (given && inkernel) {
+  if (given) {
     ia.ss.rec = given;
     ia.ss.nrec = given_count > 1 ? given_count : 1;
     for (int i = 0; i < WA; ++i) ia.ss.gain[i] = gain[i];

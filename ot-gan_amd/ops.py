@@ -643,8 +643,6 @@ def _split_block_plan(N, H, W, C0, L, F, segs0, preact, device):
     import os
     if os.environ.get("OTGAN_DENSE_SPLIT", "1") == "0" or F != 16 or L < 2 or any(int(c) % 4 for c in segs0):
         return None
-    if H * W < int(os.environ.get("OTGAN_DENSE_SPLIT_MIN_PIX", "0")):
-        return None
     mult = 2 if preact in DOUBLED else 1
     Ctot = C0 + L * F
     lib = _lib.lib()
@@ -656,8 +654,6 @@ def _split_block_plan(N, H, W, C0, L, F, segs0, preact, device):
     # measured on the DenseNet step (L = 16): halves 51.9 ms, groups of four 52.9 (with 64-column convolutions allowed
     # 53.5), pairs 60.7, block input only 58.2 -- a wide convolution with K = 128 is bound by its transforms
     group = int(os.environ.get("OTGAN_DENSE_GROUP", str((L + 1) // 2)))
-    if H * W < int(os.environ.get("OTGAN_DENSE_GROUP_MIN_PIX", "0")):
-        group = 0
     g0 = [0] * L          # growth outputs [0, g0[k]) reach layer k through wide convolutions
     for s0 in range(0, L, group) if group > 0 else ():
         s1 = min(s0 + group, L)

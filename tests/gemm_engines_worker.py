@@ -1,5 +1,5 @@
-"""Worker of tests/test_stream_gemm_gpu.py: runs three Winograd layers (forward, dgrad, wgrad) whose batched GEMMs
-have few tiles per compute unit, under whatever OTGAN_X3_STREAM the parent set, twice, and writes the results."""
+"""Worker of tests/test_gemm_engines_gpu.py: runs three Winograd layers (forward, dgrad, wgrad) whose batched GEMMs
+have few tiles per compute unit, under whatever engine switches the parent set, twice, and writes the results."""
 import os
 import sys
 

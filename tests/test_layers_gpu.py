@@ -574,10 +574,9 @@ def test_shared_x_operand(dev, case):
         filt = ops.prepare_filters(desc, 2 if unfolded else 0, wT if unfolded else wT_use)
         buf = ops.shared_x_operand(desc, dev) if shared else None
         if shared and buf is None:
-            # the fp32 engine (OTGAN_WINO_FP32=1) and the transposing weight-gradient producers (OTGAN_WINO_WGRAD_TL=0)
-            # have different operand layouts in the two passes: nothing to share
-            assert any(os.environ.get(k) for k in ("OTGAN_WINO_FP32", "OTGAN_WINO_WGRAD_TL", "OTGAN_WINO_WGRAD_X3",
-                                                   "OTGAN_DISABLE_X_OPERAND", "OTGAN_DISABLE_WINOGRAD")), \
+            # the fp32 engine (OTGAN_WINO_FP32=1) has different operand layouts in the two passes, the direct engine
+            # (OTGAN_DISABLE_WINOGRAD=1) no transformed operand at all: nothing to share
+            assert any(os.environ.get(k) for k in ("OTGAN_WINO_FP32", "OTGAN_DISABLE_WINOGRAD")), \
                 "this layer's passes were expected to share their operand"
             pytest.skip("operand sharing is off in this engine mode")
         y = torch.empty(N, OH, OW, Cout, device=dev)

@@ -6,8 +6,7 @@ losses and gradients against the fp64 oracle and the golden vectors, N = 8 ... 1
   * OTGAN_SINKHORN_LINEAR=0        every sweep log-domain (the kernels of rounds 1 - 3),
   * OTGAN_SINKHORN_LIN_RANGE=0.01  band of +-1 %: nearly every linear sweep ends in a fold-back (the path that otherwise
                                    only runs when potentials move by more than 20 nats after they had settled),
-  * OTGAN_SINKHORN_SETTLE=0.05     the linear form is entered late (potentials within 0.05 nats per sweep),
-  * OTGAN_MATCH_NARROW=1           (not a sweep regime) the matching GEMMs of N >= 256 on the 256 x 128 kernel.
+  * OTGAN_SINKHORN_SETTLE=0.05     the linear form is entered late (potentials within 0.05 nats per sweep).
 
 The switches are read once per process, hence the subprocesses (reference utils/matching.py:50-57)."""
 import os
@@ -21,8 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"OTGAN_SINKHORN_LINEAR": "0"}, {"OTGAN_SINKHORN_LIN_RANGE": "0.01"},
-                                 {"OTGAN_SINKHORN_SETTLE": "0.05"}, {"OTGAN_MATCH_NARROW": "1"}],
-                         ids=["log_only", "fold_back", "late_entry", "narrow_gemm"])
+                                 {"OTGAN_SINKHORN_SETTLE": "0.05"}],
+                         ids=["log_only", "fold_back", "late_entry"])
 def test_matching_suite_in_every_sweep_regime(env):
     e = dict(os.environ)
     e.update(env)
@@ -30,9 +29,6 @@ def test_matching_suite_in_every_sweep_regime(env):
     # eight minutes)
     files = ["tests/test_matching_gpu.py"] + (["tests/test_matching_grad_gpu.py"] if "OTGAN_SINKHORN_LIN_RANGE" in env else [])
     sel = [] if "OTGAN_SINKHORN_LIN_RANGE" in env else ["-k", "sinkhorn or golden or full_size or iteration or equivariance"]
-    if "OTGAN_MATCH_NARROW" in env:     # the matching GEMMs of N >= 256 on the 256 x 128 kernel (off by default: 5 % slower)
-        files = ["tests/test_matching_gpu.py", "tests/test_matching_grad_gpu.py"]
-        sel = ["-k", "cost_matrix_batched or rank_of_8"]      # cost slices (NT kernel) and plan application (TL kernel) at N = 1024
     r = subprocess.run([sys.executable, "-m", "pytest", *files, "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", *sel],
                        cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -6,7 +6,7 @@
 //   * a workgroup parks at most one piece (its first) and the workgroup that continues it is the next non-empty one;
 //   * operand block indices stay inside the operand.
 // usage: stream_plan_check [M N K seg_mode seg_len seg_skip nw]...   prints "ok <n shapes>" or the first violation.
-//   hipcc -O1 -std=c++17 --offload-arch=gfx950 -I ot-gan_amd/csrc tools/stream_plan_check.hip -o tools/ablate/bin/stream_plan_check
+//   hipcc -O1 -std=c++17 --offload-arch=gfx950 -DX3_STREAM_TOOL -I ot-gan_amd/csrc -I tools/ablate tools/ablate/stream_plan_check.hip -o tools/ablate/bin/stream_plan_check
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "gemm_x3.h"
+#include "gemm_x3_stream.h"     // the stream-K kernel (left the library in round 5); build with -DX3_STREAM_TOOL
 
 void otgan_set_error(const char*, ...) {}
 void otgan_prof_begin(int, double, double, hipStream_t) {}

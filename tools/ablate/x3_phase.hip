@@ -1,7 +1,7 @@
 // x3_phase.hip -- where does a workgroup of wino_bgemm_x3_kernel spend its time?  (dev tool, GPU box)
 // Builds the production kernel from ot-gan_amd/csrc/gemm_x3.h with -DX3_TIMING (s_memtime stamps per phase kept in
 // spare LDS) and runs it on the Winograd-domain GEMM shapes of the DCGAN layers with random operands.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DX3_TIMING -I ot-gan_amd/csrc tools/ablate/x3_phase.hip -o tools/ablate/bin/x3_phase
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DX3_TIMING -DX3_STREAM_TOOL -I ot-gan_amd/csrc -I tools/ablate tools/ablate/x3_phase.hip -o tools/ablate/bin/x3_phase
 //   tools/ablate/bin/x3_phase M N K [reps]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "gemm_x3.h"
+#include "gemm_x3_stream.h"     // the stream-K kernel (left the library in round 5); build with -DX3_STREAM_TOOL
 
 void otgan_set_error(const char*, ...) {}
 void otgan_prof_begin(int, double, double, hipStream_t) {}

@@ -1,16 +1,16 @@
 """dev tool: relative L2 error against fp64 of three layers under the three GEMM engines (prints the table quoted in
-DESIGN.md; the assertion lives in tests/test_stream_gemm_gpu.py)."""
+DESIGN.md; the assertion lives in tests/test_gemm_engines_gpu.py)."""
 import os, subprocess, sys, tempfile
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import nets_torch as NT
-from stream_gemm_worker import CASES
+from gemm_engines_worker import CASES
 tmp = tempfile.mkdtemp()
 runs = {}
 for tag, env in (("fp16x2", {}), ("bf16x3", {"OTGAN_WINO_PIECES": "3"}), ("fp32", {"OTGAN_WINO_FP32": "1"})):
     path = os.path.join(tmp, tag + ".npz")
-    subprocess.run([sys.executable, os.path.join(ROOT, "tests", "stream_gemm_worker.py"), path], check=True, env=dict(os.environ, **env))
+    subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gemm_engines_worker.py"), path], check=True, env=dict(os.environ, **env))
     runs[tag] = dict(np.load(path))
 for name, N, H, C, Cout, k, s, up, pre in CASES:
     gen = torch.Generator().manual_seed(sum(map(ord, name)))

@@ -1,4 +1,4 @@
-"""dev: soak test of the 256 x 128 tile GEMM kernel (wino_bgemm_x3n_kernel) -- the layers of tests/stream_gemm_worker.py
+"""dev: soak test of the 256 x 128 tile GEMM kernel (wino_bgemm_x3n_kernel) -- the layers of tests/gemm_engines_worker.py
 plus DCGAN-sized ones, evaluated REPS times in this process under OTGAN_X3_NARROW=1 and compared bit for bit with one
 evaluation under OTGAN_X3_NARROW=0 (the variable is read per launch).  Run two copies at once to perturb timing:
     python tools/debug/narrow_stress.py 20 & python tools/debug/narrow_stress.py 20 & wait"""
