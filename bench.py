@@ -207,8 +207,10 @@ def secondary(dev, a):
         args = default_args(batch_size=bpg // 2, nr_gpu=2, sinkhorn_lambda=500.0, nr_gen_per_disc=5, seed=1, **kw)
         m = OTGAN(args, dev)
         xs = torch.rand(m.nb, size, size, 3, device=dev) * 2 - 1
+        m.prepare_step_graphs(xs)
         per = _time_steps(m, xs, w, k)
         sec[tag] = {"images_per_sec": round(m.nb / per, 1), "ms_per_step": round(per * 1e3, 2), "img_per_gpu": bpg,
+                    "step_graph": sorted(m.graphs.graphs) if m.graphs is not None else "off",
                     "steps": k, "warmup": w, "sinkhorn_iters": args.nr_sinkhorn_iter,
                     "note": "6 timed steps = 1 critic + 5 generator steps (the 5:1 mix), unprofiled wall clock"}
         if not a.no_prof:
@@ -280,6 +282,10 @@ def main():
     torch.manual_seed(1 + rank)
     x = torch.rand(model.nb, a.image_size, a.image_size, 3, device=dev) * 2 - 1   # synthetic batch in [-1,1]
 
+    # one-off setup: the trainer replays whole steps as hipGraphs (trainer.GraphedSteps); capturing them takes one eager
+    # period plus one step per kind -- done here, before the W warm-up steps, so that neither warm-up nor the timed window
+    # contains a capture (they are training steps like any other: untimed, and reported in config.step_graph_setup_steps)
+    graph_setup_steps = model.prepare_step_graphs(x)
     for _ in range(a.warmup):
         model.step(x)
     torch.cuda.synchronize()
@@ -301,6 +307,7 @@ def main():
     torch.cuda.synchronize()
     parallel.barrier()
     dt = time.perf_counter() - t0
+    graph_kinds = sorted(model.graphs.graphs) if model.graphs is not None else []    # (before the profiled pass runs eagerly)
     per_kind = {"disc": [], "gen": []}
     for i in range(a.steps):
         per_kind["disc" if i % period == 0 else "gen"].append(marks[i].elapsed_time(marks[i + 1]))
@@ -369,6 +376,9 @@ def main():
                                                                   " (all ranks on cuda:0, logic test)" if parallel.single_device_mode() else "")
                                if torch.distributed.is_initialized() else "none (single process)"),
                    "sinkhorn_rows": model.sinkhorn_rows(),
+                   "step_graph": (("hipGraph replay of whole steps, kinds captured: " + ", ".join(graph_kinds)) if graph_kinds else
+                                  "off (eager launches)"),
+                   "step_graph_setup_steps": graph_setup_steps,
                    "matching_scope": model.scope,
                    "step_mix": {"critic_steps": n_disc, "generator_steps": a.steps - n_disc,
                                 "critic_ms": round(sum(per_kind["disc"]) / max(1, len(per_kind["disc"])), 3),

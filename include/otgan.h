@@ -56,6 +56,15 @@ int otgan_prof_enable(int on);
 int otgan_prof_reset(void);
 int otgan_prof_collect(int cls, double* out4);
 
+/* Sweep statistics of the Sinkhorn kernels (reference utils/matching.py:50-57: exactly L sweeps; here every sweep runs in
+ * the log-domain form or, once the potentials have settled, in the linear form -- DESIGN.md section 3).  on = 1 allocates
+ * (once) and zeroes eight device counters that every problem solved from then on adds to: [0] problems, [1] log-domain
+ * sweeps, [2] linear sweeps, [3] entries into the linear form, [4] fold-backs to the log-domain form, [5] sum over problems
+ * of the sweep at which the linear form was first entered, [6] problems that never entered it, [7] unused; on = 0
+ * detaches them.  otgan_sinkhorn_counters_read copies them to the host (synchronises the device; reset != 0 zeroes them). */
+int otgan_sinkhorn_counters(int on);
+int otgan_sinkhorn_counters_read(long long* out8, int reset);
+
 /* ---------------------------------------------------------------------------------------
  * Matching operator (mini-batch Sinkhorn energy distance).
  * Replaces reference utils/matching.py:11-85 (two-batch), :88-136 (single-batch) and the

@@ -370,6 +370,17 @@ int otgan_adam_step_f32(float* p, const float* grad, float* v, float* mg, long n
 int otgan_adam_step_gather_f32(float* p, const float* const* grads, const long* offsets, int nseg, float* v, float* mg,
                                double lr, double mom1, double mom2, double t, float* ema_shadow, double ema_decay,
                                void* stream);
+/* The bias corrections {1 - mom1^t, 1 - mom2^t} of that step as the two entries above evaluate them (fp32, nn.py:62,67), on
+ * the HOST (no launch), and the gathered step reading them from DEVICE memory (`coef_dev` [2]; null = from `t` as above):
+ * a step captured in a hipGraph (trainer.py: one graph per step kind, replayed) keeps its launch arguments, so what changes
+ * from step to step must come from memory -- the trainer writes the next step's pair into `coef_dev` before each replay and
+ * the replayed step is bit-identical to the eager one (reference train.py:142-143: one `t` per optimiser). */
+void otgan_adam_coefficients(double mom1, double mom2, double t, float* out2);
+int otgan_adam_step_coef_f32(float* p, const float* grad, float* v, float* mg, long n, double lr,
+                             double mom1, double mom2, double t, const float* coef_dev, void* stream);
+int otgan_adam_step_gather_coef_f32(float* p, const float* const* grads, const long* offsets, int nseg, float* v, float* mg,
+                                    double lr, double mom1, double mom2, double t, const float* coef_dev, float* ema_shadow,
+                                    double ema_decay, void* stream);
 /* Up to OTGAN_COPY2D_MAX_SEGMENTS strided 2-D copies in ONE launch: dst[s][r * dst_ld[s] + c] = src[s][r * src_ld[s] + c]
  * for r < rows[s], c < cols[s].  All arrays are HOST arrays of nseg entries.  (The growth layers of a DenseNet block read
  * sub-blocks of their normalised weights -- rows of every filter tap, models/densenet.py:11-16 through

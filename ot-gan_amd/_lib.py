@@ -18,6 +18,8 @@ SIGNATURES = {
     "otgan_version": (c_int, []),
     "otgan_last_error": (ctypes.c_char_p, []),
     "otgan_prof_enable": (c_int, [c_int]),
+    "otgan_sinkhorn_counters": (c_int, [c_int]),
+    "otgan_sinkhorn_counters_read": (c_int, [c_fp, c_int]),
     "otgan_prof_reset": (c_int, []),
     "otgan_prof_collect": (c_int, [c_int, ctypes.POINTER(c_double)]),
     "otgan_matching_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -115,8 +117,33 @@ PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "cost_gemm", "sinkhorn",
                 "pointwise", "wino_gemm", "wino_gemm_bf16x3")
 
 
+_prof_on = False
+
+
 def prof_enable(on=True):
+    """Per-launch HIP events around every library launch (otgan_prof_*).  While on, the trainer runs its steps eagerly:
+    a replayed hipGraph makes no library calls (nothing to bracket), and an event recorded during a capture belongs to the
+    graph, not to the profiler."""
+    global _prof_on
     check(lib().otgan_prof_enable(1 if on else 0), "otgan_prof_enable")
+    _prof_on = bool(on)
+
+
+def prof_enabled():
+    return _prof_on
+
+
+def sinkhorn_counters(on=True):
+    check(lib().otgan_sinkhorn_counters(1 if on else 0), "otgan_sinkhorn_counters")
+
+
+def sinkhorn_counters_read(reset=False):
+    """-> dict of the Sinkhorn kernels' sweep statistics since they were enabled / last reset (synchronises)."""
+    import ctypes
+    buf = (ctypes.c_longlong * 8)()
+    check(lib().otgan_sinkhorn_counters_read(ctypes.cast(buf, ctypes.c_void_p), 1 if reset else 0), "otgan_sinkhorn_counters_read")
+    keys = ("problems", "log_sweeps", "linear_sweeps", "entries", "fold_backs", "first_entry_sweep_sum", "never_entered")
+    return {k: int(buf[i]) for i, k in enumerate(keys)}
 
 
 def prof_reset():

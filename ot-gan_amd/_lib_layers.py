@@ -88,6 +88,11 @@ SIGNATURES = {
                                     c_double, c_fp]),
     "otgan_adam_step_gather_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_double, c_double, c_double, c_double,
                                            c_fp, c_double, c_fp]),
+    "otgan_adam_step_gather_coef_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_double, c_double, c_double, c_double,
+                                                c_fp, c_fp, c_double, c_fp]),
+    "otgan_adam_coefficients": (None, [c_double, c_double, c_double, c_fp]),
+    "otgan_adam_step_coef_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_long, c_double, c_double, c_double,
+                                         c_double, c_fp, c_fp]),
     "otgan_glu_bwd_colsum_f32": (c_int, [c_fp, c_fp, c_long, c_int, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "otgan_copy2d_batched_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp]),
     "otgan_adamax_step_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_long, c_double, c_double, c_double, c_fp]),

@@ -599,7 +599,11 @@ __device__ __forceinline__ float ema_elem(float sh, float p, float decay, float 
 }
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ v,
                             float* __restrict__ mg, long n, float lr, float mom1, float om1,
-                            float mom2, float om2, float c1, float c2) {
+                            float mom2, float om2, float c1, float c2, const float* __restrict__ coef) {
+  if (coef) {      // (see adam_gather_kernel)
+    c1 = coef[0];
+    c2 = coef[1];
+  }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     p[i] = adam_elem(p[i], g[i], v, mg, i, lr, mom1, om1, mom2, om2, c1, c2);
 }
@@ -674,7 +678,11 @@ struct AdamSegs {
 };
 __global__ void adam_gather_kernel(float* __restrict__ p, AdamSegs segs, float* __restrict__ v, float* __restrict__ mg,
                                    float lr, float mom1, float om1, float mom2, float om2, float c1, float c2,
-                                   float* __restrict__ sh, float decay, float omd) {
+                                   float* __restrict__ sh, float decay, float omd, const float* __restrict__ coef) {
+  if (coef) {      // bias corrections from device memory (a captured step: the launch is replayed with a new t; trainer.py)
+    c1 = coef[0];
+    c2 = coef[1];
+  }
   const int seg = blockIdx.y;
   const long base = segs.off[seg], n = segs.off[seg + 1] - base;
   const float* __restrict__ g = segs.g[seg];
@@ -892,23 +900,38 @@ int otgan_feature_head_bwd_f32(const float* x, const float* f, const float* norm
   return otgan_feature_head_bwd_amax_f32(x, f, norm, df, N, HW, C, dx, nullptr, stream);
 }
 
+void otgan_adam_coefficients(double mom1, double mom2, double t, float* out2) {
+  // nn.py:62,67: `1. - tf.pow(mom, t)` is evaluated IN the fp32 graph (t is a float32 variable)
+  out2[0] = 1.f - powf((float)mom1, (float)t);
+  out2[1] = 1.f - powf((float)mom2, (float)t);
+}
 int otgan_adam_step_f32(float* p, const float* grad, float* v, float* mg, long n, double lr,
                         double mom1, double mom2, double t, void* stream) {
-  OTGAN_CHECK_ARG(p && grad && mg && n > 0 && t >= 1.0 && (mom1 <= 0.0 || v), "bad arguments");
+  return otgan_adam_step_coef_f32(p, grad, v, mg, n, lr, mom1, mom2, t, nullptr, stream);
+}
+int otgan_adam_step_coef_f32(float* p, const float* grad, float* v, float* mg, long n, double lr,
+                             double mom1, double mom2, double t, const float* coef_dev, void* stream) {
+  OTGAN_CHECK_ARG(p && grad && mg && n > 0 && (coef_dev || t >= 1.0) && (mom1 <= 0.0 || v), "bad arguments");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, 4.0 * 7 * (double)n, s);
   // nn.py:62,67: `1. - tf.pow(mom, t)` is evaluated IN the fp32 graph (t is a float32 variable),
   // whereas `(1. - mom)` (nn.py:61,66) is a Python double folded into an fp32 constant.
-  const float c1 = 1.f - powf((float)mom1, (float)t), c2 = 1.f - powf((float)mom2, (float)t);
+  float c[2] = {1.f, 1.f};
+  if (!coef_dev) otgan_adam_coefficients(mom1, mom2, t, c);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, grad, v, mg, n, (float)lr,
-                     (float)mom1, (float)(1.0 - mom1), (float)mom2, (float)(1.0 - mom2), c1, c2);
+                     (float)mom1, (float)(1.0 - mom1), (float)mom2, (float)(1.0 - mom2), c[0], c[1], coef_dev);
   OTGAN_CHECK_LAUNCH("adam");
   return OTGAN_OK;
 }
 int otgan_adam_step_gather_f32(float* p, const float* const* grads, const long* offsets, int nseg, float* v, float* mg,
                                double lr, double mom1, double mom2, double t, float* ema_shadow, double ema_decay,
                                void* stream) {
-  OTGAN_CHECK_ARG(p && grads && offsets && mg && nseg > 0 && nseg <= OTGAN_ADAM_MAX_SEGMENTS && t >= 1.0 && (mom1 <= 0.0 || v),
+  return otgan_adam_step_gather_coef_f32(p, grads, offsets, nseg, v, mg, lr, mom1, mom2, t, nullptr, ema_shadow, ema_decay, stream);
+}
+int otgan_adam_step_gather_coef_f32(float* p, const float* const* grads, const long* offsets, int nseg, float* v, float* mg,
+                                    double lr, double mom1, double mom2, double t, const float* coef_dev, float* ema_shadow,
+                                    double ema_decay, void* stream) {
+  OTGAN_CHECK_ARG(p && grads && offsets && mg && nseg > 0 && nseg <= OTGAN_ADAM_MAX_SEGMENTS && (coef_dev || t >= 1.0) && (mom1 <= 0.0 || v),
                   "bad arguments (at most %d segments)", OTGAN_ADAM_MAX_SEGMENTS);
   hipStream_t s = (hipStream_t)stream;
   AdamSegs segs;
@@ -923,10 +946,11 @@ int otgan_adam_step_gather_f32(float* p, const float* const* grads, const long* 
   segs.off[nseg] = offsets[nseg];
   const long n = offsets[nseg] - offsets[0];
   ProfScope ps(OTGAN_PROF_POINTWISE, 0.0, 4.0 * (ema_shadow ? 9 : 7) * (double)n, s);
-  const float c1 = 1.f - powf((float)mom1, (float)t), c2 = 1.f - powf((float)mom2, (float)t);   // (see otgan_adam_step_f32)
+  float c[2] = {1.f, 1.f};
+  if (!coef_dev) otgan_adam_coefficients(mom1, mom2, t, c);          // (see otgan_adam_step_f32)
   hipLaunchKernelGGL(adam_gather_kernel, dim3(grid_for(longest), nseg), dim3(256), 0, s, p, segs, v, mg, (float)lr,
-                     (float)mom1, (float)(1.0 - mom1), (float)mom2, (float)(1.0 - mom2), c1, c2, ema_shadow,
-                     (float)ema_decay, (float)(1.0 - ema_decay));
+                     (float)mom1, (float)(1.0 - mom1), (float)mom2, (float)(1.0 - mom2), c[0], c[1], ema_shadow,
+                     (float)ema_decay, (float)(1.0 - ema_decay), coef_dev);
   OTGAN_CHECK_LAUNCH("adam (gathered gradients)");
   return OTGAN_OK;
 }

@@ -206,6 +206,23 @@ constexpr float kLogSettle = 5.f;                       // nats per sweep
 struct LinCtl {
   int enabled;
   float settle, lo, hi;    // kLogSettle; the scaling factors stay inside (lo, hi) = (e^-20, e^20)
+  // sweep statistics (otgan_sinkhorn_counters; null = off): [0] problems solved, [1] log-domain sweeps, [2] linear sweeps,
+  // [3] entries into the linear form, [4] fold-backs to the log-domain form, [5] sum over problems of the sweep at which the
+  // linear form was first entered, [6] problems that never entered it
+  unsigned long long* counters;
+};
+struct SweepCount {
+  unsigned logs = 0, lins = 0, entries = 0, folds = 0, first = 0;
+  __device__ __forceinline__ void commit(unsigned long long* c) const {
+    if (!c) return;
+    atomicAdd(c + 0, 1ull);
+    atomicAdd(c + 1, (unsigned long long)logs);
+    atomicAdd(c + 2, (unsigned long long)lins);
+    atomicAdd(c + 3, (unsigned long long)entries);
+    atomicAdd(c + 4, (unsigned long long)folds);
+    atomicAdd(c + 5, (unsigned long long)first);
+    if (!entries) atomicAdd(c + 6, 1ull);
+  }
 };
 // value of lane (l ^ 1) / (l ^ 2) of the quad (DPP quad_perm [1,0,3,2] / [2,3,0,1])
 __device__ __forceinline__ float quad_xor1(float v) {
@@ -328,12 +345,14 @@ __global__ __launch_bounds__(512) void sinkhorn_small_kernel(const float* __rest
 
   float er[32], ec[32];
   bool linear = false;
+  SweepCount sc;
   auto absorb = [&]() {   // back to potentials: f += log u, g += log v
     if (t < n) s_f[pot_slot(t)] += logf(s_u[pot_slot(t)]);
     if (t < m) s_g[pot_slot(t)] += logf(s_v[pot_slot(t)]);
     __syncthreads();
   };
   for (int it = 0; it < iters; ++it) {
+    if (linear) ++sc.lins; else ++sc.logs;
     if (!linear) {
       const bool mf = small_half_step(kr, s_g, s_f, idx, q, n, lc.settle, s_flag, turn);  // rows:    f from g
       const bool mg = small_half_step(kc, s_f, s_g, idx, q, m, lc.settle, s_flag, turn);  // columns: g from f
@@ -351,6 +370,7 @@ __global__ __launch_bounds__(512) void sinkhorn_small_kernel(const float* __rest
         }
         __syncthreads();
         linear = true;
+        if (!sc.entries++) sc.first = it + 1;
       }
     } else {
       const bool fu = small_lin_step(er, s_v, s_u, idx, q, n, lc, s_flag, turn);  // rows:    u from v
@@ -358,9 +378,11 @@ __global__ __launch_bounds__(512) void sinkhorn_small_kernel(const float* __rest
       if (fu || fv) {
         absorb();
         linear = false;
+        ++sc.folds;
       }
     }
   }
+  if (t == 0) sc.commit(lc.counters);
   if (linear) absorb();
   small_half_step(kr, s_g, s_f, idx, q, n, lc.settle, s_flag, turn);    // final row softmax (matching.py:56)
 
@@ -617,6 +639,7 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
   auto moved = [&](float fresh, float old) { return !(fabsf(fresh - old) < lc.settle); };
   auto far = [&](float fresh, float) { return !(fresh > lc.lo && fresh < lc.hi); };
   bool linear = false, need_k = true;
+  SweepCount sc;
   auto absorb = [&]() {   // linear -> log: f += log u, g += log v; K comes back at the top of the loop (its one load site)
     if (t < N) {
       s_f[t] += logf(s_u[t]);
@@ -633,6 +656,7 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
       need_k = false;
     }
     if (it >= a.iters || !ok) break;
+    if (linear) ++sc.lins; else ++sc.logs;
     if (!linear) {
       log_rows();
       const bool mf = consume_all(f, s_f, moved);
@@ -673,6 +697,7 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
         s_v[t] = 1.f;
         __syncthreads();
         linear = true;
+        if (!sc.entries++) sc.first = it + 1;
       }
     } else {
       const int q32 = fresh(q * 32), kb = fresh(q * 32 * RPW + line);
@@ -704,9 +729,13 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
       panel_combine_lin<TPR, RPW>(sm, s_pm, line, q, r, N, g, ++phase);
       const bool fv = consume_all(g, s_v, far);
       if (!ok) break;
-      if (fu || fv) absorb();
+      if (fu || fv) {
+        absorb();
+        ++sc.folds;
+      }
     }
   }
+  if (t == 0 && r == 0) sc.commit(lc.counters);     // (every workgroup of a problem takes the same decisions: one reports)
   if (ok) {   // the final row softmax (matching.py:56)
     log_rows();
     consume_all(f, s_f, moved);
@@ -752,9 +781,11 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
 // OTGAN_SINKHORN_LINEAR=0: every sweep in the log domain (the kernels of rounds 1 - 3).  Test knobs:
 // OTGAN_SINKHORN_LIN_RANGE=<nats> (default 20) narrows the band of the scaling factors, OTGAN_SINKHORN_SETTLE=<nats>
 // (default 5) the entry condition -- tiny values force the fold-back path on every sweep.
-inline LinCtl lin_ctl() {
+unsigned long long* g_sweep_counters = nullptr;      // otgan_sinkhorn_counters(1): device buffer of eight counters
+inline LinCtl lin_ctl_static() {
   static const LinCtl c = [] {
     LinCtl v;
+    v.counters = nullptr;
     const char* e = getenv("OTGAN_SINKHORN_LINEAR");
     v.enabled = e && e[0] == '0' ? 0 : 1;
     const char* r = getenv("OTGAN_SINKHORN_LIN_RANGE");
@@ -765,6 +796,11 @@ inline LinCtl lin_ctl() {
     v.hi = expf(range);
     return v;
   }();
+  return c;
+}
+inline LinCtl lin_ctl() {
+  LinCtl c = lin_ctl_static();
+  c.counters = g_sweep_counters;
   return c;
 }
 
@@ -2210,6 +2246,39 @@ int otgan_calc_distance_f32(const float* a, const float* b, const float* aa, con
   OTGAN_CHECK_ARG(rows > 0 && D > 0 && denom != 0.0, "bad sizes");
   return launch_distance(a, b, aa, bb, ab, rows * (long)D, denom, dist, scratch3,
                          (hipStream_t)stream);
+}
+
+
+// Sweep statistics of the Sinkhorn kernels (DESIGN section 3 "Sinkhorn sweeps without exponentials"; tools/soak_sinkhorn.py):
+// on = 1 allocates (once) and zeroes eight device counters that every problem solved from now on adds to -- [0] problems,
+// [1] log-domain sweeps, [2] linear sweeps, [3] entries into the linear form, [4] fold-backs, [5] sum of first-entry sweeps,
+// [6] problems that never entered; on = 0 detaches them.  otgan_sinkhorn_counters_read synchronises the device.
+int otgan_sinkhorn_counters(int on) {
+  static unsigned long long* buf = nullptr;
+  if (on && !buf) {
+    void* p = nullptr;
+    if (hipMalloc(&p, 8 * sizeof(unsigned long long)) != hipSuccess) {
+      otgan_set_error("otgan_sinkhorn_counters: allocation failed");
+      return OTGAN_ERR_LAUNCH;
+    }
+    buf = static_cast<unsigned long long*>(p);
+  }
+  if (on) (void)hipMemset(buf, 0, 8 * sizeof(unsigned long long));
+  g_sweep_counters = on ? buf : nullptr;
+  return OTGAN_OK;
+}
+int otgan_sinkhorn_counters_read(long long* out8, int reset) {
+  OTGAN_CHECK_ARG(out8, "null pointer");
+  if (!g_sweep_counters) {
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    return OTGAN_OK;
+  }
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out8, g_sweep_counters, 8 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) {
+    otgan_set_error("otgan_sinkhorn_counters_read: copy failed");
+    return OTGAN_ERR_LAUNCH;
+  }
+  if (reset) (void)hipMemset(g_sweep_counters, 0, 8 * sizeof(unsigned long long));
+  return OTGAN_OK;
 }
 
 }  // extern "C"

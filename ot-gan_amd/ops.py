@@ -226,6 +226,13 @@ def amax_slot(device):
     return rec
 
 
+def reset_amax_pool():
+    """Forget the current pool of zeroed records: the next amax_slot() allocates (and zeroes) a new one.  A step captured in
+    a hipGraph calls this at the start of the capture, so that the pool's zeroing is part of the graph and every replay starts
+    from zeroed records, and at its end, so that eager code never draws from a pool a replay re-zeroes."""
+    _amax_pool.clear()
+
+
 def tag_amax(t, rec):
     """`t` was just written by a kernel that max-accumulated |t| into rec[0]."""
     t._otgan_amax = (rec, t._version)
@@ -1317,29 +1324,39 @@ feature_head = FeatureHeadFunction.apply
 
 
 # ------------------------------------------------------------------------------- optimiser steps
-def adam_step(p, grad, v, mg, lr, mom1, mom2, t):
+def adam_step(p, grad, v, mg, lr, mom1, mom2, t, coef=None):
     bump_weights_epoch(p)
-    _lib.check(_lib.lib().otgan_adam_step_f32(p.data_ptr(), grad.data_ptr(), _lib.ptr(v), mg.data_ptr(),
-                                              p.numel(), float(lr), float(mom1), float(mom2),
-                                              float(t), _lib.stream_ptr()), "adam_step")
+    _lib.check(_lib.lib().otgan_adam_step_coef_f32(p.data_ptr(), grad.data_ptr(), _lib.ptr(v), mg.data_ptr(),
+                                                   p.numel(), float(lr), float(mom1), float(mom2),
+                                                   float(t), _lib.ptr(coef), _lib.stream_ptr()), "adam_step")
 
 
 ADAM_MAX_SEGMENTS = 32      # otgan_layers.h: OTGAN_ADAM_MAX_SEGMENTS
 
 
-def adam_step_gather(p_flat, grads, offsets, v, mg, lr, mom1, mom2, t, ema_shadow=None, ema_decay=0.0):
+def adam_coefficients(mom1, mom2, t):
+    """(1 - mom1^t, 1 - mom2^t) as the library's Adam entries evaluate them (fp32; host only, no launch)."""
+    out = (ctypes.c_float * 2)()
+    _lib.lib().otgan_adam_coefficients(float(mom1), float(mom2), float(t), ctypes.cast(out, ctypes.c_void_p))
+    return float(out[0]), float(out[1])
+
+
+def adam_step_gather(p_flat, grads, offsets, v, mg, lr, mom1, mom2, t, ema_shadow=None, ema_decay=0.0, coef=None):
     """Adam on a flat parameter buffer from per-variable gradient tensors (no concatenation); optionally the EMA of the
-    updated parameters in the same launch (otgan_adam_step_gather_f32)."""
+    updated parameters in the same launch (otgan_adam_step_gather_f32).  coef: a device tensor [2] holding the step's
+    bias corrections (adam_coefficients) -- read by the kernel instead of being derived from `t` on the host, so that a
+    captured launch can be replayed for later steps (trainer.GraphedSteps)."""
     n = len(grads)
     bump_weights_epoch(p_flat)
     if ema_shadow is not None:
         bump_weights_epoch(ema_shadow)
     gp = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads])
     off = (ctypes.c_long * (n + 1))(*offsets)
-    _lib.check(_lib.lib().otgan_adam_step_gather_f32(p_flat.data_ptr(), ctypes.cast(gp, ctypes.c_void_p),
-                                                     ctypes.cast(off, ctypes.c_void_p), n, _lib.ptr(v), mg.data_ptr(),
-                                                     float(lr), float(mom1), float(mom2), float(t), _lib.ptr(ema_shadow),
-                                                     float(ema_decay), _lib.stream_ptr()), "adam_step_gather")
+    _lib.check(_lib.lib().otgan_adam_step_gather_coef_f32(p_flat.data_ptr(), ctypes.cast(gp, ctypes.c_void_p),
+                                                          ctypes.cast(off, ctypes.c_void_p), n, _lib.ptr(v), mg.data_ptr(),
+                                                          float(lr), float(mom1), float(mom2), float(t), _lib.ptr(coef),
+                                                          _lib.ptr(ema_shadow), float(ema_decay), _lib.stream_ptr()),
+               "adam_step_gather")
 
 
 COPY2D_MAX_SEGMENTS = 64   # include/otgan_layers.h

@@ -66,6 +66,9 @@ def build_parser():
     p.add_argument('--inception_model', type=str, default='',
                    help='TorchScript classifier (float32 images [n,H,W,3] in 0..255 -> class probabilities); without it the '
                         'Inception-score hook is skipped (the reference downloads the 2015 Inception graph)')
+    p.add_argument('--step_graph', action='store_true',
+                   help='replay whole steps as hipGraphs after the first period (single-process runs; bit-identical to the '
+                        'eager steps, measured 3 - 6 %% slower than stream launches on MI355X / ROCm 7: off by default)')
     return p
 
 

@@ -10,6 +10,11 @@ from . import parallel
 from .utils import matching, nn
 
 
+def _lib_prof_on():
+    from . import _lib
+    return _lib.prof_enabled()
+
+
 class _frozen:
     """Context manager: the given leaf tensors do not require grad inside the block."""
 
@@ -138,6 +143,13 @@ class OTGAN:
         self.step_counter = 0
         self.last = {}
         self.timers = None        # name -> [(start event, end event)]; see enable_timers()
+        self._d_weights_in_graph = False
+        # whole steps as hipGraphs (opt-in: --step_graph / OTGAN_STEP_GRAPH=1; measured SLOWER than stream launches on this
+        # stack, see GraphedSteps): single-process runs only (gloo cannot be captured; RCCL under capture is untested here)
+        want = bool(getattr(args, "step_graph", False)) or os.environ.get("OTGAN_STEP_GRAPH", "0") == "1"
+        if os.environ.get("OTGAN_STEP_GRAPH") == "0":
+            want = False
+        self.graphs = GraphedSteps(self) if (want and not self.collectives and self.world == 1) else None
 
     # ---------------------------------------------------------------- per-region step times (bench.py, ranks > 1)
     def enable_timers(self, on=True):
@@ -147,6 +159,9 @@ class OTGAN:
         (the gradient SUM).  In the default serial schedule the stream waits for every collective where it is issued,
         so the regions do not overlap compute and their sum is the non-scaling part of the step."""
         self.timers = {} if on else None
+        if on and self.graphs is not None:
+            self.graphs.drop("region timers need the eager step")
+            self.graphs = None
 
     def _timed(self, name):
         if self.timers is None:
@@ -246,14 +261,49 @@ class OTGAN:
         """x_data: [shards*batch_size, H, W, 3] in [-1, 1].  Runs a critic step when
         step_counter % (nr_gen_per_disc+1) == 0, else a generator step (train.py:214-226).
         `noise` (tests) replaces the generator's own latent draw; `apply_updates=False`
-        (tests) leaves the parameters untouched and returns the summed gradients."""
-        a = self.args
+        (tests) leaves the parameters untouched and returns the summed gradients.
+
+        With `args.step_graph` (opt-in, single-process runs) the step is captured in a hipGraph per step kind after one
+        eager period and replayed (GraphedSteps below): the same launches with the same arguments."""
         assert x_data.shape[0] == self.nb
+        period = self.args.nr_gen_per_disc + 1
+        phase = self.step_counter % period
+        kind = "disc" if phase == 0 else "gen"
+        if self.graphs is not None and noise is None and apply_updates:
+            done = self.graphs.run(x_data, phase)
+            if done is not None:
+                self.last = done
+                return self.last
+        dist, ent, grads = self._step_body(x_data, kind, noise, apply_updates)
+        if kind == "disc":
+            self._d_weights_in_graph = False      # the critic changed: graphs that read its cached operands wait for a refresh
+        self.step_counter += 1
+        self.last = {"kind": kind, "distance": dist, "entropy": ent}      # device scalars, no sync
+        if not apply_updates:
+            self.last["grads"] = grads
+        return self.last
+
+    def prepare_step_graphs(self, x_data):
+        """Run training steps on `x_data` until every step kind is captured (one eager period, then each kind the first time
+        it is due: at most 3 periods) -- the one-off setup of the replayed steps, for callers that time a window afterwards
+        (bench.py).  Returns the number of steps run (0 when graphs are off)."""
+        if self.graphs is None:
+            return 0
+        period = self.args.nr_gen_per_disc + 1
+        kinds = {self.graphs._kind(p) for p in range(period)}
+        n = 0
+        while self.graphs is not None and self.graphs.dead is None and set(self.graphs.graphs) != kinds and n < 3 * period + 2:
+            self.step(x_data)
+            n += 1
+        return n
+
+    def _step_body(self, x_data, kind, noise=None, apply_updates=True):
+        """The launches of one step (no host-side bookkeeping): -> (distance, entropy, summed gradients)."""
+        a = self.args
         gkw = dict(self.model_opts)
         if noise is not None:
             gkw["noise"] = noise
-        if self.step_counter % (a.nr_gen_per_disc + 1) == 0:
-            kind = "disc"
+        if kind == "disc":
             with torch.no_grad():
                 ema = self.ema if a.train_disc_against_ema else None    # train.py:119-123
                 x_gen = self.generator(batch_size=self.nb, ema=ema, device=self.device, **gkw)
@@ -270,7 +320,6 @@ class OTGAN:
             if apply_updates:
                 self.disc_optimizer(grads, lr=-a.learning_rate_disc)                              # train.py:143
         else:
-            kind = "gen"
             with torch.no_grad():
                 f_dat = self.discriminator(x_data, **self.model_opts)
             # the real-data features are final here: start their all-gather now, it overlaps the
@@ -297,11 +346,7 @@ class OTGAN:
                 self.gen_optimizer(grads, lr=a.learning_rate_gen)                                 # train.py:142
                 if not self.ema_fused:
                     self.maintain_averages()                                                      # train.py:223
-        self.step_counter += 1
-        self.last = {"kind": kind, "distance": dist, "entropy": ent}      # device scalars, no sync
-        if not apply_updates:
-            self.last["grads"] = grads
-        return self.last
+        return dist, ent, grads
 
     @torch.no_grad()
     def sample(self, n, ema=False):
@@ -325,6 +370,8 @@ class OTGAN:
 
     def load_state_dict(self, sd):
         from . import ops
+        if self.graphs is not None:
+            self.graphs.drop("checkpoint loaded (the optimisers' moment buffers are new tensors)", recapture=True)
         with torch.no_grad():
             for t in (self.discriminator, self.generator):
                 for k, v in t.named_variables().items():
@@ -359,6 +406,126 @@ class OTGAN:
             if b is not None:
                 b.remove()
         self.disc_buckets = self.gen_buckets = None
+        if self.graphs is not None:
+            self.graphs.drop("trainer closed")
+            self.graphs = None
+
+
+class GraphedSteps:
+    """Whole training steps captured as hipGraphs and replayed (the launch-bound inner loop of the reference's
+    `sess.run`, train.py:207-226: ~130 launches per DCGAN step, ~640 per DenseNet step, each behind Python, ctypes and
+    the autograd engine -- 17 - 23 % of a DenseNet step was idle time between kernels in round 4).
+
+    One graph per step KIND, because the step's launch sequence depends on which cached operands are valid:
+        "disc"  critic step (phase 0 of the period nr_gen_per_disc + 1);
+        "gen1"  the generator step right after it: the critic's normalised weights and Winograd-domain filters are
+                recomputed here (the critic just changed);
+        "gen"   every later generator step of the period: reads them.
+    The first period always runs eagerly (workspaces, function attributes, optimiser state, device tables are created
+    there); from then on a kind is captured the first time it is due -- which is the order gen1, gen, disc -- and
+    replayed afterwards.  What crosses graph boundaries: the critic's cached operands (written by "gen1", read by "gen"
+    and "disc": captured after it, so they hold its addresses) and the parameter / moment / EMA buffers (static).  The
+    generator's cached operands never cross: every kind recomputes them (it changed in the previous step; "gen1"
+    invalidates them itself, the critic step before it does not touch the generator).
+
+    What changes from step to step comes from device memory: the data batch (copied into a static buffer), the RNG
+    (torch's graph-safe generator state) and Adam's bias corrections (`coef_dev`, written before each replay with the
+    values the eager step would pass: otgan_adam_coefficients).  A replayed step is therefore the SAME arithmetic as
+    the eager one -- tests/test_step_graph_gpu.py asserts bit-identical parameters after a period of each.  amax
+    records used inside a capture come from a pool allocated (zeroed) inside it, so every replay starts from zeroed
+    records like the eager step does.  Any failure to capture disables the graphs with a warning; the eager step is
+    always available.
+
+    OFF BY DEFAULT (`--step_graph`, OTGAN_STEP_GRAPH=1 to opt in).  Measured in round 5 on one box, A/B/A/B, replay against
+    eager launches: DCGAN 9.38 / 9.38 ms against 8.80 / 8.79 ms per step (-6 %), DenseNet 29.29 / 29.34 against 28.41 / 28.44
+    (-3 %).  The step is not launch-bound outside a tracer (kernel time 0.91 of the wall clock in the eager profiled pass),
+    and the runtime's graph launch orders every node behind its predecessor, where stream launches let a kernel's first
+    workgroups start under the previous kernel's tail.  What the capture is good for: the bit-identity it proves (a replay
+    of the recorded launches IS the step -- no host-side value leaks into the arithmetic) and boxes whose host is slow."""
+
+    def __init__(self, model):
+        self.m = model
+        self.graphs = {}          # kind -> (CUDAGraph, dist, ent)
+        self.x = None             # static input batch
+        self.stream = None
+        self.warm = 0             # eager steps seen
+        self.dead = None          # reason, once disabled
+
+    def drop(self, why, recapture=False):
+        self.graphs = {}
+        self.m._d_weights_in_graph = False
+        self.warm = 0
+        if not recapture:
+            self.dead = why
+
+    def _kind(self, phase):
+        return "disc" if phase == 0 else ("gen1" if phase == 1 else "gen")
+
+    def run(self, x_data, phase):
+        """Replay (capturing first if due) the step of `phase`; None = run it eagerly."""
+        from . import ops
+        m = self.m
+        period = m.args.nr_gen_per_disc + 1
+        if self.dead is not None or _lib_prof_on():
+            return None                   # (profiled passes bracket library launches: eager)
+        if self.warm < period:            # the first period: eager
+            self.warm += 1
+            return None
+        kind = self._kind(phase)
+        if kind not in self.graphs:
+            # capture order: "gen1" first (right after an eager or replayed critic step), then the kinds that read its
+            # operands
+            if kind != "gen1" and period > 1 and not m._d_weights_in_graph:
+                return None
+            try:
+                self._capture(x_data, kind)
+            except Exception as e:          # never lose a run over the optimisation
+                import warnings
+                warnings.warn(f"otgan_amd: step graph capture failed ({type(e).__name__}: {e}); continuing with eager steps")
+                self.drop(f"capture failed: {e}")
+                return None
+        elif kind != "gen1" and period > 1 and not m._d_weights_in_graph:
+            return None                     # an eager step refreshed the critic elsewhere: wait for the next "gen1"
+        g, dist, ent = self.graphs[kind]
+        opt = m.disc_optimizer if kind == "disc" else m.gen_optimizer
+        self.x.copy_(x_data)
+        if getattr(opt, "coef_dev", None) is not None:
+            opt.write_coefficients()
+        g.replay()
+        # the host-side bookkeeping of the step
+        opt.t += 1.0
+        m.step_counter += 1
+        m._d_weights_in_graph = kind != "disc"
+        ops.bump_weights_epoch()            # the host caches describe capture time, not this replay: eager users recompute
+        return {"kind": "disc" if kind == "disc" else "gen", "distance": dist, "entropy": ent}
+
+    def _capture(self, x_data, kind):
+        from . import ops
+        m = self.m
+        if self.x is None:
+            self.x = torch.empty_like(x_data)
+            self.stream = torch.cuda.Stream(device=m.device)
+        for opt in (m.gen_optimizer, m.disc_optimizer):
+            if hasattr(opt, "ensure_state"):
+                opt.ensure_state()
+                if opt.coef_dev is None:
+                    opt.coef_dev = torch.ones(2, dtype=torch.float32, device=m.device)
+        self.x.copy_(x_data)
+        if kind == "gen1":
+            # the generator's cached operands must not cross graphs (see the class comment): recompute them here
+            ops.bump_weights_epoch(m.gen_params[0])
+        saved_t = (m.gen_optimizer.t, m.disc_optimizer.t)
+        ops.reset_amax_pool()
+        g = torch.cuda.CUDAGraph()
+        try:
+            m.gen_optimizer.capturing = m.disc_optimizer.capturing = True      # Adam reads its bias corrections from coef_dev
+            with torch.cuda.graph(g, stream=self.stream):
+                dist, ent, _ = m._step_body(self.x, "disc" if kind == "disc" else "gen")
+        finally:
+            m.gen_optimizer.capturing = m.disc_optimizer.capturing = False
+            m.gen_optimizer.t, m.disc_optimizer.t = saved_t      # (the capture only recorded the launches)
+            ops.reset_amax_pool()                                 # eager code must not draw from the graph's pool
+        self.graphs[kind] = (g, dist, ent)
 
 
 def rank_log_kernel_slices(rank, world, f_gen, f_dat, fa, fb, lam):
@@ -417,7 +584,7 @@ def default_args(**over):
              load_params=False, model_name='med_gan_params-2399', no_sinkhorn=False,
              image_size=32, matching_scope='global', synthetic=False, max_steps=0, save_every=200,
              synthetic_size=50000, data_dependent_init=False, eval_every=100, eval_samples=50000,
-             inception_model='', ranks=0)
+             inception_model='', ranks=0, step_graph=False)
     d.update(over)
     return argparse.Namespace(**d)
 

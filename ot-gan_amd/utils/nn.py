@@ -473,14 +473,30 @@ class _Adam(_Updates):
         ema = self._ema
         ops.adam_step_gather(p, self.group.in_buffer_order(grads, self.params), self.group.offsets(), st["v"], st["mg"],
                              lr, self.mom1, self.mom2, self.t,
-                             ema._flat[0] if ema is not None else None, ema.decay if ema is not None else 0.0)
+                             ema._flat[0] if ema is not None else None, ema.decay if ema is not None else 0.0,
+                             coef=self.coef_dev if self.capturing else None)
         return True
+
+    coef_dev = None      # device [2]: the step's bias corrections, written by the trainer before a captured step is replayed
+    capturing = False    # True while the trainer records a step into a hipGraph: the launch then reads coef_dev
+
+    def ensure_state(self):
+        """Allocate the moment buffers now (a captured step must not be the one that creates them)."""
+        if self.group is not None and not self.state[0]:
+            p = self.group.flat
+            self.state[0]["mg"] = torch.zeros_like(p)
+            self.state[0]["v"] = torch.zeros_like(p) if self.mom1 > 0 else None
+
+    def write_coefficients(self):
+        """The bias corrections of the NEXT step (self.t) into coef_dev: the same fp32 values the eager step derives."""
+        c1, c2 = ops.adam_coefficients(self.mom1, self.mom2, self.t)
+        self.coef_dev.copy_(torch.tensor([c1, c2], dtype=torch.float32))
 
     def _step(self, p, g, st, lr):
         if not st:
             st["mg"] = torch.zeros_like(p)
             st["v"] = torch.zeros_like(p) if self.mom1 > 0 else None
-        ops.adam_step(p, g, st["v"], st["mg"], lr, self.mom1, self.mom2, self.t)
+        ops.adam_step(p, g, st["v"], st["mg"], lr, self.mom1, self.mom2, self.t, coef=self.coef_dev if self.capturing else None)
 
 
 class _Adamax(_Updates):
