@@ -164,14 +164,19 @@ def secondary(dev, a):
             allk = torch.stack([T.rank_log_kernel_slices(r, W, own(fa_flat, r), own(fb_flat, r), fa_flat, fb_flat, 500.0)
                                 for r in range(W)], 0)
             K6 = T.assemble_log_kernels(allk, W)
-            del allk
+            stack_path = T.rank_stack_ok(rows, fa_flat)
+            if not stack_path:
+                del allk
 
             def rank_step(need_b):
+                if stack_path:      # what trainer._match runs since round 5: ONE split of the gathered features for both calls
+                    return T.rank_matching_stack(0, W, rows, fa_flat, fb_flat, 500.0, L, need_b, gather=allk)
                 T.rank_log_kernel_slices(0, W, own(fa_flat, 0), own(fb_flat, 0), fa_flat, fb_flat, 500.0)
                 return matching.matched_feature_grads(fa_flat, fb_flat, 500.0, L, need_b=need_b, rows=rr, log_kernels=K6)
             calls["rank_generator_step"] = lambda: rank_step(False)
             calls["rank_critic_step"] = lambda: rank_step(True)
             case["ranks"] = W
+            case["rank_path"] = "feature stack split once per step (matching.FeatureStack)" if stack_path else "one split per library call"
             case["note"] = ("us_rank_*: what one rank of %d runs (cost row slices + Sinkhorn + plans on its rows; slice "
                             "all-gather excluded); us / us_grads_*: the same rows WITHOUT precomputed log-kernels -- the "
                             "library computes all six N x N costs, not a rank's workload" % W)
@@ -193,7 +198,7 @@ def secondary(dev, a):
             else:
                 case["us_" + tag] = round(us, 1)
         blocks.append(case)
-        K6 = None
+        K6 = allk = None
         del fa, fb, fa_flat, fb_flat
     sec["matching_block"] = {"unit": "microseconds per call (wall, 5 calls); `us` / `tflops` (on 12*N^2*D + 24*N^2*D*(rows/2N)): the "
                                      "reference's operator = four matched arrays; us_grads_*: the training-mode entry the step calls "

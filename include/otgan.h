@@ -135,6 +135,33 @@ int otgan_matching_two_batch_rows_grad_f32(const float* fa, const float* fb, int
                                            void* stream);
 
 /*
+ * One split of the features per step for a data-parallel rank (round 5).  A rank of the global matching scope multiplies the
+ * gathered features in two library calls per step -- its three cost row slices (matching.py:29-39) and the plans applied to
+ * its own rows (:64-83) -- and each call used to split the fp32 blocks it read into the GEMM engine's operand (two scaled
+ * fp16 planes) itself.  The STACK is that operand as an object of the caller: six N-row blocks [a1 b1 b2 a2 a1 b1] (the layout
+ * inside otgan_matching_two_batch_grad_f32: every injected difference contracts over three adjacent blocks).
+ *   otgan_matching_stack_bytes      size of the buffer; 0 when the engine does not take the shape (N < 256, ...): use the
+ *                                   entries above.
+ *   otgan_matching_stack_split_f32  fills the given stack-row ranges (multiples of 32 rows) from fa / fb [2N, D]; a
+ *                                   first-half rank in a generator step needs rows [N, 4N) (the Y blocks of its cost slices
+ *                                   and the contraction blocks of g(a1)) plus its own rows of a1; all ranges of a step in ONE
+ *                                   call (they share the operand's scale).
+ *   otgan_cost_slices_stack_f32     K[p] = -lambda (1 - x.y) for P <= 6 problems: X = stack rows [xrow[p], +nrows),
+ *                                   Y = the N-row block at stack row yrow[p] -> K [P][nrows][N].
+ *   otgan_matching_two_batch_rows_grad_stack_f32   otgan_matching_two_batch_rows_grad_f32 reading the stack (K_pre required).
+ */
+size_t otgan_matching_stack_bytes(int N, int D);
+int otgan_matching_stack_split_f32(const float* fa, const float* fb, int N, int D, long ldf, int nranges,
+                                   const int* range_begin, const int* range_rows, void* stack, void* stream);
+size_t otgan_cost_slices_stack_workspace_bytes(int P, int nrows, int N, int D);
+int otgan_cost_slices_stack_f32(const void* stack, int N, int D, int P, const long* xrow, const long* yrow, int nrows,
+                                float sinkhorn_lambda, float* K, void* workspace, size_t workspace_bytes, void* stream);
+int otgan_matching_two_batch_rows_grad_stack_f32(const void* stack, int N, int D, float sinkhorn_lambda, int iters,
+                                                 int row_begin, int row_count, const float* K_pre, float* grad_a,
+                                                 float* grad_b, long ldo, float* entropy, double* dist, double* stats,
+                                                 void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Single-batch matching (matching.py:88-136): fa, fb [n, D]; 999 is added to the a-a and
  * b-b cost diagonals.  stats: [3][4] doubles (aa, bb, ab).
  */

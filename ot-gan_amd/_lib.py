@@ -35,6 +35,12 @@ SIGNATURES = {
     "otgan_matching_two_batch_rows_grad_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_long, c_float, c_int, c_int, c_int,
                                                        c_fp, c_fp, c_fp, c_long, c_fp, c_fp, c_fp, c_fp, c_size_t,
                                                        c_fp]),
+    "otgan_matching_stack_bytes": (c_size_t, [c_int, c_int]),
+    "otgan_matching_stack_split_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_long, c_int, c_fp, c_fp, c_fp, c_fp]),
+    "otgan_cost_slices_stack_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "otgan_cost_slices_stack_f32": (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_fp, c_int, c_float, c_fp, c_fp, c_size_t, c_fp]),
+    "otgan_matching_two_batch_rows_grad_stack_f32": (c_int, [c_fp, c_int, c_int, c_float, c_int, c_int, c_int, c_fp, c_fp, c_fp,
+                                                             c_long, c_fp, c_fp, c_fp, c_fp, c_size_t, c_fp]),
     "otgan_matching_single_batch_grad_workspace_bytes": (c_size_t, [c_int, c_int]),
     "otgan_matching_single_batch_grad_f32": (c_int, [c_fp, c_fp, c_int, c_int, c_long, c_float, c_int, c_fp, c_fp, c_long,
                                                      c_fp, c_fp, c_fp, c_fp, c_size_t, c_fp]),

@@ -1809,8 +1809,8 @@ int otgan_matching_two_batch_rows_f32(const float* fa, const float* fb, int N, i
 static int matching_grad_impl(const float* fa, const float* fb, int N, int D, long ldf, float lambda, int iters,
                               int row_begin, int row_count, const float* K_pre, float* grad_a, float* grad_b, long ldo,
                               float* entropy, double* dist, double* stats, void* workspace, size_t workspace_bytes,
-                              void* stream) {
-  OTGAN_CHECK_ARG(fa && fb && grad_a && entropy && dist, "null pointer");
+                              void* stream, const void* stack = nullptr) {
+  OTGAN_CHECK_ARG((stack || (fa && fb)) && grad_a && entropy && dist, "null pointer");
   OTGAN_CHECK_ARG(N > 0 && D > 0 && ldf >= D && ldo >= D && iters >= 0, "bad sizes N=%d D=%d", N, D);
   OTGAN_CHECK_ARG(row_begin >= 0 && row_count > 0 && row_begin + row_count <= 2 * N,
                   "row range [%d, %d) outside [0, %d)", row_begin, row_begin + row_count, 2 * N);
@@ -1830,7 +1830,11 @@ static int matching_grad_impl(const float* fa, const float* fb, int N, int D, lo
   const bool x3 = w.x3 && ldf % 4 == 0 && ldo % 4 == 0 && aligned16(fa) && aligned16(fb) && aligned16(grad_a) &&
                   aligned16(grad_b) && row_begin % 16 == 0;
   const int nstack = grad_b ? 6 : 4;
-  if (x3) {
+  if (stack) {
+    // the caller split the blocks this call reads already (otgan_matching_stack_split_f32): same layout, its own buffer
+    OTGAN_CHECK_ARG(x3 && K_pre, "a feature stack needs the split-precision engine's shapes / alignment and precomputed log-kernels");
+    w.FP = (u16*)((char*)const_cast<void*>(stack) + kX3HdrBytes);
+  } else if (x3) {
     // stacked feature operand [a1 b1 b2 a2 (a1 b1)]: every difference contracts over three ADJACENT blocks
     SplitSrc ss;
     memset(&ss, 0, sizeof(ss));
@@ -1924,6 +1928,84 @@ static int matching_grad_impl(const float* fa, const float* fb, int N, int D, lo
   OTGAN_CHECK_LAUNCH("matching finalize");
   if (stats) hipMemcpyAsync(stats, w.stats, sizeof(double) * 24, hipMemcpyDeviceToDevice, s);
   return OTGAN_OK;
+}
+
+// ---- one split of the features per step for a data-parallel rank (round 5) ------------------------------------------
+// A rank of the global matching scope multiplies the gathered features twice per step -- its three cost row slices
+// (matching.py:29-39) and the plans applied to its own rows (:64-83) -- and until round 5 each library call split the
+// blocks it read into the engine's two-fp16-plane operand itself: 3 328 + 4 096 rows of D floats at N = 1024, 0.76 ms of a
+// 1.44 ms rank call.  The STACK is that operand as an object of the caller: six N-row blocks [a1 b1 b2 a2 a1 b1] (the
+// layout of otgan_matching_two_batch_grad_f32: every difference contracts over three adjacent blocks), of which a rank
+// fills only the row ranges its calls read -- a first-half rank in a generator step rows [N, 4N) = b1 b2 a2 (the Y blocks
+// of its cost slices AND the contraction blocks of g(a1)) plus its own rows of a1 -- once, and hands it to both calls.
+size_t otgan_matching_stack_bytes(int N, int D) {
+  if (N <= 0 || D <= 0 || !x3_shape_ok(N, N, D)) return 0;
+  return kX3HdrBytes + sizeof(u16) * X3_NP * x3_plane_elems(6 * (size_t)N, D);
+}
+int otgan_matching_stack_split_f32(const float* fa, const float* fb, int N, int D, long ldf, int nranges,
+                                   const int* range_begin, const int* range_rows, void* stack, void* stream) {
+  OTGAN_CHECK_ARG(fa && fb && stack && range_begin && range_rows, "null pointer");
+  OTGAN_CHECK_ARG(x3_shape_ok(N, N, D) && ldf >= D && ldf % 4 == 0 && aligned16(fa) && aligned16(fb),
+                  "shape N=%d D=%d not taken by the split-precision engine (otgan_matching_stack_bytes == 0) or unaligned", N, D);
+  OTGAN_CHECK_ARG(nranges > 0 && nranges <= 6, "1 .. 6 row ranges");
+  hipStream_t s = (hipStream_t)stream;
+  const float *fa1 = fa, *fa2 = fa + (long)N * ldf, *fb1 = fb, *fb2 = fb + (long)N * ldf;
+  const float* blocks[6] = {fa1, fb1, fb2, fa2, fa1, fb1};
+  u16* FP = (u16*)((char*)stack + kX3HdrBytes);
+  const long plane = (long)x3_plane_elems(6 * (size_t)N, D);
+  // one job per (range, block it touches): a job's sources share a row count
+  X3SplitJob jobs[12];
+  int nj = 0;
+  for (int i = 0; i < nranges; ++i) {
+    int b = range_begin[i], e = range_begin[i] + range_rows[i];
+    OTGAN_CHECK_ARG(b >= 0 && e <= 6 * N && b < e && b % 32 == 0 && e % 32 == 0, "range %d: [%d, %d) outside the stack or not on 32-row blocks", i, b, e);
+    while (b < e) {
+      const int blk = b / N, stop = (blk + 1) * N < e ? (blk + 1) * N : e;
+      OTGAN_CHECK_ARG(nj < 12, "too many block pieces");
+      X3SplitJob& q = jobs[nj++];
+      memset(&q, 0, sizeof(q));
+      q.ss.n = 1;
+      q.ss.src[0] = blocks[blk] + (long)(b - blk * N) * ldf; q.ss.ld[0] = ldf; q.ss.row0[0] = b; q.ss.scale[0] = 1.f;
+      q.rows = stop - b; q.K = D; q.dst = FP; q.plane_stride = plane;
+      b = stop;
+    }
+  }
+  x3_split_group(jobs, nj, x3_hdr(FP), kX3FeatureExp, s);
+  OTGAN_CHECK_LAUNCH("feature stack split");
+  return OTGAN_OK;
+}
+size_t otgan_cost_slices_stack_workspace_bytes(int P, int nrows, int N, int D) {
+  if (P <= 0 || P > kMaxProb || nrows <= 0 || N <= 0 || D <= 0) return 0;
+  return align_up(sizeof(float) * (size_t)P * nrows * N * x3_plan_cost(P, nrows, N, D).nsplit, 256);
+}
+int otgan_cost_slices_stack_f32(const void* stack, int N, int D, int P, const long* xrow, const long* yrow, int nrows,
+                                float lambda, float* K, void* workspace, size_t workspace_bytes, void* stream) {
+  OTGAN_CHECK_ARG(stack && xrow && yrow && K, "null pointer");
+  OTGAN_CHECK_ARG(P > 0 && P <= kMaxProb && x3_shape_ok(nrows, N, D) && x3_shape_ok(N, N, D), "shape not taken by the split-precision engine");
+  for (int p = 0; p < P; ++p)
+    OTGAN_CHECK_ARG(xrow[p] >= 0 && xrow[p] % 32 == 0 && xrow[p] + nrows <= 6L * N && yrow[p] >= 0 && yrow[p] % N == 0 && yrow[p] < 6L * N,
+                    "problem %d: rows outside the stack", p);
+  const size_t need = otgan_cost_slices_stack_workspace_bytes(P, nrows, N, D);
+  if (!workspace || workspace_bytes < need) {
+    otgan_set_error("workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    return OTGAN_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const u16* FP = (const u16*)((const char*)stack + kX3HdrBytes);
+  const long plane = (long)x3_plane_elems(6 * (size_t)N, D);
+  ProfScope ps(OTGAN_PROF_COST_GEMM, 2.0 * P * nrows * (double)N * D, 4.0 * P * ((double)nrows + N) * D, s);
+  return launch_cost_x3(FP, plane, 6L * N, xrow, yrow, nullptr, P, nrows, N, D, lambda, (float*)workspace, K, s);
+}
+int otgan_matching_two_batch_rows_grad_stack_f32(const void* stack, int N, int D, float lambda, int iters, int row_begin,
+                                                 int row_count, const float* K_pre, float* grad_a, float* grad_b, long ldo,
+                                                 float* entropy, double* dist, double* stats, void* workspace,
+                                                 size_t workspace_bytes, void* stream) {
+  OTGAN_CHECK_ARG(stack, "null stack");
+  OTGAN_CHECK_ARG(!(row_begin == 0 && row_count == 2 * N), "the row-range variant takes a range inside one mini-batch");
+  // (the feature pointers only serve the alignment test of the shared implementation)
+  const float* aligned = reinterpret_cast<const float*>(stack);
+  return matching_grad_impl(aligned, aligned, N, D, D, lambda, iters, row_begin, row_count, K_pre, grad_a, grad_b, ldo, entropy,
+                            dist, stats, workspace, workspace_bytes, stream, stack);
 }
 
 size_t otgan_matching_grad_workspace_bytes(int N, int D) {

@@ -204,6 +204,11 @@ class OTGAN:
                 # second half its rows of (b2,b1) (a2,b1) (a2,b2); the slices are all-gathered.
                 # Every rank then solves the six (small, on-chip) Sinkhorn problems and applies the
                 # plans only to the rows of its own samples.
+                if rank_stack_ok(self.nb, allg):
+                    # round 5: the gathered features are split into the GEMM engine's operand ONCE for both library calls
+                    g_gen, g_dat, ent, dist = rank_matching_stack(self.rank, self.world, self.nb, allg, alld, a.sinkhorn_lambda,
+                                                                  a.nr_sinkhorn_iter, need_dat, self._gather_slices)
+                    return g_gen, g_dat, dist, ent
                 K = self._sharded_log_kernels(f_gen, f_dat, allg, alld)
                 g_gen, g_dat, ent, dist = matching.matched_feature_grads(
                     allg, alld, a.sinkhorn_lambda, a.nr_sinkhorn_iter, need_b=need_dat,
@@ -243,6 +248,10 @@ class OTGAN:
         grad_gen = pick(m[0]) - pick(m[2])
         grad_dat = pick(m[1]) - pick(m[3])
         return grad_gen, grad_dat, dist, m[4]
+
+    def _gather_slices(self, mine):
+        with self._timed("allgather_in_match"):
+            return parallel.all_gather_rows(mine.unsqueeze(0))                          # [W,3,nb,N]
 
     def _sharded_log_kernels(self, f_gen, f_dat, fa, fb):
         mine = rank_log_kernel_slices(self.rank, self.world, f_gen, f_dat, fa, fb, self.args.sinkhorn_lambda)
@@ -545,6 +554,33 @@ def rank_log_kernel_slices(rank, world, f_gen, f_dat, fa, fb, lam):
         return matching.cost_log_kernels([f_gen, f_gen, f_gen], [a2, b1, b2], lam)
     # my rows belong to a2 / b2:  p1 (b2,b1), p4 (a2,b1), p5 (a2,b2)
     return matching.cost_log_kernels([f_dat, f_gen, f_gen], [b1, b1, b2], lam)
+
+
+def rank_stack_ok(nb, allg):
+    """Does the one-split-per-step path (matching.FeatureStack) take a rank with `nb` rows of the gathered [2N, D] features?
+    (The split-precision matching engine's shapes: N >= 256, D % 32 == 0, a rank's row slice at least one 256-row tile.)"""
+    N, D = allg.shape[0] // 2, allg.shape[1]
+    return (os.environ.get("OTGAN_MATCH_STACK", "1") != "0" and nb >= 256 and nb % 32 == 0 and N % nb == 0 and
+            matching.FeatureStack.supported(N, D))
+
+
+def rank_matching_stack(rank, world, nb, allg, alld, lam, iters, need_dat, gather=None):
+    """What rank `rank` of `world` runs per step in the global matching scope, with ONE split of the gathered features
+    (reference utils/matching.py:29-39 row sharding of the cost GEMMs, :64-83 plan application): the feature stack filled
+    where this rank reads it, its three [nb, N] cost row slices from the stack, the slices of all ranks gathered
+    (`gather`: [3, nb, N] -> [world, 3, nb, N]; None = precomputed by the caller as `gather(mine)` is not needed for one
+    rank's timing) and assembled, the six Sinkhorn problems, the plans applied to the rank's rows from the same stack.
+    -> (grad_gen, grad_dat or None, entropy, distance)."""
+    N = allg.shape[0] // 2
+    ranges, own_gen, own_dat = matching.FeatureStack.rank_plan(rank * nb, nb, N, need_dat)
+    st = matching.FeatureStack(allg, alld, ranges)
+    if rank < world // 2:       # p0 (a1,a2), p2 (a1,b1), p3 (a1,b2)
+        mine = st.cost_slices([own_gen] * 3, [3 * N, N, 2 * N], nb, lam)
+    else:                       # p1 (b2,b1), p4 (a2,b1), p5 (a2,b2)
+        mine = st.cost_slices([own_dat, own_gen, own_gen], [N, N, 2 * N], nb, lam)
+    allk = gather(mine) if callable(gather) else gather
+    K = assemble_log_kernels(allk, world)
+    return st.rows_grad(lam, iters, (rank * nb, nb), K, need_b=need_dat)
 
 
 def rank_single_log_kernel_slices(f_gen, f_dat, allg, alld, lam):

@@ -237,6 +237,90 @@ def matched_feature_grads(fa, fb, sinkhorn_lambda, nr_sinkhorn_iter, need_b=True
     return grad_a, grad_b, entropy, dist
 
 
+class FeatureStack:
+    """The gathered features of one step as the matching GEMMs' operand (otgan_matching_stack_split_f32): six N-row blocks
+    [a1 b1 b2 a2 a1 b1] as two scaled fp16 planes, of which a data-parallel rank fills the row ranges its two library calls
+    read -- ONCE per step instead of once per call (round 5: 7 424 -> 3 328 split rows for a rank of eight in a generator
+    step).  `FeatureStack.for_rank(...)` picks the ranges from the rank's position the way trainer._match needs them."""
+
+    def __init__(self, fa, fb, ranges):
+        import ctypes
+        for t in (fa, fb):
+            if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.shape != fa.shape or t.shape[0] % 2:
+                raise ValueError("fa and fb must be float32 [2N, D] CUDA tensors of one shape")
+        fa, fb = fa.detach().contiguous(), fb.detach().contiguous()
+        L = _lib.lib()
+        self.N, self.D = fa.shape[0] // 2, fa.shape[1]
+        nbytes = L.otgan_matching_stack_bytes(self.N, self.D)
+        if not nbytes:
+            raise _lib.OtganError("the split-precision matching engine does not take this shape (N >= 256, D % 32 == 0)")
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=fa.device)
+        self.ranges = [(int(b), int(r)) for b, r in ranges]
+        n = len(self.ranges)
+        rb = (ctypes.c_int * n)(*[b for b, _ in self.ranges])
+        rr = (ctypes.c_int * n)(*[r for _, r in self.ranges])
+        rc = L.otgan_matching_stack_split_f32(fa.data_ptr(), fb.data_ptr(), self.N, self.D, self.D, n,
+                                              ctypes.cast(rb, ctypes.c_void_p), ctypes.cast(rr, ctypes.c_void_p),
+                                              self.buf.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "otgan_matching_stack_split_f32")
+
+    @staticmethod
+    def supported(N, D):
+        return bool(_lib.lib().otgan_matching_stack_bytes(int(N), int(D)))
+
+    @staticmethod
+    def rank_plan(row_begin, row_count, N, need_b):
+        """-> (ranges to split, stack rows of the rank's generated / data samples) for the rank that owns rows
+        [row_begin, +row_count) of the [2N] global batch.  Stack rows: a1 0, b1 N, b2 2N, a2 3N, a1 4N, b1 5N."""
+        half, r0 = divmod(int(row_begin), N)
+        if half == 0:
+            # g(a1) contracts over [N, 4N) = b1 b2 a2 (also the Y blocks of (a1,a2) (a1,b1) (a1,b2)); with the data-side gradient
+            # g(b1) adds [4N, 5N) = a1 -- the rank's own generated rows are then read from that copy
+            ranges = [(N, 4 * N)] if need_b else [(N, 3 * N), (r0, row_count)]
+            own_gen = (4 * N if need_b else 0) + r0
+            own_dat = N + r0
+        else:
+            # g(a2) contracts over [0, 3N) = a1 b1 b2 (b1, b2: the Y blocks of (b2,b1) (a2,b1) (a2,b2)); g(b2) adds [3N, 6N)
+            ranges = [(0, 6 * N)] if need_b else [(0, 3 * N), (3 * N + r0, row_count)]
+            own_gen = 3 * N + r0
+            own_dat = 2 * N + r0
+        return ranges, own_gen, own_dat
+
+    def cost_slices(self, xrows, yrows, nrows, sinkhorn_lambda):
+        """K[p] = -lambda * cosine cost of stack rows [xrows[p], +nrows) against the N-row block at yrows[p] -> [P, nrows, N]."""
+        import ctypes
+        L = _lib.lib()
+        P = len(xrows)
+        K = torch.empty((P, nrows, self.N), dtype=torch.float32, device=self.buf.device)
+        ws = _workspace(max(L.otgan_cost_slices_stack_workspace_bytes(P, nrows, self.N, self.D), 256), self.buf.device)
+        xr = (ctypes.c_long * P)(*[int(v) for v in xrows])
+        yr = (ctypes.c_long * P)(*[int(v) for v in yrows])
+        rc = L.otgan_cost_slices_stack_f32(self.buf.data_ptr(), self.N, self.D, P, ctypes.cast(xr, ctypes.c_void_p),
+                                           ctypes.cast(yr, ctypes.c_void_p), int(nrows), float(sinkhorn_lambda), K.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "otgan_cost_slices_stack_f32")
+        return K
+
+    def rows_grad(self, sinkhorn_lambda, nr_sinkhorn_iter, rows, log_kernels, need_b=True):
+        """matched_feature_grads(..., rows=rows, log_kernels=log_kernels) reading this stack."""
+        L = _lib.lib()
+        N, D, dev = self.N, self.D, self.buf.device
+        log_kernels = log_kernels.contiguous()
+        assert tuple(log_kernels.shape) == (6, N, N) and log_kernels.dtype == torch.float32
+        nrows = int(rows[1])
+        grad_a = torch.empty((nrows, D), dtype=torch.float32, device=dev)
+        grad_b = torch.empty((nrows, D), dtype=torch.float32, device=dev) if need_b else None
+        entropy = torch.empty((), dtype=torch.float32, device=dev)
+        dist = torch.empty((), dtype=torch.float64, device=dev)
+        ws = _workspace(L.otgan_matching_grad_workspace_bytes(N, D), dev)
+        rc = L.otgan_matching_two_batch_rows_grad_stack_f32(self.buf.data_ptr(), N, D, float(sinkhorn_lambda),
+                                                            int(nr_sinkhorn_iter), int(rows[0]), nrows, log_kernels.data_ptr(),
+                                                            grad_a.data_ptr(), _lib.ptr(grad_b), D, entropy.data_ptr(),
+                                                            dist.data_ptr(), None, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "otgan_matching_two_batch_rows_grad_stack_f32")
+        return grad_a, grad_b, entropy, dist
+
+
 def matched_feature_grads_single_batch(fa, fb, sinkhorn_lambda, nr_sinkhorn_iter, need_b=True, rows=None, log_kernels=None):
     """Training-mode --single_batch matching (otgan_matching_single_batch_grad_f32 / _rows_grad_): the injected gradients
     `features_a_a - features_a_b` (train.py:111) and `features_b_b - features_b_a` (train.py:125-126) of

@@ -154,3 +154,52 @@ def test_panel_kernel_falls_back_when_grid_cannot_be_resident(dev, monkeypatch):
     for p in range(P):
         Mref, _, _ = M.sinkhorn_plan(-Kh[p].astype(np.float64) / lam, lam, iters)
         assert _rel(b[p], Mref) < 1e-4
+
+
+@pytest.mark.parametrize("D,iters", [(32768, 100), (7296, 200)], ids=["cfg3_dcgan", "cfg4_densenet"])
+def test_rank_of_8_feature_stack(dev, D, iters):
+    """Round 5: a rank splits the gathered features into the GEMM engine's operand ONCE per step (matching.FeatureStack,
+    otgan_matching_stack_split_f32) and both of its library calls -- cost row slices (matching.py:29-39) and plans applied to
+    its rows (:64-83) -- read that stack.  Every rank's slices from its stack assemble to the log-kernels of the
+    one-split-per-call path, and the injected gradients of ranks 0, 3 (first half), 4, 7 (second half), generator and
+    critic steps, match the fp64 oracle and the older path."""
+    from otgan_amd import trainer
+    from otgan_amd.utils import matching
+    S, B, lam = 16, 128, 500.0
+    nb, N = 2 * B, S * B // 2
+    fa_h, fb_h = _features(11, S, B, D)
+    fa_d, fb_d = torch.as_tensor(fa_h, device=dev), torch.as_tensor(fb_h, device=dev)
+    assert trainer.rank_stack_ok(nb, fa_d)
+    fa, fb = list(torch.chunk(fa_d, S, 0)), list(torch.chunk(fb_d, S, 0))
+    old = torch.stack([trainer.rank_log_kernel_slices(r, WORLD, fa_d[r * nb:(r + 1) * nb], fb_d[r * nb:(r + 1) * nb], fa, fb, lam)
+                       for r in range(WORLD)], 0)
+    mines = []
+    for r in range(WORLD):
+        for need_b in (False, True):        # the stack's ranges (and where the rank's own rows sit) depend on the step kind
+            ranges, own_gen, own_dat = matching.FeatureStack.rank_plan(r * nb, nb, N, need_b)
+            st = matching.FeatureStack(fa_d, fb_d, ranges)
+            if r < WORLD // 2:
+                m = st.cost_slices([own_gen] * 3, [3 * N, N, 2 * N], nb, lam)
+            else:
+                m = st.cost_slices([own_dat, own_gen, own_gen], [N, N, 2 * N], nb, lam)
+            assert (m - old[r]).abs().max() <= 2e-5 * lam, (r, need_b)
+        mines.append(m)
+    allk = torch.stack(mines, 0)
+    K_old = trainer.assemble_log_kernels(old, WORLD)
+    f64 = lambda z: z.astype(np.float64)
+    fa1, fa2, fb1, fb2 = f64(fa_h[:N]), f64(fa_h[N:]), f64(fb_h[:N]), f64(fb_h[N:])
+    plans, costs, ent_ref = M.two_batch_plans(fa1, fa2, fb1, fb2, lam, iters)
+    dref = M.closed_form_from(plans, costs, N)
+    for r in (0, 3, 4, 7):
+        half, r0 = divmod(r * nb, N)
+        aa, bb, ab, ba = M.matched_rows(plans, fa1, fa2, fb1, fb2, half, r0, r0 + nb)
+        for need_b in (False, True):
+            ga, gb, ent, dist = trainer.rank_matching_stack(r, WORLD, nb, fa_d, fb_d, lam, iters, need_b, gather=allk)
+            assert _rel(ga.cpu().numpy(), aa - ab) < REL_DIFF_INJECTED, (r, need_b)
+            assert (gb is None) == (not need_b)
+            if need_b:
+                assert _rel(gb.cpu().numpy(), bb - ba) < REL_DIFF_INJECTED, r
+            assert float(ent) == pytest.approx(float(ent_ref), rel=2e-4)
+            assert abs(float(dist) - dref) <= REL_LOSS * abs(dref) + 1e-7, (r, float(dist), dref)
+            ga0, gb0, _, _ = matching.matched_feature_grads(fa_d, fb_d, lam, iters, need_b=need_b, rows=(r * nb, nb), log_kernels=K_old)
+            assert _rel(ga.cpu().numpy(), ga0.cpu().numpy()) < 1e-5, (r, need_b)
