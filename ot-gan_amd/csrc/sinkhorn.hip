@@ -452,6 +452,8 @@ struct PanelArgs {
   unsigned long long* f;   // [P][N] exchange buffers: (sequence number << 32) | float bits; zeroed before the launch
   unsigned long long* g;   // [P][N]
   unsigned* fail;          // [1] set when a spin gave up
+  int P;                   // problems
+  int xcd_local;           // 1: problem p runs on XCD p (workgroup x -> XCD x % 8, r = x / 8): its exchanges stay in one L2
   float* plan;
   float* planT;
   double* stats;       // zeroed before the launch
@@ -466,9 +468,16 @@ struct PanelArgs {
 // counter poll + data load (measured: N = 1024, 100 sweeps 2.25 ms -> see profiles/README.md).
 // Reuse of the two buffers is safe: a workgroup can publish f of sweep k+1 only after it consumed
 // every g of sweep k, which every workgroup publishes only after consuming every f of sweep k.
-__device__ __forceinline__ void publish_tagged(unsigned long long* p, float v, unsigned seq) {
+// Round 5, XCD-local problems (PanelArgs::xcd_local): an agent-scope store (sc1) writes through AND drops the line from the
+// writer's L2, so every poll -- also one from the same XCD -- is served at the cross-XCD rate (MI355X_MICROARCH.md,
+// "stores of each flavour").  When all workgroups of a problem sit on ONE XCD the word can stay in that XCD's L2: a PLAIN
+// 8-byte store (still single-copy atomic, still written through by the L1) and the same L1-bypassing polls, which then hit
+// the L2.  Only valid while no other XCD reads the word -- the launcher checks the workgroup -> XCD mapping once per process
+// and every workgroup checks its own XCC_ID.
+__device__ __forceinline__ void publish_tagged(unsigned long long* p, float v, unsigned seq, bool local = false) {
   const unsigned long long w = ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(v);
-  __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (local) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(w) : "memory");
+  else __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ float consume_tagged(const unsigned long long* p, unsigned seq, unsigned* fail,
                                                 bool& ok) {
@@ -492,7 +501,7 @@ __device__ __forceinline__ float value_of(const unsigned long long* p) {   // a 
 template <int TPR, int RPW>
 __device__ __forceinline__ void panel_combine(float mx, float s, float* s_pm, float* s_ps, int line,
                                               int q, int gline, int N, unsigned long long* out_global,
-                                              unsigned seq) {
+                                              unsigned seq, bool local) {
   s_pm[q * RPW + line] = mx;
   s_ps[q * RPW + line] = s;
   __syncthreads();
@@ -505,7 +514,7 @@ __device__ __forceinline__ void panel_combine(float mx, float s, float* s_pm, fl
     for (int k = 0; k < TPR; ++k) S += s_ps[k * RPW + line] * exp_neg(s_pm[k * RPW + line] - M);
     int gl = gline;
     asm volatile("" : "+v"(gl));      // (address formed here, not carried around the loop in a register pair)
-    if (gline < N) publish_tagged(out_global + gl, -(M + logf(S)), seq);
+    if (gline < N) publish_tagged(out_global + gl, -(M + logf(S)), seq, local);
   }
 }
 
@@ -522,7 +531,7 @@ __device__ __forceinline__ float exp_native(float x) { return __builtin_amdgcn_e
 // and the RPW results published by consecutive lanes.
 template <int TPR, int RPW>
 __device__ __forceinline__ void panel_combine_lin(float sum, float* s_part, int line, int q, int r, int N,
-                                                  unsigned long long* out_global, unsigned seq) {
+                                                  unsigned long long* out_global, unsigned seq, bool local) {
   constexpr int LD = TPR + 4;
   constexpr int H = RPW >= 64 ? 1 : 64 / RPW;       // threads per line in the publishing stripe
   constexpr int PER = TPR / H;                      // partial sums per thread: 16 (RPW 32), 16 (RPW 64), 8 (RPW 128)
@@ -539,7 +548,7 @@ __device__ __forceinline__ void panel_combine_lin(float sum, float* s_part, int 
     if (H == 2) S += __shfl_xor(S, 32, 64);
     int gl = r * RPW + ln;
     asm volatile("" : "+v"(gl));
-    if (h == 0 && gl < N) publish_tagged(out_global + gl, 1.f / S, seq);
+    if (h == 0 && gl < N) publish_tagged(out_global + gl, 1.f / S, seq, local);
   }
 }
 
@@ -568,7 +577,14 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
   float* s_pm = s_v + 1024;                  // [TPR][RPW]
   float* s_ps = s_pm + TPR * RPW;            // [TPR][RPW]
   unsigned* s_flag = reinterpret_cast<unsigned*>(s_ps + TPR * RPW);   // [4] mode requests in turn, [4] a spin gave up
-  const int p = blockIdx.x / a.R, r = blockIdx.x % a.R;
+  const bool local = a.xcd_local != 0;
+  const int p = local ? (int)(blockIdx.x & 7) : (int)(blockIdx.x / a.R), r = local ? (int)(blockIdx.x >> 3) : (int)(blockIdx.x % a.R);
+  if (p >= a.P) return;                 // (XCD-local grid: 8 R workgroups, XCDs P .. 7 have no problem)
+  if (local && (int)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15) != p) {   // HW_REG_XCC_ID
+    // not where the mapping says: plain stores would not reach the other workgroups of the problem -- fail loudly
+    // (the others' spins are bounded; entropy and distance come out NaN)
+    if (threadIdx.x == 0) __hip_atomic_store(a.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   const int N = a.N;
   const float* K = a.K + (long)p * N * N;
   const int t = threadIdx.x, line = t % RPW, q = t / RPW;
@@ -634,7 +650,7 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
     float sm = 0.f;
 #pragma unroll
     for (int e = 0; e < 32; ++e) sm += exp_neg(xr[e] + s_g[q32 + e] - mx);
-    panel_combine<TPR, RPW>(mx, sm, s_pm, s_ps, line, q, gline, N, f, ++phase);
+    panel_combine<TPR, RPW>(mx, sm, s_pm, s_ps, line, q, gline, N, f, ++phase, local);
   };
   auto moved = [&](float fresh, float old) { return !(fabsf(fresh - old) < lc.settle); };
   auto far = [&](float fresh, float) { return !(fresh > lc.lo && fresh < lc.hi); };
@@ -681,7 +697,7 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
           sm = sm * exp_neg(mx - mn) + sc * exp_neg(m - mn);
           mx = mn;
         }
-        panel_combine<TPR, RPW>(mx, sm, s_pm, s_ps, line, q, gline, N, g, ++phase);
+        panel_combine<TPR, RPW>(mx, sm, s_pm, s_ps, line, q, gline, N, g, ++phase, local);
       }
       const bool mg = consume_all(g, s_g, moved);
       if (!ok) break;
@@ -712,7 +728,7 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
         sm = fmaf(xr[4 * c + 3], vv[3], sm);
       }
       PT_STAMP(1);
-      panel_combine_lin<TPR, RPW>(sm, s_pm, line, q, r, N, f, ++phase);
+      panel_combine_lin<TPR, RPW>(sm, s_pm, line, q, r, N, f, ++phase, local);
       PT_STAMP(2);
       const bool fu = consume_all(f, s_u, far);
       PT_STAMP(3);
@@ -726,7 +742,7 @@ __global__ __launch_bounds__(kPanelThreads) void sinkhorn_panel_kernel(PanelArgs
         sm = fmaf(s_kc[kb + (4 * c + 2) * RPW], uu[2], sm);
         sm = fmaf(s_kc[kb + (4 * c + 3) * RPW], uu[3], sm);
       }
-      panel_combine_lin<TPR, RPW>(sm, s_pm, line, q, r, N, g, ++phase);
+      panel_combine_lin<TPR, RPW>(sm, s_pm, line, q, r, N, g, ++phase, local);
       const bool fv = consume_all(g, s_v, far);
       if (!ok) break;
       if (fu || fv) {
@@ -804,6 +820,30 @@ inline LinCtl lin_ctl() {
   return c;
 }
 
+// Does this device place workgroup x of a one-dimensional grid on XCD x % 8?  (MI355X in SPX mode does; a partitioned
+// device has fewer XCDs.)  Probed once per process with a 64-workgroup launch that records HW_REG_XCC_ID; OTGAN_PANEL_XCD=0
+// keeps the problem-major grid and agent-scope publishes of round 4.
+__global__ void xcc_id_probe_kernel(int* out) {
+  if (threadIdx.x == 0) out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15);
+}
+inline bool xcd_round_robin() {
+  static const bool ok = [] {
+    const char* e = getenv("OTGAN_PANEL_XCD");
+    if (e && e[0] == '0') return false;
+    int* d = nullptr;
+    int h[64];
+    if (hipMalloc((void**)&d, sizeof(h)) != hipSuccess) return false;
+    hipLaunchKernelGGL(xcc_id_probe_kernel, dim3(64), dim3(64), 0, 0, d);
+    const bool copied = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    if (!copied) { (void)hipGetLastError(); return false; }
+    for (int i = 0; i < 64; ++i)
+      if (h[i] != (i & 7)) return false;
+    return true;
+  }();
+  return ok;
+}
+
 // The panel kernel spin-waits across its P*R workgroups, so ALL of them must be resident at once.
 // co_resident_capacity = (workgroups of this kernel one CU can host) x (CUs of the current device),
 // from the occupancy calculator -- on a partitioned / CU-masked device it is smaller than on the
@@ -834,7 +874,13 @@ bool launch_panel(const PanelArgs& a, int P, hipStream_t s) {
   const char* lim = getenv("OTGAN_PANEL_MAX_WG");   // tests: pretend a smaller / partitioned device
   if (lim && atoi(lim) >= 0 && atoi(lim) < cap) cap = atoi(lim);
   if (P * a.R > cap) return false;
-  hipLaunchKernelGGL(sinkhorn_panel_kernel<TPR>, dim3(P * a.R), dim3(kPanelThreads), lds, s, a, lin_ctl());
+  PanelArgs b = a;
+  b.P = P;
+  // one problem per XCD when the device dispatches workgroup x to XCD x % 8 (probed once) and every XCD can host a problem's
+  // R workgroups: the grid is then 8 R workgroups of which those on XCDs P .. 7 return at once
+  b.xcd_local = (P <= 8 && 8 * a.R <= capacity && !(lim && atoi(lim) >= 0) && xcd_round_robin()) ? 1 : 0;
+  const unsigned grid = b.xcd_local ? 8u * (unsigned)a.R : (unsigned)(P * a.R);
+  hipLaunchKernelGGL(sinkhorn_panel_kernel<TPR>, dim3(grid), dim3(kPanelThreads), lds, s, b, lin_ctl());
   return true;
 }
 
