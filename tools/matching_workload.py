@@ -26,12 +26,17 @@ if mode == "rank":
     from otgan_amd import trainer as T
     W = 2 * N // rows
     own = lambda t, r: t[r * rows:(r + 1) * rows]
-    K6 = T.assemble_log_kernels(torch.stack([T.rank_log_kernel_slices(r, W, own(fa_flat, r), own(fb_flat, r), fa_flat, fb_flat, 500.0)
-                                             for r in range(W)], 0), W)
+    allk = torch.stack([T.rank_log_kernel_slices(r, W, own(fa_flat, r), own(fb_flat, r), fa_flat, fb_flat, 500.0)
+                        for r in range(W)], 0)
+    K6 = T.assemble_log_kernels(allk, W)
     torch.cuda.synchronize()
 for _ in range(4):
     if mode == "grad":
         out = matching.matched_feature_grads(fa_flat, fb_flat, 500.0, L, need_b=True, rows=None if rows is None else (0, rows))
+    elif mode == "rank" and T.rank_stack_ok(rows, fa_flat):
+        # round 5: what trainer._match runs -- ONE split of the gathered features (matching.FeatureStack) for the rank's cost
+        # row slices and its plan application; the other ranks' slices are precomputed (allk)
+        out = T.rank_matching_stack(0, W, rows, fa_flat, fb_flat, 500.0, L, True, gather=allk)
     elif mode == "rank":
         T.rank_log_kernel_slices(0, W, own(fa_flat, 0), own(fb_flat, 0), fa_flat, fb_flat, 500.0)
         out = matching.matched_feature_grads(fa_flat, fb_flat, 500.0, L, need_b=True, rows=(0, rows), log_kernels=K6)

@@ -6,6 +6,8 @@ R=$GRAFT_REPO_ROOT
 TAG=${1:-r01}
 MODEL=${2:-dcgan}
 ARGS="--steps 6 --warmup 6 --no_cpu_baseline --no_secondary --model $MODEL"
+# "dcgan64": BASELINE configs[4] shape on one GPU (64x64 images, 512 per GPU = two halves of 256, D = 131072)
+[ "$MODEL" = "dcgan64" ] && ARGS="--steps 6 --warmup 6 --no_cpu_baseline --no_secondary --model dcgan --image_size 64 --batch_per_gpu 512"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_trace -- python $R/bench.py $ARGS > $R/gpurun_out/${TAG}_trace.json 2> $R/gpurun_out/${TAG}_trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/${TAG}_fetch -- python $R/bench.py $ARGS --no_prof > /dev/null 2> $R/gpurun_out/${TAG}_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/${TAG}_write -- python $R/bench.py $ARGS --no_prof > /dev/null 2> $R/gpurun_out/${TAG}_write.err
