@@ -20,6 +20,17 @@ DOUBLED = (1, 2)
 _ws = {}
 
 
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_CTX = _NullCtx()
+
+
 def workspace(nbytes, device):
     """Grow-only scratch buffer per (device, stream) -- the caller-provided workspace of the C ABI.
     Kernels of one stream run in order, so one buffer per stream is race-free; two trainers driving
@@ -216,11 +227,18 @@ def colsum_of(t):
 
 
 def amax_slot(device):
-    """A zeroed amax record (one launch zeroes 256 of them)."""
+    """A zeroed amax record (one launch zeroes 256 of them).  The pool is shared by the streams of a step (trainer.py runs two
+    chains of a step on a second stream): a stream other than the one that zeroed the pool waits for that launch."""
     ent = _amax_pool.get(device)
+    cur = torch.cuda.current_stream(device)
     if ent is None or ent[1] >= _AMAX_SLOTS:
-        ent = [torch.zeros((_AMAX_SLOTS, AMAX_RECORD_FLOATS), dtype=torch.float32, device=device), 0]
+        pool = torch.zeros((_AMAX_SLOTS, AMAX_RECORD_FLOATS), dtype=torch.float32, device=device)
+        ent = [pool, 0, cur.cuda_stream, cur.record_event(), set()]
         _amax_pool[device] = ent
+    elif cur.cuda_stream != ent[2] and cur.cuda_stream not in ent[4]:
+        cur.wait_event(ent[3])
+        ent[0].record_stream(cur)
+        ent[4].add(cur.cuda_stream)
     rec = ent[0][ent[1]]
     ent[1] += 1
     return rec
@@ -304,6 +322,28 @@ def fold_weights(desc, w):
     _lib.check(_lib.lib().otgan_conv2d_fold_weights_f32(ctypes.byref(desc), w.data_ptr(), weff.data_ptr(),
                                                         weffT.data_ptr(), _lib.stream_ptr()), "fold_weights")
     return weff, weffT
+
+
+# ------------------------------------------------------------------------------- second stream for weight gradients
+# A layer's weight-gradient chain (adjoint transform of dy, t-leading GEMM, adjoint filter transform, weight-norm backward) feeds
+# nothing but the optimiser, while its input-gradient chain is what the next layer's backward waits for.  With a side stream set
+# (trainer.py: single-process runs), Conv2dFunction.backward issues the weight-gradient chain there: the two chains alternate
+# HBM-bound transforms and matrix-bound GEMMs, and on one in-order stream every kernel also waits for the previous one's last
+# workgroup -- on two streams each chain's kernels start in the other's tails.  Same kernels, same arguments, same results.
+# The caller joins the side stream before it reads the gradients (ops.join_side_stream).
+SIDE_STREAM = None
+
+
+def join_side_stream(tensors=()):
+    """Make the current stream wait for the side stream's work and tell the allocator that `tensors` (allocated there) are
+    used here from now on."""
+    if SIDE_STREAM is None:
+        return
+    cur = torch.cuda.current_stream()
+    cur.wait_stream(SIDE_STREAM)
+    for t in tensors:
+        if t is not None and t.is_cuda:
+            t.record_stream(cur)
 
 
 # ------------------------------------------------------------------------------- conv2d / dense
@@ -394,6 +434,17 @@ class Conv2dFunction(torch.autograd.Function):
             desc.x_amax = None
         if y_rec is not None:
             tag_amax(y, y_rec)
+        if (SIDE_STREAM is not None and ctx.needs_input_grad[0] and not filt["bwd_done"] and
+                _lib.lib().otgan_conv2d_filter_bytes(ctypes.byref(desc), filt["bwd_which"]) > 0):
+            # the input-gradient pass will want its Winograd-domain filters (a function of the weights alone): made now on the
+            # side stream, under this forward pass, instead of on the backward pass's critical path
+            cur = torch.cuda.current_stream()
+            SIDE_STREAM.wait_stream(cur)                 # (the normalised weights were written on this stream)
+            with torch.cuda.stream(SIDE_STREAM):
+                filt["bwd"], filt["bwd_done"] = prepare_filters(desc, filt["bwd_which"], wd), True
+                filt["bwd_event"] = SIDE_STREAM.record_event()
+            wd.record_stream(SIDE_STREAM)
+            desc.w_amax = w_rec.data_ptr() if w_rec is not None else None      # (prepare_filters cleared it)
         ctx.save_for_backward(x, V2d, g, wd, inv_norm)
         ctx.filt = filt
         ctx.desc, ctx.cmap, ctx.inv = desc, cmap, inv
@@ -418,6 +469,12 @@ class Conv2dFunction(torch.autograd.Function):
             filt = ctx.filt
             if not filt["bwd_done"]:
                 filt["bwd"], filt["bwd_done"] = prepare_filters(desc, filt["bwd_which"], w), True
+            elif filt.get("bwd_event") is not None:
+                # made on the side stream during a forward pass: this stream waits for that launch (once is enough, but the
+                # wait is free when the event has long completed) and the buffer is in use here from now on
+                torch.cuda.current_stream().wait_event(filt["bwd_event"])
+                if filt["bwd"] is not None:
+                    filt["bwd"].record_stream(torch.cuda.current_stream())
             dx_rec = None
             # (a list input keeps a layer off the Winograd passes; the implicit-GEMM epilogue writes every real channel
             # once whatever the channel map, round 4)
@@ -429,16 +486,26 @@ class Conv2dFunction(torch.autograd.Function):
             desc.dx_amax_out = None
             if dx_rec is not None:
                 tag_amax(dx, dx_rec)
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            dw = torch.empty_like(V2d)
-            conv_wgrad_raw(desc, x, ctx.cmap, dy, dw)
-            dV2d, dg = weightnorm_bwd(V2d, g, inv_norm, dw)
-            dV = dV2d.view(ctx.vshape)
-        if ctx.has_b and ctx.needs_input_grad[3]:
-            db = colsum_of(dy)
-            if db is None:
-                rows = dy.numel() // dy.shape[-1]
-                db = colsum(dy.data_ptr(), rows, dy.shape[-1], dy.shape[-1], dy.device)
+        need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        need_b = ctx.has_b and ctx.needs_input_grad[3]
+        side = SIDE_STREAM if (need_w or need_b) else None
+        if side is not None:
+            # fork: everything dy depends on is enqueued on the current stream
+            side.wait_stream(torch.cuda.current_stream())
+            for t in (dy, x, ctx.x_op, dy_rec, ctx.x_rec):
+                if t is not None:
+                    t.record_stream(side)        # (dy and the kept operand are freed when this node is: not before the side stream is done)
+        with (torch.cuda.stream(side) if side is not None else _NULL_CTX):
+            if need_w:
+                dw = torch.empty_like(V2d)
+                conv_wgrad_raw(desc, x, ctx.cmap, dy, dw)
+                dV2d, dg = weightnorm_bwd(V2d, g, inv_norm, dw)
+                dV = dV2d.view(ctx.vshape)
+            if need_b:
+                db = colsum_of(dy)
+                if db is None:
+                    rows = dy.numel() // dy.shape[-1]
+                    db = colsum(dy.data_ptr(), rows, dy.shape[-1], dy.shape[-1], dy.device)
         return dx, dV, dg, db, None, None, None, None, None
 
 

@@ -144,12 +144,26 @@ class OTGAN:
         self.last = {}
         self.timers = None        # name -> [(start event, end event)]; see enable_timers()
         self._d_weights_in_graph = False
+        # Two chains of every step are independent of its critical path and run on a SECOND STREAM (round 5; single-process
+        # runs; OTGAN_SIDE_STREAM=0 = everything on one stream): the critic's pass over the real batch of a generator step
+        # (under the generator's forward pass) and every layer's weight-gradient chain (under the input-gradient chain of the
+        # layers in front of it).  Same kernels, same arguments, bit-identical results (tests/test_side_stream_gpu.py); the
+        # chains alternate HBM-bound transforms and matrix-bound GEMMs and, on one in-order stream, every kernel also waits
+        # for its predecessor's last workgroup: A/B/A/B on one box 8.95 / 8.96 -> 8.48 / 8.50 ms per DCGAN step, DenseNet
+        # 28.8 -> 27.7 ms (profiles/r05_side_stream_ab.txt).  Off with more than one rank (the gradient-bucket hooks read
+        # the gradients on the main stream) and under step graphs.
+        on = (os.environ.get("OTGAN_SIDE_STREAM", "1") != "0" and not self.collectives and self.world == 1)
+        self.fork_real_pass = on and os.environ.get("OTGAN_FORK_REAL", "1") != "0"
+        self.fork_wgrad = on and os.environ.get("OTGAN_FORK_WGRAD", "1") != "0"
+        self._side_stream = torch.cuda.Stream(device=device) if on else None
         # whole steps as hipGraphs (opt-in: --step_graph / OTGAN_STEP_GRAPH=1; measured SLOWER than stream launches on this
         # stack, see GraphedSteps): single-process runs only (gloo cannot be captured; RCCL under capture is untested here)
         want = bool(getattr(args, "step_graph", False)) or os.environ.get("OTGAN_STEP_GRAPH", "0") == "1"
         if os.environ.get("OTGAN_STEP_GRAPH") == "0":
             want = False
         self.graphs = GraphedSteps(self) if (want and not self.collectives and self.world == 1) else None
+        if self.graphs is not None:          # (a capture records ONE stream's launches)
+            self.fork_real_pass = self.fork_wgrad = False
 
     # ---------------------------------------------------------------- per-region step times (bench.py, ranks > 1)
     def enable_timers(self, on=True):
@@ -283,7 +297,12 @@ class OTGAN:
             if done is not None:
                 self.last = done
                 return self.last
-        dist, ent, grads = self._step_body(x_data, kind, noise, apply_updates)
+        from . import ops
+        ops.SIDE_STREAM = self._side_stream if self.fork_wgrad else None
+        try:
+            dist, ent, grads = self._step_body(x_data, kind, noise, apply_updates)
+        finally:
+            ops.SIDE_STREAM = None
         if kind == "disc":
             self._d_weights_in_graph = False      # the critic changed: graphs that read its cached operands wait for a refresh
         self.step_counter += 1
@@ -291,6 +310,22 @@ class OTGAN:
         if not apply_updates:
             self.last["grads"] = grads
         return self.last
+
+    def _optimise(self, opt, grads, lr, critic):
+        """The optimiser step (and the generator's EMA).  (Round 5 also tried it on a third stream, so that the next step's
+        critic pass over a resident real batch starts under this HBM-bound launch: 8.46 / 8.53 ms without against 8.59 / 8.57 ms
+        with -- dropped.)"""
+        opt(grads, lr=lr)
+        if not critic and not self.ema_fused:
+            self.maintain_averages()
+
+    def _backward(self, outputs, params, grad_outputs):
+        """torch.autograd.grad with the layers' weight-gradient chains on the side stream (ops.SIDE_STREAM) when enabled."""
+        from . import ops
+        grads = torch.autograd.grad(outputs, params, grad_outputs)
+        if self.fork_wgrad:
+            ops.join_side_stream(grads)
+        return grads
 
     def prepare_step_graphs(self, x_data):
         """Run training steps on `x_data` until every step kind is captured (one eager period, then each kind the first time
@@ -322,22 +357,36 @@ class OTGAN:
                 g_gen, g_dat, dist, ent = self._match(f_gen.detach(), f_dat.detach())
             if self.disc_buckets is not None:
                 self.disc_buckets.arm()
-            grads = torch.autograd.grad(f_all, self.disc_params, torch.cat([g_dat, g_gen], 0))   # train.py:127-128
+            grads = self._backward(f_all, self.disc_params, torch.cat([g_dat, g_gen], 0))        # train.py:127-128
             with self._timed("allreduce"):
                 grads = (self.disc_buckets.finish() if self.disc_buckets is not None
                          else parallel.allreduce_sum_(list(grads)))                               # train.py:134-139
             if apply_updates:
-                self.disc_optimizer(grads, lr=-a.learning_rate_disc)                              # train.py:143
+                self._optimise(self.disc_optimizer, grads, -a.learning_rate_disc, critic=True)    # train.py:143
         else:
-            with torch.no_grad():
-                f_dat = self.discriminator(x_data, **self.model_opts)
-            # the real-data features are final here: start their all-gather now, it overlaps the
-            # generator forward and the second critic pass
-            with self._timed("allgather_early"):
-                pending = (parallel.all_gather_rows_async(f_dat)
-                           if (self.scope == "global" and self.world > 1) or (self.collectives and self.world == 1)
-                           else None)
-            x_gen = self.generator(batch_size=self.nb, device=self.device, **gkw)
+            side = self._side_stream if (self.fork_real_pass and noise is None) else None
+            if side is not None:
+                # the critic's pass over the real batch has no dependence on the generator: it runs on the second stream under
+                # the generator's forward pass, so that each chain's kernels start in the other's tails and under-filled GEMM
+                # grids (the 4x4 / 8x8 stages launch half a round of tiles) share the device
+                main = torch.cuda.current_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side), torch.no_grad():
+                    f_dat = self.discriminator(x_data, **self.model_opts)
+                f_dat.record_stream(main)
+                pending = None
+                x_gen = self.generator(batch_size=self.nb, device=self.device, **gkw)
+                main.wait_stream(side)
+            else:
+                with torch.no_grad():
+                    f_dat = self.discriminator(x_data, **self.model_opts)
+                # the real-data features are final here: start their all-gather now, it overlaps the
+                # generator forward and the second critic pass
+                with self._timed("allgather_early"):
+                    pending = (parallel.all_gather_rows_async(f_dat)
+                               if (self.scope == "global" and self.world > 1) or (self.collectives and self.world == 1)
+                               else None)
+                x_gen = self.generator(batch_size=self.nb, device=self.device, **gkw)
             # only the generator's variables are differentiated in this step (train.py:112): run the critic with
             # its variables frozen, so that its layers skip their weight gradients (autograd's needs_input_grad
             # follows requires_grad, not the `inputs` list of autograd.grad) and only propagate d/dx
@@ -347,14 +396,12 @@ class OTGAN:
                 g_gen, _g_dat, dist, ent = self._match(f_gen.detach(), f_dat, pending, need_dat=False)
             if self.gen_buckets is not None:
                 self.gen_buckets.arm()
-            grads = torch.autograd.grad(f_gen, self.gen_params, g_gen)                            # train.py:112
+            grads = self._backward(f_gen, self.gen_params, g_gen)                                 # train.py:112
             with self._timed("allreduce"):
                 grads = (self.gen_buckets.finish() if self.gen_buckets is not None
                          else parallel.allreduce_sum_(list(grads)))
             if apply_updates:
-                self.gen_optimizer(grads, lr=a.learning_rate_gen)                                 # train.py:142
-                if not self.ema_fused:
-                    self.maintain_averages()                                                      # train.py:223
+                self._optimise(self.gen_optimizer, grads, a.learning_rate_gen, critic=False)      # train.py:142, 223
         return dist, ent, grads
 
     @torch.no_grad()

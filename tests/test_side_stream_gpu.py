@@ -1,0 +1,40 @@
+"""GPU: the second stream of a single-process step (trainer.OTGAN: the critic's pass over the real batch under the generator's
+forward pass, every layer's weight-gradient chain under the input-gradient chain in front of it, the input-gradient filters
+prepared under the forward pass) changes WHEN kernels run, not what they compute: a run with OTGAN_SIDE_STREAM=0 (everything
+on one stream) and the default run end with bit-identical parameters, EMA shadows, optimiser moments and losses
+(reference train.py:207-226 is one `sess.run` per step either way)."""
+import pytest
+import torch
+
+from test_step_graph_gpu import _run, _same
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("model,ngd,kw", [("dcgan", 2, {}), ("densenet", 1, {}), ("dcgan", 1, {"train_disc_against_ema": True}),
+                                          ("dcgan", 2, {"single_batch": True})],
+                         ids=["dcgan", "densenet", "dcgan_ema_critic", "dcgan_single_batch"])
+def test_two_streams_equal_one_stream(dev, model, ngd, kw, monkeypatch):
+    steps = 3 * (ngd + 1) + 1
+    monkeypatch.setenv("OTGAN_SIDE_STREAM", "0")
+    one = _run(dev, model, False, steps, ngd, **kw)
+    monkeypatch.delenv("OTGAN_SIDE_STREAM")
+    two = _run(dev, model, False, steps, ngd, **kw)
+    _same(one, two)
+
+
+def test_side_stream_is_on_by_default_and_off_with_more_ranks(dev, monkeypatch):
+    from otgan_amd.trainer import OTGAN, default_args
+    monkeypatch.delenv("OTGAN_SIDE_STREAM", raising=False)
+    m = OTGAN(default_args(batch_size=2, nr_gpu=2, nr_sinkhorn_iter=5), dev)
+    assert m.fork_real_pass and m.fork_wgrad and m._side_stream is not None
+    m.close()
+    m = OTGAN(default_args(batch_size=2, nr_gpu=2, nr_sinkhorn_iter=5, step_graph=True), dev)
+    assert not m.fork_real_pass and not m.fork_wgrad          # a capture records one stream
+    m.close()

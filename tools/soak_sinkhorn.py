@@ -25,7 +25,7 @@ def run(a):
     _lib.lib()
     _lib.sinkhorn_counters(True)          # before any capture: the counters' address travels in the kernels' arguments
     args = default_args(model=a.model, batch_size=a.batch // 2, nr_gpu=2, sinkhorn_lambda=500.0, nr_sinkhorn_iter=a.iters,
-                        nr_gen_per_disc=5, seed=1, step_graph=not a.eager)
+                        nr_gen_per_disc=5, seed=1, step_graph=a.graph)
     m = OTGAN(args, dev)
     g = torch.Generator(device=dev).manual_seed(3)
     # a small fixed "data set" of smooth images (so that the critic has something to separate) cycled in batches
@@ -52,7 +52,7 @@ def run(a):
     P = max(tot["problems"], 1)
     out = {"steps": a.steps, "batch": a.batch, "iters": a.iters, "model": a.model,
            "regime": {k: v for k, v in os.environ.items() if k.startswith("OTGAN_SINKHORN")},
-           "step_graph": not a.eager, "non_finite_steps": nan, "totals": tot,
+           "step_graph": bool(a.graph), "side_stream": os.environ.get("OTGAN_SIDE_STREAM", "1") != "0" and not a.graph, "non_finite_steps": nan, "totals": tot,
            "sweeps_per_problem": (tot["log_sweeps"] + tot["linear_sweeps"]) / P,
            "log_sweeps_per_problem": tot["log_sweeps"] / P,
            "fold_backs_per_1000_problems": 1000.0 * tot["fold_backs"] / P,
@@ -87,7 +87,7 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--model", default="dcgan")
-    ap.add_argument("--eager", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the steps as hipGraphs (trainer.GraphedSteps; disables the side stream)")
     ap.add_argument("--out", default="gpurun_out/soak.json")
     ap.add_argument("--compare", nargs=2)
     a = ap.parse_args()
