@@ -1168,6 +1168,19 @@ def _backward_by_slice(ctx, buf, saved, G, dbuf, need_w):
     R0 = amax_slot(buf.device)
     ctx.dx0_rec = R0
     gptr, bptr = G.data_ptr(), buf.data_ptr()
+    # weight-gradient work on the side stream (SIDE_STREAM, see Conv2dFunction.backward): every weight gradient of the block
+    # reads slices of G that are FINAL when it is issued and writes its own tensors, so it can run under the input-gradient
+    # kernels that follow on this stream (they add into OTHER channels of G)
+    side = SIDE_STREAM if need_w else None
+    if side is not None:
+        for t in [G, buf, RR, R0] + [t for t in ctx.x_ops if t is not None] + ([ctx.fwd_recs[0]] if ctx.fwd_recs is not None else []):
+            t.record_stream(side)
+
+    def wgrad_stream():
+        if side is None:
+            return _NULL_CTX
+        side.wait_stream(torch.cuda.current_stream())      # (what the weight gradient reads is enqueued on this stream)
+        return torch.cuda.stream(side)
 
     def wide_bwd(i, need_dx):
         wd, ops_ = wides[i], sw["wide"][i]
@@ -1176,8 +1189,9 @@ def _backward_by_slice(ctx, buf, saved, G, dbuf, need_w):
         desc.x_amax, desc.x_amax_count = ctx.x_recs[i][0].data_ptr(), ctx.x_recs[i][1]
         desc.dy_amax, desc.dy_amax_count = RR[wd["d0"]].data_ptr(), L + 1 - wd["d0"]
         if need_w:
-            dw = torch.empty_like(ops_["w"])
-            conv_wgrad_raw(desc, src, None, G, dw)
+            with wgrad_stream():
+                dw = torch.empty_like(ops_["w"])
+                conv_wgrad_raw(desc, src, None, G, dw)
             dw_wide[i] = dw
         if need_dx:
             if not ops_["bwd_done"]:
@@ -1208,7 +1222,8 @@ def _backward_by_slice(ctx, buf, saved, G, dbuf, need_w):
                 desc = ctx.descs[c]
                 cmap, _inv = ctx.maps[c]
                 off = C0 + plan["g0"][c] * F
-                dw_g[c] = torch.empty_like(sw["w_g"][c])
+                with wgrad_stream():
+                    dw_g[c] = torch.empty_like(sw["w_g"][c])
                 if ctx.fwd_recs is not None:
                     # records of the slices the layer read (the rows its forward kernel read) and of its output gradient (the
                     # slices' rows from c on and the incoming bound): the kernel runs on the fp16 matrix pipe (round 4)
@@ -1216,7 +1231,8 @@ def _backward_by_slice(ctx, buf, saved, G, dbuf, need_w):
                     desc.x_amax = R[gbase[gidx[plan["g0"][c]]]].data_ptr()
                     desc.x_amax_count = 1 + plan["own_len"][c]
                     desc.dy_amax, desc.dy_amax_count = RR[c].data_ptr(), L + 1 - c
-                conv_wgrad_raw(desc, buf[..., off:], cmap, G, dw_g[c])
+                with wgrad_stream():
+                    conv_wgrad_raw(desc, buf[..., off:], cmap, G, dw_g[c])
                 desc.x_amax = desc.dy_amax = None
                 desc.x_amax_count = desc.dy_amax_count = 0
     wide_bwd(0, ctx.needs_input_grad[0])
@@ -1232,12 +1248,13 @@ def _backward_by_slice(ctx, buf, saved, G, dbuf, need_w):
             if dw_g[k] is not None:
                 pk.append((dw_g[k].data_ptr(), None, dw_g[k].shape[0] // 9, F))
             parts.append(pk)
-        dVs, dgs = weightnorm_bwd_block(saved[0::4], saved[1::4], saved[3::4], parts)
-        for k in range(L):
-            grads[3 * k:3 * k + 2] = [dVs[k].view(ctx.vshapes[k]), dgs[k]]
-        db_all = colsum(G.data_ptr() + 4 * C0, rows, L * F, Ctot, G.device)
-        for k in range(L):
-            grads[3 * k + 2] = db_all[k * F:(k + 1) * F]
+        with wgrad_stream():
+            dVs, dgs = weightnorm_bwd_block(saved[0::4], saved[1::4], saved[3::4], parts)
+            for k in range(L):
+                grads[3 * k:3 * k + 2] = [dVs[k].view(ctx.vshapes[k]), dgs[k]]
+            db_all = colsum(G.data_ptr() + 4 * C0, rows, L * F, Ctot, G.device)
+            for k in range(L):
+                grads[3 * k + 2] = db_all[k * F:(k + 1) * F]
     return grads
 
 
