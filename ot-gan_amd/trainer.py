@@ -131,9 +131,16 @@ class OTGAN:
         if args.optimizer not in mk:
             raise ValueError("unsupported optimizer")
         kw = {"mom1": 0.5} if args.optimizer == "nesterov" else {"mom1": 0.5, "mom2": 0.999}
-        # more than one rank: the gradient all-reduce runs bucket by bucket underneath the backward pass
+        # The second stream (see below): single-process runs, and ranks whose collectives are SERIAL (the default): there
+        # the gradient buckets buy no overlap (every bucket leaves after the backward pass anyway), so the gradients are
+        # all-reduced through one flat buffer after the side stream has been joined.  With overlapped collectives
+        # (OTGAN_OVERLAP_COLLECTIVES=1) the bucket hooks read every gradient on the main stream as soon as autograd has it
+        # and the real features' all-gather runs under the generator: one stream, as before.
+        side_ok = (os.environ.get("OTGAN_SIDE_STREAM", "1") != "0" and
+                   (not self.collectives or parallel.collectives_mode() == "serial"))
+        # more than one rank, overlapped schedule: the gradient all-reduce runs bucket by bucket underneath the backward pass
         # (OTGAN_GRAD_OVERLAP=0: one all-reduce after the backward pass instead)
-        overlap = self.collectives and os.environ.get("OTGAN_GRAD_OVERLAP", "1") != "0"
+        overlap = self.collectives and os.environ.get("OTGAN_GRAD_OVERLAP", "1") != "0" and not side_ok
         self.disc_buckets = parallel.GradBuckets(self.disc_params) if overlap else None
         self.gen_buckets = parallel.GradBuckets(self.gen_params) if overlap else None
         self.gen_optimizer = mk[args.optimizer](self.gen_params, **kw)          # train.py:142
@@ -150,9 +157,8 @@ class OTGAN:
         # layers in front of it).  Same kernels, same arguments, bit-identical results (tests/test_side_stream_gpu.py); the
         # chains alternate HBM-bound transforms and matrix-bound GEMMs and, on one in-order stream, every kernel also waits
         # for its predecessor's last workgroup: A/B/A/B on one box 8.95 / 8.96 -> 8.48 / 8.50 ms per DCGAN step, DenseNet
-        # 28.8 -> 27.7 ms (profiles/r05_side_stream_ab.txt).  Off with more than one rank (the gradient-bucket hooks read
-        # the gradients on the main stream) and under step graphs.
-        on = (os.environ.get("OTGAN_SIDE_STREAM", "1") != "0" and not self.collectives and self.world == 1)
+        # 29.2 -> 27.4 ms (profiles/r05_side_stream_ab.txt).  Off with overlapped collectives and under step graphs.
+        on = side_ok
         self.fork_real_pass = on and os.environ.get("OTGAN_FORK_REAL", "1") != "0"
         self.fork_wgrad = on and os.environ.get("OTGAN_FORK_WGRAD", "1") != "0"
         self._side_stream = torch.cuda.Stream(device=device) if on else None
@@ -364,7 +370,7 @@ class OTGAN:
             if apply_updates:
                 self._optimise(self.disc_optimizer, grads, -a.learning_rate_disc, critic=True)    # train.py:143
         else:
-            side = self._side_stream if (self.fork_real_pass and noise is None) else None
+            side = self._side_stream if self.fork_real_pass else None
             if side is not None:
                 # the critic's pass over the real batch has no dependence on the generator: it runs on the second stream under
                 # the generator's forward pass, so that each chain's kernels start in the other's tails and under-filled GEMM

@@ -48,7 +48,10 @@ def run(force):
     args = default_args(model="dcgan", batch_size=4, nr_gpu=2, sinkhorn_lambda=100.0, nr_sinkhorn_iter=10,
                         nr_gen_per_disc=1, seed=5)
     m = OTGAN(args, dev)
-    assert m.collectives == force and (m.gen_buckets is not None) == force
+    # (round 5: with serial collectives -- the default -- a rank runs the two-stream schedule and all-reduces one flat buffer
+    # after the backward pass; the gradient buckets exist in the overlapped schedule)
+    assert m.collectives == force and (m.gen_buckets is not None) == (force and not m.fork_wgrad)
+    assert m.fork_wgrad == (parallel.collectives_mode() == "serial" or not force)
     g = torch.Generator().manual_seed(3)
     xd = (torch.rand(m.nb, 32, 32, 3, generator=g) * 2 - 1).to(dev)
     u = (torch.rand(m.nb, 100, generator=g) * 2 - 1).to(dev)
