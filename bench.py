@@ -30,10 +30,12 @@ _CONV_NOTE = ("fp32 tensors and fp32 accumulation everywhere; the Winograd-domai
               "split on dot products (fp32 accumulation itself: 3e-7; a plain fp32 MFMA chain: 1.3e-6), layer parity vs fp64 at "
               "2e-5; OTGAN_WINO_PIECES=3 = three bf16 pieces (24 bits, six MFMAs; `secondary.three_bf16_pieces_24bit`), "
               "OTGAN_WINO_FP32=1 = the same transforms on the fp32 MFMA engine.  ")
-_MATCH_NOTE = ("Matching GEMMs (cost, plan application): Sinkhorn rows N < 256 (this configuration at one GPU: N = 128) on the "
-               "EXACT-fp32 MFMA engine (v_mfma_f32_32x32x2_f32); N >= 256 (64x64 configuration, every multi-GPU problem) on "
-               "two scaled fp16 pieces / three MFMAs like the convolutions (OTGAN_MATCH_FP32=1 keeps them on the fp32 "
-               "engine); injected gradients 3.7e-6 ... 6.0e-6 rel. L2 vs fp64 at lambda = 500 either way "
+_MATCH_NOTE = ("Matching GEMMs (cost, plan application) on two scaled fp16 pieces / three MFMAs per product like the convolutions "
+               "at every size since round 5: Sinkhorn rows N <= 128 (this configuration at one GPU) in cost128_h2_kernel / "
+               "plan_apply128_h2_kernel, which split the fp32 operands while staging them (a-priori scale 2^13: unit-length "
+               "feature rows, plan entries <= 1); N >= 256 (64x64 configuration, every multi-GPU problem) on the pre-split "
+               "operand engine.  OTGAN_MATCH_FP32=1 keeps them on the exact-fp32 MFMA engine (v_mfma_f32_32x32x2_f32); "
+               "injected gradients 3.7e-6 ... 6.0e-6 rel. L2 vs fp64 at lambda = 500 either way "
                "(tests/test_matching_engine_accuracy_gpu.py)")
 PRECISION_NOTE = {
     "dcgan": _CONV_NOTE + _MATCH_NOTE,
@@ -220,13 +222,16 @@ def secondary(dev, a):
                     "note": "6 timed steps = 1 critic + 5 generator steps (the 5:1 mix), unprofiled wall clock"}
         if not a.no_prof:
             # the same six steps once more with per-launch HIP events: the configuration's own roofline object
+            # (one stream in this pass, as in the headline's roofline pass: every launch has the device to itself)
             from otgan_amd import _lib
+            m.fork_real_pass = m.fork_wgrad = False
             _lib.prof_reset()
             _lib.prof_enable(True)
             per_prof = _time_steps(m, xs, 0, k)
             prof = _lib.prof_collect()
             _lib.prof_enable(False)
             sec[tag]["roofline"] = roofline_of(prof, kw["model"], per_prof * 1e3, k, False, "dcgan64" if size == 64 else None)
+            sec[tag]["roofline"]["pass"] += "; ONE stream in this pass (each launch has the device to itself)"
             sec[tag]["launches_per_step"] = round(sum(v["launches"] for c, v in prof.items() if not c.startswith("wino_gemm")) / k, 1)
         m.close()
         del m, xs
@@ -344,19 +349,31 @@ def main():
             rank_times = [mine]
     # ---- pass 2 (feeds `roofline` / `kernel_classes` only): the same K steps with every library launch
     # bracketed by HIP events on its launch stream (otgan_prof_*).  Never mixed into `value`.
-    prof, dt_prof = None, None
+    # Two sub-passes since the step runs on two streams (round 5): (2a) the schedule of the headline pass -- the GEMM's
+    # launches overlap HBM-bound transform kernels of the other stream, so their event-bracketed durations are those of a
+    # kernel SHARING the device (reported as `roofline.two_stream`); (2b) the same K steps with the second stream off: every
+    # launch has the device to itself, which is what a kernel-vs-pipe roofline means (`roofline.achieved` / `frac`).
+    prof, dt_prof, prof_ovl, dt_ovl = None, None, None, None
     if not a.no_prof:
-        _lib.prof_reset()
-        _lib.prof_enable(True)
-        model.step_counter = 0
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(a.steps):
-            model.step(x)
-        torch.cuda.synchronize()
-        dt_prof = time.perf_counter() - t1
-        prof = _lib.prof_collect()
-        _lib.prof_enable(False)
+        def _prof_pass():
+            _lib.prof_reset()
+            _lib.prof_enable(True)
+            model.step_counter = 0
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                model.step(x)
+            torch.cuda.synchronize()
+            d = time.perf_counter() - t1
+            p = _lib.prof_collect()
+            _lib.prof_enable(False)
+            return p, d
+        forks = (model.fork_real_pass, model.fork_wgrad)
+        if any(forks):
+            prof_ovl, dt_ovl = _prof_pass()
+            model.fork_real_pass = model.fork_wgrad = False
+        prof, dt_prof = _prof_pass()
+        model.fork_real_pass, model.fork_wgrad = forks
     parallel.barrier()
 
     if rank != 0:
@@ -407,6 +424,16 @@ def main():
     if prof:
         out["roofline"] = roofline_of(prof, a.model, dt_prof / a.steps * 1e3, a.steps, default_cfg,
                                       "dcgan64" if (a.model == "dcgan" and a.image_size == 64) else None)
+        if prof_ovl:
+            ro = roofline_of(prof_ovl, a.model, dt_ovl / a.steps * 1e3, a.steps, default_cfg, None)
+            out["roofline"]["pass"] += ("; ONE stream in this pass (OTGAN_SIDE_STREAM=0 schedule): each launch has the device to "
+                                        "itself -- the kernel against its pipe")
+            out["roofline"]["two_stream"] = {
+                "achieved": ro["achieved"], "frac": ro["frac"], "avg_ms": ro["avg_ms"], "launches": ro["launches"],
+                "ms_per_step": round(dt_ovl / a.steps * 1e3, 3),
+                "note": "the same kernel's launches bracketed by events in the DEFAULT two-stream schedule of the headline pass: "
+                        "they share the device with the HBM-bound transform kernels of the other stream, so each launch takes "
+                        "longer while the step gets shorter; not a kernel-vs-pipe figure"}
         out["kernel_classes"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                      "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flop"] > 0 else None}
                                  for k, v in prof.items() if v["launches"]}

@@ -79,6 +79,157 @@ __global__ __launch_bounds__(256) void cost_partial_kernel(CostArgs a) {
   }
 }
 
+// The same Gram blocks on the fp16 matrix pipe (round 5; cosine cost, the N <= 128 problems of a single-GPU step --
+// VERDICT r4 item 6).  The fp32 instruction above spends 64 matrix cycles per 32 x 32 x 2 products; here every float4 is
+// split ONCE while it is staged, x * 2^13 = hi + lo (two fp16 pieces, 22 significand bits: the arithmetic of the N >= 256
+// matching GEMMs and of the convolutions, 5.6e-6 against 5.9e-6 for the fp32 chain on the injected gradients,
+// tests/test_matching_engine_accuracy_gpu.py), and a 16-wide k slab of a 32 x 32 tile costs three v_mfma_f32_32x32x16_f16
+// = 96 cycles instead of 512.  The kernel is then bound by how many feature bytes a compute unit keeps in flight, not by
+// the matrix pipe: registers hold the float4s of TWO k steps ahead of the one in LDS (gemm_mainloop_x2h keeps one).
+// The scale is a priori (cosine features are rows of unit length: |x| <= 1; anything below 8 is representable, beyond it
+// the pieces overflow to infinity and the result is NaN -- loud; OTGAN_MATCH_FP32=1 keeps the exact-fp32 kernel).
+// Requires 16-byte aligned rows and D % 4 == 0 (launch_cost checks).
+constexpr float kCostH2Scale = 8192.f;              // 2^13
+struct CostH2Loader {
+  const float* base;   // row 0, k0
+  long ld;
+  int rlast, kdim, klast;
+  // rows: valid rows (rows past them re-read the last one: they only feed accumulators that are never stored);
+  // kdim: k (relative to k0) from which the split contributes zeros; kmax: the row's remaining floats (a multiple of 4)
+  __device__ __forceinline__ void init(const float* b, long ld_, int rows, int kdim_, int kmax) {
+    base = b; ld = ld_; rlast = rows - 1; kdim = kdim_; klast = kmax - 4;
+  }
+  __device__ __forceinline__ void load(int kt, float4 (&reg)[2]) const {
+    const int c = threadIdx.x & 3, r0 = threadIdx.x >> 2;
+    const int k = kt * 16 + 4 * c;
+    const int kc = k < klast ? k : klast;     // branch-free: a clamped address, then a select
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      int r = r0 + 64 * p;
+      r = r < rlast ? r : rlast;
+      reg[p] = *reinterpret_cast<const float4*>(base + (long)r * ld + kc);
+    }
+  }
+  // (the select lives here, not in load(): anything that touches the loaded value waits for it)
+  __device__ __forceinline__ void store2(unsigned char* t, int kt, const float4 (&reg)[2]) const {
+    const int c = threadIdx.x & 3, r0 = threadIdx.x >> 2;
+    const float sc = (kt * 16 + 4 * c < kdim) ? kCostH2Scale : 0.f;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      float4 v = reg[p];
+      v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+      x2h_store4(t, 128 * kX3sRowBytes, r0 + 64 * p, 4 * c, v);
+    }
+  }
+};
+
+template <bool FUSE>
+__global__ __launch_bounds__(256) void cost128_h2_kernel(CostArgs a) {
+  using L = X2hLds<SCfg>;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[L::BYTES];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + 2 * L::TA;
+  // workgroup x runs on XCD x % 8 (round-robin placement): the P problems of one K split take adjacent slots of ONE XCD, so
+  // the feature blocks they share (every block is an operand of three of the six problems) meet in that XCD's L2
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int split = (slot / a.P) * 8 + xcd, p = slot % a.P;
+  const int nkt_total = (a.D + 15) / 16;
+  const int kt0 = split * a.kt_per_split;
+  int nkt = nkt_total - kt0;
+  if (nkt <= 0) return;
+  if (nkt > a.kt_per_split) nkt = a.kt_per_split;
+  const int k0 = kt0 * 16;
+  CostH2Loader la, lb;
+  {
+    const int kmax = a.D - k0, kd = nkt * 16 < kmax ? nkt * 16 : kmax;
+    la.init(a.X[p] + k0, a.ldf, a.n, kd, kmax);
+    lb.init(a.Y[p] + k0, a.ldf, a.m, kd, kmax);
+  }
+  typename SCfg::acc_t acc[2][2];
+  zero_acc<SCfg>(acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    a_off[t] = x3s_off((wm * 2 + t) * 32 + li, 8 * lh);
+    b_off[t] = x3s_off((wn * 2 + t) * 32 + li, 8 * lh);
+  }
+  float4 ra0[2], ra1[2], rb0[2], rb1[2];   // two register sets: k steps kt + 1 and kt + 2 in flight while step kt is multiplied
+  auto mma = [&](int cur) {
+    const unsigned char* pa = sA + cur * L::TA;
+    const unsigned char* pb = sB + cur * L::TB;
+    gt_f16x8 fa[2][2], fb[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        fa[q][t] = *reinterpret_cast<const gt_f16x8*>(pa + q * L::PA + a_off[t]);
+        fb[q][t] = *reinterpret_cast<const gt_f16x8*>(pb + q * L::PB + b_off[t]);
+      }
+#pragma unroll
+    for (int term = 0; term < 3; ++term) {   // lo*hi, hi*lo, hi*hi (smallest first)
+      constexpr int pa_of[3] = {1, 0, 0}, pb_of[3] = {0, 1, 0};
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[pa_of[term]][mt], fb[pb_of[term]][nt], acc[mt][nt], 0, 0, 0);
+    }
+  };
+  // No conditionals in the loop (loads past the split's range are clamped and selected to zero, stores past it write a
+  // buffer nobody reads): an odd step count runs one all-zero step more.
+  la.load(0, ra0); lb.load(0, rb0);
+  la.load(1, ra1); lb.load(1, rb1);
+  la.store2(sA, 0, ra0);
+  lb.store2(sB, 0, rb0);
+  __syncthreads();
+  // hipcc hoists the conversion of a register set (pure arithmetic: no chain to a scheduling barrier) to the top of the
+  // trip, where it waits for loads issued a moment ago; an empty asm that "rewrites" the set pins its first use
+#define COST_H2_PIN(R)                                                                                        \
+  asm volatile("" : "+v"(R[0].x), "+v"(R[0].y), "+v"(R[0].z), "+v"(R[0].w), "+v"(R[1].x), "+v"(R[1].y), "+v"(R[1].z), "+v"(R[1].w))
+  for (int kt = 0; kt < nkt; kt += 2) {
+    la.load(kt + 2, ra0); lb.load(kt + 2, rb0);
+    __builtin_amdgcn_sched_barrier(0);        // (the loads stay in front of the matrix work: hipcc sinks them behind it otherwise)
+    mma(0);
+    __builtin_amdgcn_sched_barrier(0);
+    COST_H2_PIN(ra1); COST_H2_PIN(rb1);
+    la.store2(sA + L::TA, kt + 1, ra1);
+    lb.store2(sB + L::TB, kt + 1, rb1);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);        // (nor does the other set's conversion move up here: it would wait for its loads)
+    la.load(kt + 3, ra1); lb.load(kt + 3, rb1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1);
+    __builtin_amdgcn_sched_barrier(0);
+    COST_H2_PIN(ra0); COST_H2_PIN(rb0);
+    la.store2(sA, kt + 2, ra0);
+    lb.store2(sB, kt + 2, rb0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef COST_H2_PIN
+  const int n = a.n, m = a.m;
+  constexpr float inv = 1.f / (kCostH2Scale * kCostH2Scale);
+  if (FUSE) {
+    float* out = a.K + (long)p * n * m;
+    const float lam = a.lambda, dg = a.diag[p];
+    foreach_acc<SCfg>(acc, [&](int r, int c, int, int, int, float v) {
+      if (r < n && c < m) {
+        float cst = 1.f - v * inv;
+        if (r == c) cst += dg;
+        out[(long)r * m + c] = -lam * cst;
+      }
+    });
+  } else {
+    float* out = a.ws + ((long)split * a.P + p) * n * m;
+    foreach_acc<SCfg>(acc, [&](int r, int c, int, int, int, float v) {
+      if (r < n && c < m) out[(long)r * m + c] = v * inv;
+    });
+  }
+}
+
 struct FinishArgs {
   const float* ws;
   int nsplit, P, n, m;
@@ -1037,6 +1188,165 @@ __global__ __launch_bounds__(256) void plan_apply_kernel(ApplyArgs a) {
   });
 }
 
+// The plan application of the one-tile problems (N <= 128) on the fp16 matrix pipe (round 5), next to cost128_h2_kernel:
+// out[128 x 128 d] = sum_t coef_t * plan_t[128 x kdim] . feat_t[kdim x 128 d], both operands split while they are staged
+// (plan entries are at most 1 -- rows and columns sum to 1 or less -- and features are rows of unit length: scale 2^13 for both).
+// The plan rows are k-contiguous (the cost kernel's LDS planes); the features are d-contiguous, so their tile goes to LDS
+// as it is read -- eight blocks of [16 k][16 d] fp16 (32 bytes a row, the two 16-byte halves swapped on k rows 8..15, 32
+// bytes of padding per block so that a 16-lane write group hits 32 distinct banks) -- and the MFMA fragments (eight
+// consecutive k of one column per lane) come out of ds_read_b64_tr_b16, as in the t-leading mode of gemm_x3.h.
+// The accumulator rescaling of plan_apply_kernel ("(-1/2)(M2 F1 + M3 F2) + M0 F0") is folded into the plan operand's
+// scale per term (powers of two: exact).  Workgroup x -> XCD x % 8: the blocks of one d tile (they read the same
+// feature columns) take adjacent slots of one XCD.
+struct ApplyH2Term {
+  const float* plan;
+  const float* feat;
+  float coef;      // pscale * (product of the rescale factors applied after this term) : the plan operand's scale
+};
+struct ApplyH2Block {
+  float* out;
+  float out_scale;   // alpha / (pscale * kCostH2Scale)
+  ApplyH2Term t[3];
+};
+struct ApplyH2Args {
+  ApplyH2Block b[4];
+  int nblk, rows, kdim, nterms, D, tiles_d;
+  long ldp, ldf, ldo;
+};
+constexpr int kApplyCbStride = 544;                       // bytes per [16 k][16 d] block (512 + padding)
+constexpr int kApplyPB = 8 * kApplyCbStride;              // one feature plane of a stage
+constexpr int kApplyPA = 128 * kX3sRowBytes;              // one plan plane of a stage
+
+__global__ __launch_bounds__(256) void plan_apply128_h2_kernel(ApplyH2Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * kApplyPA + 2 * 2 * kApplyPB];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + 4 * kApplyPA;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int dtile = (slot / a.nblk) * 8 + xcd, z = slot % a.nblk;
+  if (dtile >= a.tiles_d) return;
+  const int d0 = dtile * 128;
+  const ApplyH2Block& blk = a.b[z];
+  const int spt = a.kdim >> 4, nst = a.nterms * spt;     // k steps per term, in all
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // ---- loaders.  Plan: thread -> (row r0 / r0 + 64, float4 c of the 16 k); features: thread -> (k row kk / kk + 8, float4 d4)
+  const int pc = tid & 3, pr0 = tid >> 2;
+  const int fd4 = tid & 31, fk0 = tid >> 5;
+  const int rlast = a.rows - 1;
+  int dcol = d0 + 4 * fd4;
+  const bool dok = dcol < a.D;
+  if (!dok) dcol = a.D - 4;
+  const long prow0 = (long)(pr0 < rlast ? pr0 : rlast) * a.ldp, prow1 = (long)(pr0 + 64 < rlast ? pr0 + 64 : rlast) * a.ldp;
+  auto load = [&](int st, float4 (&rp)[2], float4 (&rf)[2]) {
+    int s2 = st < nst ? st : nst - 1;                    // (steps past the end re-read the last one; stored with scale 0)
+    const int term = s2 / spt, kt = s2 - term * spt;
+    const float* pp = blk.t[term].plan + kt * 16 + 4 * pc;
+    const float* fp = blk.t[term].feat + (long)(kt * 16 + fk0) * a.ldf + dcol;
+    rp[0] = *reinterpret_cast<const float4*>(pp + prow0);
+    rp[1] = *reinterpret_cast<const float4*>(pp + prow1);
+    rf[0] = *reinterpret_cast<const float4*>(fp);
+    rf[1] = *reinterpret_cast<const float4*>(fp + 8 * a.ldf);
+  };
+  const int fgrp = fd4 & 3, fcb = fd4 >> 2;
+  auto store = [&](int st, int buf, const float4 (&rp)[2], const float4 (&rf)[2]) {
+    const bool live = st < nst;
+    const int term = live ? st / spt : 0;
+    const float ps = live ? blk.t[term].coef : 0.f;
+    const float fs = (live && dok) ? kCostH2Scale : 0.f;
+    unsigned char* ta = sA + buf * 2 * kApplyPA;
+    unsigned char* tb = sB + buf * 2 * kApplyPB;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      float4 v = rp[p];
+      v.x *= ps; v.y *= ps; v.z *= ps; v.w *= ps;
+      x2h_store4(ta, kApplyPA, pr0 + 64 * p, 4 * pc, v);
+      float4 w = rf[p];
+      w.x *= fs; w.y *= fs; w.z *= fs; w.w *= fs;
+      const int kk = fk0 + 8 * p;
+      unsigned char* d = tb + fcb * kApplyCbStride + kk * 32 + (((fgrp >> 1) ^ p) << 4) + ((fgrp & 1) << 3);   // (kk >> 3 == p)
+      gt_f32x2 x = {w.x, w.y}, y = {w.z, w.w};
+      const gt_f16x2 hx = __builtin_convertvector(x, gt_f16x2), hy = __builtin_convertvector(y, gt_f16x2);
+      x -= __builtin_convertvector(hx, gt_f32x2);
+      y -= __builtin_convertvector(hy, gt_f32x2);
+      const gt_f16x2 lx = __builtin_convertvector(x, gt_f16x2), ly = __builtin_convertvector(y, gt_f16x2);
+      *reinterpret_cast<gt_u32x2*>(d) = gt_u32x2{__builtin_bit_cast(unsigned, hx), __builtin_bit_cast(unsigned, hy)};
+      *reinterpret_cast<gt_u32x2*>(d + kApplyPB) = gt_u32x2{__builtin_bit_cast(unsigned, lx), __builtin_bit_cast(unsigned, ly)};
+    }
+  };
+  // ---- fragments
+  const int li = lane & 31, lh = lane >> 5;
+  const int g4 = lane >> 4, l16 = lane & 15;
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    a_off[t] = x3s_off((wm * 2 + t) * 32 + li, 8 * lh);
+    b_off[t] = ((wn * 2 + t) * 2 + (g4 & 1)) * kApplyCbStride + (8 * (g4 >> 1) + (l16 >> 2)) * 32 +
+               ((((l16 >> 1) & 1) ^ (g4 >> 1)) << 4) + ((l16 & 1) << 3);
+  }
+  typename SCfg::acc_t acc[2][2];
+  zero_acc<SCfg>(acc);
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  auto mma = [&](int buf) {
+    const unsigned char* pa = sA + buf * 2 * kApplyPA;
+    const unsigned char* pb = sB + buf * 2 * kApplyPB;
+    gt_f16x8 fa[2][2], fb[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        fa[q][t] = *reinterpret_cast<const gt_f16x8*>(pa + q * kApplyPA + a_off[t]);
+        const unsigned char* p = pb + q * kApplyPB + b_off[t];
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 128));
+        fb[q][t] = __builtin_bit_cast(gt_f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+    for (int term = 0; term < 3; ++term) {   // lo*hi, hi*lo, hi*hi (smallest first)
+      constexpr int pa_of[3] = {1, 0, 0}, pb_of[3] = {0, 1, 0};
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[pa_of[term]][mt], fb[pb_of[term]][nt], acc[mt][nt], 0, 0, 0);
+    }
+  };
+  // ---- the cost kernel's loop: two register sets, k steps st + 1 and st + 2 in flight while step st is multiplied
+  float4 p0[2], p1[2], f0[2], f1[2];
+#define APPLY_H2_PIN(R)                                                                                       \
+  asm volatile("" : "+v"(R[0].x), "+v"(R[0].y), "+v"(R[0].z), "+v"(R[0].w), "+v"(R[1].x), "+v"(R[1].y), "+v"(R[1].z), "+v"(R[1].w))
+  load(0, p0, f0);
+  load(1, p1, f1);
+  store(0, 0, p0, f0);
+  __syncthreads();
+  for (int st = 0; st < nst; st += 2) {
+    load(st + 2, p0, f0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0);
+    __builtin_amdgcn_sched_barrier(0);
+    APPLY_H2_PIN(p1); APPLY_H2_PIN(f1);
+    store(st + 1, 1, p1, f1);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    load(st + 3, p1, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1);
+    __builtin_amdgcn_sched_barrier(0);
+    APPLY_H2_PIN(p0); APPLY_H2_PIN(f0);
+    store(st + 2, 0, p0, f0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef APPLY_H2_PIN
+  float* out = blk.out;
+  const int rows = a.rows, D = a.D;
+  const long ldo = a.ldo;
+  const float os = blk.out_scale;
+  foreach_acc<SCfg>(acc, [&](int r, int c, int, int, int, float v) {
+    const int col = d0 + c;
+    if (r < rows && col < D) out[(long)r * ldo + col] = os * v;
+  });
+}
+
 // ======================================================================================
 // 4. distance (matching.py:139-153) with fp64 accumulation
 // ======================================================================================
@@ -1384,7 +1694,11 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 struct CostPlan {
   int tiles, nsplit, kt_per_split;
 };
-inline CostPlan plan_cost(int P, int n, int m, int D) {
+// the one-tile cosine problems (N <= 128) on two fp16 pieces: cost128_h2_kernel
+inline bool cost_h2_ok(int n, int m, int D, long ldf, int cost_kind, bool vec) {
+  return match_x3_enabled() && cost_kind == OTGAN_COST_COSINE && vec && n <= 128 && m <= 128 && D % 4 == 0 && ldf % 4 == 0;
+}
+inline CostPlan plan_cost(int P, int n, int m, int D, bool h2 = false) {
   CostPlan c;
   c.tiles = ceil_div(n, 128) * ceil_div(m, 128);
   const int nkt = ceil_div(D, SCfg::BK);
@@ -1392,7 +1706,9 @@ inline CostPlan plan_cost(int P, int n, int m, int D) {
   // log-kernel itself (no partial sums in memory at all).  Small problems (N = 128: 6 tiles) need the
   // parallelism: ~3 workgroups per CU (768; 512 = 2 per CU measured 92 vs 67 us at
   // N = 128, D = 32768: the engine hides its staging latency with co-resident workgroups), reduced by cost_finish_kernel.
-  constexpr int target = 768;
+  // cost128_h2_kernel (h2): 384 -- 1.5 workgroups per CU, two k steps in flight each: 35.8 us at N = 128, D = 32768 against
+  // 45 / 35 / 52 at 512 / 768 / 1024 (profiles/r05_cost128_ab.txt); fewer splits = fewer partial sums for cost_finish4_kernel
+  const int target = h2 ? 384 : 768;
   int want = c.tiles * P >= 256 ? 1 : ceil_div(target, c.tiles * P);
   if (want < 1) want = 1;
   if (want > nkt) want = nkt;
@@ -1415,7 +1731,6 @@ struct Carver {
 int launch_cost(const float* const* X, const float* const* Y, const float* const* xsq,
                 const float* const* ysq, const float* diag, int P, int n, int m, int D, long ldf,
                 float lambda, int cost_kind, float* partial_ws, float* K, hipStream_t s) {
-  const CostPlan cp = plan_cost(P, n, m, D);
   CostArgs ca;
   memset(&ca, 0, sizeof(ca));
   bool vec = (ldf % 4 == 0);
@@ -1424,6 +1739,8 @@ int launch_cost(const float* const* X, const float* const* Y, const float* const
     ca.Y[p] = Y[p];
     vec = vec && aligned16(X[p]) && aligned16(Y[p]);
   }
+  // (the workspace queries size the partial sums with the fp32 kernel's split count, which is never smaller)
+  const CostPlan cp = plan_cost(P, n, m, D, cost_h2_ok(n, m, D, ldf, cost_kind, vec));
   ca.P = P; ca.n = n; ca.m = m; ca.D = D; ca.ldf = ldf;
   ca.kt_per_split = cp.kt_per_split;
   ca.ws = partial_ws;
@@ -1438,7 +1755,11 @@ int launch_cost(const float* const* X, const float* const* Y, const float* const
   {
     ProfScope ps(OTGAN_PROF_COST_GEMM, 2.0 * P * n * (double)m * D,
                  4.0 * P * ((double)n + m) * D, s);
-    if (fuse) {
+    if (cost_h2_ok(n, m, D, ldf, cost_kind, vec)) {
+      const dim3 g2(8 * ceil_div(cp.nsplit, 8) * P);
+      if (fuse) hipLaunchKernelGGL(cost128_h2_kernel<true>, g2, dim3(256), 0, s, ca);
+      else hipLaunchKernelGGL(cost128_h2_kernel<false>, g2, dim3(256), 0, s, ca);
+    } else if (fuse) {
       if (vec) hipLaunchKernelGGL((cost_partial_kernel<true, true>), grid, dim3(256), 0, s, ca);
       else hipLaunchKernelGGL((cost_partial_kernel<false, true>), grid, dim3(256), 0, s, ca);
     } else {
@@ -1506,8 +1827,9 @@ int launch_sinkhorn(const float* K, int P, int n, int m, int iters, float lambda
   return OTGAN_OK;
 }
 
+// bounded_plans: the plan operands are Sinkhorn plans (entries <= 1: what plan_apply128_h2_kernel's scale assumes)
 int launch_apply(const ApplyBlock* blocks, int nblocks, int max_rows, int D, long ldf, long ldo,
-                 hipStream_t s) {
+                 hipStream_t s, bool bounded_plans = true) {
   ApplyArgs aa;
   memset(&aa, 0, sizeof(aa));
   bool vec = (ldf % 4 == 0);
@@ -1519,6 +1841,46 @@ int launch_apply(const ApplyBlock* blocks, int nblocks, int max_rows, int D, lon
             (blocks[b].t[t].ldp % 4 == 0);
       flops += 2.0 * blocks[b].rows * (double)blocks[b].t[t].kdim * D;
     }
+  }
+  // one-tile problems on the fp16 matrix pipe: every block max_rows <= 128 rows, one contraction length (a multiple of 16)
+  // and one plan stride for all terms
+  bool h2 = bounded_plans && match_x3_enabled() && vec && max_rows <= 128 && D % 4 == 0 && D >= 4 && nblocks > 0;
+  const int kdim = blocks[0].t[0].kdim;
+  const long ldp = blocks[0].t[0].ldp;
+  for (int b = 0; b < nblocks && h2; ++b) {
+    h2 = blocks[b].rows == max_rows && blocks[b].nterms >= 1 && blocks[b].nterms <= 3;
+    for (int t = 0; t < blocks[b].nterms && h2; ++t) h2 = blocks[b].t[t].kdim == kdim && blocks[b].t[t].ldp == ldp;
+  }
+  if (h2 && kdim % 16 == 0 && kdim >= 16) {
+    const float pscale = kCostH2Scale;                    // (a plan's rows and columns sum to 1 or less: entries <= 1)
+    ProfScope ps(OTGAN_PROF_PLAN_APPLY, flops, 0.0, s);
+    for (int nt = 1; nt <= 3; ++nt) {
+      ApplyH2Args ha;
+      memset(&ha, 0, sizeof(ha));
+      ha.rows = max_rows; ha.kdim = kdim; ha.nterms = nt; ha.D = D; ha.tiles_d = ceil_div(D, 128);
+      ha.ldp = ldp; ha.ldf = ldf; ha.ldo = ldo;
+      auto flush = [&]() {
+        if (!ha.nblk) return;
+        hipLaunchKernelGGL(plan_apply128_h2_kernel, dim3(8 * ceil_div(ha.tiles_d, 8) * ha.nblk), dim3(256), 0, s, ha);
+        ha.nblk = 0;
+      };
+      for (int b = 0; b < nblocks; ++b) {
+        if (blocks[b].nterms != nt) continue;
+        ApplyH2Block& hb = ha.b[ha.nblk++];
+        hb.out = blocks[b].out;
+        hb.out_scale = blocks[b].alpha / (pscale * kCostH2Scale);
+        float c = 1.f;                                    // product of the rescale factors applied after term t
+        for (int t = nt - 1; t >= 0; --t) {
+          hb.t[t] = ApplyH2Term{blocks[b].t[t].plan, blocks[b].t[t].feat, pscale * c};
+          const float rs = blocks[b].rescale[t];
+          if (rs != 0.f && rs != 1.f) c *= rs;
+        }
+        if (ha.nblk == 4) flush();
+      }
+      flush();
+    }
+    OTGAN_CHECK_LAUNCH("plan_apply128_h2_kernel");
+    return OTGAN_OK;
   }
   aa.D = D; aa.ldf = ldf; aa.ldo = ldo;
   aa.tiles_d = ceil_div(D, 128);
@@ -2364,7 +2726,7 @@ int otgan_plan_apply_f32(const float* plan, long ldp, int rows, int kdim, const 
   memset(&blk, 0, sizeof(blk));
   blk.out = out; blk.rows = rows; blk.nterms = 1; blk.alpha = alpha;
   blk.t[0] = ApplyTerm{plan, feat, ldp, kdim};
-  return launch_apply(&blk, 1, rows, D, ldf, ldo, (hipStream_t)stream);
+  return launch_apply(&blk, 1, rows, D, ldf, ldo, (hipStream_t)stream, /*bounded_plans=*/false);   // (any matrix: the exact-fp32 kernel)
 }
 
 int otgan_calc_distance_f32(const float* a, const float* b, const float* aa, const float* bb,

@@ -1,12 +1,13 @@
 """GPU: what the matching GEMM engines cost on the TRAINING SIGNAL.
 
 The step injects `f_aa - f_ab` and `f_bb - f_ba` as upstream gradients (reference train.py:111,125-126): differences of
-matched features, lambda-amplified through the log-kernel (lambda = 500).  From N = 256 rows on the cost and plan-application
-GEMMs run on two scaled fp16 pieces per operand (22 significand bits, three MFMAs per product); `OTGAN_MATCH_FP32=1` keeps
-them on the exact-fp32 MFMA engine (the yardstick: `v_mfma_f32_32x32x2_f32`, what the N = 128 headline problem always uses).
+matched features, lambda-amplified through the log-kernel (lambda = 500).  The cost and plan-application GEMMs run on two
+scaled fp16 pieces per operand at every size (N >= 256 since round 4; the one-tile problems N <= 128 since round 5:
+cost128_h2_kernel / plan_apply128_h2_kernel) (22 significand bits, three MFMAs per product); `OTGAN_MATCH_FP32=1` keeps
+them on the exact-fp32 MFMA engine (the yardstick: `v_mfma_f32_32x32x2_f32`, what the N = 128 headline problem ran on until round 5).
 One process per engine (the library reads the switch once), every case against the fp64 oracle:
 
-    N = 128  / D = 32768  / 100 sweeps   configs[1] (one engine only: the exact-fp32 one)
+    N = 128  / D = 32768  / 100 sweeps   configs[1]
     N = 256  / D = 7296   / 200 sweeps   configs[3] width
     N = 256  / D = 131072 / 100 sweeps   configs[4]
     N = 1024 / D = 32768 and D = 7296 (200 sweeps): the rows of ranks 0 and 5 of eight, configs[2] / configs[3]
