@@ -1633,6 +1633,10 @@ int launch_cost_x3(const u16* FP, long plane, long rows_total, const long* xrow,
     b.epi = 1; b.epi_scale = lambda; b.epi_bias = -lambda;
   }
   x3_ensure_lds<wino_bgemm_x3_kernel<true, false>>();
+  // (Round 5: the tiles of one K split on one XCD -- a one-dimensional grid, workgroup x -> XCD x % 8 -- were measured on a
+  // rank's 12 tiles: each workgroup ran 30 % faster, but 12 tiles x a multiple of 8 splits fill 24 of an XCD's 32 compute
+  // units: 153 - 158 us on 192 workgroups against 158 - 160 us on 252 in the linear order, N = 512 6 % slower;
+  // profiles/r05_cost_xcd_ab.txt.  Not kept.)
   const dim3 grid(b.tiles_m * b.tiles_n, cp.nsplit, P);
   hipLaunchKernelGGL((wino_bgemm_x3_kernel<true, false>), grid, dim3(X3_THREADS), X3_LDS, s, b);
   OTGAN_CHECK_LAUNCH("cost GEMM (split precision)");
