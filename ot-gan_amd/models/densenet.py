@@ -22,12 +22,14 @@ def disc_spec(x, init=False, layers_per_block=16, filters_per_layer=16, nonlinea
               **kwargs):
     with nn.arg_scope([nn.conv2d, nn.dense, nn.dense_block], counters={}, init=init, weight_norm=True,
                       ema=ema):
-        x = nn.conv2d(x, 2 * filters_per_layer, pre_activation=None)
+        # (grow: the dense block that follows appends its L * F outputs behind this layer's, in the same buffer)
+        room = layers_per_block * filters_per_layer
+        x = nn.conv2d(x, 2 * filters_per_layer, pre_activation=None, grow=room)
         for _stage in range(3):
             feats = nn.dense_block(x, layers_per_block, filters_per_layer, pre_activation=nonlinearity)
             width = sum(int(t.shape[-1]) for t in feats)
             # transition: stride-2 conv over the whole concatenation, halving the channels (:18-21)
-            x = nn.conv2d(feats, width // 2, pre_activation=nonlinearity, stride=[2, 2])
+            x = nn.conv2d(feats, width // 2, pre_activation=nonlinearity, stride=[2, 2], grow=room if _stage < 2 else 0)
         return nn.feature_head(x)
 
 
@@ -50,7 +52,7 @@ def gen_spec(batch_size, init=False, layers_per_block=16, filters_per_layer=16, 
         for scale in (2, 3):
             # upsample: concatenate, nearest-neighbour x2 (folded into the conv), halve channels (:67-73)
             width = sum(int(t.shape[-1]) for t in feats)
-            x = nn.conv2d(feats, width // 2, pre_activation=nonlinearity, upsample=True)
+            x = nn.conv2d(feats, width // 2, pre_activation=nonlinearity, upsample=True, grow=F + layers_per_block * F)
             feats = nn.dense_block([x, noise[scale]], layers_per_block, F, pre_activation=nonlinearity)
         return nn.tanh(nn.conv2d(feats, 3, pre_activation=nonlinearity, init_scale=0.1))
 

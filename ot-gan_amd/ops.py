@@ -354,7 +354,7 @@ class Conv2dFunction(torch.autograd.Function):
     V: [KH,KW,Cin_eff,Cout]; g, b: [Cout]."""
 
     @staticmethod
-    def forward(ctx, x, V, g, b, stride, upsample, preact, segs, glu_hint=False):
+    def forward(ctx, x, V, g, b, stride, upsample, preact, segs, glu_hint=False, grow=0):
         _need_cuda(x, V, g, b)
         x = x.contiguous()
         N, H, W, C = x.shape
@@ -366,8 +366,16 @@ class Conv2dFunction(torch.autograd.Function):
                              f"{C * (2 if preact in DOUBLED else 1)}")
         V2d = V.contiguous().view(KH * KW * Cin_eff, Cout)
         OH, OW = out_hw(H, W, upsample, stride)
-        y = torch.empty((N, OH, OW, Cout), dtype=x.dtype, device=x.device)
-        desc = make_desc(x, C, upsample, KH, KW, stride, Cout, Cout, 0, preact,
+        grow = int(grow) if (grow and Cout % 4 == 0 and not glu_hint) else 0
+        if grow:
+            # the caller appends `grow` channels next (a dense block, nn.dense_block): the output is the channel prefix of a
+            # buffer with room for them (ldy of the conv ABI) -- the block grows there in place instead of copying its input
+            full = torch.empty((N, OH, OW, Cout + grow), dtype=x.dtype, device=x.device)
+            full._otgan_grow = True
+            y = full[..., :Cout]
+        else:
+            y = torch.empty((N, OH, OW, Cout), dtype=x.dtype, device=x.device)
+        desc = make_desc(x, C, upsample, KH, KW, stride, Cout, Cout + grow, 0, preact,
                          segs if (segs and not upsample) else None)
         # with upsample the reference concatenates the list BEFORE the pre-activation
         # (nn.py:235-237), so the doubled ordering is [x_all, -x_all], not per element
@@ -455,14 +463,33 @@ class Conv2dFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, V2d, g, w, inv_norm = ctx.saved_tensors
-        dy = dy.contiguous()
+        desc = ctx.desc
+        # dy may be the channel prefix of a dense block's gradient buffer (DenseBlockFunction.backward hands it on without a
+        # copy): read in place through the ABI's channel stride.  Anything else is made contiguous.
+        ld_fwd = desc.ldy
+        ld = channel_prefix_stride(dy)
+        if ld is None:
+            rec = amax_of(dy)
+            dy = dy.contiguous()
+            ld = dy.shape[-1]
+            if rec is not None:
+                tag_amax(dy, rec)
+        desc.ldy = ld
+        try:
+            return Conv2dFunction._backward_impl(ctx, dy, ld, x, V2d, g, w, inv_norm)
+        finally:
+            desc.ldy = ld_fwd
+
+    @staticmethod
+    def _backward_impl(ctx, dy, ld, x, V2d, g, w, inv_norm):
         desc = ctx.desc
         dx = dV = dg = db = None
         dy_rec = None
         if ctx.x_rec is not None and dy.shape[-1] % 4 == 0:
             dy_rec = amax_of(dy)              # left by dy's producer, else reduced here; shared by dgrad and wgrad
             if dy_rec is None:
-                dy_rec = absmax_record(dy)
+                dy_rec = (absmax_record(dy) if dy.is_contiguous() else
+                          absmax_record_strided(dy.data_ptr(), dy.numel() // dy.shape[-1], dy.shape[-1], ld, dy.device))
             desc.dy_amax = dy_rec.data_ptr()
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -505,15 +532,43 @@ class Conv2dFunction(torch.autograd.Function):
                 db = colsum_of(dy)
                 if db is None:
                     rows = dy.numel() // dy.shape[-1]
-                    db = colsum(dy.data_ptr(), rows, dy.shape[-1], dy.shape[-1], dy.device)
-        return dx, dV, dg, db, None, None, None, None, None
+                    db = colsum(dy.data_ptr(), rows, dy.shape[-1], ld, dy.device)
+        return dx, dV, dg, db, None, None, None, None, None, None
 
 
-def conv2d_op(x, V, g, b, stride=1, upsample=False, preact=0, segs=None, glu_hint=False):
+def conv2d_op(x, V, g, b, stride=1, upsample=False, preact=0, segs=None, glu_hint=False, grow=0):
     """glu_hint: the caller feeds the result to glu() next -- where the library can, the layer's output kernel also
-    writes the gated product and glu() takes it from there (same values; the hint changes nothing else)."""
+    writes the gated product and glu() takes it from there (same values; the hint changes nothing else).
+    grow: the caller appends that many channels next (nn.dense_block): the result is the channel prefix of a buffer with
+    room for them, same values."""
     return Conv2dFunction.apply(x, V, g, b, int(stride), bool(upsample), int(preact),
-                                tuple(segs) if segs else None, bool(glu_hint))
+                                tuple(segs) if segs else None, bool(glu_hint), int(grow))
+
+
+def channel_prefix_stride(t):
+    """ld when `t` [N,H,W,C] is a channel slice of a contiguous [N,H,W,ld] buffer that the kernels can read in place
+    (16-byte aligned, ld % 4 == 0), else None (also for contiguous tensors: nothing to do)."""
+    if t.dim() != 4 or t.is_contiguous():
+        return None
+    N, H, W, C = t.shape
+    ld = t.stride(2)
+    if (t.stride(3) != 1 or ld < C or ld % 4 or C % 4 or t.stride(1) != W * ld or t.stride(0) != H * W * ld
+            or t.data_ptr() % 16):
+        return None
+    return int(ld)
+
+
+def grown_buffer(x, Ctot, claim=False):
+    """The [N,H,W,Ctot] buffer a convolution with `grow` allocated around its output `x` (its channel prefix), or None."""
+    base = x._base if x.dim() == 4 else None
+    if base is None or not getattr(base, "_otgan_grow", False) or not base.is_contiguous():
+        return None
+    N, H, W, C = x.shape
+    if tuple(base.shape) != (N, H, W, Ctot) or x.data_ptr() != base.data_ptr() or channel_prefix_stride(x) != Ctot:
+        return None
+    if claim:
+        base._otgan_grow = False       # one block grows in a buffer
+    return base
 
 
 def dense_op(x, V, g, b, preact=0, segs=None):
@@ -814,8 +869,10 @@ class DenseBlockFunction(torch.autograd.Function):
         N, H, W, C0 = x0.shape
         F = params[0].shape[-1]
         Ctot = C0 + L * F
-        buf = torch.empty((N, H, W, Ctot), dtype=x0.dtype, device=x0.device)
-        buf[..., :C0].copy_(x0)
+        buf = grown_buffer(x0, Ctot, claim=True)      # the producing convolution left room (conv2d_op grow): no copy
+        if buf is None:
+            buf = torch.empty((N, H, W, Ctot), dtype=x0.dtype, device=x0.device)
+            buf[..., :C0].copy_(x0)
         mult = 2 if preact in DOUBLED else 1
         saved, descs, maps, per_layer = [], [], [], []
         segs = list(segs0)
@@ -1001,7 +1058,7 @@ class DenseBlockFunction(torch.autograd.Function):
         if (plan is not None and plan.get("h2") and ctx.batched and len(plan["wide"]) <= 2 and
                 os.environ.get("OTGAN_DENSE16_BWD_H2", "1") != "0"):
             grads = DenseBlockFunction._backward_by_slice(ctx, buf, saved, G, dbuf, need_w)
-            dx0 = G[..., :C0].contiguous() if ctx.needs_input_grad[0] else None
+            dx0 = _block_input_grad(G, C0) if ctx.needs_input_grad[0] else None
             if dx0 is not None and _FUSED_AMAX and C0 % 4 == 0:
                 tag_amax(dx0, ctx.dx0_rec)
             return (dx0, None, None, None, *grads)
@@ -1101,8 +1158,16 @@ class DenseBlockFunction(torch.autograd.Function):
             db_all = colsum(G.data_ptr() + 4 * C0, rows, L * F, Ctot, G.device)
             for k in range(L):
                 grads[3 * k + 2] = db_all[k * F:(k + 1) * F]
-        dx0 = G[..., :C0].contiguous() if ctx.needs_input_grad[0] else None
+        dx0 = _block_input_grad(G, C0) if ctx.needs_input_grad[0] else None
         return (dx0, None, None, None, *grads)
+
+
+def _block_input_grad(G, C0):
+    """Gradient of a dense block's input = channels [0, C0) of its finished gradient buffer: handed on as a VIEW when the
+    kernels of the layer in front can read it through a channel stride (Conv2dFunction.backward: channel_prefix_stride),
+    else as a copy (round 5: one copy of the block input's gradient per block and pass less)."""
+    v = G[..., :C0]
+    return v if channel_prefix_stride(v) is not None else v.contiguous()
 
 
 def _dense16_bwd_filters(sw, plan, L, F, device):
@@ -1400,6 +1465,55 @@ class ConcatChannelsFunction(torch.autograd.Function):
 
 def concat_channels(xs):
     return ConcatChannelsFunction.apply(*xs)
+
+
+class ExtendChannelsFunction(torch.autograd.Function):
+    """[x, *others] concatenated along the channels IN the buffer a convolution with `grow` allocated around x (round 5):
+    the other elements (the 16-channel noise inputs of the DenseNet generator, models/densenet.py:60-73) are copied behind
+    x, the result is the channel prefix [0, C0) of that buffer -- x itself is not copied, and its gradient is handed back
+    as a view of the incoming one.  Records as in ConcatChannelsFunction."""
+
+    @staticmethod
+    def forward(ctx, Ctot, x, *others):
+        base = grown_buffer(x, Ctot)
+        assert base is not None
+        ctx.widths = [int(t.shape[-1]) for t in (x,) + others]
+        off = ctx.widths[0]
+        for t in others:
+            base[..., off:off + t.shape[-1]].copy_(t)
+            off += t.shape[-1]
+        y = base[..., :off]
+        if _FUSED_AMAX and all(w % 4 == 0 for w in ctx.widths) and amax_of(x) is not None:
+            rec = amax_of(x)
+            for t in others:
+                r = amax_of(t)
+                rec = torch.maximum(rec, r if r is not None else absmax_record(t.contiguous()))
+            tag_amax(y, rec)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rec = amax_of(dy)
+        outs, off = [], 0
+        for i, w in enumerate(ctx.widths):
+            piece = dy[..., off:off + w]
+            off += w
+            if not ctx.needs_input_grad[1 + i]:
+                outs.append(None)
+                continue
+            if i > 0 or channel_prefix_stride(piece) is None:
+                piece = piece.contiguous()
+            if rec is not None:
+                tag_amax(piece, rec)
+            outs.append(piece)
+        return (None, *outs)
+
+
+def extend_channels(xs, Ctot):
+    """concat_channels(xs) inside the grown buffer of xs[0] when there is one with Ctot channels, else None."""
+    if grown_buffer(xs[0], Ctot) is None or any(t.shape[:3] != xs[0].shape[:3] for t in xs[1:]):
+        return None
+    return ExtendChannelsFunction.apply(int(Ctot), *xs)
 
 
 glu = GluFunction.apply

@@ -310,11 +310,13 @@ def dense(x, num_units, pre_activation='celu', init_scale=1., counters={}, init=
 @_scoped
 def conv2d(x, num_filters, pre_activation='celu', filter_size=[3, 3], stride=[1, 1], pad='SAME',
            dilate=1, upsample=False, init_scale=1., counters={}, init=False, ema=None,
-           weight_norm=True, use_b=True, use_g=True, glu_hint=False, **kwargs):
+           weight_norm=True, use_b=True, use_g=True, glu_hint=False, grow=0, **kwargs):
     """2-D convolution on an NHWC tensor or list of tensors (reference nn.py:327-338):
     optional 2x nearest-neighbour upsample, pre-activation over the list, weight-normalised
     HWIO filter, TF 'SAME' padding, bias.  `glu_hint` (not in the reference): the caller passes the
-    result to glu() next, see ops.conv2d_op -- values unchanged."""
+    result to glu() next, see ops.conv2d_op -- values unchanged.  `grow` (not in the reference): the caller appends that
+    many channels to the result next (dense_block: its list input + L * F outputs): the result is allocated as the
+    channel prefix of a buffer with room for them, so the block grows there without copying its input -- values unchanged."""
     if pad != 'SAME' or dilate != 1:
         raise NotImplementedError("the reference models only use pad='SAME', dilate=1")
     if not (weight_norm and use_g and use_b):
@@ -339,7 +341,8 @@ def conv2d(x, num_filters, pre_activation='celu', filter_size=[3, 3], stride=[1,
                                preact=ops.ACT[pre_activation], segs=[int(t.shape[-1]) for t in xs])
         _run_data_init(y0, g, b, init_scale)
     return ops.conv2d_op(xin, V, g, b, stride=stride[0], upsample=upsample,
-                         preact=ops.ACT[pre_activation], segs=[int(t.shape[-1]) for t in xs], glu_hint=glu_hint)
+                         preact=ops.ACT[pre_activation], segs=[int(t.shape[-1]) for t in xs], glu_hint=glu_hint,
+                         grow=grow)
 
 
 class ConcatList(list):
@@ -367,8 +370,16 @@ def dense_block(x, layers_per_block, filters_per_layer, pre_activation='celu', f
         return feats
     dev = xs[0].device
     segs0 = [int(t.shape[-1]) for t in xs]
-    x0 = xs.buffer if isinstance(xs, ConcatList) and xs.buffer is not None else (
-        xs[0] if len(xs) == 1 else ops.concat_channels(xs))
+    if isinstance(xs, ConcatList) and xs.buffer is not None:
+        x0 = xs.buffer
+    elif len(xs) == 1:
+        x0 = xs[0]
+    else:
+        # the first element inside a buffer with room for the rest of the list and the block's outputs (conv2d grow=):
+        # the other elements are copied behind it there; else one concatenation
+        x0 = ops.extend_channels(xs, sum(segs0) + layers_per_block * filters_per_layer)
+        if x0 is None:
+            x0 = ops.concat_channels(xs)
     mult = 2 if pre_activation in ("celu", "crelu") else 1
     params = []
     c = sum(segs0)
