@@ -41,7 +41,8 @@ def gen_spec(batch_size, init=False, nonlinearity='crelu', ema=None, noise=None,
     base = image_size // 8
     if noise is None:
         # models/dcgan.py:30 -- fresh uniform(-1, 1) latent on every call
-        noise = torch.rand((batch_size, 100), device=device or 'cuda') * 2.0 - 1.0
+        # U(-1, 1) (models/dcgan.py:30) in one launch: the same Philox draws and the same fp32 arithmetic as rand() * 2 - 1
+        noise = torch.empty((batch_size, 100), device=device or 'cuda').uniform_(-1.0, 1.0)
     with nn.arg_scope([nn.conv2d, nn.dense], counters={}, init=init, weight_norm=True, ema=ema):
         x = nn.glu(nn.dense(noise, 2 * base * base * 1024, pre_activation=None))   # split along axis 1
         x = ops.carry_amax(x.view(noise.shape[0], base, base, 1024), x)   # (the GLU's amax record survives the reshape)

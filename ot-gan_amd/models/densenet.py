@@ -41,7 +41,8 @@ def gen_spec(batch_size, init=False, layers_per_block=16, filters_per_layer=16, 
     F = filters_per_layer
     if noise is None:
         dev = device or 'cuda'
-        noise = [torch.rand(shape, device=dev) * 2.0 - 1.0
+        # (one launch per draw: the same Philox draws and fp32 arithmetic as rand() * 2 - 1)
+        noise = [torch.empty(shape, device=dev).uniform_(-1.0, 1.0)
                  for shape in ((batch_size, 100), (batch_size, 8, 8, F), (batch_size, 16, 16, F),
                                (batch_size, 32, 32, F))]
     B = noise[0].shape[0]

@@ -905,7 +905,12 @@ class DenseBlockFunction(torch.autograd.Function):
         ctx.plan = plan
         if plan is not None:
             sw = _split_block_weights(params[0::3], per_layer, plan, F)
-            bias_all = torch.cat([b for b in params[2::3]])
+            # the L biases side by side, kept with the block's operands: rebuilt with them after a weight update (the optimiser
+            # kernels bump the storage epoch that invalidates `sw`), or when a torch op touched a bias (version counters)
+            bkey = tuple((id(b), b._version) for b in params[2::3])
+            if sw.get("bias_key") != bkey:
+                sw["bias_all"], sw["bias_key"] = torch.cat([b.detach() for b in params[2::3]]), bkey
+            bias_all = sw["bias_all"]
             rows = N * H * W
             ctx.x_recs, ctx.x_ops = [], []
             # amax records without extra passes (OTGAN_DENSE_AMAX=0: one reduction per slice, as in round 2): every kernel
