@@ -7,9 +7,11 @@
 #   tools/r05b_profiles.sh   -> gpurun_out/r05b_*  (copy the summaries to profiles/)
 R=$GRAFT_REPO_ROOT
 cd $R
-bash tools/pmc_r02.sh r05b dcgan > /dev/null 2>&1
-bash tools/pmc_r02.sh r05b densenet > /dev/null 2>&1
-bash tools/pmc_r02.sh r05b dcgan64 > /dev/null 2>&1
+# (per-kernel figures with the second stream OFF: every kernel alone on the device, durations comparable with rounds 1 - 4 and
+# with `roofline.avg_ms`; the timed windows below show the default two-stream schedule)
+OTGAN_SIDE_STREAM=0 bash tools/pmc_r02.sh r05b dcgan > /dev/null 2>&1
+OTGAN_SIDE_STREAM=0 bash tools/pmc_r02.sh r05b densenet > /dev/null 2>&1
+OTGAN_SIDE_STREAM=0 bash tools/pmc_r02.sh r05b dcgan64 > /dev/null 2>&1
 bash tools/window_dcgan.sh > /dev/null 2>&1; cp gpurun_out/window_stats.txt gpurun_out/r05b_window_stats_dcgan.txt
 bash tools/window_densenet.sh > /dev/null 2>&1; cp gpurun_out/window_stats_densenet.txt gpurun_out/r05b_window_stats_densenet.txt
 ( cd /tmp && export TMPDIR=/tmp && OTGAN_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r05b_one_trace -- python $R/bench.py --steps 6 --warmup 6 --no_cpu_baseline --no_secondary > $R/gpurun_out/r05b_bench_under_rocprof_dcgan_one_stream.json 2> /dev/null
