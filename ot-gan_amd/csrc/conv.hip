@@ -65,6 +65,7 @@ inline void ensure_lds(size_t bytes) {
   (void)done;
 }
 
+constexpr size_t kIgemmCmapBytes = 8192;
 constexpr int kMaxTaps = 36;
 constexpr int kMaxClass = 4;
 
@@ -296,6 +297,62 @@ struct ConvALoader {
       }
     }
   }
+  // ---- stage interface of gemm_mainloop_x2h_d2 (vector path): the data of a k tile in flight lives in a caller-owned stage
+  struct Stage {
+    float4 reg[PASSES];
+    unsigned ok;         // bit p: pass p loaded a real element (inside the image, inside the K range)
+    float sgn;
+  };
+  const int* cmap_lds = nullptr;   // the channel map in LDS (set by the kernel; the global one would tie every trip to a load)
+  __device__ __forceinline__ void load_s(Stage& st, bool live) {
+    static_assert(VEC, "stage interface: vector gathers only");
+    const int c4 = threadIdx.x % CPR;
+    const int t = __builtin_amdgcn_readfirstlane(nt);
+    const int d = __builtin_amdgcn_readfirstlane(nd) + 4 * c4;
+    const bool kin = live && d < g.Ck;
+    int sc;
+    float sg;
+    decode_map(g, d, (g.cmap && kin) ? cmap_lds[d] : 0, sc, sg);
+    if (!kin) sc = 0;
+    const int dhw = taps.dhw[t];
+    const int dh = dhw >> 16, dw = sx16(dhw);
+    unsigned ok = 0u;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int ih = ia[p] + dh, iw = ib[p] + dw;
+      const bool in = kin && (unsigned)ih < (unsigned)vH && (unsigned)iw < (unsigned)vW;
+      const int ihc = in ? ih : 0, iwc = in ? iw : 0;          // (branch-free: a masked element reads pixel 0 of its image)
+      const long pix = (long)pixbase[p] + (long)(ihc >> g.logUp) * g.W + (iwc >> g.logUp);
+      st.reg[p] = *reinterpret_cast<const float4*>(g.x + pix * g.ldx + sc);
+      ok |= in ? (1u << p) : 0u;
+    }
+    st.ok = ok;
+    st.sgn = sg;
+    nt += 1;
+    if (nt >= taps.n) {
+      nt = 0;
+      nd += BK;
+    }
+  }
+  __device__ __forceinline__ void store2_s(unsigned char* t, const Stage& st) const {
+    const int c4 = threadIdx.x % CPR, r0 = threadIdx.x / CPR;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int r = r0 + p * RPP;
+      if (r < BR) {
+        const bool ok = (st.ok >> p) & 1u;
+        float4 v = st.reg[p];
+        v.x = ok ? act_apply<ACT>(v.x * st.sgn) * xs : 0.f; v.y = ok ? act_apply<ACT>(v.y * st.sgn) * xs : 0.f;
+        v.z = ok ? act_apply<ACT>(v.z * st.sgn) * xs : 0.f; v.w = ok ? act_apply<ACT>(v.w * st.sgn) * xs : 0.f;
+        x2h_store4(t, BR * kX3sRowBytes, r, 4 * c4, v);
+      }
+    }
+  }
+  __device__ __forceinline__ static void pin_s(Stage& st) {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p)
+      asm volatile("" : "+v"(*reinterpret_cast<gt_f32x4*>(&st.reg[p])));   // (one 128-bit operand: the load's register tuple stays whole)
+  }
 };
 
 // Weight ("B") operand: element (n, k=(tap, c)) at w[boff[tap] + row(n)*ldbn + c].
@@ -433,6 +490,51 @@ struct ConvBLoader {
       }
     }
   }
+  // ---- stage interface of gemm_mainloop_x2h_d2 (vector path)
+  struct Stage {
+    float4 reg[PASSES];
+    unsigned ok;
+  };
+  __device__ __forceinline__ void load_s(Stage& st, bool live) {
+    static_assert(VEC, "stage interface: vector gathers only");
+    const int c4 = threadIdx.x % CPR;
+    const int t = __builtin_amdgcn_readfirstlane(nt);
+    int d = __builtin_amdgcn_readfirstlane(nd) + 4 * c4;
+    const bool kin = live && d < b.Ck;
+    if (!kin) d = 0;                           // (a masked quad reads the row's first one)
+    const float* base = wbase + taps.boff[t] + d;
+    unsigned ok = 0u;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const bool in = kin && rowoff[p] >= 0;
+      st.reg[p] = *reinterpret_cast<const float4*>(base + (rowoff[p] >= 0 ? rowoff[p] : 0));
+      ok |= in ? (1u << p) : 0u;
+    }
+    st.ok = ok;
+    nt += 1;
+    if (nt >= taps.n) {
+      nt = 0;
+      nd += BK;
+    }
+  }
+  __device__ __forceinline__ void store2_s(unsigned char* t, const Stage& st) const {
+    const int c4 = threadIdx.x % CPR, r0 = threadIdx.x / CPR;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int r = r0 + p * RPP;
+      if (r < BR) {
+        const float m = ((st.ok >> p) & 1u) ? xs : 0.f;
+        float4 v = st.reg[p];
+        v.x *= m; v.y *= m; v.z *= m; v.w *= m;
+        x2h_store4(t, BR * kX3sRowBytes, r, 4 * c4, v);
+      }
+    }
+  }
+  __device__ __forceinline__ static void pin_s(Stage& st) {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p)
+      asm volatile("" : "+v"(*reinterpret_cast<gt_f32x4*>(&st.reg[p])));   // (one 128-bit operand: the load's register tuple stays whole)
+  }
 };
 
 // ---------------------------------------------------------------------------------------
@@ -501,6 +603,19 @@ __global__ __launch_bounds__(Cfg::THREADS) void conv_igemm_kernel(GatherA g, Cla
     la.xs = x2h_scale(aA, &eA);
     lb.xs = x2h_scale(aB, &eB);
     descale = __builtin_ldexpf(1.f, eA + eB - 28);
+#ifndef OTGAN_IGEMM_D1
+    if constexpr (VEC) {
+      // loads two k steps ahead (gemm_tile.h); the channel map of a list input moves to LDS behind the operand planes
+      // (kIgemmCmapBytes at most: the launcher checks), so that no trip waits on a global load it has just issued
+      int* s_cmap = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(smem) + X2hLds<Cfg>::BYTES);
+      if (g.cmap) {
+        for (int i = threadIdx.x; i < g.Ck; i += Cfg::THREADS) s_cmap[i] = g.cmap[i];
+        __syncthreads();
+      }
+      la.cmap_lds = s_cmap;
+      gemm_mainloop_x2h_d2<Cfg>(la, lb, nkt, reinterpret_cast<unsigned char*>(smem), acc);
+    } else
+#endif
     gemm_mainloop_x2h<Cfg>(la, lb, nkt, reinterpret_cast<unsigned char*>(smem), acc);
   } else if constexpr (XS == 1) {
     gemm_mainloop_x3s<Cfg>(la, lb, nkt, reinterpret_cast<unsigned char*>(smem), acc);   // bf16 pipe, three pieces
@@ -2518,8 +2633,8 @@ template <class Cfg, int EPI, int ACT>
 void launch_igemm3_x3s(dim3 grid, hipStream_t s, const GatherA& ga, const ClassTab& ct, const WeightB& wb,
                        const EpiArgs& e) {
   static_assert(Cfg::BK == 16 && Cfg::TS == 32, "");
-  if (e.amax_a && e.amax_b) {   // both records at hand: two scaled fp16 pieces, three MFMAs per product
-    constexpr size_t lds2 = X2hLds<Cfg>::BYTES;
+  if (e.amax_a && e.amax_b && (!ga.cmap || (size_t)ga.Ck * sizeof(int) <= kIgemmCmapBytes)) {   // both records at hand: two scaled fp16 pieces, three MFMAs per product
+    constexpr size_t lds2 = X2hLds<Cfg>::BYTES + kIgemmCmapBytes;
     ensure_lds<conv_igemm_kernel<Cfg, true, EPI, ACT, 2>>(lds2);
     hipLaunchKernelGGL((conv_igemm_kernel<Cfg, true, EPI, ACT, 2>), grid, dim3(Cfg::THREADS), lds2, s, ga, ct, wb, e);
     return;

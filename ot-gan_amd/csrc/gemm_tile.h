@@ -125,6 +125,7 @@ __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int nkt, float* sm
 typedef __bf16 gt_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 gt_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float gt_f32x2 __attribute__((ext_vector_type(2)));
+typedef float gt_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int gt_u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kX3sRowBytes = 32;
@@ -303,6 +304,84 @@ __device__ __forceinline__ void gemm_mainloop_x2h(LA& la, LB& lb, int nkt, unsig
       lb.store2(sB + (cur ^ 1) * L::TB);
     }
     __syncthreads();
+  }
+}
+
+// The same loop with the global loads TWO k steps ahead (round 5, late).  The one-deep loop above runs one k step per
+// global-load round trip: with two workgroups per compute unit a stride-2 transition of the DenseNet critic spends 1.65 us
+// per k step for 0.23 us of matrix work.  Here a loader keeps its in-flight data in caller-owned STAGES (two per operand):
+//     load_s(Stage&, live)          issue the loads of the next k tile (branch-free: clamped addresses; `live` false past
+//                                   the end of the K range: the stage converts to zeros)
+//     store2_s(tile, const Stage&)  convert and store (masked elements as zeros)
+//     pin_s(Stage&)                 an empty asm that "rewrites" the stage's registers: hipcc otherwise hoists the conversion
+//                                   (pure arithmetic: no chain to a scheduling barrier) to the top of the trip, where it waits
+//                                   for loads issued a moment ago
+// and nothing in the loop may wait on a load issued in the same half trip (a loader that prefetches an index through
+// global memory -- the channel map of the list inputs -- reads it from LDS instead).
+template <class Cfg, class LA, class LB>
+__device__ __forceinline__ void gemm_mainloop_x2h_d2(LA& la, LB& lb, int nkt, unsigned char* smem,
+                                                     typename Cfg::acc_t (&acc)[Cfg::MT][Cfg::NT]) {
+  constexpr int MT = Cfg::MT, NT = Cfg::NT, TS = Cfg::TS;
+  static_assert(TS == 32 && Cfg::BK == 16, "split-precision main loop: 32x32 tiles, BK = 16");
+  using L = X2hLds<Cfg>;
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + 2 * L::TA;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int li = lane & 31, lh = lane >> 5;
+  int a_off[MT], b_off[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) a_off[mt] = x3s_off((wm * MT + mt) * TS + li, 8 * lh);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) b_off[nt] = x3s_off((wn * NT + nt) * TS + li, 8 * lh);
+  if (nkt <= 0) return;
+  auto mma = [&](int cur) {
+    const unsigned char* pa = sA + cur * L::TA;
+    const unsigned char* pb = sB + cur * L::TB;
+    gt_f16x8 fa[2][MT], fb[2][NT];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) fa[p][mt] = *reinterpret_cast<const gt_f16x8*>(pa + p * L::PA + a_off[mt]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) fb[p][nt] = *reinterpret_cast<const gt_f16x8*>(pb + p * L::PB + b_off[nt]);
+    }
+#pragma unroll
+    for (int term = 0; term < 3; ++term) {
+      constexpr int pa_of[3] = {1, 0, 0}, pb_of[3] = {0, 1, 0};
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[pa_of[term]][mt], fb[pb_of[term]][nt], acc[mt][nt], 0, 0, 0);
+    }
+  };
+  typename LA::Stage a0, a1;
+  typename LB::Stage b0, b1;
+  la.load_s(a0, true); lb.load_s(b0, true);
+  la.load_s(a1, 1 < nkt); lb.load_s(b1, 1 < nkt);
+  la.store2_s(sA, a0);
+  lb.store2_s(sB, b0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; kt += 2) {
+    la.load_s(a0, kt + 2 < nkt); lb.load_s(b0, kt + 2 < nkt);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0);
+    __builtin_amdgcn_sched_barrier(0);
+    LA::pin_s(a1); LB::pin_s(b1);
+    la.store2_s(sA + L::TA, a1);
+    lb.store2_s(sB + L::TB, b1);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    la.load_s(a1, kt + 3 < nkt); lb.load_s(b1, kt + 3 < nkt);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1);
+    __builtin_amdgcn_sched_barrier(0);
+    LA::pin_s(a0); LB::pin_s(b0);
+    la.store2_s(sA, a0);
+    lb.store2_s(sB, b0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

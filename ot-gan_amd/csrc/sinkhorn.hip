@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void cost128_h2_kernel(CostArgs a) {
   // hipcc hoists the conversion of a register set (pure arithmetic: no chain to a scheduling barrier) to the top of the
   // trip, where it waits for loads issued a moment ago; an empty asm that "rewrites" the set pins its first use
 #define COST_H2_PIN(R)                                                                                        \
-  asm volatile("" : "+v"(R[0].x), "+v"(R[0].y), "+v"(R[0].z), "+v"(R[0].w), "+v"(R[1].x), "+v"(R[1].y), "+v"(R[1].z), "+v"(R[1].w))
+  asm volatile("" : "+v"(*reinterpret_cast<gt_f32x4*>(&R[0])), "+v"(*reinterpret_cast<gt_f32x4*>(&R[1])))   /* 128-bit operands: the loads' register tuples stay whole */
   for (int kt = 0; kt < nkt; kt += 2) {
     la.load(kt + 2, ra0); lb.load(kt + 2, rb0);
     __builtin_amdgcn_sched_barrier(0);        // (the loads stay in front of the matrix work: hipcc sinks them behind it otherwise)
@@ -1313,7 +1313,7 @@ __global__ __launch_bounds__(256) void plan_apply128_h2_kernel(ApplyH2Args a) {
   // ---- the cost kernel's loop: two register sets, k steps st + 1 and st + 2 in flight while step st is multiplied
   float4 p0[2], p1[2], f0[2], f1[2];
 #define APPLY_H2_PIN(R)                                                                                       \
-  asm volatile("" : "+v"(R[0].x), "+v"(R[0].y), "+v"(R[0].z), "+v"(R[0].w), "+v"(R[1].x), "+v"(R[1].y), "+v"(R[1].z), "+v"(R[1].w))
+  asm volatile("" : "+v"(*reinterpret_cast<gt_f32x4*>(&R[0])), "+v"(*reinterpret_cast<gt_f32x4*>(&R[1])))
   load(0, p0, f0);
   load(1, p1, f1);
   store(0, 0, p0, f0);
