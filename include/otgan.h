@@ -89,6 +89,11 @@ size_t otgan_matching_workspace_bytes(int mode, int rows, int D);
  * fp64 accumulation.  stats (nullable): [6][4] doubles per problem in the reference order
  * (a1a2, b2b1, a1b1, a1b2, a2b1, a2b2): {sum of row entropies, <M,C>, sum(M), 0}.
  * Exactly `iters` row->column sweeps are run, then a row softmax (no early exit).
+ * Cosine cost: the features are what the reference's critics return (models/dcgan.py:16-19, models/densenet.py:40-42):
+ * rows of unit length.  The cost and plan-application GEMMs multiply operands split into two scaled fp16 pieces with an
+ * a-priori scale for such rows; an element of magnitude >= 8 overflows a piece and the outputs come out NaN (loud, never
+ * silently wrong).  OTGAN_MATCH_FP32=1 (environment, read once) keeps these GEMMs on the exact-fp32 MFMA engine, which
+ * has no such limit; the toy cost always runs there.
  */
 int otgan_matching_two_batch_f32(const float* fa, const float* fb, int N, int D, long ldf,
                                  float sinkhorn_lambda, int iters, int cost_kind,
