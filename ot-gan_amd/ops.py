@@ -366,7 +366,7 @@ class Conv2dFunction(torch.autograd.Function):
                              f"{C * (2 if preact in DOUBLED else 1)}")
         V2d = V.contiguous().view(KH * KW * Cin_eff, Cout)
         OH, OW = out_hw(H, W, upsample, stride)
-        grow = int(grow) if (grow and Cout % 4 == 0 and not glu_hint) else 0
+        grow = int(grow) if (grow and Cout % 4 == 0 and not glu_hint and _GROW_IN_PLACE) else 0
         if grow:
             # the caller appends `grow` channels next (a dense block, nn.dense_block): the output is the channel prefix of a
             # buffer with room for them (ldy of the conv ABI) -- the block grows there in place instead of copying its input
@@ -837,6 +837,8 @@ def _calibrate_backward_arg_refs():
 
 
 _BACKWARD_ARG_REFS = _calibrate_backward_arg_refs()
+# OTGAN_GROW=0 (test / A-B knob): convolutions ignore `grow`, dense blocks copy their input into their own buffer as before round 5
+_GROW_IN_PLACE = os.environ.get("OTGAN_GROW", "1") != "0"
 
 
 class DenseBlockFunction(torch.autograd.Function):
