@@ -312,14 +312,22 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     parallel.barrier()
     torch.cuda.synchronize()
+    ms0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
     marks[0].record()
+    _dbg = os.environ.get("OTGAN_BENCH_ALLOC_DEBUG") == "1"
     for i in range(a.steps):
         last = model.step(x)
         marks[i + 1].record()
+        if _dbg:
+            print("step", i, torch.cuda.memory_stats(dev)["num_device_alloc"], file=sys.stderr)
     torch.cuda.synchronize()
     parallel.barrier()
     dt = time.perf_counter() - t0
+    ms1 = torch.cuda.memory_stats(dev)
+    # device-level allocations (hipMalloc / hipFree by torch's caching allocator) INSIDE the timed window: 0 when the warm-up
+    # left the allocator in its steady state; anything else means some steps paid for a synchronising hipMalloc (diagnostic)
+    alloc_diag = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
     graph_kinds = sorted(model.graphs.graphs) if model.graphs is not None else []    # (before the profiled pass runs eagerly)
     per_kind = {"disc": [], "gen": []}
     for i in range(a.steps):
@@ -406,6 +414,8 @@ def main():
                    "step_graph_setup_steps": graph_setup_steps,
                    "matching_scope": model.scope,
                    "step_mix": {"critic_steps": n_disc, "generator_steps": a.steps - n_disc,
+                                "critic_ms_each": [round(v, 3) for v in per_kind["disc"]],
+                                "device_allocations_in_window": alloc_diag,
                                 "critic_ms": round(sum(per_kind["disc"]) / max(1, len(per_kind["disc"])), 3),
                                 "generator_ms": (round(sum(per_kind["gen"]) / len(per_kind["gen"]), 3) if per_kind["gen"] else None),
                                 "note": "timed window starts on a critic step; the reference's schedule is 1 critic : "

@@ -149,6 +149,9 @@ class OTGAN:
         self.ema_fused = self.gen_optimizer.fuse_ema(self.ema)
         self.step_counter = 0
         self.last = {}
+        import collections
+        self._max_ahead = int(os.environ.get("OTGAN_MAX_STEPS_AHEAD", "2"))
+        self._step_ends, self._free_events = collections.deque(), []
         self.timers = None        # name -> [(start event, end event)]; see enable_timers()
         self._d_weights_in_graph = False
         # Two chains of every step are independent of its critical path and run on a SECOND STREAM (round 5; single-process
@@ -298,10 +301,12 @@ class OTGAN:
         period = self.args.nr_gen_per_disc + 1
         phase = self.step_counter % period
         kind = "disc" if phase == 0 else "gen"
+        self._throttle()
         if self.graphs is not None and noise is None and apply_updates:
             done = self.graphs.run(x_data, phase)
             if done is not None:
                 self.last = done
+                self._mark_step_end()
                 return self.last
         from . import ops
         ops.SIDE_STREAM = self._side_stream if self.fork_wgrad else None
@@ -309,6 +314,7 @@ class OTGAN:
             dist, ent, grads = self._step_body(x_data, kind, noise, apply_updates)
         finally:
             ops.SIDE_STREAM = None
+        self._mark_step_end()
         if kind == "disc":
             self._d_weights_in_graph = False      # the critic changed: graphs that read its cached operands wait for a refresh
         self.step_counter += 1
@@ -316,6 +322,27 @@ class OTGAN:
         if not apply_updates:
             self.last["grads"] = grads
         return self.last
+
+    # The host never gets more than `_max_ahead` steps ahead of the device (default 2; OTGAN_MAX_STEPS_AHEAD=0: unbounded).  With
+    # two streams a tensor that the other stream has used (record_stream) returns to torch's caching allocator only once
+    # that stream's work on it has COMPLETED; a host that enqueues step after step never sees those completions and the
+    # allocator answers with fresh hipMallocs -- four per step, without end (bench.py: 120 device allocations inside a
+    # 30-step window, reserved memory growing, the first critic step of the window 0.4 ms slow and once in ten runs 13 ms).
+    # Waiting for the END of the step before the previous one costs nothing (a whole step is still queued behind it) and
+    # puts the allocator in a steady state after two periods.
+    def _throttle(self):
+        if self._max_ahead > 0 and len(self._step_ends) >= self._max_ahead:
+            ev = self._step_ends.popleft()
+            ev.synchronize()
+            self._free_events.append(ev)
+
+    def _mark_step_end(self):
+        if self._max_ahead > 0:
+            ev = self._free_events.pop() if self._free_events else torch.cuda.Event()
+            ev.record()
+            self._step_ends.append(ev)
+            if len(self._step_ends) > self._max_ahead:          # (callers that bypass step(): keep the queue bounded)
+                self._free_events.append(self._step_ends.popleft())
 
     def _optimise(self, opt, grads, lr, critic):
         """The optimiser step (and the generator's EMA).  (Round 5 also tried it on a third stream, so that the next step's

@@ -38,3 +38,26 @@ def test_side_stream_is_on_by_default_and_off_with_more_ranks(dev, monkeypatch):
     m = OTGAN(default_args(batch_size=2, nr_gpu=2, nr_sinkhorn_iter=5, step_graph=True), dev)
     assert not m.fork_real_pass and not m.fork_wgrad          # a capture records one stream
     m.close()
+
+
+def test_allocator_reaches_a_steady_state_with_the_host_running_ahead(dev, monkeypatch):
+    """Two streams + record_stream + a host that never synchronises made torch's caching allocator call hipMalloc about four
+    times per step, without end (a tensor the other stream has used is reusable only once that stream's work on it has
+    COMPLETED).  trainer.OTGAN.step keeps the host at most two steps ahead of the device (OTGAN_MAX_STEPS_AHEAD): after
+    two warm-up periods a window of steps without any synchronisation allocates (next to) nothing."""
+    from otgan_amd.trainer import OTGAN, default_args
+    monkeypatch.delenv("OTGAN_SIDE_STREAM", raising=False)
+    monkeypatch.delenv("OTGAN_MAX_STEPS_AHEAD", raising=False)
+    m = OTGAN(default_args(batch_size=32, nr_gpu=2, nr_sinkhorn_iter=10, nr_gen_per_disc=2, seed=3), dev)
+    assert m._side_stream is not None and m._max_ahead == 2
+    x = torch.rand(m.nb, 32, 32, 3, device=dev) * 2 - 1
+    for _ in range(9):
+        m.step(x)
+    torch.cuda.synchronize()
+    n0 = torch.cuda.memory_stats(dev)["num_device_alloc"]
+    for _ in range(18):
+        m.step(x)
+    torch.cuda.synchronize()
+    n1 = torch.cuda.memory_stats(dev)["num_device_alloc"]
+    m.close()
+    assert n1 - n0 <= 4, (n0, n1)
