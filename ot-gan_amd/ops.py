@@ -244,6 +244,21 @@ def amax_slot(device):
     return rec
 
 
+def amax_slots(device, n):
+    """n CONSECUTIVE zeroed records ([n, AMAX_RECORD_FLOATS]) from the pool: the record arrays of a dense block's passes
+    (one row per layer) without a zeroing launch each."""
+    if n > _AMAX_SLOTS:
+        return torch.zeros((n, AMAX_RECORD_FLOATS), dtype=torch.float32, device=device)
+    ent = _amax_pool.get(device)
+    if ent is not None and ent[1] + n > _AMAX_SLOTS:
+        ent[1] = _AMAX_SLOTS                      # not enough left in this pool: the next draw opens a new one
+    first = amax_slot(device)                     # (opens / joins the pool; takes slot ent[1] - 1)
+    ent = _amax_pool[device]
+    i0 = ent[1] - 1
+    ent[1] = i0 + n
+    return ent[0][i0:i0 + n]
+
+
 def reset_amax_pool():
     """Forget the current pool of zeroed records: the next amax_slot() allocates (and zeroes) a new one.  A step captured in
     a hipGraph calls this at the start of the capture, so that the pool's zeroing is part of the graph and every replay starts
@@ -931,7 +946,7 @@ class DenseBlockFunction(torch.autograd.Function):
             wides = plan["wide"]
             gbase = [wd["d0"] + i for i, wd in enumerate(wides)] + [L + len(wides)]
             gidx = {wd["d0"]: i for i, wd in enumerate(wides)}
-            R = torch.zeros((L + len(wides), AMAX_RECORD_FLOATS), dtype=torch.float32, device=buf.device) if shared else None
+            R = amax_slots(buf.device, L + len(wides)) if shared else None
 
             def wide_fwd(i):
                 wd, ops_ = plan["wide"][i], sw["wide"][i]
@@ -1234,7 +1249,7 @@ def _backward_by_slice(ctx, buf, saved, G, dbuf, need_w):
     # One array: rows [0, L) = RS, row L = Rc -- a reader of the slices from d0 on passes rows [d0, L] as they are
     # (otgan_conv_desc::dy_amax_count consecutive records; until round 4 an amax over the rows and a maximum with Rc: two launches).
     tag = amax_of(dbuf)
-    RR = torch.zeros((L + 1, AMAX_RECORD_FLOATS), dtype=torch.float32, device=buf.device)
+    RR = amax_slots(buf.device, L + 1)
     RS, Rc = RR[:L], RR[L]
     Rc.copy_(tag if tag is not None else absmax_record(G))
     R0 = amax_slot(buf.device)
