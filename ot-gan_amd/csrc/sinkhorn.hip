@@ -2373,12 +2373,19 @@ int otgan_matching_stack_split_f32(const float* fa, const float* fb, int N, int 
     OTGAN_CHECK_ARG(b >= 0 && e <= 6 * N && b < e && b % 32 == 0 && e % 32 == 0, "range %d: [%d, %d) outside the stack or not on 32-row blocks", i, b, e);
     while (b < e) {
       const int blk = b / N, stop = (blk + 1) * N < e ? (blk + 1) * N : e;
-      OTGAN_CHECK_ARG(nj < 12, "too many block pieces");
-      X3SplitJob& q = jobs[nj++];
-      memset(&q, 0, sizeof(q));
-      q.ss.n = 1;
-      q.ss.src[0] = blocks[blk] + (long)(b - blk * N) * ldf; q.ss.ld[0] = ldf; q.ss.row0[0] = b; q.ss.scale[0] = 1.f;
-      q.rows = stop - b; q.K = D; q.dst = FP; q.plane_stride = plane;
+      // pieces with the same row count share a job = ONE launch per pass (blockIdx.y = piece): a rank's three or four whole
+      // blocks were four launches of 45 - 50 us plus four empty second-pass launches (round 5, late: 205 -> ~185 us per step)
+      int j = 0;
+      while (j < nj && !(jobs[j].rows == stop - b && jobs[j].ss.n < 12)) ++j;
+      if (j == nj) {
+        OTGAN_CHECK_ARG(nj < 12, "too many block pieces");
+        memset(&jobs[nj], 0, sizeof(jobs[nj]));
+        jobs[nj].rows = stop - b; jobs[nj].K = D; jobs[nj].dst = FP; jobs[nj].plane_stride = plane;
+        ++nj;
+      }
+      X3SplitJob& q = jobs[j];
+      const int k = q.ss.n++;
+      q.ss.src[k] = blocks[blk] + (long)(b - blk * N) * ldf; q.ss.ld[k] = ldf; q.ss.row0[k] = b; q.ss.scale[k] = 1.f;
       b = stop;
     }
   }

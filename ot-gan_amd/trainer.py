@@ -680,14 +680,22 @@ def assemble_single_log_kernels(allk, lam):
     return K
 
 
+_ASSEMBLE_IDX = {}
+
+
 def assemble_log_kernels(allk, world):
     """[world, 3, nb, N] all-gathered slices -> the six [N, N] log-kernels in the reference's problem order
     a1a2, b2b1, a1b1, a1b2, a2b1, a2b2 (matching.py:41-43)."""
     W2 = world // 2
     N = allk.shape[3]
-    lo = allk[:W2].permute(1, 0, 2, 3).reshape(3, N, N)     # problems 0, 2, 3
-    hi = allk[W2:].permute(1, 0, 2, 3).reshape(3, N, N)     # problems 1, 4, 5
-    return torch.stack([lo[0], hi[0], lo[1], lo[2], hi[1], hi[2]], 0).contiguous()
+    # problem p = slice js[p] of the ranks of half hs[p]: ONE gather (three copies as permute / reshape / stack before)
+    key = (allk.device, "assemble")
+    idx = _ASSEMBLE_IDX.get(key)
+    if idx is None:
+        idx = (torch.tensor([0, 1, 0, 0, 1, 1], device=allk.device), torch.tensor([0, 0, 1, 2, 1, 2], device=allk.device))
+        _ASSEMBLE_IDX[key] = idx
+    a5 = allk.reshape(2, W2, 3, allk.shape[2], N)
+    return a5[idx[0], :, idx[1]].reshape(6, N, N)      # problems 0, 2, 3 from the first half's ranks; 1, 4, 5 from the second's
 
 
 def default_args(**over):
