@@ -326,8 +326,8 @@ class OTGAN:
     # The host never gets more than `_max_ahead` steps ahead of the device (default 2; OTGAN_MAX_STEPS_AHEAD=0: unbounded).  With
     # two streams a tensor that the other stream has used (record_stream) returns to torch's caching allocator only once
     # that stream's work on it has COMPLETED; a host that enqueues step after step never sees those completions and the
-    # allocator answers with fresh hipMallocs -- four per step, without end (bench.py: 120 device allocations inside a
-    # 30-step window, reserved memory growing, the first critic step of the window 0.4 ms slow and once in ten runs 13 ms).
+    # allocator answers with fresh hipMallocs -- four per step for the first ~150 steps of a run (bench.py: 120 device
+    # allocations inside a 30-step window, the first critic step of the window 0.4 ms slow and once in ten runs 13 ms).
     # Waiting for the END of the step before the previous one costs nothing (a whole step is still queued behind it) and
     # puts the allocator in a steady state after two periods.
     def _throttle(self):
