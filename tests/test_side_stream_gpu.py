@@ -42,8 +42,8 @@ def test_side_stream_is_on_by_default_and_off_with_more_ranks(dev, monkeypatch):
 
 def test_allocator_reaches_a_steady_state_with_the_host_running_ahead(dev, monkeypatch):
     """Two streams + record_stream + a host that never synchronises made torch's caching allocator call hipMalloc about four
-    times per step, without end (a tensor the other stream has used is reusable only once that stream's work on it has
-    COMPLETED).  trainer.OTGAN.step keeps the host at most two steps ahead of the device (OTGAN_MAX_STEPS_AHEAD): after
+    times per step through the first ~150 steps of a run (a tensor the other stream has used is reusable only once that
+    stream's work on it has COMPLETED).  trainer.OTGAN.step keeps the host at most two steps ahead of the device (OTGAN_MAX_STEPS_AHEAD): after
     two warm-up periods a window of steps without any synchronisation allocates (next to) nothing."""
     from otgan_amd.trainer import OTGAN, default_args
     monkeypatch.delenv("OTGAN_SIDE_STREAM", raising=False)
