@@ -101,3 +101,26 @@ def test_outside_the_contract_runs_the_fp32_kernels(dev, N, D):
     aa, bb, ab, ba = M.matched_rows(plans, fa1, fa2, fb1, fb2, 0, 0, N)
     assert _rel(ga[:N].cpu().numpy(), aa - ab) < REL_DIFF_INJECTED
     assert _rel(gb[:N].cpu().numpy(), bb - ba) < REL_DIFF_INJECTED
+
+
+def test_cost_h2_row_pitch(dev):
+    """features inside a wider buffer (ldf > D), through the C ABI: the same log-kernel as from a packed copy, bit for bit"""
+    from otgan_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(9)
+    n, m, D, ld = 64, 96, 100, 112
+    nrm = lambda z: z / np.linalg.norm(z, axis=1, keepdims=True)
+    X, Y = nrm(rng.randn(n, D)).astype(np.float32), nrm(rng.randn(m, D)).astype(np.float32)
+    xw, yw = torch.full((n, ld), 7.0, device=dev), torch.full((m, ld), -3.0, device=dev)     # (the padding must not be read)
+    xw[:, :D], yw[:, :D] = _t(X, dev), _t(Y, dev)
+    out = []
+    for x, y, l in ((xw, yw, ld), (_t(X, dev), _t(Y, dev), D)):
+        K = torch.empty(n, m, device=dev)
+        need = L.otgan_cost_matrix_workspace_bytes(n, m, D)
+        ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+        _lib.check(L.otgan_cost_matrix_f32(x.data_ptr(), y.data_ptr(), n, m, D, l, 500.0, 0, 0.0, K.data_ptr(), ws.data_ptr(),
+                                           ws.numel(), _lib.stream_ptr()), "cost")
+        out.append(K)
+    assert torch.equal(out[0], out[1])
+    ref = -500.0 * M.cosine_cost(X.astype(np.float64), Y.astype(np.float64))
+    assert np.abs(out[0].cpu().numpy() - ref).max() < 1e-3
