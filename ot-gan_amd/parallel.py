@@ -87,7 +87,14 @@ def self_launch(script, argv, nranks):
     # --standalone: torchrun's own rendezvous picks a free port on the loopback address (no bind-then-close race)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
            f"--nproc-per-node={nranks}", script] + list(argv)
-    return subprocess.call(cmd, env=env)
+    rc = subprocess.call(cmd, env=env)
+    if rc == 2:
+        # argparse's exit code: a torch.distributed.run without --local-addr (before torch 2.2).  The same rendezvous spelled
+        # out -- c10d store on a free loopback port (what --standalone sets up) -- without the flag
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--rdzv-backend=c10d", "--rdzv-endpoint=127.0.0.1:0",
+               f"--rdzv-id=otgan-{os.getpid()}", "--nnodes=1", f"--nproc-per-node={nranks}", script] + list(argv)
+        rc = subprocess.call(cmd, env=env)
+    return rc
 
 
 def world_size():
