@@ -7,6 +7,7 @@ fallback: CPU tensors raise OtganError.
 import ctypes
 import os
 import sys
+import weakref
 from collections import OrderedDict
 
 import torch
@@ -361,6 +362,21 @@ def join_side_stream(tensors=()):
             t.record_stream(cur)
 
 
+# The gated product a convolution wrote for the glu() that follows it (glu_hint) rides on the convolution's output as an
+# attribute until GluFunction.forward claims it.  A caller that passes the hint and then never applies glu to that very
+# tensor would keep the product alive as long as the output: the next convolution's forward pass drops it.
+_PENDING_GLU = [None]
+
+
+def _drop_unclaimed_glu():
+    ref = _PENDING_GLU[0]
+    if ref is not None:
+        t = ref()
+        if t is not None and hasattr(t, "_otgan_glu"):
+            del t._otgan_glu
+        _PENDING_GLU[0] = None
+
+
 # ------------------------------------------------------------------------------- conv2d / dense
 class Conv2dFunction(torch.autograd.Function):
     """y = conv2d(preact(upsample(x)), g*V/||V||) + b     (reference nn.py:327-338).
@@ -371,6 +387,7 @@ class Conv2dFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, V, g, b, stride, upsample, preact, segs, glu_hint=False, grow=0):
         _need_cuda(x, V, g, b)
+        _drop_unclaimed_glu()
         x = x.contiguous()
         N, H, W, C = x.shape
         # a dense layer passes its [Cin_eff, Cout] variable as is (a 1x1 filter): the weight cache is keyed by
@@ -452,6 +469,7 @@ class Conv2dFunction(torch.autograd.Function):
             if glu_rec is not None:
                 tag_amax(y_glu, glu_rec)
             y._otgan_glu = (y_glu, y._version)
+            _PENDING_GLU[0] = weakref.ref(y)
         desc.y_amax_out = None
         if ctx.x_rec is None:
             desc.x_amax = None
@@ -1367,6 +1385,7 @@ class GluFunction(torch.autograd.Function):
         if pre is not None and pre[1] == x._version:
             # the layer that produced x already wrote the gated product (Conv2dFunction, glu_hint)
             del x._otgan_glu
+            _PENDING_GLU[0] = None
             ctx.save_for_backward(x)
             return pre[0]
         y = torch.empty(x.shape[:-1] + (C2 // 2,), dtype=x.dtype, device=x.device)
