@@ -242,6 +242,47 @@ def secondary(dev, a):
     return sec
 
 
+def project_eight_ranks(gen_ms, disc_ms, sec, link_gbps=76.8):
+    """What the FIRST real 8-GPU line should look like, from this run's single-GPU measurements (a projection, never a
+    result; SURVEY 8e partitioning).  Per rank and step: the 1-GPU step with its N = 128 matching call replaced
+    by the rank-of-eight call at N = 1024 (measured here, `secondary.matching_block`), plus the exchanges over xGMI as a direct
+    exchange on the seven links (each 153.6 GB/s bidirectional = `link_gbps` per direction): a feature all-gather moves
+    33.5 MB per link, the cost-slice gather 3.1 MB, the gradient SUM 2 x 151 / 8 MB (reduce-scatter + all-gather).
+    `exposed`: milliseconds the compute stream waits; `hidden`: milliseconds that run under compute."""
+    cases = {(c["N"], c["D"], c["rows"]): c for c in sec.get("matching_block", {}).get("cases", [])}
+    one, rank8 = cases.get((128, 32768, "all")), cases.get((1024, 32768, 256))
+    if not one or not rank8 or "us_rank_generator_step" not in rank8:
+        return None
+    feat = 256 * 32768 * 4 / 1e6 / link_gbps                  # ms per feature all-gather (one 33.5 MB block per link)
+    slices = 3 * 256 * 1024 * 4 / 1e6 / link_gbps + 0.03      # + one small-message latency
+    red = {"gen": 2 * 151.0 / 8 / link_gbps, "disc": 2 * 138.0 / 8 / link_gbps}
+    out = {"link_GBps_per_direction": link_gbps, "steps": {}}
+    tot = {"serial": 0.0, "overlapped": 0.0}
+    for kind, ms1, w in (("gen", gen_ms, 5), ("disc", disc_ms, 1)):
+        if ms1 is None:
+            return None
+        extra = (rank8["us_rank_generator_step" if kind == "gen" else "us_rank_critic_step"] -
+                 one["us_grads_generator_step" if kind == "gen" else "us_grads_critic_step"]) / 1e3
+        # serial: both feature gathers, the slice gather and the whole all-reduce are waited for where they are issued.
+        # overlapped: a generator step hides the real features' gather under the generator + second critic pass, and both
+        # kinds hide three of the four gradient buckets under the backward pass (the last bucket leaves after it)
+        ser = 2 * feat + slices + red[kind]
+        ovl = (feat if kind == "gen" else 2 * feat) + slices + red[kind] / 4
+        out["steps"][kind] = {"ms_1gpu": round(ms1, 3), "matching_extra_ms": round(extra, 3),
+                              "serial": {"exposed_ms": round(ser, 3), "hidden_ms": 0.0, "step_ms": round(ms1 + extra + ser, 3)},
+                              "overlapped": {"exposed_ms": round(ovl, 3), "hidden_ms": round(ser - ovl, 3),
+                                             "step_ms": round(ms1 + extra + ovl, 3)}}
+        tot["serial"] += w * (ms1 + extra + ser) / 6
+        tot["overlapped"] += w * (ms1 + extra + ovl) / 6
+    base = (5 * gen_ms + disc_ms) / 6
+    for mode in tot:
+        out[mode] = {"ms_per_step": round(tot[mode], 3), "images_per_sec": round(8 * 256 / tot[mode] * 1e3, 0),
+                     "weak_scaling_efficiency": round(base / tot[mode], 3)}
+    out["note"] = ("PROJECTION from single-GPU measurements (no multi-GPU run exists): the replicated N = 1024 matching call is the "
+                   "largest non-scaling term; link rate is the per-direction xGMI figure, RCCL efficiency not modelled")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -421,9 +462,7 @@ def main():
                                 "note": "timed window starts on a critic step; the reference's schedule is 1 critic : "
                                         f"{args.nr_gen_per_disc} generator steps (train.py:24,214)"},
                    **({"collectives": "forced (RCCL, world size 1)"} if (world == 1 and model.collectives) else {}),
-                   "collectives_mode": (parallel.collectives_mode() + (" (default: no collective kernel runs beside the step's "
-                                        "kernels; OTGAN_OVERLAP_COLLECTIVES=1 opts into buckets inside the backward pass)"
-                                        if parallel.collectives_mode() == "serial" else " (opt-in)")
+                   "collectives_mode": (f"{model.collectives_mode}: {parallel.collectives_mode_reason()}"
                                         if model.collectives else "none (single process, no collectives)"),
                    **({"rank_times": {"per_rank": rank_times,
                                       "note": "separate pass of the same K steps with events around the exchange regions on each rank's "
@@ -458,6 +497,10 @@ def main():
         torch.cuda.empty_cache()
         out["secondary"] = secondary(dev, a)
         if default_cfg:
+            sm = out["config"]["step_mix"]
+            proj = project_eight_ranks(sm["generator_ms"], sm["critic_ms"], out["secondary"])
+            if proj is not None:
+                out["config"]["projected_8_ranks"] = proj
             # the headline configuration with the convolution GEMMs on three bf16 pieces per operand element (24
             # significand bits, six MFMAs per product: the scheme before the two-piece fp16 operands) -- a fresh process
             # (OTGAN_WINO_PIECES=3), the same unprofiled timing; not the headline, a reference point for the trade

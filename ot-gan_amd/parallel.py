@@ -114,24 +114,113 @@ def get_rank():
     return dist.get_rank() if dist.is_initialized() else 0
 
 
-def collectives_mode():
-    """'serial' or 'overlapped': may a collective's kernels run BESIDE the step's own kernels?
+# ---- may a collective run BESIDE the step's own kernels? ------------------------------------------------------------------
+# Overlapped: the gradient buckets leave inside the backward pass and the real features' all-gather runs under the generator's
+# forward pass (RCCL's stream next to the compute streams).  Serial: every collective is enqueued behind the compute that
+# precedes it and the compute stream waits for it before it continues, so no collective kernel is ever co-resident with a
+# kernel of this library.  DESIGN "Four hazards", item 3: kernels co-resident with the 256 x 128 GEMM were once seen computing
+# wrong values (root-caused to one packed-fp32 instruction form that the library no longer contains), and RCCL's own kernels
+# are not ours to recompile.  So the mode is DECIDED BY A MEASUREMENT at start-up (round 6): `resolve_collectives_mode` runs
+# RCCL collectives co-resident with the 256 x 128 GEMM, compares both sides bit for bit with their serial results, and picks
+# "overlapped" only when everything matches on every rank; anything else (a mismatch, an exception, gloo) is "serial".
+# OTGAN_COLLECTIVES=serial|overlapped pins the mode (no self-check); "auto" / unset = the guarded default.
+_MODE = {"mode": None, "why": "not resolved yet (serial until parallel.resolve_collectives_mode runs)"}
 
-    Overlapped: the gradient buckets leave inside the backward pass and the feature all-gather runs under the generator's
-    forward pass (RCCL's stream next to the compute stream).  Serial: every collective is enqueued behind the compute
-    that precedes it and the compute stream waits for it before it continues, so no collective kernel is ever
-    co-resident with a kernel of this library.  DESIGN section 3 "Four hazards", item 3: kernels co-resident with the
-    256 x 128 GEMM were seen computing wrong values, and RCCL's own kernels (not recompilable) have never run beside that
-    GEMM on the one-GPU boxes of this build -- so SERIAL IS THE DEFAULT on RCCL, and overlap is an explicit opt-in
-    (OTGAN_OVERLAP_COLLECTIVES=1) for whoever has verified a multi-GPU run against its single-GPU twin.
-    OTGAN_SERIAL_COLLECTIVES=1 (round 3's switch) still forces serial.  gloo (tests) stages through the host and is
-    synchronous either way."""
-    if os.environ.get("OTGAN_SERIAL_COLLECTIVES") == "1":
-        return "serial"
-    v = os.environ.get("OTGAN_OVERLAP_COLLECTIVES")
-    if v is not None and v != "":
-        return "overlapped" if v != "0" else "serial"
-    return "serial"
+
+def collectives_mode():
+    """'serial' or 'overlapped' (see above).  Before `resolve_collectives_mode` has run, 'auto' reads as 'serial'."""
+    v = os.environ.get("OTGAN_COLLECTIVES", "auto").strip().lower()
+    if v in ("serial", "overlapped"):
+        return v
+    return _MODE["mode"] or "serial"
+
+
+def collectives_mode_reason():
+    v = os.environ.get("OTGAN_COLLECTIVES", "auto").strip().lower()
+    if v in ("serial", "overlapped"):
+        return f"pinned by OTGAN_COLLECTIVES={v}"
+    return _MODE["why"]
+
+
+def resolve_collectives_mode(device=None, force=False):
+    """The guarded default: decide once per process (all ranks together) whether collectives may overlap compute.
+    Returns the mode.  No-op when the mode is pinned, already resolved, or no exchange will happen."""
+    v = os.environ.get("OTGAN_COLLECTIVES", "auto").strip().lower()
+    if v in ("serial", "overlapped"):
+        return v
+    if _MODE["mode"] is not None and not force:
+        return _MODE["mode"]
+    if _skip_collectives():
+        _MODE.update(mode="serial", why="no exchange (one rank, collectives not forced)")
+    elif _staged():
+        _MODE.update(mode="serial", why="gloo stages through host memory and is synchronous")
+    elif device is None or not torch.cuda.is_available():
+        _MODE.update(mode="serial", why="no device for the co-residency self-check")
+    else:
+        ok, why = overlap_self_check(device)
+        _MODE.update(mode="overlapped" if ok else "serial", why=why)
+    return _MODE["mode"]
+
+
+def overlap_self_check(device, rounds=3):
+    """RCCL collectives co-resident with the 256 x 128 split-precision GEMM, both checked bit for bit.
+
+    Per round: a SUM all-reduce of 64 MB and an all-gather of 8 MB per rank are started asynchronously (RCCL's stream) and
+    eight forward passes of a G.conv1-shaped layer (input transform, 256 x 128-tile GEMM, output transform: the kernels of a
+    training step) are enqueued on the compute stream while they run.  The layer's outputs must equal the output computed
+    with nothing else on the device; the collectives' results must equal their closed forms (rank r contributes
+    (r + 1) x small integers: the sum and every gathered row are exact in fp32).  The verdict is the minimum over ranks.
+    -> (ok, reason)."""
+    try:
+        from . import ops
+        w, r = world_size(), get_rank()
+        gen = torch.Generator(device=device).manual_seed(4321)
+        B, H, C, Cout = 128, 8, 512, 512
+        x = torch.randn(B, H, H, C, device=device, generator=gen)
+        V = torch.randn(5, 5, C, Cout, device=device, generator=gen) * 0.05
+        g = torch.ones(Cout, device=device)
+        b = torch.zeros(Cout, device=device)
+        conv = lambda: ops.conv2d_op(x, V, g, b, stride=1, upsample=True, preact=0)
+        n_red, n_gat = 1 << 24, 1 << 21
+        base = (torch.arange(n_red, device=device) % 1021).float()
+        ok = True
+        with torch.no_grad():
+            y_ref = conv().clone()
+            torch.cuda.synchronize(device)
+            for _ in range(rounds):
+                buf = base * float(r + 1)
+                mine = buf[:n_gat].clone()
+                out = torch.empty(w * n_gat, device=device)
+                w1 = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+                ys = [conv() for _ in range(4)]
+                w2 = dist.all_gather_into_tensor(out, mine, async_op=True)
+                ys += [conv() for _ in range(4)]
+                w1.wait()
+                w2.wait()
+                ok = ok and all(torch.equal(y, y_ref) for y in ys)
+                ok = ok and torch.equal(buf, base * float(w * (w + 1) // 2))
+                want = base[:n_gat][None, :] * torch.arange(1, w + 1, device=device, dtype=torch.float32)[:, None]
+                ok = ok and torch.equal(out.view(w, n_gat), want)
+        flag = torch.tensor([1.0 if ok else 0.0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        torch.cuda.synchronize(device)
+        if float(flag) == 1.0:
+            return True, (f"self-check passed on {w} rank(s): {rounds} x (64 MB all-reduce + all-gather) co-resident with 8 GEMM "
+                          "layers, all results bit-identical to the serial ones")
+        return False, "self-check FAILED (" + ("this rank" if not ok else "another rank") + " saw a mismatch): collectives stay serial"
+    except Exception as e:      # noqa: BLE001 -- never lose a run over the optimisation
+        return False, f"self-check raised {type(e).__name__}: {e}: collectives stay serial"
+
+
+class _NoCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_CTX = _NoCtx()
 
 
 def _staged():
@@ -165,6 +254,8 @@ class PendingGather:
         if self.work is not None:
             self.work.wait()
             self.work = None
+            if self.out.is_cuda:      # (the gather may have been started from another stream's context: used HERE from now on)
+                self.out.record_stream(torch.cuda.current_stream())
         return self.out
 
 
@@ -283,22 +374,40 @@ class GradBuckets:
     def _on_grad(self, i, g):
         if not self.armed:
             return None
-        self.views[i].copy_(g)
-        b = self.bucket_of[i]
-        self.left[b] -= 1
-        if self.left[b] == 0:
-            lo, hi = self.ranges[b]
-            seg = self.flat[lo:hi]
-            if _staged() and seg.is_cuda:      # gloo on device tensors (tests): through host memory
-                host = seg.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM)
-                seg.copy_(host)
-            elif collectives_mode() == "serial":
-                # no collective kernel beside the backward pass's kernels (collectives_mode): all buckets go out after
-                # the last gradient, in finish()
-                self.deferred.append(seg)
-            else:
-                self.works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
+        # With the layers' weight-gradient chains on a second stream (ops.SIDE_STREAM) a gradient handed to this hook may
+        # still be in flight THERE while the hook runs in the main stream's context.  The copy into the bucket and the
+        # bucket's all-reduce are therefore issued on the side stream, which first waits for the main stream's position
+        # (a gradient produced on the main stream -- a dense layer's, a bias' -- is covered by that; the weight-gradient
+        # chain of the NEXT layer depends on the main stream's input-gradient kernels up to here anyway, so the wait costs
+        # nothing).  The main stream is never made to wait for the side stream inside the backward pass.
+        side = None
+        if g.is_cuda:
+            from . import ops
+            side = ops.SIDE_STREAM
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            g.record_stream(side)
+            ctx = torch.cuda.stream(side)
+        else:
+            ctx = _NO_CTX
+        with ctx:
+            self.views[i].copy_(g)
+            b = self.bucket_of[i]
+            self.left[b] -= 1
+            if self.left[b] == 0:
+                lo, hi = self.ranges[b]
+                seg = self.flat[lo:hi]
+                if _staged() and seg.is_cuda:      # gloo on device tensors (tests): through host memory
+                    host = seg.cpu()
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                    seg.copy_(host)
+                elif collectives_mode() == "serial":
+                    # no collective kernel beside the backward pass's kernels (collectives_mode): all buckets go out after
+                    # the last gradient, in finish()
+                    self.deferred.append(seg)
+                else:
+                    # (the process group orders the collective behind the CURRENT stream: the side stream when there is one)
+                    self.works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
         return None
 
     def finish(self):

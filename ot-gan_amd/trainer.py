@@ -131,16 +131,16 @@ class OTGAN:
         if args.optimizer not in mk:
             raise ValueError("unsupported optimizer")
         kw = {"mom1": 0.5} if args.optimizer == "nesterov" else {"mom1": 0.5, "mom2": 0.999}
-        # The second stream (see below): single-process runs, and ranks whose collectives are SERIAL (the default): there
-        # the gradient buckets buy no overlap (every bucket leaves after the backward pass anyway), so the gradients are
-        # all-reduced through one flat buffer after the side stream has been joined.  With overlapped collectives
-        # (OTGAN_OVERLAP_COLLECTIVES=1) the bucket hooks read every gradient on the main stream as soon as autograd has it
-        # and the real features' all-gather runs under the generator: one stream, as before.
-        side_ok = (os.environ.get("OTGAN_SIDE_STREAM", "1") != "0" and
-                   (not self.collectives or parallel.collectives_mode() == "serial"))
-        # more than one rank, overlapped schedule: the gradient all-reduce runs bucket by bucket underneath the backward pass
-        # (OTGAN_GRAD_OVERLAP=0: one all-reduce after the backward pass instead)
-        overlap = self.collectives and os.environ.get("OTGAN_GRAD_OVERLAP", "1") != "0" and not side_ok
+        # Exchange schedule (parallel.collectives_mode; round 6: decided at start-up by a co-residency self-check on every rank
+        # -- RCCL collectives beside the 256 x 128 GEMM, bit-compared -- unless OTGAN_COLLECTIVES pins it).  "overlapped": the
+        # gradient all-reduce leaves bucket by bucket underneath the backward pass (parallel.GradBuckets) and the real
+        # features' all-gather starts right behind the critic's pass over the real batch; "serial": one flat all-reduce after
+        # the backward pass, every gather waited for where it is issued.  The second stream (below) runs in both.
+        if self.collectives:
+            parallel.resolve_collectives_mode(device)
+        self.collectives_mode = parallel.collectives_mode() if self.collectives else "none"
+        side_ok = os.environ.get("OTGAN_SIDE_STREAM", "1") != "0"
+        overlap = self.collectives and self.collectives_mode == "overlapped"
         self.disc_buckets = parallel.GradBuckets(self.disc_params) if overlap else None
         self.gen_buckets = parallel.GradBuckets(self.gen_params) if overlap else None
         self.gen_optimizer = mk[args.optimizer](self.gen_params, **kw)          # train.py:142
@@ -160,10 +160,11 @@ class OTGAN:
         # layers in front of it).  Same kernels, same arguments, bit-identical results (tests/test_side_stream_gpu.py); the
         # chains alternate HBM-bound transforms and matrix-bound GEMMs and, on one in-order stream, every kernel also waits
         # for its predecessor's last workgroup: A/B/A/B on one box 8.95 / 8.96 -> 8.48 / 8.50 ms per DCGAN step, DenseNet
-        # 29.2 -> 27.4 ms (profiles/r05_side_stream_ab.txt).  Off with overlapped collectives and under step graphs.
+        # 29.2 -> 27.4 ms (profiles/r05_side_stream_ab.txt).  Off under step graphs.  With overlapped collectives the bucket
+        # hooks copy and all-reduce on the side stream (parallel.GradBuckets._on_grad) and the real features' all-gather is
+        # issued from it (below): the main stream never waits for the side stream inside a pass.
         on = side_ok
-        self.fork_real_pass = on and os.environ.get("OTGAN_FORK_REAL", "1") != "0"
-        self.fork_wgrad = on and os.environ.get("OTGAN_FORK_WGRAD", "1") != "0"
+        self.fork_real_pass = self.fork_wgrad = on
         self._side_stream = torch.cuda.Stream(device=device) if on else None
         # whole steps as hipGraphs (opt-in: --step_graph / OTGAN_STEP_GRAPH=1; measured SLOWER than stream launches on this
         # stack, see GraphedSteps): single-process runs only (gloo cannot be captured; RCCL under capture is untested here)
@@ -406,8 +407,13 @@ class OTGAN:
                 side.wait_stream(main)
                 with torch.cuda.stream(side), torch.no_grad():
                     f_dat = self.discriminator(x_data, **self.model_opts)
+                    # overlapped schedule: the real features are final here -- their all-gather starts now, ordered behind
+                    # the side stream, and runs under the generator's forward pass and the second critic pass
+                    pending = None
+                    if self.collectives_mode == "overlapped" and (self.scope == "global" or self.world == 1):
+                        with self._timed("allgather_early"):
+                            pending = parallel.all_gather_rows_async(f_dat)
                 f_dat.record_stream(main)
-                pending = None
                 x_gen = self.generator(batch_size=self.nb, device=self.device, **gkw)
                 main.wait_stream(side)
             else:
@@ -417,8 +423,7 @@ class OTGAN:
                 # generator forward and the second critic pass
                 with self._timed("allgather_early"):
                     pending = (parallel.all_gather_rows_async(f_dat)
-                               if (self.scope == "global" and self.world > 1) or (self.collectives and self.world == 1)
-                               else None)
+                               if self.collectives and (self.scope == "global" or self.world == 1) else None)
                 x_gen = self.generator(batch_size=self.nb, device=self.device, **gkw)
             # only the generator's variables are differentiated in this step (train.py:112): run the critic with
             # its variables frozen, so that its layers skip their weight gradients (autograd's needs_input_grad
@@ -585,8 +590,27 @@ class GraphedSteps:
         opt.t += 1.0
         m.step_counter += 1
         m._d_weights_in_graph = kind != "disc"
-        ops.bump_weights_epoch()            # the host caches describe capture time, not this replay: eager users recompute
+        self._bump_written(kind)
         return {"kind": "disc" if kind == "disc" else "gen", "distance": dist, "entropy": ent}
+
+    def _bump_written(self, kind):
+        """The host-side effect of the replayed optimiser step: invalidate the cached operands of the network it updated
+        (and of the EMA shadows a generator step moves) -- what ops.adam_step_gather does in an eager step.  The OTHER
+        network's cached operands stay valid: they are the tensors a graph of this period wrote ("gen1" for the critic), which
+        is what lets "gen" and "disc" be captured reading them.  (Until round 6 this bumped the global epoch: every kind was
+        then captured with the critic's cache invalid and recomputed the critic's normalised weights and Winograd filters
+        in every replay -- more work than the eager step it was measured against)"""
+        from . import ops
+        m = self.m
+        ts = list(m.disc_params if kind == "disc" else m.gen_params)
+        if kind != "disc":
+            ts += [m.ema.average(p) for p in m.gen_params]
+        seen = set()
+        for t in ts:
+            key = t.untyped_storage().data_ptr()
+            if key not in seen:
+                seen.add(key)
+                ops.bump_weights_epoch(t)
 
     def _capture(self, x_data, kind):
         from . import ops

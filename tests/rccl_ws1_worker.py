@@ -48,10 +48,11 @@ def run(force):
     args = default_args(model="dcgan", batch_size=4, nr_gpu=2, sinkhorn_lambda=100.0, nr_sinkhorn_iter=10,
                         nr_gen_per_disc=1, seed=5)
     m = OTGAN(args, dev)
-    # (round 5: with serial collectives -- the default -- a rank runs the two-stream schedule and all-reduces one flat buffer
-    # after the backward pass; the gradient buckets exist in the overlapped schedule)
-    assert m.collectives == force and (m.gen_buckets is not None) == (force and not m.fork_wgrad)
-    assert m.fork_wgrad == (parallel.collectives_mode() == "serial" or not force)
+    # (round 6: the two-stream schedule runs in BOTH exchange schedules; serial all-reduces one flat buffer after the backward
+    # pass, overlapped sends gradient buckets from the side stream inside it and gathers the real features under the generator)
+    assert m.collectives == force and (m.gen_buckets is not None) == (force and parallel.collectives_mode() == "overlapped")
+    assert m.fork_wgrad and m.fork_real_pass
+    assert m.collectives_mode == (parallel.collectives_mode() if force else "none")
     g = torch.Generator().manual_seed(3)
     xd = (torch.rand(m.nb, 32, 32, 3, generator=g) * 2 - 1).to(dev)
     u = (torch.rand(m.nb, 100, generator=g) * 2 - 1).to(dev)
@@ -66,15 +67,29 @@ def run(force):
     m.close()
     return out
 
-os.environ.pop("OTGAN_OVERLAP_COLLECTIVES", None)
-os.environ.pop("OTGAN_SERIAL_COLLECTIVES", None)
-assert parallel.collectives_mode() == "serial"           # the default on RCCL: no collective kernel beside the step's kernels
+os.environ["OTGAN_COLLECTIVES"] = "serial"               # pinned: no collective kernel beside the step's kernels
+assert parallel.collectives_mode() == "serial"
 a, b = run(True), run(False)
-os.environ["OTGAN_OVERLAP_COLLECTIVES"] = "1"            # opt-in: buckets inside the backward pass, gather under the generator
+os.environ["OTGAN_COLLECTIVES"] = "overlapped"           # pinned: buckets inside the backward pass, gather under the generator
 assert parallel.collectives_mode() == "overlapped"
 c = run(True)
-os.environ.pop("OTGAN_OVERLAP_COLLECTIVES")
-for other in (a, c):
+# the guarded default: the trainer's start-up self-check (RCCL collectives co-resident with the 256 x 128 GEMM, bit-compared)
+# passes on a healthy device and selects the overlapped schedule; a forced failure falls back to serial and says so
+os.environ["OTGAN_COLLECTIVES"] = "auto"
+parallel._MODE["mode"] = None
+os.environ["OTGAN_FORCE_COLLECTIVES"] = "1"
+ok, why = parallel.overlap_self_check(dev)
+assert ok and "bit-identical" in why, why
+d = run(True)
+assert parallel.collectives_mode() == "overlapped" and "self-check passed" in parallel.collectives_mode_reason()
+real_check = parallel.overlap_self_check
+parallel.overlap_self_check = lambda device, rounds=3: (False, "self-check FAILED (injected by the test): collectives stay serial")
+parallel._MODE["mode"] = None
+e = run(True)
+assert parallel.collectives_mode() == "serial" and "FAILED" in parallel.collectives_mode_reason()
+parallel.overlap_self_check = real_check
+parallel._MODE["mode"] = None
+for other in (a, c, d, e):
     for (ga, da), (gb_, db) in zip(other, b):
         assert abs(da - db) <= 1e-12 * abs(db), (da, db)     # fp64 atomics in the distance reduction: order-dependent last bits
         assert all(torch.equal(s, t) for s, t in zip(ga, gb_))

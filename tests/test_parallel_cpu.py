@@ -86,13 +86,8 @@ def _worker(rank, world, port, out):
 
 @pytest.mark.parametrize("serial", [False, True], ids=["overlapped", "serial_collectives"])
 def test_two_rank_plumbing_gloo(serial, monkeypatch):
-    # serial (the default, parallel.collectives_mode): the gradient buckets go out after the backward pass instead of
-    # inside it; overlapped: OTGAN_OVERLAP_COLLECTIVES=1
-    monkeypatch.delenv("OTGAN_SERIAL_COLLECTIVES", raising=False)
-    if serial:
-        monkeypatch.delenv("OTGAN_OVERLAP_COLLECTIVES", raising=False)
-    else:
-        monkeypatch.setenv("OTGAN_OVERLAP_COLLECTIVES", "1")
+    # serial (parallel.collectives_mode): the gradient buckets go out after the backward pass instead of inside it
+    monkeypatch.setenv("OTGAN_COLLECTIVES", "serial" if serial else "overlapped")
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
@@ -107,18 +102,22 @@ def test_two_rank_plumbing_gloo(serial, monkeypatch):
     assert got == [(0, True), (1, True)]
 
 
-def test_collectives_are_serial_unless_overlap_is_asked_for(monkeypatch):
+def test_collectives_mode_is_guarded(monkeypatch):
+    """Round 6: the mode is pinned by OTGAN_COLLECTIVES or decided by the start-up self-check; until that has run -- and whenever it
+    cannot run (one rank without forced collectives, gloo, no device) -- 'auto' means serial."""
     from otgan_amd import parallel
-    monkeypatch.delenv("OTGAN_SERIAL_COLLECTIVES", raising=False)
-    monkeypatch.delenv("OTGAN_OVERLAP_COLLECTIVES", raising=False)
+    monkeypatch.delenv("OTGAN_COLLECTIVES", raising=False)
+    monkeypatch.setitem(parallel._MODE, "mode", None)
     assert parallel.collectives_mode() == "serial"
-    monkeypatch.setenv("OTGAN_OVERLAP_COLLECTIVES", "1")
+    assert parallel.resolve_collectives_mode(None) == "serial" and "no exchange" in parallel.collectives_mode_reason()
+    monkeypatch.setenv("OTGAN_COLLECTIVES", "overlapped")
+    assert parallel.collectives_mode() == "overlapped" and parallel.resolve_collectives_mode(None) == "overlapped"
+    assert "pinned" in parallel.collectives_mode_reason()
+    monkeypatch.setenv("OTGAN_COLLECTIVES", "serial")
+    assert parallel.collectives_mode() == "serial"
+    monkeypatch.setenv("OTGAN_COLLECTIVES", "auto")
+    monkeypatch.setitem(parallel._MODE, "mode", "overlapped")     # what a passed self-check leaves
     assert parallel.collectives_mode() == "overlapped"
-    monkeypatch.setenv("OTGAN_SERIAL_COLLECTIVES", "1")         # round 3's switch wins
-    assert parallel.collectives_mode() == "serial"
-    monkeypatch.delenv("OTGAN_SERIAL_COLLECTIVES")
-    monkeypatch.setenv("OTGAN_OVERLAP_COLLECTIVES", "0")
-    assert parallel.collectives_mode() == "serial"
 
 
 def test_single_process_passthrough():
