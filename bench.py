@@ -356,12 +356,9 @@ def main():
     ms0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
     marks[0].record()
-    _dbg = os.environ.get("OTGAN_BENCH_ALLOC_DEBUG") == "1"
     for i in range(a.steps):
         last = model.step(x)
         marks[i + 1].record()
-        if _dbg:
-            print("step", i, torch.cuda.memory_stats(dev)["num_device_alloc"], file=sys.stderr)
     torch.cuda.synchronize()
     parallel.barrier()
     dt = time.perf_counter() - t0

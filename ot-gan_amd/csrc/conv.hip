@@ -3053,8 +3053,7 @@ int otgan_conv2d_fwd_pf_f32(const otgan_conv_desc* d, const float* x, const int3
 int otgan_conv2d_glu_fused(const otgan_conv_desc* d) {
   Geo g;
   if (!d || make_geo(d, &g) != OTGAN_OK) return 0;
-  static const bool off = getenv("OTGAN_WINO_GLU_FUSED") && getenv("OTGAN_WINO_GLU_FUSED")[0] == '0';
-  return !off && wino_ok(d, g) && d->Cout % 8 == 0 && d->y_coff == 0 && d->ldy == d->Cout && !d->y_accumulate;
+  return wino_ok(d, g) && d->Cout % 8 == 0 && d->y_coff == 0 && d->ldy == d->Cout && !d->y_accumulate;
 }
 
 static int conv2d_fwd_body(const otgan_conv_desc* d, const float* x, const int32_t* cmap, const float* wT,

@@ -209,14 +209,20 @@ def absmax_record(t):
 # kernel that writes the tensor -- GLU forward / backward, the output transforms of the strided layers, the RGB-in
 # layer, the feature head's backward -- leaves it in a zeroed slot, and the tensor carries the slot to its consumer
 # as a Python attribute (checked against the tensor's version counter; a tensor that arrives without one, e.g.
-# through a view or from outside, is reduced as before).  OTGAN_FUSED_AMAX=0 disables the producers.
+# through a view or from outside, is reduced as before).
 AMAX_RECORD_FLOATS = 512     # otgan_layers.h: OTGAN_AMAX_RECORD_FLOATS
 _AMAX_SLOTS = 256
 _amax_pool = {}       # device -> [zeroed [slots, AMAX_RECORD_FLOATS] tensor, next free slot]
-_FUSED_AMAX = os.environ.get("OTGAN_FUSED_AMAX", "1") != "0"
-_GLU_COLSUM = os.environ.get("OTGAN_GLU_COLSUM", "1") != "0"
-_GLU_FUSED = os.environ.get("OTGAN_WINO_GLU_FUSED", "1") != "0"
-_GRAD_INPLACE = os.environ.get("OTGAN_DENSE_GRAD_INPLACE", "1") != "0"   # DenseBlockFunction.backward   # (the library reads the same switch)
+# Constants since round 6 (they were OTGAN_* environment switches while each mechanism was being A/B-ed; the measurements are in
+# DESIGN / docs/history).  Tests that compare a mechanism with its predecessor patch the attribute in-process.
+_FUSED_AMAX = True        # producers leave the amax record of what they write
+_GLU_COLSUM = True        # the gate's backward kernel also leaves the column sums (bias gradient) of what it writes
+_GLU_FUSED = True         # the Winograd output transform writes the gated product beside y
+_GRAD_INPLACE = True      # DenseBlockFunction.backward walks ONE gradient buffer
+DENSE_SPLIT = True        # dense blocks: block input and finished halves through wide Winograd convolutions (_split_block_plan)
+DENSE_GROUP = None        # growth outputs per wide convolution; None = half the block
+DENSE_AMAX = True         # one record array per dense block, filled by the kernels that write its channels
+WN_BATCHED = True         # one weight-norm launch per dense block
 
 
 def colsum_of(t):
@@ -378,6 +384,18 @@ def _drop_unclaimed_glu():
 
 
 # ------------------------------------------------------------------------------- conv2d / dense
+# Test instrumentation (tests/test_dist_gpu.py): a list here makes every layer with a ReLU-type pre-activation and the feature
+# head append the sign pattern of its input (a CPU bool tensor per call, in call order).  Two fp32 evaluations of one step
+# agree to rounding EXCEPT where a pre-activation that is zero to rounding lands on different sides: the unit's gradient then
+# switches branches (CReLU: [relu(x), relu(-x)], nn.py:198-200) -- counting those units separates arithmetic from flips.
+SIGN_TRACE = None
+
+
+def _trace_signs(x):
+    if SIGN_TRACE is not None:
+        SIGN_TRACE.append((x.detach() > 0).cpu())
+
+
 class Conv2dFunction(torch.autograd.Function):
     """y = conv2d(preact(upsample(x)), g*V/||V||) + b     (reference nn.py:327-338).
 
@@ -389,6 +407,8 @@ class Conv2dFunction(torch.autograd.Function):
         _need_cuda(x, V, g, b)
         _drop_unclaimed_glu()
         x = x.contiguous()
+        if preact in (1, 4):
+            _trace_signs(x)
         N, H, W, C = x.shape
         # a dense layer passes its [Cin_eff, Cout] variable as is (a 1x1 filter): the weight cache is keyed by
         # the parameter OBJECT, so a fresh .view() per call would miss every time and pin a new entry
@@ -798,12 +818,11 @@ def _split_block_plan(N, H, W, C0, L, F, segs0, preact, device):
     channel), so the share of a FINISHED channel group in all later layers is one 3x3 convolution group -> (later
     layers) * F, wide enough for the Winograd F(4x4,3x3) passes:
       * the block input (C0 channels) into all L layers, before the chain starts;
-      * every group of `OTGAN_DENSE_GROUP` (default L/2: the first half into the second half) consecutive growth outputs
+      * every group of `DENSE_GROUP` (default L/2: the first half into the second half) consecutive growth outputs
         into all layers after the group, once its last layer is done -- as long as the library takes that convolution
         on its Winograd path.
     What stays on the 16-output growth kernels is each layer's chain inside its own group."""
-    import os
-    if os.environ.get("OTGAN_DENSE_SPLIT", "1") == "0" or F != 16 or L < 2 or any(int(c) % 4 for c in segs0):
+    if not DENSE_SPLIT or F != 16 or L < 2 or any(int(c) % 4 for c in segs0):
         return None
     mult = 2 if preact in DOUBLED else 1
     Ctot = C0 + L * F
@@ -815,7 +834,7 @@ def _split_block_plan(N, H, W, C0, L, F, segs0, preact, device):
              "order": _input_row_order(segs0, preact, device), "accumulate": 0, "after": -1}]
     # measured on the DenseNet step (L = 16): halves 51.9 ms, groups of four 52.9 (with 64-column convolutions allowed
     # 53.5), pairs 60.7, block input only 58.2 -- a wide convolution with K = 128 is bound by its transforms
-    group = int(os.environ.get("OTGAN_DENSE_GROUP", str((L + 1) // 2)))
+    group = (L + 1) // 2 if DENSE_GROUP is None else int(DENSE_GROUP)
     g0 = [0] * L          # growth outputs [0, g0[k]) reach layer k through wide convolutions
     for s0 in range(0, L, group) if group > 0 else ():
         s1 = min(s0 + group, L)
@@ -835,7 +854,7 @@ def _split_block_plan(N, H, W, C0, L, F, segs0, preact, device):
     # the chains on the two-scaled-fp16-piece kernel (CReLU, 16-channel list elements; otgan_layers.h: list_width)
     probe = ConvDesc(N, H, W, F, Ctot, 0, 3, 3, 1, F, Ctot, C0, preact, 1)
     probe.y_accumulate, probe.list_width = 1, F
-    h2 = bool(lib.otgan_dense16_h2_ok(ctypes.byref(probe))) and os.environ.get("OTGAN_DENSE_AMAX", "1") != "0" and _FUSED_AMAX
+    h2 = bool(lib.otgan_dense16_h2_ok(ctypes.byref(probe))) and DENSE_AMAX and _FUSED_AMAX
     # the library prepares at most OTGAN_DENSE16_MAX_BATCH chain layers per call (forward and by-slice backward filters) and
     # a chain call takes at most 17 slices per group: longer blocks / groups (layers_per_block > 18 at the default grouping)
     # keep the fp32 growth kernels
@@ -870,8 +889,8 @@ def _calibrate_backward_arg_refs():
 
 
 _BACKWARD_ARG_REFS = _calibrate_backward_arg_refs()
-# OTGAN_GROW=0 (test / A-B knob): convolutions ignore `grow`, dense blocks copy their input into their own buffer as before round 5
-_GROW_IN_PLACE = os.environ.get("OTGAN_GROW", "1") != "0"
+# False (tests): convolutions ignore `grow`, dense blocks copy their input into their own buffer as before round 5
+_GROW_IN_PLACE = True
 
 
 class DenseBlockFunction(torch.autograd.Function):
@@ -917,7 +936,7 @@ class DenseBlockFunction(torch.autograd.Function):
             assert tuple(V.shape) == (ksize, ksize, (C0 + k * F) * mult, F), (V.shape, C0 + k * F, mult)
             V2ds.append(V.contiguous().view(-1, F))
         gs = list(params[1::3])
-        ctx.batched = F == 16 and ksize == 3 and _aligned16(*V2ds, *gs) and os.environ.get("OTGAN_WN_BATCHED", "1") != "0"
+        ctx.batched = F == 16 and ksize == 3 and _aligned16(*V2ds, *gs) and WN_BATCHED
         batch = []
 
         def normalised(k):
@@ -948,11 +967,11 @@ class DenseBlockFunction(torch.autograd.Function):
             bias_all = sw["bias_all"]
             rows = N * H * W
             ctx.x_recs, ctx.x_ops = [], []
-            # amax records without extra passes (OTGAN_DENSE_AMAX=0: one reduction per slice, as in round 2): every kernel
+            # amax records without extra passes (DENSE_AMAX False: one reduction per slice, as in round 2): every kernel
             # that writes growth channels -- the wide convolutions (the second one adds onto the first) and the 16-output
             # kernels of the chains -- leaves the largest magnitude of the values it writes in a record (layout below);
             # the block's output carries max(record of x0, all of them) for the transition that reads the whole buffer.
-            shared = os.environ.get("OTGAN_DENSE_AMAX", "1") != "0" and _FUSED_AMAX
+            shared = DENSE_AMAX and _FUSED_AMAX
             rec_x0 = amax_of(x0) if shared else None
             # round 4: ONE zeroed array of records per block.  Group i (the layers between two wide convolutions) owns
             # rows [gbase(i), gbase(i + 1)): first the record of the sums the group's wide convolution leaves in the
@@ -1095,8 +1114,7 @@ class DenseBlockFunction(torch.autograd.Function):
         grads = [None] * (3 * L)
         rows = N * H * W
         plan = ctx.plan
-        if (plan is not None and plan.get("h2") and ctx.batched and len(plan["wide"]) <= 2 and
-                os.environ.get("OTGAN_DENSE16_BWD_H2", "1") != "0"):
+        if plan is not None and plan.get("h2") and ctx.batched and len(plan["wide"]) <= 2:
             grads = DenseBlockFunction._backward_by_slice(ctx, buf, saved, G, dbuf, need_w)
             dx0 = _block_input_grad(G, C0) if ctx.needs_input_grad[0] else None
             if dx0 is not None and _FUSED_AMAX and C0 % 4 == 0:
@@ -1450,6 +1468,7 @@ class FeatureHeadFunction(torch.autograd.Function):
     def forward(ctx, x):
         _need_cuda(x)
         x = x.contiguous()
+        _trace_signs(x)
         N, H, W, C = x.shape
         f = torch.empty((N, H * W * 2 * C), dtype=x.dtype, device=x.device)
         norm = torch.empty(N, dtype=x.dtype, device=x.device)

@@ -66,9 +66,10 @@ def build_parser():
     p.add_argument('--inception_model', type=str, default='',
                    help='TorchScript classifier (float32 images [n,H,W,3] in 0..255 -> class probabilities); without it the '
                         'Inception-score hook is skipped (the reference downloads the 2015 Inception graph)')
-    p.add_argument('--step_graph', action='store_true',
+    p.add_argument('--step_graph', type=int, nargs='?', const=1, default=None, choices=(0, 1),
                    help='replay whole steps as hipGraphs after the first period (single-process runs; bit-identical to the '
-                        'eager steps, measured 3 - 6 %% slower than stream launches on MI355X / ROCm 7: off by default)')
+                        'eager steps).  Default: on for --model densenet (launch-bound: replay 25.5 ms against 27.6 - 29.6 ms), '
+                        'off for dcgan (8.60 against 8.52 - 8.56 ms); --step_graph / --step_graph 1 forces it on, --step_graph 0 off')
     return p
 
 

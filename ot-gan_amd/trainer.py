@@ -150,7 +150,7 @@ class OTGAN:
         self.step_counter = 0
         self.last = {}
         import collections
-        self._max_ahead = int(os.environ.get("OTGAN_MAX_STEPS_AHEAD", "2"))
+        self._max_ahead = 2          # steps the host may run ahead of the device (_throttle; 0 = unbounded)
         self._step_ends, self._free_events = collections.deque(), []
         self.timers = None        # name -> [(start event, end event)]; see enable_timers()
         self._d_weights_in_graph = False
@@ -166,14 +166,14 @@ class OTGAN:
         on = side_ok
         self.fork_real_pass = self.fork_wgrad = on
         self._side_stream = torch.cuda.Stream(device=device) if on else None
-        # whole steps as hipGraphs (opt-in: --step_graph / OTGAN_STEP_GRAPH=1; measured SLOWER than stream launches on this
-        # stack, see GraphedSteps): single-process runs only (gloo cannot be captured; RCCL under capture is untested here)
-        want = bool(getattr(args, "step_graph", False)) or os.environ.get("OTGAN_STEP_GRAPH", "0") == "1"
-        if os.environ.get("OTGAN_STEP_GRAPH") == "0":
-            want = False
+        # Whole steps as hipGraphs (GraphedSteps).  Default since round 6: ON for --model densenet (a launch-bound step: ~600
+        # launches, replay 25.5 ms against 27.6 - 29.6 ms eager), OFF for dcgan (replay 8.60 ms against 8.52 - 8.56 ms eager);
+        # --step_graph / OTGAN_STEP_GRAPH=1 force it on, OTGAN_STEP_GRAPH=0 off.  Single-process runs only (gloo cannot be
+        # captured; RCCL under capture is untested here).  The second stream's chains are captured with the step.
+        env = os.environ.get("OTGAN_STEP_GRAPH")
+        asked = getattr(args, "step_graph", None)
+        want = (env == "1") if env in ("0", "1") else (args.model == "densenet" if asked is None else bool(asked))
         self.graphs = GraphedSteps(self) if (want and not self.collectives and self.world == 1) else None
-        if self.graphs is not None:          # (a capture records ONE stream's launches)
-            self.fork_real_pass = self.fork_wgrad = False
 
     # ---------------------------------------------------------------- per-region step times (bench.py, ranks > 1)
     def enable_timers(self, on=True):
@@ -296,7 +296,7 @@ class OTGAN:
         `noise` (tests) replaces the generator's own latent draw; `apply_updates=False`
         (tests) leaves the parameters untouched and returns the summed gradients.
 
-        With `args.step_graph` (opt-in, single-process runs) the step is captured in a hipGraph per step kind after one
+        With step graphs (single-process runs; default for densenet) the step is captured in a hipGraph per step kind after one
         eager period and replayed (GraphedSteps below): the same launches with the same arguments."""
         assert x_data.shape[0] == self.nb
         period = self.args.nr_gen_per_disc + 1
@@ -324,7 +324,7 @@ class OTGAN:
             self.last["grads"] = grads
         return self.last
 
-    # The host never gets more than `_max_ahead` steps ahead of the device (default 2; OTGAN_MAX_STEPS_AHEAD=0: unbounded).  With
+    # The host never gets more than `_max_ahead` steps ahead of the device (default 2; 0: unbounded).  With
     # two streams a tensor that the other stream has used (record_stream) returns to torch's caching allocator only once
     # that stream's work on it has COMPLETED; a host that enqueues step after step never sees those completions and the
     # allocator answers with fresh hipMallocs -- four per step for the first ~150 steps of a run (bench.py: 120 device
@@ -530,12 +530,14 @@ class GraphedSteps:
     records like the eager step does.  Any failure to capture disables the graphs with a warning; the eager step is
     always available.
 
-    OFF BY DEFAULT (`--step_graph`, OTGAN_STEP_GRAPH=1 to opt in).  Measured in round 5 on one box, A/B/A/B, replay against
-    eager launches: DCGAN 9.38 / 9.38 ms against 8.80 / 8.79 ms per step (-6 %), DenseNet 29.29 / 29.34 against 28.41 / 28.44
-    (-3 %).  The step is not launch-bound outside a tracer (kernel time 0.91 of the wall clock in the eager profiled pass),
-    and the runtime's graph launch orders every node behind its predecessor, where stream launches let a kernel's first
-    workgroups start under the previous kernel's tail.  What the capture is good for: the bit-identity it proves (a replay
-    of the recorded launches IS the step -- no host-side value leaks into the arithmetic) and boxes whose host is slow."""
+    DEFAULT FOR DENSENET, off for DCGAN (`--step_graph [0|1]`, OTGAN_STEP_GRAPH=0/1 override).  Measured in round 6 on one box
+    (profiles/r06_step_graph_two_stream_ab.txt; eager / replay with one stream / replay with both streams' chains captured):
+    DenseNet 27.6 - 29.6 / 27.2 / 25.5 ms per step -- the step is ~600 launches, each behind Python, ctypes and the autograd
+    engine, and the eager figure moves by 2 ms from run to run with the host; DCGAN 8.52 - 8.56 / 8.90 / 8.60 ms -- ~130 launches,
+    not launch-bound, and the runtime's graph launch orders every node behind its predecessors where stream launches let a
+    kernel's first workgroups start under the previous kernel's tail.  (Round 5 measured replays 3 - 6 % SLOWER on both models:
+    every replay then recomputed the critic's normalised weights and Winograd filters -- `_bump_written` -- and the capture
+    held one stream.)"""
 
     def __init__(self, model):
         self.m = model
@@ -632,9 +634,14 @@ class GraphedSteps:
         g = torch.cuda.CUDAGraph()
         try:
             m.gen_optimizer.capturing = m.disc_optimizer.capturing = True      # Adam reads its bias corrections from coef_dev
+            # the second stream's chains are captured with the step: the side stream joins the capture where the step forks
+            # (wait_stream on the capturing stream) and every fork is joined before the step ends, so the graph holds two
+            # parallel branches wherever the eager step runs two streams
+            ops.SIDE_STREAM = m._side_stream if m.fork_wgrad else None
             with torch.cuda.graph(g, stream=self.stream):
                 dist, ent, _ = m._step_body(self.x, "disc" if kind == "disc" else "gen")
         finally:
+            ops.SIDE_STREAM = None
             m.gen_optimizer.capturing = m.disc_optimizer.capturing = False
             m.gen_optimizer.t, m.disc_optimizer.t = saved_t      # (the capture only recorded the launches)
             ops.reset_amax_pool()                                 # eager code must not draw from the graph's pool
@@ -664,8 +671,7 @@ def rank_stack_ok(nb, allg):
     """Does the one-split-per-step path (matching.FeatureStack) take a rank with `nb` rows of the gathered [2N, D] features?
     (The split-precision matching engine's shapes: N >= 256, D % 32 == 0, a rank's row slice at least one 256-row tile.)"""
     N, D = allg.shape[0] // 2, allg.shape[1]
-    return (os.environ.get("OTGAN_MATCH_STACK", "1") != "0" and nb >= 256 and nb % 32 == 0 and N % nb == 0 and
-            matching.FeatureStack.supported(N, D))
+    return nb >= 256 and nb % 32 == 0 and N % nb == 0 and matching.FeatureStack.supported(N, D)
 
 
 def rank_matching_stack(rank, world, nb, allg, alld, lam, iters, need_dat, gather=None):
@@ -732,7 +738,7 @@ def default_args(**over):
              load_params=False, model_name='med_gan_params-2399', no_sinkhorn=False,
              image_size=32, matching_scope='global', synthetic=False, max_steps=0, save_every=200,
              synthetic_size=50000, data_dependent_init=False, eval_every=100, eval_samples=50000,
-             inception_model='', ranks=0, step_graph=False)
+             inception_model='', ranks=0, step_graph=None)
     d.update(over)
     return argparse.Namespace(**d)
 

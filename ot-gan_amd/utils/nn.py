@@ -467,13 +467,11 @@ class _Adam(_Updates):
         flat = getattr(ema, "_flat", None)
         if self.group is None or flat is None or flat[1] is not self.group or len(self.params) > ops.ADAM_MAX_SEGMENTS:
             return False
-        if os.environ.get("OTGAN_ADAM_GATHER", "1") == "0":      # the escape hatch keeps the separate EMA launch
-            return False
         self._ema = ema
         return True
 
     def _step_gather(self, grads, lr):
-        if len(self.params) > ops.ADAM_MAX_SEGMENTS or os.environ.get("OTGAN_ADAM_GATHER", "1") == "0":
+        if len(self.params) > ops.ADAM_MAX_SEGMENTS:
             if self._ema is not None:       # (the caller was told the shadows are ours)
                 raise RuntimeError("fused EMA needs the gathered Adam step")
             return False

@@ -28,8 +28,7 @@ def test_row_order_is_the_reference_interleave():
 
 @pytest.mark.parametrize("C0,segs0,H", [(224, (208, 16), 32), (160, (144, 16), 16), (144, (144,), 16), (200, (200,), 8), (32, (32,), 32)])
 def test_densenet_blocks_are_cut_into_input_and_halves(C0, segs0, H, monkeypatch):
-    for k in ("OTGAN_DENSE_SPLIT", "OTGAN_DENSE_GROUP", "OTGAN_PLAIN3_MIN_CEFF", "OTGAN_PLAIN3_MIN_COUT", "OTGAN_DISABLE_WINOGRAD"):
-        monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("OTGAN_DISABLE_WINOGRAD", raising=False)
     L, F = 16, 16
     plan = ops._split_block_plan(256, H, H, C0, L, F, segs0, ops.ACT["crelu"], CPU)
     assert plan is not None and len(plan["wide"]) == 2
@@ -50,16 +49,15 @@ def test_densenet_blocks_are_cut_into_input_and_halves(C0, segs0, H, monkeypatch
 
 
 def test_blocks_that_are_not_cut(monkeypatch):
-    monkeypatch.delenv("OTGAN_DENSE_SPLIT", raising=False)
     act = ops.ACT["crelu"]
     assert ops._split_block_plan(8, 8, 8, 32, 2, 16, (32,), act, CPU) is None            # 2 layers: 32 columns, too narrow
     assert ops._split_block_plan(8, 8, 8, 32, 16, 12, (32,), act, CPU) is None           # growth rate other than 16
     assert ops._split_block_plan(8, 8, 8, 30, 16, 16, (22, 8), act, CPU) is None         # list widths not multiples of 4
     assert ops._split_block_plan(8, 6, 6, 32, 16, 16, (32,), act, CPU) is None           # 6x6 is not tiled by 4x4
-    monkeypatch.setenv("OTGAN_DENSE_SPLIT", "0")
+    monkeypatch.setattr(ops, "DENSE_SPLIT", False)
     assert ops._split_block_plan(8, 8, 8, 32, 16, 16, (32,), act, CPU) is None
-    monkeypatch.delenv("OTGAN_DENSE_SPLIT")
-    monkeypatch.setenv("OTGAN_DENSE_GROUP", "0")                                         # block input only
+    monkeypatch.setattr(ops, "DENSE_SPLIT", True)
+    monkeypatch.setattr(ops, "DENSE_GROUP", 0)                                           # block input only
     plan = ops._split_block_plan(8, 8, 8, 32, 16, 16, (32,), act, CPU)
     assert len(plan["wide"]) == 1 and plan["g0"] == [0] * 16
 
@@ -68,8 +66,6 @@ def test_long_blocks_keep_the_fp32_growth_kernels(monkeypatch):
     """the two-scaled-fp16-piece chain path prepares at most 16 chain layers per library call and a chain call
     takes at most 17 slices; a block with more (layers_per_block = 32 at the default grouping: 30 own-chain layers) must not
     select it -- it used to raise OtganError in the forward pass."""
-    for k in ("OTGAN_DENSE_SPLIT", "OTGAN_DENSE_GROUP", "OTGAN_DENSE_AMAX", "OTGAN_FUSED_AMAX"):
-        monkeypatch.delenv(k, raising=False)
     act = ops.ACT["crelu"]
     p16 = ops._split_block_plan(8, 16, 16, 32, 16, 16, (32,), act, CPU)
     p32 = ops._split_block_plan(8, 16, 16, 32, 32, 16, (32,), act, CPU)
@@ -77,6 +73,6 @@ def test_long_blocks_keep_the_fp32_growth_kernels(monkeypatch):
     assert sum(1 for n in p16["own_len"] if n) == 14 and sum(1 for n in p32["own_len"] if n) == 30
     assert p32["h2"] is False
     # (whether the 16-layer block takes the fp16 chain kernels is the library's answer: otgan_dense16_h2_ok)
-    monkeypatch.setenv("OTGAN_DENSE_GROUP", "0")              # block input only: one group of 20 slices > 17 per chain call
+    monkeypatch.setattr(ops, "DENSE_GROUP", 0)                # block input only: one group of 20 slices > 17 per chain call
     p20 = ops._split_block_plan(8, 16, 16, 32, 20, 16, (32,), act, CPU)
     assert p20 is not None and len(p20["wide"]) == 1 and p20["h2"] is False

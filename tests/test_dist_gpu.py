@@ -33,7 +33,8 @@ def _report(tag, got, ref, names=None):
 # Bound on |multi-rank - single process| / |single process| per gradient tensor.  Both sides are this library in fp32; they differ
 # in batch composition per process (operand scales of the two-piece split follow the rank's own amax, weight-gradient K
 # splits follow the rank's tile count) and in the matching route (row-sharded global path against the local call).
-TOL = 2e-3
+TOL = 7e-5
+TOL_FLIPPED = 1e-2
 
 
 def _free_port():
@@ -52,14 +53,50 @@ def _data():
 
 
 def _run_steps(model, x, u):
+    from otgan_amd import ops
     out = {}
     for kind, ctr in (("disc", 0), ("gen", 1)):
         model.step_counter = ctr
-        r = model.step(x, noise=u, apply_updates=False)
+        ops.SIGN_TRACE = []
+        try:
+            r = model.step(x, noise=u, apply_updates=False)
+        finally:
+            out[kind + "_signs"], ops.SIGN_TRACE = ops.SIGN_TRACE, None
         assert r["kind"] == kind
         out[kind] = [t.detach().cpu() for t in r["grads"]]
         out[kind + "_dist"] = float(r["distance"])
     return out
+
+
+def _flips(rank_signs, single_signs, world, blocks):
+    """ReLU-type units (CReLU layer inputs, the feature head) whose input has a different sign in the ranks' passes than in the
+    single process's pass over the same samples.  rank_signs[r]: rank r's trace (one bool tensor per traced call);
+    single_signs: the single process's trace.  blocks: sample blocks per traced call -- 2 in a critic step (one critic pass
+    over cat([x_data, x_gen]), train.py:83-85), 1 in a generator step (a pass per batch); a rank's samples are contiguous
+    inside each block."""
+    n = 0
+    for r, trace in enumerate(rank_signs):
+        assert len(trace) == len(single_signs) and len(trace) > 0
+        for a, b in zip(trace, single_signs):
+            assert b.shape[0] == world * a.shape[0] and a.shape[0] % blocks == 0
+            per = a.shape[0] // blocks
+            for j in range(blocks):
+                ref = b[j * world * per + r * per: j * world * per + (r + 1) * per]
+                n += int((a[j * per:(j + 1) * per] != ref).sum())
+    return n
+
+
+def _check(tag, got, ref, signs, world):
+    """got / ref: _run_steps() of a rank / of the single process; signs: every rank's traces {kind: [trace per rank]}."""
+    for kind, blocks in (("disc", 2), ("gen", 1)):
+        assert got[kind + "_dist"] == pytest.approx(ref[kind + "_dist"], rel=1e-4, abs=1e-8), (tag, kind)
+        flips = _flips(signs[kind], ref[kind + "_signs"], world, blocks)
+        errs = _report(f"{tag} {kind} sign_flips={flips}", got[kind], ref[kind])
+        # No unit changed sides: the two runs differ by fp32 rounding only (operand scales follow each process's own amax, the
+        # weight gradients' K splits its tile count, the matching route its row sharding).  Measured over seeds 5 - 8 x twelve
+        # cases (profiles/r06_dist_tolerance_sweep.txt): at most 2.3e-5 -> bound 3 x that.  With flipped units (each moves the
+        # gradients near it by up to 3.1e-3 in that sweep) the run is only required to stay at the flipped-unit level.
+        assert max(errs) < (TOL if flips == 0 else TOL_FLIPPED), (tag, kind, flips, max(errs))
 
 
 def _worker(rank, world, port, path, single_batch=False):
@@ -77,8 +114,7 @@ def _worker(rank, world, port, path, single_batch=False):
     x, u = _data()
     sl = slice(rank * B, (rank + 1) * B)
     res = _run_steps(m, x[sl].to(dev), u[sl].to(dev))
-    if rank == 0:
-        torch.save(res, path)
+    torch.save(res, path + str(rank))
     parallel.barrier()
     torch.distributed.destroy_process_group()
 
@@ -98,7 +134,7 @@ def test_two_ranks_equal_single_process(single_batch):
         for p in procs:
             p.join(600)
             assert p.exitcode == 0
-        got = torch.load(path)
+        got = [torch.load(path + str(r)) for r in range(2)]
     from otgan_amd.trainer import OTGAN, default_args
     dev = torch.device("cuda:0")
     args = default_args(model="dcgan", batch_size=B, nr_gpu=2, sinkhorn_lambda=LAM, nr_sinkhorn_iter=ITERS,
@@ -106,13 +142,13 @@ def test_two_ranks_equal_single_process(single_batch):
     m = OTGAN(args, dev)          # world 1: both shards local
     x, u = _data()
     ref = _run_steps(m, x.to(dev), u.to(dev))
+    # (distance: two evaluations of the same loss -- the sharded path uses the closed form over row slices of separately
+    # computed cost blocks; the loss is a cancellation of O(1) terms, so fp32 rounding of the features shows at ~1e-5)
+    signs = {kind: [g[kind + "_signs"] for g in got] for kind in ("disc", "gen")}
     for kind in ("disc", "gen"):
-        # two evaluations of the same loss: the sharded path uses the closed form over row slices of
-        # separately computed cost blocks, the single-process path calc_distance; the loss is a
-        # cancellation of O(1) terms (here 0.016), so fp32 rounding of the features shows at ~1e-5
-        assert got[kind + "_dist"] == pytest.approx(ref[kind + "_dist"], rel=1e-4, abs=1e-8)
-        errs = _report(f"2 ranks single_batch={single_batch} {kind}", got[kind], ref[kind])
-        assert max(errs) < TOL, (kind, max(errs))
+        for a, a1 in zip(got[0][kind], got[1][kind]):
+            assert torch.equal(a, a1)               # every rank holds the same all-reduced sum
+    _check(f"2 ranks single_batch={single_batch}", got[0], ref, signs, 2)
 
 
 def _ddi_worker(rank, world, port, path):
@@ -199,8 +235,9 @@ def _worker8(rank, world, port, path):
         sl = slice(rank * m.nb, (rank + 1) * m.nb)
         out[(nr_gpu, single)] = _run_steps(m, x[sl].to(dev), u[sl].to(dev))
         m.close()
-    if rank in (0, world - 1):          # the all-reduced gradients of a first-half and of a second-half rank
-        torch.save(out, path + str(rank))
+    if rank not in (0, world - 1):      # the all-reduced gradients of a first-half and of a second-half rank; everyone's sign traces
+        out = {c: {k: v for k, v in o.items() if k.endswith("_signs")} for c, o in out.items()}
+    torch.save(out, path + str(rank))
     parallel.barrier()
     torch.distributed.destroy_process_group()
 
@@ -218,7 +255,8 @@ def test_eight_ranks_equal_single_process():
         for p in procs:
             p.join(900)
             assert p.exitcode == 0
-        got0, got7 = torch.load(path + "0"), torch.load(path + str(world - 1))
+        allr = [torch.load(path + str(r)) for r in range(world)]
+        got0, got7 = allr[0], allr[world - 1]
     from otgan_amd.trainer import OTGAN
     dev = torch.device("cuda:0")
     for nr_gpu, single in EIGHT_CASES:
@@ -228,9 +266,8 @@ def test_eight_ranks_equal_single_process():
         m.close()
         g0, g7 = got0[(nr_gpu, single)], got7[(nr_gpu, single)]
         for kind in ("disc", "gen"):
-            assert g0[kind + "_dist"] == pytest.approx(ref[kind + "_dist"], rel=1e-4, abs=1e-8), (nr_gpu, single, kind)
             assert g7[kind + "_dist"] == g0[kind + "_dist"]
             for a, a7 in zip(g0[kind], g7[kind]):
                 assert torch.equal(a, a7)               # every rank holds the same all-reduced sum
-            errs = _report(f"8 ranks nr_gpu={nr_gpu} single_batch={single} {kind}", g0[kind], ref[kind])
-            assert max(errs) < TOL, (nr_gpu, single, kind, max(errs))
+        signs = {kind: [o[(nr_gpu, single)][kind + "_signs"] for o in allr] for kind in ("disc", "gen")}
+        _check(f"8 ranks nr_gpu={nr_gpu} single_batch={single}", g0, ref, signs, world)

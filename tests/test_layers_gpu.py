@@ -493,7 +493,7 @@ def test_dense_block_split_matches_chain(dev, case, monkeypatch):
     grads_ref = torch.autograd.grad(y_ref, xs64 + flat64, dy64)
 
     def run(split):
-        monkeypatch.setenv("OTGAN_DENSE_SPLIT", "1" if split else "0")
+        monkeypatch.setattr(ops, "DENSE_SPLIT", bool(split))
         ops.bump_weights_epoch()
         x0 = torch.cat([t.detach().float() for t in xs64], 3).to(dev).requires_grad_(True)
         params = [[t.detach().float().to(dev).requires_grad_(True) for t in p] for p in P64]
@@ -646,7 +646,7 @@ def test_full_size_dense_block_split_matches_chain(dev, case, monkeypatch):
     """A 16-layer dense block at 256 images, where no oracle finishes in seconds: the block computed as wide Winograd
     convolutions of finished channel groups + short growth chains (the default; its GEMMs take the tile-count dependent
     branches of the bench -- 256 x 128 tiles, K padding, K splits of the weight gradients, batched weight norm) against
-    the SAME block as a plain chain of 16-output convolutions on the dense16 kernels (OTGAN_DENSE_SPLIT=0): two
+    the SAME block as a plain chain of 16-output convolutions on the dense16 kernels (ops.DENSE_SPLIT = False): two
     different algorithms, kernels and summation orders for every output, input gradient and weight gradient.  Each is
     pinned to the fp64 oracle at small sizes (test_dense_block_split_matches_chain)."""
     from otgan_amd import ops
@@ -663,7 +663,7 @@ def test_full_size_dense_block_split_matches_chain(dev, case, monkeypatch):
     dy = torch.randn(B, H, H, C0 + L * F, generator=gen)
 
     def run(split):
-        monkeypatch.setenv("OTGAN_DENSE_SPLIT", "1" if split else "0")
+        monkeypatch.setattr(ops, "DENSE_SPLIT", bool(split))
         ops.bump_weights_epoch()
         x0 = x.to(dev).requires_grad_(True)
         params = [[t.to(dev).requires_grad_(True) for t in p] for p in P]

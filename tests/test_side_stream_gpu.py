@@ -29,25 +29,24 @@ def test_two_streams_equal_one_stream(dev, model, ngd, kw, monkeypatch):
     _same(one, two)
 
 
-def test_side_stream_is_on_by_default_and_off_with_more_ranks(dev, monkeypatch):
+def test_side_stream_is_on_by_default_and_under_step_graphs(dev, monkeypatch):
     from otgan_amd.trainer import OTGAN, default_args
     monkeypatch.delenv("OTGAN_SIDE_STREAM", raising=False)
     m = OTGAN(default_args(batch_size=2, nr_gpu=2, nr_sinkhorn_iter=5), dev)
     assert m.fork_real_pass and m.fork_wgrad and m._side_stream is not None
     m.close()
     m = OTGAN(default_args(batch_size=2, nr_gpu=2, nr_sinkhorn_iter=5, step_graph=True), dev)
-    assert not m.fork_real_pass and not m.fork_wgrad          # a capture records one stream
+    assert m.fork_real_pass and m.fork_wgrad and m.graphs is not None      # round 6: the capture holds both streams' chains
     m.close()
 
 
 def test_allocator_reaches_a_steady_state_with_the_host_running_ahead(dev, monkeypatch):
     """Two streams + record_stream + a host that never synchronises made torch's caching allocator call hipMalloc about four
     times per step through the first ~150 steps of a run (a tensor the other stream has used is reusable only once that
-    stream's work on it has COMPLETED).  trainer.OTGAN.step keeps the host at most two steps ahead of the device (OTGAN_MAX_STEPS_AHEAD): after
+    stream's work on it has COMPLETED).  trainer.OTGAN.step keeps the host at most two steps ahead of the device: after
     two warm-up periods a window of steps without any synchronisation allocates (next to) nothing."""
     from otgan_amd.trainer import OTGAN, default_args
     monkeypatch.delenv("OTGAN_SIDE_STREAM", raising=False)
-    monkeypatch.delenv("OTGAN_MAX_STEPS_AHEAD", raising=False)
     m = OTGAN(default_args(batch_size=32, nr_gpu=2, nr_sinkhorn_iter=10, nr_gen_per_disc=2, seed=3), dev)
     assert m._side_stream is not None and m._max_ahead == 2
     x = torch.rand(m.nb, 32, 32, 3, device=dev) * 2 - 1
