@@ -1538,16 +1538,19 @@ class ExtendChannelsFunction(torch.autograd.Function):
         base = grown_buffer(x, Ctot)
         assert base is not None
         ctx.widths = [int(t.shape[-1]) for t in (x,) + others]
+        # the records are read BEFORE the copies: x is a view of `base` and shares its version counter, so the in-place
+        # copies below make x's tag look stale (the record was never carried and the block reduced its input again)
+        rec = amax_of(x) if (_FUSED_AMAX and all(w % 4 == 0 for w in ctx.widths)) else None
+        if rec is not None:
+            for t in others:
+                r = amax_of(t)
+                rec = torch.maximum(rec, r if r is not None else absmax_record(t.contiguous()))
         off = ctx.widths[0]
         for t in others:
             base[..., off:off + t.shape[-1]].copy_(t)
             off += t.shape[-1]
         y = base[..., :off]
-        if _FUSED_AMAX and all(w % 4 == 0 for w in ctx.widths) and amax_of(x) is not None:
-            rec = amax_of(x)
-            for t in others:
-                r = amax_of(t)
-                rec = torch.maximum(rec, r if r is not None else absmax_record(t.contiguous()))
+        if rec is not None:
             tag_amax(y, rec)
         return y
 

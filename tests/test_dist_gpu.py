@@ -33,7 +33,7 @@ def _report(tag, got, ref, names=None):
 # Bound on |multi-rank - single process| / |single process| per gradient tensor.  Both sides are this library in fp32; they differ
 # in batch composition per process (operand scales of the two-piece split follow the rank's own amax, weight-gradient K
 # splits follow the rank's tile count) and in the matching route (row-sharded global path against the local call).
-TOL = 7e-5
+TOL = 1.5e-4
 TOL_FLIPPED = 1e-2
 
 
@@ -93,9 +93,9 @@ def _check(tag, got, ref, signs, world):
         flips = _flips(signs[kind], ref[kind + "_signs"], world, blocks)
         errs = _report(f"{tag} {kind} sign_flips={flips}", got[kind], ref[kind])
         # No unit changed sides: the two runs differ by fp32 rounding only (operand scales follow each process's own amax, the
-        # weight gradients' K splits its tile count, the matching route its row sharding).  Measured over seeds 5 - 8 x twelve
-        # cases (profiles/r06_dist_tolerance_sweep.txt): at most 2.3e-5 -> bound 3 x that.  With flipped units (each moves the
-        # gradients near it by up to 3.1e-3 in that sweep) the run is only required to stay at the flipped-unit level.
+        # weight gradients' K splits its tile count, the matching route its row sharding).  Measured over seeds 5 - 10 x twelve
+        # cases (profiles/r06_dist_tolerance_sweep.txt): 66 cases without a flipped unit, at most 4.8e-5 (median tensor 2e-6 .. 8e-6)
+        # -> TOL = 3 x that.  The six cases with ONE flipped unit each: 8.3e-5 .. 3.3e-3 -> TOL_FLIPPED = 3 x that.
         assert max(errs) < (TOL if flips == 0 else TOL_FLIPPED), (tag, kind, flips, max(errs))
 
 

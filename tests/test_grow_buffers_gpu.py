@@ -64,8 +64,13 @@ def _run(dev, kind, grow_on):
     grow = (C0 - Cout) + L * F if grow_on else 0
     y = ops.conv2d_op(x, V, g.abs() + 0.5, b, grow=grow, **kw)
     if others:
+        y_rec = ops.amax_of(y)              # (read before the in-place extension bumps the shared version counter)
         x0 = ops.extend_channels([y] + others, C0 + L * F) if grow_on else None
         assert (x0 is not None) == grow_on
+        if grow_on:
+            # the producing convolution's amax record travels with the extended block input (the block would
+            # otherwise reduce its input once more per step)
+            assert y_rec is not None and ops.amax_of(x0) is not None
         if x0 is None:
             x0 = ops.concat_channels([y] + others)
         segs0 = [Cout] + [int(t.shape[-1]) for t in others]
