@@ -389,6 +389,17 @@ int otgan_adam_step_gather_coef_f32(float* p, const float* const* grads, const l
 #define OTGAN_COPY2D_MAX_SEGMENTS 64
 int otgan_copy2d_batched_f32(const float* const* src, float* const* dst, const int* rows, const int* cols,
                              const long* src_ld, const long* dst_ld, int nseg, void* stream);
+/* Up to OTGAN_GATHER3D_MAX_SEGMENTS strided 3-D copies with a gathered middle index in ONE launch:
+ *   dst[s][i0 * dst_s0[s] + i1 * dst_s1[s] + i2] = src[s][i0 * src_s0[s] + (base1 + map1[i1]) * src_s1[s] + i2]
+ * for i0 < n0[s], i1 < n1, i2 < n2 (map1: n1 device ints, or NULL = identity); the per-segment arrays are HOST arrays of nseg
+ * entries, strides in elements.  (The wide convolutions of a split DenseNet block -- reference models/densenet.py:11-16 through
+ * ops.py _split_block_plan -- read the rows of one channel group out of the weights of all later growth layers, side by side
+ * and re-ordered from the reference's per-list-element CReLU order [x0, -x0, x1, -x1, ...] (utils/nn.py:198-200) to the
+ * single-tensor order: one launch per operand instead of a cat, an index_select and their copies per layer.) */
+#define OTGAN_GATHER3D_MAX_SEGMENTS 32
+int otgan_gather3d_batched_f32(const float* const* src, float* const* dst, const int* n0, int n1, int n2,
+                               const long* src_s0, const long* src_s1, const long* dst_s0, const long* dst_s1,
+                               int base1, const int* map1_dev, int nseg, void* stream);
 int otgan_adamax_step_f32(float* p, const float* grad, float* v, float* mg, long n, double lr,
                           double mom1, double mom2, void* stream);
 int otgan_nesterov_step_f32(float* p, const float* grad, float* v, long n, double lr, double mom1,

@@ -672,6 +672,54 @@ extern "C" int otgan_copy2d_batched_f32(const float* const* src, float* const* d
   return OTGAN_OK;
 }
 
+// ---- batched 3-D gathers (otgan_gather3d_batched_f32) ----
+struct Gather3dSegs {
+  const float* src[OTGAN_GATHER3D_MAX_SEGMENTS];
+  float* dst[OTGAN_GATHER3D_MAX_SEGMENTS];
+  int n0[OTGAN_GATHER3D_MAX_SEGMENTS];
+  long ss0[OTGAN_GATHER3D_MAX_SEGMENTS], ss1[OTGAN_GATHER3D_MAX_SEGMENTS];
+  long ds0[OTGAN_GATHER3D_MAX_SEGMENTS], ds1[OTGAN_GATHER3D_MAX_SEGMENTS];
+  int n1, n2, base1;
+  const int* map1;
+};
+__global__ __launch_bounds__(256) void gather3d_batched_kernel(Gather3dSegs g) {
+  const int sg = blockIdx.y;
+  const float* __restrict__ src = g.src[sg];
+  float* __restrict__ dst = g.dst[sg];
+  const long ss0 = g.ss0[sg], ss1 = g.ss1[sg], ds0 = g.ds0[sg], ds1 = g.ds1[sg];
+  const int n1 = g.n1, n2 = g.n2;
+  const long total = (long)g.n0[sg] * n1 * n2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int i2 = (int)(i % n2);
+    const long r = i / n2;
+    const int i1 = (int)(r % n1);
+    const long i0 = r / n1;
+    const int j1 = g.base1 + (g.map1 ? g.map1[i1] : i1);
+    dst[i0 * ds0 + i1 * ds1 + i2] = src[i0 * ss0 + j1 * ss1 + i2];
+  }
+}
+extern "C" int otgan_gather3d_batched_f32(const float* const* src, float* const* dst, const int* n0, int n1, int n2,
+                                          const long* src_s0, const long* src_s1, const long* dst_s0, const long* dst_s1,
+                                          int base1, const int* map1_dev, int nseg, void* stream) {
+  OTGAN_CHECK_ARG(src && dst && n0 && src_s0 && src_s1 && dst_s0 && dst_s1 && n1 > 0 && n2 > 0 && base1 >= 0 && nseg > 0 &&
+                  nseg <= OTGAN_GATHER3D_MAX_SEGMENTS, "bad arguments");
+  Gather3dSegs g;
+  long most = 0;
+  for (int i = 0; i < nseg; ++i) {
+    OTGAN_CHECK_ARG(src[i] && dst[i] && n0[i] > 0, "bad segment");
+    g.src[i] = src[i]; g.dst[i] = dst[i]; g.n0[i] = n0[i];
+    g.ss0[i] = src_s0[i]; g.ss1[i] = src_s1[i]; g.ds0[i] = dst_s0[i]; g.ds1[i] = dst_s1[i];
+    const long t = (long)n0[i] * n1 * n2;
+    most = t > most ? t : most;
+  }
+  g.n1 = n1; g.n2 = n2; g.base1 = base1; g.map1 = map1_dev;
+  long bx = (most + 256 * 4 - 1) / (256 * 4);
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(gather3d_batched_kernel, dim3((unsigned)bx, (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, g);
+  OTGAN_CHECK_LAUNCH("gather3d_batched");
+  return OTGAN_OK;
+}
+
 struct AdamSegs {
   const float* g[OTGAN_ADAM_MAX_SEGMENTS];
   long off[OTGAN_ADAM_MAX_SEGMENTS + 1];

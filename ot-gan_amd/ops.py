@@ -739,13 +739,33 @@ def _wide_operands(per_layer, layers, row0, nrows, order, F, desc):
     """One wide 3x3 convolution gathered from a dense block: rows [row0, row0 + nrows) of the normalised weights of
     `layers` (the effective channels of one finished channel group), side by side.  w [9*nrows][len(layers)*F],
     wT [len(layers)*F][9*nrows], rows re-ordered to the single-tensor order when `order` is given."""
-    w = torch.cat([per_layer[k][0].view(9, -1, F)[:, row0:row0 + nrows, :] for k in layers], dim=2)
-    wT = torch.cat([per_layer[k][1].view(F, 9, -1)[:, :, row0:row0 + nrows] for k in layers], dim=0)
+    layers = list(layers)
+    nl = len(layers)
+    n = nl * F
+    ref = per_layer[layers[0]][0]
+    w = torch.empty((9 * nrows, n), dtype=ref.dtype, device=ref.device)
+    wT = torch.empty((n, 9 * nrows), dtype=ref.dtype, device=ref.device)
+    map32 = None
     if order is not None:
-        w = w.index_select(1, order)
-        wT = wT.index_select(2, order)
-    n = len(layers) * F
-    w, wT = w.contiguous().view(9 * nrows, n), wT.contiguous().view(n, 9 * nrows)
+        key = ("rows32", order.data_ptr())
+        hit = _map_cache.get(key)
+        if hit is None:
+            hit = (order, order.to(torch.int32))      # holding `order` keeps its data_ptr from being reused
+            _map_cache[key] = hit
+        map32 = hit[1]
+    # two launches (otgan_gather3d_batched_f32: one segment per layer) instead of a cat, an index_select and their copies
+    # per operand -- 0.33 ms of framework kernels per DenseNet step before round 6; same values, bit for bit
+    segs_w, segs_t = [], []
+    for j, k in enumerate(layers):
+        w_k, wT_k = per_layer[k][0], per_layer[k][1]
+        assert w_k.is_contiguous() and wT_k.is_contiguous()
+        ceff = w_k.shape[0] // 9
+        assert row0 + nrows <= ceff
+        # w_k [9][ceff][F] -> w [9][nrows][nl F] at column j F;  wT_k [F 9][ceff] -> wT [nl F 9][nrows] at row j F 9
+        segs_w.append((w_k.data_ptr(), w.data_ptr() + 4 * j * F, 9, ceff * F, F, nrows * n, n))
+        segs_t.append((wT_k.data_ptr(), wT.data_ptr() + 4 * j * F * 9 * nrows, F * 9, ceff, 1, nrows, 1))
+    gather3d_batched(segs_w, nrows, F, row0, map32)
+    gather3d_batched(segs_t, nrows, 1, row0, map32)
     return {"w": w, "wT": wT, "fwd": prepare_filters(desc, 0, wT), "bwd": None, "bwd_done": False}
 
 
@@ -1638,6 +1658,24 @@ def copy2d_batched(segs):
         cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
         _lib.check(_lib.lib().otgan_copy2d_batched_f32(cast(src), cast(dst), cast(rows), cast(cols), cast(sld), cast(dld), n,
                                                        _lib.stream_ptr()), "copy2d_batched")
+
+
+GATHER3D_MAX_SEGMENTS = 32   # include/otgan_layers.h
+
+
+def gather3d_batched(segs, n1, n2, base1=0, map1=None):
+    """Strided 3-D copies with a gathered middle index in one launch (otgan_gather3d_batched_f32): segs = [(src_ptr, dst_ptr, n0,
+    src_stride0, src_stride1, dst_stride0, dst_stride1)], element units; map1: int32 device tensor of n1 indices or None."""
+    assert map1 is None or (map1.dtype == torch.int32 and map1.numel() == n1 and map1.is_contiguous())
+    for i0 in range(0, len(segs), GATHER3D_MAX_SEGMENTS):
+        part = segs[i0:i0 + GATHER3D_MAX_SEGMENTS]
+        n = len(part)
+        cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+        arr = lambda ty, i: cast((ty * n)(*[q[i] for q in part]))
+        _lib.check(_lib.lib().otgan_gather3d_batched_f32(arr(ctypes.c_void_p, 0), arr(ctypes.c_void_p, 1), arr(ctypes.c_int, 2),
+                                                         int(n1), int(n2), arr(ctypes.c_long, 3), arr(ctypes.c_long, 4),
+                                                         arr(ctypes.c_long, 5), arr(ctypes.c_long, 6), int(base1),
+                                                         _lib.ptr(map1), n, _lib.stream_ptr()), "gather3d_batched")
 
 
 def adamax_step(p, grad, v, mg, lr, mom1, mom2):

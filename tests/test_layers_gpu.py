@@ -854,3 +854,35 @@ def test_unfolded_weight_gradient_in_the_adjoint_filter_transform(tmp_path):
     for a, b, c in zip(*outs):
         assert torch.equal(a, b)                                   # fused, twice
         assert float((a - c).abs().max()) <= 2e-6 * float(c.abs().max())   # fused against the two kernels it replaces
+
+
+def test_wide_operand_gather_equals_cat_and_index_select(dev):
+    """Round 6: the weights of a dense block's wide convolutions (rows of one channel group out of all later growth layers,
+    side by side, re-ordered from the reference's per-list-element CReLU order -- utils/nn.py:198-200 -- to the single-tensor
+    order) come from otgan_gather3d_batched_f32 instead of torch.cat / index_select: the same elements, bit for bit."""
+    from otgan_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    F, L, segs0 = 16, 6, (24, 8)
+    C0 = sum(segs0)
+    per_layer = []
+    for k in range(L):
+        ceff = 2 * (C0 + k * F)
+        w = torch.randn(9 * ceff, F, generator=gen).to(dev)
+        per_layer.append((w, w.view(9, ceff, F).permute(2, 0, 1).contiguous().view(F, 9 * ceff)))
+    order = ops._input_row_order(segs0, ops.ACT["crelu"], dev)
+    for layers, row0, nrows, od in ((range(0, L), 0, 2 * C0, order), (range(3, L), 2 * C0, 2 * 3 * F, None),
+                                    (range(2, L), 2 * C0 + 8, 40, None)):
+        layers = list(layers)
+        w = torch.cat([per_layer[k][0].view(9, -1, F)[:, row0:row0 + nrows, :] for k in layers], dim=2)
+        wT = torch.cat([per_layer[k][1].view(F, 9, -1)[:, :, row0:row0 + nrows] for k in layers], dim=0)
+        if od is not None:
+            w, wT = w.index_select(1, od), wT.index_select(2, od)
+        n = len(layers) * F
+        w, wT = w.contiguous().view(9 * nrows, n), wT.contiguous().view(n, 9 * nrows)
+        real_prepare = ops.prepare_filters
+        ops.prepare_filters = lambda desc, which, t: None        # (only the gathered weights are under test)
+        try:
+            got = ops._wide_operands(per_layer, layers, row0, nrows, od, F, None)
+        finally:
+            ops.prepare_filters = real_prepare
+        assert torch.equal(got["w"], w) and torch.equal(got["wT"], wT)
