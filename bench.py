@@ -83,7 +83,7 @@ def roofline_of(prof, model, ms_per_step_prof, steps, default_cfg, cfg_tag=None)
         tag = model if (default_cfg or model == "densenet") else cfg_tag
         if tag is None:
             raise LookupError("no PMC summary for this configuration")
-        for rnd in ("r05b", "r05", "r04", "r03", "r02", "r02b", "r01"):          # newest committed PMC summary of this configuration
+        for rnd in ("r06", "r05b", "r05", "r04", "r03", "r02", "r02b", "r01"):          # newest committed PMC summary of this configuration
             fn = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary_{tag}.json")
             if os.path.exists(fn):
                 with open(fn) as f:
@@ -93,7 +93,7 @@ def roofline_of(prof, model, ms_per_step_prof, steps, default_cfg, cfg_tag=None)
                 break
     except Exception:
         pass
-    # the kernels behind the class in a default run (profiles/r05_kernel_stats_*.csv: wino_bgemm_x3n_kernel<false> = NT,
+    # the kernels behind the class in a default run (profiles/r06_kernel_stats_*.csv: wino_bgemm_x3n_kernel<false> = NT,
     # forward / input-gradient GEMMs, <true> = t-leading, weight-gradient GEMMs; the three-piece build
     # OTGAN_WINO_PIECES=3 runs wino_bgemm_x3_kernel, the 256 x 256 tile, instead)
     three = os.environ.get("OTGAN_WINO_PIECES") == "3"

@@ -81,6 +81,25 @@ class OtganError(RuntimeError):
     pass
 
 
+# Every OTGAN_* environment variable this build reads: the library's engine / test switches, the
+# host side's, and the names only the test suite and its workers use.  Anything else that starts with OTGAN_ is a switch of an
+# earlier round (or a typo) and changes NOTHING: say so once, so that an A/B over a dead knob cannot be read as "no difference"
+# (ADVICE r5).
+KNOWN_SWITCHES = frozenset("""
+OTGAN_WINO_PIECES OTGAN_WINO_FP32 OTGAN_DISABLE_WINOGRAD OTGAN_X3_NARROW OTGAN_IGEMM_X3 OTGAN_WINO_UNFOLD_FUSED
+OTGAN_MATCH_FP32 OTGAN_SINKHORN_LINEAR OTGAN_SINKHORN_LIN_RANGE OTGAN_SINKHORN_SETTLE
+OTGAN_PANEL_XCD OTGAN_PANEL_MAX_WG
+OTGAN_LIB_PATH OTGAN_DIST_BACKEND OTGAN_FORCE_COLLECTIVES OTGAN_SINGLE_DEVICE OTGAN_COLLECTIVES OTGAN_SIDE_STREAM OTGAN_STEP_GRAPH
+OTGAN_ROOT OTGAN_WORKER_CASES OTGAN_WORKER_DATA OTGAN_TEST_DIST_SEED
+""".split())
+
+
+def unknown_switches(environ=None):
+    """OTGAN_* names in the environment that this build does not read."""
+    environ = os.environ if environ is None else environ
+    return sorted(k for k in environ if k.startswith("OTGAN_") and k not in KNOWN_SWITCHES)
+
+
 def lib():
     """Load the HIP library once.  Fails loudly -- there is no fallback path."""
     global _lib
@@ -88,6 +107,11 @@ def lib():
         return _lib
     with _lock:
         if _lib is None:
+            dead = unknown_switches()
+            if dead:
+                import warnings
+                warnings.warn("otgan_amd: " + ", ".join(dead) + " set in the environment but not read by this build (a switch of an "
+                              "earlier round, or a typo): no effect.  Supported switches: INTEGRATION.md section 4.")
             if not os.path.exists(LIB_PATH):
                 raise OtganError(
                     f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "

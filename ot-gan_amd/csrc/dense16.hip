@@ -1664,11 +1664,7 @@ static int h2_pt(int N, int H, int W) {
 size_t dense16_h2_filter_bytes(int nsl) { return nsl > 0 ? (size_t)kH2HdrBytes + (size_t)nsl * kH2SliceU16 * 2 : 0; }
 
 bool dense16_h2_shape_ok(int N, int H, int W) {
-  static const bool on = [] {
-    const char* e = getenv("OTGAN_DENSE16_H2");
-    return !(e && e[0] == '0');
-  }();
-  if (!on || !(W == 8 || W == 16 || W == 32) || H * W < 64) return false;
+  if (!(W == 8 || W == 16 || W == 32) || H * W < 64) return false;
   const int PT = h2_pt(N, H, W);
   const int TR = 64 * PT / W;
   return TR >= 1 && H % TR == 0 && (W != 8 || PT == 1);   // (8-wide images: only the one-tile instantiation exists)
@@ -1785,8 +1781,7 @@ int dense16_wgrad(const Dense16Geo& g, const float* x, const float* dy, int ldy,
   a.doubled = g.doubled; a.ldy = ldy;
   a.TR = t.TR; a.RS = t.RS; a.tiles = t.tiles; a.tiles_per_split = t.tiles_per_split;
   a.slab_elems = (long)9 * g.Ceff * 16;
-  static const bool h2_off = [] { const char* e = getenv("OTGAN_DENSE16_WGRAD_H2"); return e && e[0] == '0'; }();
-  const bool h2 = !h2_off && x_rec && dy_rec && x_nrec > 0 && dy_nrec > 0 && g.W >= 4;
+  const bool h2 = x_rec && dy_rec && x_nrec > 0 && dy_nrec > 0 && g.W >= 4;
   a.x_rec = x_rec; a.dy_rec = dy_rec; a.x_nrec = x_nrec; a.dy_nrec = dy_nrec;
   size_t lds = ((size_t)64 * t.PT * kAStride + (size_t)(t.TR + 2) * t.RS * kDyStride) * 4;
   if (lds < 18 * 64 * 16) lds = 18 * 64 * 16;   // wave-reduction scratch

@@ -61,3 +61,26 @@ def test_operator_argument_errors():
     x = torch.zeros(4, 8)
     with pytest.raises(ValueError):
         matching.get_matched_features([x, x], [x], 1.0, 1)                  # list length mismatch
+
+
+def test_every_switch_the_sources_read_is_known_and_dead_ones_are_reported():
+    """A/B tools kept setting switches that the round-5 prune had removed and compared identical configurations.
+    `_lib.KNOWN_SWITCHES` lists every OTGAN_* variable the build reads -- checked here against the sources (getenv in csrc/,
+    os.environ in the package and bench.py) -- and loading the library warns once about any other OTGAN_* name."""
+    import glob
+    import re
+    from otgan_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    read = set()
+    for path in glob.glob(os.path.join(root, "ot-gan_amd", "csrc", "*.h*")) + glob.glob(os.path.join(root, "ot-gan_amd", "csrc", "*.inc")):
+        read |= set(re.findall(r'getenv\("(OTGAN_[A-Z0-9_]+)"\)', open(path).read()))
+    for path in (glob.glob(os.path.join(root, "ot-gan_amd", "*.py")) + glob.glob(os.path.join(root, "ot-gan_amd", "*", "*.py")) +
+                 [os.path.join(root, "bench.py")]):
+        src = open(path).read()
+        read |= set(re.findall(r'environ(?:\.get|\.setdefault|\.pop)?[\(\[]\s*"(OTGAN_[A-Z0-9_]+)"', src))
+    assert read, "no switch found: the scan is broken"
+    assert read <= _lib.KNOWN_SWITCHES, sorted(read - _lib.KNOWN_SWITCHES)
+    host_side = {s for s in read if s in ("OTGAN_LIB_PATH", "OTGAN_DIST_BACKEND", "OTGAN_FORCE_COLLECTIVES", "OTGAN_SINGLE_DEVICE",
+                                          "OTGAN_COLLECTIVES", "OTGAN_SIDE_STREAM", "OTGAN_STEP_GRAPH")}
+    assert len(host_side) <= 10
+    assert _lib.unknown_switches({"OTGAN_DENSE_SPLIT": "0", "OTGAN_SIDE_STREAM": "0", "PATH": "x"}) == ["OTGAN_DENSE_SPLIT"]
