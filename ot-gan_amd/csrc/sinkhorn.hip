@@ -3,6 +3,7 @@
 //   iteration count)  ->  plan application (fp32 MFMA)  ->  distance (fp64 accumulation).
 // Replaces reference utils/matching.py:11-153 and toy_example/matching_cpu.py:4-164.
 #include <stdlib.h>
+#include <atomic>
 
 #include "gemm_tile.h"
 // the matching GEMMs of N >= 256 on two scaled fp16 pieces (round 4; three bf16 pieces until then): section 5
@@ -977,21 +978,38 @@ inline LinCtl lin_ctl() {
 __global__ void xcc_id_probe_kernel(int* out) {
   if (threadIdx.x == 0) out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15);
 }
-inline bool xcd_round_robin() {
-  static const bool ok = [] {
+// (cached PER DEVICE; never probed while `s` is capturing -- the probe allocates, launches on the NULL stream and
+// copies back synchronously, any of which would invalidate a capture: an unprobed device then takes the placement-independent
+// agent-scope protocol for that launch and is probed by the next launch outside a capture.)
+inline bool xcd_round_robin(hipStream_t s) {
+  static const bool enabled = [] {
     const char* e = getenv("OTGAN_PANEL_XCD");
-    if (e && e[0] == '0') return false;
-    int* d = nullptr;
-    int h[64];
-    if (hipMalloc((void**)&d, sizeof(h)) != hipSuccess) return false;
+    return !(e && e[0] == '0');
+  }();
+  if (!enabled) return false;
+  constexpr int kMaxDev = 64;
+  static std::atomic<int> state[kMaxDev];      // 0 unknown, 1 round-robin, 2 not
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) { (void)hipGetLastError(); return false; }
+  const int st = state[dev].load(std::memory_order_acquire);
+  if (st) return st == 1;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (cap != hipStreamCaptureStatusNone) return false;
+  int* d = nullptr;
+  int h[64];
+  bool ok = false;
+  if (hipMalloc((void**)&d, sizeof(h)) == hipSuccess) {
     hipLaunchKernelGGL(xcc_id_probe_kernel, dim3(64), dim3(64), 0, 0, d);
     const bool copied = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
     (void)hipFree(d);
-    if (!copied) { (void)hipGetLastError(); return false; }
-    for (int i = 0; i < 64; ++i)
-      if (h[i] != (i & 7)) return false;
-    return true;
-  }();
+    if (!copied) (void)hipGetLastError();
+    ok = copied;
+    for (int i = 0; ok && i < 64; ++i) ok = h[i] == (i & 7);
+  } else {
+    (void)hipGetLastError();
+  }
+  state[dev].store(ok ? 1 : 2, std::memory_order_release);
   return ok;
 }
 
@@ -1029,7 +1047,7 @@ bool launch_panel(const PanelArgs& a, int P, hipStream_t s) {
   b.P = P;
   // one problem per XCD when the device dispatches workgroup x to XCD x % 8 (probed once) and every XCD can host a problem's
   // R workgroups: the grid is then 8 R workgroups of which those on XCDs P .. 7 return at once
-  b.xcd_local = (P <= 8 && 8 * a.R <= capacity && !(lim && atoi(lim) >= 0) && xcd_round_robin()) ? 1 : 0;
+  b.xcd_local = (P <= 8 && 8 * a.R <= capacity && !(lim && atoi(lim) >= 0) && xcd_round_robin(s)) ? 1 : 0;
   const unsigned grid = b.xcd_local ? 8u * (unsigned)a.R : (unsigned)(P * a.R);
   hipLaunchKernelGGL(sinkhorn_panel_kernel<TPR>, dim3(grid), dim3(kPanelThreads), lds, s, b, lin_ctl());
   return true;

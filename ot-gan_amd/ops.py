@@ -354,11 +354,17 @@ def fold_weights(desc, w):
 # workgroup -- on two streams each chain's kernels start in the other's tails.  Same kernels, same arguments, same results.
 # The caller joins the side stream before it reads the gradients (ops.join_side_stream).
 SIDE_STREAM = None
+# Variables whose weight gradient this backward pass has already produced on the side stream.  A variable used by TWO nodes of one
+# graph (weight sharing, the critic called twice under grad) has its gradients accumulated by the autograd engine on the MAIN
+# stream as soon as the second node returns: that node therefore makes the main stream wait for the side stream before it hands
+# its gradients back (today's models use every variable once per graph, so the wait never happens).
+_SIDE_SEEN = set()
 
 
 def join_side_stream(tensors=()):
     """Make the current stream wait for the side stream's work and tell the allocator that `tensors` (allocated there) are
     used here from now on."""
+    _SIDE_SEEN.clear()
     if SIDE_STREAM is None:
         return
     cur = torch.cuda.current_stream()
@@ -586,6 +592,11 @@ class Conv2dFunction(torch.autograd.Function):
                 if db is None:
                     rows = dy.numel() // dy.shape[-1]
                     db = colsum(dy.data_ptr(), rows, dy.shape[-1], ld, dy.device)
+        if side is not None:
+            key = V2d.untyped_storage().data_ptr() + V2d.storage_offset()
+            if key in _SIDE_SEEN:       # second use of this variable in one pass: the engine will add the two gradients on the main stream
+                torch.cuda.current_stream().wait_stream(side)
+            _SIDE_SEEN.add(key)
         return dx, dV, dg, db, None, None, None, None, None, None
 
 

@@ -60,3 +60,34 @@ def test_allocator_reaches_a_steady_state_with_the_host_running_ahead(dev, monke
     n1 = torch.cuda.memory_stats(dev)["num_device_alloc"]
     m.close()
     assert n1 - n0 <= 4, (n0, n1)
+
+
+def test_variable_used_twice_under_the_side_stream(dev):
+    """a variable consumed by two nodes of one graph has its two weight gradients (both produced on the side stream)
+    added by the autograd engine on the main stream; the second node makes the main stream wait first.  Same bits as on one
+    stream, over several repetitions (the race was latent: today's models use every variable once per graph)."""
+    from otgan_amd import ops
+    gen = torch.Generator(device=dev).manual_seed(9)
+    xs = [torch.randn((64, 16, 16, 128), generator=gen, device=dev).requires_grad_(True) for _ in range(2)]
+    V = (torch.randn((5, 5, 256, 128), generator=gen, device=dev) * 0.05).requires_grad_(True)
+    g = torch.ones(128, device=dev, requires_grad=True)
+    b = torch.zeros(128, device=dev, requires_grad=True)
+    dys = [torch.randn((64, 8, 8, 128), generator=gen, device=dev) for _ in range(2)]
+
+    def run(side):
+        ops.SIDE_STREAM = side
+        try:
+            ys = [ops.conv2d_op(x, V, g, b, stride=2, preact=ops.ACT["crelu"]) for x in xs]
+            grads = torch.autograd.grad(ys, xs + [V, g, b], dys)
+            ops.join_side_stream(grads)
+        finally:
+            ops.SIDE_STREAM = None
+        torch.cuda.synchronize()
+        return [t.clone() for t in grads]
+
+    one = run(None)
+    side = torch.cuda.Stream(device=dev)
+    for _ in range(5):
+        two = run(side)
+        for u, v in zip(one, two):
+            assert torch.equal(u, v)
