@@ -91,8 +91,10 @@ size_t otgan_matching_workspace_bytes(int mode, int rows, int D);
  * Exactly `iters` row->column sweeps are run, then a row softmax (no early exit).
  * Cosine cost: the features are what the reference's critics return (models/dcgan.py:16-19, models/densenet.py:40-42):
  * rows of unit length.  The cost and plan-application GEMMs multiply operands split into two scaled fp16 pieces with an
- * a-priori scale for such rows; an element of magnitude >= 8 overflows a piece and the outputs come out NaN (loud, never
- * silently wrong).  OTGAN_MATCH_FP32=1 (environment, read once) keeps these GEMMs on the exact-fp32 MFMA engine, which
+ * a-priori scale for such rows (the one-tile kernels of N <= 128; rows need not be of unit length, only |x| < 8); an element of
+ * magnitude >= 8 overflows a piece there and the outputs come out NaN (loud, never silently wrong).  The pre-split engine of
+ * N >= 256 measures its operands and re-splits when the largest magnitude leaves the expected band: it has no such limit
+ * (tests/test_matching_h2_gpu.py::test_features_outside_the_cosine_contract_are_loud).  OTGAN_MATCH_FP32=1 (environment, read once) keeps these GEMMs on the exact-fp32 MFMA engine, which
  * has no such limit; the toy cost always runs there.
  */
 int otgan_matching_two_batch_f32(const float* fa, const float* fb, int N, int D, long ldf,

@@ -124,3 +124,44 @@ def test_cost_h2_row_pitch(dev):
     assert torch.equal(out[0], out[1])
     ref = -500.0 * M.cosine_cost(X.astype(np.float64), Y.astype(np.float64))
     assert np.abs(out[0].cpu().numpy() - ref).max() < 1e-3
+
+
+@pytest.mark.parametrize("N,D", [(128, 512), (256, 512)], ids=["one_tile_kernels", "pre_split_operands"])
+def test_features_outside_the_cosine_contract_are_loud(dev, N, D):
+    """include/otgan.h: the default matching engine splits its operands into two fp16 pieces with an a-priori scale for rows of
+    unit length (what the reference's critics return, models/dcgan.py:16-19); the reference itself has no such precondition
+    (utils/matching.py:29-39 multiplies whatever it is given).  The contract is therefore: |x| < 8 is computed correctly -- rows
+    that are NOT of unit length included -- and an element of magnitude >= 8 poisons the result with NaN instead of returning a
+    wrong finite number.  Both engines of the split path: N <= 128 (cost128_h2 / plan_apply128_h2) and N >= 256 (pre-split)."""
+    from otgan_amd.utils import matching
+    lam, iters = 20.0, 10
+    rng = np.random.RandomState(N + D)
+    ca, cb = rng.randn(4, D), rng.randn(4, D)
+    fa = M.clustered_features(rng, 2 * N, D, ca).astype(np.float32)
+    fb = M.clustered_features(rng, 2 * N, D, cb).astype(np.float32)
+    # inside the contract but not of unit length: rows scaled by 0.5 .. 3 (largest element well below 8)
+    sa = (0.5 + 2.5 * rng.rand(2 * N, 1)).astype(np.float32)
+    fa_s = fa * sa
+    assert np.abs(fa_s).max() < 8.0
+    ga, gb, ent, dist = matching.matched_feature_grads(_t(fa_s, dev), _t(fb, dev), lam, iters)
+    f64 = lambda z: z.astype(np.float64)
+    a1, a2, b1, b2 = f64(fa_s[:N]), f64(fa_s[N:]), f64(fb[:N]), f64(fb[N:])
+    plans, _, _ = M.two_batch_plans(a1, a2, b1, b2, lam, iters)
+    aa, bb, ab, ba = M.matched_rows(plans, a1, a2, b1, b2, 0, 0, N)
+    assert np.isfinite(float(dist)) and np.isfinite(float(ent))
+    assert _rel(ga[:N].cpu().numpy(), aa - ab) < 2e-4
+    # outside: ONE element of 9.0
+    bad = fa.copy()
+    bad[3, 5] = 9.0
+    ga, gb, ent, dist = matching.matched_feature_grads(_t(bad, dev), _t(fb, dev), lam, iters)
+    loud = not np.isfinite(float(dist)) or not bool(torch.isfinite(ga).all())
+    if N <= 128:
+        assert loud, "the one-tile kernels' a-priori scale cannot hold 9.0: the result must be NaN, never a wrong finite number"
+    elif not loud:
+        # the pre-split engine measures its operands (speculative split, re-split when the largest magnitude leaves the expected
+        # band): it may take the element -- then the answer has to be RIGHT
+        a1, a2 = f64(bad[:N]), f64(bad[N:])
+        b1, b2 = f64(fb[:N]), f64(fb[N:])
+        plans, _, _ = M.two_batch_plans(a1, a2, b1, b2, lam, iters)
+        aa, bb, ab, ba = M.matched_rows(plans, a1, a2, b1, b2, 0, 0, N)
+        assert _rel(ga[:N].cpu().numpy(), aa - ab) < 2e-4
