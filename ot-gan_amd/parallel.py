@@ -171,9 +171,10 @@ def overlap_self_check(device, rounds=3):
     with nothing else on the device; the collectives' results must equal their closed forms (rank r contributes
     (r + 1) x small integers: the sum and every gathered row are exact in fp32).  The verdict is the minimum over ranks.
     -> (ok, reason)."""
+    w, r = world_size(), get_rank()
+    ok, err = True, None
     try:
         from . import ops
-        w, r = world_size(), get_rank()
         gen = torch.Generator(device=device).manual_seed(4321)
         B, H, C, Cout = 128, 8, 512, 512
         x = torch.randn(B, H, H, C, device=device, generator=gen)
@@ -183,7 +184,6 @@ def overlap_self_check(device, rounds=3):
         conv = lambda: ops.conv2d_op(x, V, g, b, stride=1, upsample=True, preact=0)
         n_red, n_gat = 1 << 24, 1 << 21
         base = (torch.arange(n_red, device=device) % 1021).float()
-        ok = True
         with torch.no_grad():
             y_ref = conv().clone()
             torch.cuda.synchronize(device)
@@ -201,15 +201,22 @@ def overlap_self_check(device, rounds=3):
                 ok = ok and torch.equal(buf, base * float(w * (w + 1) // 2))
                 want = base[:n_gat][None, :] * torch.arange(1, w + 1, device=device, dtype=torch.float32)[:, None]
                 ok = ok and torch.equal(out.view(w, n_gat), want)
+    except Exception as e:      # noqa: BLE001 -- never lose a run over the optimisation
+        ok, err = False, f"{type(e).__name__}: {e}"
+    # every rank reaches the vote, whatever happened above (a rank that raised must not leave the others waiting in it)
+    try:
         flag = torch.tensor([1.0 if ok else 0.0], device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         torch.cuda.synchronize(device)
-        if float(flag) == 1.0:
-            return True, (f"self-check passed on {w} rank(s): {rounds} x (64 MB all-reduce + all-gather) co-resident with 8 GEMM "
-                          "layers, all results bit-identical to the serial ones")
-        return False, "self-check FAILED (" + ("this rank" if not ok else "another rank") + " saw a mismatch): collectives stay serial"
-    except Exception as e:      # noqa: BLE001 -- never lose a run over the optimisation
-        return False, f"self-check raised {type(e).__name__}: {e}: collectives stay serial"
+        agreed = float(flag) == 1.0
+    except Exception as e:      # noqa: BLE001
+        agreed, err = False, err or f"{type(e).__name__}: {e}"
+    if agreed:
+        return True, (f"self-check passed on {w} rank(s): {rounds} x (64 MB all-reduce + all-gather) co-resident with 8 GEMM "
+                      "layers, all results bit-identical to the serial ones")
+    if err:
+        return False, f"self-check raised {err}: collectives stay serial"
+    return False, "self-check FAILED (" + ("this rank" if not ok else "another rank") + " saw a mismatch): collectives stay serial"
 
 
 class _NoCtx:
