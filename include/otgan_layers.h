@@ -395,11 +395,13 @@ int otgan_copy2d_batched_f32(const float* const* src, float* const* dst, const i
  * entries, strides in elements.  (The wide convolutions of a split DenseNet block -- reference models/densenet.py:11-16 through
  * ops.py _split_block_plan -- read the rows of one channel group out of the weights of all later growth layers, side by side
  * and re-ordered from the reference's per-list-element CReLU order [x0, -x0, x1, -x1, ...] (utils/nn.py:198-200) to the
- * single-tensor order: one launch per operand instead of a cat, an index_select and their copies per layer.) */
+ * single-tensor order: one launch per operand instead of a cat, an index_select and their copies per layer.)  amax_out
+ * (nullable): a zeroed amax record (OTGAN_AMAX_RECORD_FLOATS floats) that receives the largest magnitude written -- the
+ * record `otgan_conv_desc::w_amax` wants for the gathered weights, without a reduction pass over them. */
 #define OTGAN_GATHER3D_MAX_SEGMENTS 32
 int otgan_gather3d_batched_f32(const float* const* src, float* const* dst, const int* n0, int n1, int n2,
                                const long* src_s0, const long* src_s1, const long* dst_s0, const long* dst_s1,
-                               int base1, const int* map1_dev, int nseg, void* stream);
+                               int base1, const int* map1_dev, float* amax_out, int nseg, void* stream);
 int otgan_adamax_step_f32(float* p, const float* grad, float* v, float* mg, long n, double lr,
                           double mom1, double mom2, void* stream);
 int otgan_nesterov_step_f32(float* p, const float* grad, float* v, long n, double lr, double mom1,

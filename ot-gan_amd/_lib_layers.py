@@ -95,7 +95,7 @@ SIGNATURES = {
                                          c_double, c_fp, c_fp]),
     "otgan_glu_bwd_colsum_f32": (c_int, [c_fp, c_fp, c_long, c_int, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "otgan_copy2d_batched_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp]),
-    "otgan_gather3d_batched_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_int, c_fp]),
+    "otgan_gather3d_batched_f32": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_int, c_fp]),
     "otgan_adamax_step_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_long, c_double, c_double, c_double, c_fp]),
     "otgan_nesterov_step_f32": (c_int, [c_fp, c_fp, c_fp, c_long, c_double, c_double, c_fp]),
     "otgan_ema_update_f32": (c_int, [c_fp, c_fp, c_long, c_double, c_fp]),

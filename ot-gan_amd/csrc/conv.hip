@@ -2428,6 +2428,7 @@ inline WinoUp3Geo wino_up3_geo(const otgan_conv_desc* d, const Geo& g) {
   w.N = d->N; w.H = d->H; w.W = d->W; w.C = d->C; w.Ceff = g.Ceff; w.ldx = d->ldx; w.Cout = d->Cout; w.ldy = d->ldy;
   w.y_coff = d->y_coff; w.x_amax = d->x_amax;
   w.y_amax_out = d->y_amax_out;
+  w.w_amax = d->w_amax;
   return w;
 }
 

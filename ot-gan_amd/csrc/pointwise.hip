@@ -681,6 +681,7 @@ struct Gather3dSegs {
   long ds0[OTGAN_GATHER3D_MAX_SEGMENTS], ds1[OTGAN_GATHER3D_MAX_SEGMENTS];
   int n1, n2, base1;
   const int* map1;
+  float* amax;      // zeroed amax record (common.h: amax_commit) of the values written, or null
 };
 __global__ __launch_bounds__(256) void gather3d_batched_kernel(Gather3dSegs g) {
   const int sg = blockIdx.y;
@@ -689,18 +690,23 @@ __global__ __launch_bounds__(256) void gather3d_batched_kernel(Gather3dSegs g) {
   const long ss0 = g.ss0[sg], ss1 = g.ss1[sg], ds0 = g.ds0[sg], ds1 = g.ds1[sg];
   const int n1 = g.n1, n2 = g.n2;
   const long total = (long)g.n0[sg] * n1 * n2;
+  unsigned mb = 0u;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int i2 = (int)(i % n2);
     const long r = i / n2;
     const int i1 = (int)(r % n1);
     const long i0 = r / n1;
     const int j1 = g.base1 + (g.map1 ? g.map1[i1] : i1);
-    dst[i0 * ds0 + i1 * ds1 + i2] = src[i0 * ss0 + j1 * ss1 + i2];
+    const float v = src[i0 * ss0 + j1 * ss1 + i2];
+    const unsigned b = amax_bits(v);
+    mb = b > mb ? b : mb;
+    dst[i0 * ds0 + i1 * ds1 + i2] = v;
   }
+  if (g.amax) amax_commit(g.amax, mb);     // (every thread of the workgroup arrives here: the loop has no early exit)
 }
 extern "C" int otgan_gather3d_batched_f32(const float* const* src, float* const* dst, const int* n0, int n1, int n2,
                                           const long* src_s0, const long* src_s1, const long* dst_s0, const long* dst_s1,
-                                          int base1, const int* map1_dev, int nseg, void* stream) {
+                                          int base1, const int* map1_dev, float* amax_out, int nseg, void* stream) {
   OTGAN_CHECK_ARG(src && dst && n0 && src_s0 && src_s1 && dst_s0 && dst_s1 && n1 > 0 && n2 > 0 && base1 >= 0 && nseg > 0 &&
                   nseg <= OTGAN_GATHER3D_MAX_SEGMENTS, "bad arguments");
   Gather3dSegs g;
@@ -712,7 +718,7 @@ extern "C" int otgan_gather3d_batched_f32(const float* const* src, float* const*
     const long t = (long)n0[i] * n1 * n2;
     most = t > most ? t : most;
   }
-  g.n1 = n1; g.n2 = n2; g.base1 = base1; g.map1 = map1_dev;
+  g.n1 = n1; g.n2 = n2; g.base1 = base1; g.map1 = map1_dev; g.amax = amax_out;
   long bx = (most + 256 * 4 - 1) / (256 * 4);
   if (bx > 256) bx = 256;
   hipLaunchKernelGGL(gather3d_batched_kernel, dim3((unsigned)bx, (unsigned)nseg), dim3(256), 0, (hipStream_t)stream, g);

@@ -88,6 +88,7 @@ struct WinoUp3Geo {
   const float* x_amax = nullptr;
   float* x_op = nullptr;  // as in WinoGeo (read back by the one-class weight gradient, WinoS2Geo plain + up)
   float* y_amax_out = nullptr;   // otgan_conv_desc::y_amax_out: the output transform leaves the record of y (round 4)
+  const float* w_amax = nullptr; // otgan_conv_desc::w_amax (round 6: the filter transform reduced the weights itself until then)
 };
 inline long wino_up3_tiles(const WinoUp3Geo& g) { return (long)g.N * (2 * g.H / kWinoM) * (2 * g.W / kWinoM); }
 // wT: un-folded [Cout][9 * Ceff]

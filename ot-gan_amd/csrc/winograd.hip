@@ -1920,7 +1920,7 @@ size_t wino_up3_fwd_ws_floats(const WinoUp3Geo& g) {
   return operand_floats(op_elems(T, g.Ceff)) + WF * T * (size_t)g.Cout;
 }
 int wino_up3_prepare_filters(const WinoUp3Geo& g, const float* wT, float* out, hipStream_t s) {
-  op_scales(wT, 1, 9 * g.Ceff * g.Cout, 0, out, kGainG, 1.f, false, s);
+  op_scales(wT, 1, 9 * g.Ceff * g.Cout, 0, out, kGainG, 1.f, false, s, g.w_amax);
   hipLaunchKernelGGL(wino_up3_filter_fwd_kernel, dim3(op_grid(g.Cout, g.Ceff / 4)), dim3(256), 0, s, wT, g.Ceff, g.Cout, out,
                      op_planes(out));
   return OTGAN_OK;

@@ -775,8 +775,14 @@ def _wide_operands(per_layer, layers, row0, nrows, order, F, desc):
         # w_k [9][ceff][F] -> w [9][nrows][nl F] at column j F;  wT_k [F 9][ceff] -> wT [nl F 9][nrows] at row j F 9
         segs_w.append((w_k.data_ptr(), w.data_ptr() + 4 * j * F, 9, ceff * F, F, nrows * n, n))
         segs_t.append((wT_k.data_ptr(), wT.data_ptr() + 4 * j * F * 9 * nrows, F * 9, ceff, 1, nrows, 1))
-    gather3d_batched(segs_w, nrows, F, row0, map32)
+    # the first gather also leaves the amax record of the gathered weights (w and wT hold the same elements): the filter
+    # transforms of the wide convolution take it from there instead of reducing the weights again (15 launches per DenseNet step)
+    rec = amax_slot(ref.device) if _FUSED_AMAX else None
+    gather3d_batched(segs_w, nrows, F, row0, map32, rec)
     gather3d_batched(segs_t, nrows, 1, row0, map32)
+    if rec is not None:
+        tag_amax(w, rec)
+        tag_amax(wT, rec)
     return {"w": w, "wT": wT, "fwd": prepare_filters(desc, 0, wT), "bwd": None, "bwd_done": False}
 
 
@@ -1674,10 +1680,11 @@ def copy2d_batched(segs):
 GATHER3D_MAX_SEGMENTS = 32   # include/otgan_layers.h
 
 
-def gather3d_batched(segs, n1, n2, base1=0, map1=None):
+def gather3d_batched(segs, n1, n2, base1=0, map1=None, amax_out=None):
     """Strided 3-D copies with a gathered middle index in one launch (otgan_gather3d_batched_f32): segs = [(src_ptr, dst_ptr, n0,
     src_stride0, src_stride1, dst_stride0, dst_stride1)], element units; map1: int32 device tensor of n1 indices or None."""
     assert map1 is None or (map1.dtype == torch.int32 and map1.numel() == n1 and map1.is_contiguous())
+    assert amax_out is None or len(segs) <= GATHER3D_MAX_SEGMENTS
     for i0 in range(0, len(segs), GATHER3D_MAX_SEGMENTS):
         part = segs[i0:i0 + GATHER3D_MAX_SEGMENTS]
         n = len(part)
@@ -1686,7 +1693,8 @@ def gather3d_batched(segs, n1, n2, base1=0, map1=None):
         _lib.check(_lib.lib().otgan_gather3d_batched_f32(arr(ctypes.c_void_p, 0), arr(ctypes.c_void_p, 1), arr(ctypes.c_int, 2),
                                                          int(n1), int(n2), arr(ctypes.c_long, 3), arr(ctypes.c_long, 4),
                                                          arr(ctypes.c_long, 5), arr(ctypes.c_long, 6), int(base1),
-                                                         _lib.ptr(map1), n, _lib.stream_ptr()), "gather3d_batched")
+                                                         _lib.ptr(map1), _lib.ptr(amax_out), n, _lib.stream_ptr()),
+                   "gather3d_batched")
 
 
 def adamax_step(p, grad, v, mg, lr, mom1, mom2):
