@@ -199,6 +199,39 @@ def secondary(dev, a):
                 case["tflops"] = round(flop / us / 1e6, 1)
             else:
                 case["us_" + tag] = round(us, 1)
+        if not a.no_prof:
+            # per kernel class of the training-mode call (HIP events around the library's launches): the cost GEMMs against THEIR
+            # roofline -- at N = 128 the six Gram blocks read 4 x N x D x 4 B = 67 MB for 6.4 GFLOP of products (8 us of fp16
+            # matrix work at peak, 11 us of HBM at 6.3 TB/s): HBM-bound, so GB/s is the figure of merit and the north star's
+            # "MFMA utilisation of the cost-matrix kernel" applies from N = 1024 (768 FLOP per byte) on
+            from otgan_amd import _lib
+            step_call = calls.get("rank_critic_step", calls["grads_critic_step"])
+            _lib.prof_reset()
+            _lib.prof_enable(True)
+            for _ in range(5):
+                step_call()
+            torch.cuda.synchronize()
+            pc = _lib.prof_collect()
+            _lib.prof_enable(False)
+            kc = {}
+            for cls in ("cost_gemm", "sinkhorn", "plan_apply"):
+                v = pc[cls]
+                if not v["launches"]:
+                    continue
+                e = {"us_per_call": round(v["ms"] * 1e3 / 5, 1), "launches_per_call": round(v["launches"] / 5, 1)}
+                if v["bytes"] > 0:
+                    e["algorithmic_GBps"] = round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 0)
+                    e["frac_of_8TBps"] = round(v["bytes"] / (v["ms"] * 1e-3) / 8e12, 3)
+                if v["flop"] > 0:
+                    e["product_tflops"] = round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 1)
+                kc[cls] = e
+            if "cost_gemm" in kc:
+                ai = (12.0 * N * N * D if rows is None else 6.0 * rows * N * D) / (16.0 * N * D if rows is None else 12.0 * (rows + N) * D)
+                kc["cost_gemm"]["bound"] = "hbm" if ai < 2500e12 / 3 / 6.3e12 else "mfma"
+                kc["cost_gemm"]["flop_per_byte"] = round(ai, 1)
+            if "sinkhorn" in kc:
+                kc["sinkhorn"]["bound"] = "on-chip latency (barriers / inter-workgroup exchanges; no HBM or MFMA roofline applies)"
+            case["kernel_classes_critic_step"] = kc
         blocks.append(case)
         K6 = allk = None
         del fa, fb, fa_flat, fb_flat
