@@ -220,8 +220,13 @@ def secondary(dev, a):
                     continue
                 e = {"us_per_call": round(v["ms"] * 1e3 / 5, 1), "launches_per_call": round(v["launches"] / 5, 1)}
                 if v["bytes"] > 0:
-                    e["algorithmic_GBps"] = round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 0)
-                    e["frac_of_8TBps"] = round(v["bytes"] / (v["ms"] * 1e-3) / 8e12, 3)
+                    # the library counts a GEMM's operand bytes per problem (every block is an operand of three of the six
+                    # problems: L2-level bytes); the HBM floor reads each of the four [N, D] blocks once
+                    e["operand_GBps"] = round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 0)
+                    if cls == "cost_gemm" and rows is None:
+                        uniq = 16.0 * N * D * 5
+                        e["hbm_unique_GBps"] = round(uniq / (v["ms"] * 1e-3) / 1e9, 0)
+                        e["frac_of_8TBps"] = round(uniq / (v["ms"] * 1e-3) / 8e12, 3)
                 if v["flop"] > 0:
                     e["product_tflops"] = round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 1)
                 kc[cls] = e
