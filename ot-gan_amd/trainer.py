@@ -160,7 +160,7 @@ class OTGAN:
         # layers in front of it).  Same kernels, same arguments, bit-identical results (tests/test_side_stream_gpu.py); the
         # chains alternate HBM-bound transforms and matrix-bound GEMMs and, on one in-order stream, every kernel also waits
         # for its predecessor's last workgroup: A/B/A/B on one box 8.95 / 8.96 -> 8.48 / 8.50 ms per DCGAN step, DenseNet
-        # 29.2 -> 27.4 ms (profiles/r05_side_stream_ab.txt).  Off under step graphs.  With overlapped collectives the bucket
+        # 29.2 -> 27.4 ms (profiles/r05_side_stream_ab.txt).  Captured with the step under step graphs.  With overlapped collectives the bucket
         # hooks copy and all-reduce on the side stream (parallel.GradBuckets._on_grad) and the real features' all-gather is
         # issued from it (below): the main stream never waits for the side stream inside a pass.
         on = side_ok
