@@ -88,7 +88,7 @@ class OtganError(RuntimeError):
 KNOWN_SWITCHES = frozenset("""
 OTGAN_WINO_PIECES OTGAN_WINO_FP32 OTGAN_DISABLE_WINOGRAD OTGAN_X3_NARROW OTGAN_IGEMM_X3 OTGAN_WINO_UNFOLD_FUSED
 OTGAN_MATCH_FP32 OTGAN_SINKHORN_LINEAR OTGAN_SINKHORN_LIN_RANGE OTGAN_SINKHORN_SETTLE
-OTGAN_PANEL_XCD OTGAN_PANEL_MAX_WG
+OTGAN_PANEL_XCD OTGAN_PANEL_MAX_WG OTGAN_DENSE16_CHAIN
 OTGAN_LIB_PATH OTGAN_DIST_BACKEND OTGAN_FORCE_COLLECTIVES OTGAN_SINGLE_DEVICE OTGAN_COLLECTIVES OTGAN_SIDE_STREAM OTGAN_STEP_GRAPH
 OTGAN_ROOT OTGAN_WORKER_CASES OTGAN_WORKER_DATA OTGAN_TEST_DIST_SEED
 """.split())

@@ -2909,8 +2909,21 @@ int otgan_dense16_chain_fwd_f32(int N, int H, int W, int nslices, float* buf_gro
   OTGAN_CHECK_ARG(dense16_enabled() && dense16_h2_shape_ok(N, H, W), "geometry not taken by the fp16 x 2 growth kernels");
   hipStream_t s = (hipStream_t)stream;
   const int R = OTGAN_AMAX_RECORD_FLOATS;
-  for (int j = 1; j < nslices; ++j) {
+  for (int j = 1; j < nslices; ++j)
     OTGAN_CHECK_ARG(filters[j - 1] && aligned16(filters[j - 1]), "null / misaligned filters of chain layer %d", j);
+  // one launch for the whole chain where a workgroup covers an image (round 6: dense16_chain_fwd_h2_kernel; OTGAN_DENSE16_CHAIN=0,
+  // a test knob, keeps the launch per layer)
+  static const bool one_launch = [] { const char* e = getenv("OTGAN_DENSE16_CHAIN"); return !(e && e[0] == '0'); }();
+  if (one_launch && H == W && (W == 8 || W == 16)) {
+    double flop = 0.0;
+    for (int j = 1; j < nslices; ++j) flop += 2.0 * (double)N * H * W * 9.0 * 32.0 * j * 16.0;
+    ProfScope ps(OTGAN_PROF_CONV_FWD, flop, 0.0, s);
+    if (dense16_chain_fwd_h2(N, H, W, nslices, buf_group, ld, filters, records, s)) {
+      OTGAN_CHECK_LAUNCH("dense16 chain fwd (one launch)");
+      return OTGAN_OK;
+    }
+  }
+  for (int j = 1; j < nslices; ++j) {
     ProfScope ps(OTGAN_PROF_CONV_FWD, 2.0 * (double)N * H * W * 9.0 * 32.0 * j * 16.0, 0.0, s);
     const int rc = dense16_fwd_h2(N, H, W, j, buf_group, ld, filters[j - 1], records, 1 + j, buf_group, ld, 16 * j, s,
                                   records + (size_t)(1 + j) * R);
@@ -2927,9 +2940,19 @@ int otgan_dense16_chain_bwd_f32(int N, int H, int W, int nslices, float* g_group
   OTGAN_CHECK_ARG(dense16_enabled() && dense16_h2_shape_ok(N, H, W), "geometry not taken by the fp16 x 2 growth kernels");
   hipStream_t s = (hipStream_t)stream;
   const int R = OTGAN_AMAX_RECORD_FLOATS;
+  for (int c = nslices - 2; c >= 0; --c) OTGAN_CHECK_ARG(filters[c] && aligned16(filters[c]), "null / misaligned filters of slice %d", c);
+  static const bool one_launch = [] { const char* e = getenv("OTGAN_DENSE16_CHAIN"); return !(e && e[0] == '0'); }();
+  if (one_launch && H == W && (W == 8 || W == 16)) {      // round 6: the slices last to first inside one workgroup per image
+    double flop = 0.0;
+    for (int c = nslices - 2; c >= 0; --c) flop += 2.0 * (double)N * H * W * 9.0 * 16.0 * (nslices - 1 - c) * 32.0;
+    ProfScope ps(OTGAN_PROF_CONV_DGRAD, flop, 0.0, s);
+    if (dense16_chain_bwd_h2(N, H, W, nslices, g_group, ldg, x_group, ldx, filters, rec0, slice_records, s)) {
+      OTGAN_CHECK_LAUNCH("dense16 chain bwd (one launch)");
+      return OTGAN_OK;
+    }
+  }
   for (int c = nslices - 2; c >= 0; --c) {
     const int nsl = nslices - 1 - c;
-    OTGAN_CHECK_ARG(filters[c] && aligned16(filters[c]), "null / misaligned filters of slice %d", c);
     ProfScope ps(OTGAN_PROF_CONV_DGRAD, 2.0 * (double)N * H * W * 9.0 * 16.0 * nsl * 32.0, 0.0, s);
     const int rc = dense16_bwd_h2(N, H, W, nsl, g_group + 16 * (c + 1), ldg, filters[c], x_group + 16 * c, ldx, g_group + 16 * c,
                                   rec0, 1, slice_records + (size_t)(c + 1) * R, nsl, s, slice_records + (size_t)c * R);

@@ -27,6 +27,12 @@ int dense16_fwd(const Dense16Geo& g, const float* x, const float* wT, const floa
 size_t dense16_h2_filter_bytes(int nsl);
 bool dense16_h2_shape_ok(int N, int H, int W);
 int dense16_h2_prepare(const float* const* wT, const int* nsl, void* const* out, int count, hipStream_t s);
+// the chain of a group (layers 1 .. nslices - 1 over the slices in front of each) in ONE launch where a workgroup covers an
+// image (8 x 8, 16 x 16); false: shape not taken, the caller launches layer by layer
+bool dense16_chain_fwd_h2(int N, int H, int W, int nslices, float* buf, int ld, const void* const* filters, float* records,
+                          hipStream_t s);
+bool dense16_chain_bwd_h2(int N, int H, int W, int nslices, float* g, int ldg, const float* x, int ldx,
+                          const void* const* filters, const float* rec0, float* slice_records, hipStream_t s);
 int dense16_fwd_h2(int N, int H, int W, int nsl, const float* x, int ldx, const void* wq, const float* rec, int nrec,
                    float* y, int ldy, int coff, hipStream_t s, float* amax_out);
 

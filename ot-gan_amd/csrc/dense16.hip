@@ -890,6 +890,209 @@ __global__ __launch_bounds__(256, 2) void dense16_fwd_h2_kernel(FwdH2Args a) {
   if (a.amax) amax_commit(a.amax, omax);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One launch per chain (round 6).  Where a workgroup of dense16_fwd_h2_kernel covers a WHOLE image (8 x 8
+// with PT = 1, 16 x 16 with PT = 4), layer j + 1 of a group's chain reads, for its image, only what layer j's workgroup OF THE
+// SAME IMAGE wrote: the chain has no dependence between workgroups, and one workgroup can walk all the layers of its image --
+// the launches of nslices - 1 kernels that ran 9 us (8 x 8) / 15 us (16 x 16) each at MFMA busy 0.05 - 0.15 become one.
+// What changes in the arithmetic: the scale of a layer's fp16 operand pieces.  The per-layer kernel takes it from the GLOBAL amax
+// records of the input slices; the records of the slices this launch produces are still being accumulated by the other
+// workgroups when the next layer starts, so a workgroup bounds those slices by the largest magnitude IT wrote (its image is all
+// it reads) together with the records that were final before the launch (the wide convolutions' sums, slice 0).  A valid
+// bound, per image instead of per batch: deterministic, never looser than the global one, results within an fp16-piece
+// rounding (2^-22 of the operand) of the per-layer kernels'.  The global records of the produced slices are still written
+// (later consumers: the wide convolutions behind the group, the weight gradients).
+struct ChainH2Args {
+  float* buf;                 // first channel of the group's first slice; [N, H, W, ld]
+  const unsigned char* wq[16];    // prepared weights of chain layers 1 .. nslices - 1
+  float* rec;                 // records: [0] the wide convolutions' sums, [1 + c] slice c (c >= 1 written here)
+  int nslices;
+  int N, H, W, ld;
+};
+template <int PT, int WW>
+__global__ __launch_bounds__(256, 2) void dense16_chain_fwd_h2_kernel(ChainH2Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smemh[];
+  __shared__ float s_sc[2];
+  __shared__ unsigned s_run[2];                              // [0] bits of the largest magnitude this workgroup wrote; [1] base records
+  constexpr int NIT = PT + 1;
+  constexpr int WBYTES = kH2SliceU16 * 2;
+  constexpr bool W8 = WW == 8;
+  constexpr int TR = 64 * PT / WW, RS = WW == 8 ? 16 : WW + 2, LOGW = WW == 8 ? 3 : WW == 16 ? 4 : 5;
+  constexpr int PLANE = (TR + 2) * RS * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 15, g = lane >> 4;
+  const int n = blockIdx.x;                                  // one workgroup per image (TR == H)
+  unsigned char* const smw = smemh + 4 * PLANE;
+  for (int i = tid; i < 4 * PLANE / 16; i += 256) reinterpret_cast<u32x4*>(smemh)[i] = u32x4{0u, 0u, 0u, 0u};
+  if (wave == 0) {                                           // records final before the launch: the wide sums and slice 0
+    unsigned mb = 0u;
+    for (int i = lane; i < 16 * 2; i += 64) {
+      const unsigned v = reinterpret_cast<const unsigned*>(a.rec)[(long)(i >> 4) * (kAmaxSub * kAmaxSubStride) + (i & 15) * kAmaxSubStride];
+      mb = v > mb ? v : mb;
+    }
+    for (int o = 32; o; o >>= 1) {
+      const unsigned t = __shfl_xor(mb, o);
+      mb = t > mb ? t : mb;
+    }
+    if (lane == 0) { s_run[0] = 0u; s_run[1] = mb; }
+  }
+  const int slot = tid & 3;
+  const int total = (TR + 2) * WW * 4;
+  const long img_base = (long)n * a.H * WW;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  long xoff[NIT];
+  int loff[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = it * 256 + tid;
+    const int px = i >> 2;
+    const int row = px >> LOGW, col = px & (WW - 1);
+    const int ir = row - 1;                                  // (r0 = 0: the band is the image with one halo row above and below)
+    const bool ok = i < total && (unsigned)ir < (unsigned)a.H;
+    xoff[it] = ok ? (img_base + (long)ir * WW + col) * a.ld + 4 * slot : -1;
+    loff[it] = i < total ? (row * RS + col + 1) * 32 + slot * 8 : -1;
+  }
+  int ab[PT];
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    const int q0 = (wave * PT + t) * 16;
+    int rr, cc;
+    if (W8) {
+      rr = (q0 >> 3) + (p >> 3);
+      cc = p & 7;
+    } else {
+      rr = q0 >> LOGW;
+      cc = (q0 & (WW - 1)) + p;
+    }
+    ab[t] = ((rr + 1) * RS + cc + 1) * 32 + 16 * (g & 1);
+  }
+  const int hiTap = g >> 1;
+  const long m0 = img_base;
+  const float* const x = a.buf;
+  for (int j = 1; j < a.nslices; ++j) {
+    const unsigned char* const wq = a.wq[j - 1];
+    __syncthreads();               // the zero fill (first trip) / the previous layer's LDS reads and s_run update are complete
+    if (tid == 0) {
+      const unsigned mb = s_run[0] > s_run[1] ? s_run[0] : s_run[1];
+      const float amax = __uint_as_float(mb);
+      int e = 0;
+      if (amax > 0.f) e = __builtin_amdgcn_frexp_expf(amax);
+      const int ew = *reinterpret_cast<const int*>(wq);
+      s_sc[0] = (amax <= 3.0e38f) ? __builtin_ldexpf(1.f, 14 - e) : __builtin_nanf("");
+      s_sc[1] = (amax <= 3.0e38f) ? __builtin_ldexpf(1.f, e + ew - 28) : __builtin_nanf("");
+    }
+    f32x4 R[NIT];
+    u32x4 WR[5];
+    const unsigned char* wsrc = wq + kH2HdrBytes + tid * 16;
+    auto stage_load = [&](int sl) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) R[it] = xoff[it] >= 0 ? *reinterpret_cast<const f32x4*>(x + xoff[it] + 16 * sl) : zero;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) WR[q] = *reinterpret_cast<const u32x4*>(wsrc + (long)sl * WBYTES + q * 4096);
+    };
+    auto stage_store = [&](float sx) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        if (loff[it] >= 0) {
+          unsigned wd[4][2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const d16_f2 v = d16_f2{R[it][2 * h], R[it][2 * h + 1]} * sx;
+            const d16_h2 hi = __builtin_convertvector(v, d16_h2);
+            const d16_h2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, d16_f2), d16_h2);
+            const d16_h2 z = {(_Float16)0.f, (_Float16)0.f};
+            typedef short d16_s2 __attribute__((ext_vector_type(2)));
+            const unsigned neg = __builtin_bit_cast(unsigned, (d16_s2)(__builtin_bit_cast(d16_s2, hi) >> 15));
+            const unsigned lb = __builtin_bit_cast(unsigned, lo);
+            wd[0][h] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(hi, z));
+            wd[1][h] = lb & ~neg;
+            wd[2][h] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(-hi, z));
+            wd[3][h] = (lb ^ 0x80008000u) & neg;
+          }
+          unsigned char* dst = smemh + loff[it];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x2*>(dst + q * PLANE) = u32x2{wd[q][0], wd[q][1]};
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 5; ++q) *reinterpret_cast<u32x4*>(smw + q * 4096 + tid * 16) = WR[q];
+    };
+    f32x4 acc[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) acc[t] = zero;
+    stage_load(0);
+    __syncthreads();               // scales complete
+    const float sx = s_sc[0];
+    stage_store(sx);
+    __syncthreads();
+    const int coff = 16 * j;
+    float yv[PT][4];
+    for (int sl = 0; sl < j; ++sl) {
+      const bool more = sl + 1 < j;
+      if (more) {
+        stage_load(sl + 1);
+      } else {
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) yv[t][r] = a.buf[(m0 + (wave * PT + t) * 16 + 4 * g + r) * a.ld + coff + p];
+      }
+#pragma unroll
+      for (int st = 0; st < 10; ++st) {
+        const int sign = st / 5, tp = st % 5;
+        const unsigned char* plane = smemh + 2 * sign * PLANE;
+        const d16_h8 Bh = *reinterpret_cast<const d16_h8*>(smw + st * 2048 + lane * 16);
+        const d16_h8 Bl = *reinterpret_cast<const d16_h8*>(smw + st * 2048 + 1024 + lane * 16);
+        const int t0 = 2 * tp, t1 = (2 * tp + 1 < 9) ? 2 * tp + 1 : 8;
+        const int sh0 = ((t0 / 3 - 1) * RS + (t0 % 3 - 1)) * 32;
+        const int sh1 = ((t1 / 3 - 1) * RS + (t1 % 3 - 1)) * 32;
+        const int sh = hiTap ? sh1 : sh0;
+        d16_h8 Ah[PT], Al[PT];
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+          const unsigned char* ap = plane + ab[t] + sh;
+          Ah[t] = *reinterpret_cast<const d16_h8*>(ap);
+          Al[t] = *reinterpret_cast<const d16_h8*>(ap + PLANE);
+        }
+#pragma unroll
+        for (int t = 0; t < PT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[t], Bh, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < PT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[t], Bl, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < PT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[t], Bh, acc[t], 0, 0, 0);
+      }
+      __syncthreads();
+      if (more) {
+        stage_store(sx);
+        __syncthreads();
+      }
+    }
+    const float so = s_sc[1];
+    unsigned omax = 0u;
+#pragma unroll
+    for (int t = 0; t < PT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long m = m0 + (wave * PT + t) * 16 + 4 * g + r;
+        const float o = fmaf(acc[t][r], so, yv[t][r]);
+        a.buf[m * a.ld + coff + p] = o;
+        const unsigned ob = amax_bits(o);
+        omax = ob > omax ? ob : omax;
+      }
+    // the workgroup's own maximum bounds what the next layers read of this slice; the global record for the later consumers
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned w = (unsigned)__shfl_xor((int)omax, o, 64);
+      omax = w > omax ? w : omax;
+    }
+    if (lane == 0) atomicMax(&s_run[0], omax);
+    amax_commit(a.rec + (size_t)(1 + j) * (kAmaxSub * kAmaxSubStride), omax);
+    // (the slice just written is read back by other waves of THIS workgroup in the next trip: the barrier at the top of the loop
+    // orders the stores before those loads -- workgroup scope, the vector cache is shared by the workgroup's waves; an
+    // agent-scope release here would write the whole L2 back once per layer and workgroup)
+  }
+}
+
 // =======================================================================================
 // Input gradient of the chains BY SLICE on two scaled fp16 pieces (round 4).
 //
@@ -1150,6 +1353,201 @@ __global__ __launch_bounds__(256, 2) void dense16_bwd_h2_kernel(BwdH2Args a) {
       omax = ob > omax ? ob : omax;
     }
   if (a.amax) amax_commit(a.amax, omax);
+}
+
+// One launch per chain, input gradient (round 6): the slices of a group last to first inside one workgroup per image, as in
+// dense16_chain_fwd_h2_kernel -- slice c gathers from the gradient slices c + 1 .. of ITS image, all of them written by this
+// workgroup in the trips before (or final before the launch: the last slice), so the chain needs no other workgroup.  The
+// source slices are bounded by the records that were final before the launch (rec0: the incoming gradient and the wide
+// convolutions' shares; the last slice's record) and by the largest magnitude this workgroup has written so far.
+struct ChainBwdH2Args {
+  float* g;                    // gradient buffer at the first channel of the group's first slice; [N, H, W, ldg]
+  const float* x;              // forward buffer at the same channel; [N, H, W, ldx]
+  const unsigned char* wq[16]; // prepared weights of output slices 0 .. nslices - 2
+  const float* rec0;           // one record
+  float* slice_rec;            // [nslices] records: [c] written here for c <= nslices - 2, [nslices - 1] read
+  int nslices;
+  int N, H, W, ldg, ldx;
+};
+template <int PT, int WW>
+__global__ __launch_bounds__(256, 2) void dense16_chain_bwd_h2_kernel(ChainBwdH2Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smemh[];
+  __shared__ float s_sc[2];
+  __shared__ unsigned s_run[2];
+  constexpr int NIT = PT + 1;
+  constexpr int WBYTES = kH2SliceU16 * 2;
+  constexpr bool W8 = WW == 8;
+  constexpr int TR = 64 * PT / WW, RS = WW == 8 ? 16 : WW + 2, LOGW = WW == 8 ? 3 : WW == 16 ? 4 : 5;
+  constexpr int PLANE = (TR + 2) * RS * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 15, g = lane >> 4;
+  const int n = blockIdx.x;
+  unsigned char* const smw = smemh + 2 * PLANE;
+  for (int i = tid; i < 2 * PLANE / 16; i += 256) reinterpret_cast<u32x4*>(smemh)[i] = u32x4{0u, 0u, 0u, 0u};
+  if (wave == 0) {
+    unsigned mb = 0u;
+    for (int i = lane; i < 16 * 2; i += 64) {
+      const float* base = (i >> 4) == 0 ? a.rec0 : a.slice_rec + (long)(a.nslices - 1) * (kAmaxSub * kAmaxSubStride);
+      const unsigned v = reinterpret_cast<const unsigned*>(base)[(i & 15) * kAmaxSubStride];
+      mb = v > mb ? v : mb;
+    }
+    for (int o = 32; o; o >>= 1) {
+      const unsigned t = __shfl_xor(mb, o);
+      mb = t > mb ? t : mb;
+    }
+    if (lane == 0) { s_run[0] = 0u; s_run[1] = mb; }
+  }
+  const int slot = tid & 3;
+  const int total = (TR + 2) * WW * 4;
+  const long img_base = (long)n * a.H * WW;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  long goff[NIT];
+  int loff[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = it * 256 + tid;
+    const int px = i >> 2;
+    const int row = px >> LOGW, col = px & (WW - 1);
+    const int ir = row - 1;
+    const bool ok = i < total && (unsigned)ir < (unsigned)a.H;
+    goff[it] = ok ? (img_base + (long)ir * WW + col) * a.ldg + 4 * slot : -1;
+    loff[it] = i < total ? (row * RS + col + 1) * 32 + slot * 8 : -1;
+  }
+  int ab[PT];
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    const int q0 = (wave * PT + t) * 16;
+    int rr, cc;
+    if (W8) {
+      rr = (q0 >> 3) + (p >> 3);
+      cc = p & 7;
+    } else {
+      rr = q0 >> LOGW;
+      cc = (q0 & (WW - 1)) + p;
+    }
+    ab[t] = ((rr + 1) * RS + cc + 1) * 32 + 16 * (g & 1);
+  }
+  const int hiTap = g >> 1;
+  const long m0 = img_base;
+  for (int c = a.nslices - 2; c >= 0; --c) {
+    const int nsl = a.nslices - 1 - c;
+    const unsigned char* const wq = a.wq[c];
+    const float* const gsrc = a.g + 16 * (c + 1);
+    float* const dx = a.g + 16 * c;
+    const float* const xc = a.x + 16 * c;
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned mb = s_run[0] > s_run[1] ? s_run[0] : s_run[1];
+      const float amax = __uint_as_float(mb);
+      int e = 0;
+      if (amax > 0.f) e = __builtin_amdgcn_frexp_expf(amax);
+      const int ew = *reinterpret_cast<const int*>(wq);
+      s_sc[0] = (amax <= 3.0e38f) ? __builtin_ldexpf(1.f, 14 - e) : __builtin_nanf("");
+      s_sc[1] = (amax <= 3.0e38f) ? __builtin_ldexpf(1.f, e + ew - 28) : __builtin_nanf("");
+    }
+    f32x4 R[NIT];
+    u32x4 WR[5];
+    const unsigned char* wsrc = wq + kH2HdrBytes + tid * 16;
+    auto stage_load = [&](int sl) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) R[it] = goff[it] >= 0 ? *reinterpret_cast<const f32x4*>(gsrc + goff[it] + 16 * sl) : zero;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) WR[q] = *reinterpret_cast<const u32x4*>(wsrc + (long)sl * WBYTES + q * 4096);
+    };
+    auto stage_store = [&](float sd) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        if (loff[it] >= 0) {
+          unsigned wd[2][2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const d16_f2 v = d16_f2{R[it][2 * h], R[it][2 * h + 1]} * sd;
+            const d16_h2 hi = __builtin_convertvector(v, d16_h2);
+            const d16_h2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, d16_f2), d16_h2);
+            wd[0][h] = __builtin_bit_cast(unsigned, hi);
+            wd[1][h] = __builtin_bit_cast(unsigned, lo);
+          }
+          unsigned char* dst = smemh + loff[it];
+          *reinterpret_cast<u32x2*>(dst) = u32x2{wd[0][0], wd[0][1]};
+          *reinterpret_cast<u32x2*>(dst + PLANE) = u32x2{wd[1][0], wd[1][1]};
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 5; ++q) *reinterpret_cast<u32x4*>(smw + q * 4096 + tid * 16) = WR[q];
+    };
+    f32x4 acc[2][PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) acc[0][t] = acc[1][t] = zero;
+    stage_load(0);
+    __syncthreads();
+    const float sd = s_sc[0];
+    stage_store(sd);
+    __syncthreads();
+    for (int sl = 0; sl < nsl; ++sl) {
+      const bool more = sl + 1 < nsl;
+      if (more) stage_load(sl + 1);
+#pragma unroll
+      for (int tp = 0; tp < 5; ++tp) {
+        const d16_h8 Bhp = *reinterpret_cast<const d16_h8*>(smw + tp * 2048 + lane * 16);
+        const d16_h8 Blp = *reinterpret_cast<const d16_h8*>(smw + tp * 2048 + 1024 + lane * 16);
+        const d16_h8 Bhn = *reinterpret_cast<const d16_h8*>(smw + (5 + tp) * 2048 + lane * 16);
+        const d16_h8 Bln = *reinterpret_cast<const d16_h8*>(smw + (5 + tp) * 2048 + 1024 + lane * 16);
+        const int t0 = 2 * tp, t1 = (2 * tp + 1 < 9) ? 2 * tp + 1 : 8;
+        const int sh0 = ((t0 / 3 - 1) * RS + (t0 % 3 - 1)) * 32;
+        const int sh1 = ((t1 / 3 - 1) * RS + (t1 % 3 - 1)) * 32;
+        const int sh = hiTap ? sh1 : sh0;
+        d16_h8 Ah[PT], Al[PT];
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+          const unsigned char* ap = smemh + ab[t] + sh;
+          Ah[t] = *reinterpret_cast<const d16_h8*>(ap);
+          Al[t] = *reinterpret_cast<const d16_h8*>(ap + PLANE);
+        }
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[t], Bhp, acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[t], Bhn, acc[1][t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[t], Blp, acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[t], Bln, acc[1][t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[t], Bhp, acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[t], Bhn, acc[1][t], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+      if (more) {
+        stage_store(sd);
+        __syncthreads();
+      }
+    }
+    const float so = s_sc[1];
+    unsigned omax = 0u;
+#pragma unroll
+    for (int t = 0; t < PT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long m = m0 + (wave * PT + t) * 16 + 4 * g + r;
+        const float xq = xc[m * a.ldx + p];
+        float o = dx[m * a.ldg + p];
+        o = fmaf(acc[0][t][r] * so, xq > 0.f ? 1.f : 0.f, o);
+        o = fmaf(acc[1][t][r] * so, xq < 0.f ? -1.f : 0.f, o);
+        dx[m * a.ldg + p] = o;
+        const unsigned ob = amax_bits(o);
+        omax = ob > omax ? ob : omax;
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned w = (unsigned)__shfl_xor((int)omax, o, 64);
+      omax = w > omax ? w : omax;
+    }
+    if (lane == 0) atomicMax(&s_run[0], omax);
+    amax_commit(a.slice_rec + (size_t)c * (kAmaxSub * kAmaxSubStride), omax);
+  }
 }
 
 // =======================================================================================
@@ -1697,6 +2095,36 @@ int dense16_fwd_h2(int N, int H, int W, int nsl, const float* x, int ldx, const 
   else D16_H2(1, 8);
 #undef D16_H2
   return OTGAN_OK;
+}
+
+bool dense16_chain_bwd_h2(int N, int H, int W, int nslices, float* g, int ldg, const float* x, int ldx,
+                          const void* const* filters, const float* rec0, float* slice_records, hipStream_t s) {
+  if (!(H == W && (W == 8 || W == 16)) || nslices < 2 || nslices > 17) return false;
+  ChainBwdH2Args a;
+  memset(&a, 0, sizeof(a));
+  a.g = g; a.x = x; a.rec0 = rec0; a.slice_rec = slice_records; a.nslices = nslices;
+  a.N = N; a.H = H; a.W = W; a.ldg = ldg; a.ldx = ldx;
+  for (int c = 0; c + 1 < nslices; ++c) a.wq[c] = (const unsigned char*)filters[c];
+  const int TR = H, RS = W == 8 ? 16 : W + 2;
+  const size_t lds = (size_t)2 * (TR + 2) * RS * 32 + (size_t)kH2SliceU16 * 2;
+  if (W == 8) hipLaunchKernelGGL((dense16_chain_bwd_h2_kernel<1, 8>), dim3(N), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((dense16_chain_bwd_h2_kernel<4, 16>), dim3(N), dim3(256), lds, s, a);
+  return true;
+}
+// the whole chain of a group in ONE launch where a workgroup covers an image (dense16_chain_fwd_h2_kernel); false: not this shape
+bool dense16_chain_fwd_h2(int N, int H, int W, int nslices, float* buf, int ld, const void* const* filters, float* records,
+                          hipStream_t s) {
+  if (!(H == W && (W == 8 || W == 16)) || nslices < 2 || nslices > 17) return false;
+  ChainH2Args a;
+  memset(&a, 0, sizeof(a));
+  a.buf = buf; a.rec = records; a.nslices = nslices; a.N = N; a.H = H; a.W = W; a.ld = ld;
+  for (int j = 1; j < nslices; ++j) a.wq[j - 1] = (const unsigned char*)filters[j - 1];
+  const int PT = W == 8 ? 1 : 4, TR = H, RS = W == 8 ? 16 : W + 2;
+  const size_t lds = (size_t)4 * (TR + 2) * RS * 32 + (size_t)kH2SliceU16 * 2;
+  if (W == 8) hipLaunchKernelGGL((dense16_chain_fwd_h2_kernel<1, 8>), dim3(N), dim3(256), lds, s, a);       // 40 KB of LDS
+  else hipLaunchKernelGGL((dense16_chain_fwd_h2_kernel<4, 16>), dim3(N), dim3(256), lds, s, a);             // 61 KB
+  (void)PT;
+  return true;
 }
 
 size_t dense16_h2_bwd_filter_bytes(int nsl) { return dense16_h2_filter_bytes(nsl); }
