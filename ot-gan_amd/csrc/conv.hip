@@ -2942,7 +2942,7 @@ int otgan_dense16_chain_bwd_f32(int N, int H, int W, int nslices, float* g_group
   const int R = OTGAN_AMAX_RECORD_FLOATS;
   for (int c = nslices - 2; c >= 0; --c) OTGAN_CHECK_ARG(filters[c] && aligned16(filters[c]), "null / misaligned filters of slice %d", c);
   static const bool one_launch = [] { const char* e = getenv("OTGAN_DENSE16_CHAIN"); return !(e && e[0] == '0'); }();
-  if (one_launch && H == W && (W == 8 || W == 16)) {      // round 6: the slices last to first inside one workgroup per image
+  if (one_launch && H == W && W == 8) {      // round 6: the slices last to first inside one workgroup per image (8 x 8: dense16.hip)
     double flop = 0.0;
     for (int c = nslices - 2; c >= 0; --c) flop += 2.0 * (double)N * H * W * 9.0 * 16.0 * (nslices - 1 - c) * 32.0;
     ProfScope ps(OTGAN_PROF_CONV_DGRAD, flop, 0.0, s);

@@ -2099,7 +2099,9 @@ int dense16_fwd_h2(int N, int H, int W, int nsl, const float* x, int ldx, const 
 
 bool dense16_chain_bwd_h2(int N, int H, int W, int nslices, float* g, int ldg, const float* x, int ldx,
                           const void* const* filters, const float* rec0, float* slice_records, hipStream_t s) {
-  if (!(H == W && (W == 8 || W == 16)) || nslices < 2 || nslices > 17) return false;
+  // 8 x 8 only: at 16 x 16 one workgroup per image (256 of them, PT = 4) measured 124.6 us per chain against 7 x 15.3 us for the
+  // per-slice kernels on half images (512 workgroups, PT = 2) -- profiles/r06_pmc_kernels_densenet.txt; 8 x 8: 45.6 against 64 us
+  if (!(H == W && W == 8) || nslices < 2 || nslices > 17) return false;
   ChainBwdH2Args a;
   memset(&a, 0, sizeof(a));
   a.g = g; a.x = x; a.rec0 = rec0; a.slice_rec = slice_records; a.nslices = nslices;

@@ -189,6 +189,7 @@ def test_one_launch_chains_agree_with_the_per_layer_kernels(dev, tmp_path):
         assert bool(torch.isfinite(a).all())
         err = float((a.double() - c.double()).norm() / c.double().norm().clamp_min(1e-30))
         assert err < 1e-5, (k, err)
-    # two blocks x two groups of eight slices: 7 forward layers / 7 backward slices per group become one launch each
+    # two blocks x two groups of eight slices: 7 forward layers per group become one launch (8 x 8 and 16 x 16), 7 backward
+    # slices per group too at 8 x 8 (at 16 x 16 the per-slice kernels on half images are faster and stay)
     one, per = res["one"]["launches"].tolist(), res["per_layer"]["launches"].tolist()
-    assert per[0] - one[0] == 2 * 2 * 6 and per[1] - one[1] == 2 * 2 * 6, (one, per)
+    assert per[0] - one[0] == 2 * 2 * 6 and per[1] - one[1] == 2 * 6, (one, per)
