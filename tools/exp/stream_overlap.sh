@@ -1,9 +1,9 @@
 #!/bin/bash
-# two-stream schedule of the DCGAN step under the tracer: per queue busy time, union, idle gaps, and what runs alone (dev)
+# two-stream schedule of a step (extra arguments go to bench.py, e.g. --model densenet --nr_sinkhorn_iter 200) under the tracer: per queue busy time, union, idle gaps, and what runs alone (dev)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/so_trace
-rocprofv3 --kernel-trace -d $R/gpurun_out/so_trace -- python $R/bench.py --steps 12 --warmup 6 --no_cpu_baseline --no_prof --no_secondary > /dev/null 2>&1
+rocprofv3 --kernel-trace -d $R/gpurun_out/so_trace -- python $R/bench.py --steps 12 --warmup 6 --no_cpu_baseline --no_prof --no_secondary "$@" > /dev/null 2>&1
 t=$(find $R/gpurun_out/so_trace -name "*.db" | head -1)
 python - "$t" <<'PY'
 import sqlite3, sys, collections
